@@ -1,0 +1,217 @@
+/*
+ * tem_hip.h -- C-ABI of libtem_hip.so: the MI355X (gfx950) kernels behind the
+ * torch-em 3D U-Net training path.
+ *
+ * The reference (constantinpape/torch-em) has NO native code and no FFI: its hot
+ * path is Python nn.Modules over ATen ops.  This header
+ * is therefore the boundary the build ADDS: every entry point names the
+ * reference symbol (file:line under /root/reference) whose arithmetic it
+ * replaces.  INTEGRATION.md shows the ctypes binding a torch-em maintainer
+ * would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; every buffer (inputs, outputs,
+ *     workspaces) is owned by the caller and is DEVICE memory on the current
+ *     HIP device; the library allocates nothing persistent;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no
+ *     implicit device synchronisation, re-entrant, no global mutable state
+ *     except the thread-local last-error string;
+ *   - return 0 on success, negative TEM_E* on failure (never throws);
+ *     tem_last_error() gives the message for the calling thread;
+ *   - activations are fp32, channels-last "NDHWC": element (n,z,y,x,c) of a
+ *     tensor with leading dimension `ld` (floats between consecutive voxels,
+ *     ld >= C, so a tensor can be a channel slice of a wider concat buffer)
+ *     lives at ((((n*D+z)*H+y)*W+x)*ld + c);  2-D data uses D == 1;
+ *   - V = D*H*W voxels per sample.
+ */
+#ifndef TEM_HIP_H
+#define TEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEM_OK 0
+#define TEM_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define TEM_ELAUNCH (-2)  /* HIP launch / runtime error */
+#define TEM_EWS (-3)      /* workspace too small */
+
+typedef void* tem_stream_t; /* hipStream_t */
+
+/* ---- library ---------------------------------------------------------- */
+const char* tem_last_error(void);
+int tem_version(void);
+/* number of CUs of the current device (used by callers to size split-K). */
+int tem_device_cus(void);
+
+/* ---- convolution -------------------------------------------------------
+ * Replaces nn.Conv3d / nn.Conv2d as used by ConvBlock (model/unet.py:417-438),
+ * Upsampler.conv (model/unet.py:453) and out_conv (model/unet.py:638), plus the
+ * autograd convolution_backward of those modules.  Stride 1, zero padding
+ * (k-1)/2 per axis ("same"), kernel sizes 1 or 3 per axis.
+ *
+ * Weight layouts (tem_conv_pack_weights converts from the reference's
+ * state_dict layout [Cout][Cin][kd][kh][kw]):
+ *   TEM_WL_GENERIC  [tap][ci][co]                       any Cin, Cout
+ *   TEM_WL_MFMA     [co/32][tap][ci/8][2][32][4]        Cin%16==0, Cout%32==0
+ *                   (the B-fragment order of v_mfma_f32_32x32x2_f32)
+ * transpose==1 packs the data-gradient operator: taps flipped, Cin<->Cout
+ * swapped, so that dgrad is again a tem_conv3d_fwd call.
+ */
+#define TEM_WL_GENERIC 0
+#define TEM_WL_MFMA 1
+#define TEM_ACT_NONE 0
+#define TEM_ACT_RELU 1
+#define TEM_ACT_SIGMOID 2
+
+int64_t tem_conv_packed_size(int Cout, int Cin, int kd, int kh, int kw); /* floats */
+int tem_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw,
+                          int transpose, int layout, tem_stream_t stream);
+/* inverse of the GENERIC pack for weight gradients: [tap][ci][co] -> [Cout][Cin][kd][kh][kw] */
+int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Cin, int kd, int kh, int kw,
+                          tem_stream_t stream);
+
+/* y = act(conv(x * scale + shift) + bias) [* (ref > 0)]
+ *   scale/shift: optional [N][Cin] per-sample per-channel affine applied to the
+ *                input BEFORE zero padding (the fused pre-norm of ConvBlock,
+ *                model/unet.py:429-438); NULL = identity.
+ *   bias:        optional [Cout].
+ *   ref:         optional tensor (ld ref_ld) of y's shape; when given the result
+ *                is zeroed where ref <= 0 (ReLU backward, threshold_backward).
+ *   use_mfma:    1 = v_mfma_f32_32x32x2_f32 implicit-GEMM kernel (needs the
+ *                TEM_WL_MFMA pack), 0 = VALU kernel (TEM_WL_GENERIC pack).
+ */
+int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                   const float* w_packed, const float* bias, float* y, int64_t y_ld,
+                   const float* ref, int64_t ref_ld,
+                   int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                   int act, int use_mfma, tem_stream_t stream);
+
+/* dw[tap][ci][co] = sum_v xhat[v+tap][ci] * g[v][co]  (xhat = x*scale+shift, zero padded)
+ * db[co] = sum_v g[v][co] (optional).  ws: workspace of tem_conv3d_wgrad_ws() bytes.
+ * The result is in the GENERIC tap-major layout; tem_conv_unpack_wgrad gives the
+ * state_dict layout. */
+int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
+int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                     const float* g, int64_t g_ld, float* dw_tap_ci_co, float* db,
+                     void* ws, int64_t ws_bytes,
+                     int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                     int use_mfma, tem_stream_t stream);
+
+/* ---- normalisation ------------------------------------------------------
+ * Replaces nn.InstanceNorm3d / nn.GroupNorm from get_norm_layer
+ * (model/unet.py:391-406): statistics per (sample, group) over V*(C/G) values,
+ * biased variance, eps inside the sqrt.  InstanceNorm == G = C, no affine.
+ * Outputs: mean[N][G], rstd[N][G] and the fused per-channel affine
+ *   scale[N][C] = rstd*gamma, shift[N][C] = beta - mean*rstd*gamma
+ * that tem_conv3d_fwd / tem_conv3d_wgrad apply while loading x.
+ */
+int64_t tem_norm_ws(int N, int64_t V, int C);
+int tem_norm_stats(const float* x, int64_t x_ld, int N, int64_t V, int C, int G,
+                   const float* gamma, const float* beta, float eps,
+                   float* mean, float* rstd, float* scale, float* shift,
+                   void* ws, int64_t ws_bytes, tem_stream_t stream);
+/* Backward of y = norm(x)*gamma+beta given gy:
+ *   gx = rstd*(gy*gamma - mean_grp(gy*gamma) - xn*mean_grp(gy*gamma*xn)),  xn=(x-mean)*rstd
+ *   [gx *= (x > 0) when relu_mask != 0: x is itself a ReLU output]
+ *   dgamma[c] = sum_{n,v} gy*xn, dbeta[c] = sum_{n,v} gy   (optional, accumulate==0 overwrites)
+ */
+int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld,
+                 int N, int64_t V, int C, int G, const float* gamma,
+                 const float* mean, const float* rstd, int relu_mask,
+                 float* gx, int64_t gx_ld, float* dgamma, float* dbeta,
+                 void* ws, int64_t ws_bytes, tem_stream_t stream);
+
+/* ---- pooling / upsampling ------------------------------------------------
+ * nn.MaxPool3d(factor) (model/unet.py:300-302,645): kernel == stride == factor.
+ * Backward routes the gradient to the first maximum in (z,y,x) scan order (ATen's
+ * rule), optionally adds a skip-connection gradient and applies the ReLU mask of x:
+ *   gx = [gskip] + scatter(gy) ; gx *= (x > 0) if relu_mask
+ */
+int tem_maxpool3d_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld,
+                      int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
+int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld,
+                      const float* gskip, int64_t gskip_ld, int relu_mask,
+                      float* gx, int64_t gx_ld,
+                      int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
+/* F.interpolate(mode="trilinear"/"bilinear", align_corners=False, integer scale
+ * factors) (model/unet.py:456).  (D,H,W) are the INPUT dims; output is (D*fz,H*fy,W*fx).
+ * bwd is the exact adjoint (upsample_trilinear3d_backward). */
+int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld,
+                     int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
+int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld,
+                     int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
+
+/* ---- Dice ------------------------------------------------------------------
+ * dice_score / DiceLoss (loss/dice.py:34-133) and the masked variant
+ * LossWrapper + ApplyAndRemoveMask("multiply") (loss/wrapper.py:84-87,129-152).
+ * Generic strides (in floats): element (n,c,v) at n*sn + c*sc + v*sv, so NCDHW
+ * targets and NDHWC predictions are read in place (no flatten_samples copy).
+ * sums[c] = { sum p*t, sum p*p, sum t*t } over (n,v) with p,t already multiplied by
+ * mask when mask != NULL.  (mask uses the target strides.)
+ */
+int64_t tem_dice_ws(int N, int64_t V, int C);
+int tem_dice_sums(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv,
+                  const float* t, int64_t t_sn, int64_t t_sc, int64_t t_sv,
+                  const float* mask, int N, int C, int64_t V,
+                  double* sums /*[C][3]*/, void* ws, int64_t ws_bytes, tem_stream_t stream);
+/* sums -> score (loss/dice.py:65-84) on device, no host sync:
+ *   score_c = 2*num_c/max(den_c,eps); out_c = invert ? 1-score_c : score_c;
+ *   channelwise==0 pools all channels first; reduce: 0 none (out[C]), 1 sum, 2 mean, 3 max, 4 min.
+ * Also emits ca[C], cb[C] with  d out / d p[n,c,v] = ca[c]*t + cb[c]*p  (clamp gradient included). */
+int tem_dice_finalize(const double* sums, int C, double eps, int channelwise, int invert, int reduce,
+                      float* out, float* ca, float* cb, tem_stream_t stream);
+/* gp[n,c,v] = gout * (ca[c]*t + cb[c]*p) * mask, with p,t masked as above; gout: device scalar
+ * (or [C] when gout_per_channel), NULL = 1. */
+int tem_dice_grad(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv,
+                  const float* t, int64_t t_sn, int64_t t_sc, int64_t t_sv,
+                  const float* mask, const float* ca, const float* cb,
+                  const float* gout, int gout_per_channel,
+                  float* gp, int64_t g_sn, int64_t g_sc, int64_t g_sv,
+                  int N, int C, int64_t V, tem_stream_t stream);
+
+/* ---- optimizer -------------------------------------------------------------
+ * torch.optim.AdamW step as configured by default_segmentation_trainer
+ * (segmentation.py:543): decoupled weight decay, bias correction, eps outside
+ * the sqrt; one launch over a flat parameter arena.  `step` is the 1-based step
+ * count AFTER the increment.  grad_scale multiplies the gradient first (1/world
+ * for data-parallel SUM all-reduce). */
+int tem_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                   float grad_scale, tem_stream_t stream);
+/* theta_k = m*theta_k + (1-m)*theta_q : SPOCOTrainer._momentum_update (trainer/spoco_trainer.py:45-47) */
+int tem_ema_update(float* theta_k, const float* theta_q, int64_t n, float momentum, tem_stream_t stream);
+
+/* ---- label targets (integer, bit-exact) -----------------------------------------
+ * BoundaryTransform (transform/label.py:100-129; skimage find_boundaries mode="thick":
+ * a voxel is boundary iff any face neighbour inside the volume has a different label)
+ * and AffinityTransform (transform/label.py:248-327; semantics pinned by
+ * test/transform/test_label_transforms.py:5-55).  labels: int64 [D][H][W] on device.
+ * out: float32 channels [C][D][H][W] (the reference's output layout).
+ */
+int tem_boundary_target(const int64_t* labels, float* out, int D, int H, int W,
+                        int add_binary_target, tem_stream_t stream);
+/* offsets: HOST array [n_off][3] (z,y,x); 2-D data: D==1 and z offset 0.
+ * out channels: [binary?] + n_off affinities (1 = different/invalid) [+ (binary mask?) + n_off mask].
+ * has_ignore==0: no ignore label (mask = in-bounds only). */
+int tem_affinity_target(const int64_t* labels, float* out, int D, int H, int W,
+                        const int* offsets, int n_off, int has_ignore, int64_t ignore_label,
+                        int add_binary_target, int add_mask, int include_ignore_transitions,
+                        tem_stream_t stream);
+
+/* ---- small utilities ---------------------------------------------------------- */
+/* NCDHW (contiguous) <-> NDHWC(ld) layout change at the module boundary. */
+int tem_nchw_to_nhwc(const float* src, float* dst, int64_t dst_ld, int N, int C, int64_t V, tem_stream_t stream);
+int tem_nhwc_to_nchw(const float* src, int64_t src_ld, float* dst, int N, int C, int64_t V, tem_stream_t stream);
+/* backward of the final activation on a contiguous array: sigmoid gx = gy*y*(1-y); relu gx = gy*(y>0)
+ * (UNetBase._get_activation, model/unet.py:162-172) */
+int tem_act_bwd(const float* gy, const float* y, float* gx, int64_t n, int act, tem_stream_t stream);
+/* per-sample standardize (transform/raw.py:40-65): (x-mean)/(std+eps) over each of N rows of length L */
+int tem_standardize(const float* x, float* y, int N, int64_t L, float eps, void* ws, int64_t ws_bytes, tem_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEM_HIP_H */

@@ -1,0 +1,83 @@
+"""CPU restatement of the reference U-Net forward (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+Functional, driven by a reference-format state_dict, so the same weights go through the
+reference (when generating fixtures), this oracle, and the HIP engine.  Follows:
+  UNetBase._apply_default   /root/reference/torch_em/model/unet.py:194-209
+  Encoder.forward           :311-321   (block -> keep skip -> MaxPool(factor))
+  ConvBlock                 :429-438   (norm -> conv(k, pad=k//2) -> ReLU) x 2, norm=None drops norms
+  get_norm_layer            :391-406   (InstanceNorm: no affine, eps 1e-5; GroupNorm(min(32,C), C))
+  Upsampler.forward         :455-458   (interpolate(scale, linear, align_corners=False) -> 1x1 conv)
+  Decoder.forward/_concat   :363-388   (cat([upsampled, skip], dim=1) -> block)
+  out_conv / activation     :202-205
+Gradients come from torch autograd over these ops (which is what the reference's
+loss.backward() does as well).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _conv(x, w, b):
+    pad = tuple(k // 2 for k in w.shape[2:])
+    return (F.conv2d if w.dim() == 4 else F.conv3d)(x, w, b, padding=pad)
+
+
+def _norm(x, norm, gamma, beta, n_groups=32):
+    if norm is None:
+        return x
+    if norm == "InstanceNorm":
+        return F.instance_norm(x, eps=1e-5)
+    if norm == "GroupNorm":
+        c = x.shape[1]
+        return F.group_norm(x, min(n_groups, c), gamma, beta, eps=1e-5)
+    raise ValueError(norm)
+
+
+def _block(sd, prefix, x, norm):
+    idx = (1, 4) if norm is not None else (0, 2)
+    nidx = (0, 3)
+    for j in range(2):
+        gamma = sd.get(f"{prefix}.block.{nidx[j]}.weight") if norm == "GroupNorm" else None
+        beta = sd.get(f"{prefix}.block.{nidx[j]}.bias") if norm == "GroupNorm" else None
+        x = _norm(x, norm, gamma, beta)
+        x = F.relu(_conv(x, sd[f"{prefix}.block.{idx[j]}.weight"], sd[f"{prefix}.block.{idx[j]}.bias"]))
+    return x
+
+
+def unet_forward(sd, x, scale_factors, norm="InstanceNorm", final_activation=None):
+    """sd: reference-layout state_dict (tensors, may require grad); x: [N,C,*spatial];
+    scale_factors: per-level pooling factor (int or list), encoder order."""
+    dim = x.dim() - 2
+    depth = len(scale_factors)
+    pool = F.max_pool2d if dim == 2 else F.max_pool3d
+    mode = "bilinear" if dim == 2 else "trilinear"
+    skips = []
+    for l in range(depth):
+        x = _block(sd, f"encoder.blocks.{l}", x, norm)
+        skips.append(x)
+        f = scale_factors[l]
+        x = pool(x, f if isinstance(f, int) else tuple(f))
+    x = _block(sd, "base", x, norm)
+    for i in range(depth):
+        f = scale_factors[depth - 1 - i]
+        x = F.interpolate(x, scale_factor=f if isinstance(f, int) else tuple(float(v) for v in f), mode=mode,
+                          align_corners=False)
+        x = _conv(x, sd[f"decoder.samplers.{i}.conv.weight"], sd[f"decoder.samplers.{i}.conv.bias"])
+        x = torch.cat([x, skips[depth - 1 - i]], dim=1)
+        x = _block(sd, f"decoder.blocks.{i}", x, norm)
+    if "out_conv.weight" in sd:
+        x = _conv(x, sd["out_conv.weight"], sd["out_conv.bias"])
+    if final_activation == "Sigmoid":
+        x = torch.sigmoid(x)
+    elif final_activation is not None:
+        raise ValueError(final_activation)
+    return x
+
+
+def unet_loss_and_grads(sd, x, y, scale_factors, norm="InstanceNorm", final_activation=None, loss_fn=None):
+    """Returns (prediction, loss, {param: grad}) with fp32 CPU autograd."""
+    from .loss_ref import dice_loss
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    pred = unet_forward(sd, x, scale_factors, norm, final_activation)
+    loss = (loss_fn or dice_loss)(pred, y)
+    loss.backward()
+    return pred.detach(), loss.detach(), {k: v.grad for k, v in sd.items()}

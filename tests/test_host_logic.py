@@ -1,0 +1,99 @@
+"""CPU: host-side mirror of the reference interface (no kernels run)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from torch_em_amd.loss import ApplyAndRemoveMask, DiceLoss, LossWrapper
+from torch_em_amd.model import AnisotropicUNet, UNet2d, UNet3d
+
+
+def test_init_matches_reference_state_dict():
+    """Same construction order => same random init under the same seed, same keys and shapes."""
+    g = dict(np.load(os.path.join(GOLDEN, "g1b_init_unet3d.npz")))
+    torch.manual_seed(0)
+    sd = UNet3d(1, 2, depth=2, initial_features=4).state_dict()
+    assert sorted(sd) == sorted(g)
+    for k in g:
+        assert np.array_equal(sd[k].numpy(), g[k]), k
+
+
+@pytest.mark.parametrize("fixture,build", [
+    ("g1_unet3d_GroupNorm.npz", lambda: UNet3d(1, 2, depth=2, initial_features=4, norm="GroupNorm")),
+    ("g1_unet3d_None.npz", lambda: UNet3d(1, 2, depth=2, initial_features=4, norm=None)),
+    ("g2_aniso_1.npz", lambda: AnisotropicUNet(1, 12, [[1, 2, 2], [2, 2, 2]], initial_features=4,
+                                               final_activation="Sigmoid", anisotropic_kernel=True)),
+    ("g3_unet2d.npz", lambda: UNet2d(1, 2, depth=2, initial_features=4)),
+])
+def test_state_dict_keys_and_shapes(fixture, build):
+    g = dict(np.load(os.path.join(GOLDEN, fixture)))
+    ref = {k[3:]: v.shape for k, v in g.items() if k.startswith("sd.")}
+    sd = build().state_dict()
+    assert sorted(sd) == sorted(ref)
+    for k, shape in ref.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+
+
+def test_parameter_counts_of_the_benchmark_model():
+    assert sum(p.numel() for p in UNet3d(1, 2).parameters()) == 21356802
+    assert sum(p.numel() for p in UNet3d(1, 2, norm="GroupNorm").parameters()) == 21362628
+    assert sum(p.numel() for p in UNet2d(1, 2).parameters()) == 7237314
+
+
+def test_interface_properties_and_init_kwargs():
+    m = UNet3d(1, 2, depth=3, initial_features=8, final_activation="Sigmoid")
+    assert (m.in_channels, m.out_channels, m.depth) == (1, 2, 3)
+    assert m.init_kwargs["depth"] == 3 and m.init_kwargs["final_activation"] == "Sigmoid"
+    a = AnisotropicUNet(1, 2, [[1, 2, 2], [2, 2, 2]], initial_features=4)
+    assert a.init_kwargs["scale_factors"] == [[1, 2, 2], [2, 2, 2]] and a.depth == 2
+    # class + kwargs must survive pickling (mp.spawn in train_multi_gpu) and deepcopy (SPOCO teacher)
+    cls, kw = pickle.loads(pickle.dumps((UNet3d, {"in_channels": 1, "out_channels": 2})))
+    assert cls(**kw).out_channels == 2
+    import copy
+    copy.deepcopy(m)
+
+
+def test_errors_match_the_reference():
+    with pytest.raises(ValueError, match="Invalid activation"):
+        UNet3d(1, 2, depth=1, initial_features=4, final_activation="NoSuchActivation")
+    with pytest.raises(ValueError, match="Invalid norm"):
+        UNet3d(1, 2, depth=1, initial_features=4, norm="LayerNorm")
+    m = UNet3d(1, 2, depth=3, initial_features=4)
+    with pytest.raises(ValueError, match="is not divisible by"):
+        m(torch.zeros(1, 1, 20, 32, 32))
+    a = AnisotropicUNet(1, 2, [[1, 2, 2], [2, 2, 2]], initial_features=4)
+    with pytest.raises(ValueError, match="is not divisible by"):
+        a(torch.zeros(1, 1, 3, 16, 16))
+    with pytest.raises(ValueError, match="dimensions don't agree"):
+        a(torch.zeros(1, 1, 16, 16))
+    with pytest.raises(ValueError, match="Unsupported channel reduction"):
+        DiceLoss(reduce_channel="median")
+    with pytest.raises(ValueError, match="transform has to be callable"):
+        LossWrapper(DiceLoss(), transform=3)
+    with pytest.raises(ValueError, match="is not available"):
+        ApplyAndRemoveMask(masking_method="zero")
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly instead of silently computing on the CPU."""
+    m = UNet3d(1, 2, depth=1, initial_features=4)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.zeros(1, 1, 8, 8, 8))
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        DiceLoss()(torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 4, 4))
+    with pytest.raises(ValueError, match="Expect input and target of same shape"):
+        DiceLoss()(torch.zeros(1, 1, 4, 4), torch.zeros(1, 2, 4, 4))
+
+
+def test_product_does_not_import_the_oracle():
+    import re
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "torch_em_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)

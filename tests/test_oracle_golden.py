@@ -1,0 +1,139 @@
+"""CPU: pin the oracle (oracle/*.py) to the reference through the golden vectors that
+tests/golden/gen_golden.py produced by importing the reference itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from oracle import label_ref, loss_ref, optim_ref, unet_ref
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+def _sd(g):
+    return {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+
+
+@pytest.mark.parametrize("norm", ["InstanceNorm", "GroupNorm", None])
+def test_unet3d_oracle_matches_reference(norm):
+    g = _load(f"g1_unet3d_{norm}.npz")
+    pred, loss, grads = unet_ref.unet_loss_and_grads(_sd(g), torch.from_numpy(g["x"]), torch.from_numpy(g["y"]),
+                                                     [2, 2], norm=norm)
+    assert rel_err(pred, g["pred"]) < 1e-5
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for k, v in grads.items():
+        assert rel_err(v, g[f"grad.{k}"]) < 1e-4, k
+
+
+@pytest.mark.parametrize("aniso", [0, 1])
+def test_aniso_oracle_matches_reference(aniso):
+    g = _load(f"g2_aniso_{aniso}.npz")
+    pred, loss, grads = unet_ref.unet_loss_and_grads(
+        _sd(g), torch.from_numpy(g["x"]), torch.from_numpy(g["y"]), [[1, 2, 2], [2, 2, 2]],
+        final_activation="Sigmoid", loss_fn=loss_ref.masked_dice_loss)
+    assert rel_err(pred, g["pred"]) < 1e-5
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for k, v in grads.items():
+        assert rel_err(v, g[f"grad.{k}"]) < 1e-4, k
+
+
+def test_unet2d_oracle_matches_reference():
+    g = _load("g3_unet2d.npz")
+    pred, loss, grads = unet_ref.unet_loss_and_grads(_sd(g), torch.from_numpy(g["x"]), torch.from_numpy(g["y"]),
+                                                     [2, 2])
+    assert rel_err(pred, g["pred"]) < 1e-5
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for k, v in grads.items():
+        assert rel_err(v, g[f"grad.{k}"]) < 1e-4, k
+
+
+def test_dice_oracle_matches_reference():
+    g = _load("g5_dice.npz")
+    p, t = torch.from_numpy(g["p"]), torch.from_numpy(g["t"])
+    for cw in (True, False):
+        for red in ("sum", "mean", "max", "min"):
+            pp = p.clone().requires_grad_(True)
+            val = loss_ref.dice_loss(pp, t, channelwise=cw, reduce_channel=red)
+            val.backward()
+            assert abs(float(val) - float(g[f"loss_{int(cw)}_{red}"])) < 1e-6
+            assert rel_err(pp.grad, g[f"grad_{int(cw)}_{red}"]) < 1e-5
+    assert rel_err(loss_ref.dice_score(p, t, reduce_channel=None), g["score_none"]) < 1e-6
+    pm = torch.from_numpy(g["pm"]).requires_grad_(True)
+    val = loss_ref.masked_dice_loss(pm, torch.from_numpy(g["tm"]))
+    val.backward()
+    assert abs(float(val) - float(g["loss_masked"])) < 1e-6
+    assert rel_err(pm.grad, g["grad_masked"]) < 1e-5
+    # the reference's own known answers (test/loss/test_dice.py:25-38)
+    ones, zeros = torch.ones(1, 1, 32, 32), torch.zeros(1, 1, 32, 32)
+    assert abs(float(loss_ref.dice_loss(ones, ones)) - float(g["kat_ones_ones"])) < 1e-7
+    assert abs(float(loss_ref.dice_loss(ones, zeros)) - float(g["kat_ones_zeros"])) < 1e-7
+    assert float(g["kat_ones_ones"]) == 0.0 and float(g["kat_ones_zeros"]) == 1.0
+
+
+# --- label targets: the reference's own brute-force definitions are the vectors ----------
+OFFSETS_2D = [[-1, 0], [0, -1], [-3, 0], [0, -3], [4, 5], [-3, 2]]  # test_label_transforms.py:70-72
+
+
+def _labels(shape, with_zero, seed):
+    rng = np.random.RandomState(seed)
+    lab = rng.randint(1, 6, size=shape).astype("int64")
+    if with_zero:
+        lab[rng.rand(*shape) < 0.25] = 0
+    return lab
+
+
+def test_affinities_vectorised_equals_brute_force_2d():
+    seg = _labels((64, 64), False, 0)
+    affs = label_ref.affinities(seg, OFFSETS_2D)
+    exp, _ = label_ref.affinities_brute_force(seg, OFFSETS_2D)
+    assert np.array_equal(affs, exp)
+    seg = _labels((64, 64), True, 1)
+    for incl in (False, True):
+        out = label_ref.affinities(seg, OFFSETS_2D, ignore_label=0, add_mask=True, include_ignore_transitions=incl)
+        ea, em = label_ref.affinities_brute_force(seg, OFFSETS_2D, ignore_label=0, include_ignore_transitions=incl)
+        assert np.array_equal(out[:6], ea) and np.array_equal(out[6:], em)
+
+
+def test_affinities_3d_and_channels():
+    seg = _labels((6, 9, 10), True, 2)
+    offs = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0], [0, 0, -3], [1, 2, -3]]
+    out = label_ref.affinities(seg, offs, ignore_label=0, add_binary_target=True, add_mask=True)
+    ea, em = label_ref.affinities_brute_force(seg, offs, ignore_label=0)
+    n = len(offs)
+    assert out.shape == (2 * (n + 1),) + seg.shape
+    assert np.array_equal(out[0], (seg != 0).astype("float32"))
+    assert np.array_equal(out[1:n + 1], ea)
+    assert np.array_equal(out[n + 1], (seg != 0).astype("float32"))
+    assert np.array_equal(out[n + 2:], em)
+
+
+def test_boundaries_kat_and_morphology():
+    lab = np.zeros((5, 6), "int64")
+    lab[:, 3:] = 2
+    b = label_ref.boundaries(lab)[0]
+    exp = np.zeros((5, 6), "float32")
+    exp[:, 2:4] = 1
+    assert np.array_equal(b, exp)  # 'thick': both sides of the edge, nothing at the image border
+    for shape, seed in (((32, 32), 3), ((8, 12, 10), 4)):
+        lab = _labels(shape, True, seed)
+        assert np.array_equal(label_ref.boundaries(lab), label_ref.boundaries_morphology(lab))
+    out = label_ref.boundaries(lab, add_binary_target=True)
+    assert out.shape == (2,) + lab.shape and np.array_equal(out[0], (lab != 0).astype("float32"))
+
+
+def test_adamw_oracle_matches_torch():
+    rng = np.random.RandomState(0)
+    p0 = rng.randn(1000).astype("float32")
+    p_t = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.AdamW([p_t], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for step in range(1, 6):
+        g = rng.randn(1000).astype("float32")
+        p_t.grad = torch.from_numpy(g.copy())
+        opt.step()
+        p, m, v = optim_ref.adamw_step(p, g, m, v, step)
+        assert rel_err(p, p_t.detach().numpy()) < 1e-6

@@ -1,0 +1,107 @@
+"""ctypes binding of libtem_hip.so (C-ABI declared in include/tem_hip.h).
+
+The reference has no native code; this is the binding a torch-em maintainer would add
+(see INTEGRATION.md).  The product path has NO CPU fallback: if the shared library is
+missing, every op raises.  `build()` compiles it in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtem_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+c_f32p = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_double = ctypes.c_double
+c_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/tem_hip.h
+SIGNATURES = {
+    "tem_last_error": (ctypes.c_char_p, []),
+    "tem_version": (c_int, []),
+    "tem_device_cus": (c_int, []),
+    "tem_conv_packed_size": (c_i64, [c_int] * 5),
+    "tem_conv_pack_weights": (c_int, [c_vp, c_vp] + [c_int] * 7 + [c_vp]),
+    "tem_conv_unpack_wgrad": (c_int, [c_vp, c_vp] + [c_int] * 5 + [c_vp]),
+    "tem_conv3d_fwd": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64] + [c_int] * 11 + [c_vp]),
+    "tem_conv3d_wgrad_ws": (c_i64, [c_int] * 10),
+    "tem_conv3d_wgrad": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp]),
+    "tem_norm_ws": (c_i64, [c_int, c_i64, c_int]),
+    "tem_norm_stats": (c_int, [c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_float,
+                               c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "tem_norm_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
+                             c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "tem_maxpool3d_fwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
+    "tem_maxpool3d_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
+    "tem_upsample_fwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
+    "tem_upsample_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
+    "tem_dice_ws": (c_i64, [c_int, c_i64, c_int]),
+    "tem_dice_sums": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_i64,
+                              c_vp, c_vp, c_i64, c_vp]),
+    "tem_dice_finalize": (c_int, [c_vp, c_int, c_double, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "tem_dice_grad": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int,
+                              c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_vp]),
+    "tem_adamw_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_i64,
+                               c_float, c_vp]),
+    "tem_ema_update": (c_int, [c_vp, c_vp, c_i64, c_float, c_vp]),
+    "tem_boundary_target": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "tem_affinity_target": (c_int, [c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_i64,
+                                    c_int, c_int, c_int, c_vp]),
+    "tem_nchw_to_nhwc": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_i64, c_vp]),
+    "tem_nhwc_to_nchw": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_i64, c_vp]),
+    "tem_standardize": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_vp, c_i64, c_vp]),
+    "tem_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
+}
+
+_lib = None
+
+
+class TemError(RuntimeError):
+    """HIP launch / runtime failure inside libtem_hip.so."""
+
+
+def build(verbose=False):
+    """Compile libtem_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building libtem_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libtem_hip.so not found at {LIB_PATH}: the MI355X kernels are not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C torch_em_amd/csrc). "
+            "There is no CPU fallback for this path."
+        )
+    import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so both share one HIP runtime)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    """Map a C-ABI return code to the exception the reference raises for the same mistake."""
+    if rc == 0:
+        return
+    msg = load().tem_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg or f"{what}: invalid argument")
+    raise TemError(f"{what}: {msg} (rc={rc})")

@@ -1,0 +1,193 @@
+// capi.hip -- library-level entry points of libtem_hip.so and the layout utilities.
+#include "tem_common.h"
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void tem_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* tem_last_error(void) { return g_err; }
+extern "C" int tem_version(void) { return 100; }
+
+extern "C" int tem_device_cus(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return TEM_ELAUNCH;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return TEM_ELAUNCH;
+    return prop.multiProcessorCount;
+}
+
+// ---------------------------------------------------------------------------
+// NCDHW <-> NDHWC.  Tiled through LDS so that both sides are coalesced:
+// a tile is 64 voxels x 32 channels.
+// ---------------------------------------------------------------------------
+#define TT_V 64
+#define TT_C 32
+
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst,
+                                                      int64_t dst_ld, int C, int64_t V, int64_t vtiles, int ctiles) {
+    __shared__ float tile[TT_C][TT_V + 1];
+    int64_t ntiles = vtiles * ctiles;
+    int n = blockIdx.y;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int ct = (int)(t % ctiles);
+        int64_t vt = t / ctiles;
+        int64_t v0 = vt * TT_V;
+        int c0 = ct * TT_C;
+        // read: voxel fastest
+        for (int i = threadIdx.x; i < TT_C * TT_V; i += 256) {
+            int c = i / TT_V, v = i % TT_V;
+            float val = 0.f;
+            if (c0 + c < C && v0 + v < V) val = src[((int64_t)n * C + c0 + c) * V + v0 + v];
+            tile[c][v] = val;
+        }
+        __syncthreads();
+        // write: channel fastest
+        for (int i = threadIdx.x; i < TT_C * TT_V; i += 256) {
+            int v = i / TT_C, c = i % TT_C;
+            if (c0 + c < C && v0 + v < V) dst[((int64_t)n * V + v0 + v) * dst_ld + c0 + c] = tile[c][v];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nhwc_to_nchw(const float* __restrict__ src, int64_t src_ld,
+                                                      float* __restrict__ dst, int C, int64_t V, int64_t vtiles,
+                                                      int ctiles) {
+    __shared__ float tile[TT_C][TT_V + 1];
+    int64_t ntiles = vtiles * ctiles;
+    int n = blockIdx.y;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int ct = (int)(t % ctiles);
+        int64_t vt = t / ctiles;
+        int64_t v0 = vt * TT_V;
+        int c0 = ct * TT_C;
+        for (int i = threadIdx.x; i < TT_C * TT_V; i += 256) {
+            int v = i / TT_C, c = i % TT_C;
+            float val = 0.f;
+            if (c0 + c < C && v0 + v < V) val = src[((int64_t)n * V + v0 + v) * src_ld + c0 + c];
+            tile[c][v] = val;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TT_C * TT_V; i += 256) {
+            int c = i / TT_V, v = i % TT_V;
+            if (c0 + c < C && v0 + v < V) dst[((int64_t)n * C + c0 + c) * V + v0 + v] = tile[c][v];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int tem_nchw_to_nhwc(const float* src, float* dst, int64_t dst_ld, int N, int C, int64_t V,
+                                tem_stream_t stream) {
+    TEM_REQUIRE(src && dst && N > 0 && C > 0 && V > 0 && dst_ld >= C, "tem_nchw_to_nhwc: bad arguments");
+    int64_t vtiles = tem_cdiv(V, TT_V);
+    int ctiles = (int)tem_cdiv(C, TT_C);
+    int64_t nt = vtiles * ctiles;
+    dim3 grid((unsigned)(nt > 4096 ? 4096 : nt), N);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, (hipStream_t)stream, src, dst, dst_ld, C, V, vtiles, ctiles);
+    TEM_CHECK_LAUNCH("tem_nchw_to_nhwc");
+    return TEM_OK;
+}
+
+extern "C" int tem_nhwc_to_nchw(const float* src, int64_t src_ld, float* dst, int N, int C, int64_t V,
+                                tem_stream_t stream) {
+    TEM_REQUIRE(src && dst && N > 0 && C > 0 && V > 0 && src_ld >= C, "tem_nhwc_to_nchw: bad arguments");
+    int64_t vtiles = tem_cdiv(V, TT_V);
+    int ctiles = (int)tem_cdiv(C, TT_C);
+    int64_t nt = vtiles * ctiles;
+    dim3 grid((unsigned)(nt > 4096 ? 4096 : nt), N);
+    hipLaunchKernelGGL(k_nhwc_to_nchw, grid, dim3(256), 0, (hipStream_t)stream, src, src_ld, dst, C, V, vtiles, ctiles);
+    TEM_CHECK_LAUNCH("tem_nhwc_to_nchw");
+    return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// standardize: y = (x - mean) / (std + eps) per row (transform/raw.py:40-65;
+// numpy mean/std => population std).  Two-stage deterministic reduction.
+// ---------------------------------------------------------------------------
+#define STD_BLOCKS 256
+
+__global__ __launch_bounds__(256) void k_std_partial(const float* __restrict__ x, int64_t L, double* __restrict__ part) {
+    int n = blockIdx.y;
+    const float* row = x + (int64_t)n * L;
+    double s = 0.0, ss = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < L; i += (int64_t)gridDim.x * 256) {
+        double v = (double)row[i];
+        s += v;
+        ss += v * v;
+    }
+    s = tem_wave_sum_d(s);
+    ss = tem_wave_sum_d(ss);
+    __shared__ double sh[2][4];
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((int64_t)n * gridDim.x + blockIdx.x) * 2 + 0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        part[((int64_t)n * gridDim.x + blockIdx.x) * 2 + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_std_apply(const float* __restrict__ x, float* __restrict__ y, int64_t L,
+                                                   const double* __restrict__ part, int nblk, float eps) {
+    int n = blockIdx.y;
+    __shared__ float sh_mean, sh_inv;
+    if (threadIdx.x == 0) {
+        double s = 0.0, ss = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            s += part[((int64_t)n * nblk + b) * 2 + 0];
+            ss += part[((int64_t)n * nblk + b) * 2 + 1];
+        }
+        double mean = s / (double)L;
+        double var = ss / (double)L - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sh_mean = (float)mean;
+        sh_inv = (float)(1.0 / (sqrt(var) + (double)eps));
+    }
+    __syncthreads();
+    float mean = sh_mean, inv = sh_inv;
+    const float* row = x + (int64_t)n * L;
+    float* out = y + (int64_t)n * L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < L; i += (int64_t)gridDim.x * 256)
+        out[i] = (row[i] - mean) * inv;
+}
+
+extern "C" int tem_standardize(const float* x, float* y, int N, int64_t L, float eps, void* ws, int64_t ws_bytes,
+                               tem_stream_t stream) {
+    TEM_REQUIRE(x && y && ws && N > 0 && L > 0, "tem_standardize: bad arguments");
+    int nblk = (int)(tem_cdiv(L, 256) < STD_BLOCKS ? tem_cdiv(L, 256) : STD_BLOCKS);
+    if ((int64_t)N * nblk * 2 * (int64_t)sizeof(double) > ws_bytes) {
+        tem_set_error("tem_standardize: workspace too small (%lld bytes needed)",
+                      (long long)((int64_t)N * nblk * 2 * sizeof(double)));
+        return TEM_EWS;
+    }
+    hipLaunchKernelGGL(k_std_partial, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, x, L, (double*)ws);
+    hipLaunchKernelGGL(k_std_apply, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, x, y, L, (const double*)ws, nblk, eps);
+    TEM_CHECK_LAUNCH("tem_standardize");
+    return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// final-activation backward (contiguous arrays)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ gy, const float* __restrict__ y,
+                                                 float* __restrict__ gx, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float yv = y[i], g = gy[i];
+        gx[i] = (act == TEM_ACT_SIGMOID) ? g * yv * (1.f - yv) : ((yv > 0.f) ? g : 0.f);
+    }
+}
+
+extern "C" int tem_act_bwd(const float* gy, const float* y, float* gx, int64_t n, int act, tem_stream_t stream) {
+    TEM_REQUIRE(gy && y && gx && n > 0, "tem_act_bwd: bad arguments");
+    TEM_REQUIRE(act == TEM_ACT_RELU || act == TEM_ACT_SIGMOID, "tem_act_bwd: Invalid activation: %d", act);
+    hipLaunchKernelGGL(k_act_bwd, dim3(tem_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, gy, y, gx, n, act);
+    TEM_CHECK_LAUNCH("tem_act_bwd");
+    return TEM_OK;
+}

@@ -1,0 +1,463 @@
+// conv.hip -- convolution entry points (reference nn.Conv3d/nn.Conv2d inside ConvBlock,
+// Upsampler.conv and out_conv: model/unet.py:417-438,453,638, and their autograd backward),
+// weight (un)packing, and the VALU kernels used where the MFMA path does not apply:
+// Cin==1 first layer (HBM-bound, 13 flop/B), the 32->Cout<=16 output projection
+// (HBM-bound, 0.9 flop/B) and the small test networks.
+#include "tem_common.h"
+#include "conv_internal.h"
+
+// ---------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------
+extern "C" int64_t tem_conv_packed_size(int Cout, int Cin, int kd, int kh, int kw) {
+    return (int64_t)Cout * Cin * kd * kh * kw;
+}
+
+__global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, float* __restrict__ dst, int Cout,
+                                                      int Cin, int KD, int KH, int KW, int transpose, int layout) {
+    const int ntaps = KD * KH * KW;
+    const int64_t total = (int64_t)Cout * Cin * ntaps;
+    // logical operator: CoutL x CinL
+    const int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        // enumerate logical (tap, ci, co), co fastest
+        int co = (int)(i % CoutL);
+        int64_t r = i / CoutL;
+        int ci = (int)(r % CinL);
+        int tap = (int)(r / CinL);
+        int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+        float val;
+        if (!transpose) {
+            val = w[(((int64_t)co * Cin + ci) * KD + tz) * KH * KW + ty * KW + tx];
+        } else {
+            // Wl[co][ci][tap] = w[ci][co][flip(tap)]  (source is [Cout=CinL][Cin=CoutL])
+            val = w[(((int64_t)ci * Cin + co) * KD + (KD - 1 - tz)) * KH * KW + (KH - 1 - ty) * KW + (KW - 1 - tx)];
+        }
+        int64_t o;
+        if (layout == TEM_WL_GENERIC) {
+            o = ((int64_t)tap * CinL + ci) * CoutL + co;
+        } else {
+            int nt = co >> 5, col = co & 31, c8 = ci >> 3, kh = (ci >> 2) & 1, j = ci & 3;
+            o = (((((int64_t)nt * ntaps + tap) * (CinL >> 3) + c8) * 2 + kh) * 32 + col) * 4 + j;
+        }
+        dst[o] = val;
+    }
+}
+
+extern "C" int tem_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw,
+                                     int transpose, int layout, tem_stream_t stream) {
+    TEM_REQUIRE(w && dst && Cout > 0 && Cin > 0, "tem_conv_pack_weights: bad arguments");
+    TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
+                "tem_conv_pack_weights: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
+    if (layout == TEM_WL_MFMA) {
+        int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
+        TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: MFMA layout needs Cin%%16==0, Cout%%32==0");
+    } else {
+        TEM_REQUIRE(layout == TEM_WL_GENERIC, "tem_conv_pack_weights: unknown layout %d", layout);
+    }
+    int64_t total = (int64_t)Cout * Cin * kd * kh * kw;
+    hipLaunchKernelGGL(k_pack_weights, dim3(tem_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout,
+                       Cin, kd, kh, kw, transpose, layout);
+    TEM_CHECK_LAUNCH("tem_conv_pack_weights");
+    return TEM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_wgrad(const float* __restrict__ src, float* __restrict__ dw, int Cout,
+                                                      int Cin, int ntaps) {
+    const int64_t total = (int64_t)Cout * Cin * ntaps;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        // i enumerates the destination [co][ci][tap]
+        int tap = (int)(i % ntaps);
+        int64_t r = i / ntaps;
+        int ci = (int)(r % Cin);
+        int co = (int)(r / Cin);
+        dw[i] = src[((int64_t)tap * Cin + ci) * Cout + co];
+    }
+}
+
+extern "C" int tem_conv_unpack_wgrad(const float* src, float* dw, int Cout, int Cin, int kd, int kh, int kw,
+                                     tem_stream_t stream) {
+    TEM_REQUIRE(src && dw && Cout > 0 && Cin > 0, "tem_conv_unpack_wgrad: bad arguments");
+    int64_t total = (int64_t)Cout * Cin * kd * kh * kw;
+    hipLaunchKernelGGL(k_unpack_wgrad, dim3(tem_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dw, Cout,
+                       Cin, kd * kh * kw);
+    TEM_CHECK_LAUNCH("tem_conv_unpack_wgrad");
+    return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generic VALU forward: thread <-> (voxel, co), co fastest.  Lanes that share a
+// voxel broadcast the x reads; weight reads and the output store are coalesced.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == TEM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == TEM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+template <int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void k_conv_fwd_generic(const float* __restrict__ x, int64_t x_ld,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int64_t y_ld, const float* __restrict__ ref, int64_t ref_ld,
+                                                          int N, int D, int H, int W, int Cin, int Cout, int act) {
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    const int64_t NV = (int64_t)N * D * H * W;
+    const int64_t items = NV * Cout;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t v = i / Cout;
+    int co = (int)(i % Cout);
+    const int64_t dv = stride / Cout;
+    const int dco = (int)(stride % Cout);
+    for (; i < items; i += stride, v += dv, co += dco) {
+        if (co >= Cout) {
+            co -= Cout;
+            ++v;
+        }
+        int xx = (int)(v % W);
+        int64_t r = v / W;
+        int yy = (int)(r % H);
+        r /= H;
+        int zz = (int)(r % D);
+        int n = (int)(r / D);
+        float acc = bias ? bias[co] : 0.f;
+        const float* sc = scale ? scale + (int64_t)n * Cin : nullptr;
+        const float* sf = shift ? shift + (int64_t)n * Cin : nullptr;
+#pragma unroll
+        for (int tz = 0; tz < KD; ++tz) {
+            int z2 = zz + tz - PZ;
+            if (z2 < 0 || z2 >= D) continue;
+#pragma unroll
+            for (int ty = 0; ty < KH; ++ty) {
+                int y2 = yy + ty - PY;
+                if (y2 < 0 || y2 >= H) continue;
+#pragma unroll
+                for (int tx = 0; tx < KW; ++tx) {
+                    int x2 = xx + tx - PX;
+                    if (x2 < 0 || x2 >= W) continue;
+                    const int tap = (tz * KH + ty) * KW + tx;
+                    const float* xp = x + ((((int64_t)n * D + z2) * H + y2) * W + x2) * x_ld;
+                    const float* wp = w + (int64_t)tap * Cin * Cout + co;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        float xv = xp[ci];
+                        if (sc) xv = fmaf(xv, sc[ci], sf[ci]);
+                        acc = fmaf(xv, wp[(int64_t)ci * Cout], acc);
+                    }
+                }
+            }
+        }
+        acc = apply_act(acc, act);
+        if (ref && !(ref[v * ref_ld + co] > 0.f)) acc = 0.f;
+        y[v * y_ld + co] = acc;
+    }
+}
+
+// 1x1x1 projection to a few channels (out_conv 32->2/12): thread <-> voxel, reads its
+// whole channel row with 16-byte loads, keeps Cout accumulators; weights via L1.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv1x1_smallcout(const float* __restrict__ x, int64_t x_ld,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ w /*[ci][co]*/,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int64_t y_ld, const float* __restrict__ ref, int64_t ref_ld,
+                                                           int64_t V, int64_t NV, int Cin, int act) {
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < NV; v += (int64_t)gridDim.x * 256) {
+        const int n = (int)(v / V);
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+        const float* xp = x + v * x_ld;
+        for (int ci = 0; ci < Cin; ci += 4) {
+            float4 t = *reinterpret_cast<const float4*>(xp + ci);
+            float xv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (scale) xv[j] = fmaf(xv[j], scale[(int64_t)n * Cin + ci + j], shift[(int64_t)n * Cin + ci + j]);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv[j], w[(ci + j) * COUT + co], acc[co]);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float a = apply_act(acc[co], act);
+            if (ref && !(ref[v * ref_ld + co] > 0.f)) a = 0.f;
+            y[v * y_ld + co] = a;
+        }
+    }
+}
+
+template <int KD, int KH, int KW>
+static void launch_fwd_generic(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
+                               const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D,
+                               int H, int W, int Cin, int Cout, int act, hipStream_t s) {
+    int64_t items = (int64_t)N * D * H * W * Cout;
+    hipLaunchKernelGGL((k_conv_fwd_generic<KD, KH, KW>), dim3(tem_grid_1d(items, 256, 256 * 16)), dim3(256), 0, s, x,
+                       x_ld, scale, shift, w, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act);
+}
+
+#define DISPATCH_K(KD, KH, KW, CALL)                                  \
+    do {                                                              \
+        int key__ = ((KD) == 3) * 4 + ((KH) == 3) * 2 + ((KW) == 3);  \
+        switch (key__) {                                              \
+            case 0: { CALL(1, 1, 1); } break;                         \
+            case 1: { CALL(1, 1, 3); } break;                         \
+            case 2: { CALL(1, 3, 1); } break;                         \
+            case 3: { CALL(1, 3, 3); } break;                         \
+            case 4: { CALL(3, 1, 1); } break;                         \
+            case 5: { CALL(3, 1, 3); } break;                         \
+            case 6: { CALL(3, 3, 1); } break;                         \
+            default: { CALL(3, 3, 3); } break;                        \
+        }                                                             \
+    } while (0)
+
+extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                              const float* w_packed, const float* bias, float* y, int64_t y_ld, const float* ref,
+                              int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                              int act, int use_mfma, tem_stream_t stream) {
+    TEM_REQUIRE(x && w_packed && y, "tem_conv3d_fwd: null pointer");
+    TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= Cin && y_ld >= Cout,
+                "tem_conv3d_fwd: bad shape");
+    TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
+                "tem_conv3d_fwd: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
+    TEM_REQUIRE((scale == nullptr) == (shift == nullptr), "tem_conv3d_fwd: scale and shift must both be given");
+    TEM_REQUIRE(act >= 0 && act <= 2, "tem_conv3d_fwd: Invalid activation: %d", act);
+    TEM_REQUIRE(!ref || ref_ld >= Cout, "tem_conv3d_fwd: bad ref_ld");
+    hipStream_t s = (hipStream_t)stream;
+    if (use_mfma) {
+        int rc = tem_conv_fwd_mfma(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout,
+                                   kd, kh, kw, act, s);
+        if (rc != TEM_OK) return rc;
+        TEM_CHECK_LAUNCH("tem_conv3d_fwd(mfma)");
+        return TEM_OK;
+    }
+    const int64_t NV = (int64_t)N * D * H * W;
+    if (kd == 1 && kh == 1 && kw == 1 && Cin % 4 == 0 && x_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) &&
+        (Cout == 1 || Cout == 2 || Cout == 3 || Cout == 4 || Cout == 8 || Cout == 12 || Cout == 16)) {
+        dim3 grid(tem_grid_1d(NV, 256, 256 * 16));
+#define SC(CO)                                                                                                   \
+    case CO:                                                                                                     \
+        hipLaunchKernelGGL((k_conv1x1_smallcout<CO>), grid, dim3(256), 0, s, x, x_ld, scale, shift, w_packed, bias, y, \
+                           y_ld, ref, ref_ld, (int64_t)D * H * W, NV, Cin, act);                                 \
+        break;
+        switch (Cout) {
+            SC(1) SC(2) SC(3) SC(4) SC(8) SC(12) SC(16)
+        }
+#undef SC
+        TEM_CHECK_LAUNCH("tem_conv3d_fwd(1x1)");
+        return TEM_OK;
+    }
+#define CALL(A, B, C) \
+    launch_fwd_generic<A, B, C>(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, s)
+    DISPATCH_K(kd, kh, kw, CALL);
+#undef CALL
+    TEM_CHECK_LAUNCH("tem_conv3d_fwd(generic)");
+    return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generic VALU weight gradient.  thread <-> (pair=(ci,co) of a <=256-pair block, row r);
+// all taps accumulate in registers so g is read once.  Two-stage deterministic:
+// partial[chunk][tap][ci][co] -> fp64 merge.
+// ---------------------------------------------------------------------------
+template <int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void k_conv_wgrad_generic(const float* __restrict__ x, int64_t x_ld,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ g, int64_t g_ld, int N, int D,
+                                                            int H, int W, int Cin, int Cout, int npairs_blk, int rows,
+                                                            int64_t vper, float* __restrict__ part) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    extern __shared__ float sh[];  // [NT][rows][npairs_blk]
+    const int64_t NV = (int64_t)N * D * H * W;
+    const int chunk = blockIdx.x, pb = blockIdx.y;
+    const int pl = threadIdx.x % npairs_blk, r = threadIdx.x / npairs_blk;
+    const int pair = pb * npairs_blk + pl;
+    const bool active = pair < Cin * Cout && r < rows;
+    const int ci = active ? pair / Cout : 0, co = active ? pair % Cout : 0;
+    float acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    int64_t v0 = (int64_t)chunk * vper, v1 = v0 + vper;
+    if (v1 > NV) v1 = NV;
+    if (active) {
+        for (int64_t v = v0 + r; v < v1; v += rows) {
+            int xx = (int)(v % W);
+            int64_t q = v / W;
+            int yy = (int)(q % H);
+            q /= H;
+            int zz = (int)(q % D);
+            int n = (int)(q / D);
+            const float gv = g[v * g_ld + co];
+            float sc = 1.f, sf = 0.f;
+            if (scale) {
+                sc = scale[(int64_t)n * Cin + ci];
+                sf = shift[(int64_t)n * Cin + ci];
+            }
+#pragma unroll
+            for (int tz = 0; tz < KD; ++tz) {
+                int z2 = zz + tz - PZ;
+#pragma unroll
+                for (int ty = 0; ty < KH; ++ty) {
+                    int y2 = yy + ty - PY;
+#pragma unroll
+                    for (int tx = 0; tx < KW; ++tx) {
+                        int x2 = xx + tx - PX;
+                        if (z2 < 0 || z2 >= D || y2 < 0 || y2 >= H || x2 < 0 || x2 >= W) continue;
+                        float xv = x[((((int64_t)n * D + z2) * H + y2) * W + x2) * x_ld + ci];
+                        xv = fmaf(xv, sc, sf);
+                        acc[(tz * KH + ty) * KW + tx] = fmaf(xv, gv, acc[(tz * KH + ty) * KW + tx]);
+                    }
+                }
+            }
+        }
+    }
+    if (r < rows) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sh[((int64_t)t * rows + r) * npairs_blk + pl] = acc[t];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NT * npairs_blk; idx += 256) {
+        int t = idx / npairs_blk, p = idx % npairs_blk;
+        int gp = pb * npairs_blk + p;
+        if (gp >= Cin * Cout) continue;
+        float s = 0.f;
+        for (int rr = 0; rr < rows; ++rr) s += sh[((int64_t)t * rows + rr) * npairs_blk + p];
+        // partial[chunk][tap][ci][co]; pair index == ci*Cout+co
+        part[((int64_t)chunk * NT + t) * Cin * Cout + gp] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, int nchunks, int64_t n,
+                                                         float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double s = 0.0;
+        for (int c = 0; c < nchunks; ++c) s += (double)part[(int64_t)c * n + i];
+        out[i] = (float)s;
+    }
+}
+
+// column sums: db[co] = sum_v g[v][co]
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ g, int64_t g_ld, int64_t NV, int C,
+                                                        int rows, int64_t vper, float* __restrict__ part) {
+    extern __shared__ float sh[];  // [rows][Cb]
+    const int Cb = C < 256 ? C : 256;
+    const int cl = threadIdx.x % Cb, r = threadIdx.x / Cb;
+    int64_t v0 = (int64_t)blockIdx.x * vper, v1 = v0 + vper;
+    if (v1 > NV) v1 = NV;
+    for (int c0 = 0; c0 < C; c0 += Cb) {
+        int c = c0 + cl;
+        float s = 0.f;
+        if (c < C && r < rows)
+            for (int64_t v = v0 + r; v < v1; v += rows) s += g[v * g_ld + c];
+        if (r < rows) sh[r * Cb + cl] = s;
+        __syncthreads();
+        if (r == 0 && c < C) {
+            float a = 0.f;
+            for (int rr = 0; rr < rows; ++rr) a += sh[rr * Cb + cl];
+            part[(int64_t)blockIdx.x * C + c] = a;
+        }
+        __syncthreads();
+    }
+}
+
+struct WgradGenericPlan {
+    int npairs_blk, rows, npb, nchunks;
+    int64_t vper;
+    int64_t part_floats;   // wgrad partials
+    int db_chunks;
+    int64_t db_floats;
+};
+
+static WgradGenericPlan wgrad_generic_plan(int64_t NV, int Cin, int Cout, int ntaps) {
+    WgradGenericPlan p;
+    int pairs = Cin * Cout;
+    p.npairs_blk = pairs < 256 ? pairs : 256;
+    p.rows = 256 / p.npairs_blk;
+    if (p.rows < 1) p.rows = 1;
+    p.npb = (int)tem_cdiv(pairs, p.npairs_blk);
+    int64_t nch = tem_cdiv(NV, (int64_t)p.rows * 64);
+    int64_t cap = (64ll << 20) / ((int64_t)ntaps * pairs * 4);
+    if (cap < 1) cap = 1;
+    if (nch > cap) nch = cap;
+    if (nch > 2048) nch = 2048;
+    if (nch < 1) nch = 1;
+    p.nchunks = (int)nch;
+    p.vper = tem_cdiv(NV, nch);
+    p.part_floats = (int64_t)p.nchunks * ntaps * pairs;
+    int64_t dbc = tem_cdiv(NV, 256);
+    if (dbc > 1024) dbc = 1024;
+    p.db_chunks = (int)dbc;
+    p.db_floats = (int64_t)p.db_chunks * Cout;
+    return p;
+}
+
+extern "C" int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                                       int use_mfma) {
+    int64_t NV = (int64_t)N * D * H * W;
+    int ntaps = kd * kh * kw;
+    WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
+    int64_t bytes = p.db_floats * 4;
+    if (use_mfma)
+        bytes += tem_conv_wgrad_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
+    else
+        bytes += p.part_floats * 4;
+    return bytes + 256;
+}
+
+template <int KD, int KH, int KW>
+static void launch_wgrad_generic(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                                 int64_t g_ld, int N, int D, int H, int W, int Cin, int Cout,
+                                 const WgradGenericPlan& p, float* part, hipStream_t s) {
+    constexpr int NT = KD * KH * KW;
+    size_t lds = (size_t)NT * p.rows * p.npairs_blk * sizeof(float);
+    hipLaunchKernelGGL((k_conv_wgrad_generic<KD, KH, KW>), dim3(p.nchunks, p.npb), dim3(256), lds, s, x, x_ld, scale,
+                       shift, g, g_ld, N, D, H, W, Cin, Cout, p.npairs_blk, p.rows, p.vper, part);
+}
+
+extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                                int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H,
+                                int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma, tem_stream_t stream) {
+    TEM_REQUIRE(x && g && dw && ws, "tem_conv3d_wgrad: null pointer");
+    TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= Cin && g_ld >= Cout,
+                "tem_conv3d_wgrad: bad shape");
+    TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
+                "tem_conv3d_wgrad: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
+    TEM_REQUIRE((scale == nullptr) == (shift == nullptr), "tem_conv3d_wgrad: scale and shift must both be given");
+    if (ws_bytes < tem_conv3d_wgrad_ws(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma)) {
+        tem_set_error("tem_conv3d_wgrad: workspace too small");
+        return TEM_EWS;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t NV = (int64_t)N * D * H * W;
+    const int ntaps = kd * kh * kw;
+    WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
+    float* dbpart = (float*)ws;
+    float* rest = dbpart + tem_align_up(p.db_floats, 64);
+    if (db) {
+        int Cb = Cout < 256 ? Cout : 256;
+        int rows = 256 / Cb;
+        int64_t vper = tem_cdiv(NV, p.db_chunks);
+        hipLaunchKernelGGL(k_colsum_partial, dim3(p.db_chunks), dim3(256), (size_t)rows * Cb * sizeof(float), s, g, g_ld,
+                           NV, Cout, rows, vper, dbpart);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(tem_grid_1d(Cout, 256)), dim3(256), 0, s, dbpart, p.db_chunks,
+                           (int64_t)Cout, db);
+    }
+    if (use_mfma) {
+        int rc = tem_conv_wgrad_mfma(x, x_ld, scale, shift, g, g_ld, dw, rest,
+                                     ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw, s);
+        if (rc != TEM_OK) return rc;
+        TEM_CHECK_LAUNCH("tem_conv3d_wgrad(mfma)");
+        return TEM_OK;
+    }
+#define CALL(A, B, C) launch_wgrad_generic<A, B, C>(x, x_ld, scale, shift, g, g_ld, N, D, H, W, Cin, Cout, p, rest, s)
+    DISPATCH_K(kd, kh, kw, CALL);
+#undef CALL
+    int64_t n = (int64_t)ntaps * Cin * Cout;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(tem_grid_1d(n, 256)), dim3(256), 0, s, rest, p.nchunks, n, dw);
+    TEM_CHECK_LAUNCH("tem_conv3d_wgrad(generic)");
+    return TEM_OK;
+}

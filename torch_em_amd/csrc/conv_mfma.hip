@@ -1,0 +1,488 @@
+// conv_mfma.hip -- implicit-GEMM 3-D convolution on the gfx950 matrix cores in EXACT fp32
+// (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 157 TFLOP/s peak = the fp32 roofline of
+// this path).  Replaces aten::convolution / convolution_backward behind
+// nn.Conv3d in ConvBlock (reference model/unet.py:417-438).
+//
+// Forward / data-gradient (one kernel; dgrad = forward with the transposed, tap-flipped pack):
+//   GEMM view  M = voxels, N = Cout, K = taps*Cin.
+//   workgroup  = 4 waves, output patch TZxTYxTX = 256 voxels x (32*NR) output channels;
+//                wave w owns 64 consecutive patch voxels (two 32-row MFMA tiles) x NR column tiles.
+//   per 16-channel chunk of Cin the (TZ+2)(TY+2)(TX+2) halo tile is staged ONCE into LDS
+//   (with the fused pre-norm x*scale+shift applied, zero padding after the norm) and reused
+//   by all taps: A fragments are ds_read_b128 (4 channels -> 4 MFMAs) at compile-time tap offsets,
+//   B fragments (weights, pre-packed in fragment order, L2-resident) are 16-byte global loads.
+//   Epilogue: bias + ReLU/Sigmoid + optional ReLU-backward mask, 128-byte row stores.
+//
+// Weight gradient:
+//   GEMM view  M = Cin (32-row tile), N = Cout (32-col tiles), K = voxels, one accumulator per tap.
+//   workgroup  = 4 waves over a (ci-tile, co-tile group, patch range); the taps x co-tiles
+//   "units" are dealt round-robin to the waves (<= 7 accumulators = 112 VGPRs each); X halo
+//   tile and G tile staged in LDS per 2x8x8 patch; split over patch ranges, partial slabs are
+//   merged by a deterministic fp64 reduction (no atomics).
+#include "tem_common.h"
+#include "conv_internal.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define CK 16      // input channels per staged chunk (fwd)
+#define LSF 20     // LDS floats per halo voxel (16 + 4 pad -> 80 B, keeps b128 alignment)
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == TEM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == TEM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// forward / dgrad
+// ---------------------------------------------------------------------------
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR>
+__global__ __launch_bounds__(256, 2) void k_conv_fwd_mfma(
+    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
+    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
+    int nY, int nX) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
+    constexpr int HV = HZ * HY * HX;
+    constexpr int NIT = (HV * 4 + 255) / 256;
+    static_assert(TZ * TY * TX == 256, "patch must hold 256 voxels");
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [HV][LSF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kh = lane >> 5, r = lane & 31;
+
+    int bid = tem_xcd_remap(blockIdx.x, gridDim.x);
+    const int ncot = Cout / (32 * NR);
+    const int cot = bid % ncot;
+    bid /= ncot;
+    const int ptx = bid % nX;
+    bid /= nX;
+    const int pty = bid % nY;
+    bid /= nY;
+    const int ptz = bid % nZ;
+    const int n = bid / nZ;
+    const int z0 = ptz * TZ, y0 = pty * TY, x0 = ptx * TX;
+
+    int abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int p = wv * 64 + m * 32 + r;
+        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+        abase[m] = ((pz * HY + py) * HX + px) * LSF + kh * 4;
+    }
+
+    floatx16 acc[2][NR];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
+
+    const int cin8 = Cin >> 3;
+    const float4* __restrict__ wp4 = reinterpret_cast<const float4*>(wp);
+    const int c4 = tid & 3;  // channel quad of this thread's staging items (256 % 4 == 0)
+
+    for (int chunk = 0; chunk < Cin / CK; ++chunk) {
+        // ---- stage the halo tile of this 16-channel chunk (global -> regs -> LDS) ----
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) {
+            sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + chunk * CK + c4 * 4);
+            sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + chunk * CK + c4 * 4);
+        }
+        float4 tmp[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * 256;
+            const int hv = item >> 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hv < HV) {
+                const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+                const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
+                if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    v = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld +
+                                                         chunk * CK + c4 * 4);
+                    v.x = fmaf(v.x, sc4.x, sf4.x);
+                    v.y = fmaf(v.y, sc4.y, sf4.y);
+                    v.z = fmaf(v.z, sc4.z, sf4.z);
+                    v.w = fmaf(v.w, sc4.w, sf4.w);
+                }
+            }
+            tmp[it] = v;
+        }
+        __syncthreads();  // previous chunk's MFMA reads are done
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * 256;
+            const int hv = item >> 2;
+            if (hv < HV) *reinterpret_cast<float4*>(lds + hv * LSF + c4 * 4) = tmp[it];
+        }
+        __syncthreads();
+
+        // ---- MFMA over all taps of this chunk ----
+        const float4* wq[NR];
+#pragma unroll
+        for (int nn = 0; nn < NR; ++nn)
+            wq[nn] = wp4 + ((int64_t)(cot * NR + nn) * NT * cin8 + chunk * 2) * 64 + lane;
+        const int tapstride = cin8 * 64;
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+            const int toff = ((tz * HY + ty) * HX + tx) * LSF;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                float4 b[NR];
+#pragma unroll
+                for (int nn = 0; nn < NR; ++nn) b[nn] = wq[nn][tap * tapstride + kg * 64];
+                float4 a[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff + kg * 8);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < NR; ++nn) {
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[nn].x, acc[m][nn], 0, 0, 0);
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[nn].y, acc[m][nn], 0, 0, 0);
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[nn].z, acc[m][nn], 0, 0, 0);
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[nn].w, acc[m][nn], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue: D[row = voxel][col = co];  row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31 ----
+#pragma unroll
+    for (int nn = 0; nn < NR; ++nn) {
+        const int co = (cot * NR + nn) * 32 + r;
+        const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                const int p = wv * 64 + m * 32 + row;
+                const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+                const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+                if (gz < D && gy < H && gx < W) {
+                    const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
+                    float o = act_apply(acc[m][nn][reg] + bv, act);
+                    if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
+                    y[v * y_ld + co] = o;
+                }
+            }
+        }
+    }
+}
+
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR>
+static void launch_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                       const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
+                       int W, int Cin, int Cout, int act, hipStream_t s) {
+    constexpr int HV = (TZ + KD - 1) * (TY + KH - 1) * (TX + KW - 1);
+    const int nZ = (D + TZ - 1) / TZ, nY = (H + TY - 1) / TY, nX = (W + TX - 1) / TX;
+    const int64_t nblk = (int64_t)N * nZ * nY * nX * (Cout / (32 * NR));
+    size_t ldsb = (size_t)HV * LSF * sizeof(float);
+    hipLaunchKernelGGL((k_conv_fwd_mfma<KD, KH, KW, TZ, TY, TX, NR>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld,
+                       scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, nZ, nY, nX);
+}
+
+int tem_conv_fwd_mfma(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
+                      int W, int Cin, int Cout, int kd, int kh, int kw, int act, hipStream_t s) {
+    TEM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0, "tem_conv3d_fwd(mfma): needs Cin%%16==0 and Cout%%32==0 (got %d,%d)",
+                Cin, Cout);
+    TEM_REQUIRE(x_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)wp % 16 == 0),
+                "tem_conv3d_fwd(mfma): x / packed weights must be 16-byte aligned with ld%%4==0");
+    TEM_REQUIRE(!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)),
+                "tem_conv3d_fwd(mfma): scale/shift must be 16-byte aligned");
+    const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
+    const bool nr2 = (Cout % 64 == 0);
+    const bool flat = (D == 1);
+#define GO(KD, KH, KW, TZ, TY, TX)                                                                                 \
+    do {                                                                                                           \
+        if (nr2)                                                                                                   \
+            launch_fwd<KD, KH, KW, TZ, TY, TX, 2>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
+                                                  Cin, Cout, act, s);                                              \
+        else                                                                                                       \
+            launch_fwd<KD, KH, KW, TZ, TY, TX, 1>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
+                                                  Cin, Cout, act, s);                                              \
+    } while (0)
+    if (key == 7) {
+        GO(3, 3, 3, 4, 8, 8);
+    } else if (key == 3) {
+        if (flat)
+            GO(1, 3, 3, 1, 16, 16);
+        else
+            GO(1, 3, 3, 4, 8, 8);
+    } else if (key == 0) {
+        if (flat)
+            GO(1, 1, 1, 1, 16, 16);
+        else
+            GO(1, 1, 1, 4, 8, 8);
+    } else {
+        tem_set_error("tem_conv3d_fwd(mfma): kernel (%d,%d,%d) has no MFMA instantiation", kd, kh, kw);
+        return TEM_EINVAL;
+    }
+#undef GO
+    return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------
+#define WG_TZ 2
+#define WG_TY 8
+#define WG_TX 8
+#define WG_MAXU 7   // accumulators per wave
+
+template <int KD, int KH, int KW, int NCO>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_mfma(const float* __restrict__ x, int64_t x_ld,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ g, int64_t g_ld,
+                                                            float* __restrict__ part, int N, int D, int H, int W,
+                                                            int Cin, int Cout, int T, int S, int P, int nZ, int nY,
+                                                            int nX) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int HZ = WG_TZ + KD - 1, HY = WG_TY + KH - 1, HX = WG_TX + KW - 1;
+    constexpr int HV = HZ * HY * HX;
+    constexpr int PV = WG_TZ * WG_TY * WG_TX;  // 128 patch voxels
+    constexpr int XIT = (HV * 8 + 255) / 256;
+    constexpr int GC = 32 * NCO;               // staged g channels
+    constexpr int GIT = (PV * (GC / 4) + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ldsX = lds;                // [HV][32]
+    float* ldsG = lds + HV * 32;      // [PV][GC]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kh = lane >> 5, r = lane & 31;
+
+    const int bid = tem_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid % T, sp = bid / T;
+    const int ncit = Cin >> 5;
+    const int cit = tile % ncit, cog = tile / ncit;
+    const int ncot_total = Cout >> 5;
+    int nco_here = ncot_total - cog * NCO;
+    if (nco_here > NCO) nco_here = NCO;
+    const int U = NT * nco_here;
+
+    // units of this wave
+    int xoff[WG_MAXU], goff[WG_MAXU];
+#pragma unroll
+    for (int i = 0; i < WG_MAXU; ++i) {
+        const int u = wv + 4 * i;
+        const int tap = u % NT, ct = u / NT;
+        const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+        xoff[i] = ((tz * HY + ty) * HX + tx) * 32 + r;
+        goff[i] = ct * 32 + r;
+    }
+
+    floatx16 acc[WG_MAXU];
+#pragma unroll
+    for (int i = 0; i < WG_MAXU; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+
+    const int p_lo = (int)(((int64_t)sp * P) / S), p_hi = (int)(((int64_t)(sp + 1) * P) / S);
+    const int c8x = tid & 7;  // channel quad (of 8) for X staging items
+
+    for (int pidx = p_lo; pidx < p_hi; ++pidx) {
+        int q = pidx;
+        const int ptx = q % nX;
+        q /= nX;
+        const int pty = q % nY;
+        q /= nY;
+        const int ptz = q % nZ;
+        const int n = q / nZ;
+        const int z0 = ptz * WG_TZ, y0 = pty * WG_TY, x0 = ptx * WG_TX;
+
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) {
+            sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + c8x * 4);
+            sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + c8x * 4);
+        }
+        __syncthreads();  // previous patch's MFMA reads are done
+        // X halo tile, batches of 4 x 16-byte loads per thread (bounded registers: the 7
+        // accumulators own the register file; the co-resident workgroup hides this latency)
+        constexpr int XB = 4;
+#pragma unroll 1
+        for (int it0 = 0; it0 < XIT; it0 += XB) {
+            float4 t4[XB];
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int item = tid + (it0 + j) * 256;
+                const int hv = item >> 3;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (hv < HV) {
+                    const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+                    const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
+                    if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                        v = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld +
+                                                             cit * 32 + c8x * 4);
+                        v.x = fmaf(v.x, sc4.x, sf4.x);
+                        v.y = fmaf(v.y, sc4.y, sf4.y);
+                        v.z = fmaf(v.z, sc4.z, sf4.z);
+                        v.w = fmaf(v.w, sc4.w, sf4.w);
+                    }
+                }
+                t4[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int item = tid + (it0 + j) * 256;
+                const int hv = item >> 3;
+                if (hv < HV) *reinterpret_cast<float4*>(ldsX + hv * 32 + c8x * 4) = t4[j];
+            }
+        }
+#pragma unroll 1
+        for (int it0 = 0; it0 < GIT; it0 += XB) {
+            float4 t4[XB];
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int item = tid + (it0 + j) * 256;
+                const int pv = item / (GC / 4), cq = item % (GC / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pv < PV && cq < nco_here * 8) {
+                    const int pz = pv / (WG_TY * WG_TX), py = (pv / WG_TX) % WG_TY, px = pv % WG_TX;
+                    const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+                    if (gz < D && gy < H && gx < W)
+                        v = *reinterpret_cast<const float4*>(g + ((((int64_t)n * D + gz) * H + gy) * W + gx) * g_ld +
+                                                             cog * NCO * 32 + cq * 4);
+                }
+                t4[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int item = tid + (it0 + j) * 256;
+                const int pv = item / (GC / 4), cq = item % (GC / 4);
+                if (pv < PV) *reinterpret_cast<float4*>(ldsG + pv * GC + cq * 4) = t4[j];
+            }
+        }
+        __syncthreads();
+
+        // K loop over voxel pairs: lanes 0-31 take voxel 2k, lanes 32-63 voxel 2k+1
+        for (int zy = 0; zy < WG_TZ * WG_TY; ++zy) {
+            const int pz = zy / WG_TY, py = zy % WG_TY;
+            const int rowX = ((pz * HY + py) * HX) * 32;
+            const int rowG = (zy * WG_TX) * GC;
+#pragma unroll
+            for (int xp = 0; xp < WG_TX / 2; ++xp) {
+                const int px = 2 * xp + kh;
+                const float* ax = ldsX + rowX + px * 32;
+                const float* bg = ldsG + rowG + px * GC;
+#pragma unroll
+                for (int i = 0; i < WG_MAXU; ++i) {
+                    if (wv + 4 * i < U) {
+                        const float a = ax[xoff[i]];
+                        const float b = bg[goff[i]];
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: D[row = ci][col = co]
+#pragma unroll
+    for (int i = 0; i < WG_MAXU; ++i) {
+        const int u = wv + 4 * i;
+        if (u < U) {
+            const int tap = u % NT, ct = u / NT;
+            float* dst = part + (((int64_t)sp * NT + tap) * Cin + cit * 32) * Cout + (cog * NCO + ct) * 32 + r;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                dst[(int64_t)row * Cout] = acc[i][reg];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials_mf(const float* __restrict__ part, int nchunks, int64_t n,
+                                                            float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double s = 0.0;
+        for (int c = 0; c < nchunks; ++c) s += (double)part[(int64_t)c * n + i];
+        out[i] = (float)s;
+    }
+}
+
+struct WgradPlan {
+    int nco, T, S, P, nZ, nY, nX;
+};
+
+static WgradPlan wgrad_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) {
+    WgradPlan p;
+    p.nco = ntaps == 27 ? 1 : (ntaps == 9 ? 3 : 4);
+    int ncot = Cout / 32;
+    int ngroups = (ncot + p.nco - 1) / p.nco;
+    p.T = (Cin / 32) * ngroups;
+    p.nZ = (D + WG_TZ - 1) / WG_TZ;
+    p.nY = (H + WG_TY - 1) / WG_TY;
+    p.nX = (W + WG_TX - 1) / WG_TX;
+    int64_t P = (int64_t)N * p.nZ * p.nY * p.nX;
+    p.P = (int)P;
+    int64_t S = (1024 + p.T - 1) / p.T;
+    // keep the partial slab below 256 MiB
+    int64_t slab = (int64_t)ntaps * Cin * Cout * 4;
+    int64_t cap = (256ll << 20) / slab;
+    if (cap < 1) cap = 1;
+    if (S > cap) S = cap;
+    if (S > P) S = P;
+    if (S < 1) S = 1;
+    p.S = (int)S;
+    return p;
+}
+
+int64_t tem_conv_wgrad_mfma_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    WgradPlan p = wgrad_plan(N, D, H, W, Cin, Cout, kd * kh * kw);
+    return (int64_t)p.S * kd * kh * kw * Cin * Cout * 4;
+}
+
+template <int KD, int KH, int KW, int NCO>
+static void launch_wgrad(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                         int64_t g_ld, float* part, int N, int D, int H, int W, int Cin, int Cout, const WgradPlan& p,
+                         hipStream_t s) {
+    constexpr int HV = (WG_TZ + KD - 1) * (WG_TY + KH - 1) * (WG_TX + KW - 1);
+    constexpr int PV = WG_TZ * WG_TY * WG_TX;
+    size_t ldsb = ((size_t)HV * 32 + (size_t)PV * 32 * NCO) * sizeof(float);
+    hipLaunchKernelGGL((k_conv_wgrad_mfma<KD, KH, KW, NCO>), dim3((unsigned)(p.T * p.S)), dim3(256), ldsb, s, x, x_ld,
+                       scale, shift, g, g_ld, part, N, D, H, W, Cin, Cout, p.T, p.S, p.P, p.nZ, p.nY, p.nX);
+}
+
+int tem_conv_wgrad_mfma(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                        int64_t g_ld, float* dw, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin,
+                        int Cout, int kd, int kh, int kw, hipStream_t s) {
+    TEM_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "tem_conv3d_wgrad(mfma): needs Cin%%32==0 and Cout%%32==0 (got %d,%d)",
+                Cin, Cout);
+    TEM_REQUIRE(x_ld % 4 == 0 && g_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0),
+                "tem_conv3d_wgrad(mfma): x / g must be 16-byte aligned with ld%%4==0");
+    TEM_REQUIRE(!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)),
+                "tem_conv3d_wgrad(mfma): scale/shift must be 16-byte aligned");
+    const int ntaps = kd * kh * kw;
+    WgradPlan p = wgrad_plan(N, D, H, W, Cin, Cout, ntaps);
+    if (ws_bytes < tem_conv_wgrad_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw)) {
+        tem_set_error("tem_conv3d_wgrad(mfma): workspace too small");
+        return TEM_EWS;
+    }
+    float* part = (float*)ws;
+    const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
+    if (key == 7)
+        launch_wgrad<3, 3, 3, 1>(x, x_ld, scale, shift, g, g_ld, part, N, D, H, W, Cin, Cout, p, s);
+    else if (key == 3)
+        launch_wgrad<1, 3, 3, 3>(x, x_ld, scale, shift, g, g_ld, part, N, D, H, W, Cin, Cout, p, s);
+    else if (key == 0)
+        launch_wgrad<1, 1, 1, 4>(x, x_ld, scale, shift, g, g_ld, part, N, D, H, W, Cin, Cout, p, s);
+    else {
+        tem_set_error("tem_conv3d_wgrad(mfma): kernel (%d,%d,%d) has no MFMA instantiation", kd, kh, kw);
+        return TEM_EINVAL;
+    }
+    const int64_t n = (int64_t)ntaps * Cin * Cout;
+    hipLaunchKernelGGL(k_reduce_partials_mf, dim3(tem_grid_1d(n, 256)), dim3(256), 0, s, part, p.S, n, dw);
+    return TEM_OK;
+}

@@ -1,0 +1,244 @@
+// dice.hip -- Dice score / loss (reference loss/dice.py:34-133) and the masked variant of
+// LossWrapper + ApplyAndRemoveMask(masking_method="multiply") (loss/wrapper.py:84-87,129-152).
+// Pure HBM-bound: prediction, target (and mask) are read ONCE in place through generic
+// strides -- no flatten_samples() permute+copy (loss/dice.py:22-31), no p*m / t*m temporaries.
+// Reduction: fp32 per-thread partials -> fp32 per-block partials -> fp64 per-channel sums.
+#include "tem_common.h"
+
+#define DICE_MAX_BLOCKS 1024
+
+extern "C" int64_t tem_dice_ws(int N, int64_t V, int C) {
+    (void)N;
+    (void)V;
+    return (int64_t)DICE_MAX_BLOCKS * C * 3 * (int64_t)sizeof(float);
+}
+
+// thread -> (channel c, voxel sub-row r); CFAST: consecutive threads walk channels (NDHWC
+// prediction), else consecutive threads walk voxels (NCDHW prediction).
+template <bool CFAST>
+__global__ void k_dice_partial(const float* __restrict__ p, int64_t p_sn, int64_t p_sc, int64_t p_sv,
+                               const float* __restrict__ t, int64_t t_sn, int64_t t_sc, int64_t t_sv,
+                               const float* __restrict__ mask, int N, int C, int64_t V, int rows, int64_t vper,
+                               int nblk_per_n, float* __restrict__ part) {
+    extern __shared__ float sh[];  // [rows][C][3]
+    const int n = blockIdx.x / nblk_per_n, b = blockIdx.x % nblk_per_n;
+    int c, r;
+    if (CFAST) {
+        c = threadIdx.x % C;
+        r = threadIdx.x / C;
+    } else {
+        r = threadIdx.x % rows;
+        c = threadIdx.x / rows;
+    }
+    int64_t v0 = (int64_t)b * vper, v1 = v0 + vper;
+    if (v1 > V) v1 = V;
+    const float* pp = p + (int64_t)n * p_sn + (int64_t)c * p_sc;
+    const float* tp = t + (int64_t)n * t_sn + (int64_t)c * t_sc;
+    const float* mp = mask ? mask + (int64_t)n * t_sn + (int64_t)c * t_sc : nullptr;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t v = v0 + r; v < v1; v += rows) {
+        float pv = pp[v * p_sv], tv = tp[v * t_sv];
+        if (mp) {
+            float m = mp[v * t_sv];
+            pv *= m;
+            tv *= m;
+        }
+        s0 = fmaf(pv, tv, s0);
+        s1 = fmaf(pv, pv, s1);
+        s2 = fmaf(tv, tv, s2);
+    }
+    float* my = sh + ((int64_t)r * C + c) * 3;
+    my[0] = s0;
+    my[1] = s1;
+    my[2] = s2;
+    __syncthreads();
+    if (r == 0) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int rr = 0; rr < rows; ++rr) {
+            const float* o = sh + ((int64_t)rr * C + c) * 3;
+            a0 += o[0];
+            a1 += o[1];
+            a2 += o[2];
+        }
+        float* o = part + ((int64_t)blockIdx.x * C + c) * 3;
+        o[0] = a0;
+        o[1] = a1;
+        o[2] = a2;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dice_reduce(const float* __restrict__ part, int nblk, int C,
+                                                     double* __restrict__ sums) {
+    const int c = blockIdx.x;
+    double a[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const float* o = part + ((int64_t)b * C + c) * 3;
+        a[0] += (double)o[0];
+        a[1] += (double)o[1];
+        a[2] += (double)o[2];
+    }
+    __shared__ double sh[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a[k] = tem_wave_sum_d(a[k]);
+        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) sums[c * 3 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+extern "C" int tem_dice_sums(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
+                             int64_t t_sc, int64_t t_sv, const float* mask, int N, int C, int64_t V, double* sums,
+                             void* ws, int64_t ws_bytes, tem_stream_t stream) {
+    TEM_REQUIRE(p && t && sums && ws, "tem_dice_sums: null pointer");
+    TEM_REQUIRE(N > 0 && C > 0 && C <= 1024 && V > 0, "tem_dice_sums: bad shape (C=%d)", C);
+    if (ws_bytes < tem_dice_ws(N, V, C)) {
+        tem_set_error("tem_dice_sums: workspace too small");
+        return TEM_EWS;
+    }
+    int rows = 256 / C;
+    if (rows < 1) rows = 1;
+    int threads = rows * C;
+    int64_t nb = tem_cdiv(V, (int64_t)rows * 8);
+    int64_t maxb = DICE_MAX_BLOCKS / N;
+    if (maxb < 1) {
+        tem_set_error("tem_dice_sums: batch too large (N=%d)", N);
+        return TEM_EINVAL;
+    }
+    if (nb > maxb) nb = maxb;
+    int64_t vper = tem_cdiv(V, nb);
+    int nblk = (int)nb * N;
+    size_t lds = (size_t)rows * C * 3 * sizeof(float);
+    float* part = (float*)ws;
+    bool cfast = (p_sc == 1);
+    if (cfast)
+        hipLaunchKernelGGL((k_dice_partial<true>), dim3(nblk), dim3(threads), lds, (hipStream_t)stream, p, p_sn, p_sc,
+                           p_sv, t, t_sn, t_sc, t_sv, mask, N, C, V, rows, vper, (int)nb, part);
+    else
+        hipLaunchKernelGGL((k_dice_partial<false>), dim3(nblk), dim3(threads), lds, (hipStream_t)stream, p, p_sn, p_sc,
+                           p_sv, t, t_sn, t_sc, t_sv, mask, N, C, V, rows, vper, (int)nb, part);
+    hipLaunchKernelGGL(k_dice_reduce, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums);
+    TEM_CHECK_LAUNCH("tem_dice_sums");
+    return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// finalize: sums -> score/loss (+ the per-channel coefficients of d out / d p)
+//   score_c = 2*num/max(den,eps)  (loss/dice.py:65-67), out_c = invert ? 1-score_c : score_c
+//   reduce: 0 none, 1 sum, 2 mean, 3 max, 4 min (loss/dice.py:71-84)
+//   d out_c / d p = ca_c * t + cb_c * p
+// ---------------------------------------------------------------------------
+__global__ void k_dice_finalize(const double* __restrict__ sums, int C, double eps, int channelwise, int invert,
+                                int reduce, float* __restrict__ out, float* __restrict__ ca, float* __restrict__ cb) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double sgn = invert ? -1.0 : 1.0;
+    if (!channelwise) {
+        double num = 0.0, den = 0.0;
+        for (int c = 0; c < C; ++c) {
+            num += sums[c * 3];
+            den += sums[c * 3 + 1] + sums[c * 3 + 2];
+        }
+        double cd = den < eps ? eps : den;
+        double score = 2.0 * num / cd;
+        out[0] = (float)(invert ? 1.0 - score : score);
+        double a = sgn * 2.0 / cd, b = (den >= eps) ? -sgn * 4.0 * num / (cd * cd) : 0.0;
+        for (int c = 0; c < C; ++c) {
+            ca[c] = (float)a;
+            cb[c] = (float)b;
+        }
+        return;
+    }
+    double acc = 0.0;
+    int arg = 0;
+    double best = 0.0;
+    for (int c = 0; c < C; ++c) {
+        double num = sums[c * 3], den = sums[c * 3 + 1] + sums[c * 3 + 2];
+        double cd = den < eps ? eps : den;
+        double score = 2.0 * num / cd;
+        double val = invert ? 1.0 - score : score;
+        ca[c] = (float)(sgn * 2.0 / cd);
+        cb[c] = (float)((den >= eps) ? -sgn * 4.0 * num / (cd * cd) : 0.0);
+        if (reduce == 0) out[c] = (float)val;
+        acc += val;
+        if (c == 0 || (reduce == 3 && val > best) || (reduce == 4 && val < best)) {
+            best = val;
+            arg = c;
+        }
+    }
+    if (reduce == 1) out[0] = (float)acc;
+    if (reduce == 2) {
+        out[0] = (float)(acc / C);
+        for (int c = 0; c < C; ++c) {
+            ca[c] /= (float)C;
+            cb[c] /= (float)C;
+        }
+    }
+    if (reduce == 3 || reduce == 4) {
+        out[0] = (float)best;
+        for (int c = 0; c < C; ++c)
+            if (c != arg) {
+                ca[c] = 0.f;
+                cb[c] = 0.f;
+            }
+    }
+}
+
+extern "C" int tem_dice_finalize(const double* sums, int C, double eps, int channelwise, int invert, int reduce,
+                                 float* out, float* ca, float* cb, tem_stream_t stream) {
+    TEM_REQUIRE(sums && out && ca && cb && C > 0, "tem_dice_finalize: bad arguments");
+    TEM_REQUIRE(reduce >= 0 && reduce <= 4, "tem_dice_finalize: Unsupported channel reduction %d", reduce);
+    hipLaunchKernelGGL(k_dice_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, C, eps, channelwise, invert,
+                       reduce, out, ca, cb);
+    TEM_CHECK_LAUNCH("tem_dice_finalize");
+    return TEM_OK;
+}
+
+// gp = gout * (ca*t + cb*p) * mask   (p, t masked first)
+template <bool CFAST>
+__global__ __launch_bounds__(256) void k_dice_grad(const float* __restrict__ p, int64_t p_sn, int64_t p_sc,
+                                                   int64_t p_sv, const float* __restrict__ t, int64_t t_sn,
+                                                   int64_t t_sc, int64_t t_sv, const float* __restrict__ mask,
+                                                   const float* __restrict__ ca, const float* __restrict__ cb,
+                                                   const float* __restrict__ gout, int gout_per_channel,
+                                                   float* __restrict__ gp, int64_t g_sn, int64_t g_sc, int64_t g_sv,
+                                                   int C, int64_t V) {
+    const int n = blockIdx.y;
+    const int64_t items = V * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        int c;
+        int64_t v;
+        if (CFAST) {
+            v = i / C;
+            c = (int)(i - v * C);
+        } else {
+            c = (int)(i / V);
+            v = i - (int64_t)c * V;
+        }
+        float pv = p[(int64_t)n * p_sn + (int64_t)c * p_sc + v * p_sv];
+        float tv = t[(int64_t)n * t_sn + (int64_t)c * t_sc + v * t_sv];
+        float m = 1.f;
+        if (mask) {
+            m = mask[(int64_t)n * t_sn + (int64_t)c * t_sc + v * t_sv];
+            pv *= m;
+            tv *= m;
+        }
+        float go = gout ? gout[gout_per_channel ? c : 0] : 1.f;
+        gp[(int64_t)n * g_sn + (int64_t)c * g_sc + v * g_sv] = go * (ca[c] * tv + cb[c] * pv) * m;
+    }
+}
+
+extern "C" int tem_dice_grad(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
+                             int64_t t_sc, int64_t t_sv, const float* mask, const float* ca, const float* cb,
+                             const float* gout, int gout_per_channel, float* gp, int64_t g_sn, int64_t g_sc,
+                             int64_t g_sv, int N, int C, int64_t V, tem_stream_t stream) {
+    TEM_REQUIRE(p && t && ca && cb && gp && N > 0 && C > 0 && V > 0, "tem_dice_grad: bad arguments");
+    dim3 grid(tem_grid_1d(V * C, 256, 2048), N);
+    if (p_sc == 1)
+        hipLaunchKernelGGL((k_dice_grad<true>), grid, dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
+                           t_sc, t_sv, mask, ca, cb, gout, gout_per_channel, gp, g_sn, g_sc, g_sv, C, V);
+    else
+        hipLaunchKernelGGL((k_dice_grad<false>), grid, dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
+                           t_sc, t_sv, mask, ca, cb, gout, gout_per_channel, gp, g_sn, g_sc, g_sv, C, V);
+    TEM_CHECK_LAUNCH("tem_dice_grad");
+    return TEM_OK;
+}

@@ -1,0 +1,327 @@
+// norm.hip -- InstanceNorm / GroupNorm statistics and backward for NDHWC fp32 tensors.
+// Replaces nn.InstanceNorm3d / nn.GroupNorm of get_norm_layer (reference model/unet.py:391-406).
+// The normalisation itself is never materialised: tem_norm_stats emits per-(n,c)
+// scale/shift that the conv kernels apply while staging their input (HBM: one
+// read of x instead of read+write+read).  All reductions are two-stage and
+// deterministic: fp32 per-thread partials -> fp32 per-block partials -> fp64 merge.
+#include "tem_common.h"
+
+#define NORM_MAX_BLOCKS 512
+#define NORM_MAX_C 1024
+
+struct NormGeom {
+    int vec;       // 4 or 1 floats per thread item
+    int cq;        // channel items per voxel (C / vec)
+    int rows;      // voxel rows processed concurrently by one block
+    int threads;   // cq * rows
+    int nblk;      // blocks per sample
+    int64_t vper;  // voxels per block
+};
+
+static NormGeom norm_geom(const void* p0, const void* p1, int64_t ld0, int64_t ld1, int64_t V, int C) {
+    NormGeom g;
+    bool al = ((uintptr_t)p0 % 16 == 0) && (p1 == nullptr || (uintptr_t)p1 % 16 == 0);
+    g.vec = (C % 4 == 0 && ld0 % 4 == 0 && (p1 == nullptr || ld1 % 4 == 0) && al) ? 4 : 1;
+    g.cq = C / g.vec;
+    g.rows = 256 / g.cq;
+    if (g.rows < 1) g.rows = 1;
+    g.threads = g.cq * g.rows;
+    int64_t nb = tem_cdiv(V, (int64_t)g.rows * 16);
+    if (nb > NORM_MAX_BLOCKS) nb = NORM_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    g.nblk = (int)nb;
+    g.vper = tem_cdiv(V, nb);
+    return g;
+}
+
+extern "C" int64_t tem_norm_ws(int N, int64_t V, int C) {
+    (void)V;
+    // partials [N][NORM_MAX_BLOCKS][C][2] floats + coefficients [N][C][4] floats
+    return ((int64_t)N * NORM_MAX_BLOCKS * C * 2 + (int64_t)N * C * 4) * (int64_t)sizeof(float);
+}
+
+// ---------------------------------------------------------------------------
+// stage 1: per-block partial sums.  MODE 0: (sum x, sum x^2); MODE 1: (sum g, sum g*xn)
+// ---------------------------------------------------------------------------
+template <int VEC, int MODE>
+__global__ __launch_bounds__(VEC == 4 ? 256 : 1024) void k_norm_partial(const float* __restrict__ x, int64_t x_ld,
+                                                       const float* __restrict__ g, int64_t g_ld, int64_t V, int C,
+                                                       int G, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int cq, int rows, int64_t vper,
+                                                       float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // [rows][C][2]
+    const int n = blockIdx.y, b = blockIdx.x, nblk = gridDim.x;
+    const int q = threadIdx.x % cq, r = threadIdx.x / cq;
+    const int c0 = q * VEC;
+    int64_t v0 = (int64_t)b * vper, v1 = v0 + vper;
+    if (v1 > V) v1 = V;
+    float a0[VEC], a1[VEC];
+    float mu[VEC], rs[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        a0[j] = 0.f;
+        a1[j] = 0.f;
+        mu[j] = 0.f;
+        rs[j] = 1.f;
+    }
+    if (MODE == 1) {
+        const int cg = C / G;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            int grp = (c0 + j) / cg;
+            mu[j] = mean[n * G + grp];
+            rs[j] = rstd[n * G + grp];
+        }
+    }
+    const float* xb = x + (int64_t)n * V * x_ld;
+    const float* gb = (MODE == 1) ? g + (int64_t)n * V * g_ld : nullptr;
+    for (int64_t v = v0 + r; v < v1; v += rows) {
+        float xv[VEC], gv[VEC];
+        if constexpr (VEC == 4) {
+            float4 t = *reinterpret_cast<const float4*>(xb + v * x_ld + c0);
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            if constexpr (MODE == 1) {
+                float4 u = *reinterpret_cast<const float4*>(gb + v * g_ld + c0);
+                gv[0] = u.x; gv[1] = u.y; gv[2] = u.z; gv[3] = u.w;
+            }
+        } else {
+            xv[0] = xb[v * x_ld + c0];
+            if constexpr (MODE == 1) gv[0] = gb[v * g_ld + c0];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (MODE == 0) {
+                a0[j] += xv[j];
+                a1[j] = fmaf(xv[j], xv[j], a1[j]);
+            } else {
+                float xn = (xv[j] - mu[j]) * rs[j];
+                a0[j] += gv[j];
+                a1[j] = fmaf(gv[j], xn, a1[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        sh[((int64_t)r * C + c0 + j) * 2 + 0] = a0[j];
+        sh[((int64_t)r * C + c0 + j) * 2 + 1] = a1[j];
+    }
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int rr = 0; rr < rows; ++rr) {
+                s0 += sh[((int64_t)rr * C + c0 + j) * 2 + 0];
+                s1 += sh[((int64_t)rr * C + c0 + j) * 2 + 1];
+            }
+            int64_t o = (((int64_t)n * nblk + b) * C + c0 + j) * 2;
+            part[o] = s0;
+            part[o + 1] = s1;
+        }
+    }
+}
+
+__device__ __forceinline__ void block_sum2_d(double& a, double& b) {
+    __shared__ double sh2[2][4];
+    a = tem_wave_sum_d(a);
+    b = tem_wave_sum_d(b);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sh2[0][w] = a;
+        sh2[1][w] = b;
+    }
+    __syncthreads();
+    a = sh2[0][0] + sh2[0][1] + sh2[0][2] + sh2[0][3];
+    b = sh2[1][0] + sh2[1][1] + sh2[1][2] + sh2[1][3];
+    __syncthreads();
+}
+
+// stage 2 (forward): one block per (n, group)
+__global__ __launch_bounds__(256) void k_norm_finalize(const float* __restrict__ part, int nblk, int64_t V, int C, int G,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                       float* __restrict__ scale, float* __restrict__ shift) {
+    const int n = blockIdx.x / G, grp = blockIdx.x % G;
+    const int cg = C / G;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < nblk * cg; i += 256) {
+        int b = i / cg, c = grp * cg + i % cg;
+        int64_t o = (((int64_t)n * nblk + b) * C + c) * 2;
+        s += (double)part[o];
+        ss += (double)part[o + 1];
+    }
+    block_sum2_d(s, ss);
+    double cnt = (double)V * (double)cg;
+    double m = s / cnt;
+    double var = ss / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    double r = 1.0 / sqrt(var + (double)eps);
+    if (threadIdx.x == 0) {
+        mean[n * G + grp] = (float)m;
+        rstd[n * G + grp] = (float)r;
+    }
+    for (int i = threadIdx.x; i < cg; i += 256) {
+        int c = grp * cg + i;
+        double ga = gamma ? (double)gamma[c] : 1.0;
+        double be = beta ? (double)beta[c] : 0.0;
+        scale[(int64_t)n * C + c] = (float)(r * ga);
+        shift[(int64_t)n * C + c] = (float)(be - m * r * ga);
+    }
+}
+
+// stage 2 (backward): one block per (n, group) -> coef[n][c] = {a, m1, m2r, mean}
+//   gx = a*g - m1 - (x - mean)*m2r
+__global__ __launch_bounds__(256) void k_norm_bwd_finalize(const float* __restrict__ part, int nblk, int64_t V, int C,
+                                                           int G, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ coef) {
+    const int n = blockIdx.x / G, grp = blockIdx.x % G;
+    const int cg = C / G;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nblk * cg; i += 256) {
+        int b = i / cg, c = grp * cg + i % cg;
+        double ga = gamma ? (double)gamma[c] : 1.0;
+        int64_t o = (((int64_t)n * nblk + b) * C + c) * 2;
+        s1 += ga * (double)part[o];
+        s2 += ga * (double)part[o + 1];
+    }
+    block_sum2_d(s1, s2);
+    double cnt = (double)V * (double)cg;
+    double r = (double)rstd[n * G + grp], m = (double)mean[n * G + grp];
+    for (int i = threadIdx.x; i < cg; i += 256) {
+        int c = grp * cg + i;
+        double ga = gamma ? (double)gamma[c] : 1.0;
+        float* o = coef + ((int64_t)n * C + c) * 4;
+        o[0] = (float)(r * ga);
+        o[1] = (float)(r * s1 / cnt);
+        o[2] = (float)(r * r * s2 / cnt);
+        o[3] = (float)m;
+    }
+}
+
+// dgamma[c] = sum_{n,b} part[..][1], dbeta[c] = sum part[..][0]
+__global__ __launch_bounds__(256) void k_norm_bwd_affine(const float* __restrict__ part, int N, int nblk, int C,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < N * nblk; ++i) {
+        int64_t o = ((int64_t)i * C + c) * 2;
+        s1 += (double)part[o];
+        s2 += (double)part[o + 1];
+    }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict__ gy, int64_t gy_ld,
+                                                        const float* __restrict__ x, int64_t x_ld,
+                                                        float* __restrict__ gx, int64_t gx_ld, int64_t V, int C,
+                                                        const float* __restrict__ coef, int relu_mask) {
+    const int n = blockIdx.y;
+    const int cq = C / VEC;
+    const int64_t items = V * cq;
+    const float* gb = gy + (int64_t)n * V * gy_ld;
+    const float* xb = x + (int64_t)n * V * x_ld;
+    float* ob = gx + (int64_t)n * V * gx_ld;
+    const float* cf = coef + (int64_t)n * C * 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t dv = stride / cq;
+    const int dq = (int)(stride % cq);
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t v = i / cq;
+    int q = (int)(i % cq);
+    for (; i < items; i += stride, v += dv, q += dq) {
+        if (q >= cq) {
+            q -= cq;
+            ++v;
+        }
+        const int c0 = q * VEC;
+        if constexpr (VEC == 4) {
+            float4 g4 = *reinterpret_cast<const float4*>(gb + v * gy_ld + c0);
+            float4 x4 = *reinterpret_cast<const float4*>(xb + v * x_ld + c0);
+            float gv[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w}, ov[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 k = *reinterpret_cast<const float4*>(cf + (int64_t)(c0 + j) * 4);
+                float r = k.x * gv[j] - k.y - (xv[j] - k.w) * k.z;
+                ov[j] = (relu_mask && !(xv[j] > 0.f)) ? 0.f : r;
+            }
+            *reinterpret_cast<float4*>(ob + v * gx_ld + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        } else {
+            float gv = gb[v * gy_ld + c0], xv = xb[v * x_ld + c0];
+            float4 k = *reinterpret_cast<const float4*>(cf + (int64_t)c0 * 4);
+            float r = k.x * gv - k.y - (xv - k.w) * k.z;
+            ob[v * gx_ld + c0] = (relu_mask && !(xv > 0.f)) ? 0.f : r;
+        }
+    }
+}
+
+extern "C" int tem_norm_stats(const float* x, int64_t x_ld, int N, int64_t V, int C, int G, const float* gamma,
+                              const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                              void* ws, int64_t ws_bytes, tem_stream_t stream) {
+    TEM_REQUIRE(x && mean && rstd && scale && shift && ws, "tem_norm_stats: null pointer");
+    TEM_REQUIRE(N > 0 && V > 0 && C > 0 && C <= NORM_MAX_C && x_ld >= C, "tem_norm_stats: bad shape (C=%d)", C);
+    TEM_REQUIRE(G > 0 && C % G == 0, "tem_norm_stats: C=%d not divisible by G=%d", C, G);
+    if (ws_bytes < tem_norm_ws(N, V, C)) {
+        tem_set_error("tem_norm_stats: workspace too small");
+        return TEM_EWS;
+    }
+    NormGeom g = norm_geom(x, nullptr, x_ld, 0, V, C);
+    float* part = (float*)ws;
+    size_t lds = (size_t)g.rows * C * 2 * sizeof(float);
+    dim3 grid(g.nblk, N);
+    if (g.vec == 4)
+        hipLaunchKernelGGL((k_norm_partial<4, 0>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, nullptr,
+                           (int64_t)0, V, C, G, nullptr, nullptr, g.cq, g.rows, g.vper, part);
+    else
+        hipLaunchKernelGGL((k_norm_partial<1, 0>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, nullptr,
+                           (int64_t)0, V, C, G, nullptr, nullptr, g.cq, g.rows, g.vper, part);
+    hipLaunchKernelGGL(k_norm_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, g.nblk, V, C, G, gamma,
+                       beta, eps, mean, rstd, scale, shift);
+    TEM_CHECK_LAUNCH("tem_norm_stats");
+    return TEM_OK;
+}
+
+extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C,
+                            int G, const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx,
+                            int64_t gx_ld, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
+                            tem_stream_t stream) {
+    TEM_REQUIRE(gy && x && mean && rstd && gx && ws, "tem_norm_bwd: null pointer");
+    TEM_REQUIRE(N > 0 && V > 0 && C > 0 && C <= NORM_MAX_C && x_ld >= C && gy_ld >= C && gx_ld >= C,
+                "tem_norm_bwd: bad shape (C=%d)", C);
+    TEM_REQUIRE(G > 0 && C % G == 0, "tem_norm_bwd: C=%d not divisible by G=%d", C, G);
+    if (ws_bytes < tem_norm_ws(N, V, C)) {
+        tem_set_error("tem_norm_bwd: workspace too small");
+        return TEM_EWS;
+    }
+    NormGeom g = norm_geom(x, gy, x_ld, gy_ld, V, C);
+    float* part = (float*)ws;
+    float* coef = part + (int64_t)N * NORM_MAX_BLOCKS * C * 2;
+    size_t lds = (size_t)g.rows * C * 2 * sizeof(float);
+    dim3 grid(g.nblk, N);
+    if (g.vec == 4)
+        hipLaunchKernelGGL((k_norm_partial<4, 1>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, gy, gy_ld,
+                           V, C, G, mean, rstd, g.cq, g.rows, g.vper, part);
+    else
+        hipLaunchKernelGGL((k_norm_partial<1, 1>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, gy, gy_ld,
+                           V, C, G, mean, rstd, g.cq, g.rows, g.vper, part);
+    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, g.nblk, V, C, G,
+                       gamma, mean, rstd, coef);
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(k_norm_bwd_affine, dim3((unsigned)tem_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part,
+                           N, g.nblk, C, dgamma, dbeta);
+    bool v4 = (C % 4 == 0) && gy_ld % 4 == 0 && x_ld % 4 == 0 && gx_ld % 4 == 0 && (uintptr_t)gy % 16 == 0 &&
+              (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0;
+    int64_t items = V * (v4 ? C / 4 : C);
+    dim3 agrid(tem_grid_1d(items, 256, 2048), N);
+    if (v4)
+        hipLaunchKernelGGL((k_norm_bwd_apply<4>), agrid, dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x, x_ld, gx,
+                           gx_ld, V, C, coef, relu_mask);
+    else
+        hipLaunchKernelGGL((k_norm_bwd_apply<1>), agrid, dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x, x_ld, gx,
+                           gx_ld, V, C, coef, relu_mask);
+    TEM_CHECK_LAUNCH("tem_norm_bwd");
+    return TEM_OK;
+}

@@ -1,0 +1,317 @@
+// pool_upsample.hip -- nn.MaxPool3d(factor) and F.interpolate(trilinear, align_corners=False)
+// for NDHWC fp32 tensors (reference model/unet.py:300-302,645 and :455-458).
+// HBM-bound streaming kernels: one workgroup per output row (n, z, y), threads
+// sweep (x, channel-quad) so every access is a coalesced 16-byte vector.
+#include "tem_common.h"
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> {
+    typedef float4 type;
+};
+template <>
+struct VecT<1> {
+    typedef float type;
+};
+
+template <int VEC>
+__device__ __forceinline__ void ld_vec(const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void st_vec(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *p = v[0];
+    }
+}
+
+static inline bool vec4_ok(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+    if (C % 4) return false;
+    for (const void* p : ptrs)
+        if (p && ((uintptr_t)p % 16)) return false;
+    for (int64_t l : lds)
+        if (l % 4) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// max pool
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, int64_t x_ld, float* __restrict__ y,
+                                                     int64_t y_ld, int D, int H, int W, int C, int fz, int fy, int fx) {
+    const int Do = D / fz, Ho = H / fy, Wo = W / fx;
+    const int cq = C / VEC;
+    int row = blockIdx.x;  // (n, zo, yo)
+    const int yo = row % Ho;
+    row /= Ho;
+    const int zo = row % Do;
+    const int n = row / Do;
+    for (int i = threadIdx.x; i < Wo * cq; i += 256) {
+        const int xo = i / cq, c0 = (i % cq) * VEC;
+        float m[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
+        for (int dz = 0; dz < fz; ++dz)
+            for (int dy = 0; dy < fy; ++dy)
+                for (int dx = 0; dx < fx; ++dx) {
+                    int64_t v = (((int64_t)n * D + zo * fz + dz) * H + yo * fy + dy) * W + xo * fx + dx;
+                    float t[VEC];
+                    ld_vec<VEC>(x + v * x_ld + c0, t);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        if (t[j] > m[j] || t[j] != t[j]) m[j] = t[j];
+                }
+        int64_t vo = (((int64_t)n * Do + zo) * Ho + yo) * Wo + xo;
+        st_vec<VEC>(y + vo * y_ld + c0, m);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ gy, int64_t gy_ld,
+                                                     const float* __restrict__ x, int64_t x_ld,
+                                                     const float* __restrict__ gskip, int64_t gskip_ld, int relu_mask,
+                                                     float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
+                                                     int fz, int fy, int fx) {
+    const int Do = D / fz, Ho = H / fy, Wo = W / fx;
+    const int cq = C / VEC;
+    int row = blockIdx.x;
+    const int yo = row % Ho;
+    row /= Ho;
+    const int zo = row % Do;
+    const int n = row / Do;
+    for (int i = threadIdx.x; i < Wo * cq; i += 256) {
+        const int xo = i / cq, c0 = (i % cq) * VEC;
+        float m[VEC];
+        int am[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            m[j] = -INFINITY;
+            am[j] = 0;
+        }
+        int k = 0;
+        for (int dz = 0; dz < fz; ++dz)
+            for (int dy = 0; dy < fy; ++dy)
+                for (int dx = 0; dx < fx; ++dx, ++k) {
+                    int64_t v = (((int64_t)n * D + zo * fz + dz) * H + yo * fy + dy) * W + xo * fx + dx;
+                    float t[VEC];
+                    ld_vec<VEC>(x + v * x_ld + c0, t);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        if (t[j] > m[j] || t[j] != t[j]) {
+                            m[j] = t[j];
+                            am[j] = k;
+                        }
+                }
+        int64_t vo = (((int64_t)n * Do + zo) * Ho + yo) * Wo + xo;
+        float g[VEC];
+        ld_vec<VEC>(gy + vo * gy_ld + c0, g);
+        k = 0;
+        for (int dz = 0; dz < fz; ++dz)
+            for (int dy = 0; dy < fy; ++dy)
+                for (int dx = 0; dx < fx; ++dx, ++k) {
+                    int64_t v = (((int64_t)n * D + zo * fz + dz) * H + yo * fy + dy) * W + xo * fx + dx;
+                    float o[VEC];
+                    if (gskip) {
+                        ld_vec<VEC>(gskip + v * gskip_ld + c0, o);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+                    }
+                    float t[VEC];
+                    if (relu_mask) ld_vec<VEC>(x + v * x_ld + c0, t);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        if (am[j] == k) o[j] += g[j];
+                        if (relu_mask && !(t[j] > 0.f)) o[j] = 0.f;
+                    }
+                    st_vec<VEC>(gx + v * gx_ld + c0, o);
+                }
+    }
+}
+
+extern "C" int tem_maxpool3d_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W,
+                                 int C, int fz, int fy, int fx, tem_stream_t stream) {
+    TEM_REQUIRE(x && y && N > 0 && C > 0 && x_ld >= C && y_ld >= C, "tem_maxpool3d_fwd: bad arguments");
+    TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0 && D % fz == 0 && H % fy == 0 && W % fx == 0,
+                "tem_maxpool3d_fwd: shape (%d,%d,%d) not divisible by factors (%d,%d,%d)", D, H, W, fz, fy, fx);
+    int64_t rows = (int64_t)N * (D / fz) * (H / fy);
+    TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_fwd: too many rows");
+    if (vec4_ok(C, {x, y}, {x_ld, y_ld}))
+        hipLaunchKernelGGL((k_maxpool_fwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, x_ld, y, y_ld,
+                           D, H, W, C, fz, fy, fx);
+    else
+        hipLaunchKernelGGL((k_maxpool_fwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, x_ld, y, y_ld,
+                           D, H, W, C, fz, fy, fx);
+    TEM_CHECK_LAUNCH("tem_maxpool3d_fwd");
+    return TEM_OK;
+}
+
+extern "C" int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, const float* gskip,
+                                 int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H, int W,
+                                 int C, int fz, int fy, int fx, tem_stream_t stream) {
+    TEM_REQUIRE(gy && x && gx && N > 0 && C > 0 && x_ld >= C && gy_ld >= C && gx_ld >= C,
+                "tem_maxpool3d_bwd: bad arguments");
+    TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0 && D % fz == 0 && H % fy == 0 && W % fx == 0,
+                "tem_maxpool3d_bwd: shape (%d,%d,%d) not divisible by factors (%d,%d,%d)", D, H, W, fz, fy, fx);
+    int64_t rows = (int64_t)N * (D / fz) * (H / fy);
+    TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_bwd: too many rows");
+    if (vec4_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}))
+        hipLaunchKernelGGL((k_maxpool_bwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
+                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx);
+    else
+        hipLaunchKernelGGL((k_maxpool_bwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
+                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx);
+    TEM_CHECK_LAUNCH("tem_maxpool3d_bwd");
+    return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// linear upsampling, align_corners=False, integer factor f per axis.
+// ATen: src = (dst + 0.5) / f - 0.5, clamped at 0; i0 = floor(src); i1 = i0 + (i0 < in-1);
+// l1 = src - i0; l0 = 1 - l1   (area_pixel_compute_source_index)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lin_src(int o, int f, int in, int& i0, int& i1, float& l0, float& l1) {
+    float scale = 1.0f / (float)f;
+    float src = scale * ((float)o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_upsample_fwd(const float* __restrict__ x, int64_t x_ld, float* __restrict__ y,
+                                                      int64_t y_ld, int D, int H, int W, int C, int fz, int fy, int fx) {
+    const int Do = D * fz, Ho = H * fy, Wo = W * fx;
+    const int cq = C / VEC;
+    int row = blockIdx.x;  // (n, zo, yo)
+    const int yo = row % Ho;
+    row /= Ho;
+    const int zo = row % Do;
+    const int n = row / Do;
+    int z0, z1, y0, y1;
+    float lz0, lz1, ly0, ly1;
+    lin_src(zo, fz, D, z0, z1, lz0, lz1);
+    lin_src(yo, fy, H, y0, y1, ly0, ly1);
+    const int64_t r00 = (((int64_t)n * D + z0) * H + y0) * W, r01 = (((int64_t)n * D + z0) * H + y1) * W;
+    const int64_t r10 = (((int64_t)n * D + z1) * H + y0) * W, r11 = (((int64_t)n * D + z1) * H + y1) * W;
+    for (int i = threadIdx.x; i < Wo * cq; i += 256) {
+        const int xo = i / cq, c0 = (i % cq) * VEC;
+        int x0, x1;
+        float lx0, lx1;
+        lin_src(xo, fx, W, x0, x1, lx0, lx1);
+        float a[VEC], b[VEC], c[VEC], d[VEC], e[VEC], f[VEC], g[VEC], h[VEC], o[VEC];
+        ld_vec<VEC>(x + (r00 + x0) * x_ld + c0, a);
+        ld_vec<VEC>(x + (r00 + x1) * x_ld + c0, b);
+        ld_vec<VEC>(x + (r01 + x0) * x_ld + c0, c);
+        ld_vec<VEC>(x + (r01 + x1) * x_ld + c0, d);
+        ld_vec<VEC>(x + (r10 + x0) * x_ld + c0, e);
+        ld_vec<VEC>(x + (r10 + x1) * x_ld + c0, f);
+        ld_vec<VEC>(x + (r11 + x0) * x_ld + c0, g);
+        ld_vec<VEC>(x + (r11 + x1) * x_ld + c0, h);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            o[j] = lz0 * (ly0 * (lx0 * a[j] + lx1 * b[j]) + ly1 * (lx0 * c[j] + lx1 * d[j])) +
+                   lz1 * (ly0 * (lx0 * e[j] + lx1 * f[j]) + ly1 * (lx0 * g[j] + lx1 * h[j]));
+        int64_t vo = (((int64_t)n * Do + zo) * Ho + yo) * Wo + xo;
+        st_vec<VEC>(y + vo * y_ld + c0, o);
+    }
+}
+
+// weight with which output index o reads input index i along one axis
+__device__ __forceinline__ float lin_w(int o, int f, int in, int i) {
+    int i0, i1;
+    float l0, l1;
+    lin_src(o, f, in, i0, i1, l0, l1);
+    float w = 0.f;
+    if (i0 == i) w += l0;
+    if (i1 == i) w += l1;
+    return w;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ gy, int64_t gy_ld,
+                                                      float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
+                                                      int fz, int fy, int fx) {
+    const int Do = D * fz, Ho = H * fy, Wo = W * fx;
+    const int cq = C / VEC;
+    int row = blockIdx.x;  // (n, z, y) of the INPUT grid
+    const int yi = row % H;
+    row /= H;
+    const int zi = row % D;
+    const int n = row / D;
+    const int zlo = max(0, fz * zi - fz), zhi = min(Do - 1, fz * zi + 2 * fz - 1);
+    const int ylo = max(0, fy * yi - fy), yhi = min(Ho - 1, fy * yi + 2 * fy - 1);
+    for (int i = threadIdx.x; i < W * cq; i += 256) {
+        const int xi = i / cq, c0 = (i % cq) * VEC;
+        const int xlo = max(0, fx * xi - fx), xhi = min(Wo - 1, fx * xi + 2 * fx - 1);
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        for (int zo = zlo; zo <= zhi; ++zo) {
+            float wz = lin_w(zo, fz, D, zi);
+            if (wz == 0.f) continue;
+            for (int yo = ylo; yo <= yhi; ++yo) {
+                float wy = lin_w(yo, fy, H, yi);
+                if (wy == 0.f) continue;
+                const int64_t r = (((int64_t)n * Do + zo) * Ho + yo) * Wo;
+                for (int xo = xlo; xo <= xhi; ++xo) {
+                    float wx = lin_w(xo, fx, W, xi);
+                    if (wx == 0.f) continue;
+                    float t[VEC];
+                    ld_vec<VEC>(gy + (r + xo) * gy_ld + c0, t);
+                    const float w = wz * wy * wx;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(w, t[j], acc[j]);
+                }
+            }
+        }
+        int64_t v = (((int64_t)n * D + zi) * H + yi) * W + xi;
+        st_vec<VEC>(gx + v * gx_ld + c0, acc);
+    }
+}
+
+extern "C" int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C,
+                                int fz, int fy, int fx, tem_stream_t stream) {
+    TEM_REQUIRE(x && y && N > 0 && C > 0 && x_ld >= C && y_ld >= C && D > 0 && H > 0 && W > 0,
+                "tem_upsample_fwd: bad arguments");
+    TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0, "tem_upsample_fwd: bad factors");
+    int64_t rows = (int64_t)N * D * fz * H * fy;
+    TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_fwd: too many rows");
+    if (vec4_ok(C, {x, y}, {x_ld, y_ld}))
+        hipLaunchKernelGGL((k_upsample_fwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
+                           y_ld, D, H, W, C, fz, fy, fx);
+    else
+        hipLaunchKernelGGL((k_upsample_fwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
+                           y_ld, D, H, W, C, fz, fy, fx);
+    TEM_CHECK_LAUNCH("tem_upsample_fwd");
+    return TEM_OK;
+}
+
+extern "C" int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld, int N, int D, int H, int W,
+                                int C, int fz, int fy, int fx, tem_stream_t stream) {
+    TEM_REQUIRE(gy && gx && N > 0 && C > 0 && gy_ld >= C && gx_ld >= C && D > 0 && H > 0 && W > 0,
+                "tem_upsample_bwd: bad arguments");
+    TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0, "tem_upsample_bwd: bad factors");
+    int64_t rows = (int64_t)N * D * H;
+    TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_bwd: too many rows");
+    if (vec4_ok(C, {gy, gx}, {gy_ld, gx_ld}))
+        hipLaunchKernelGGL((k_upsample_bwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
+                           gx_ld, D, H, W, C, fz, fy, fx);
+    else
+        hipLaunchKernelGGL((k_upsample_bwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
+                           gx_ld, D, H, W, C, fz, fy, fx);
+    TEM_CHECK_LAUNCH("tem_upsample_bwd");
+    return TEM_OK;
+}

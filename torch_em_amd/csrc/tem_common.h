@@ -1,0 +1,60 @@
+// tem_common.h -- shared helpers for the gfx950 kernels of libtem_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tem_hip.h"
+
+void tem_set_error(const char* fmt, ...);
+
+#define TEM_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            tem_set_error(__VA_ARGS__);        \
+            return TEM_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+#define TEM_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            tem_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return TEM_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+static inline int64_t tem_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t tem_align_up(int64_t a, int64_t b) { return tem_cdiv(a, b) * b; }
+
+// Memory-bound kernels: cap the grid at ~8 blocks per CU and grid-stride the rest.
+static inline int tem_grid_1d(int64_t work_items, int block, int max_blocks = 256 * 8) {
+    int64_t g = tem_cdiv(work_items, block);
+    if (g > max_blocks) g = max_blocks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+#define TEM_WAVE 64
+
+__device__ __forceinline__ float tem_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double tem_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive logical ids
+// land on the same XCD (dispatch places block b on XCD b % 8), so neighbouring
+// tiles share that XCD's L2.  Speed only; any mapping is correct.
+__device__ __forceinline__ int tem_xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int q = nwg / nx, r = nwg % nx;
+    int xcd = bid % nx, idx = bid / nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,3 @@
+"""Losses of the MI355X path (reference torch_em/loss/__init__.py:4-11 lists the public names)."""
+from .dice import DiceLoss, dice_score, flatten_samples
+from .wrapper import ApplyAndRemoveMask, ApplyMask, LossWrapper, MaskIgnoreLabel

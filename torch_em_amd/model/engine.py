@@ -1,0 +1,372 @@
+"""Forward/backward engine of the MI355X U-Net path.
+
+One `torch.autograd.Function` (`UNetFunction`) spans the whole network.  Its forward mirrors
+the data flow of the reference (`UNetBase._apply_default`, model/unet.py:194-209; `Encoder.forward`
+:311-321; `Decoder.forward` :375-388; `ConvBlock` :429-438; `Upsampler.forward` :455-458) and its
+hand-written backward replaces what autograd derives for those modules -- but both are
+sequenced MI355X-first:
+
+* activations are channels-last (NDHWC) fp32 in HBM, allocated once per step; torch is used
+  for memory, streams and the autograd hook only, every FLOP runs in libtem_hip.so;
+* pre-norm is never materialised: `norm_stats` emits per-(n,c) scale/shift and the conv kernel
+  applies them while staging its input tile (zero padding AFTER the norm, as in the reference);
+* bias + ReLU live in the conv epilogue; ReLU-backward masks live in the dgrad epilogue, the
+  norm-backward apply kernel or the max-pool-backward kernel (never a pass of their own);
+* skip concatenation is free: the encoder block writes its output into the upper channel half of
+  a [.., Cup+Cskip] buffer, the decoder's upsampler writes the lower half (leading dimension `ld`);
+* Upsampler = interpolate -> 1x1 conv in the reference; both are linear and the interpolation
+  weights sum to one, so the engine runs the 1x1 conv first (1/8 of the voxels) and interpolates
+  its output.  Results differ from the reference order only by fp32 rounding (tests: 1e-4);
+* parameter gradients are written into ONE flat fp32 arena per step (views are returned to
+  autograd), so the optimizer step and the data-parallel all-reduce are single launches.
+"""
+import os
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+_FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
+
+
+def _k3(k):
+    k = tuple(int(v) for v in k)
+    return (1,) * (3 - len(k)) + k
+
+
+def _f3(f, dim):
+    if isinstance(f, int):
+        f = (f,) * dim
+    f = tuple(int(v) for v in f)
+    return (1,) * (3 - len(f)) + f
+
+
+class ConvSpec:
+    """A conv layer of the reference model plus the norm that precedes it (both parameter holders)."""
+
+    def __init__(self, conv: nn.Module, norm: Optional[nn.Module]):
+        self.conv, self.norm = conv, norm
+        self.k = _k3(conv.kernel_size)
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+
+    # --- norm description -------------------------------------------------------
+    def norm_args(self):
+        """(groups, gamma, beta, eps) or None"""
+        n = self.norm
+        if n is None:
+            return None
+        if isinstance(n, nn.GroupNorm):
+            return n.num_groups, n.weight, n.bias, n.eps
+        # InstanceNorm == one group per channel; affine=False by default in the reference
+        return self.cin, getattr(n, "weight", None), getattr(n, "bias", None), n.eps
+
+    # --- packed weights (cached until the parameter changes) -----------------------
+    def packed(self):
+        w = self.conv.weight
+        ent = getattr(self.conv, "_tem_pack", None)
+        if ent is None or ent["version"] != w._version or ent["ptr"] != w.data_ptr():
+            mf = (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k)
+            md = (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k)
+            mw = (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k, wgrad=True)
+            ent = {
+                "version": w._version, "ptr": w.data_ptr(),
+                "fwd": ops.pack_weights(w, transpose=False, mfma=mf), "fwd_mfma": mf,
+                "dgrad": ops.pack_weights(w, transpose=True, mfma=md), "dgrad_mfma": md,
+                "wgrad_mfma": mw,
+            }
+            object.__setattr__(self.conv, "_tem_pack", ent)
+        return ent
+
+
+def fused_activation(act: nn.Module) -> Optional[str]:
+    """Final activations that run inside the out_conv epilogue."""
+    if isinstance(act, nn.Sigmoid):
+        return "sigmoid"
+    if isinstance(act, nn.ReLU):
+        return "relu"
+    return None
+
+
+# -----------------------------------------------------------------------------------
+# building blocks
+# -----------------------------------------------------------------------------------
+def _conv(spec: ConvSpec, x, y, stats=None, act=None):
+    ent = spec.packed()
+    scale, shift = (stats[2], stats[3]) if stats is not None else (None, None)
+    ops.conv_fwd(x, ent["fwd"], spec.conv.bias, y, spec.k, spec.cin, spec.cout, scale=scale, shift=shift, act=act,
+                 mfma=ent["fwd_mfma"])
+
+
+def _dgrad(spec: ConvSpec, g, gx, ref=None):
+    ent = spec.packed()
+    ops.conv_fwd(g, ent["dgrad"], None, gx, spec.k, spec.cout, spec.cin, ref=ref, mfma=ent["dgrad_mfma"])
+
+
+class _Grads:
+    """Flat fp32 gradient arena; one view per parameter, in `model.parameters()` order."""
+
+    def __init__(self, params: List[torch.Tensor]):
+        total, self.offsets = 0, {}
+        for p in params:
+            self.offsets[id(p)] = (total, p.numel(), p.shape)
+            total += (p.numel() + 3) // 4 * 4  # keep every view 16-byte aligned
+        self.flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        self.written = set()
+
+    def view(self, p: torch.Tensor) -> torch.Tensor:
+        o, n, shape = self.offsets[id(p)]
+        self.written.add(id(p))
+        return self.flat[o:o + n].view(shape)
+
+
+def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None):
+    ent = spec.packed()
+    scale, shift = (stats[2], stats[3]) if stats is not None else (None, None)
+    dw = grads.view(spec.conv.weight)
+    db = grads.view(spec.conv.bias) if spec.conv.bias is not None else None
+    ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
+
+
+def _stats(spec: ConvSpec, x):
+    na = spec.norm_args()
+    if na is None:
+        return None
+    groups, gamma, beta, eps = na
+    return ops.norm_stats(x, groups, gamma, beta, eps)
+
+
+def _block_fwd(blk, xin, out):
+    """ConvBlock (reference model/unet.py:429-438): [norm->conv->ReLU] x 2.  Returns what backward needs."""
+    c1, c2 = blk.conv_specs()
+    N, D, H, W, _ = xin.shape
+    s1 = _stats(c1, xin)
+    a1 = ops.new_act(N, D, H, W, c1.cout, xin.device)
+    _conv(c1, xin, a1, s1, act="relu")
+    s2 = _stats(c2, a1)
+    _conv(c2, a1, out, s2, act="relu")
+    return {"xin": xin, "a1": a1, "out": out, "s1": s1, "s2": s2, "c1": c1, "c2": c2}
+
+
+def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads):
+    groups, gamma, beta, _ = spec.norm_args()
+    dgamma = grads.view(gamma) if gamma is not None else None
+    dbeta = grads.view(beta) if beta is not None else None
+    ops.norm_bwd(g, x, groups, gamma, stats[0], stats[1], relu_mask, g, dgamma, dbeta)
+
+
+def _block_bwd(bs, gout, gin, grads: _Grads):
+    """gout: gradient w.r.t. the block's pre-ReLU conv2 output (i.e. already ReLU-masked).
+    gin: buffer for the gradient w.r.t. the block input, or None when not needed."""
+    c1, c2, xin, a1 = bs["c1"], bs["c2"], bs["xin"], bs["a1"]
+    _wgrad(c2, a1, gout, grads, bs["s2"])
+    ga1 = torch.empty_like(a1)
+    if bs["s2"] is not None:
+        _dgrad(c2, gout, ga1)
+        _norm_bwd_inplace(c2, ga1, a1, bs["s2"], True, grads)  # a1 is a ReLU output: mask fused
+    else:
+        _dgrad(c2, gout, ga1, ref=a1)
+    _wgrad(c1, xin, ga1, grads, bs["s1"])
+    affine1 = bs["s1"] is not None and c1.norm_args()[1] is not None
+    if gin is None and not affine1:
+        return
+    if gin is None:
+        N, D, H, W, _ = xin.shape
+        gin = ops.new_act(N, D, H, W, c1.cin, xin.device)
+    _dgrad(c1, ga1, gin)
+    if bs["s1"] is not None:
+        _norm_bwd_inplace(c1, gin, xin, bs["s1"], False, grads)
+
+
+# -----------------------------------------------------------------------------------
+# whole network
+# -----------------------------------------------------------------------------------
+def _dim_of(model) -> int:
+    conv = model.encoder.blocks[0].block[1] if model.encoder.blocks[0].norm is not None else \
+        model.encoder.blocks[0].block[0]
+    return 2 if isinstance(conv, nn.Conv2d) else 3
+
+
+def _forward_impl(model, x: torch.Tensor, keep: bool):
+    dim = _dim_of(model)
+    if x.dim() != dim + 2:
+        raise ValueError(f"expected a {dim + 2}-D input [N, C, *spatial], got shape {tuple(x.shape)}")
+    if x.shape[1] != model.in_channels:
+        raise ValueError(f"expected {model.in_channels} input channels, got {x.shape[1]}")
+    enc, dec = model.encoder, model.decoder
+    depth = len(enc)
+    xin = ops.nchw_to_nhwc(x.float())
+    N = xin.shape[0]
+    dev = xin.device
+    st = {"levels": [], "dim": dim, "x_shape": tuple(x.shape)}
+    cur = xin
+    for l in range(depth):
+        blk = enc.blocks[l]
+        f = _f3(enc.scale_factors[l], dim)
+        c_up = dec.samplers[depth - 1 - l].conv.out_channels
+        _, D, H, W, _ = cur.shape
+        if D % f[0] or H % f[1] or W % f[2]:
+            raise ValueError(f"Invalid shape for U-Net: {(D, H, W)[3 - dim:]} is not divisible by {f[3 - dim:]}")
+        cat = ops.new_act(N, D, H, W, c_up + blk.out_channels, dev)
+        skip = cat[..., c_up:]
+        bs = _block_fwd(blk, cur, skip)
+        pooled = ops.new_act(N, D // f[0], H // f[1], W // f[2], blk.out_channels, dev)
+        ops.maxpool_fwd(skip, pooled, f)
+        st["levels"].append({"cat": cat, "skip": skip, "bs": bs, "f": f, "c_up": c_up})
+        cur = pooled
+    _, D, H, W, _ = cur.shape
+    base_out = ops.new_act(N, D, H, W, model.base.out_channels, dev)
+    st["base"] = _block_fwd(model.base, cur, base_out)
+    cur = base_out
+    st["dec"] = []
+    for i in range(depth):
+        lv = st["levels"][depth - 1 - i]
+        sampler, blk = dec.samplers[i], dec.blocks[i]
+        f = _f3(dec.scale_factors[i], dim)
+        if f != lv["f"]:
+            raise ValueError("decoder scale factors must mirror the encoder's")
+        sspec = ConvSpec(sampler.conv, None)
+        _, d, h, w, _ = cur.shape
+        t = ops.new_act(N, d, h, w, sspec.cout, dev)
+        _conv(sspec, cur, t)                       # 1x1 conv at low resolution ...
+        cat = lv["cat"]
+        if (d * f[0], h * f[1], w * f[2]) != tuple(cat.shape[1:4]):
+            raise NotImplementedError("skip connections that need cropping are not supported")
+        ops.upsample_fwd(t, cat[..., :lv["c_up"]], f)  # ... interpolated straight into the concat buffer
+        out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev)
+        bs = _block_fwd(blk, cat, out)
+        st["dec"].append({"low": cur, "sspec": sspec, "bs": bs, "f": f})
+        cur = out
+    st["last"] = cur
+    act = fused_activation(model.final_activation) if model.final_activation is not None else None
+    st["act"] = act
+    if model.out_conv is not None:
+        ospec = ConvSpec(model.out_conv, None)
+        y = ops.new_act(N, cur.shape[1], cur.shape[2], cur.shape[3], ospec.cout, dev)
+        _conv(ospec, cur, y, act=act)
+        st["ospec"] = ospec
+    else:
+        y = cur
+        if act == "sigmoid":
+            raise NotImplementedError("final Sigmoid without out_conv is not supported")
+    st["y"] = y
+    return y, (st if keep else None)
+
+
+def _to_logical(y5: torch.Tensor, dim: int) -> torch.Tensor:
+    """NDHWC buffer -> logical [N, C, *spatial] view (channels_last memory format, no copy)."""
+    y = y5.permute(0, 4, 1, 2, 3)
+    return y[:, :, 0] if dim == 2 else y
+
+
+def _from_logical(g: torch.Tensor, dim: int) -> torch.Tensor:
+    """logical [N, C, *spatial] gradient -> contiguous NDHWC buffer (free if it already is one)."""
+    if dim == 2:
+        g = g.unsqueeze(2)
+    g5 = g.permute(0, 2, 3, 4, 1)
+    if g5.is_contiguous():
+        return g5
+    return ops.nchw_to_nhwc(g.contiguous())
+
+
+def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need_input_grad: bool):
+    dim = st["dim"]
+    depth = len(st["levels"])
+    grads = _Grads(params)
+    g = _from_logical(gy.float(), dim)
+    y = st["y"]
+    if st["act"] is not None:
+        g = ops.act_bwd(g, y, st["act"])
+    last = st["last"]
+    if "ospec" in st:
+        _wgrad(st["ospec"], last, g, grads)
+        g_cur = torch.empty_like(last)
+        _dgrad(st["ospec"], g, g_cur, ref=last)
+    else:
+        g_cur = torch.empty_like(last)
+        ops.maxpool_bwd(g, last, g_cur, (1, 1, 1), relu_mask=True)
+    for i in reversed(range(depth)):
+        d = st["dec"][i]
+        lv = st["levels"][depth - 1 - i]
+        g_cat = torch.empty_like(lv["cat"])
+        _block_bwd(d["bs"], g_cur, g_cat, grads)
+        low, sspec = d["low"], d["sspec"]
+        g_t = ops.new_act(low.shape[0], low.shape[1], low.shape[2], low.shape[3], sspec.cout, low.device)
+        ops.upsample_bwd(g_cat[..., :lv["c_up"]], g_t, d["f"])
+        _wgrad(sspec, low, g_t, grads)
+        g_low = torch.empty_like(low)
+        _dgrad(sspec, g_t, g_low, ref=low)  # `low` is the ReLU output of the previous block
+        lv["g_skip"] = g_cat[..., lv["c_up"]:]
+        g_cur = g_low
+    bb = st["base"]
+    g_pooled = torch.empty_like(bb["xin"])
+    _block_bwd(bb, g_cur, g_pooled, grads)
+    g_cur = g_pooled
+    for l in reversed(range(depth)):
+        lv = st["levels"][l]
+        skip = lv["skip"]
+        g_skip_full = ops.new_act(skip.shape[0], skip.shape[1], skip.shape[2], skip.shape[3], skip.shape[4],
+                                  skip.device)
+        ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True)
+        need_in = (l > 0) or need_input_grad
+        xin = lv["bs"]["xin"]
+        g_in = torch.empty_like(xin) if need_in else None
+        _block_bwd(lv["bs"], g_skip_full, g_in, grads)
+        g_cur = g_in
+    gx = None
+    if need_input_grad:
+        gx = ops.nhwc_to_nchw(g_cur)
+        if dim == 2:
+            gx = gx[:, :, 0]
+    return gx, grads
+
+
+class UNetFunction(torch.autograd.Function):
+    """y = UNet(x; params) as a single autograd node (see the module docstring)."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        need_grad = any(ctx.needs_input_grad[1:])
+        y5, st = _forward_impl(model, x, keep=need_grad)
+        ctx.model, ctx.st, ctx.nparams = model, st, len(params)
+        ctx.params = list(params)
+        return _to_logical(y5, _dim_of(model))
+
+    @staticmethod
+    def backward(ctx, gy):
+        st = ctx.st
+        if st is None:
+            raise RuntimeError("UNetFunction.backward called twice (activations were released)")
+        gx, grads = _backward_impl(ctx.model, st, gy, ctx.params, ctx.needs_input_grad[1])
+        ctx.st = None  # release activations
+        out = [None, gx]
+        for i, p in enumerate(ctx.params):
+            if ctx.needs_input_grad[2 + i]:
+                out.append(grads.view(p) if id(p) in grads.written else torch.zeros_like(p))
+            else:
+                out.append(None)
+        hook = getattr(ctx.model, "_tem_grad_hook", None)
+        if hook is not None:
+            hook(grads)
+        return tuple(out)
+
+
+def unet_forward(model, x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError(
+            "torch_em_amd.model runs on MI355X only (input is a CPU tensor). There is no CPU fallback for this "
+            "path; move model and data to 'cuda' or use the reference torch_em on CPU."
+        )
+    params = [p for p in model.parameters()]
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        return UNetFunction.apply(model, x, *params)
+    y5, _ = _forward_impl(model, x, keep=False)
+    return _to_logical(y5, _dim_of(model))
+
+
+def run_single_block(block, x):
+    raise NotImplementedError(
+        "ConvBlock modules of torch_em_amd are parameter containers driven by the U-Net engine; "
+        "stand-alone calls are not supported"
+    )

@@ -1,0 +1,406 @@
+"""Tensor-level wrappers over the C-ABI (include/tem_hip.h).
+
+Every function takes torch CUDA tensors only to obtain device pointers, strides and the
+current HIP stream -- all arithmetic happens in libtem_hip.so.  Activations are 5-D
+channels-last views `t[N, D, H, W, C]` with `t.stride(4) == 1`; `t.stride(3)` (the leading
+dimension `ld`) may exceed C so that a tensor can be a channel slice of a concat buffer.
+There is no CPU fallback: CPU tensors raise.
+"""
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2}
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "torch_em_amd ops run on MI355X only (got a CPU tensor); there is no CPU fallback for this path"
+            )
+
+
+def _act5(t: torch.Tensor) -> Tuple[int, int, int, int, int, int]:
+    """(N, D, H, W, C, ld) of a channels-last 5-D view; validates the stride contract:
+    element (n,z,y,x,c) at (((n*D+z)*H+y)*W+x)*ld + c."""
+    if t.dim() != 5:
+        raise ValueError(f"expected a 5-D NDHWC tensor, got shape {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        raise ValueError(f"expected float32, got {t.dtype}")
+    N, D, H, W, C = t.shape
+    s = t.stride()
+    sizes = (N, D, H, W)
+    inner = [1, 1, 1, 1]  # voxels spanned by one step along each dim
+    for k in (2, 1, 0):
+        inner[k] = inner[k + 1] * sizes[k + 1]
+    ld = None
+    for k in (3, 2, 1, 0):
+        if sizes[k] > 1:
+            if s[k] % inner[k]:
+                raise ValueError(f"tensor is not a channels-last NDHWC view: shape {tuple(t.shape)}, strides {s}")
+            ld = s[k] // inner[k]
+            break
+    if ld is None:
+        ld = C
+    ok = (C == 1 or s[4] == 1) and ld >= C
+    for k in range(4):
+        if sizes[k] > 1 and s[k] != ld * inner[k]:
+            ok = False
+    if not ok:
+        raise ValueError(f"tensor is not a channels-last NDHWC view: shape {tuple(t.shape)}, strides {s}")
+    return N, D, H, W, C, ld
+
+
+def new_act(N, D, H, W, C, device) -> torch.Tensor:
+    return torch.empty((N, D, H, W, C), dtype=torch.float32, device=device)
+
+
+# ---------------------------------------------------------------- layout ----
+def nchw_to_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[N, C, *spatial] contiguous -> NDHWC (spatial may be 2-D or 3-D; 2-D gets D == 1)."""
+    _req_cuda(x)
+    x = x.contiguous()
+    N, C = x.shape[:2]
+    sp = tuple(x.shape[2:])
+    D, H, W = (1,) * (3 - len(sp)) + sp
+    if C == 1 and out is None:
+        return x.reshape(N, D, H, W, 1)
+    if out is None:
+        out = new_act(N, D, H, W, C, x.device)
+    _, _, _, _, _, ld = _act5(out)
+    lib = _lib.load()
+    _lib.check(lib.tem_nchw_to_nhwc(_p(x), _p(out), ld, N, C, D * H * W, _stream(x)), "tem_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _req_cuda(x)
+    N, D, H, W, C, ld = _act5(x)
+    out = torch.empty((N, C, D, H, W), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.tem_nhwc_to_nchw(_p(x), ld, _p(out), N, C, D * H * W, _stream(x)), "tem_nhwc_to_nchw")
+    return out
+
+
+# ------------------------------------------------------------------ conv ----
+def mfma_ok(cin: int, cout: int, k: Sequence[int], wgrad: bool = False) -> bool:
+    key = tuple(int(v) for v in k)
+    if key not in ((3, 3, 3), (1, 3, 3), (1, 1, 1)):
+        return False
+    if wgrad:
+        return cin % 32 == 0 and cout % 32 == 0
+    return cin % 16 == 0 and cout % 32 == 0
+
+
+def pack_weights(w: torch.Tensor, transpose: bool, mfma: bool) -> torch.Tensor:
+    """state_dict layout [Cout, Cin, (kd,) kh, kw] -> kernel layout (see tem_hip.h)."""
+    _req_cuda(w)
+    w = w.detach().contiguous()
+    cout, cin = w.shape[:2]
+    k = tuple(w.shape[2:])
+    k = (1,) * (3 - len(k)) + k
+    dst = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    lib = _lib.load()
+    _lib.check(lib.tem_conv_pack_weights(_p(w), _p(dst), cout, cin, k[0], k[1], k[2], int(transpose),
+                                         1 if mfma else 0, _stream(w)), "tem_conv_pack_weights")
+    return dst
+
+
+def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=None, ref=None, mfma=False):
+    _req_cuda(x, w_packed, y)
+    N, D, H, W, C, x_ld = _act5(x)
+    Ny, Dy, Hy, Wy, Cy, y_ld = _act5(y)
+    if C != cin or Cy != cout or (N, D, H, W) != (Ny, Dy, Hy, Wy):
+        raise ValueError(f"conv_fwd: shape mismatch x{tuple(x.shape)} y{tuple(y.shape)} cin={cin} cout={cout}")
+    ref_ld = 0
+    if ref is not None:
+        ref_ld = _act5(ref)[5]
+    lib = _lib.load()
+    _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
+                                  ref_ld, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma), _stream(x)),
+               "tem_conv3d_fwd")
+    return y
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """A per-device scratch buffer (grown on demand, reused across calls on the same stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, mfma=False):
+    """dw_out: flat [ntaps*cin*cout] in the reference's [Cout,Cin,kd,kh,kw] order; db_out: [cout]."""
+    _req_cuda(x, g, dw_out)
+    N, D, H, W, C, x_ld = _act5(x)
+    _, _, _, _, Cg, g_ld = _act5(g)
+    if C != cin or Cg != cout:
+        raise ValueError("conv_wgrad: channel mismatch")
+    lib = _lib.load()
+    nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma))
+    ntaps = k[0] * k[1] * k[2]
+    tmp_bytes = ntaps * cin * cout * 4
+    ws = _workspace(nws + tmp_bytes + 256, x.device)
+    tmp_ptr = ws.data_ptr()
+    ws_ptr = tmp_ptr + ((tmp_bytes + 255) // 256) * 256
+    _lib.check(lib.tem_conv3d_wgrad(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, ctypes.c_void_p(tmp_ptr),
+                                    _p(db_out), ctypes.c_void_p(ws_ptr), nws, N, D, H, W, cin, cout, k[0], k[1], k[2],
+                                    int(mfma), _stream(x)), "tem_conv3d_wgrad")
+    _lib.check(lib.tem_conv_unpack_wgrad(ctypes.c_void_p(tmp_ptr), _p(dw_out), cout, cin, k[0], k[1], k[2],
+                                         _stream(x)), "tem_conv_unpack_wgrad")
+    return dw_out
+
+
+# ------------------------------------------------------------------ norm ----
+def norm_stats(x, groups: int, gamma=None, beta=None, eps: float = 1e-5):
+    """-> (mean[N,G], rstd[N,G], scale[N,C], shift[N,C])"""
+    _req_cuda(x)
+    N, D, H, W, C, ld = _act5(x)
+    dev = x.device
+    mean = torch.empty((N, groups), dtype=torch.float32, device=dev)
+    rstd = torch.empty((N, groups), dtype=torch.float32, device=dev)
+    scale = torch.empty((N, C), dtype=torch.float32, device=dev)
+    shift = torch.empty((N, C), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    V = D * H * W
+    nws = lib.tem_norm_ws(N, V, C)
+    ws = _workspace(nws, dev)
+    _lib.check(lib.tem_norm_stats(_p(x), ld, N, V, C, groups, _p(gamma), _p(beta), eps, _p(mean), _p(rstd), _p(scale),
+                                  _p(shift), _p(ws), nws, _stream(x)), "tem_norm_stats")
+    return mean, rstd, scale, shift
+
+
+def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None, dbeta=None):
+    _req_cuda(gy, x, gx)
+    N, D, H, W, C, x_ld = _act5(x)
+    gy_ld = _act5(gy)[5]
+    gx_ld = _act5(gx)[5]
+    lib = _lib.load()
+    V = D * H * W
+    nws = lib.tem_norm_ws(N, V, C)
+    ws = _workspace(nws, x.device)
+    _lib.check(lib.tem_norm_bwd(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd),
+                                int(relu_mask), _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(ws), nws, _stream(x)),
+               "tem_norm_bwd")
+    return gx
+
+
+# --------------------------------------------------------- pool / upsample ----
+def maxpool_fwd(x, y, f):
+    _req_cuda(x, y)
+    N, D, H, W, C, x_ld = _act5(x)
+    y_ld = _act5(y)[5]
+    lib = _lib.load()
+    _lib.check(lib.tem_maxpool3d_fwd(_p(x), x_ld, _p(y), y_ld, N, D, H, W, C, f[0], f[1], f[2], _stream(x)),
+               "tem_maxpool3d_fwd")
+    return y
+
+
+def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False):
+    _req_cuda(gy, x, gx)
+    N, D, H, W, C, x_ld = _act5(x)
+    gy_ld = _act5(gy)[5]
+    gx_ld = _act5(gx)[5]
+    gs_ld = _act5(gskip)[5] if gskip is not None else 0
+    lib = _lib.load()
+    _lib.check(lib.tem_maxpool3d_bwd(_p(gy), gy_ld, _p(x), x_ld, _p(gskip), gs_ld, int(relu_mask), _p(gx), gx_ld,
+                                     N, D, H, W, C, f[0], f[1], f[2], _stream(x)), "tem_maxpool3d_bwd")
+    return gx
+
+
+def upsample_fwd(x, y, f):
+    _req_cuda(x, y)
+    N, D, H, W, C, x_ld = _act5(x)
+    y_ld = _act5(y)[5]
+    lib = _lib.load()
+    _lib.check(lib.tem_upsample_fwd(_p(x), x_ld, _p(y), y_ld, N, D, H, W, C, f[0], f[1], f[2], _stream(x)),
+               "tem_upsample_fwd")
+    return y
+
+
+def upsample_bwd(gy, gx, f):
+    """gx has the low-resolution shape; gy = gx's shape scaled by f."""
+    _req_cuda(gy, gx)
+    N, D, H, W, C, gx_ld = _act5(gx)
+    gy_ld = _act5(gy)[5]
+    lib = _lib.load()
+    _lib.check(lib.tem_upsample_bwd(_p(gy), gy_ld, _p(gx), gx_ld, N, D, H, W, C, f[0], f[1], f[2], _stream(gx)),
+               "tem_upsample_bwd")
+    return gx
+
+
+def act_bwd(gy, y, act: str):
+    _req_cuda(gy, y)
+    gy = gy.contiguous()
+    y = y.contiguous()
+    gx = torch.empty_like(gy)
+    lib = _lib.load()
+    _lib.check(lib.tem_act_bwd(_p(gy), _p(y), _p(gx), gy.numel(), ACT[act], _stream(gy)), "tem_act_bwd")
+    return gx
+
+
+# ------------------------------------------------------------------ dice ----
+def _ncv_strides(t: torch.Tensor):
+    """(sn, sc, sv, N, C, V) for a logical [N, C, *spatial] tensor whose spatial dims are
+    jointly contiguous up to a common voxel stride; returns None if not expressible."""
+    N, C = t.shape[:2]
+    sp = tuple(t.shape[2:])
+    V = 1
+    for s in sp:
+        V *= s
+    st = t.stride()
+    sv = st[-1] if len(sp) > 0 else 1
+    # check spatial dims collapse to a single stride sv
+    expect = sv
+    for d in range(len(sp) - 1, -1, -1):
+        if sp[d] != 1 and st[2 + d] != expect:
+            return None
+        expect *= sp[d]
+    return st[0], st[1], sv, N, C, V
+
+
+def dice_sums(p, t, mask=None) -> torch.Tensor:
+    """-> double[C, 3] = (sum p*t, sum p*p, sum t*t) with optional multiplicative mask."""
+    _req_cuda(p, t)
+    ps = _ncv_strides(p)
+    if ps is None:
+        p = p.contiguous()
+        ps = _ncv_strides(p)
+    ts = _ncv_strides(t)
+    if ts is None:
+        t = t.contiguous()
+        ts = _ncv_strides(t)
+    if mask is not None:
+        ms = _ncv_strides(mask)
+        if ms is None or ms[:3] != ts[:3]:
+            raise ValueError("dice: mask must share the target's strides")
+    N, C, V = ps[3:]
+    sums = torch.empty((C, 3), dtype=torch.float64, device=p.device)
+    lib = _lib.load()
+    nws = lib.tem_dice_ws(N, V, C)
+    ws = _workspace(nws, p.device)
+    _lib.check(lib.tem_dice_sums(_p(p), ps[0], ps[1], ps[2], _p(t), ts[0], ts[1], ts[2], _p(mask), N, C, V,
+                                 _p(sums), _p(ws), nws, _stream(p)), "tem_dice_sums")
+    return sums, p, t
+
+
+REDUCE = {None: 0, "sum": 1, "mean": 2, "max": 3, "min": 4}
+
+
+def dice_finalize(sums, eps, channelwise, invert, reduce):
+    C = sums.shape[0]
+    dev = sums.device
+    n_out = C if (channelwise and reduce is None) else 1
+    out = torch.empty((n_out,), dtype=torch.float32, device=dev)
+    ca = torch.empty((C,), dtype=torch.float32, device=dev)
+    cb = torch.empty((C,), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.tem_dice_finalize(_p(sums), C, float(eps), int(channelwise), int(invert), REDUCE[reduce], _p(out),
+                                     _p(ca), _p(cb), _stream(sums)), "tem_dice_finalize")
+    return out, ca, cb
+
+
+def dice_grad(p, t, mask, ca, cb, gout, gout_per_channel, channels_last: bool):
+    """d out / d p, laid out like p (channels_last_3d memory format when p has it)."""
+    ps = _ncv_strides(p)
+    ts = _ncv_strides(t)
+    N, C, V = ps[3:]
+    if channels_last:
+        # physical [N, V, C]
+        gp_phys = torch.empty((N,) + tuple(p.shape[2:]) + (C,), dtype=torch.float32, device=p.device)
+        gp = gp_phys.permute(0, gp_phys.dim() - 1, *range(1, gp_phys.dim() - 1))
+        gs = (V * C, 1, C)
+    else:
+        gp = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+        gs = (C * V, V, 1)
+    lib = _lib.load()
+    _lib.check(lib.tem_dice_grad(_p(p), ps[0], ps[1], ps[2], _p(t), ts[0], ts[1], ts[2], _p(mask), _p(ca), _p(cb),
+                                 _p(gout), int(gout_per_channel), _p(gp), gs[0], gs[1], gs[2], N, C, V, _stream(p)),
+               "tem_dice_grad")
+    return gp
+
+
+# ------------------------------------------------------------- optimizer ----
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _req_cuda(param, grad, exp_avg, exp_avg_sq)
+    lib = _lib.load()
+    _lib.check(lib.tem_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2,
+                                  eps, weight_decay, int(step), grad_scale, _stream(param)), "tem_adamw_step")
+
+
+def ema_update(theta_k, theta_q, momentum):
+    _req_cuda(theta_k, theta_q)
+    lib = _lib.load()
+    _lib.check(lib.tem_ema_update(_p(theta_k), _p(theta_q), theta_k.numel(), momentum, _stream(theta_k)),
+               "tem_ema_update")
+
+
+# ---------------------------------------------------------------- labels ----
+def boundary_target(labels: torch.Tensor, add_binary_target: bool) -> torch.Tensor:
+    _req_cuda(labels)
+    labels = labels.to(torch.int64).contiguous()
+    sp = tuple(labels.shape)
+    D, H, W = (1,) * (3 - len(sp)) + sp
+    nch = 2 if add_binary_target else 1
+    out = torch.empty((nch,) + sp, dtype=torch.float32, device=labels.device)
+    lib = _lib.load()
+    _lib.check(lib.tem_boundary_target(_p(labels), _p(out), D, H, W, int(add_binary_target), _stream(labels)),
+               "tem_boundary_target")
+    return out
+
+
+def affinity_target(labels, offsets, ignore_label=None, add_binary_target=False, add_mask=False,
+                    include_ignore_transitions=False) -> torch.Tensor:
+    _req_cuda(labels)
+    labels = labels.to(torch.int64).contiguous()
+    sp = tuple(labels.shape)
+    nd = len(sp)
+    D, H, W = (1,) * (3 - nd) + sp
+    offs = []
+    for o in offsets:
+        o = [int(v) for v in o]
+        if len(o) != nd:
+            raise ValueError("offset dimensionality does not match the labels")
+        offs.extend([0] * (3 - nd) + o)
+    n_off = len(offsets)
+    arr = (ctypes.c_int * len(offs))(*offs)
+    cb = 1 if add_binary_target else 0
+    nch = (n_off + cb) * (2 if add_mask else 1)
+    out = torch.empty((nch,) + sp, dtype=torch.float32, device=labels.device)
+    lib = _lib.load()
+    _lib.check(lib.tem_affinity_target(_p(labels), _p(out), D, H, W, arr, n_off, int(ignore_label is not None),
+                                       int(ignore_label or 0), int(add_binary_target), int(add_mask),
+                                       int(include_ignore_transitions), _stream(labels)), "tem_affinity_target")
+    return out
+
+
+def standardize(x: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
+    """Per-sample (first axis) standardisation of a contiguous tensor."""
+    _req_cuda(x)
+    x = x.contiguous()
+    N = x.shape[0]
+    L = x.numel() // N
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    nws = N * 256 * 16
+    ws = _workspace(nws, x.device)
+    _lib.check(lib.tem_standardize(_p(x), _p(y), N, L, eps, _p(ws), nws, _stream(x)), "tem_standardize")
+    return y
