@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: voxels/s of one training step
+(zero_grad -> forward -> DiceLoss -> backward -> AdamW) of UNet3d(1->2, initial_features=32,
+depth=4, InstanceNorm) on synthetic 2x1x128^3 batches per GPU (cfg 2; cfg 4 = the same per
+rank under data parallelism, weak scaling).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA 3x3x3
+implicit-GEMM convolution), its duration measured live with HIP events on the launch stream
+inside the timed region; `cpu_baseline` times the oracle (oracle/unet_ref.py, a torch-CPU
+restatement pinned to the reference) on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md:41
+PEAK_HBM_TBS = 8.0              # ibid. :35
+STEP_GFLOP = 5700.8             # conv fwd+bwd of cfg 2 per GPU
+STEP_GB = 25.58                 # conv-centric fp32 traffic of cfg 2 per GPU
+
+
+def cpu_baseline(threads):
+    """Oracle fwd+bwd on the host cores; bounded sample: the benchmark model on 1x1x64^3."""
+    from oracle import unet_ref
+    from torch_em_amd.model import UNet3d
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in UNet3d(1, 2, initial_features=32, depth=4).state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 1, 64, 64, 64, generator=g)
+    y = (torch.rand(1, 2, 64, 64, 64, generator=g) > 0.5).float()
+    times = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        unet_ref.unet_loss_and_grads(sd, x, y, [2, 2, 2, 2])
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": 64 ** 3 / best, "unit": "voxels/s", "cores": threads, "kind": "port",
+            "sample": "oracle (torch-CPU fp32 restatement) fwd+DiceLoss+bwd of the same UNet3d on 1x1x64^3 "
+                      f"(1/16 of one cfg-2 batch), best of 2 after 1 warm-up: {best:.3f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="per-GPU batch (cfg 2: 2)")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--norm", default="InstanceNorm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table to this file")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from torch_em_amd import ops
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.multi_gpu_training import DDP
+    from torch_em_amd.optim import FusedAdamW
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    torch.manual_seed(0)
+    net = UNet3d(1, 2, initial_features=32, depth=4, norm=args.norm).to(dev)
+    model = DDP(net, device_ids=[local_rank]) if world > 1 else net
+    opt = FusedAdamW(net.parameters(), lr=1e-3)
+    loss_fn = DiceLoss()
+    g = torch.Generator().manual_seed(rank)
+    S = args.size
+    x = torch.randn(args.batch, 1, S, S, S, generator=g).to(dev)
+    y = (torch.rand(args.batch, 2, S, S, S, generator=g) > 0.5).float().to(dev)
+
+    def step():
+        opt.zero_grad()
+        loss = loss_fn(model(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.PROFILER = [] if rank == 0 else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILER = ops.PROFILER, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        voxels = args.batch * S ** 3
+        ms = elapsed / args.steps * 1e3
+        value = world * voxels * args.steps / elapsed
+        # ---- per-kernel table from the live HIP events ----
+        table = {}
+        for tag, flops, e0, e1 in prof:
+            d = table.setdefault(tag, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        rows = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
+        lines = [f"{'kernel':58s} {'launches':>8s} {'avg_ms':>9s} {'total_ms/step':>13s} {'TFLOP/s':>9s}"]
+        for tag, d in rows:
+            lines.append(f"{tag:58s} {d['launches']:8d} {d['ms'] / d['launches']:9.4f} "
+                         f"{d['ms'] / args.steps:13.3f} {d['flops'] / d['ms'] / 1e9:9.2f}")
+        conv_ms = sum(d["ms"] for d in table.values()) / args.steps
+        lines.append(f"conv kernels {conv_ms:.2f} ms/step of {ms:.2f} ms/step")
+        print("\n".join(lines), file=sys.stderr)
+        if args.kernel_table:
+            with open(args.kernel_table, "w") as f:
+                f.write("\n".join(lines) + "\n")
+        dom_tag, dom = rows[0]
+        achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s
+        standard = (args.batch == 2 and S == 128)
+        out = {
+            "metric": "voxels/sec fwd+bwd, UNet3d 1x128^3 bs=2",
+            "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"UNet3d(1->2, initial_features=32, depth=4, norm={args.norm}) + DiceLoss, "
+                                   f"zero_grad+fwd+loss+bwd+AdamW, per-GPU batch {args.batch}x1x{S}^3"
+                                   + ("" if standard else " (NON-STANDARD SIZE)"),
+                       "parallelism": f"dp{world}", "global_batch": world * args.batch, "final_loss": final_loss},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": dom_tag,
+                         "launches_per_step": dom["launches"] // args.steps,
+                         "avg_launch_ms": dom["ms"] / dom["launches"],
+                         "flops_per_launch_avg": dom["flops"] / dom["launches"]},
+        }
+        if standard:
+            out["step_roofline"] = {
+                "flops_frac_fp32_mfma": STEP_GFLOP / ms / PEAK_FP32_MFMA_TFLOPS,
+                "hbm_frac_8TBs": (STEP_GB / (ms / 1e3)) / (PEAK_HBM_TBS * 1e3),
+                "note": "5700.8 GFLOP and 25.58 GB algorithmic per step (SURVEY.md 8d); fp32 arithmetic => MFMA-bound"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

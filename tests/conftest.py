@@ -19,9 +19,28 @@ def golden_dir():
     return GOLDEN
 
 
-def rel_err(a, b):
-    """max |a-b| / max(|b|) -- the 'relative fp32 tolerance' of the north star."""
+def rel_err(a, b, floor=0.0):
+    """max |a-b| / max(|b|) -- the 'relative fp32 tolerance' of the north star.
+    `floor` bounds the denominator from below for quantities that are mathematically zero
+    (e.g. the bias gradient of a conv that feeds an InstanceNorm is pure round-off, ~1e-8)."""
     import numpy as np
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor, 1e-30))
+
+
+def check_grads(named_grads, ref_grads, tol, what=""):
+    """Every parameter gradient within `tol` (relative to that tensor's max) plus an absolute
+    round-off allowance of 1e-6 x the largest gradient of the model: gradients that are
+    mathematically zero (the bias of a conv feeding an InstanceNorm) are pure fp32 noise ~1e-8."""
+    import numpy as np
+    ref = {k: np.asarray(v, dtype=np.float64) for k, v in ref_grads.items()}
+    gscale = max(float(np.abs(v).max()) for v in ref.values())
+    worst = 0.0
+    for k, g in named_grads.items():
+        a = np.asarray(g, dtype=np.float64)
+        diff = float(np.abs(a - ref[k]).max())
+        bound = tol * float(np.abs(ref[k]).max()) + 1e-6 * gscale
+        assert diff <= bound, f"{what}{k}: |diff|={diff:.3e} > {bound:.3e} (|ref|max={np.abs(ref[k]).max():.3e})"
+        worst = max(worst, diff / max(float(np.abs(ref[k]).max()), 1e-6 * gscale / tol))
+    return worst

@@ -1,0 +1,282 @@
+"""GPU: every C-ABI op against the oracle / a plain torch fp32 CPU reference of the same op.
+Tolerances are relative fp32 (max|a-b|/max|b|); integer/label ops are bit-exact."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def to5(x):  # [N,C,D,H,W] cpu -> NDHWC cuda contiguous
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+
+
+def from5(x5):
+    return x5.permute(0, 4, 1, 2, 3).cpu()
+
+
+def _ops():
+    from torch_em_amd import ops
+    return ops
+
+
+CONV_CASES = [
+    # N, D, H, W, Cin, Cout, k
+    (1, 5, 6, 7, 1, 4, (3, 3, 3)),
+    (2, 4, 9, 10, 3, 5, (1, 3, 3)),
+    (1, 6, 6, 6, 4, 2, (1, 1, 1)),
+    (2, 9, 11, 13, 16, 32, (3, 3, 3)),
+    (1, 8, 16, 16, 32, 64, (3, 3, 3)),
+    (1, 5, 17, 9, 32, 32, (1, 3, 3)),
+    (1, 1, 20, 33, 16, 64, (1, 3, 3)),   # 2-D layout (D == 1)
+    (2, 4, 8, 8, 64, 32, (1, 1, 1)),
+    (1, 1, 16, 16, 32, 32, (1, 1, 1)),
+    (1, 3, 5, 4, 8, 16, (3, 1, 3)),      # generic-only kernel shape
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("fused", [False, True])
+def test_conv_fwd_dgrad_wgrad(case, fused):
+    ops = _ops()
+    N, D, H, W, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    scale = (torch.rand(N, Cin, generator=g) + 0.5) if fused else None
+    shift = torch.randn(N, Cin, generator=g) if fused else None
+    pad = tuple(v // 2 for v in k)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    xh = xr * scale[:, :, None, None, None] + shift[:, :, None, None, None] if fused else xr
+    pre = F.conv3d(xh, wr, br, padding=pad)
+    yr = F.relu(pre) if fused else pre
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    x5 = to5(x)
+    wd = w.to(DEV)
+    for mfma in ([False, True] if ops.mfma_ok(Cin, Cout, k) else [False]):
+        wp = ops.pack_weights(wd, transpose=False, mfma=mfma)
+        y5 = ops.new_act(N, D, H, W, Cout, DEV)
+        ops.conv_fwd(x5, wp, b.to(DEV), y5, k, Cin, Cout, scale=None if scale is None else scale.to(DEV),
+                     shift=None if shift is None else shift.to(DEV), act="relu" if fused else None, mfma=mfma)
+        assert rel_err(from5(y5), yr.detach()) < 2e-5, f"fwd mfma={mfma}"
+    # gradient w.r.t. the conv input (of xhat when fused): g' = gy * (y > 0)
+    gpre = gy * (yr.detach() > 0) if fused else gy
+    g5 = to5(gpre)
+    for mfma in ([False, True] if ops.mfma_ok(Cout, Cin, k) else [False]):
+        wpt = ops.pack_weights(wd, transpose=True, mfma=mfma)
+        gx5 = ops.new_act(N, D, H, W, Cin, DEV)
+        ops.conv_fwd(g5, wpt, None, gx5, k, Cout, Cin, mfma=mfma)
+        exp = xr.grad / scale[:, :, None, None, None] if fused else xr.grad
+        assert rel_err(from5(gx5), exp) < 2e-5, f"dgrad mfma={mfma}"
+    for mfma in ([False, True] if ops.mfma_ok(Cin, Cout, k, wgrad=True) else [False]):
+        dw = torch.empty(w.numel(), device=DEV)
+        db = torch.empty(Cout, device=DEV)
+        ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=None if scale is None else scale.to(DEV),
+                       shift=None if shift is None else shift.to(DEV), mfma=mfma)
+        assert rel_err(dw.cpu().view(w.shape), wr.grad) < 5e-5, f"wgrad mfma={mfma}"
+        assert rel_err(db.cpu(), br.grad) < 5e-5, f"bgrad mfma={mfma}"
+
+
+def test_conv_relu_mask_ref_and_channel_slices():
+    """ref-mask epilogue and leading-dimension (concat-buffer slice) addressing."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    N, D, H, W, Cin, Cout, k = 1, 4, 8, 8, 32, 32, (3, 3, 3)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.1
+    ref = torch.randn(N, Cout, D, H, W, generator=g)
+    exp = F.conv3d(x, w, None, padding=1) * (ref > 0)
+    big_in = torch.zeros(N, D, H, W, Cin + 32, device=DEV)
+    big_in[..., 32:] = to5(x)
+    big_out = torch.full((N, D, H, W, Cout + 16), 7.0, device=DEV)
+    big_ref = torch.zeros(N, D, H, W, Cout + 4, device=DEV)
+    big_ref[..., 4:] = to5(ref)
+    for mfma in (False, True):
+        wp = ops.pack_weights(w.to(DEV), False, mfma)
+        ops.conv_fwd(big_in[..., 32:], wp, None, big_out[..., :Cout], k, Cin, Cout, ref=big_ref[..., 4:], mfma=mfma)
+        assert rel_err(from5(big_out[..., :Cout]), exp) < 2e-5
+        assert float(big_out[..., Cout:].min()) == 7.0 and float(big_out[..., Cout:].max()) == 7.0
+
+
+@pytest.mark.parametrize("C,G,affine,shape", [(1, 1, False, (2, 6, 7, 9)), (4, 4, False, (1, 5, 6, 7)),
+                                               (32, 32, False, (2, 8, 8, 8)), (64, 32, True, (2, 4, 8, 8)),
+                                               (6, 3, True, (1, 3, 5, 7)), (512, 512, False, (1, 2, 2, 2))])
+def test_norm_stats_and_backward(C, G, affine, shape):
+    ops = _ops()
+    N, D, H, W = shape
+    g = torch.Generator().manual_seed(C + G)
+    x = torch.randn(N, C, D, H, W, generator=g) * 2 + 0.7
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)) if affine else None
+    beta = (0.2 * torch.randn(C, generator=g)) if affine else None
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True) if affine else None
+    br = beta.clone().requires_grad_(True) if affine else None
+    yr = F.group_norm(xr, G, gr, br, eps=1e-5)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    x5 = to5(x)
+    mean, rstd, scale, shift = ops.norm_stats(x5, G, None if gamma is None else gamma.to(DEV),
+                                              None if beta is None else beta.to(DEV), 1e-5)
+    y5 = x5 * scale[:, None, None, None, :] + shift[:, None, None, None, :]
+    assert rel_err(from5(y5), yr.detach()) < 2e-5
+    for relu_mask in (False, True):
+        gx5 = torch.empty_like(x5)
+        dgamma = torch.empty(C, device=DEV) if affine else None
+        dbeta = torch.empty(C, device=DEV) if affine else None
+        ops.norm_bwd(to5(gy), x5, G, None if gamma is None else gamma.to(DEV), mean, rstd, relu_mask, gx5, dgamma,
+                     dbeta)
+        exp = xr.grad * (x > 0) if relu_mask else xr.grad
+        assert rel_err(from5(gx5), exp) < 5e-5
+        if affine:
+            assert rel_err(dgamma.cpu(), gr.grad) < 5e-5 and rel_err(dbeta.cpu(), br.grad) < 5e-5
+
+
+@pytest.mark.parametrize("C,f,shape", [(4, (2, 2, 2), (2, 4, 6, 8)), (32, (1, 2, 2), (1, 3, 8, 8)),
+                                        (3, (2, 2, 2), (1, 2, 2, 2)), (64, (1, 2, 2), (2, 1, 16, 16))])
+def test_maxpool(C, f, shape):
+    ops = _ops()
+    N, D, H, W = shape
+    g = torch.Generator().manual_seed(C)
+    x = F.relu(torch.randn(N, C, D, H, W, generator=g))  # many exact ties at 0, as after a ReLU
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, f)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    x5 = to5(x)
+    y5 = ops.new_act(N, D // f[0], H // f[1], W // f[2], C, DEV)
+    ops.maxpool_fwd(x5, y5, f)
+    assert torch.equal(from5(y5), yr.detach())
+    gskip = torch.randn(N, C, D, H, W, generator=g)
+    gx5 = torch.empty_like(x5)
+    ops.maxpool_bwd(to5(gy), x5, gx5, f)
+    assert torch.equal(from5(gx5), xr.grad)  # first-max tie rule identical to ATen
+    ops.maxpool_bwd(to5(gy), x5, gx5, f, gskip=to5(gskip), relu_mask=True)
+    assert rel_err(from5(gx5), (xr.grad + gskip) * (x > 0)) < 1e-6
+
+
+@pytest.mark.parametrize("C,f,shape", [(4, (2, 2, 2), (2, 3, 4, 5)), (32, (1, 2, 2), (1, 3, 4, 4)),
+                                        (8, (2, 2, 2), (1, 1, 1, 1)), (64, (1, 2, 2), (1, 1, 8, 8)),
+                                        (4, (1, 3, 3), (1, 2, 3, 4))])
+def test_upsample(C, f, shape):
+    ops = _ops()
+    N, D, H, W = shape
+    g = torch.Generator().manual_seed(C + sum(f))
+    x = torch.randn(N, C, D, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=tuple(float(v) for v in f), mode="trilinear", align_corners=False)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    y5 = ops.new_act(N, D * f[0], H * f[1], W * f[2], C, DEV)
+    ops.upsample_fwd(to5(x), y5, f)
+    assert rel_err(from5(y5), yr.detach()) < 1e-6
+    gx5 = ops.new_act(N, D, H, W, C, DEV)
+    ops.upsample_bwd(to5(gy), gx5, f)
+    assert rel_err(from5(gx5), xr.grad) < 1e-5
+
+
+def test_layout_roundtrip_and_standardize():
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 37, 3, 5, 71, generator=g)
+    x5 = ops.nchw_to_nhwc(x.to(DEV))
+    assert torch.equal(from5(x5), x)
+    assert torch.equal(ops.nhwc_to_nchw(x5).cpu(), x)
+    r = torch.randn(3, 1, 16, 16, 16, generator=g) * 5 + 3
+    s = ops.standardize(r.to(DEV), eps=1e-7).cpu()
+    exp = (r - r.mean(dim=(1, 2, 3, 4), keepdim=True)) / (r.std(dim=(1, 2, 3, 4), unbiased=False, keepdim=True) + 1e-7)
+    assert rel_err(s, exp) < 1e-5
+
+
+def test_dice_against_reference_golden():
+    from torch_em_amd.loss import ApplyAndRemoveMask, DiceLoss, LossWrapper, dice_score
+    gd = dict(np.load(os.path.join(GOLDEN, "g5_dice.npz")))
+    p, t = torch.from_numpy(gd["p"]), torch.from_numpy(gd["t"])
+    for layout in ("nchw", "channels_last"):
+        for cw in (True, False):
+            for red in ("sum", "mean", "max", "min"):
+                pp = p.to(DEV)
+                if layout == "channels_last":
+                    pp = pp.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+                pp.requires_grad_(True)
+                val = DiceLoss(channelwise=cw, reduce_channel=red)(pp, t.to(DEV))
+                val.backward()
+                assert abs(float(val) - float(gd[f"loss_{int(cw)}_{red}"])) < 2e-6, (layout, cw, red)
+                assert rel_err(pp.grad.cpu(), gd[f"grad_{int(cw)}_{red}"]) < 2e-5, (layout, cw, red)
+    assert rel_err(dice_score(p.to(DEV), t.to(DEV), reduce_channel=None).cpu(), gd["score_none"]) < 1e-6
+    pm = torch.from_numpy(gd["pm"]).to(DEV).requires_grad_(True)
+    tm = torch.from_numpy(gd["tm"]).to(DEV)
+    loss = LossWrapper(DiceLoss(), transform=ApplyAndRemoveMask(masking_method="multiply"))
+    val = loss(pm, tm)
+    val.backward()
+    assert abs(float(val) - float(gd["loss_masked"])) < 2e-6
+    assert rel_err(pm.grad.cpu(), gd["grad_masked"]) < 2e-5
+    # exactly zero gradient outside the mask (reference test/loss/test_loss_wrapper.py:36-62)
+    mask = tm[:, 12:].bool()
+    assert float(pm.grad[~mask].abs().max()) == 0.0 and float(pm.grad[mask].abs().sum()) > 0
+    # reference known answers (test/loss/test_dice.py:25-38)
+    ones, zeros = torch.ones(1, 1, 32, 32, device=DEV), torch.zeros(1, 1, 32, 32, device=DEV)
+    assert abs(float(DiceLoss()(ones, ones))) < 1e-7 and abs(float(DiceLoss()(ones, zeros)) - 1.0) < 1e-7
+    with pytest.raises(ValueError):
+        DiceLoss()(ones, torch.zeros(1, 2, 32, 32, device=DEV))
+    with pytest.raises(ValueError, match="_crop only supports a mask with a singleton channel axis"):
+        LossWrapper(DiceLoss(), transform=ApplyAndRemoveMask())(pm, tm)
+
+
+def test_adamw_and_ema_against_oracle():
+    ops = _ops()
+    from oracle import optim_ref
+    rng = np.random.RandomState(0)
+    n = 100003
+    p, m, v = rng.randn(n).astype("float32"), np.zeros(n, "float32"), np.zeros(n, "float32")
+    pd, md, vd = torch.from_numpy(p.copy()).to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 5):
+        g = rng.randn(n).astype("float32")
+        ops.adamw_step(pd, torch.from_numpy(g).to(DEV), md, vd, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step)
+        p, m, v = optim_ref.adamw_step(p, g, m, v, step)
+        assert rel_err(pd.cpu().numpy(), p) < 1e-6 and rel_err(md.cpu().numpy(), m) < 1e-6
+    k, q = rng.randn(n).astype("float32"), rng.randn(n).astype("float32")
+    kd = torch.from_numpy(k.copy()).to(DEV)
+    ops.ema_update(kd, torch.from_numpy(q).to(DEV), 0.999)
+    assert rel_err(kd.cpu().numpy(), optim_ref.ema(k, q, 0.999)) < 1e-7
+
+
+def _labels(shape, seed, with_zero=True):
+    rng = np.random.RandomState(seed)
+    lab = rng.randint(1, 6, size=shape).astype("int64")
+    if with_zero:
+        lab[rng.rand(*shape) < 0.25] = 0
+    return lab
+
+
+def test_label_targets_bit_exact():
+    ops = _ops()
+    from oracle import label_ref
+    offs2 = [[-1, 0], [0, -1], [-3, 0], [0, -3], [4, 5], [-3, 2]]              # reference test offsets
+    offs3 = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0], [0, 0, -3], [-3, 0, 0], [0, -9, 0],
+             [0, 0, -9], [-4, 0, 0], [0, -27, 0], [0, 0, -27]]                  # reference cli.py:86-91
+    for shape, offs in (((64, 64), offs2), ((8, 40, 48), offs3), ((1, 1), [[0, 1]]), ((3, 70, 5), offs3)):
+        lab = _labels(shape, sum(shape))
+        ld = torch.from_numpy(lab).to(DEV)
+        for kw in (dict(), dict(ignore_label=0, add_mask=True),
+                   dict(ignore_label=0, add_mask=True, include_ignore_transitions=True),
+                   dict(ignore_label=0, add_binary_target=True, add_mask=True), dict(add_binary_target=True)):
+            exp = label_ref.affinities(lab, offs, **kw)
+            got = ops.affinity_target(ld, offs, **kw).cpu().numpy()
+            assert got.shape == exp.shape and np.array_equal(got, exp), (shape, kw)
+        for add_bin in (False, True):
+            exp = label_ref.boundaries(lab, add_bin)
+            got = ops.boundary_target(ld, add_bin).cpu().numpy()
+            assert np.array_equal(got, exp), (shape, add_bin)

@@ -105,20 +105,38 @@ def _dgrad(spec: ConvSpec, g, gx, ref=None):
 
 
 class _Grads:
-    """Flat fp32 gradient arena; one view per parameter, in `model.parameters()` order."""
+    """Flat fp32 gradient arena (layout: torch_em_amd.arena.arena_layout, `model.parameters()` order).
+    Tracks which element ranges backward has produced so that a data-parallel `GradSync` can
+    all-reduce them while the rest of backward is still running."""
 
     def __init__(self, params: List[torch.Tensor]):
-        total, self.offsets = 0, {}
-        for p in params:
-            self.offsets[id(p)] = (total, p.numel(), p.shape)
-            total += (p.numel() + 3) // 4 * 4  # keep every view 16-byte aligned
+        from ..arena import arena_layout
+        self.offsets, total = arena_layout(params)
+        self.shapes = {id(p): p.shape for p in params}
         self.flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
         self.written = set()
+        self._new = []
 
-    def view(self, p: torch.Tensor) -> torch.Tensor:
-        o, n, shape = self.offsets[id(p)]
-        self.written.add(id(p))
-        return self.flat[o:o + n].view(shape)
+    def view(self, p: torch.Tensor, track: bool = True) -> torch.Tensor:
+        o, n = self.offsets[id(p)]
+        if track:
+            self.written.add(id(p))
+            self._new.append((o, o + (n + 3) // 4 * 4))
+        return self.flat[o:o + n].view(self.shapes[id(p)])
+
+    def take_new_ranges(self):
+        """Coalesced element ranges written since the last call."""
+        if not self._new:
+            return []
+        rs = sorted(self._new)
+        self._new = []
+        out = [list(rs[0])]
+        for lo, hi in rs[1:]:
+            if lo <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], hi)
+            else:
+                out.append([lo, hi])
+        return [tuple(r) for r in out]
 
 
 def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None):
@@ -274,6 +292,13 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
     dim = st["dim"]
     depth = len(st["levels"])
     grads = _Grads(params)
+    sync = getattr(model, "_tem_grad_sync", None)  # data-parallel gradient exchange (multi_gpu_training.DDP)
+
+    def stage_done():
+        if sync is not None:
+            for lo, hi in grads.take_new_ranges():
+                sync.ready(grads.flat, lo, hi)
+
     g = _from_logical(gy.float(), dim)
     y = st["y"]
     if st["act"] is not None:
@@ -299,10 +324,12 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         _dgrad(sspec, g_t, g_low, ref=low)  # `low` is the ReLU output of the previous block
         lv["g_skip"] = g_cat[..., lv["c_up"]:]
         g_cur = g_low
+        stage_done()
     bb = st["base"]
     g_pooled = torch.empty_like(bb["xin"])
     _block_bwd(bb, g_cur, g_pooled, grads)
     g_cur = g_pooled
+    stage_done()
     for l in reversed(range(depth)):
         lv = st["levels"][l]
         skip = lv["skip"]
@@ -314,6 +341,9 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         g_in = torch.empty_like(xin) if need_in else None
         _block_bwd(lv["bs"], g_skip_full, g_in, grads)
         g_cur = g_in
+        stage_done()
+    if sync is not None:
+        sync.finish(grads.flat)
     gx = None
     if need_input_grad:
         gx = ops.nhwc_to_nchw(g_cur)
@@ -343,12 +373,9 @@ class UNetFunction(torch.autograd.Function):
         out = [None, gx]
         for i, p in enumerate(ctx.params):
             if ctx.needs_input_grad[2 + i]:
-                out.append(grads.view(p) if id(p) in grads.written else torch.zeros_like(p))
+                out.append(grads.view(p, track=False))
             else:
                 out.append(None)
-        hook = getattr(ctx.model, "_tem_grad_hook", None)
-        if hook is not None:
-            hook(grads)
         return tuple(out)
 
 

@@ -15,6 +15,26 @@ from . import _lib
 
 ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2}
 
+# Optional live kernel timing (bench.py): a list that receives (tag, flops, start_event, end_event)
+# for every convolution launch; events are recorded on the stream the kernel is launched on.
+PROFILER = None
+
+
+def _prof_begin(t):
+    if PROFILER is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record(torch.cuda.current_stream(t.device))
+    return ev
+
+
+def _prof_end(t, ev0, tag, flops):
+    if ev0 is None:
+        return
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record(torch.cuda.current_stream(t.device))
+    PROFILER.append((tag, flops, ev0, ev1))
+
 
 def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
@@ -128,9 +148,14 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     if ref is not None:
         ref_ld = _act5(ref)[5]
     lib = _lib.load()
+    ev0 = _prof_begin(x)
     _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
                                   ref_ld, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma), _stream(x)),
                "tem_conv3d_fwd")
+    if ev0 is not None:
+        kind = ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu") + f"<{k[0]},{k[1]},{k[2]}"
+        kind += (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
+        _prof_end(x, ev0, kind, 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return y
 
 
@@ -161,11 +186,15 @@ def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, 
     ws = _workspace(nws + tmp_bytes + 256, x.device)
     tmp_ptr = ws.data_ptr()
     ws_ptr = tmp_ptr + ((tmp_bytes + 255) // 256) * 256
+    ev0 = _prof_begin(x)
     _lib.check(lib.tem_conv3d_wgrad(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, ctypes.c_void_p(tmp_ptr),
                                     _p(db_out), ctypes.c_void_p(ws_ptr), nws, N, D, H, W, cin, cout, k[0], k[1], k[2],
                                     int(mfma), _stream(x)), "tem_conv3d_wgrad")
     _lib.check(lib.tem_conv_unpack_wgrad(ctypes.c_void_p(tmp_ptr), _p(dw_out), cout, cin, k[0], k[1], k[2],
                                          _stream(x)), "tem_conv_unpack_wgrad")
+    if ev0 is not None:
+        kind = ("k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + f"<{k[0]},{k[1]},{k[2]}>(+bias,reduce,unpack)"
+        _prof_end(x, ev0, kind, 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return dw_out
 
 

@@ -1,0 +1,322 @@
+"""DefaultTrainer for the MI355X path.
+
+Same constructor, `fit()` contract, counters and checkpoint schema as the reference
+(torch_em/trainer/default_trainer.py: ctor :86-146, `_initialize` :503-575, `save_checkpoint` :577-602,
+`load_checkpoint` :604-642, `fit` :651-775, hot loop `_train_epoch_impl` :805-831, `_validate_impl` :841-861),
+so scripts written against torch-em's trainer run unchanged and reference tools can read the
+checkpoints (`iteration, epoch, best_epoch, best_metric, current_metric, model_state, optimizer_state,
+init, train_time, timestamp[, scheduler_state]`).
+
+Differences that follow from the MI355X-first design:
+  * arithmetic is exact fp32 on the matrix cores, so `mixed_precision` is accepted (and recorded) but
+    no autocast/GradScaler is applied -- there is no fp16 overflow to guard against;
+  * `compile_model` is accepted and ignored: the model is already one hand-scheduled autograd node,
+    there is no tracing compiler in this path;
+  * the hot loop never synchronises the host: loss values are kept on device and only read at
+    validation / logging time.
+"""
+import os
+import time
+import warnings
+from collections import OrderedDict
+from datetime import datetime
+from importlib import import_module
+from typing import Any, Callable, Dict, Optional, Union
+
+import numpy as np
+import torch
+
+try:
+    from tqdm import tqdm
+except ImportError:  # pragma: no cover
+    tqdm = None
+
+
+def _class_path(obj):
+    cls = obj if isinstance(obj, type) else obj.__class__
+    return f"{cls.__module__}.{cls.__name__}"
+
+
+def _import_class(path):
+    mod, name = path.rsplit(".", 1)
+    return getattr(import_module(mod), name)
+
+
+def _init_kwargs(obj):
+    """Constructor arguments of torch_em-style objects (they store `init_kwargs`; reference util/util.py:299-304)."""
+    if hasattr(obj, "init_kwargs"):
+        return dict(obj.init_kwargs)
+    if isinstance(obj, torch.optim.Optimizer):
+        return {k: v for k, v in obj.defaults.items() if k in ("lr", "betas", "eps", "weight_decay")}
+    if isinstance(obj, torch.optim.lr_scheduler.ReduceLROnPlateau):
+        return {"mode": obj.mode, "factor": obj.factor, "patience": obj.patience}
+    return {}
+
+
+class _NullProgress:
+    total = 0
+
+    def update(self, n):
+        pass
+
+    def set_description(self, *a, **k):
+        pass
+
+
+class DefaultTrainer:
+    """Trainer with the reference's interface; see the module docstring."""
+
+    def __init__(self, name: Optional[str], train_loader, val_loader, model: torch.nn.Module, loss, optimizer,
+                 metric: Callable, device: Union[str, torch.device, int], lr_scheduler=None,
+                 log_image_interval: int = 100, mixed_precision: bool = True, early_stopping: Optional[int] = None,
+                 logger=None, logger_kwargs: Optional[Dict[str, Any]] = None, id_: Optional[str] = None,
+                 save_root: Optional[str] = None, compile_model: Optional[Union[bool, str]] = None,
+                 rank: Optional[int] = None, mixed_precision_dtype: Optional[str] = None):
+        if name is None:
+            raise TypeError("Name cannot be None if not using the WandbLogger")
+        self.name, self.id_ = name, id_ or name
+        self.train_loader, self.val_loader = train_loader, val_loader
+        self.model, self.loss, self.optimizer, self.metric = model, loss, optimizer, metric
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.lr_scheduler = lr_scheduler
+        self.log_image_interval = log_image_interval
+        self.save_root, self.compile_model, self.rank = save_root, compile_model, rank
+        self._iteration = self._epoch = self._best_epoch = 0
+        self.mixed_precision = mixed_precision
+        self.mixed_precision_dtype = mixed_precision_dtype or "float16"
+        self.scaler = None  # exact-fp32 path: no loss scaling
+        self.early_stopping = early_stopping
+        self.train_time = 0.0
+        self.logger_class, self.logger_kwargs = logger, logger_kwargs
+        self.logger = None
+
+    # ---- bookkeeping ------------------------------------------------------------------
+    @property
+    def checkpoint_folder(self):
+        root = getattr(self, "save_root", None)
+        return os.path.join("./checkpoints", self.id_) if root is None else os.path.join(root, "./checkpoints", self.id_)
+
+    iteration = property(lambda self: self._iteration)
+    epoch = property(lambda self: self._epoch)
+
+    def _build_init(self):
+        """What `from_checkpoint` needs to rebuild the trainer (class paths + kwargs; reference :332-501)."""
+        inner = getattr(self.model, "module", self.model)
+        return {
+            "name": self.name, "id_": self.id_, "device": str(self.device), "rank": self.rank,
+            "save_root": self.save_root, "compile_model": self.compile_model,
+            "mixed_precision": self.mixed_precision, "mixed_precision_dtype": self.mixed_precision_dtype,
+            "early_stopping": self.early_stopping, "log_image_interval": self.log_image_interval,
+            "logger_class": None if self.logger_class is None else _class_path(self.logger_class),
+            "logger_kwargs": self.logger_kwargs,
+            "model_class": _class_path(inner), "model_kwargs": _init_kwargs(inner),
+            "loss_class": _class_path(self.loss), "loss_kwargs": _init_kwargs(self.loss),
+            "metric_class": _class_path(self.metric), "metric_kwargs": _init_kwargs(self.metric),
+            "optimizer_class": _class_path(self.optimizer), "optimizer_kwargs": _init_kwargs(self.optimizer),
+            "lr_scheduler_class": None if self.lr_scheduler is None else _class_path(self.lr_scheduler),
+            "lr_scheduler_kwargs": None if self.lr_scheduler is None else _init_kwargs(self.lr_scheduler),
+            "train_dataset": getattr(self.train_loader, "dataset", None),
+            "val_dataset": getattr(self.val_loader, "dataset", None),
+            "train_loader_kwargs": {"batch_size": getattr(self.train_loader, "batch_size", None)},
+            "val_loader_kwargs": {"batch_size": getattr(self.val_loader, "batch_size", None)},
+        }
+
+    def _initialize(self, iterations, load_from_checkpoint, epochs=None):
+        for attr in ("train_loader", "val_loader", "model", "loss", "optimizer", "metric", "device"):
+            assert getattr(self, attr) is not None
+        if load_from_checkpoint is not None:
+            self.load_checkpoint(load_from_checkpoint)
+        if sum((iterations is not None, epochs is not None)) != 1:
+            raise ValueError(
+                "Exactly one of 'iterations' or 'epochs' has to be specified to initialize the trainer."
+                f"You have passed 'iterations'={iterations} and 'epochs'={epochs}"
+            )
+        if epochs is None:
+            epochs = int(np.ceil(float(iterations) / len(self.train_loader)))
+        else:
+            iterations = epochs * len(self.train_loader)
+        self.max_iteration = self._iteration + iterations
+        self.max_epoch = self._epoch + epochs
+        if not getattr(self, "_is_initialized", False):
+            self.model.to(self.device)
+            if isinstance(self.loss, torch.nn.Module):
+                self.loss.to(self.device)
+            self.init_data = self._build_init()
+            if self.logger_class is not None:
+                self.logger = self.logger_class(self, self.save_root, **(self.logger_kwargs or {}))
+            try:
+                os.makedirs(self.checkpoint_folder, exist_ok=True)
+            except PermissionError:
+                warnings.warn(f"The checkpoint folder at {self.checkpoint_folder} could not be created.")
+            self._is_initialized = True
+        return np.inf
+
+    # ---- checkpoints --------------------------------------------------------------------
+    def save_checkpoint(self, name, current_metric, best_metric, train_time=0.0, **extra_save_dict):
+        extra_init = extra_save_dict.pop("init", {})
+        save_dict = {
+            "iteration": self._iteration, "epoch": self._epoch, "best_epoch": self._best_epoch,
+            "best_metric": best_metric, "current_metric": current_metric,
+            "model_state": self.model.state_dict(), "optimizer_state": self.optimizer.state_dict(),
+            "init": {**self.init_data, **extra_init}, "train_time": train_time,
+            "timestamp": datetime.now().strftime("%d-%m-%Y (%H:%M:%S)"),
+        }
+        save_dict.update(**extra_save_dict)
+        if self.lr_scheduler is not None:
+            save_dict["scheduler_state"] = self.lr_scheduler.state_dict()
+        if self.rank is None or self.rank == 0:  # rank-0 only, as the reference (:600-602)
+            torch.save(save_dict, os.path.join(self.checkpoint_folder, f"{name}.pt"))
+
+    def load_checkpoint(self, checkpoint="best"):
+        if isinstance(checkpoint, str):
+            path = os.path.join(self.checkpoint_folder, f"{checkpoint}.pt")
+            if not os.path.exists(path):
+                warnings.warn(f"Cannot load checkpoint. {path} does not exist.")
+                return
+            save_dict = torch.load(path, weights_only=False)
+        elif isinstance(checkpoint, dict):
+            save_dict = checkpoint
+        else:
+            raise RuntimeError
+        self._iteration, self._epoch = save_dict["iteration"], save_dict["epoch"]
+        self._best_epoch = save_dict["best_epoch"]
+        self.best_metric, self.current_metric = save_dict["best_metric"], save_dict["current_metric"]
+        self.train_time = save_dict.get("train_time", 0.0)
+        prefix = "_orig_mod."  # checkpoints written from torch.compile'd reference models (:626-630)
+        state = OrderedDict((k[len(prefix):] if k.startswith(prefix) else k, v)
+                            for k, v in save_dict["model_state"].items())
+        self.model.load_state_dict(state)
+        self.model.to(self.device)
+        self.optimizer.load_state_dict(save_dict["optimizer_state"])
+        if self.lr_scheduler is not None and "scheduler_state" in save_dict:
+            self.lr_scheduler.load_state_dict(save_dict["scheduler_state"])
+        return save_dict
+
+    @classmethod
+    def from_checkpoint(cls, checkpoint_folder, name="best", device=None, train_loader=None, val_loader=None):
+        """Rebuild a trainer from `<checkpoint_folder>/<name>.pt` (reference :288-330).  Loaders are rebuilt
+        from the pickled datasets unless given."""
+        save_dict = torch.load(os.path.join(checkpoint_folder, f"{name}.pt"), weights_only=False)
+        init = save_dict["init"]
+        model = _import_class(init["model_class"])(**init["model_kwargs"])
+        loss = _import_class(init["loss_class"])(**init["loss_kwargs"])
+        metric = _import_class(init["metric_class"])(**init["metric_kwargs"])
+        optimizer = _import_class(init["optimizer_class"])(model.parameters(), **init["optimizer_kwargs"])
+        sched = None
+        if init.get("lr_scheduler_class"):
+            sched = _import_class(init["lr_scheduler_class"])(optimizer, **init["lr_scheduler_kwargs"])
+        if train_loader is None:
+            train_loader = torch.utils.data.DataLoader(init["train_dataset"], **init["train_loader_kwargs"])
+        if val_loader is None:
+            val_loader = torch.utils.data.DataLoader(init["val_dataset"], **init["val_loader_kwargs"])
+        trainer = cls(name=init["name"], train_loader=train_loader, val_loader=val_loader, model=model, loss=loss,
+                      optimizer=optimizer, metric=metric, device=device or init["device"], lr_scheduler=sched,
+                      log_image_interval=init["log_image_interval"], mixed_precision=init["mixed_precision"],
+                      early_stopping=init["early_stopping"], logger=None, id_=init["id_"],
+                      save_root=init["save_root"], rank=init.get("rank"),
+                      mixed_precision_dtype=init["mixed_precision_dtype"])
+        trainer._initialize(0, save_dict)
+        trainer._is_initialized = True
+        return trainer
+
+    def _verify_if_training_completed(self, checkpoint="latest"):
+        path = os.path.join(self.checkpoint_folder, f"{checkpoint}.pt")
+        save_dict = torch.load(path, weights_only=False) if os.path.exists(path) else None
+        return bool(save_dict and self.max_iteration == save_dict.get("iteration"))
+
+    # ---- training ------------------------------------------------------------------------
+    def fit(self, iterations: Optional[int] = None, load_from_checkpoint=None, epochs: Optional[int] = None,
+            save_every_kth_epoch: Optional[int] = None, progress=None, overwrite_training: bool = True):
+        """Run training; exactly one of `iterations` / `epochs` (reference :651-775)."""
+        best_metric = self._initialize(iterations, load_from_checkpoint, epochs)
+        if not overwrite_training:
+            if load_from_checkpoint is not None:
+                raise ValueError(
+                    "We do not support 'overwrite_training=False' and 'load_from_checkpoint' at the same time."
+                )
+            if self._verify_if_training_completed():
+                print(f"The model is trained for {self.max_iteration} iterations / {self.max_epoch} epochs "
+                      "and 'overwrite_training' is set to 'False'.")
+                return
+        print("Start fitting for", self.max_iteration - self._iteration, "iterations / ",
+              self.max_epoch - self._epoch, "epochs")
+        print("with", len(self.train_loader), "iterations per epoch")
+        print("Training with single precision (exact fp32 on the MI355X matrix cores)")
+        total = epochs * len(self.train_loader) if iterations is None else iterations
+        if progress is None:
+            progress = tqdm(total=total, desc=f"Epoch {self._epoch}", leave=True) if tqdm else _NullProgress()
+        else:
+            progress.total = total
+            progress.set_description(f"Epoch {self._epoch}")
+        msg = "Epoch %i: average [s/it]: %f, current metric: %f, best metric: %f"
+        t_start = time.time()
+        total_train_time = self.train_time
+        for epoch in range(self.max_epoch - self._epoch):
+            try:
+                self.train_loader.sampler.set_epoch(epoch)  # DistributedSampler reshuffle
+            except AttributeError:
+                pass
+            t_per_iter = self._train_epoch(progress)
+            current_metric = self._validate()
+            if self.lr_scheduler is not None:
+                self.lr_scheduler.step(current_metric)
+            total_train_time = (time.time() - t_start) + self.train_time
+            if current_metric < best_metric:
+                best_metric, self._best_epoch = current_metric, self._epoch
+                self.save_checkpoint("best", current_metric, best_metric, train_time=total_train_time)
+            self.save_checkpoint("latest", current_metric, best_metric, train_time=total_train_time)
+            if save_every_kth_epoch is not None and (self._epoch + 1) % save_every_kth_epoch == 0:
+                self.save_checkpoint(f"epoch-{self._epoch + 1}", current_metric, best_metric,
+                                     train_time=total_train_time)
+            if self.early_stopping is not None and self._epoch - self._best_epoch > self.early_stopping:
+                print("Stopping training because there has been no improvement for", self.early_stopping, "epochs")
+                break
+            self._epoch += 1
+            progress.set_description(msg % (self._epoch, t_per_iter, current_metric, best_metric), refresh=True)
+        print(f"Finished training after {self._epoch} epochs / {self._iteration} iterations.")
+        print(f"The best epoch is number {self._best_epoch}.")
+        self.train_time = total_train_time
+
+    def _forward_and_loss(self, x, y):
+        pred = self.model(x)
+        return pred, self.loss(pred, y)
+
+    def _backprop(self, loss):
+        loss.backward()
+        self.optimizer.step()
+
+    def _train_epoch(self, progress):
+        """The hot loop (reference :805-831): H2D copy, zero_grad, forward, loss, backward, step."""
+        self.model.train()
+        n_iter, t0 = 0, time.time()
+        for x, y in self.train_loader:
+            x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
+            self.optimizer.zero_grad()
+            pred, loss = self._forward_and_loss(x, y)
+            self._backprop(loss)
+            if self.logger is not None:
+                lr = [pm["lr"] for pm in self.optimizer.param_groups][0]
+                self.logger.log_train(self._iteration, loss, lr, x, y, pred, log_gradients=True)
+            self._iteration += 1
+            n_iter += 1
+            if self._iteration >= self.max_iteration:
+                break
+            progress.update(1)
+        return (time.time() - t0) / max(n_iter, 1)
+
+    def _validate(self):
+        """Mean metric over the validation loader (reference :841-861)."""
+        self.model.eval()
+        metric_val = loss_val = None
+        with torch.no_grad():
+            for x, y in self.val_loader:
+                x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
+                pred, loss = self._forward_and_loss(x, y)
+                metric = self.metric(pred, y)
+                loss_val = loss.detach() if loss_val is None else loss_val + loss.detach()
+                metric_val = metric.detach() if metric_val is None else metric_val + metric.detach()
+        n = len(self.val_loader)
+        metric_val, loss_val = float(metric_val) / n, float(loss_val) / n  # the only host sync of the epoch
+        if self.logger is not None:
+            self.logger.log_validation(self._iteration, metric_val, loss_val, x, y, pred)
+        return metric_val
