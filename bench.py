@@ -123,12 +123,14 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * voxels * args.steps / elapsed
         # ---- per-kernel table from the live HIP events ----
-        table = {}
-        for tag, flops, e0, e1 in prof:
-            d = table.setdefault(tag, {"launches": 0, "ms": 0.0, "flops": 0.0})
-            d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["flops"] += flops
+        table, detail = {}, {}
+        for (tag, shape), flops, e0, e1 in prof:
+            dt = e0.elapsed_time(e1)
+            for tab, key in ((table, tag), (detail, (tag, shape))):
+                d = tab.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0})
+                d["launches"] += 1
+                d["ms"] += dt
+                d["flops"] += flops
         rows = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
         lines = [f"{'kernel':58s} {'launches':>8s} {'avg_ms':>9s} {'total_ms/step':>13s} {'TFLOP/s':>9s}"]
         for tag, d in rows:
@@ -136,6 +138,11 @@ def main():
                          f"{d['ms'] / args.steps:13.3f} {d['flops'] / d['ms'] / 1e9:9.2f}")
         conv_ms = sum(d["ms"] for d in table.values()) / args.steps
         lines.append(f"conv kernels {conv_ms:.2f} ms/step of {ms:.2f} ms/step")
+        lines.append("")
+        lines.append(f"{'kernel / layer (NxDxHxW cin->cout)':78s} {'launches':>8s} {'avg_ms':>9s} {'TFLOP/s':>9s}")
+        for (tag, shape), d in sorted(detail.items(), key=lambda kv: -kv[1]["ms"]):
+            lines.append(f"{tag + '  ' + shape:78s} {d['launches']:8d} {d['ms'] / d['launches']:9.4f} "
+                         f"{d['flops'] / d['ms'] / 1e9:9.2f}")
         print("\n".join(lines), file=sys.stderr)
         if args.kernel_table:
             with open(args.kernel_table, "w") as f:

@@ -36,3 +36,22 @@ ops.norm_bwd(g5, x5, 32, None, mean, rstd, True, out)
 g5b = g5.clone()
 ops.norm_bwd(g5b, x5, 32, None, mean, rstd, True, g5b)
 print("inplace diff", float((out - g5b).abs().max()))
+
+# MFMA-size case vs oracle
+from oracle import unet_ref  # noqa: E402
+torch.manual_seed(0)
+model = UNet3d(1, 2, depth=2, initial_features=32)
+gen = torch.Generator().manual_seed(4)
+x = torch.randn(2, 1, 16, 24, 32, generator=gen)
+y = (torch.rand(2, 2, 16, 24, 32, generator=gen) > 0.5).float()
+pred_o, loss_o, grads_o = unet_ref.unet_loss_and_grads({k: v.detach().clone() for k, v in model.state_dict().items()},
+                                                       x, y, [2, 2])
+model.cuda()
+pred = model(x.cuda())
+loss = DiceLoss()(pred, y.cuda())
+loss.backward()
+print("mfma case loss", float(loss), float(loss_o))
+for k, p in model.named_parameters():
+    ref = grads_o[k].numpy()
+    d = np.abs(p.grad.cpu().numpy() - ref).max()
+    print(f"  {k:45s} diff {d:.3e}  |ref|={np.abs(ref).max():.3e} rel {d / np.abs(ref).max():.2e}")

@@ -155,7 +155,7 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     if ev0 is not None:
         kind = ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu") + f"<{k[0]},{k[1]},{k[2]}"
         kind += (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
-        _prof_end(x, ev0, kind, 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
+        _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return y
 
 
@@ -194,7 +194,7 @@ def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, 
                                          _stream(x)), "tem_conv_unpack_wgrad")
     if ev0 is not None:
         kind = ("k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + f"<{k[0]},{k[1]},{k[2]}>(+bias,reduce,unpack)"
-        _prof_end(x, ev0, kind, 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
+        _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return dw_out
 
 
