@@ -82,10 +82,15 @@ int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Ci
  *                is zeroed where ref <= 0 (ReLU backward, threshold_backward).
  *   use_mfma:    1 = v_mfma_f32_32x32x2_f32 implicit-GEMM kernel (needs the
  *                TEM_WL_MFMA pack), 0 = VALU kernel (TEM_WL_GENERIC pack).
+ *   ws:          optional workspace of tem_conv3d_fwd_ws() bytes.  Spatially small, channel-rich
+ *                layers (the 8^3/16^3 levels) cannot fill 256 CUs with (patch x Cout-tile)
+ *                workgroups; with a workspace the MFMA kernel also splits the input channels
+ *                ("split-K") and a second tiny kernel sums the slices and applies the epilogue.
  */
+int64_t tem_conv3d_fwd_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift,
                    const float* w_packed, const float* bias, float* y, int64_t y_ld,
-                   const float* ref, int64_t ref_ld,
+                   const float* ref, int64_t ref_ld, void* ws, int64_t ws_bytes,
                    int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                    int act, int use_mfma, tem_stream_t stream);
 

@@ -40,7 +40,8 @@ def test_version_and_error_string():
     assert lib.tem_version() >= 100
     assert isinstance(lib.tem_last_error(), bytes)
     # argument validation happens before any HIP call: exercise the error path on CPU
-    rc = lib.tem_conv3d_fwd(None, 0, None, None, None, None, None, 0, None, 0, 1, 1, 1, 1, 1, 1, 3, 3, 3, 0, 0, None)
+    rc = lib.tem_conv3d_fwd(None, 0, None, None, None, None, None, 0, None, 0, None, 0, 1, 1, 1, 1, 1, 1, 3, 3, 3, 0, 0,
+                            None)
     assert rc == -1 and b"null pointer" in lib.tem_last_error()
     with pytest.raises(ValueError):
         _lib.check(rc, "tem_conv3d_fwd")

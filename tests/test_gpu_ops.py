@@ -40,6 +40,12 @@ CONV_CASES = [
     (2, 4, 8, 8, 64, 32, (1, 1, 1)),
     (1, 1, 16, 16, 32, 32, (1, 1, 1)),
     (1, 3, 5, 4, 8, 16, (3, 1, 3)),      # generic-only kernel shape
+    (2, 8, 8, 8, 128, 128, (3, 3, 3)),   # few workgroups => split-K over input channels
+    (1, 4, 8, 8, 256, 64, (1, 1, 1)),    # split-K, 1x1x1
+    (2, 9, 17, 10, 1, 32, (3, 3, 3)),    # Cin == 1 first-layer kernels
+    (1, 1, 19, 21, 1, 16, (1, 3, 3)),    # Cin == 1, 2-D
+    (2, 4, 9, 8, 32, 2, (1, 1, 1)),      # out_conv projection kernels
+    (1, 3, 8, 8, 64, 12, (1, 1, 1)),     # projection to 12 affinity channels
 ]
 
 

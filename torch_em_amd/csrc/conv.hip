@@ -116,13 +116,26 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float* __restric
             co -= Cout;
             ++v;
         }
+        float acc = bias ? bias[co] : 0.f;
+        if constexpr (KD * KH * KW == 1) {
+            const int n1 = scale ? (int)(v / ((int64_t)D * H * W)) : 0;
+            const float* xp = x + v * x_ld;
+            for (int ci = 0; ci < Cin; ++ci) {
+                float xv = xp[ci];
+                if (scale) xv = fmaf(xv, scale[(int64_t)n1 * Cin + ci], shift[(int64_t)n1 * Cin + ci]);
+                acc = fmaf(xv, w[(int64_t)ci * Cout + co], acc);
+            }
+            acc = apply_act(acc, act);
+            if (ref && !(ref[v * ref_ld + co] > 0.f)) acc = 0.f;
+            y[v * y_ld + co] = acc;
+            continue;
+        }
         int xx = (int)(v % W);
         int64_t r = v / W;
         int yy = (int)(r % H);
         r /= H;
         int zz = (int)(r % D);
         int n = (int)(r / D);
-        float acc = bias ? bias[co] : 0.f;
         const float* sc = scale ? scale + (int64_t)n * Cin : nullptr;
         const float* sf = shift ? shift + (int64_t)n * Cin : nullptr;
 #pragma unroll
@@ -213,10 +226,16 @@ static void launch_fwd_generic(const float* x, int64_t x_ld, const float* scale,
         }                                                             \
     } while (0)
 
+extern "C" int64_t tem_conv3d_fwd_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                                     int use_mfma) {
+    if (!use_mfma || Cin % 16 || Cout % 32) return 0;
+    return tem_conv_fwd_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
+}
+
 extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift,
                               const float* w_packed, const float* bias, float* y, int64_t y_ld, const float* ref,
-                              int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
-                              int act, int use_mfma, tem_stream_t stream) {
+                              int64_t ref_ld, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout,
+                              int kd, int kh, int kw, int act, int use_mfma, tem_stream_t stream) {
     TEM_REQUIRE(x && w_packed && y, "tem_conv3d_fwd: null pointer");
     TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= Cin && y_ld >= Cout,
                 "tem_conv3d_fwd: bad shape");
@@ -227,13 +246,23 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
     TEM_REQUIRE(!ref || ref_ld >= Cout, "tem_conv3d_fwd: bad ref_ld");
     hipStream_t s = (hipStream_t)stream;
     if (use_mfma) {
-        int rc = tem_conv_fwd_mfma(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout,
-                                   kd, kh, kw, act, s);
+        int rc = tem_conv_fwd_mfma(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
+                                   W, Cin, Cout, kd, kh, kw, act, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(mfma)");
         return TEM_OK;
     }
     const int64_t NV = (int64_t)N * D * H * W;
+    if (tem_conv_fwd_cin1(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, N, D, H, W, Cin, Cout, kd, kh, kw, act,
+                          s)) {
+        TEM_CHECK_LAUNCH("tem_conv3d_fwd(cin1)");
+        return TEM_OK;
+    }
+    if (kd == 1 && kh == 1 && kw == 1 &&
+        tem_conv1x1_proj(x, x_ld, scale, w_packed, bias, y, y_ld, ref, NV, Cin, Cout, act, s)) {
+        TEM_CHECK_LAUNCH("tem_conv3d_fwd(proj)");
+        return TEM_OK;
+    }
     if (kd == 1 && kh == 1 && kw == 1 && Cin % 4 == 0 && x_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) &&
         (Cout == 1 || Cout == 2 || Cout == 3 || Cout == 4 || Cout == 8 || Cout == 12 || Cout == 16)) {
         dim3 grid(tem_grid_1d(NV, 256, 256 * 16));
@@ -331,15 +360,6 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_generic(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, int nchunks, int64_t n,
-                                                         float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        double s = 0.0;
-        for (int c = 0; c < nchunks; ++c) s += (double)part[(int64_t)c * n + i];
-        out[i] = (float)s;
-    }
-}
-
 // column sums: db[co] = sum_v g[v][co]
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ g, int64_t g_ld, int64_t NV, int C,
                                                         int rows, int64_t vper, float* __restrict__ part) {
@@ -388,8 +408,9 @@ static WgradGenericPlan wgrad_generic_plan(int64_t NV, int Cin, int Cout, int nt
     p.nchunks = (int)nch;
     p.vper = tem_cdiv(NV, nch);
     p.part_floats = (int64_t)p.nchunks * ntaps * pairs;
-    int64_t dbc = tem_cdiv(NV, 256);
-    if (dbc > 1024) dbc = 1024;
+    int64_t dbc = tem_cdiv(NV, 2048);
+    if (dbc > 512) dbc = 512;
+    if (dbc < 1) dbc = 1;
     p.db_chunks = (int)dbc;
     p.db_floats = (int64_t)p.db_chunks * Cout;
     return p;
@@ -400,11 +421,16 @@ extern "C" int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int 
     int64_t NV = (int64_t)N * D * H * W;
     int ntaps = kd * kh * kw;
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
-    int64_t bytes = p.db_floats * 4;
-    if (use_mfma)
+    int64_t bytes = tem_align_up(p.db_floats, 64) * 4;
+    if (use_mfma) {
         bytes += tem_conv_wgrad_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
-    else
-        bytes += p.part_floats * 4;
+    } else {
+        int64_t b = p.part_floats * 4;
+        int64_t c1 = tem_conv_wgrad_cin1_ws(Cout, ntaps), pj = tem_conv1x1_proj_wgrad_ws(Cin, Cout);
+        if (Cin == 1 && c1 > b) b = c1;
+        if (ntaps == 1 && pj > b) b = pj;
+        bytes += b;
+    }
     return bytes + 256;
 }
 
@@ -437,27 +463,34 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
     float* dbpart = (float*)ws;
     float* rest = dbpart + tem_align_up(p.db_floats, 64);
+    if (use_mfma) {
+        int rc = tem_conv_wgrad_mfma(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
+                                     ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw, s);
+        if (rc != TEM_OK) return rc;
+        TEM_CHECK_LAUNCH("tem_conv3d_wgrad(mfma)");
+        return TEM_OK;
+    }
+    if (tem_conv_wgrad_cin1(x, x_ld, scale, shift, g, g_ld, dw, db, rest, N, D, H, W, Cin, Cout, kd, kh, kw, s)) {
+        TEM_CHECK_LAUNCH("tem_conv3d_wgrad(cin1)");
+        return TEM_OK;
+    }
+    if (ntaps == 1 && tem_conv1x1_proj_wgrad(x, x_ld, scale, g, g_ld, dw, db, rest, NV, Cin, Cout, s)) {
+        TEM_CHECK_LAUNCH("tem_conv3d_wgrad(proj)");
+        return TEM_OK;
+    }
     if (db) {
         int Cb = Cout < 256 ? Cout : 256;
         int rows = 256 / Cb;
         int64_t vper = tem_cdiv(NV, p.db_chunks);
         hipLaunchKernelGGL(k_colsum_partial, dim3(p.db_chunks), dim3(256), (size_t)rows * Cb * sizeof(float), s, g, g_ld,
                            NV, Cout, rows, vper, dbpart);
-        hipLaunchKernelGGL(k_reduce_partials, dim3(tem_grid_1d(Cout, 256)), dim3(256), 0, s, dbpart, p.db_chunks,
-                           (int64_t)Cout, db);
-    }
-    if (use_mfma) {
-        int rc = tem_conv_wgrad_mfma(x, x_ld, scale, shift, g, g_ld, dw, rest,
-                                     ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw, s);
-        if (rc != TEM_OK) return rc;
-        TEM_CHECK_LAUNCH("tem_conv3d_wgrad(mfma)");
-        return TEM_OK;
+        tem_reduce_slabs(dbpart, p.db_chunks, (int64_t)Cout, (int64_t)Cout, db, s);
     }
 #define CALL(A, B, C) launch_wgrad_generic<A, B, C>(x, x_ld, scale, shift, g, g_ld, N, D, H, W, Cin, Cout, p, rest, s)
     DISPATCH_K(kd, kh, kw, CALL);
 #undef CALL
     int64_t n = (int64_t)ntaps * Cin * Cout;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(tem_grid_1d(n, 256)), dim3(256), 0, s, rest, p.nchunks, n, dw);
+    tem_reduce_slabs(rest, p.nchunks, n, n, dw, s);
     TEM_CHECK_LAUNCH("tem_conv3d_wgrad(generic)");
     return TEM_OK;
 }

@@ -4,11 +4,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+int64_t tem_conv_fwd_mfma_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int tem_conv_fwd_mfma(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w_packed,
-                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
-                      int W, int Cin, int Cout, int kd, int kh, int kw, int act, hipStream_t s);
+                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
+                      int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
+                      hipStream_t s);
 
 int64_t tem_conv_wgrad_mfma_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int tem_conv_wgrad_mfma(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
-                        int64_t g_ld, float* dw_tap_ci_co, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
-                        int Cin, int Cout, int kd, int kh, int kw, hipStream_t s);
+                        int64_t g_ld, float* dw_tap_ci_co, float* db, void* ws, int64_t ws_bytes, int N, int D, int H,
+                        int W, int Cin, int Cout, int kd, int kh, int kw, hipStream_t s);
+
+// conv_small.hip: HBM-bound special cases (return false when the shape is not covered)
+bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
+                       const float* bias, float* y, int64_t y_ld, const float* ref, int N, int D, int H, int W,
+                       int Cin, int Cout, int kd, int kh, int kw, int act, hipStream_t s);
+int64_t tem_conv_wgrad_cin1_ws(int Cout, int ntaps);
+bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                         int64_t g_ld, float* dw, float* db, void* ws, int N, int D, int H, int W, int Cin, int Cout,
+                         int kd, int kh, int kw, hipStream_t s);
+bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const float* w, const float* bias, float* y,
+                      int64_t y_ld, const float* ref, int64_t NV, int Cin, int Cout, int act, hipStream_t s);
+int64_t tem_conv1x1_proj_wgrad_ws(int Cin, int Cout);
+bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, const float* g, int64_t g_ld, float* dw,
+                            float* db, void* ws, int64_t NV, int Cin, int Cout, hipStream_t s);
+void tem_reduce_slabs(const float* part, int nchunks, int64_t n, int64_t chunk_stride, float* out, hipStream_t s);

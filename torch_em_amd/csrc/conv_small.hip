@@ -1,0 +1,419 @@
+// conv_small.hip -- HBM-bound convolution kernels for the two ends of the U-Net where the
+// matrix cores have nothing to chew on (first conv 13 flop/B, out_conv 0.9 flop/B):
+//   * Cin == 1 first layer (forward + weight gradient; its data gradient is never needed),
+//   * 1x1x1 projection to <= 16 channels (out_conv: forward + weight gradient).
+// Each reads/writes its big tensor exactly once with 16-byte, fully coalesced accesses.
+#include "tem_common.h"
+#include "conv_internal.h"
+
+__device__ __forceinline__ float act_apply_s(float v, int act) {
+    if (act == TEM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == TEM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Cin == 1 forward.  Workgroup = 4x8x8 output patch; the (tiny) halo tile and the weights
+// live in LDS; thread <-> (voxel, 4 output channels): 27 LDS broadcasts + 27 float4 weight
+// reads + 108 FMA, one 16-byte store.
+// ---------------------------------------------------------------------------
+template <int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__ x, int64_t x_ld,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const float* __restrict__ w /*[tap][co]*/,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       int64_t y_ld, int N, int D, int H, int W, int Cout, int act,
+                                                       int nZ, int nY, int nX) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int TZ = 4, TY = 8, TX = 8;
+    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1, HV = HZ * HY * HX;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lx = lds;                       // [HV]
+    float* lw = lds + ((HV + 3) / 4) * 4;  // [NT][Cout]
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int ptx = bid % nX;
+    bid /= nX;
+    const int pty = bid % nY;
+    bid /= nY;
+    const int ptz = bid % nZ;
+    const int n = bid / nZ;
+    const int z0 = ptz * TZ, y0 = pty * TY, x0 = ptx * TX;
+    float sc = 1.f, sf = 0.f;
+    if (scale) {
+        sc = scale[n];
+        sf = shift[n];
+    }
+    for (int i = tid; i < NT * Cout; i += 256) lw[i] = w[i];
+    for (int hv = tid; hv < HV; hv += 256) {
+        const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+        const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
+        float v = 0.f;
+        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = fmaf(x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld], sc, sf);
+        lx[hv] = v;
+    }
+    __syncthreads();
+    const int cq = Cout >> 2;
+    for (int item = tid; item < 256 * cq; item += 256) {
+        const int p = item / cq, q = item % cq;
+        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+        const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+        if (gz >= D || gy >= H || gx >= W) continue;
+        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* xb = lx + (pz * HY + py) * HX + px;
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+            const float xv = xb[(tz * HY + ty) * HX + tx];
+            const float4 wv = *reinterpret_cast<const float4*>(lw + tap * Cout + q * 4);
+            acc.x = fmaf(xv, wv.x, acc.x);
+            acc.y = fmaf(xv, wv.y, acc.y);
+            acc.z = fmaf(xv, wv.z, acc.z);
+            acc.w = fmaf(xv, wv.w, acc.w);
+        }
+        acc.x = act_apply_s(acc.x, act);
+        acc.y = act_apply_s(acc.y, act);
+        acc.z = act_apply_s(acc.z, act);
+        acc.w = act_apply_s(acc.w, act);
+        const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
+        *reinterpret_cast<float4*>(y + v * y_ld + q * 4) = acc;
+    }
+}
+
+bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
+                       const float* bias, float* y, int64_t y_ld, const float* ref, int N, int D, int H, int W,
+                       int Cin, int Cout, int kd, int kh, int kw, int act, hipStream_t s) {
+    if (Cin != 1 || Cout % 4 || Cout > 128 || ref || y_ld % 4 || ((uintptr_t)y % 16) ||
+        (bias && ((uintptr_t)bias % 16)))
+        return false;
+    const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
+    if (key != 7 && key != 3) return false;
+    const int nZ = (D + 3) / 4, nY = (H + 7) / 8, nX = (W + 7) / 8;
+    const int64_t nblk = (int64_t)N * nZ * nY * nX;
+    if (key == 7) {
+        size_t ldsb = (size_t)(((6 * 10 * 10 + 3) / 4) * 4 + 27 * Cout) * sizeof(float);
+        hipLaunchKernelGGL((k_conv_fwd_cin1<3, 3, 3>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, shift,
+                           w, bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX);
+    } else {
+        size_t ldsb = (size_t)(((4 * 10 * 10 + 3) / 4) * 4 + 9 * Cout) * sizeof(float);
+        hipLaunchKernelGGL((k_conv_fwd_cin1<1, 3, 3>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, shift,
+                           w, bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Cin == 1 weight gradient: dw[tap][co] = sum_v xhat[v+tap] * g[v][co]  (+ db[co] = sum_v g).
+// Persistent workgroups walk 4x8x8 patches; thread <-> (voxel lane, co quad) keeps NT x 4
+// accumulators in registers, g is read once with 16-byte loads; one reduction at the end.
+// ---------------------------------------------------------------------------
+template <int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict__ x, int64_t x_ld,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ g, int64_t g_ld,
+                                                         float* __restrict__ part /*[grid][NT+1][Cout]*/, int N,
+                                                         int D, int H, int W, int Cout, int P, int nZ, int nY,
+                                                         int nX) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int TZ = 4, TY = 8, TX = 8;
+    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1, HV = HZ * HY * HX;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(HV, 4*(NT+1)*Cout)
+    const int tid = threadIdx.x;
+    const int cq = Cout >> 2;       // power of two, <= 16
+    const int q = tid % cq, vl = tid / cq;
+    const int nvl = 256 / cq;       // voxel lanes per workgroup
+    float4 acc[NT + 1];
+#pragma unroll
+    for (int t = 0; t <= NT; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pidx = blockIdx.x; pidx < P; pidx += gridDim.x) {
+        int b = pidx;
+        const int ptx = b % nX;
+        b /= nX;
+        const int pty = b % nY;
+        b /= nY;
+        const int ptz = b % nZ;
+        const int n = b / nZ;
+        const int z0 = ptz * TZ, y0 = pty * TY, x0 = ptx * TX;
+        float sc = 1.f, sf = 0.f;
+        if (scale) {
+            sc = scale[n];
+            sf = shift[n];
+        }
+        __syncthreads();
+        for (int hv = tid; hv < HV; hv += 256) {
+            const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+            const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
+            float v = 0.f;
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = fmaf(x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld], sc, sf);
+            lds[hv] = v;
+        }
+        __syncthreads();
+        for (int p = vl; p < 256; p += nvl) {
+            const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+            const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+            if (gz >= D || gy >= H || gx >= W) continue;
+            const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
+            const float4 gv = *reinterpret_cast<const float4*>(g + v * g_ld + q * 4);
+            const float* xb = lds + (pz * HY + py) * HX + px;
+#pragma unroll
+            for (int tap = 0; tap < NT; ++tap) {
+                const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+                const float xv = xb[(tz * HY + ty) * HX + tx];
+                acc[tap].x = fmaf(xv, gv.x, acc[tap].x);
+                acc[tap].y = fmaf(xv, gv.y, acc[tap].y);
+                acc[tap].z = fmaf(xv, gv.z, acc[tap].z);
+                acc[tap].w = fmaf(xv, gv.w, acc[tap].w);
+            }
+            acc[NT].x += gv.x;
+            acc[NT].y += gv.y;
+            acc[NT].z += gv.z;
+            acc[NT].w += gv.w;
+        }
+    }
+    // reduce over the voxel lanes: lanes sharing q inside a wave sit cq apart
+#pragma unroll
+    for (int t = 0; t <= NT; ++t) {
+        for (int o = cq; o < 64; o <<= 1) {
+            acc[t].x += __shfl_xor(acc[t].x, o, 64);
+            acc[t].y += __shfl_xor(acc[t].y, o, 64);
+            acc[t].z += __shfl_xor(acc[t].z, o, 64);
+            acc[t].w += __shfl_xor(acc[t].w, o, 64);
+        }
+    }
+    __syncthreads();
+    const int wv = tid >> 6, lane = tid & 63;
+    if (lane < cq) {
+#pragma unroll
+        for (int t = 0; t <= NT; ++t)
+            *reinterpret_cast<float4*>(lds + ((wv * (NT + 1) + t) * Cout) + lane * 4) = acc[t];
+    }
+    __syncthreads();
+    for (int i = tid; i < (NT + 1) * Cout; i += 256) {
+        float s = lds[i] + lds[(NT + 1) * Cout + i] + lds[2 * (NT + 1) * Cout + i] + lds[3 * (NT + 1) * Cout + i];
+        part[(int64_t)blockIdx.x * (NT + 1) * Cout + i] = s;
+    }
+}
+
+// out[i] = sum_c part[c][i]  (fp64 accumulation; chunk-parallel so that small n is not latency-bound)
+__global__ __launch_bounds__(512) void k_reduce_slabs(const float* __restrict__ part, int nchunks, int64_t n,
+                                                      int64_t chunk_stride, float* __restrict__ out) {
+    __shared__ double sh[8][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = i0 + tx;
+        double s = 0.0;
+        if (i < n)
+            for (int c = ty; c < nchunks; c += 8) s += (double)part[(int64_t)c * chunk_stride + i];
+        sh[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && i < n) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += sh[k][tx];
+            out[i] = (float)a;
+        }
+        __syncthreads();
+    }
+}
+
+void tem_reduce_slabs(const float* part, int nchunks, int64_t n, int64_t chunk_stride, float* out, hipStream_t s) {
+    int64_t nb = tem_cdiv(n, 64);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)nb), dim3(512), 0, s, part, nchunks, n, chunk_stride, out);
+}
+
+#define CIN1_GRID 1024
+
+int64_t tem_conv_wgrad_cin1_ws(int Cout, int ntaps) { return (int64_t)CIN1_GRID * (ntaps + 1) * Cout * 4; }
+
+bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                         int64_t g_ld, float* dw, float* db, void* ws, int N, int D, int H, int W, int Cin, int Cout,
+                         int kd, int kh, int kw, hipStream_t s) {
+    const int cq = Cout / 4;
+    if (Cin != 1 || Cout % 4 || cq > 16 || (cq & (cq - 1)) || g_ld % 4 || ((uintptr_t)g % 16)) return false;
+    const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
+    if (key != 7 && key != 3) return false;
+    const int nZ = (D + 3) / 4, nY = (H + 7) / 8, nX = (W + 7) / 8;
+    const int64_t P64 = (int64_t)N * nZ * nY * nX;
+    const int P = (int)P64;
+    const int grid = P < CIN1_GRID ? P : CIN1_GRID;
+    const int NT = kd * kh * kw;
+    float* part = (float*)ws;
+    if (key == 7) {
+        size_t ldsf = 6 * 10 * 10 > 4 * (NT + 1) * Cout ? 6 * 10 * 10 : 4 * (NT + 1) * Cout;
+        hipLaunchKernelGGL((k_conv_wgrad_cin1<3, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x, x_ld, scale,
+                           shift, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX);
+    } else {
+        size_t ldsf = 4 * 10 * 10 > 4 * (NT + 1) * Cout ? 4 * 10 * 10 : 4 * (NT + 1) * Cout;
+        hipLaunchKernelGGL((k_conv_wgrad_cin1<1, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x, x_ld, scale,
+                           shift, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX);
+    }
+    // dw[tap][ci=0][co] is exactly the first NT*Cout entries of a slab; db the last Cout
+    tem_reduce_slabs(part, grid, (int64_t)NT * Cout, (int64_t)(NT + 1) * Cout, dw, s);
+    if (db) tem_reduce_slabs(part + (int64_t)NT * Cout, grid, Cout, (int64_t)(NT + 1) * Cout, db, s);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// 1x1x1 projection to COUT <= 16 channels, Cin % 32 == 0: 8 lanes share a voxel, each reads
+// 16 bytes of its channel row (one fully coalesced 128-byte line per voxel per pass), partial
+// dot products are combined with 3 xor-shuffles.
+// ---------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv1x1_proj(const float* __restrict__ x, int64_t x_ld,
+                                                      const float* __restrict__ w /*[ci][co]*/,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      int64_t y_ld, int64_t NV, int Cin, int act) {
+    const int l8 = threadIdx.x & 7;
+    const int64_t vstride = (int64_t)gridDim.x * 32;
+    for (int64_t v = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); v < NV; v += vstride) {
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+        const float* xp = x + v * x_ld;
+        for (int c0 = l8 * 4; c0 < Cin; c0 += 32) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + c0);
+            const float xv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv[j], w[(c0 + j) * COUT + co], acc[co]);
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            acc[co] += __shfl_xor(acc[co], 1, 64);
+            acc[co] += __shfl_xor(acc[co], 2, 64);
+            acc[co] += __shfl_xor(acc[co], 4, 64);
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+            if ((co & 7) == l8) y[v * y_ld + co] = act_apply_s(acc[co] + (bias ? bias[co] : 0.f), act);
+    }
+}
+
+bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const float* w, const float* bias, float* y,
+                      int64_t y_ld, const float* ref, int64_t NV, int Cin, int Cout, int act, hipStream_t s) {
+    if (scale || ref || Cin % 32 || x_ld % 4 || ((uintptr_t)x % 16)) return false;
+    dim3 grid(tem_grid_1d(NV, 32, 256 * 16));
+#define PJ(CO)                                                                                                     \
+    case CO:                                                                                                       \
+        hipLaunchKernelGGL((k_conv1x1_proj<CO>), grid, dim3(256), 0, s, x, x_ld, w, bias, y, y_ld, NV, Cin, act);  \
+        return true;
+    switch (Cout) {
+        PJ(1) PJ(2) PJ(3) PJ(4) PJ(6) PJ(8) PJ(12) PJ(16)
+        default: return false;
+    }
+#undef PJ
+}
+
+// weight gradient of the projection: dw[ci][co] = sum_v x[v][ci] * g[v][co], db[co] = sum_v g[v][co]
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restrict__ x, int64_t x_ld,
+                                                            const float* __restrict__ g, int64_t g_ld,
+                                                            float* __restrict__ part /*[grid][Cin+1][COUT]*/,
+                                                            int64_t NV, int Cin) {
+    extern __shared__ float lds[];  // [4][Cin+1][COUT]
+    const int l8 = threadIdx.x & 7;
+    const int64_t vstride = (int64_t)gridDim.x * 32;
+    const int nj = Cin / 32;        // 16-byte pieces per lane (<= 4 supported)
+    float acc[4][4][COUT];
+    float gacc[COUT];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[a][j][co] = 0.f;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) gacc[co] = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); v < NV; v += vstride) {
+        float gv[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            gv[co] = g[v * g_ld + co];
+            gacc[co] += gv[co];
+        }
+        const float* xp = x + v * x_ld;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a < nj) {
+                const float4 t = *reinterpret_cast<const float4*>(xp + a * 32 + l8 * 4);
+                const float xv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[a][j][co] = fmaf(xv[j], gv[co], acc[a][j][co]);
+            }
+        }
+    }
+    // lanes with equal l8 inside a wave: xor 8, 16, 32
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                float t = acc[a][j][co];
+                t += __shfl_xor(t, 8, 64);
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                acc[a][j][co] = t;
+            }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        float t = gacc[co];
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        gacc[co] = t;
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slab = (Cin + 1) * COUT;
+    if (lane < 8) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < nj)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co)
+                        lds[wv * slab + (a * 32 + lane * 4 + j) * COUT + co] = acc[a][j][co];
+        if (lane == 0)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) lds[wv * slab + Cin * COUT + co] = gacc[co];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < slab; i += 256)
+        part[(int64_t)blockIdx.x * slab + i] = lds[i] + lds[slab + i] + lds[2 * slab + i] + lds[3 * slab + i];
+}
+
+#define PROJ_GRID 1024
+int64_t tem_conv1x1_proj_wgrad_ws(int Cin, int Cout) { return (int64_t)PROJ_GRID * (Cin + 1) * Cout * 4; }
+
+bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, const float* g, int64_t g_ld, float* dw,
+                            float* db, void* ws, int64_t NV, int Cin, int Cout, hipStream_t s) {
+    if (scale || Cin % 32 || Cin > 128 || x_ld % 4 || ((uintptr_t)x % 16)) return false;
+    int64_t nb = tem_cdiv(NV, 32);
+    const int grid = (int)(nb < PROJ_GRID ? nb : PROJ_GRID);
+    float* part = (float*)ws;
+    size_t ldsb = (size_t)4 * (Cin + 1) * Cout * sizeof(float);
+#define PW(CO)                                                                                                    \
+    case CO:                                                                                                      \
+        hipLaunchKernelGGL((k_conv1x1_proj_wgrad<CO>), dim3(grid), dim3(256), ldsb, s, x, x_ld, g, g_ld, part, NV, Cin); \
+        break;
+    switch (Cout) {
+        PW(1) PW(2) PW(3) PW(4)
+        default: return false;
+    }
+#undef PW
+    const int64_t slab = (int64_t)(Cin + 1) * Cout;
+    tem_reduce_slabs(part, grid, (int64_t)Cin * Cout, slab, dw, s);  // [tap=0][ci][co]
+    if (db) tem_reduce_slabs(part + (int64_t)Cin * Cout, grid, Cout, slab, db, s);
+    return true;
+}

@@ -148,10 +148,12 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     if ref is not None:
         ref_ld = _act5(ref)[5]
     lib = _lib.load()
+    nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if mfma else 0
+    ws = _workspace(nws, x.device) if nws else None
     ev0 = _prof_begin(x)
     _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
-                                  ref_ld, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma), _stream(x)),
-               "tem_conv3d_fwd")
+                                  ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma),
+                                  _stream(x)), "tem_conv3d_fwd")
     if ev0 is not None:
         kind = ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu") + f"<{k[0]},{k[1]},{k[2]}"
         kind += (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
