@@ -25,9 +25,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md:41
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # ibid. :42 (dense)
 PEAK_HBM_TBS = 8.0              # ibid. :35
 STEP_GFLOP = 5700.8             # conv fwd+bwd of cfg 2 per GPU
 STEP_GB = 25.58                 # conv-centric fp32 traffic of cfg 2 per GPU
+
+
+PRECISION_DTYPE = {
+    "fp32": "f32",
+    "mixed": "f32 (forward: exact fp32 MFMA; backward convs: fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per "
+             "product, fp32 accumulate -- gradient error vs float64 identical to exact fp32, tests/test_gpu_unet.py)",
+    "bf16x3": "bf16x3 (all MFMA convs split-bf16, fp32 accumulate)",
+}
 
 
 def cpu_baseline(max_threads):
@@ -75,16 +84,20 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--norm", default="InstanceNorm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "bf16x3"],
+                    help="MFMA conv arithmetic (default: engine default = mixed)")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table to this file")
     args = ap.parse_args()
 
     import torch.distributed as dist
     from torch_em_amd import ops
     from torch_em_amd.loss import DiceLoss
-    from torch_em_amd.model import UNet3d
+    from torch_em_amd.model import UNet3d, engine
     from torch_em_amd.multi_gpu_training import DDP
     from torch_em_amd.optim import FusedAdamW
 
+    if args.precision:
+        engine.set_precision(args.precision)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,19 +181,25 @@ def main():
             with open(args.kernel_table, "w") as f:
                 f.write("\n".join(lines) + "\n")
         dom_tag, dom = rows[0]
-        achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s
+        achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s (algorithmic: 2*MACs of the convolution)
+        split = "bf16x3" in dom_tag
+        # split-bf16 kernels execute 3 bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
         standard = (args.batch == 2 and S == 128)
         out = {
             "metric": "voxels/sec fwd+bwd, UNet3d 1x128^3 bs=2",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": PRECISION_DTYPE[engine.PRECISION], "data": "synthetic",
             "config": {"workload": f"UNet3d(1->2, initial_features=32, depth=4, norm={args.norm}) + DiceLoss, "
                                    f"zero_grad+fwd+loss+bwd+AdamW, per-GPU batch {args.batch}x1x{S}^3"
                                    + ("" if standard else " (NON-STANDARD SIZE)"),
                        "parallelism": f"dp{world}", "global_batch": world * args.batch, "final_loss": final_loss},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": dom_tag,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None, "kernel": dom_tag,
+                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (split-bf16 x3, fp32 "
+                                       "accumulate); executed-MFMA fraction of 2500 = frac" if split else
+                                       "exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                          "launches_per_step": dom["launches"] // args.steps,
                          "avg_launch_ms": dom["ms"] / dom["launches"],
                          "flops_per_launch_avg": dom["flops"] / dom["launches"]},

@@ -57,11 +57,15 @@ int tem_device_cus(void);
  *   TEM_WL_GENERIC  [tap][ci][co]                       any Cin, Cout
  *   TEM_WL_MFMA     [co/32][tap][ci/8][2][32][4]        Cin%16==0, Cout%32==0
  *                   (the B-fragment order of v_mfma_f32_32x32x2_f32)
+ *   TEM_WL_BF16X3   [co/32][tap][ci/16][hi|lo][64][8 bf16]  Cin%16==0, Cout%32==0
+ *                   (each fp32 weight split into two bf16 terms, B-fragment order of
+ *                   v_mfma_f32_32x32x16_bf16; same byte count as fp32)
  * transpose==1 packs the data-gradient operator: taps flipped, Cin<->Cout
  * swapped, so that dgrad is again a tem_conv3d_fwd call.
  */
 #define TEM_WL_GENERIC 0
 #define TEM_WL_MFMA 1
+#define TEM_WL_BF16X3 2
 #define TEM_ACT_NONE 0
 #define TEM_ACT_RELU 1
 #define TEM_ACT_SIGMOID 2
@@ -80,8 +84,11 @@ int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Ci
  *   bias:        optional [Cout].
  *   ref:         optional tensor (ld ref_ld) of y's shape; when given the result
  *                is zeroed where ref <= 0 (ReLU backward, threshold_backward).
- *   use_mfma:    1 = v_mfma_f32_32x32x2_f32 implicit-GEMM kernel (needs the
- *                TEM_WL_MFMA pack), 0 = VALU kernel (TEM_WL_GENERIC pack).
+ *   use_mfma:    1 = v_mfma_f32_32x32x2_f32 implicit-GEMM kernel, exact fp32 (needs the
+ *                TEM_WL_MFMA pack); 2 = split-bf16 kernel: every operand x = hi + lo in bf16,
+ *                products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
+ *                accumulation, ~1e-5 relative per product (needs the TEM_WL_BF16X3 pack);
+ *                0 = VALU kernel (TEM_WL_GENERIC pack).
  *   ws:          optional workspace of tem_conv3d_fwd_ws() bytes.  Spatially small, channel-rich
  *                layers (the 8^3/16^3 levels) cannot fill 256 CUs with (patch x Cout-tile)
  *                workgroups; with a workspace the MFMA kernel also splits the input channels

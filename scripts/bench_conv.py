@@ -24,16 +24,17 @@ scale = torch.rand(N, Cin, device=dev) + 0.5
 shift = torch.randn(N, Cin, device=dev)
 y = torch.empty(N, D, H, W, Cout, device=dev)
 g = torch.randn(N, D, H, W, Cout, device=dev)
-wp = ops.pack_weights(w, False, True)
+MODE = int(os.environ.get("TEM_MODE", "1"))
+wp = ops.pack_weights(w, False, MODE)
 dw = torch.empty(w.numel(), device=dev)
 db = torch.empty(Cout, device=dev)
 
 
 def run():
     if kind == "fwd":
-        ops.conv_fwd(x, wp, b, y, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=True)
+        ops.conv_fwd(x, wp, b, y, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=MODE)
     else:
-        ops.conv_wgrad(x, g, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=True)
+        ops.conv_wgrad(x, g, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=MODE)
 
 
 for _ in range(2):

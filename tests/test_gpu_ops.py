@@ -72,27 +72,28 @@ def test_conv_fwd_dgrad_wgrad(case, fused):
 
     x5 = to5(x)
     wd = w.to(DEV)
-    for mfma in ([False, True] if ops.mfma_ok(Cin, Cout, k) else [False]):
+    for mfma in ([0, 1, 2] if ops.mfma_ok(Cin, Cout, k) else [0]):
         wp = ops.pack_weights(wd, transpose=False, mfma=mfma)
         y5 = ops.new_act(N, D, H, W, Cout, DEV)
         ops.conv_fwd(x5, wp, b.to(DEV), y5, k, Cin, Cout, scale=None if scale is None else scale.to(DEV),
                      shift=None if shift is None else shift.to(DEV), act="relu" if fused else None, mfma=mfma)
-        assert rel_err(from5(y5), yr.detach()) < 2e-5, f"fwd mfma={mfma}"
+        # mode 2 = split-bf16 products (~1e-5 relative each); modes 0/1 are exact fp32 FMA chains
+        assert rel_err(from5(y5), yr.detach()) < (1e-4 if mfma == 2 else 2e-5), f"fwd mfma={mfma}"
     # gradient w.r.t. the conv input (of xhat when fused): g' = gy * (y > 0)
     gpre = gy * (yr.detach() > 0) if fused else gy
     g5 = to5(gpre)
-    for mfma in ([False, True] if ops.mfma_ok(Cout, Cin, k) else [False]):
+    for mfma in ([0, 1, 2] if ops.mfma_ok(Cout, Cin, k) else [0]):
         wpt = ops.pack_weights(wd, transpose=True, mfma=mfma)
         gx5 = ops.new_act(N, D, H, W, Cin, DEV)
         ops.conv_fwd(g5, wpt, None, gx5, k, Cout, Cin, mfma=mfma)
         exp = xr.grad / scale[:, :, None, None, None] if fused else xr.grad
-        assert rel_err(from5(gx5), exp) < 2e-5, f"dgrad mfma={mfma}"
-    for mfma in ([False, True] if ops.mfma_ok(Cin, Cout, k, wgrad=True) else [False]):
+        assert rel_err(from5(gx5), exp) < (1e-4 if mfma == 2 else 2e-5), f"dgrad mfma={mfma}"
+    for mfma in ([0, 1, 2] if ops.mfma_ok(Cin, Cout, k, wgrad=True) else [0]):
         dw = torch.empty(w.numel(), device=DEV)
         db = torch.empty(Cout, device=DEV)
         ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=None if scale is None else scale.to(DEV),
                        shift=None if shift is None else shift.to(DEV), mfma=mfma)
-        assert rel_err(dw.cpu().view(w.shape), wr.grad) < 5e-5, f"wgrad mfma={mfma}"
+        assert rel_err(dw.cpu().view(w.shape), wr.grad) < (1e-4 if mfma == 2 else 5e-5), f"wgrad mfma={mfma}"
         assert rel_err(db.cpu(), br.grad) < 5e-5, f"bgrad mfma={mfma}"
 
 

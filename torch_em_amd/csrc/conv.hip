@@ -49,6 +49,12 @@ extern "C" int tem_conv_pack_weights(const float* w, float* dst, int Cout, int C
     TEM_REQUIRE(w && dst && Cout > 0 && Cin > 0, "tem_conv_pack_weights: bad arguments");
     TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
                 "tem_conv_pack_weights: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
+    if (layout == TEM_WL_BF16X3) {
+        int rc = tem_pack_weights_bf16x3(w, dst, Cout, Cin, kd, kh, kw, transpose, (hipStream_t)stream);
+        if (rc != TEM_OK) return rc;
+        TEM_CHECK_LAUNCH("tem_conv_pack_weights(bf16x3)");
+        return TEM_OK;
+    }
     if (layout == TEM_WL_MFMA) {
         int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
         TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: MFMA layout needs Cin%%16==0, Cout%%32==0");
@@ -245,6 +251,13 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
     TEM_REQUIRE(act >= 0 && act <= 2, "tem_conv3d_fwd: Invalid activation: %d", act);
     TEM_REQUIRE(!ref || ref_ld >= Cout, "tem_conv3d_fwd: bad ref_ld");
     hipStream_t s = (hipStream_t)stream;
+    if (use_mfma == 2) {
+        int rc = tem_conv_fwd_bf16x3(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
+                                     W, Cin, Cout, kd, kh, kw, act, s);
+        if (rc != TEM_OK) return rc;
+        TEM_CHECK_LAUNCH("tem_conv3d_fwd(bf16x3)");
+        return TEM_OK;
+    }
     if (use_mfma) {
         int rc = tem_conv_fwd_mfma(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
                                    W, Cin, Cout, kd, kh, kw, act, s);
@@ -422,7 +435,9 @@ extern "C" int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int 
     int ntaps = kd * kh * kw;
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
     int64_t bytes = tem_align_up(p.db_floats, 64) * 4;
-    if (use_mfma) {
+    if (use_mfma == 2) {
+        bytes += tem_conv_wgrad_bf16x3_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
+    } else if (use_mfma) {
         bytes += tem_conv_wgrad_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
     } else {
         int64_t b = p.part_floats * 4;
@@ -463,6 +478,14 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
     float* dbpart = (float*)ws;
     float* rest = dbpart + tem_align_up(p.db_floats, 64);
+    if (use_mfma == 2) {
+        int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
+                                       ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
+                                       s);
+        if (rc != TEM_OK) return rc;
+        TEM_CHECK_LAUNCH("tem_conv3d_wgrad(bf16x3)");
+        return TEM_OK;
+    }
     if (use_mfma) {
         int rc = tem_conv_wgrad_mfma(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                      ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw, s);

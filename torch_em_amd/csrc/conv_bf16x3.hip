@@ -1,0 +1,684 @@
+// conv_bf16x3.hip -- implicit-GEMM 3-D convolution on the bf16 matrix cores with fp32-class accuracy:
+// every fp32 operand is split into two bf16 terms (x = hi + lo, residual <= 2^-18 |x|) and each
+// product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+// (the dropped lo*lo term is <= 2^-18 of the product).  Per product that is ~1e-5 relative error,
+// random in sign, i.e. ~1e-6..1e-5 on a K >= 432 dot product -- two orders inside the 1e-3 parity
+// tolerance of the path -- at 3/16 of the exact-fp32 MFMA cost (2.5 PFLOP/s bf16 peak / 3 = 833
+// TFLOP/s effective vs 157 TFLOP/s).  Same data flow as conv_mfma.hip (fp32 NDHWC activations in HBM,
+// fused pre-norm while staging, bias/ReLU/mask epilogue, split-K for the small levels); the split into
+// hi/lo happens once per staged element on the way into LDS, and once per weight at pack time.
+#include "tem_common.h"
+#include "conv_internal.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define BCK 16   // input channels per staged chunk = K of one MFMA
+#define BLS 20   // LDS floats per halo voxel: 16 hi bf16 (32 B) + 16 lo bf16 (32 B) + 16 B pad
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32, round-to-nearest-even
+    return __builtin_bit_cast(unsigned, v);
+}
+// (hi, lo) split of two floats: hi = bf16(x), lo = bf16(x - hi)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pk_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, hi << 16);
+    const float rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pk_bf16(ra, rb);
+}
+__device__ __forceinline__ float act_apply_b(float v, int act) {
+    if (act == TEM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == TEM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// weight packing: [Cout][Cin][kd][kh][kw] fp32 -> [co/32][tap][ci/16][hi|lo][64 lanes][8 bf16]
+// lane = kh*32 + col, slot j <-> input channel (ci/16)*16 + kh*8 + j  (the B fragment of 32x32x16)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_weights_bf16x3(const float* __restrict__ w, unsigned short* __restrict__ dst,
+                                                             int Cout, int Cin, int KD, int KH, int KW, int transpose) {
+    const int ntaps = KD * KH * KW;
+    const int64_t total = (int64_t)Cout * Cin * ntaps;
+    const int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int co = (int)(i % CoutL);
+        int64_t r = i / CoutL;
+        int ci = (int)(r % CinL);
+        int tap = (int)(r / CinL);
+        int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+        float val;
+        if (!transpose)
+            val = w[(((int64_t)co * Cin + ci) * KD + tz) * KH * KW + ty * KW + tx];
+        else
+            val = w[(((int64_t)ci * Cin + co) * KD + (KD - 1 - tz)) * KH * KW + (KH - 1 - ty) * KW + (KW - 1 - tx)];
+        unsigned hi, lo;
+        split2(val, 0.f, hi, lo);
+        const int nt = co >> 5, col = co & 31, c16 = ci >> 4, kh = (ci >> 3) & 1, j = ci & 7;
+        const int64_t base = ((((int64_t)nt * ntaps + tap) * (CinL >> 4) + c16) * 2) * 512;  // 512 bf16 per (hi|lo) fragment
+        dst[base + (kh * 32 + col) * 8 + j] = (unsigned short)(hi & 0xffff);
+        dst[base + 512 + (kh * 32 + col) * 8 + j] = (unsigned short)(lo & 0xffff);
+    }
+}
+
+int tem_pack_weights_bf16x3(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw, int transpose,
+                            hipStream_t s) {
+    int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
+    TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: bf16x3 layout needs Cin%%16==0, Cout%%32==0");
+    int64_t total = (int64_t)Cout * Cin * kd * kh * kw;
+    hipLaunchKernelGGL(k_pack_weights_bf16x3, dim3(tem_grid_1d(total, 256)), dim3(256), 0, s, w, (unsigned short*)dst,
+                       Cout, Cin, kd, kh, kw, transpose);
+    return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// forward / dgrad
+// ---------------------------------------------------------------------------
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR>
+__global__ __launch_bounds__(256, NR == 2 ? 2 : 3) void k_conv_fwd_bf16x3(
+    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
+    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
+    int nY, int nX, int ksplit, float* __restrict__ part) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
+    constexpr int HV = HZ * HY * HX;
+    constexpr int NIT = (HV * 4 + 255) / 256;
+    constexpr int RD = (NT % 3 == 0) ? 3 : 1;  // weight-fragment ring depth over taps
+    static_assert(TZ * TY * TX == 256, "patch must hold 256 voxels");
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [HV][BLS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kh = lane >> 5, r = lane & 31;
+
+    int bid = tem_xcd_remap(blockIdx.x, gridDim.x);
+    const int ncot = Cout / (32 * NR);
+    const int cot = bid % ncot;
+    bid /= ncot;
+    const int ptx = bid % nX;
+    bid /= nX;
+    const int pty = bid % nY;
+    bid /= nY;
+    const int ptz = bid % nZ;
+    bid /= nZ;
+    const int n = bid % N;
+    const int ks = bid / N;
+    const int z0 = ptz * TZ, y0 = pty * TY, x0 = ptx * TX;
+
+    int abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int p = wv * 64 + m * 32 + r;
+        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+        abase[m] = ((pz * HY + py) * HX + px) * BLS + kh * 4;  // + 8 floats (32 B) for the lo half
+    }
+    floatx16 acc[2][NR];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
+
+    const int cin16 = Cin >> 4;
+    const int c4 = tid & 3;
+    const int cpk = cin16 / ksplit;
+    const int chunk_begin = ks * cpk, chunk_end = (ks + 1) * cpk;
+    // uint4 index of this lane's slot: ((((nt*NT + tap)*cin16 + c16)*2 + hl)*64 + lane)
+    const int tapstride = cin16 * 128;
+    const uint4* wq[NR];
+#pragma unroll
+    for (int nn = 0; nn < NR; ++nn) wq[nn] = wp + (int64_t)(cot * NR + nn) * NT * cin16 * 128 + lane;
+    uint4 bq[RD][NR][2];
+    if (RD > 1) {
+#pragma unroll
+        for (int gp = 0; gp < RD - 1; ++gp)
+#pragma unroll
+            for (int nn = 0; nn < NR; ++nn) {
+                bq[gp][nn][0] = wq[nn][(int64_t)chunk_begin * 128 + gp * tapstride];
+                bq[gp][nn][1] = wq[nn][(int64_t)chunk_begin * 128 + gp * tapstride + 64];
+            }
+    }
+    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+        // ---- stage: global fp32 -> fused pre-norm -> (hi, lo) bf16 -> LDS ----
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) {
+            sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + chunk * BCK + c4 * 4);
+            sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + chunk * BCK + c4 * 4);
+        }
+        float4 tmp[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int hv = (tid + it * 256) >> 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hv < HV) {
+                const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+                const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
+                if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    v = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld +
+                                                         chunk * BCK + c4 * 4);
+                    v.x = fmaf(v.x, sc4.x, sf4.x);
+                    v.y = fmaf(v.y, sc4.y, sf4.y);
+                    v.z = fmaf(v.z, sc4.z, sf4.z);
+                    v.w = fmaf(v.w, sc4.w, sf4.w);
+                }
+            }
+            tmp[it] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int hv = (tid + it * 256) >> 2;
+            if (hv < HV) {
+                unsigned h0, l0, h1, l1;
+                split2(tmp[it].x, tmp[it].y, h0, l0);
+                split2(tmp[it].z, tmp[it].w, h1, l1);
+                *reinterpret_cast<uint2*>(lds + hv * BLS + c4 * 2) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(lds + hv * BLS + 8 + c4 * 2) = make_uint2(l0, l1);
+            }
+        }
+        __syncthreads();
+
+        int ts = tapstride;
+        asm volatile("" : "+s"(ts));
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+            const int toff = ((tz * HY + ty) * HX + tx) * BLS;
+            if (RD > 1) {
+                const int gp = tap + RD - 1;
+                if (gp < NT) {
+#pragma unroll
+                    for (int nn = 0; nn < NR; ++nn) {
+                        bq[gp % RD][nn][0] = wq[nn][(int64_t)chunk * 128 + (int64_t)gp * ts];
+                        bq[gp % RD][nn][1] = wq[nn][(int64_t)chunk * 128 + (int64_t)gp * ts + 64];
+                    }
+                } else if (chunk + 1 < chunk_end) {
+#pragma unroll
+                    for (int nn = 0; nn < NR; ++nn) {
+                        bq[gp % RD][nn][0] = wq[nn][(int64_t)(chunk + 1) * 128 + (int64_t)(gp - NT) * ts];
+                        bq[gp % RD][nn][1] = wq[nn][(int64_t)(chunk + 1) * 128 + (int64_t)(gp - NT) * ts + 64];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0x38F);
+            } else {
+#pragma unroll
+                for (int nn = 0; nn < NR; ++nn) {
+                    bq[0][nn][0] = wq[nn][(int64_t)chunk * 128 + (int64_t)tap * ts];
+                    bq[0][nn][1] = wq[nn][(int64_t)chunk * 128 + (int64_t)tap * ts + 64];
+                }
+            }
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + toff));
+                al[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + toff + 8));
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NR; ++nn) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[tap % RD][nn][0]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[tap % RD][nn][1]);
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][nn], 0, 0, 0);
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][nn], 0, 0, 0);
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][nn], 0, 0, 0);
+                }
+        }
+    }
+
+#pragma unroll
+    for (int nn = 0; nn < NR; ++nn) {
+        const int co = (cot * NR + nn) * 32 + r;
+        const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                const int p = wv * 64 + m * 32 + row;
+                const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+                const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+                if (gz < D && gy < H && gx < W) {
+                    const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
+                    if (ksplit > 1) {
+                        part[((int64_t)ks * N * D * H * W + v) * Cout + co] = acc[m][nn][reg];
+                        continue;
+                    }
+                    float o = act_apply_b(acc[m][nn][reg] + bv, act);
+                    if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
+                    y[v * y_ld + co] = o;
+                }
+            }
+        }
+    }
+}
+
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR>
+static void launch_b(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                     const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
+                     int W, int Cin, int Cout, int act, int ksplit, float* part, hipStream_t s) {
+    constexpr int HV = (TZ + KD - 1) * (TY + KH - 1) * (TX + KW - 1);
+    const int nZ = (D + TZ - 1) / TZ, nY = (H + TY - 1) / TY, nX = (W + TX - 1) / TX;
+    const int64_t nblk = (int64_t)N * nZ * nY * nX * (Cout / (32 * NR)) * ksplit;
+    size_t ldsb = (size_t)HV * BLS * sizeof(float);
+    hipLaunchKernelGGL((k_conv_fwd_bf16x3<KD, KH, KW, TZ, TY, TX, NR>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld,
+                       scale, shift, reinterpret_cast<const uint4*>(wp), bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout,
+                       act, nZ, nY, nX, ksplit, part);
+    if (ksplit > 1) {
+        const int64_t NV = (int64_t)N * D * H * W;
+        tem_splitk_epilogue(part, ksplit, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
+    }
+}
+
+int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                        const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
+                        int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
+                        hipStream_t s) {
+    TEM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0, "tem_conv3d_fwd(bf16x3): needs Cin%%16==0 and Cout%%32==0 (got %d,%d)",
+                Cin, Cout);
+    TEM_REQUIRE(x_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)wp % 16 == 0),
+                "tem_conv3d_fwd(bf16x3): x / packed weights must be 16-byte aligned with ld%%4==0");
+    TEM_REQUIRE(!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)),
+                "tem_conv3d_fwd(bf16x3): scale/shift must be 16-byte aligned");
+    const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
+    const bool flat = (D == 1 && kd == 1);
+    const int TZ = flat ? 1 : 4, TY = flat ? 16 : 8, TX = flat ? 16 : 8;
+    const bool nr2 = (Cout % 64 == 0);
+    const int64_t nblk0 = (int64_t)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX) * (Cout / (nr2 ? 64 : 32));
+    int ks = tem_fwd_ksplit(nblk0, Cin / BCK);
+    const bool vec_ok = (y_ld % 4 == 0) && ((uintptr_t)y % 16 == 0) &&
+                        (!ref || (ref_ld % 4 == 0 && (uintptr_t)ref % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0);
+    if (ks > 1 && (!ws || !vec_ok || ws_bytes < (int64_t)ks * N * D * H * W * Cout * 4)) ks = 1;
+    float* part = (float*)ws;
+#define GO(KD, KH, KW, TZ, TY, TX)                                                                               \
+    do {                                                                                                         \
+        if (nr2)                                                                                                 \
+            launch_b<KD, KH, KW, TZ, TY, TX, 2>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
+                                                Cin, Cout, act, ks, part, s);                                    \
+        else                                                                                                     \
+            launch_b<KD, KH, KW, TZ, TY, TX, 1>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
+                                                Cin, Cout, act, ks, part, s);                                    \
+    } while (0)
+    if (key == 7) {
+        GO(3, 3, 3, 4, 8, 8);
+    } else if (key == 3) {
+        if (flat)
+            GO(1, 3, 3, 1, 16, 16);
+        else
+            GO(1, 3, 3, 4, 8, 8);
+    } else if (key == 0) {
+        if (flat)
+            GO(1, 1, 1, 1, 16, 16);
+        else
+            GO(1, 1, 1, 4, 8, 8);
+    } else {
+        tem_set_error("tem_conv3d_fwd(bf16x3): kernel (%d,%d,%d) has no MFMA instantiation", kd, kh, kw);
+        return TEM_EINVAL;
+    }
+#undef GO
+    return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient on the bf16 matrix cores (split-bf16, fp32 accumulate)
+//   dw[tap][ci][co] = sum_v xhat[v+tap][ci] * g[v][co]
+// GEMM view per tap: M = ci (32), N = co (32), K = voxels; v_mfma_f32_32x32x16_bf16 wants 8
+// consecutive k per lane, i.e. 8 voxels of ONE channel -- the transpose of the NDHWC layout.  The
+// transpose is paid once per staged element: x halo tile and g tile are written to LDS channel-major
+// ([ci][halo row][16 slots] / [co][128 voxels], bf16 hi and lo planes).  A k-slab is two x-rows of
+// 8 voxels (lane half kh takes one row each), so the B fragment is one aligned ds_read_b128 and the
+// A fragment of tap (tz,ty,tx) is the 8-element window starting at slot tx of halo row
+// (z+tz, y+ty): one row read (b128 + b32) serves the three tx taps, tx=1 via v_alignbyte.
+// The three tx accumulators of a (tz,ty) "row group" stay in one wave; row groups x Cout tiles are
+// dealt to the 4 waves.  One workgroup per CU (about 100 KB LDS, up to 512 VGPRs/wave): the next
+// patch's global loads are issued before the MFMAs of the current one.  Split over patch ranges,
+// partial slabs merged by the deterministic fp64 reduction (tem_reduce_slabs).
+// ---------------------------------------------------------------------------
+#define WB_TZ 2
+#define WB_TY 8
+#define WB_TX 8
+#define WB_PV (WB_TZ * WB_TY * WB_TX)   // 128 patch voxels = 8 k-slabs
+#define WB_GS 272                        // bytes per co row of Gt: 128 bf16 + 16 pad
+
+template <int KD, int KH, int KW, int NCO>
+__global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __restrict__ x, int64_t x_ld,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ g, int64_t g_ld,
+                                                              float* __restrict__ part, float* __restrict__ dbpart,
+                                                              int N, int D, int H, int W, int Cin, int Cout, int T,
+                                                              int S, int P, int nZ, int nY, int nX) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int NRG = KD * KH;  // row groups (tz, ty)
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int HZ = WB_TZ + KD - 1, HY = WB_TY + KH - 1, HX = WB_TX + KW - 1;
+    constexpr int ROWS = HZ * HY;
+    constexpr int CIS = ROWS * 32 + 16;          // bytes per ci plane of Xt (padded: conflict-free b128 reads)
+    constexpr int XPL = 32 * CIS;                // bytes per (hi|lo) plane of Xt
+    constexpr int GC = 32 * NCO;
+    constexpr int GPL = GC * WB_GS;              // bytes per (hi|lo) plane of Gt
+    constexpr int XPAIRS = HX / 2;               // x-adjacent voxel pairs per halo row
+    constexpr int XITEMS = ROWS * XPAIRS * 8;    // (row, pair, channel quad)
+    constexpr int XIT = (XITEMS + 255) / 256;
+    constexpr int GITEMS = 16 * 4 * (GC / 4);    // (patch row, pair, channel quad)
+    constexpr int GIT = GITEMS / 256;
+    constexpr int MAXU = (NRG * NCO + 3) / 4;    // row-group x co-tile units per wave
+    static_assert(GITEMS % 256 == 0, "g staging items");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char* Xh = ldsb;
+    unsigned char* Xl = ldsb + XPL;
+    unsigned char* Gh = ldsb + 2 * XPL;
+    unsigned char* Gl = Gh + GPL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kh = lane >> 5, r = lane & 31;
+    const int bid = tem_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid % T, sp = bid / T;
+    const int ncit = Cin >> 5;
+    const int cit = tile % ncit, cog = tile / ncit;
+    int nco_here = (Cout >> 5) - cog * NCO;
+    if (nco_here > NCO) nco_here = NCO;
+    const int U = NRG * nco_here;
+
+    floatx16 acc[MAXU][KW];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+#pragma unroll
+        for (int t = 0; t < KW; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][t][k] = 0.f;
+
+    const int p_lo = (int)(((int64_t)sp * P) / S), p_hi = (int)(((int64_t)(sp + 1) * P) / S);
+    const bool do_db = (dbpart != nullptr) && (cit == 0);
+    float dbacc[GIT][4];
+#pragma unroll
+    for (int it = 0; it < GIT; ++it)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dbacc[it][c] = 0.f;
+
+    float4 xa[XIT], xb[XIT], ga[GIT], gb[GIT];
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned inbA = 0, inbB = 0;
+    const int xcq = tid & 7;                 // channel quad of this thread's X items (256 % 8 == 0)
+
+#define WB_LOAD(PIDX)                                                                                              \
+    do {                                                                                                           \
+        int q_ = (PIDX);                                                                                           \
+        const int ptx_ = q_ % nX; q_ /= nX;                                                                        \
+        const int pty_ = q_ % nY; q_ /= nY;                                                                        \
+        const int ptz_ = q_ % nZ;                                                                                  \
+        const int n_ = q_ / nZ;                                                                                    \
+        const int z0_ = ptz_ * WB_TZ, y0_ = pty_ * WB_TY, x0_ = ptx_ * WB_TX;                                      \
+        if (scale) {                                                                                               \
+            sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n_ * Cin + cit * 32 + xcq * 4);                \
+            sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n_ * Cin + cit * 32 + xcq * 4);                \
+        }                                                                                                          \
+        inbA = 0; inbB = 0;                                                                                        \
+        _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                       \
+            const int item = tid + it * 256;                                                                       \
+            const int rp = item >> 3;                                                                              \
+            xa[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+            xb[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+            if (rp < ROWS * XPAIRS) {                                                                              \
+                const int row = rp / XPAIRS, pr = rp % XPAIRS;                                                     \
+                const int gz = z0_ + row / HY - PZ, gy = y0_ + row % HY - PY, gx = x0_ + 2 * pr - PX;              \
+                if (gz >= 0 && gz < D && gy >= 0 && gy < H) {                                                      \
+                    const float* rowp = x + (((int64_t)n_ * D + gz) * H + gy) * W * x_ld + cit * 32 + xcq * 4;     \
+                    if (gx >= 0 && gx < W) { xa[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * x_ld); inbA |= 1u << it; } \
+                    if (gx + 1 >= 0 && gx + 1 < W) { xb[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * x_ld); inbB |= 1u << it; } \
+                }                                                                                                  \
+            }                                                                                                      \
+        }                                                                                                          \
+        _Pragma("unroll") for (int it = 0; it < GIT; ++it) {                                                       \
+            const int item = tid + it * 256;                                                                       \
+            const int cq = item % (GC / 4), rp = item / (GC / 4);                                                  \
+            const int prow = rp >> 2, pr = rp & 3;                                                                 \
+            const int gz = z0_ + prow / WB_TY, gy = y0_ + prow % WB_TY, gx = x0_ + 2 * pr;                         \
+            ga[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+            gb[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+            if (gz < D && gy < H && cq < nco_here * 8) {                                                           \
+                const float* rowp = g + (((int64_t)n_ * D + gz) * H + gy) * W * g_ld + cog * NCO * 32 + cq * 4;    \
+                if (gx < W) ga[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * g_ld);                  \
+                if (gx + 1 < W) gb[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * g_ld);        \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+
+    if (p_lo < p_hi) WB_LOAD(p_lo);
+    for (int pidx = p_lo; pidx < p_hi; ++pidx) {
+        __syncthreads();  // previous patch's fragment reads are done
+        // ---- registers -> LDS: fused pre-norm, hi/lo split, transpose (two x-neighbours per 32-bit store) ----
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int item = tid + it * 256;
+            const int rp = item >> 3;
+            if (rp < ROWS * XPAIRS) {
+                const int row = rp / XPAIRS, pr = rp % XPAIRS;
+                float a[4] = {xa[it].x, xa[it].y, xa[it].z, xa[it].w}, b[4] = {xb[it].x, xb[it].y, xb[it].z, xb[it].w};
+                const float s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, f4[4] = {sf4.x, sf4.y, sf4.z, sf4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float va = (inbA & (1u << it)) ? fmaf(a[c], s4[c], f4[c]) : 0.f;
+                    const float vb = (inbB & (1u << it)) ? fmaf(b[c], s4[c], f4[c]) : 0.f;
+                    unsigned hi, lo;
+                    split2(va, vb, hi, lo);
+                    const int off = (xcq * 4 + c) * CIS + row * 32 + pr * 4;
+                    *reinterpret_cast<unsigned*>(Xh + off) = hi;
+                    *reinterpret_cast<unsigned*>(Xl + off) = lo;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < GIT; ++it) {
+            const int item = tid + it * 256;
+            const int cq = item % (GC / 4), rp = item / (GC / 4);
+            const int prow = rp >> 2, pr = rp & 3;
+            const float a[4] = {ga[it].x, ga[it].y, ga[it].z, ga[it].w}, b[4] = {gb[it].x, gb[it].y, gb[it].z, gb[it].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned hi, lo;
+                split2(a[c], b[c], hi, lo);
+                const int off = (cq * 4 + c) * WB_GS + (prow * 8 + pr * 2) * 2;
+                *reinterpret_cast<unsigned*>(Gh + off) = hi;
+                *reinterpret_cast<unsigned*>(Gl + off) = lo;
+                dbacc[it][c] += a[c] + b[c];
+            }
+        }
+        __syncthreads();
+        if (pidx + 1 < p_hi) WB_LOAD(pidx + 1);  // in flight during the MFMAs below
+
+        // ---- MFMA: 8 k-slabs of 16 voxels ----
+#pragma unroll 2
+        for (int s = 0; s < 8; ++s) {
+            const int prow = 2 * s + kh;                    // this lane half's patch row
+            const int pz = prow / WB_TY, py = prow % WB_TY;
+#pragma unroll
+            for (int i = 0; i < MAXU; ++i) {
+                const int u = wv + 4 * i;
+                if (u < U) {
+                    const int rg = u % NRG, ct = u / NRG;
+                    const int tz = rg / KH, ty = rg % KH;
+                    const int goff = (ct * 32 + r) * WB_GS + prow * 16;
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gh + goff));
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gl + goff));
+                    const int xoff = r * CIS + ((pz + tz) * HY + (py + ty)) * 32;
+                    const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
+                    const uint4 wl = *reinterpret_cast<const uint4*>(Xl + xoff);
+                    unsigned wh4 = 0, wl4 = 0;
+                    if (KW == 3) {
+                        wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
+                        wl4 = *reinterpret_cast<const unsigned*>(Xl + xoff + 16);
+                    }
+#pragma unroll
+                    for (int tx = 0; tx < KW; ++tx) {
+                        uint4 fh, fl;
+                        if (tx == 0) {
+                            fh = wh;
+                            fl = wl;
+                        } else if (tx == 1) {
+                            fh = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
+                                            __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
+                            fl = make_uint4(__builtin_amdgcn_alignbyte(wl.y, wl.x, 2), __builtin_amdgcn_alignbyte(wl.z, wl.y, 2),
+                                            __builtin_amdgcn_alignbyte(wl.w, wl.z, 2), __builtin_amdgcn_alignbyte(wl4, wl.w, 2));
+                        } else {
+                            fh = make_uint4(wh.y, wh.z, wh.w, wh4);
+                            fl = make_uint4(wl.y, wl.z, wl.w, wl4);
+                        }
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, fh), al = __builtin_bit_cast(bf16x8, fl);
+                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][tx], 0, 0, 0);
+                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][tx], 0, 0, 0);
+                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][tx], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#undef WB_LOAD
+
+    // ---- bias-gradient partial of this workgroup ----
+    if (do_db) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(ldsb);  // [256 / (GC/4)][GC]
+#pragma unroll
+        for (int it = 0; it < GIT; ++it) {
+            const int item = tid + it * 256;
+            const int cq = item % (GC / 4), rp = item / (GC / 4);
+            // contributions of the GIT items of one thread share cq; fold them into slot rp % (256/(GC/4))
+            if (it == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < GIT; ++j) a += dbacc[j][c];
+                    red[(rp % (256 / (GC / 4))) * GC + cq * 4 + c] = a;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < nco_here * 32) {
+            float a = 0.f;
+            for (int rr = 0; rr < 256 / (GC / 4); ++rr) a += red[rr * GC + tid];
+            dbpart[(int64_t)sp * Cout + cog * NCO * 32 + tid] = a;
+        }
+    }
+    // ---- partial slab: D[row = ci][col = co] ----
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = wv + 4 * i;
+        if (u < U) {
+            const int rg = u % NRG, ct = u / NRG;
+#pragma unroll
+            for (int tx = 0; tx < KW; ++tx) {
+                const int tap = rg * KW + tx;
+                float* dst = part + (((int64_t)sp * NT + tap) * Cin + cit * 32) * Cout + (cog * NCO + ct) * 32 + r;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    dst[(int64_t)row * Cout] = acc[i][tx][reg];
+                }
+            }
+        }
+    }
+}
+
+struct WbPlan {
+    int nco, T, S, P, nZ, nY, nX;
+};
+
+static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) {
+    WbPlan p;
+    const int ncot = Cout / 32;
+    p.nco = (ntaps == 1) ? (ncot >= 4 ? 4 : (ncot >= 2 ? 2 : 1)) : (ncot >= 2 ? 2 : 1);
+    int ngroups = (ncot + p.nco - 1) / p.nco;
+    p.T = (Cin / 32) * ngroups;
+    p.nZ = (D + WB_TZ - 1) / WB_TZ;
+    p.nY = (H + WB_TY - 1) / WB_TY;
+    p.nX = (W + WB_TX - 1) / WB_TX;
+    int64_t P = (int64_t)N * p.nZ * p.nY * p.nX;
+    p.P = (int)P;
+    int64_t S = (768 + p.T - 1) / p.T;  // one workgroup per CU: ~3 waves of workgroups
+    int64_t slab = (int64_t)ntaps * Cin * Cout * 4;
+    int64_t cap = (256ll << 20) / slab;
+    if (cap < 1) cap = 1;
+    if (S > cap) S = cap;
+    if (S > P) S = P;
+    if (S < 1) S = 1;
+    p.S = (int)S;
+    return p;
+}
+
+int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    WbPlan p = wb_plan(N, D, H, W, Cin, Cout, kd * kh * kw);
+    return tem_align_up((int64_t)p.S * kd * kh * kw * Cin * Cout, 64) * 4 + (int64_t)p.S * Cout * 4 + 256;
+}
+
+template <int KD, int KH, int KW, int NCO>
+static void launch_wb(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
+                      float* part, float* dbpart, int N, int D, int H, int W, int Cin, int Cout, const WbPlan& p,
+                      hipStream_t s) {
+    constexpr int ROWS = (WB_TZ + KD - 1) * (WB_TY + KH - 1);
+    constexpr size_t ldsbytes = 2 * (size_t)32 * (ROWS * 32 + 16) + 2 * (size_t)32 * NCO * WB_GS;
+    static_assert(ldsbytes <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_bf16x3<KD, KH, KW, NCO>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_conv_wgrad_bf16x3<KD, KH, KW, NCO>), dim3((unsigned)(p.T * p.S)), dim3(256), ldsbytes, s, x,
+                       x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p.T, p.S, p.P, p.nZ, p.nY, p.nX);
+}
+
+int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                          int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
+                          int Cin, int Cout, int kd, int kh, int kw, hipStream_t s) {
+    TEM_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "tem_conv3d_wgrad(bf16x3): needs Cin%%32==0 and Cout%%32==0 (got %d,%d)",
+                Cin, Cout);
+    TEM_REQUIRE(x_ld % 4 == 0 && g_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0),
+                "tem_conv3d_wgrad(bf16x3): x / g must be 16-byte aligned with ld%%4==0");
+    TEM_REQUIRE(!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)),
+                "tem_conv3d_wgrad(bf16x3): scale/shift must be 16-byte aligned");
+    const int ntaps = kd * kh * kw;
+    WbPlan p = wb_plan(N, D, H, W, Cin, Cout, ntaps);
+    if (ws_bytes < tem_conv_wgrad_bf16x3_ws(N, D, H, W, Cin, Cout, kd, kh, kw)) {
+        tem_set_error("tem_conv3d_wgrad(bf16x3): workspace too small");
+        return TEM_EWS;
+    }
+    float* part = (float*)ws;
+    float* dbpart = db ? part + tem_align_up((int64_t)p.S * ntaps * Cin * Cout, 64) : nullptr;
+    const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
+#define WGO(KD, KH, KW)                                                                                              \
+    do {                                                                                                             \
+        if (p.nco == 4)                                                                                              \
+            launch_wb<KD, KH, KW, 4>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);     \
+        else if (p.nco == 2)                                                                                         \
+            launch_wb<KD, KH, KW, 2>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);     \
+        else                                                                                                         \
+            launch_wb<KD, KH, KW, 1>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);     \
+    } while (0)
+    if (key == 7) {
+        if (p.nco == 2)
+            launch_wb<3, 3, 3, 2>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
+        else
+            launch_wb<3, 3, 3, 1>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
+    } else if (key == 3) {
+        if (p.nco == 2)
+            launch_wb<1, 3, 3, 2>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
+        else
+            launch_wb<1, 3, 3, 1>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
+    } else if (key == 0) {
+        WGO(1, 1, 1);
+    } else {
+        tem_set_error("tem_conv3d_wgrad(bf16x3): kernel (%d,%d,%d) has no MFMA instantiation", kd, kh, kw);
+        return TEM_EINVAL;
+    }
+#undef WGO
+    const int64_t n = (int64_t)ntaps * Cin * Cout;
+    tem_reduce_slabs(part, p.S, n, n, dw, s);
+    if (db) tem_reduce_slabs(dbpart, p.S, Cout, Cout, db, s);
+    return TEM_OK;
+}

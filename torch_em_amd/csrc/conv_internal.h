@@ -29,3 +29,19 @@ int64_t tem_conv1x1_proj_wgrad_ws(int Cin, int Cout);
 bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, const float* g, int64_t g_ld, float* dw,
                             float* db, void* ws, int64_t NV, int Cin, int Cout, hipStream_t s);
 void tem_reduce_slabs(const float* part, int nchunks, int64_t n, int64_t chunk_stride, float* out, hipStream_t s);
+
+// conv_bf16x3.hip: split-bf16 ("bf16x3") MFMA path
+int tem_pack_weights_bf16x3(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw, int transpose,
+                            hipStream_t s);
+int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                        const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
+                        int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
+                        hipStream_t s);
+// shared with conv_mfma.hip
+int tem_fwd_ksplit(int64_t nblk, int nchunks);
+void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, const float* bias, int act,
+                         const float* ref, int64_t ref_ld, float* y, int64_t y_ld, hipStream_t s);
+int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
+int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                          int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
+                          int Cin, int Cout, int kd, int kh, int kw, hipStream_t s);

@@ -678,13 +678,19 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
 
 // Split the input channels over `ks` workgroups when the (patches x Cout tiles) grid cannot fill
 // 256 CUs: 8^3 and 16^3 levels of the U-Net (1% of the FLOPs, 30% of the time without it).
-static int fwd_ksplit(int64_t nblk, int nchunks) {
+int tem_fwd_ksplit(int64_t nblk, int nchunks) {
     if (nblk >= 384) return 1;
     int64_t target = (768 + nblk - 1) / nblk;
     int ks = 1;
     for (int d = 1; d <= nchunks; ++d)
         if (nchunks % d == 0 && d <= target) ks = d;
     return ks;
+}
+
+void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, const float* bias, int act,
+                         const float* ref, int64_t ref_ld, float* y, int64_t y_ld, hipStream_t s) {
+    hipLaunchKernelGGL(k_splitk_epilogue, dim3(tem_grid_1d(NV * (Cout / 4), 256)), dim3(256), 0, s, part, ksplit, NV, Cout,
+                       bias, act, ref, ref_ld, y, y_ld);
 }
 
 static void fwd_geometry(int N, int D, int H, int W, int Cout, int kd, bool& flat, int& TZ, int& TY, int& TX, int& NR,
@@ -704,7 +710,7 @@ int64_t tem_conv_fwd_mfma_ws(int N, int D, int H, int W, int Cin, int Cout, int 
     int TZ, TY, TX, NR;
     int64_t nblk;
     fwd_geometry(N, D, H, W, Cout, kd, flat, TZ, TY, TX, NR, nblk);
-    int ks = fwd_ksplit(nblk, Cin / CK);
+    int ks = tem_fwd_ksplit(nblk, Cin / CK);
     return ks > 1 ? (int64_t)ks * N * D * H * W * Cout * 4 : 0;
 }
 
@@ -780,7 +786,7 @@ int tem_conv_fwd_mfma(const float* x, int64_t x_ld, const float* scale, const fl
     int64_t nblk0;
     fwd_geometry(N, D, H, W, Cout, kd, flat, TZ, TY, TX, NR, nblk0);
     const bool nr2 = NR == 2;
-    int ks = fwd_ksplit(nblk0, Cin / CK);
+    int ks = tem_fwd_ksplit(nblk0, Cin / CK);
     const bool vec_ok = (y_ld % 4 == 0) && ((uintptr_t)y % 16 == 0) && (!ref || (ref_ld % 4 == 0 && (uintptr_t)ref % 16 == 0)) &&
                         (!bias || (uintptr_t)bias % 16 == 0);
     if (ks > 1 && (!ws || !vec_ok || ws_bytes < (int64_t)ks * N * D * H * W * Cout * 4)) ks = 1;

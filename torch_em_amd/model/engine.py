@@ -30,6 +30,27 @@ from .. import ops
 
 _FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
 
+# Arithmetic of the MFMA convolutions:
+#   "fp32"   everything exact fp32 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).
+#   "mixed"  forward convolutions exact fp32; gradient-side convolutions (dgrad, wgrad) split-bf16:
+#            x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
+#            accumulation (~1e-5 relative per product, 833 TFLOP/s effective peak).
+#   "bf16x3" forward too.
+# Why "mixed" is the default: the U-Net's gradient is ill-conditioned w.r.t. the FORWARD values -- a
+# 1e-7 relative forward perturbation flips ReLU masks / pooling arg-maxes of near-ties and moves
+# gradient entries by ~1e-4..1e-3 (that is the fp32 reference's own distance from the float64
+# gradient; tests/test_gpu_unet.py) -- so 1e-5 forward noise would cost ~5e-3 in the gradients.
+# The backward convolutions are LINEAR in the incoming gradient with masks fixed by the forward
+# pass, so their 1e-5 error is not amplified.
+PRECISION = os.environ.get("TEM_PRECISION", "mixed")
+
+
+def set_precision(mode: str):
+    global PRECISION
+    if mode not in ("fp32", "mixed", "bf16x3"):
+        raise ValueError(f"unknown precision mode {mode}")
+    PRECISION = mode
+
 
 def _k3(k):
     k = tuple(int(v) for v in k)
@@ -66,12 +87,14 @@ class ConvSpec:
     def packed(self):
         w = self.conv.weight
         ent = getattr(self.conv, "_tem_pack", None)
-        if ent is None or ent["version"] != w._version or ent["ptr"] != w.data_ptr():
-            mf = (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k)
-            md = (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k)
-            mw = (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k, wgrad=True)
+        if ent is None or ent["version"] != w._version or ent["ptr"] != w.data_ptr() or ent["prec"] != PRECISION:
+            mode_f = 2 if PRECISION == "bf16x3" else 1
+            mode_d = 2 if PRECISION in ("bf16x3", "mixed") else 1
+            mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
+            md = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k) else 0
+            mw = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k, wgrad=True) else 0
             ent = {
-                "version": w._version, "ptr": w.data_ptr(),
+                "version": w._version, "ptr": w.data_ptr(), "prec": PRECISION,
                 "fwd": ops.pack_weights(w, transpose=False, mfma=mf), "fwd_mfma": mf,
                 "dgrad": ops.pack_weights(w, transpose=True, mfma=md), "dgrad_mfma": md,
                 "wgrad_mfma": mw,

@@ -124,8 +124,9 @@ def mfma_ok(cin: int, cout: int, k: Sequence[int], wgrad: bool = False) -> bool:
     return cin % 16 == 0 and cout % 32 == 0
 
 
-def pack_weights(w: torch.Tensor, transpose: bool, mfma: bool) -> torch.Tensor:
-    """state_dict layout [Cout, Cin, (kd,) kh, kw] -> kernel layout (see tem_hip.h)."""
+def pack_weights(w: torch.Tensor, transpose: bool, mfma) -> torch.Tensor:
+    """state_dict layout [Cout, Cin, (kd,) kh, kw] -> kernel layout (see tem_hip.h).
+    mfma: False/0 generic, True/1 exact-fp32 MFMA fragments, 2 split-bf16 fragments."""
     _req_cuda(w)
     w = w.detach().contiguous()
     cout, cin = w.shape[:2]
@@ -134,7 +135,7 @@ def pack_weights(w: torch.Tensor, transpose: bool, mfma: bool) -> torch.Tensor:
     dst = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
     lib = _lib.load()
     _lib.check(lib.tem_conv_pack_weights(_p(w), _p(dst), cout, cin, k[0], k[1], k[2], int(transpose),
-                                         1 if mfma else 0, _stream(w)), "tem_conv_pack_weights")
+                                         int(mfma), _stream(w)), "tem_conv_pack_weights")
     return dst
 
 
@@ -148,14 +149,15 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     if ref is not None:
         ref_ld = _act5(ref)[5]
     lib = _lib.load()
-    nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if mfma else 0
+    nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 1) if mfma else 0
     ws = _workspace(nws, x.device) if nws else None
     ev0 = _prof_begin(x)
     _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
                                   ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma),
                                   _stream(x)), "tem_conv3d_fwd")
     if ev0 is not None:
-        kind = ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu") + f"<{k[0]},{k[1]},{k[2]}"
+        kind = ("k_conv_fwd_bf16x3" if int(mfma) == 2 else "k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu") + \
+            f"<{k[0]},{k[1]},{k[2]}"
         kind += (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return y
@@ -195,7 +197,8 @@ def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, 
     _lib.check(lib.tem_conv_unpack_wgrad(ctypes.c_void_p(tmp_ptr), _p(dw_out), cout, cin, k[0], k[1], k[2],
                                          _stream(x)), "tem_conv_unpack_wgrad")
     if ev0 is not None:
-        kind = ("k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + f"<{k[0]},{k[1]},{k[2]}>(+bias,reduce,unpack)"
+        kind = ("k_conv_wgrad_bf16x3" if int(mfma) == 2 else "k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + \
+            f"<{k[0]},{k[1]},{k[2]}>(+reduce,unpack)"
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return dw_out
 
