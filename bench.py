@@ -35,6 +35,8 @@ PRECISION_DTYPE = {
     "fp32": "f32",
     "mixed": "f32 (forward: exact fp32 MFMA; backward convs: fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per "
              "product, fp32 accumulate -- gradient error vs float64 identical to exact fp32, tests/test_gpu_unet.py)",
+    "split": "f32-class (forward: fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product = 24-bit products; "
+             "backward convs: 2 terms / 3 MFMAs; fp32 accumulate)",
     "bf16x3": "bf16x3 (all MFMA convs split-bf16, fp32 accumulate)",
 }
 
@@ -84,8 +86,8 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--norm", default="InstanceNorm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "bf16x3"],
-                    help="MFMA conv arithmetic (default: engine default = mixed)")
+    ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "split", "bf16x3"],
+                    help="MFMA conv arithmetic (default: engine default = split)")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table to this file")
     args = ap.parse_args()
 
@@ -182,9 +184,9 @@ def main():
                 f.write("\n".join(lines) + "\n")
         dom_tag, dom = rows[0]
         achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s (algorithmic: 2*MACs of the convolution)
-        split = "bf16x3" in dom_tag
-        # split-bf16 kernels execute 3 bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3
-        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
+        split = 6 if "bf16x6" in dom_tag else (3 if "bf16x3" in dom_tag else 0)
+        # split-bf16 kernels execute 3 (or 6) bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3 (6)
+        peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
         standard = (args.batch == 2 and S == 128)
         out = {
             "metric": "voxels/sec fwd+bwd, UNet3d 1x128^3 bs=2",
@@ -197,7 +199,7 @@ def main():
                        "parallelism": f"dp{world}", "global_batch": world * args.batch, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None, "kernel": dom_tag,
-                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (split-bf16 x3, fp32 "
+                         "peak_note": (f"dense bf16 MFMA peak 2500 TFLOP/s / {split} MFMAs per product (split-bf16, fp32 "
                                        "accumulate); executed-MFMA fraction of 2500 = frac" if split else
                                        "exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                          "launches_per_step": dom["launches"] // args.steps,

@@ -60,12 +60,15 @@ int tem_device_cus(void);
  *   TEM_WL_BF16X3   [co/32][tap][ci/16][hi|lo][64][8 bf16]  Cin%16==0, Cout%32==0
  *                   (each fp32 weight split into two bf16 terms, B-fragment order of
  *                   v_mfma_f32_32x32x16_bf16; same byte count as fp32)
+ *   TEM_WL_BF16X6   same with three bf16 terms per weight (all 24 mantissa bits; 1.5x the bytes --
+ *                   tem_conv_packed_size() returns the size of the largest layout)
  * transpose==1 packs the data-gradient operator: taps flipped, Cin<->Cout
  * swapped, so that dgrad is again a tem_conv3d_fwd call.
  */
 #define TEM_WL_GENERIC 0
 #define TEM_WL_MFMA 1
 #define TEM_WL_BF16X3 2
+#define TEM_WL_BF16X6 3
 #define TEM_ACT_NONE 0
 #define TEM_ACT_RELU 1
 #define TEM_ACT_SIGMOID 2
@@ -88,6 +91,8 @@ int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Ci
  *                TEM_WL_MFMA pack); 2 = split-bf16 kernel: every operand x = hi + lo in bf16,
  *                products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
  *                accumulation, ~1e-5 relative per product (needs the TEM_WL_BF16X3 pack);
+ *                3 = the same with three bf16 terms per operand and the six products of order
+ *                <= 2^-16 ("bf16x6"): per-product error ~2^-23, the fp32 class (TEM_WL_BF16X6 pack);
  *                0 = VALU kernel (TEM_WL_GENERIC pack).
  *   ws:          optional workspace of tem_conv3d_fwd_ws() bytes.  Spatially small, channel-rich
  *                layers (the 8^3/16^3 levels) cannot fill 256 CUs with (patch x Cout-tile)

@@ -10,7 +10,8 @@
 // weight packing
 // ---------------------------------------------------------------------------
 extern "C" int64_t tem_conv_packed_size(int Cout, int Cin, int kd, int kh, int kw) {
-    return (int64_t)Cout * Cin * kd * kh * kw;
+    // floats; the bf16x6 layout stores 3 bf16 planes = 1.5 floats per weight
+    return ((int64_t)Cout * Cin * kd * kh * kw * 3 + 1) / 2;
 }
 
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, float* __restrict__ dst, int Cout,
@@ -49,8 +50,9 @@ extern "C" int tem_conv_pack_weights(const float* w, float* dst, int Cout, int C
     TEM_REQUIRE(w && dst && Cout > 0 && Cin > 0, "tem_conv_pack_weights: bad arguments");
     TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
                 "tem_conv_pack_weights: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
-    if (layout == TEM_WL_BF16X3) {
-        int rc = tem_pack_weights_bf16x3(w, dst, Cout, Cin, kd, kh, kw, transpose, (hipStream_t)stream);
+    if (layout == TEM_WL_BF16X3 || layout == TEM_WL_BF16X6) {
+        int rc = tem_pack_weights_bf16x3(w, dst, Cout, Cin, kd, kh, kw, transpose, layout == TEM_WL_BF16X6 ? 3 : 2,
+                                         (hipStream_t)stream);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv_pack_weights(bf16x3)");
         return TEM_OK;
@@ -251,9 +253,9 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
     TEM_REQUIRE(act >= 0 && act <= 2, "tem_conv3d_fwd: Invalid activation: %d", act);
     TEM_REQUIRE(!ref || ref_ld >= Cout, "tem_conv3d_fwd: bad ref_ld");
     hipStream_t s = (hipStream_t)stream;
-    if (use_mfma == 2) {
+    if (use_mfma == 2 || use_mfma == 3) {
         int rc = tem_conv_fwd_bf16x3(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
-                                     W, Cin, Cout, kd, kh, kw, act, s);
+                                     W, Cin, Cout, kd, kh, kw, act, use_mfma, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(bf16x3)");
         return TEM_OK;

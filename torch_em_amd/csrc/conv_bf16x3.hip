@@ -35,11 +35,17 @@ __device__ __forceinline__ float act_apply_b(float v, int act) {
 }
 
 // ---------------------------------------------------------------------------
-// weight packing: [Cout][Cin][kd][kh][kw] fp32 -> [co/32][tap][ci/16][hi|lo][64 lanes][8 bf16]
+// weight packing: [Cout][Cin][kd][kh][kw] fp32 -> [co/32][tap][ci/16][NS planes][64 lanes][8 bf16]
 // lane = kh*32 + col, slot j <-> input channel (ci/16)*16 + kh*8 + j  (the B fragment of 32x32x16)
+// NS = 2: (hi, lo);  NS = 3: three bf16 terms = all 24 mantissa bits of the fp32 weight.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_weights_bf16x3(const float* __restrict__ w, unsigned short* __restrict__ dst,
-                                                             int Cout, int Cin, int KD, int KH, int KW, int transpose) {
+__device__ __forceinline__ unsigned short bf16_bits(float v) {
+    return (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
+}
+
+__global__ __launch_bounds__(256) void k_pack_weights_bfsplit(const float* __restrict__ w, unsigned short* __restrict__ dst,
+                                                              int Cout, int Cin, int KD, int KH, int KW, int transpose,
+                                                              int NS) {
     const int ntaps = KD * KH * KW;
     const int64_t total = (int64_t)Cout * Cin * ntaps;
     const int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
@@ -54,30 +60,35 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16x3(const float* __rest
             val = w[(((int64_t)co * Cin + ci) * KD + tz) * KH * KW + ty * KW + tx];
         else
             val = w[(((int64_t)ci * Cin + co) * KD + (KD - 1 - tz)) * KH * KW + (KH - 1 - ty) * KW + (KW - 1 - tx)];
-        unsigned hi, lo;
-        split2(val, 0.f, hi, lo);
         const int nt = co >> 5, col = co & 31, c16 = ci >> 4, kh = (ci >> 3) & 1, j = ci & 7;
-        const int64_t base = ((((int64_t)nt * ntaps + tap) * (CinL >> 4) + c16) * 2) * 512;  // 512 bf16 per (hi|lo) fragment
-        dst[base + (kh * 32 + col) * 8 + j] = (unsigned short)(hi & 0xffff);
-        dst[base + 512 + (kh * 32 + col) * 8 + j] = (unsigned short)(lo & 0xffff);
+        const int64_t base = ((((int64_t)nt * ntaps + tap) * (CinL >> 4) + c16) * NS) * 512;  // 512 bf16 per plane
+        float rem = val;
+        for (int p = 0; p < NS; ++p) {
+            const unsigned short hb = bf16_bits(rem);
+            dst[base + p * 512 + (kh * 32 + col) * 8 + j] = hb;
+            rem -= __builtin_bit_cast(float, (unsigned)hb << 16);
+        }
     }
 }
 
 int tem_pack_weights_bf16x3(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw, int transpose,
-                            hipStream_t s) {
+                            int nsplit, hipStream_t s) {
     int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
-    TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: bf16x3 layout needs Cin%%16==0, Cout%%32==0");
+    TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: split-bf16 layout needs Cin%%16==0, Cout%%32==0");
     int64_t total = (int64_t)Cout * Cin * kd * kh * kw;
-    hipLaunchKernelGGL(k_pack_weights_bf16x3, dim3(tem_grid_1d(total, 256)), dim3(256), 0, s, w, (unsigned short*)dst,
-                       Cout, Cin, kd, kh, kw, transpose);
+    hipLaunchKernelGGL(k_pack_weights_bfsplit, dim3(tem_grid_1d(total, 256)), dim3(256), 0, s, w, (unsigned short*)dst,
+                       Cout, Cin, kd, kh, kw, transpose, nsplit);
     return TEM_OK;
 }
 
 // ---------------------------------------------------------------------------
-// forward / dgrad
+// forward / dgrad.  NS = 2: "bf16x3" (3 MFMAs per product, ~1e-5 relative), used for the gradient
+// side.  NS = 3: "bf16x6": x = a1+a2+a3 carries all 24 mantissa bits, products with i+j <= 4
+// (6 MFMAs) -- per-product error ~2^-23, i.e. the fp32 class, at 16/6 of the exact-fp32 MFMA rate;
+// used for the forward pass, whose rounding noise the gradient amplifies (engine.py, PRECISION).
 // ---------------------------------------------------------------------------
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR>
-__global__ __launch_bounds__(256, NR == 2 ? 2 : 3) void k_conv_fwd_bf16x3(
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS>
+__global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_bfsplit(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
@@ -88,8 +99,9 @@ __global__ __launch_bounds__(256, NR == 2 ? 2 : 3) void k_conv_fwd_bf16x3(
     constexpr int HV = HZ * HY * HX;
     constexpr int NIT = (HV * 4 + 255) / 256;
     constexpr int RD = (NT % 3 == 0) ? 3 : 1;  // weight-fragment ring depth over taps
+    constexpr int LSV = NS * 8 + 4;            // LDS floats per halo voxel: NS planes of 16 bf16 (32 B) + 16 B pad
     static_assert(TZ * TY * TX == 256, "patch must hold 256 voxels");
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [HV][BLS]
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [HV][LSV]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 2 : 3) void k_conv_fwd_bf16x3(
     for (int m = 0; m < 2; ++m) {
         const int p = wv * 64 + m * 32 + r;
         const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-        abase[m] = ((pz * HY + py) * HX + px) * BLS + kh * 4;  // + 8 floats (32 B) for the lo half
+        abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;  // + 8 floats (32 B) per further plane
     }
     floatx16 acc[2][NR];
 #pragma unroll
@@ -127,23 +139,23 @@ __global__ __launch_bounds__(256, NR == 2 ? 2 : 3) void k_conv_fwd_bf16x3(
     const int c4 = tid & 3;
     const int cpk = cin16 / ksplit;
     const int chunk_begin = ks * cpk, chunk_end = (ks + 1) * cpk;
-    // uint4 index of this lane's slot: ((((nt*NT + tap)*cin16 + c16)*2 + hl)*64 + lane)
-    const int tapstride = cin16 * 128;
+    // uint4 index of this lane's slot: ((((nt*NT + tap)*cin16 + c16)*NS + plane)*64 + lane)
+    constexpr int FR = NS * 64;                // uint4s per (tap, c16) fragment group
+    const int tapstride = cin16 * FR;
     const uint4* wq[NR];
 #pragma unroll
-    for (int nn = 0; nn < NR; ++nn) wq[nn] = wp + (int64_t)(cot * NR + nn) * NT * cin16 * 128 + lane;
-    uint4 bq[RD][NR][2];
+    for (int nn = 0; nn < NR; ++nn) wq[nn] = wp + (int64_t)(cot * NR + nn) * NT * cin16 * FR + lane;
+    uint4 bq[RD][NR][NS];
     if (RD > 1) {
 #pragma unroll
         for (int gp = 0; gp < RD - 1; ++gp)
 #pragma unroll
-            for (int nn = 0; nn < NR; ++nn) {
-                bq[gp][nn][0] = wq[nn][(int64_t)chunk_begin * 128 + gp * tapstride];
-                bq[gp][nn][1] = wq[nn][(int64_t)chunk_begin * 128 + gp * tapstride + 64];
-            }
+            for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) bq[gp][nn][p] = wq[nn][(int64_t)chunk_begin * FR + gp * tapstride + p * 64];
     }
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
-        // ---- stage: global fp32 -> fused pre-norm -> (hi, lo) bf16 -> LDS ----
+        // ---- stage: global fp32 -> fused pre-norm -> NS bf16 planes -> LDS ----
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (scale) {
             sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + chunk * BCK + c4 * 4);
@@ -173,11 +185,18 @@ __global__ __launch_bounds__(256, NR == 2 ? 2 : 3) void k_conv_fwd_bf16x3(
         for (int it = 0; it < NIT; ++it) {
             const int hv = (tid + it * 256) >> 2;
             if (hv < HV) {
-                unsigned h0, l0, h1, l1;
-                split2(tmp[it].x, tmp[it].y, h0, l0);
-                split2(tmp[it].z, tmp[it].w, h1, l1);
-                *reinterpret_cast<uint2*>(lds + hv * BLS + c4 * 2) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(lds + hv * BLS + 8 + c4 * 2) = make_uint2(l0, l1);
+                float e[4] = {tmp[it].x, tmp[it].y, tmp[it].z, tmp[it].w};
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+                    const unsigned h0 = pk_bf16(e[0], e[1]), h1 = pk_bf16(e[2], e[3]);
+                    *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
+                    if (p + 1 < NS) {
+                        e[0] -= __builtin_bit_cast(float, h0 << 16);
+                        e[1] -= __builtin_bit_cast(float, h0 & 0xffff0000u);
+                        e[2] -= __builtin_bit_cast(float, h1 << 16);
+                        e[3] -= __builtin_bit_cast(float, h1 & 0xffff0000u);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -187,45 +206,48 @@ __global__ __launch_bounds__(256, NR == 2 ? 2 : 3) void k_conv_fwd_bf16x3(
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
             const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
-            const int toff = ((tz * HY + ty) * HX + tx) * BLS;
+            const int toff = ((tz * HY + ty) * HX + tx) * LSV;
             if (RD > 1) {
                 const int gp = tap + RD - 1;
                 if (gp < NT) {
 #pragma unroll
-                    for (int nn = 0; nn < NR; ++nn) {
-                        bq[gp % RD][nn][0] = wq[nn][(int64_t)chunk * 128 + (int64_t)gp * ts];
-                        bq[gp % RD][nn][1] = wq[nn][(int64_t)chunk * 128 + (int64_t)gp * ts + 64];
-                    }
+                    for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                        for (int p = 0; p < NS; ++p)
+                            bq[gp % RD][nn][p] = wq[nn][(int64_t)chunk * FR + (int64_t)gp * ts + p * 64];
                 } else if (chunk + 1 < chunk_end) {
 #pragma unroll
-                    for (int nn = 0; nn < NR; ++nn) {
-                        bq[gp % RD][nn][0] = wq[nn][(int64_t)(chunk + 1) * 128 + (int64_t)(gp - NT) * ts];
-                        bq[gp % RD][nn][1] = wq[nn][(int64_t)(chunk + 1) * 128 + (int64_t)(gp - NT) * ts + 64];
-                    }
+                    for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                        for (int p = 0; p < NS; ++p)
+                            bq[gp % RD][nn][p] = wq[nn][(int64_t)(chunk + 1) * FR + (int64_t)(gp - NT) * ts + p * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0x38F);
             } else {
 #pragma unroll
-                for (int nn = 0; nn < NR; ++nn) {
-                    bq[0][nn][0] = wq[nn][(int64_t)chunk * 128 + (int64_t)tap * ts];
-                    bq[0][nn][1] = wq[nn][(int64_t)chunk * 128 + (int64_t)tap * ts + 64];
-                }
-            }
-            bf16x8 ah[2], al[2];
+                for (int nn = 0; nn < NR; ++nn)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                ah[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + toff));
-                al[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + toff + 8));
+                    for (int p = 0; p < NS; ++p) bq[0][nn][p] = wq[nn][(int64_t)chunk * FR + (int64_t)tap * ts + p * 64];
             }
+            bf16x8 af[2][NS];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    af[m][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + toff + p * 8));
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int nn = 0; nn < NR; ++nn) {
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[tap % RD][nn][0]);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[tap % RD][nn][1]);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][nn], 0, 0, 0);
+                    // smallest terms first: all plane pairs (i, j) with i + j <= NS - 1 (0-based)
+#pragma unroll
+                    for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                        for (int i = 0; i <= sum; ++i) {
+                            const int j = sum - i;
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                af[m][i], __builtin_bit_cast(bf16x8, bq[tap % RD][nn][j]), acc[m][nn], 0, 0, 0);
+                        }
                 }
         }
     }
@@ -257,17 +279,23 @@ __global__ __launch_bounds__(256, NR == 2 ? 2 : 3) void k_conv_fwd_bf16x3(
     }
 }
 
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR>
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS>
 static void launch_b(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
                      int W, int Cin, int Cout, int act, int ksplit, float* part, hipStream_t s) {
     constexpr int HV = (TZ + KD - 1) * (TY + KH - 1) * (TX + KW - 1);
     const int nZ = (D + TZ - 1) / TZ, nY = (H + TY - 1) / TY, nX = (W + TX - 1) / TX;
     const int64_t nblk = (int64_t)N * nZ * nY * nX * (Cout / (32 * NR)) * ksplit;
-    size_t ldsb = (size_t)HV * BLS * sizeof(float);
-    hipLaunchKernelGGL((k_conv_fwd_bf16x3<KD, KH, KW, TZ, TY, TX, NR>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld,
-                       scale, shift, reinterpret_cast<const uint4*>(wp), bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout,
-                       act, nZ, nY, nX, ksplit, part);
+    constexpr size_t ldsb = (size_t)HV * (NS * 8 + 4) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done && ldsb > 64 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS>), dim3((unsigned)nblk), dim3(256), ldsb, s, x,
+                       x_ld, scale, shift, reinterpret_cast<const uint4*>(wp), bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin,
+                       Cout, act, nZ, nY, nX, ksplit, part);
     if (ksplit > 1) {
         const int64_t NV = (int64_t)N * D * H * W;
         tem_splitk_epilogue(part, ksplit, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
@@ -277,13 +305,13 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
 int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                         const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
                         int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
-                        hipStream_t s) {
-    TEM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0, "tem_conv3d_fwd(bf16x3): needs Cin%%16==0 and Cout%%32==0 (got %d,%d)",
+                        int nsplit, hipStream_t s) {
+    TEM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0, "tem_conv3d_fwd(split-bf16): needs Cin%%16==0 and Cout%%32==0 (got %d,%d)",
                 Cin, Cout);
     TEM_REQUIRE(x_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)wp % 16 == 0),
-                "tem_conv3d_fwd(bf16x3): x / packed weights must be 16-byte aligned with ld%%4==0");
+                "tem_conv3d_fwd(split-bf16): x / packed weights must be 16-byte aligned with ld%%4==0");
     TEM_REQUIRE(!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)),
-                "tem_conv3d_fwd(bf16x3): scale/shift must be 16-byte aligned");
+                "tem_conv3d_fwd(split-bf16): scale/shift must be 16-byte aligned");
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     const bool flat = (D == 1 && kd == 1);
     const int TZ = flat ? 1 : 4, TY = flat ? 16 : 8, TX = flat ? 16 : 8;
@@ -294,14 +322,21 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
                         (!ref || (ref_ld % 4 == 0 && (uintptr_t)ref % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0);
     if (ks > 1 && (!ws || !vec_ok || ws_bytes < (int64_t)ks * N * D * H * W * Cout * 4)) ks = 1;
     float* part = (float*)ws;
-#define GO(KD, KH, KW, TZ, TY, TX)                                                                               \
-    do {                                                                                                         \
-        if (nr2)                                                                                                 \
-            launch_b<KD, KH, KW, TZ, TY, TX, 2>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
-                                                Cin, Cout, act, ks, part, s);                                    \
-        else                                                                                                     \
-            launch_b<KD, KH, KW, TZ, TY, TX, 1>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
-                                                Cin, Cout, act, ks, part, s);                                    \
+#define GO2(KD, KH, KW, TZ, TY, TX, NS)                                                                             \
+    do {                                                                                                            \
+        if (nr2)                                                                                                    \
+            launch_b<KD, KH, KW, TZ, TY, TX, 2, NS>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
+                                                    Cin, Cout, act, ks, part, s);                                   \
+        else                                                                                                        \
+            launch_b<KD, KH, KW, TZ, TY, TX, 1, NS>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
+                                                    Cin, Cout, act, ks, part, s);                                   \
+    } while (0)
+#define GO(KD, KH, KW, TZ, TY, TX)            \
+    do {                                      \
+        if (nsplit == 3)                      \
+            GO2(KD, KH, KW, TZ, TY, TX, 3);   \
+        else                                  \
+            GO2(KD, KH, KW, TZ, TY, TX, 2);   \
     } while (0)
     if (key == 7) {
         GO(3, 3, 3, 4, 8, 8);
@@ -316,10 +351,11 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
         else
             GO(1, 1, 1, 4, 8, 8);
     } else {
-        tem_set_error("tem_conv3d_fwd(bf16x3): kernel (%d,%d,%d) has no MFMA instantiation", kd, kh, kw);
+        tem_set_error("tem_conv3d_fwd(split-bf16): kernel (%d,%d,%d) has no MFMA instantiation", kd, kh, kw);
         return TEM_EINVAL;
     }
 #undef GO
+#undef GO2
     return TEM_OK;
 }
 

@@ -32,22 +32,25 @@ _FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
 
 # Arithmetic of the MFMA convolutions:
 #   "fp32"   everything exact fp32 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).
-#   "mixed"  forward convolutions exact fp32; gradient-side convolutions (dgrad, wgrad) split-bf16:
-#            x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
+#   "mixed"  forward convolutions exact fp32; gradient-side convolutions (dgrad, wgrad) split-bf16
+#            "bf16x3": x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
 #            accumulation (~1e-5 relative per product, 833 TFLOP/s effective peak).
-#   "bf16x3" forward too.
-# Why "mixed" is the default: the U-Net's gradient is ill-conditioned w.r.t. the FORWARD values -- a
+#   "split"  as "mixed", but the forward convolutions use "bf16x6": three bf16 terms per operand (all
+#            24 mantissa bits) and the six products of order <= 2^-16 -- per-product error ~2^-23,
+#            the fp32 class, at 16/6 of the exact-fp32 MFMA rate (417 TFLOP/s effective peak).
+#   "bf16x3" forward in bf16x3 too (forward noise 1e-5: NOT parity-grade, see below).
+# Why the forward keeps fp32-class products ("split" is the default; "mixed"/"fp32" use the exact MFMA): the U-Net's gradient is ill-conditioned w.r.t. the FORWARD values -- a
 # 1e-7 relative forward perturbation flips ReLU masks / pooling arg-maxes of near-ties and moves
 # gradient entries by ~1e-4..1e-3 (that is the fp32 reference's own distance from the float64
 # gradient; tests/test_gpu_unet.py) -- so 1e-5 forward noise would cost ~5e-3 in the gradients.
 # The backward convolutions are LINEAR in the incoming gradient with masks fixed by the forward
 # pass, so their 1e-5 error is not amplified.
-PRECISION = os.environ.get("TEM_PRECISION", "mixed")
+PRECISION = os.environ.get("TEM_PRECISION", "split")
 
 
 def set_precision(mode: str):
     global PRECISION
-    if mode not in ("fp32", "mixed", "bf16x3"):
+    if mode not in ("fp32", "mixed", "split", "bf16x3"):
         raise ValueError(f"unknown precision mode {mode}")
     PRECISION = mode
 
@@ -88,8 +91,8 @@ class ConvSpec:
         w = self.conv.weight
         ent = getattr(self.conv, "_tem_pack", None)
         if ent is None or ent["version"] != w._version or ent["ptr"] != w.data_ptr() or ent["prec"] != PRECISION:
-            mode_f = 2 if PRECISION == "bf16x3" else 1
-            mode_d = 2 if PRECISION in ("bf16x3", "mixed") else 1
+            mode_f = {"bf16x3": 2, "split": 3}.get(PRECISION, 1)
+            mode_d = 2 if PRECISION in ("bf16x3", "mixed", "split") else 1
             mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
             md = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k) else 0
             mw = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k, wgrad=True) else 0

@@ -132,8 +132,8 @@ def pack_weights(w: torch.Tensor, transpose: bool, mfma) -> torch.Tensor:
     cout, cin = w.shape[:2]
     k = tuple(w.shape[2:])
     k = (1,) * (3 - len(k)) + k
-    dst = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
     lib = _lib.load()
+    dst = torch.empty(lib.tem_conv_packed_size(cout, cin, k[0], k[1], k[2]), dtype=torch.float32, device=w.device)
     _lib.check(lib.tem_conv_pack_weights(_p(w), _p(dst), cout, cin, k[0], k[1], k[2], int(transpose),
                                          int(mfma), _stream(w)), "tem_conv_pack_weights")
     return dst
@@ -156,7 +156,8 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
                                   ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma),
                                   _stream(x)), "tem_conv3d_fwd")
     if ev0 is not None:
-        kind = ("k_conv_fwd_bf16x3" if int(mfma) == 2 else "k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu") + \
+        kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6"}.get(int(mfma)) or
+                ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu")) + \
             f"<{k[0]},{k[1]},{k[2]}"
         kind += (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
