@@ -106,16 +106,17 @@ int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float
                    int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                    int act, int use_mfma, tem_stream_t stream);
 
-/* dw[tap][ci][co] = sum_v xhat[v+tap][ci] * g[v][co]  (xhat = x*scale+shift, zero padded)
+/* dw = sum_v xhat[v+tap][ci] * g[v][co]  (xhat = x*scale+shift, zero padded)
  * db[co] = sum_v g[v][co] (optional).  ws: workspace of tem_conv3d_wgrad_ws() bytes.
- * The result is in the GENERIC tap-major layout; tem_conv_unpack_wgrad gives the
- * state_dict layout. */
+ * sd_layout != 0: dw is written in the reference's state_dict order [Cout][Cin][kd][kh][kw]
+ * (what param.grad needs); 0: tap-major [tap][ci][co] (tem_conv_unpack_wgrad converts).
+ * use_mfma: 0 VALU, 1 exact-fp32 MFMA, 2 split-bf16 MFMA (tem_conv3d_fwd). */
 int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const float* shift,
                      const float* g, int64_t g_ld, float* dw_tap_ci_co, float* db,
                      void* ws, int64_t ws_bytes,
                      int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
-                     int use_mfma, tem_stream_t stream);
+                     int use_mfma, int sd_layout, tem_stream_t stream);
 
 /* ---- normalisation ------------------------------------------------------
  * Replaces nn.InstanceNorm3d / nn.GroupNorm from get_norm_layer

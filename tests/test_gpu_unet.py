@@ -183,7 +183,20 @@ def test_benchmark_config_full_size_properties():
     lo.backward()
     assert rel_err(model(x).detach().cpu(), pred.detach().cpu()) < TOL
     assert abs(vals[0] - float(lo)) < 1e-4
-    # two fp32 implementations of an ill-conditioned gradient (see _check_against_fp64): 3e-2 here, the
-    # accuracy claim proper is made against float64 at the sizes where float64 is affordable
-    check_grads({k: p.grad.cpu().numpy() for k, p in model.named_parameters()},
-                {k: v.grad.cpu().numpy() for k, v in sd.items()}, 3e-2)
+    # Gradients: two fp32-class implementations of an ill-conditioned gradient (see _check_against_fp64; at this
+    # size float64 is not affordable on the CPU and ATen has no fast float64 conv here).  Robust norms only:
+    # every tensor within 5e-2 and the whole gradient within 1e-2 in relative L2.
+    named = dict(model.named_parameters())
+    num = den = 0.0
+    for k, v in sd.items():
+        a = named[k].grad.double().cpu().numpy().ravel()
+        r = v.grad.double().cpu().numpy().ravel()
+        gmax = max(float(np.abs(r).max()), 1e-30)
+        if gmax < 1e-4 * 2.0:  # mathematically-zero gradients (sampler bias before InstanceNorm): noise only
+            assert float(np.abs(a).max()) < 1e-3, k
+            continue
+        e = float(np.linalg.norm(a - r) / np.linalg.norm(r))
+        assert e < 5e-2, (k, e)
+        num += float(np.sum((a - r) ** 2))
+        den += float(np.sum(r ** 2))
+    assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5

@@ -77,7 +77,9 @@ def test_arena_layout_and_flat_grads_detection():
     flat = torch.randn(total)
     for p in ar.params:
         o, n = offs[id(p)]
-        p.grad = flat[o:o + n].view(p.shape)
+        p.grad = flat[o:o + n].view(p.shape).detach()
+    assert ar.grads_flat() is None          # nobody registered an arena
+    ar.params[0]._tem_grad_flat = flat      # what engine.UNetFunction.backward does
     g = ar.grads_flat()
     assert g is not None and g.data_ptr() == flat.data_ptr() and g.numel() == total
     # ... and anything else is not

@@ -41,17 +41,15 @@ class ParamArena:
         return all(p.data_ptr() == base + 4 * self.offsets[id(p)][0] for p in self.params)
 
     def grads_flat(self):
-        """The flat gradient arena if every p.grad is a view of one buffer in arena order, else None."""
-        g0 = self.params[0].grad
-        if g0 is None:
+        """The flat gradient arena if every p.grad is the engine's view of one buffer in arena order, else None.
+        The engine leaves a reference to its arena on the first parameter (`_tem_grad_flat`); autograd may have
+        detached the views it was handed, so membership is verified by address."""
+        flat = getattr(self.params[0], "_tem_grad_flat", None)
+        if flat is None or flat.numel() < self.total or self.params[0].grad is None:
             return None
-        base = g0.data_ptr() - 4 * self.offsets[id(self.params[0])][0]
+        base = flat.data_ptr()
         for p in self.params:
-            if p.grad is None or p.grad.data_ptr() != base + 4 * self.offsets[id(p)][0] or not p.grad.is_contiguous():
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * self.offsets[id(p)][0] or not g.is_contiguous():
                 return None
-        root = g0._base if g0._base is not None else g0
-        while root._base is not None:
-            root = root._base
-        if root.data_ptr() != base or root.numel() < self.total or root.dim() != 1:
-            return None
-        return root[:self.total]
+        return flat[:self.total]

@@ -278,6 +278,11 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(proj)");
         return TEM_OK;
     }
+    if (kd == 1 && kh == 1 && kw == 1 &&
+        tem_conv1x1_expand(x, x_ld, scale, w_packed, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s)) {
+        TEM_CHECK_LAUNCH("tem_conv3d_fwd(expand)");
+        return TEM_OK;
+    }
     if (kd == 1 && kh == 1 && kw == 1 && Cin % 4 == 0 && x_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) &&
         (Cout == 1 || Cout == 2 || Cout == 3 || Cout == 4 || Cout == 8 || Cout == 12 || Cout == 16)) {
         dim3 grid(tem_grid_1d(NV, 256, 256 * 16));
@@ -463,7 +468,8 @@ static void launch_wgrad_generic(const float* x, int64_t x_ld, const float* scal
 
 extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                                 int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H,
-                                int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma, tem_stream_t stream) {
+                                int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma, int sd_layout,
+                                tem_stream_t stream) {
     TEM_REQUIRE(x && g && dw && ws, "tem_conv3d_wgrad: null pointer");
     TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= Cin && g_ld >= Cout,
                 "tem_conv3d_wgrad: bad shape");
@@ -483,23 +489,25 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
     if (use_mfma == 2) {
         int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                        ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
-                                       s);
+                                       sd_layout, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(bf16x3)");
         return TEM_OK;
     }
     if (use_mfma) {
         int rc = tem_conv_wgrad_mfma(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
-                                     ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw, s);
+                                     ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
+                                     sd_layout, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(mfma)");
         return TEM_OK;
     }
-    if (tem_conv_wgrad_cin1(x, x_ld, scale, shift, g, g_ld, dw, db, rest, N, D, H, W, Cin, Cout, kd, kh, kw, s)) {
+    if (tem_conv_wgrad_cin1(x, x_ld, scale, shift, g, g_ld, dw, db, rest, N, D, H, W, Cin, Cout, kd, kh, kw, sd_layout,
+                            s)) {
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(cin1)");
         return TEM_OK;
     }
-    if (ntaps == 1 && tem_conv1x1_proj_wgrad(x, x_ld, scale, g, g_ld, dw, db, rest, NV, Cin, Cout, s)) {
+    if (ntaps == 1 && tem_conv1x1_proj_wgrad(x, x_ld, scale, g, g_ld, dw, db, rest, NV, Cin, Cout, sd_layout, s)) {
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(proj)");
         return TEM_OK;
     }
@@ -515,7 +523,7 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
     DISPATCH_K(kd, kh, kw, CALL);
 #undef CALL
     int64_t n = (int64_t)ntaps * Cin * Cout;
-    tem_reduce_slabs(rest, p.nchunks, n, n, dw, s);
+    tem_reduce_slabs_w(rest, p.nchunks, ntaps, Cin, Cout, n, dw, sd_layout, s);
     TEM_CHECK_LAUNCH("tem_conv3d_wgrad(generic)");
     return TEM_OK;
 }

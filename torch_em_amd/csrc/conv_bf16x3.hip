@@ -380,7 +380,7 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
 #define WB_PV (WB_TZ * WB_TY * WB_TX)   // 128 patch voxels = 8 k-slabs
 #define WB_GS 272                        // bytes per co row of Gt: 128 bf16 + 16 pad
 
-template <int KD, int KH, int KW, int NCO>
+template <int KD, int KH, int KW, int NCO, int KS2>
 __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __restrict__ x, int64_t x_ld,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
@@ -402,7 +402,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
     constexpr int XIT = (XITEMS + 255) / 256;
     constexpr int GITEMS = 16 * 4 * (GC / 4);    // (patch row, pair, channel quad)
     constexpr int GIT = GITEMS / 256;
-    constexpr int MAXU = (NRG * NCO + 3) / 4;    // row-group x co-tile units per wave
+    // work units dealt round-robin to the 4 waves: (row group, co tile, k-half), KW accumulators each (the three
+    // tx taps share one row window).  KS2 = 2 splits the 8 k-slabs of a patch between two units that write
+    // separate partial slabs: with one co tile that turns 9 units (3,2,2,2 per wave) into 18 (5,5,4,4).
+    constexpr int MAXU = (NRG * NCO * KS2 + 3) / 4;
+    constexpr int ACW = KW;
+    constexpr int SPU = 8 / KS2;                 // k-slabs per unit and patch
     static_assert(GITEMS % 256 == 0, "g staging items");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* Xh = ldsb;
@@ -418,16 +423,27 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
     const int cit = tile % ncit, cog = tile / ncit;
     int nco_here = (Cout >> 5) - cog * NCO;
     if (nco_here > NCO) nco_here = NCO;
-    const int U = NRG * nco_here;
+    const int U = NRG * nco_here * KS2;
 
-    floatx16 acc[MAXU][KW];
+    floatx16 acc[MAXU][ACW];
 #pragma unroll
     for (int i = 0; i < MAXU; ++i)
 #pragma unroll
-        for (int t = 0; t < KW; ++t)
+        for (int t = 0; t < ACW; ++t)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][t][k] = 0.f;
 
+    // per-unit LDS offsets (a non-existent last unit aliases unit 0; its result is dropped)
+    int urow[MAXU], uct[MAXU], uhalf[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        int u = wv + 4 * i;
+        if (u >= U) u = 0;
+        const int rg = u % NRG;
+        urow[i] = ((rg / KH) * HY + (rg % KH)) * 32;
+        uct[i] = (u / NRG) % nco_here;
+        uhalf[i] = u / (NRG * nco_here);
+    }
     const int p_lo = (int)(((int64_t)sp * P) / S), p_hi = (int)(((int64_t)(sp + 1) * P) / S);
     const bool do_db = (dbpart != nullptr) && (cit == 0);
     float dbacc[GIT][4];
@@ -527,48 +543,45 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
         __syncthreads();
         if (pidx + 1 < p_hi) WB_LOAD(pidx + 1);  // in flight during the MFMAs below
 
-        // ---- MFMA: 8 k-slabs of 16 voxels ----
+        // ---- MFMA.  Branch-free: every wave runs MAXU units (a wave whose last unit does not exist recomputes
+        // unit 0 and drops it in the epilogue), so hipcc can hoist the ds_reads of the next (unit, slab) above the
+        // MFMAs of the current one.  Per (unit, slab): 6 LDS reads + 8 v_alignbyte feed 9 MFMAs. ----
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
 #pragma unroll 2
-        for (int s = 0; s < 8; ++s) {
-            const int prow = 2 * s + kh;                    // this lane half's patch row
-            const int pz = prow / WB_TY, py = prow % WB_TY;
+            for (int sl = 0; sl < SPU; ++sl) {
+                const int prow = 2 * (uhalf[i] * SPU + sl) + kh;  // this lane half's patch row
+                const int pz = prow / WB_TY, py = prow % WB_TY;
+                const int goff = (uct[i] * 32 + r) * WB_GS + prow * 16;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gh + goff));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gl + goff));
+                const int xoff = r * CIS + (pz * HY + py) * 32 + urow[i];
+                const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
+                const uint4 wl = *reinterpret_cast<const uint4*>(Xl + xoff);
+                unsigned wh4 = 0, wl4 = 0;
+                if (KW == 3) {
+                    wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
+                    wl4 = *reinterpret_cast<const unsigned*>(Xl + xoff + 16);
+                }
 #pragma unroll
-            for (int i = 0; i < MAXU; ++i) {
-                const int u = wv + 4 * i;
-                if (u < U) {
-                    const int rg = u % NRG, ct = u / NRG;
-                    const int tz = rg / KH, ty = rg % KH;
-                    const int goff = (ct * 32 + r) * WB_GS + prow * 16;
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gh + goff));
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gl + goff));
-                    const int xoff = r * CIS + ((pz + tz) * HY + (py + ty)) * 32;
-                    const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
-                    const uint4 wl = *reinterpret_cast<const uint4*>(Xl + xoff);
-                    unsigned wh4 = 0, wl4 = 0;
-                    if (KW == 3) {
-                        wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
-                        wl4 = *reinterpret_cast<const unsigned*>(Xl + xoff + 16);
+                for (int tx = 0; tx < KW; ++tx) {
+                    uint4 fh, fl;
+                    if (tx == 0) {
+                        fh = wh;
+                        fl = wl;
+                    } else if (tx == 1) {
+                        fh = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
+                                        __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
+                        fl = make_uint4(__builtin_amdgcn_alignbyte(wl.y, wl.x, 2), __builtin_amdgcn_alignbyte(wl.z, wl.y, 2),
+                                        __builtin_amdgcn_alignbyte(wl.w, wl.z, 2), __builtin_amdgcn_alignbyte(wl4, wl.w, 2));
+                    } else {
+                        fh = make_uint4(wh.y, wh.z, wh.w, wh4);
+                        fl = make_uint4(wl.y, wl.z, wl.w, wl4);
                     }
-#pragma unroll
-                    for (int tx = 0; tx < KW; ++tx) {
-                        uint4 fh, fl;
-                        if (tx == 0) {
-                            fh = wh;
-                            fl = wl;
-                        } else if (tx == 1) {
-                            fh = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
-                                            __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
-                            fl = make_uint4(__builtin_amdgcn_alignbyte(wl.y, wl.x, 2), __builtin_amdgcn_alignbyte(wl.z, wl.y, 2),
-                                            __builtin_amdgcn_alignbyte(wl.w, wl.z, 2), __builtin_amdgcn_alignbyte(wl4, wl.w, 2));
-                        } else {
-                            fh = make_uint4(wh.y, wh.z, wh.w, wh4);
-                            fl = make_uint4(wl.y, wl.z, wl.w, wl4);
-                        }
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, fh), al = __builtin_bit_cast(bf16x8, fl);
-                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][tx], 0, 0, 0);
-                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][tx], 0, 0, 0);
-                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][tx], 0, 0, 0);
-                    }
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, fh), al = __builtin_bit_cast(bf16x8, fl);
+                    acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][tx], 0, 0, 0);
+                    acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][tx], 0, 0, 0);
+                    acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][tx], 0, 0, 0);
                 }
             }
         }
@@ -606,11 +619,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
     for (int i = 0; i < MAXU; ++i) {
         const int u = wv + 4 * i;
         if (u < U) {
-            const int rg = u % NRG, ct = u / NRG;
+            const int rg = u % NRG, ct = (u / NRG) % nco_here, half = u / (NRG * nco_here);
 #pragma unroll
-            for (int tx = 0; tx < KW; ++tx) {
+            for (int tx = 0; tx < ACW; ++tx) {
                 const int tap = rg * KW + tx;
-                float* dst = part + (((int64_t)sp * NT + tap) * Cin + cit * 32) * Cout + (cog * NCO + ct) * 32 + r;
+                float* dst = part + ((((int64_t)sp * KS2 + half) * NT + tap) * Cin + cit * 32) * Cout +
+                             (cog * NCO + ct) * 32 + r;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
@@ -622,13 +636,14 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
 }
 
 struct WbPlan {
-    int nco, T, S, P, nZ, nY, nX;
+    int nco, ks2, T, S, P, nZ, nY, nX;
 };
 
 static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) {
     WbPlan p;
     const int ncot = Cout / 32;
     p.nco = (ntaps == 1) ? (ncot >= 4 ? 4 : (ncot >= 2 ? 2 : 1)) : (ncot >= 2 ? 2 : 1);
+    p.ks2 = (ntaps > 1 && p.nco == 1) ? 2 : 1;  // single co tile: split the k-slabs between two units
     int ngroups = (ncot + p.nco - 1) / p.nco;
     p.T = (Cin / 32) * ngroups;
     p.nZ = (D + WB_TZ - 1) / WB_TZ;
@@ -637,7 +652,7 @@ static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) 
     int64_t P = (int64_t)N * p.nZ * p.nY * p.nX;
     p.P = (int)P;
     int64_t S = (768 + p.T - 1) / p.T;  // one workgroup per CU: ~3 waves of workgroups
-    int64_t slab = (int64_t)ntaps * Cin * Cout * 4;
+    int64_t slab = (int64_t)ntaps * Cin * Cout * 4 * p.ks2;
     int64_t cap = (256ll << 20) / slab;
     if (cap < 1) cap = 1;
     if (S > cap) S = cap;
@@ -649,10 +664,10 @@ static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) 
 
 int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     WbPlan p = wb_plan(N, D, H, W, Cin, Cout, kd * kh * kw);
-    return tem_align_up((int64_t)p.S * kd * kh * kw * Cin * Cout, 64) * 4 + (int64_t)p.S * Cout * 4 + 256;
+    return tem_align_up((int64_t)p.S * p.ks2 * kd * kh * kw * Cin * Cout, 64) * 4 + (int64_t)p.S * Cout * 4 + 256;
 }
 
-template <int KD, int KH, int KW, int NCO>
+template <int KD, int KH, int KW, int NCO, int KS2 = 1>
 static void launch_wb(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
                       float* part, float* dbpart, int N, int D, int H, int W, int Cin, int Cout, const WbPlan& p,
                       hipStream_t s) {
@@ -661,17 +676,17 @@ static void launch_wb(const float* x, int64_t x_ld, const float* scale, const fl
     static_assert(ldsbytes <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_bf16x3<KD, KH, KW, NCO>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_bf16x3<KD, KH, KW, NCO>), dim3((unsigned)(p.T * p.S)), dim3(256), ldsbytes, s, x,
+    hipLaunchKernelGGL((k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2>), dim3((unsigned)(p.T * p.S)), dim3(256), ldsbytes, s, x,
                        x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p.T, p.S, p.P, p.nZ, p.nY, p.nX);
 }
 
 int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                           int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
-                          int Cin, int Cout, int kd, int kh, int kw, hipStream_t s) {
+                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, hipStream_t s) {
     TEM_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "tem_conv3d_wgrad(bf16x3): needs Cin%%32==0 and Cout%%32==0 (got %d,%d)",
                 Cin, Cout);
     TEM_REQUIRE(x_ld % 4 == 0 && g_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0),
@@ -685,7 +700,7 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
         return TEM_EWS;
     }
     float* part = (float*)ws;
-    float* dbpart = db ? part + tem_align_up((int64_t)p.S * ntaps * Cin * Cout, 64) : nullptr;
+    float* dbpart = db ? part + tem_align_up((int64_t)p.S * p.ks2 * ntaps * Cin * Cout, 64) : nullptr;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
 #define WGO(KD, KH, KW)                                                                                              \
     do {                                                                                                             \
@@ -700,12 +715,12 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
         if (p.nco == 2)
             launch_wb<3, 3, 3, 2>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
         else
-            launch_wb<3, 3, 3, 1>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
+            launch_wb<3, 3, 3, 1, 2>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
     } else if (key == 3) {
         if (p.nco == 2)
             launch_wb<1, 3, 3, 2>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
         else
-            launch_wb<1, 3, 3, 1>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
+            launch_wb<1, 3, 3, 1, 2>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
     } else if (key == 0) {
         WGO(1, 1, 1);
     } else {
@@ -714,7 +729,7 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
     }
 #undef WGO
     const int64_t n = (int64_t)ntaps * Cin * Cout;
-    tem_reduce_slabs(part, p.S, n, n, dw, s);
+    tem_reduce_slabs_w(part, p.S * p.ks2, ntaps, Cin, Cout, n, dw, sd_layout, s);
     if (db) tem_reduce_slabs(dbpart, p.S, Cout, Cout, db, s);
     return TEM_OK;
 }

@@ -13,7 +13,7 @@ int tem_conv_fwd_mfma(const float* x, int64_t x_ld, const float* scale, const fl
 int64_t tem_conv_wgrad_mfma_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int tem_conv_wgrad_mfma(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                         int64_t g_ld, float* dw_tap_ci_co, float* db, void* ws, int64_t ws_bytes, int N, int D, int H,
-                        int W, int Cin, int Cout, int kd, int kh, int kw, hipStream_t s);
+                        int W, int Cin, int Cout, int kd, int kh, int kw, int sd_layout, hipStream_t s);
 
 // conv_small.hip: HBM-bound special cases (return false when the shape is not covered)
 bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
@@ -22,12 +22,17 @@ bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const f
 int64_t tem_conv_wgrad_cin1_ws(int Cout, int ntaps);
 bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                          int64_t g_ld, float* dw, float* db, void* ws, int N, int D, int H, int W, int Cin, int Cout,
-                         int kd, int kh, int kw, hipStream_t s);
+                         int kd, int kh, int kw, int sd_layout, hipStream_t s);
 bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const float* w, const float* bias, float* y,
                       int64_t y_ld, const float* ref, int64_t NV, int Cin, int Cout, int act, hipStream_t s);
 int64_t tem_conv1x1_proj_wgrad_ws(int Cin, int Cout);
 bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, const float* g, int64_t g_ld, float* dw,
-                            float* db, void* ws, int64_t NV, int Cin, int Cout, hipStream_t s);
+                            float* db, void* ws, int64_t NV, int Cin, int Cout, int sd_layout, hipStream_t s);
+bool tem_conv1x1_expand(const float* x, int64_t x_ld, const float* scale, const float* w, const float* bias, float* y,
+                        int64_t y_ld, const float* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act,
+                        hipStream_t s);
+void tem_reduce_slabs_w(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
+                        int sd_layout, hipStream_t s);
 void tem_reduce_slabs(const float* part, int nchunks, int64_t n, int64_t chunk_stride, float* out, hipStream_t s);
 
 // conv_bf16x3.hip: split-bf16 ("bf16x3") MFMA path
@@ -44,4 +49,4 @@ void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, co
 int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                           int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
-                          int Cin, int Cout, int kd, int kh, int kw, hipStream_t s);
+                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, hipStream_t s);

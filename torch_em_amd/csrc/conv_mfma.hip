@@ -1061,7 +1061,7 @@ static void launch_wgrad(const float* x, int64_t x_ld, const float* scale, const
 
 int tem_conv_wgrad_mfma(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                         int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
-                        int Cin, int Cout, int kd, int kh, int kw, hipStream_t s) {
+                        int Cin, int Cout, int kd, int kh, int kw, int sd_layout, hipStream_t s) {
     TEM_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "tem_conv3d_wgrad(mfma): needs Cin%%32==0 and Cout%%32==0 (got %d,%d)",
                 Cin, Cout);
     TEM_REQUIRE(x_ld % 4 == 0 && g_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0),
@@ -1088,7 +1088,7 @@ int tem_conv_wgrad_mfma(const float* x, int64_t x_ld, const float* scale, const 
         return TEM_EINVAL;
     }
     const int64_t n = (int64_t)ntaps * Cin * Cout;
-    tem_reduce_slabs(part, p.S, n, n, dw, s);
+    tem_reduce_slabs_w(part, p.S, ntaps, Cin, Cout, n, dw, sd_layout, s);
     if (db) tem_reduce_slabs(dbpart, p.S, Cout, Cout, db, s);
     return TEM_OK;
 }

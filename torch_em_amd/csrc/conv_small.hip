@@ -228,13 +228,53 @@ void tem_reduce_slabs(const float* part, int nchunks, int64_t n, int64_t chunk_s
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)nb), dim3(512), 0, s, part, nchunks, n, chunk_stride, out);
 }
 
+// weight-gradient merge that also converts the kernels' [tap][ci][co] order into the reference's
+// state_dict order [co][ci][tap] (fuses the former k_unpack_wgrad pass)
+__global__ __launch_bounds__(512) void k_reduce_slabs_sd(const float* __restrict__ part, int nchunks, int ntaps, int Cin,
+                                                         int Cout, int64_t chunk_stride, float* __restrict__ out) {
+    __shared__ double sh[8][64];
+    const int64_t n = (int64_t)ntaps * Cin * Cout;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = i0 + tx;
+        double s = 0.0;
+        if (i < n)
+            for (int c = ty; c < nchunks; c += 8) s += (double)part[(int64_t)c * chunk_stride + i];
+        sh[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && i < n) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += sh[k][tx];
+            const int co = (int)(i % Cout);
+            const int64_t r = i / Cout;
+            const int ci = (int)(r % Cin), tap = (int)(r / Cin);
+            out[((int64_t)co * Cin + ci) * ntaps + tap] = (float)a;
+        }
+        __syncthreads();
+    }
+}
+
+void tem_reduce_slabs_w(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
+                        int sd_layout, hipStream_t s) {
+    const int64_t n = (int64_t)ntaps * Cin * Cout;
+    if (!sd_layout) {
+        tem_reduce_slabs(part, nchunks, n, chunk_stride, dw, s);
+        return;
+    }
+    int64_t nb = tem_cdiv(n, 64);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_reduce_slabs_sd, dim3((unsigned)nb), dim3(512), 0, s, part, nchunks, ntaps, Cin, Cout,
+                       chunk_stride, dw);
+}
+
 #define CIN1_GRID 1024
 
 int64_t tem_conv_wgrad_cin1_ws(int Cout, int ntaps) { return (int64_t)CIN1_GRID * (ntaps + 1) * Cout * 4; }
 
 bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                          int64_t g_ld, float* dw, float* db, void* ws, int N, int D, int H, int W, int Cin, int Cout,
-                         int kd, int kh, int kw, hipStream_t s) {
+                         int kd, int kh, int kw, int sd_layout, hipStream_t s) {
     const int cq = Cout / 4;
     if (Cin != 1 || Cout % 4 || cq > 16 || (cq & (cq - 1)) || g_ld % 4 || ((uintptr_t)g % 16)) return false;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
@@ -255,7 +295,7 @@ bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const
                            shift, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX);
     }
     // dw[tap][ci=0][co] is exactly the first NT*Cout entries of a slab; db the last Cout
-    tem_reduce_slabs(part, grid, (int64_t)NT * Cout, (int64_t)(NT + 1) * Cout, dw, s);
+    tem_reduce_slabs_w(part, grid, NT, 1, Cout, (int64_t)(NT + 1) * Cout, dw, sd_layout, s);
     if (db) tem_reduce_slabs(part + (int64_t)NT * Cout, grid, Cout, (int64_t)(NT + 1) * Cout, db, s);
     return true;
 }
@@ -397,7 +437,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restr
 int64_t tem_conv1x1_proj_wgrad_ws(int Cin, int Cout) { return (int64_t)PROJ_GRID * (Cin + 1) * Cout * 4; }
 
 bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, const float* g, int64_t g_ld, float* dw,
-                            float* db, void* ws, int64_t NV, int Cin, int Cout, hipStream_t s) {
+                            float* db, void* ws, int64_t NV, int Cin, int Cout, int sd_layout, hipStream_t s) {
     if (scale || Cin % 32 || Cin > 128 || x_ld % 4 || ((uintptr_t)x % 16)) return false;
     int64_t nb = tem_cdiv(NV, 32);
     const int grid = (int)(nb < PROJ_GRID ? nb : PROJ_GRID);
@@ -413,7 +453,64 @@ bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, co
     }
 #undef PW
     const int64_t slab = (int64_t)(Cin + 1) * Cout;
-    tem_reduce_slabs(part, grid, (int64_t)Cin * Cout, slab, dw, s);  // [tap=0][ci][co]
+    tem_reduce_slabs_w(part, grid, 1, Cin, Cout, slab, dw, sd_layout, s);  // [tap=0][ci][co]
     if (db) tem_reduce_slabs(part + (int64_t)Cin * Cout, grid, Cout, slab, db, s);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// 1x1x1 expansion from a few channels (data gradient of out_conv: Cout_net <= 16 -> 32k channels):
+// thread <-> (voxel, 4 output channels); the 512 MB result is written once with 16-byte stores,
+// ReLU-backward mask fused.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv1x1_expand(const float* __restrict__ x, int64_t x_ld,
+                                                        const float* __restrict__ w /*[ci][co]*/,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int64_t y_ld, const float* __restrict__ ref, int64_t ref_ld,
+                                                        int64_t NV, int Cin, int Cout, int act) {
+    const int cq = Cout >> 2;
+    const int64_t items = NV * cq, stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t v = i / cq;
+    int q = (int)(i % cq);
+    const int64_t dv = stride / cq;
+    const int dq = (int)(stride % cq);
+    for (; i < items; i += stride, v += dv, q += dq) {
+        if (q >= cq) {
+            q -= cq;
+            ++v;
+        }
+        float4 a = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = x[v * x_ld + ci];
+            const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)ci * Cout + q * 4);
+            a.x = fmaf(xv, wv.x, a.x);
+            a.y = fmaf(xv, wv.y, a.y);
+            a.z = fmaf(xv, wv.z, a.z);
+            a.w = fmaf(xv, wv.w, a.w);
+        }
+        a.x = act_apply_s(a.x, act);
+        a.y = act_apply_s(a.y, act);
+        a.z = act_apply_s(a.z, act);
+        a.w = act_apply_s(a.w, act);
+        if (ref) {
+            const float4 rr = *reinterpret_cast<const float4*>(ref + v * ref_ld + q * 4);
+            if (!(rr.x > 0.f)) a.x = 0.f;
+            if (!(rr.y > 0.f)) a.y = 0.f;
+            if (!(rr.z > 0.f)) a.z = 0.f;
+            if (!(rr.w > 0.f)) a.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(y + v * y_ld + q * 4) = a;
+    }
+}
+
+bool tem_conv1x1_expand(const float* x, int64_t x_ld, const float* scale, const float* w, const float* bias, float* y,
+                        int64_t y_ld, const float* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act,
+                        hipStream_t s) {
+    if (scale || Cin > 16 || Cout % 4 || y_ld % 4 || ((uintptr_t)y % 16) || ((uintptr_t)w % 16) ||
+        (bias && (uintptr_t)bias % 16) || (ref && (ref_ld % 4 || (uintptr_t)ref % 16)))
+        return false;
+    hipLaunchKernelGGL(k_conv1x1_expand, dim3(tem_grid_1d(NV * (Cout / 4), 256, 256 * 16)), dim3(256), 0, s, x, x_ld, w,
+                       bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act);
     return true;
 }

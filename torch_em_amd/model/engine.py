@@ -396,6 +396,8 @@ class UNetFunction(torch.autograd.Function):
             raise RuntimeError("UNetFunction.backward called twice (activations were released)")
         gx, grads = _backward_impl(ctx.model, st, gy, ctx.params, ctx.needs_input_grad[1])
         ctx.st = None  # release activations
+        if ctx.params:
+            ctx.params[0]._tem_grad_flat = grads.flat  # lets FusedAdamW / GradSync find the arena (arena.py)
         out = [None, gx]
         for i, p in enumerate(ctx.params):
             if ctx.needs_input_grad[2 + i]:

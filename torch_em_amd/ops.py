@@ -186,20 +186,14 @@ def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, 
         raise ValueError("conv_wgrad: channel mismatch")
     lib = _lib.load()
     nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma))
-    ntaps = k[0] * k[1] * k[2]
-    tmp_bytes = ntaps * cin * cout * 4
-    ws = _workspace(nws + tmp_bytes + 256, x.device)
-    tmp_ptr = ws.data_ptr()
-    ws_ptr = tmp_ptr + ((tmp_bytes + 255) // 256) * 256
+    ws = _workspace(nws, x.device)
     ev0 = _prof_begin(x)
-    _lib.check(lib.tem_conv3d_wgrad(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, ctypes.c_void_p(tmp_ptr),
-                                    _p(db_out), ctypes.c_void_p(ws_ptr), nws, N, D, H, W, cin, cout, k[0], k[1], k[2],
-                                    int(mfma), _stream(x)), "tem_conv3d_wgrad")
-    _lib.check(lib.tem_conv_unpack_wgrad(ctypes.c_void_p(tmp_ptr), _p(dw_out), cout, cin, k[0], k[1], k[2],
-                                         _stream(x)), "tem_conv_unpack_wgrad")
+    _lib.check(lib.tem_conv3d_wgrad(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(dw_out), _p(db_out), _p(ws), nws,
+                                    N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma), 1, _stream(x)),
+               "tem_conv3d_wgrad")
     if ev0 is not None:
         kind = ("k_conv_wgrad_bf16x3" if int(mfma) == 2 else "k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + \
-            f"<{k[0]},{k[1]},{k[2]}>(+reduce,unpack)"
+            f"<{k[0]},{k[1]},{k[2]}>(+reduce)"
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return dw_out
 
