@@ -31,6 +31,16 @@ STEP_GFLOP = 5700.8             # conv fwd+bwd of cfg 2 per GPU
 STEP_GB = 25.58                 # conv-centric fp32 traffic of cfg 2 per GPU
 
 
+# live-event tags -> kernel names as rocprofv3 prints them (dominant template instantiation of each tag)
+RP_NAMES = {
+    "k_conv_fwd_bf16x6<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 3>",
+    "k_conv_fwd_bf16x6<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 3>",
+    "k_conv_fwd_bf16x3<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 2>",
+    "k_conv_fwd_bf16x3<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 2>",
+    "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_bf16x3<3, 3, 3, 2, 1>",
+    "k_conv_wgrad_bf16x3<3,3,3,NCO=1>": "k_conv_wgrad_bf16x3<3, 3, 3, 1, 2>",
+}
+
 PRECISION_DTYPE = {
     "fp32": "f32",
     "mixed": "f32 (forward: exact fp32 MFMA; backward convs: fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per "
@@ -188,6 +198,16 @@ def main():
         # split-bf16 kernels execute 3 (or 6) bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3 (6)
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
         standard = (args.batch == 2 and S == 128)
+        # HBM bytes per launch of the dominant kernel: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # passes (scripts/summarize_profiles.py -> profiles/r01_traffic_bytes_per_launch.json; gfx950 x2 FETCH correction)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_bytes_per_launch.json")))
+            key = RP_NAMES.get(dom_tag.split("(")[0])
+            if key in tj:
+                traffic = tj[key]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "voxels/sec fwd+bwd, UNet3d 1x128^3 bs=2",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,7 +218,7 @@ def main():
                                    + ("" if standard else " (NON-STANDARD SIZE)"),
                        "parallelism": f"dp{world}", "global_batch": world * args.batch, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None, "kernel": dom_tag,
+                         "frac": achieved / peak, "traffic": traffic, "kernel": dom_tag,
                          "peak_note": (f"dense bf16 MFMA peak 2500 TFLOP/s / {split} MFMAs per product (split-bf16, fp32 "
                                        "accumulate); executed-MFMA fraction of 2500 = frac" if split else
                                        "exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),

@@ -186,6 +186,7 @@ def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, 
         raise ValueError("conv_wgrad: channel mismatch")
     lib = _lib.load()
     nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma))
+    ntaps = k[0] * k[1] * k[2]
     ws = _workspace(nws, x.device)
     ev0 = _prof_begin(x)
     _lib.check(lib.tem_conv3d_wgrad(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(dw_out), _p(db_out), _p(ws), nws,
@@ -193,7 +194,8 @@ def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, 
                "tem_conv3d_wgrad")
     if ev0 is not None:
         kind = ("k_conv_wgrad_bf16x3" if int(mfma) == 2 else "k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + \
-            f"<{k[0]},{k[1]},{k[2]}>(+reduce)"
+            f"<{k[0]},{k[1]},{k[2]}" + (f",NCO={2 if cout >= 64 else 1}" if int(mfma) == 2 and ntaps > 1 else "") + \
+            ">(+reduce)"
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return dw_out
 
