@@ -1,0 +1,161 @@
+"""GPU: trainer runtime (DefaultTrainer / default_segmentation_trainer / SPOCOTrainer), fused AdamW,
+on-device label transforms -- against the oracle's CPU training loop (oracle/unet_ref.py + torch.optim.AdamW,
+which is what the reference's default_segmentation_trainer builds, segmentation.py:543)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _batches(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(1, 16, 16, 16, generator=g) for _ in range(n)]
+    ys = [(torch.rand(2, 16, 16, 16, generator=g) > 0.5).float() for _ in range(n)]
+    return torch.utils.data.TensorDataset(torch.stack(xs), torch.stack(ys))
+
+
+def test_default_trainer_matches_oracle_training(tmp_path):
+    from oracle import loss_ref, unet_ref
+    import torch_em_amd
+    from torch_em_amd.model import UNet3d
+    torch.manual_seed(0)
+    model = UNet3d(1, 2, depth=2, initial_features=4)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ds = _batches(4, 0)
+    train = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    val = torch.utils.data.DataLoader(_batches(2, 1), batch_size=1, shuffle=False)
+    trainer = torch_em_amd.default_segmentation_trainer("t", model, train, val, device=DEV, logger=None,
+                                                        save_root=str(tmp_path))
+    trainer.fit(iterations=8)
+    assert (trainer.iteration, trainer.epoch) == (8, 2)
+    # ---- oracle: same data, same order, torch.optim.AdamW with the reference's defaults ----
+    params = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-3)
+    for _ in range(2):
+        for x, y in train:
+            opt.zero_grad()
+            loss_ref.dice_loss(unet_ref.unet_forward(params, x, [2, 2]), y).backward()
+            opt.step()
+    # Adam divides by sqrt(v): a coordinate whose gradient is at round-off level (e.g. the sampler bias in front
+    # of an InstanceNorm, mathematically zero) takes +-lr steps of random sign in ANY fp32 implementation, so
+    # parameters are compared in the relative L2 norm (and those biases not at all); the loss/metric below is tight.
+    for k, v in model.state_dict().items():
+        if "samplers" in k and k.endswith("bias"):
+            continue
+        a, b = v.cpu().double(), params[k].detach().double()
+        assert float((a - b).norm() / b.norm()) < 2e-2, k
+    with torch.no_grad():
+        metric = np.mean([float(loss_ref.dice_loss(unet_ref.unet_forward(params, x, [2, 2]), y)) for x, y in val])
+    ckpt = torch.load(os.path.join(trainer.checkpoint_folder, "latest.pt"), weights_only=False)
+    assert abs(ckpt["current_metric"] - metric) < 1e-4
+    # checkpoint schema of the reference (trainer/default_trainer.py:577-602)
+    for key in ("iteration", "epoch", "best_epoch", "best_metric", "current_metric", "model_state", "optimizer_state",
+                "init", "train_time", "timestamp", "scheduler_state"):
+        assert key in ckpt, key
+    assert ckpt["iteration"] == 8 and ckpt["epoch"] == 1 and sorted(ckpt["model_state"]) == sorted(sd0)
+    st = ckpt["optimizer_state"]["state"]
+    assert len(st) == len(sd0) and {"step", "exp_avg", "exp_avg_sq"} <= set(st[0])
+    # continue, then resume from the checkpoint in a fresh trainer (reference test_default_trainer.py:69-91)
+    trainer.fit(iterations=2)
+    assert trainer.iteration == 10
+    model2 = UNet3d(1, 2, depth=2, initial_features=4)
+    trainer2 = torch_em_amd.default_segmentation_trainer("t", model2, train, val, device=DEV, logger=None,
+                                                         save_root=str(tmp_path))
+    trainer2.fit(iterations=4, load_from_checkpoint="latest")
+    assert trainer2.iteration == 14
+    # the reference class can read what we wrote
+    sd = torch.load(os.path.join(trainer.checkpoint_folder, "best.pt"), weights_only=False)["model_state"]
+    assert all(torch.is_tensor(v) for v in sd.values())
+
+
+def test_fused_adamw_single_launch_path_and_state_dict():
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    model = UNet3d(1, 2, depth=1, initial_features=4).to(DEV)
+    ref = UNet3d(1, 2, depth=1, initial_features=4).to(DEV)
+    ref.load_state_dict(model.state_dict())
+    opt, opt_ref = FusedAdamW(model.parameters(), lr=1e-3), torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    x = torch.randn(1, 1, 8, 8, 8, device=DEV)
+    y = (torch.rand(1, 2, 8, 8, 8, device=DEV) > 0.5).float()
+    for _ in range(3):
+        for m, o in ((model, opt), (ref, opt_ref)):
+            o.zero_grad()
+            DiceLoss()(m(x), y).backward()
+            o.step()
+        assert opt._arena.grads_flat() is not None  # the engine's gradient arena was recognised: one launch
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        if "samplers" in k and k.endswith("bias"):
+            continue  # round-off-level gradient: +-lr random walk under Adam (see the trainer test)
+        assert float((a - b).double().norm() / b.double().norm()) < 1e-4, k
+    sd, sd_ref = opt.state_dict(), opt_ref.state_dict()
+    assert sd["param_groups"][0]["lr"] == sd_ref["param_groups"][0]["lr"]
+    names = [k for k, _ in model.named_parameters()]
+    for i in sd_ref["state"]:
+        if "samplers" in names[i] and names[i].endswith("bias"):
+            continue
+        a, b = sd["state"][i]["exp_avg"].cpu().double(), sd_ref["state"][i]["exp_avg"].cpu().double()
+        assert float((a - b).norm() / b.norm()) < 1e-3, names[i]
+        assert int(sd["state"][i]["step"]) == int(sd_ref["state"][i]["step"]) == 3
+
+
+def test_spoco_trainer_momentum_update(tmp_path):
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.optim import FusedAdamW
+    from torch_em_amd.trainer import SPOCOTrainer
+
+    class PairLoss(torch.nn.Module):  # stands in for SPOCO like the reference's own test does
+        init_kwargs = {}
+
+        def forward(self, preds, y):
+            return DiceLoss()(preds[0], y)
+
+    torch.manual_seed(0)
+    model = UNet3d(1, 2, depth=1, initial_features=4)
+    train = torch.utils.data.DataLoader(_batches(2, 3), batch_size=1)
+    trainer = SPOCOTrainer(model=model, momentum=0.9, name="s", train_loader=train, val_loader=train, loss=PairLoss(),
+                           optimizer=FusedAdamW(model.parameters(), lr=1e-2), metric=DiceLoss(), device=DEV,
+                           save_root=str(tmp_path))
+    trainer._initialize(2, None)
+    before2 = {k: v.detach().clone() for k, v in trainer.model2.state_dict().items()}
+    x, y = next(iter(train))
+    trainer._step(x.to(DEV), trainer.loss, y.to(DEV))
+    after1 = trainer.model.state_dict()
+    for k, v in trainer.model2.state_dict().items():
+        exp = before2[k].to(DEV) * 0.9 + after1[k] * 0.1   # trainer/spoco_trainer.py:45-47
+        assert rel_err(v.cpu(), exp.cpu()) < 1e-6, k
+    assert not any(p.requires_grad for p in trainer.model2.parameters())
+    trainer.fit(iterations=2)
+    ckpt = torch.load(os.path.join(trainer.checkpoint_folder, "latest.pt"), weights_only=False)
+    assert sorted(ckpt["model2_state"]) == sorted(ckpt["model_state"])
+
+
+def test_label_transform_classes_on_device():
+    from oracle import label_ref
+    from torch_em_amd.loss import ApplyAndRemoveMask, DiceLoss, LossWrapper
+    from torch_em_amd.transform import AffinityTransform, BoundaryTransform
+    from torch_em_amd.transform.label import BatchTargets
+    rng = np.random.RandomState(0)
+    lab = rng.randint(0, 6, size=(8, 24, 20)).astype("int64")
+    offs = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0], [0, 0, -3]]
+    trafo = AffinityTransform(offs, ignore_label=0, add_mask=True)
+    out = trafo(lab)
+    assert isinstance(out, np.ndarray) and np.array_equal(out, label_ref.affinities(lab, offs, ignore_label=0, add_mask=True))
+    b = BoundaryTransform(add_binary_target=True)(torch.from_numpy(lab).to(DEV))
+    assert b.is_cuda and np.array_equal(b.cpu().numpy(), label_ref.boundaries(lab, True))
+    b2 = BoundaryTransform(ndim=2)(lab[0])
+    assert np.array_equal(b2, label_ref.boundaries(lab[0]))
+    # batch on device -> straight into the masked Dice loss (the cfg-3 target path)
+    y = BatchTargets(trafo)(torch.from_numpy(np.stack([lab, lab[::-1].copy()])).to(DEV))
+    assert tuple(y.shape) == (2, 12, 8, 24, 20)
+    pred = torch.rand(2, 6, 8, 24, 20, device=DEV, requires_grad=True)
+    LossWrapper(DiceLoss(), ApplyAndRemoveMask("multiply"))(pred, y).backward()
+    assert float(pred.grad[y[:, 6:] == 0].abs().max()) == 0.0

@@ -370,6 +370,18 @@ def dice_grad(p, t, mask, ca, cb, gout, gout_per_channel, channels_last: bool):
 
 
 # ------------------------------------------------------------- optimizer ----
+def bump_versions(tensors):
+    """The kernels below write parameters through raw pointers, which autograd's version counters do not see;
+    consumers that cache derived data per `tensor._version` (the engine's packed weight fragments) must be
+    told.  One host call per tensor, no device work."""
+    inc = getattr(torch._C, "_increment_version", None)
+    for t in tensors:
+        if inc is not None:
+            inc(t)
+        else:  # pragma: no cover -- very old torch: a no-op in-place op bumps the counter
+            t.add_(0)
+
+
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _req_cuda(param, grad, exp_avg, exp_avg_sq)
     lib = _lib.load()

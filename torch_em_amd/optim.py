@@ -69,6 +69,7 @@ class FusedAdamW(torch.optim.Optimizer):
                            group["eps"], group["weight_decay"], step, self.grad_scale)
             for p in ar.params:
                 self.state[p]["step"] += 1
+            ops.bump_versions(ar.params)
             return loss
         # general case: one launch per parameter (still the HIP kernel)
         for g in self.param_groups:
@@ -83,4 +84,5 @@ class FusedAdamW(torch.optim.Optimizer):
                 ops.adamw_step(p.data.view(-1), grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1),
                                g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                                int(st["step"].item()), self.grad_scale)
+                ops.bump_versions([p])
         return loss

@@ -71,7 +71,8 @@ class DefaultTrainer:
                  log_image_interval: int = 100, mixed_precision: bool = True, early_stopping: Optional[int] = None,
                  logger=None, logger_kwargs: Optional[Dict[str, Any]] = None, id_: Optional[str] = None,
                  save_root: Optional[str] = None, compile_model: Optional[Union[bool, str]] = None,
-                 rank: Optional[int] = None, mixed_precision_dtype: Optional[str] = None):
+                 rank: Optional[int] = None, mixed_precision_dtype: Optional[str] = None,
+                 target_transform: Optional[Callable] = None):
         if name is None:
             raise TypeError("Name cannot be None if not using the WandbLogger")
         self.name, self.id_ = name, id_ or name
@@ -89,6 +90,9 @@ class DefaultTrainer:
         self.train_time = 0.0
         self.logger_class, self.logger_kwargs = logger, logger_kwargs
         self.logger = None
+        # not in the reference: computes the training target from the label batch ON DEVICE (e.g.
+        # transform.label.BatchTargets(AffinityTransform(...))) instead of in the CPU data-loader workers
+        self.target_transform = target_transform
 
     # ---- bookkeeping ------------------------------------------------------------------
     @property
@@ -278,6 +282,8 @@ class DefaultTrainer:
         self.train_time = total_train_time
 
     def _forward_and_loss(self, x, y):
+        if getattr(self, "target_transform", None) is not None:
+            y = self.target_transform(y)
         pred = self.model(x)
         return pred, self.loss(pred, y)
 

@@ -1,0 +1,3 @@
+"""Transforms of the MI355X path that belong to the hot path (reference torch_em/transform/)."""
+from .label import AffinityTransform, BoundaryTransform, labels_to_binary
+from .raw import standardize
