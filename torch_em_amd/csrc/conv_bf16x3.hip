@@ -9,6 +9,7 @@
 // hi/lo happens once per staged element on the way into LDS, and once per weight at pack time.
 #include "tem_common.h"
 #include "conv_internal.h"
+#include <stdlib.h>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -279,6 +280,233 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
     }
 }
 
+// ---------------------------------------------------------------------------
+// forward / dgrad, wave-specialised: NL loader waves + 4 MFMA waves per workgroup, one workgroup per CU,
+// double-buffered LDS tile.  PMC on k_conv_fwd_bfsplit: the resident waves spend ~50 % of their time in
+// s_waitcnt / s_barrier (halo loads -> conversion -> LDS write -> barrier in front of every chunk) and the
+// matrix pipe is 33-56 % busy.  Here the loader waves own that whole chain for step s+1 (fp32 halo loads,
+// fused pre-norm, split into NS bf16 planes, LDS writes into the other buffer) while the MFMA waves run step s;
+// the MFMA waves' only VMEM traffic is the weight-fragment ring, so its counted vmcnt waits never queue behind
+// halo loads, and there is ONE barrier per (patch, Cout tile, 16-channel chunk) step.
+// ---------------------------------------------------------------------------
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, int NL>
+__global__ __launch_bounds__((4 + NL) * 64, 1) void k_conv_fwd_bfsplit_lc(
+    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
+    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
+    int nY, int nX, int ksplit, float* __restrict__ part, int total_units) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
+    constexpr int HV = HZ * HY * HX;
+    constexpr int RD = 3;
+    constexpr int LSV = NS * 8 + 4;
+    constexpr int LTH = NL * 64;
+    constexpr int LIT = (HV * 4 + LTH - 1) / LTH;
+    constexpr int FR = NS * 64;
+    static_assert(TZ * TY * TX == 256 && NT % RD == 0, "geometry");
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][HV][LSV]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ncot = Cout / (32 * NR);
+    const int cin16 = Cin >> 4;
+    const int spu = cin16 / ksplit;  // steps (16-channel chunks) per unit
+    const int unit0 = blockIdx.x;
+    if (unit0 >= total_units) return;
+    const int my_units = (total_units - 1 - unit0) / gridDim.x + 1;
+    const int nsteps = my_units * spu;
+    const int pvol = nX * nY * nZ;
+
+    if (wv >= 4) {
+        // ================= loader waves =================
+        const int ltid = tid - 256;
+        const int c4 = ltid & 3;
+        for (int s = 0; s < nsteps; ++s) {
+            const int u = unit0 + (s / spu) * gridDim.x;
+            int b = u / ncot;
+            const int x0 = (b % nX) * TX; b /= nX;
+            const int y0 = (b % nY) * TY; b /= nY;
+            const int z0 = (b % nZ) * TZ; b /= nZ;
+            const int n = b % N;
+            const int c16 = (b / N) * spu + s % spu;
+            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (scale) {
+                sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + c16 * 16 + c4 * 4);
+                sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + c16 * 16 + c4 * 4);
+            }
+            float4 t[LIT];
+            unsigned inb = 0;
+#pragma unroll
+            for (int it = 0; it < LIT; ++it) {
+                const int hv = (ltid + it * LTH) >> 2;
+                t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (hv < HV) {
+                    const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+                    const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
+                    if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                        t[it] = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld +
+                                                                 c16 * 16 + c4 * 4);
+                        inb |= 1u << it;
+                    }
+                }
+            }
+            float* buf = lds + (s & 1) * (HV * LSV);
+#pragma unroll
+            for (int it = 0; it < LIT; ++it) {
+                const int hv = (ltid + it * LTH) >> 2;
+                if (hv < HV) {
+                    float e[4] = {t[it].x, t[it].y, t[it].z, t[it].w};
+                    if (inb & (1u << it)) {
+                        e[0] = fmaf(e[0], sc4.x, sf4.x);
+                        e[1] = fmaf(e[1], sc4.y, sf4.y);
+                        e[2] = fmaf(e[2], sc4.z, sf4.z);
+                        e[3] = fmaf(e[3], sc4.w, sf4.w);
+                    }
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) {
+                        const unsigned h0 = pk_bf16(e[0], e[1]), h1 = pk_bf16(e[2], e[3]);
+                        *reinterpret_cast<uint2*>(buf + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
+                        if (p + 1 < NS) {
+                            e[0] -= __builtin_bit_cast(float, h0 << 16);
+                            e[1] -= __builtin_bit_cast(float, h0 & 0xffff0000u);
+                            e[2] -= __builtin_bit_cast(float, h1 << 16);
+                            e[3] -= __builtin_bit_cast(float, h1 & 0xffff0000u);
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // tile s complete; consumers are done with the buffer tile s+1 will use
+        }
+        return;
+    }
+
+    // ================= MFMA waves =================
+    const int kh = lane >> 5, r = lane & 31;
+    int abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int p = wv * 64 + m * 32 + r;
+        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+        abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;
+    }
+    const uint4* wbase = wp + lane;
+    const int64_t wtile = (int64_t)NT * cin16 * FR;  // uint4s per 32-column tile
+    const int tapstride = cin16 * FR;
+
+    floatx16 acc[2][NR];
+    uint4 bq[RD][NR][NS];
+    {
+        const int cot0 = unit0 % ncot;
+        const int c160 = ((unit0 / ncot) / pvol / N) * spu;
+#pragma unroll
+        for (int gp = 0; gp < RD - 1; ++gp)
+#pragma unroll
+            for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    bq[gp][nn][p] = wbase[(int64_t)(cot0 * NR + nn) * wtile + (int64_t)gp * tapstride + c160 * FR + p * 64];
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        const int u = unit0 + (s / spu) * gridDim.x;
+        const int cot = u % ncot;
+        const int ksl = (u / ncot) / pvol / N;
+        const int c16 = ksl * spu + s % spu;
+        const bool first = (s % spu) == 0, last = (s % spu) == spu - 1;
+        const int s1 = s + 1;
+        const int u1 = unit0 + (s1 / spu) * gridDim.x;
+        const int cot1 = u1 % ncot;
+        const int c161 = ((u1 / ncot) / pvol / N) * spu + s1 % spu;
+        const bool has_next = s1 < nsteps;
+        if (first) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
+        }
+        __syncthreads();  // tile s has landed
+        const float* buf = lds + (s & 1) * (HV * LSV);
+        int ts = tapstride;
+        asm volatile("" : "+s"(ts));
+        const int64_t wo_c = (int64_t)(cot * NR) * wtile + (int64_t)c16 * FR;
+        const int64_t wo_n = (int64_t)(cot1 * NR) * wtile + (int64_t)c161 * FR;
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+            const int toff = ((tz * HY + ty) * HX + tx) * LSV;
+            {
+                const int gp = tap + RD - 1;
+                if (gp < NT) {
+#pragma unroll
+                    for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                        for (int p = 0; p < NS; ++p)
+                            bq[gp % RD][nn][p] = wbase[wo_c + nn * wtile + (int64_t)gp * ts + p * 64];
+                } else if (has_next) {
+#pragma unroll
+                    for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                        for (int p = 0; p < NS; ++p)
+                            bq[gp % RD][nn][p] = wbase[wo_n + nn * wtile + (int64_t)(gp - NT) * ts + p * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0x38F);
+            }
+            bf16x8 af[2][NS];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    af[m][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + abase[m] + toff + p * 8));
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NR; ++nn) {
+#pragma unroll
+                    for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                        for (int i = 0; i <= sum; ++i) {
+                            const int j = sum - i;
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                af[m][i], __builtin_bit_cast(bf16x8, bq[tap % RD][nn][j]), acc[m][nn], 0, 0, 0);
+                        }
+                }
+        }
+        if (last) {
+            int b = u / ncot;
+            const int x0 = (b % nX) * TX; b /= nX;
+            const int y0 = (b % nY) * TY; b /= nY;
+            const int z0 = (b % nZ) * TZ; b /= nZ;
+            const int n = b % N;
+#pragma unroll
+            for (int nn = 0; nn < NR; ++nn) {
+                const int co = (cot * NR + nn) * 32 + r;
+                const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                        const int p = wv * 64 + m * 32 + row;
+                        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+                        const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+                        if (gz < D && gy < H && gx < W) {
+                            const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
+                            if (ksplit > 1) {
+                                part[((int64_t)ksl * N * D * H * W + v) * Cout + co] = acc[m][nn][reg];
+                            } else {
+                                float o = act_apply_b(acc[m][nn][reg] + bv, act);
+                                if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
+                                y[v * y_ld + co] = o;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS>
 static void launch_b(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
@@ -287,6 +515,36 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     const int nZ = (D + TZ - 1) / TZ, nY = (H + TY - 1) / TY, nX = (W + TX - 1) / TX;
     const int64_t nblk = (int64_t)N * nZ * nY * nX * (Cout / (32 * NR)) * ksplit;
     constexpr size_t ldsb = (size_t)HV * (NS * 8 + 4) * sizeof(float);
+    // measured slower than the 2-workgroups/CU kernel below (1 MFMA wave per SIMD cannot hide its own LDS-read
+    // latency: 32->32 128^3 bf16x3 1.47 ms vs 1.00 ms); kept as an experiment switch, off by default
+    static const int lcmode = getenv("TEM_SPLIT_LC") ? atoi(getenv("TEM_SPLIT_LC")) : 0;
+    if constexpr ((KD * KH * KW) % 3 == 0) {
+        if (lcmode) {
+            constexpr int NL = 2;
+            constexpr size_t lds2 = 2 * ldsb;
+            static_assert(lds2 <= 160 * 1024, "LDS budget");
+            static bool attr2 = false;
+            if (!attr2) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit_lc<KD, KH, KW, TZ, TY, TX, NR, NS, NL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                attr2 = true;
+            }
+            static int ncu = 0;
+            if (!ncu) {
+                ncu = tem_device_cus();
+                if (ncu <= 0) ncu = 256;
+            }
+            const int64_t grid = nblk < ncu ? nblk : ncu;
+            hipLaunchKernelGGL((k_conv_fwd_bfsplit_lc<KD, KH, KW, TZ, TY, TX, NR, NS, NL>), dim3((unsigned)grid),
+                               dim3((4 + NL) * 64), lds2, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp), bias,
+                               y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, nZ, nY, nX, ksplit, part, (int)nblk);
+            if (ksplit > 1) {
+                const int64_t NV = (int64_t)N * D * H * W;
+                tem_splitk_epilogue(part, ksplit, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
+            }
+            return;
+        }
+    }
     static bool attr_done = false;
     if (!attr_done && ldsb > 64 * 1024) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS>),
