@@ -219,6 +219,62 @@ int tem_affinity_target(const int64_t* labels, float* out, int D, int H, int W,
                         int add_binary_target, int add_mask, int include_ignore_transitions,
                         tem_stream_t stream);
 
+/* ---- SPOCO / contrastive embedding losses --------------------
+ * Embeddings: float [E][V] planes of ONE sample, voxel-fastest, channel stride cs (>= V); labels int64 [V],
+ * consecutive ids 0..C-1.  E <= 32.  Per-slice Dice terms see the volume as [nz][V/nz] (nz = first spatial
+ * axis, which is DiceLoss()'s channel axis for the reference's [1|A, *spatial] pmaps).  Every *_out / means /
+ * counts pointer is DEVICE memory; scalars come back as device floats (no host sync inside the library).
+ * Segment sums use 64-bit fixed point (2^-28) so results are bit-reproducible.  ws: tem_spoco_ws bytes. */
+int64_t tem_spoco_ws(int C, int E, int64_t V, int nz, int n_anchors, int n_offsets);
+/* out_minmax[2] (device) = {min, max} label: C = max+1; reference asserts min == 0 (loss/spoco_loss.py:30-31) */
+int tem_label_range(const int64_t* labels, int64_t V, int64_t* out_minmax, void* ws, int64_t ws_bytes, tem_stream_t stream);
+/* compute_cluster_means (loss/spoco_loss.py:16-33; torch_scatter.scatter_mean, contrastive_impl.py:14-25):
+ * means [C][E], counts [C] (as float; empty label -> mean 0, count 0). */
+int tem_spoco_cluster_means(const float* emb, int64_t cs, const int64_t* labels, int64_t V, int E, int C,
+                            float* means, float* counts, void* ws, int64_t ws_bytes, tem_stream_t stream);
+/* variance (pull) term, contrastive_impl.py:86-129: value_out[0] = sum_v (|e_v-mu_l|-delta_var)+^2 / count_l
+ * (caller divides by the instance count); S_out [C][E] = sum_{v in l} h_v * unit(e_v - mu_l) for the backward. */
+int tem_spoco_pull(const float* emb, int64_t cs, const int64_t* labels, int64_t V, int E, int C, const float* means,
+                   const float* counts, float delta_var, float* value_out, float* S_out, void* ws, int64_t ws_bytes,
+                   tem_stream_t stream);
+/* distance (push) term contrastive_impl.py:28-80 and regulariser spoco_loss.py:205-213 on the [C][E] means:
+ * values_out2 = {distance term, regulariser}; ddist/dreg [C][E] = their gradients wrt the means. */
+int tem_spoco_means_terms(const float* means, int C, int E, float delta_dist, int ignore_zero, float* values_out2,
+                          float* ddist, float* dreg, void* ws, int64_t ws_bytes, tem_stream_t stream);
+/* instance Dice term, spoco_loss.py:386-430 + GaussianKernel :85-95 (value only: the reference detaches it at :422):
+ * mean over instances i>=1 of sum_z (1 - dice(exp(-|e-mu_i|^2/two_sigma), label==i)). */
+int tem_spoco_instance_dice(const float* emb, int64_t cs, const int64_t* labels, int64_t V, int nz, int E, int C,
+                            const float* means, float two_sigma, float eps, float* value_out, void* ws, int64_t ws_bytes,
+                            tem_stream_t stream);
+/* unlabeled push, spoco_loss.py:162-190: value_out[0]; grad (nullable) += grad_scale * d push/d emb;
+ * dpush [C][E] = d push / d means.  Needs C > 1; counts[0] = number of background voxels. */
+int tem_spoco_push(const float* emb, int64_t cs, const int64_t* labels, int64_t V, int E, int C, const float* means,
+                   const float* counts, float delta_dist, float* value_out, float grad_scale, float* grad, int64_t gcs,
+                   float* dpush, void* ws, int64_t ws_bytes, tem_stream_t stream);
+/* d/d emb of  w_var*variance + w_dist*distance + w_reg*regulariser + w_push*push(means part), chained through the
+ * means: grad (=|+=) w_var*2h/(n_inst*count_l)*unit + dmu_l/count_l.  dpush may be NULL. */
+int tem_spoco_embed_grad(const float* emb, int64_t cs, const int64_t* labels, int64_t V, int E, int C,
+                         const float* means, const float* counts, const float* S, const float* ddist, const float* dreg,
+                         const float* dpush, float delta_var, float n_inst, float w_var, float w_dist, float w_reg,
+                         float w_push, float* grad, int64_t gcs, int accumulate, void* ws, int64_t ws_bytes,
+                         tem_stream_t stream);
+/* unlabeled-voxel bookkeeping for the consistency anchors (spoco_loss.py:509-514): chunk_counts has
+ * ceil(V/1024) ints; total_out[0] (device) = number of label==0 voxels; tem_zero_select maps ranks (device int64
+ * [A], each < total) to flat voxel indices in row-major order (the order of torch.nonzero). */
+int tem_zero_count(const int64_t* labels, int64_t V, int* chunk_counts, int64_t* total_out, tem_stream_t stream);
+int tem_zero_select(const int64_t* labels, int64_t V, const int* chunk_counts, const int64_t* ranks, int A,
+                    int64_t* idx_out, tem_stream_t stream);
+/* embedding consistency, spoco_loss.py:503-527: Dice between the q and k Gaussian pmaps of A anchors (A <= 64);
+ * value_out[0]; grad_q (nullable) += grad_scale * d/d emb_q (including the anchor voxels). */
+int tem_spoco_consistency(const float* emb_q, const float* emb_k, int64_t cs, int64_t V, int nz, int E,
+                          const int64_t* anchor_idx, int A, float two_sigma, float eps, float* value_out,
+                          float grad_scale, float* grad_q, int64_t gcs, void* ws, int64_t ws_bytes, tem_stream_t stream);
+/* AffinitySideLoss, loss/affinity_side_loss.py:92-172 for already-drawn offsets (HOST int [K][3] z,y,x; K <= 32;
+ * 2-D data: D == 1, z offset 0): value_out[0] = sum_k (1 - dice_k); grad (nullable) += grad_scale * d/d emb. */
+int tem_affinity_side(const float* emb, int64_t cs, const int64_t* labels, int D, int H, int W, int E,
+                      const int* offsets_zyx, int K, float delta, float eps, float* value_out, float grad_scale,
+                      float* grad, int64_t gcs, void* ws, int64_t ws_bytes, tem_stream_t stream);
+
 /* ---- small utilities ---------------------------------------------------------- */
 /* NCDHW (contiguous) <-> NDHWC(ld) layout change at the module boundary. */
 int tem_nchw_to_nhwc(const float* src, float* dst, int64_t dst_ld, int N, int C, int64_t V, tem_stream_t stream);

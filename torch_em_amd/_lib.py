@@ -56,6 +56,23 @@ SIGNATURES = {
     "tem_nchw_to_nhwc": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_i64, c_vp]),
     "tem_nhwc_to_nchw": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_i64, c_vp]),
     "tem_standardize": (c_int, [c_vp, c_vp, c_int, c_i64, c_float, c_vp, c_i64, c_vp]),
+    "tem_spoco_ws": (c_i64, [c_int, c_int, c_i64, c_int, c_int, c_int]),
+    "tem_label_range": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "tem_spoco_cluster_means": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "tem_spoco_pull": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "tem_spoco_means_terms": (c_int, [c_vp, c_int, c_int, c_float, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "tem_spoco_instance_dice": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_float, c_float, c_vp,
+                                        c_vp, c_i64, c_vp]),
+    "tem_spoco_push": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_float, c_vp, c_float, c_vp, c_i64,
+                               c_vp, c_vp, c_i64, c_vp]),
+    "tem_spoco_embed_grad": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
+                             + [c_float] * 6 + [c_vp, c_i64, c_int, c_vp, c_i64, c_vp]),
+    "tem_zero_count": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "tem_zero_select": (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "tem_spoco_consistency": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_int, c_float, c_float, c_vp,
+                                      c_float, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "tem_affinity_side": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int, c_float,
+                                  c_float, c_vp, c_float, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "tem_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
 }
 

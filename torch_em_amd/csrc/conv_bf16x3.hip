@@ -525,7 +525,7 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
             static_assert(lds2 <= 160 * 1024, "LDS budget");
             static bool attr2 = false;
             if (!attr2) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit_lc<KD, KH, KW, TZ, TY, TX, NR, NS, NL>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit_lc<KD, KH, KW, TZ, TY, TX, NR, NS, NL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
                 attr2 = true;
             }
@@ -547,7 +547,7 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     }
     static bool attr_done = false;
     if (!attr_done && ldsb > 64 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         attr_done = true;
     }
@@ -934,7 +934,7 @@ static void launch_wb(const float* x, int64_t x_ld, const float* scale, const fl
     static_assert(ldsbytes <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes);
         attr_done = true;
     }
