@@ -138,6 +138,69 @@ def test_spoco_trainer_momentum_update(tmp_path):
     assert sorted(ckpt["model2_state"]) == sorted(ckpt["model_state"])
 
 
+def test_spoco_training_matches_oracle(tmp_path):
+    """SPOCOTrainer + SPOCOLoss end to end (student fwd/bwd, no-grad teacher fwd, AdamW, EMA) vs the CPU oracle loop
+    (reference trainer/spoco_trainer.py:90-130 with loss/spoco_loss.py)."""
+    from oracle import spoco_ref, unet_ref
+    from torch_em_amd.loss import SPOCOLoss
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.optim import FusedAdamW
+    from torch_em_amd.trainer import SPOCOTrainer
+    kw = dict(delta_var=0.75, delta_dist=2.0, max_anchors=6)
+    g = torch.Generator().manual_seed(3)
+    xs = torch.randn(3, 1, 16, 16, 16, generator=g)
+    ys = torch.randint(0, 3, (3, 1, 4, 4, 4), generator=g).repeat_interleave(4, 2).repeat_interleave(4, 3) \
+        .repeat_interleave(4, 4)
+    ys[:, :, :8, :4] = 0
+    for b in range(3):
+        assert sorted(torch.unique(ys[b]).tolist()) == [0, 1, 2]
+    ds = torch.utils.data.TensorDataset(xs, ys)
+    train = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    torch.manual_seed(0)
+    model = UNet3d(1, 4, depth=2, initial_features=4)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    class Metric(torch.nn.Module):
+        init_kwargs = {}
+
+        def forward(self, pred, y):
+            return pred.float().mean() * 0 + 1.0
+
+    trainer = SPOCOTrainer(model=model, momentum=0.9, name="sp", train_loader=train, val_loader=train,
+                           loss=SPOCOLoss(**kw), optimizer=FusedAdamW(model.parameters(), lr=1e-3), metric=Metric(),
+                           device=DEV, save_root=str(tmp_path), logger=None, mixed_precision=False)
+    np.random.seed(5)
+    trainer._initialize(3, None)
+    losses = []
+    for x, y in train:
+        losses.append(float(trainer._step(x.to(DEV), trainer.loss, y.to(DEV))[1].sum()))
+    # ---- oracle ----
+    p1 = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    p2 = {k: v.clone() for k, v in sd0.items()}
+    opt = torch.optim.AdamW(list(p1.values()), lr=1e-3)
+    np.random.seed(5)
+    want = []
+    for x, y in train:
+        opt.zero_grad()
+        q = unet_ref.unet_forward(p1, x, [2, 2])
+        with torch.no_grad():
+            k = unet_ref.unet_forward(p2, x, [2, 2])
+        val = spoco_ref.spoco_forward(q, k, y, **kw)
+        val.sum().backward()
+        opt.step()
+        with torch.no_grad():
+            for key in p2:
+                p2[key] = p2[key] * 0.9 + p1[key].detach() * 0.1
+        want.append(float(val.sum()))
+    np.testing.assert_allclose(losses, want, rtol=2e-3)  # later steps sit on an Adam trajectory (see above)
+    np.testing.assert_allclose(losses[0], want[0], rtol=5e-5)
+    for k, v in trainer.model2.state_dict().items():
+        if "samplers" in k and k.endswith("bias"):
+            continue
+        a, b = v.cpu().double(), p2[k].double()
+        assert float((a - b).norm() / b.norm()) < 2e-2, k
+
+
 def test_label_transform_classes_on_device():
     from oracle import label_ref
     from torch_em_amd.loss import ApplyAndRemoveMask, DiceLoss, LossWrapper
