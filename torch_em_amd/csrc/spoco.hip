@@ -51,6 +51,43 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* sh /*[nwaves*NV
     __syncthreads();
 }
 
+// Sum 8 per-lane values over the 64 lanes with 10 shuffles instead of 48: each butterfly step keeps half of the values
+// and hands the other half to the partner lane (a transposing reduction).  Afterwards EVERY lane holds the wave total
+// of value index reduce8_index(lane).  Fixed order => deterministic.
+__device__ __forceinline__ int reduce8_index(int lane) { return (lane & 1) * 4 + ((lane >> 1) & 1) * 2 + ((lane >> 2) & 1); }
+__device__ __forceinline__ float wave_reduce8(const float* v, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float w[4], u[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float send = b0 ? v[i] : v[i + 4], keep = b0 ? v[i + 4] : v[i];
+        w[i] = keep + __shfl_xor(send, 1, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float send = b1 ? w[i] : w[i + 2], keep = b1 ? w[i + 2] : w[i];
+        u[i] = keep + __shfl_xor(send, 2, 64);
+    }
+    float t = (b2 ? u[1] : u[0]) + __shfl_xor(b2 ? u[0] : u[1], 4, 64);
+    t += __shfl_xor(t, 8, 64);
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    return t;
+}
+
+// deterministic block sum of one double per thread (butterfly inside a wave, waves in index order); valid in thread 0
+__device__ __forceinline__ double block_sum_d(double v, double* sh /*[nwaves]*/) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = tem_wave_sum_d(v);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < nw; ++w) s += sh[w];
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // label range
 // ------------------------------------------------------------------------------------------------
@@ -83,12 +120,29 @@ __global__ void k_label_range(const int64_t* __restrict__ lbl, int64_t V, long l
         part[blockIdx.x * 2 + 1] = mx;
     }
 }
-__global__ void k_label_range_final(const long long* __restrict__ part, int nb, int64_t* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        long long mn = INT64_MAX, mx = INT64_MIN;
-        for (int b = 0; b < nb; ++b) {
-            mn = part[b * 2] < mn ? part[b * 2] : mn;
-            mx = part[b * 2 + 1] > mx ? part[b * 2 + 1] : mx;
+__global__ __launch_bounds__(256) void k_label_range_final(const long long* __restrict__ part, int nb,
+                                                            int64_t* __restrict__ out) {
+    long long mn = INT64_MAX, mx = INT64_MIN;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        mn = part[b * 2] < mn ? part[b * 2] : mn;
+        mx = part[b * 2 + 1] > mx ? part[b * 2 + 1] : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        long long a = shfl_xor_ll(mn, o), b = shfl_xor_ll(mx, o);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    __shared__ long long sh[2][4];
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = mn;
+        sh[1][threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            mn = sh[0][w] < mn ? sh[0][w] : mn;
+            mx = sh[1][w] > mx ? sh[1][w] : mx;
         }
         out[0] = mn;
         out[1] = mx;
@@ -103,7 +157,7 @@ extern "C" int64_t tem_spoco_ws(int C, int E, int64_t V, int nz, int A, int K) {
     b += (int64_t)C * (2 * E + 4) * 8;                         // row values / combined dmeans
     b += (int64_t)nz * (C > 0 ? C : 1) * SP_NCH * 4 * 4;       // instance-dice partials
     b += (int64_t)nz * SP_NCH * (3 + (int64_t)(A > 0 ? A : 1) * E) * 4 + (int64_t)nz * 16 + (int64_t)A * E * 8;
-    b += (int64_t)SP_MAXB * (K > 0 ? K : 1) * 3 * 4 + (int64_t)K * 16;
+    b += (int64_t)SP_MAXB * (K > 0 ? K : 1) * 3 * 4 + (int64_t)K * 24;
     return b + 4096;
 }
 
@@ -114,7 +168,7 @@ extern "C" int tem_label_range(const int64_t* lbl, int64_t V, int64_t* out_minma
     const int nb = tem_grid_1d(V, 256, SP_MAXB);
     TEM_REQUIRE(ws_bytes >= (int64_t)nb * 16, "tem_label_range: workspace too small");
     hipLaunchKernelGGL(k_label_range, dim3(nb), dim3(256), 0, s, lbl, V, (long long*)ws);
-    hipLaunchKernelGGL(k_label_range_final, dim3(1), dim3(64), 0, s, (const long long*)ws, nb, out_minmax);
+    hipLaunchKernelGGL(k_label_range_final, dim3(1), dim3(256), 0, s, (const long long*)ws, nb, out_minmax);
     TEM_CHECK_LAUNCH("tem_label_range");
     return TEM_OK;
 }
@@ -208,12 +262,13 @@ __global__ void k_means_finalize(const u64* __restrict__ acc, int C, int E, floa
     if (e == 0) counts[c] = (float)cnt;
 }
 
-__global__ void k_sum_partials(const float* __restrict__ part, int n, double scale, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += (double)part[i];
-        out[0] = (float)(s * scale);
-    }
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int n, double scale,
+                                                       float* __restrict__ out) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += (double)part[i];
+    const double s = block_sum_d(v, sh);
+    if (threadIdx.x == 0) out[0] = (float)(s * scale);
 }
 
 #define SP_DISPATCH_E(E, CALL)                       \
@@ -277,7 +332,7 @@ extern "C" int tem_spoco_pull(const float* emb, int64_t cs, const int64_t* lbl, 
                        means, counts, delta_var, acc, use_lds, vpart)
     SP_DISPATCH_E(E, CALL);
 #undef CALL
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, vpart, nb, 1.0, value_out);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, vpart, nb, 1.0, value_out);
     hipLaunchKernelGGL(k_fix_to_float, dim3((unsigned)tem_cdiv((int64_t)C * E, 256)), dim3(256), 0, s, acc, C, E, S_out);
     TEM_CHECK_LAUNCH("tem_spoco_pull");
     return TEM_OK;
@@ -419,29 +474,32 @@ __global__ __launch_bounds__(256) void k_instance_sums(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void k_instance_final(const float* __restrict__ part, int nz, int C, double eps,
-                                                         double* __restrict__ per_inst, float* __restrict__ out) {
-    for (int i = 1 + threadIdx.x; i < C; i += blockDim.x) {
-        double loss = 0.0;
-        for (int z = 0; z < nz; ++z) {
-            double num = 0.0, pp = 0.0, mm = 0.0;
-            for (int ch = 0; ch < SP_NCH; ++ch) {
-                const float* q = part + (((int64_t)z * C + i) * SP_NCH + ch) * 3;
-                num += q[0];
-                pp += q[1];
-                mm += q[2];
-            }
-            const double den = pp + mm;
-            loss += 1.0 - 2.0 * (num / (den < eps ? eps : den));
+__global__ __launch_bounds__(256) void k_instance_rows(const float* __restrict__ part, int nz, int C, double eps,
+                                                        double* __restrict__ per_inst) {
+    __shared__ double sh[4];
+    const int i = blockIdx.x + 1;
+    double loss = 0.0;
+    for (int z = threadIdx.x; z < nz; z += blockDim.x) {
+        double num = 0.0, pp = 0.0, mm = 0.0;
+        for (int ch = 0; ch < SP_NCH; ++ch) {
+            const float* q = part + (((int64_t)z * C + i) * SP_NCH + ch) * 3;
+            num += q[0];
+            pp += q[1];
+            mm += q[2];
         }
-        per_inst[i] = loss;
+        const double den = pp + mm;
+        loss += 1.0 - 2.0 * (num / (den < eps ? eps : den));
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 1; i < C; ++i) s += per_inst[i];
-        out[0] = C > 1 ? (float)(s / (C - 1)) : 0.f;
-    }
+    const double s = block_sum_d(loss, sh);
+    if (threadIdx.x == 0) per_inst[i] = s;
+}
+__global__ __launch_bounds__(256) void k_instance_final(const double* __restrict__ per_inst, int C,
+                                                         float* __restrict__ out) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int i = 1 + threadIdx.x; i < C; i += blockDim.x) v += per_inst[i];
+    const double s = block_sum_d(v, sh);
+    if (threadIdx.x == 0) out[0] = C > 1 ? (float)(s / (C - 1)) : 0.f;
 }
 
 extern "C" int tem_spoco_instance_dice(const float* emb, int64_t cs, const int64_t* lbl, int64_t V, int nz, int E, int C,
@@ -465,7 +523,8 @@ extern "C" int tem_spoco_instance_dice(const float* emb, int64_t cs, const int64
         SP_DISPATCH_E(E, CALL);
 #undef CALL
     }
-    hipLaunchKernelGGL(k_instance_final, dim3(1), dim3(256), 0, s, part, nz, C, (double)eps, per_inst, value_out);
+    if (C > 1) hipLaunchKernelGGL(k_instance_rows, dim3(C - 1), dim3(256), 0, s, part, nz, C, (double)eps, per_inst);
+    hipLaunchKernelGGL(k_instance_final, dim3(1), dim3(256), 0, s, (const double*)per_inst, C, value_out);
     TEM_CHECK_LAUNCH("tem_spoco_instance_dice");
     return TEM_OK;
 }
@@ -648,12 +707,13 @@ __global__ __launch_bounds__(256) void k_zero_counts(const int64_t* __restrict__
     block_sum<1>(a, sh, o1);  // <= 1024: exact in fp32
     if (threadIdx.x == 0) chunk_counts[blockIdx.x] = (int)o1[0];
 }
-__global__ void k_zero_total(const int* __restrict__ chunk_counts, int64_t nchunk, int64_t* __restrict__ total) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        long long s = 0;
-        for (int64_t i = 0; i < nchunk; ++i) s += chunk_counts[i];
-        total[0] = s;
-    }
+__global__ __launch_bounds__(256) void k_zero_total(const int* __restrict__ chunk_counts, int64_t nchunk,
+                                                     int64_t* __restrict__ total) {
+    __shared__ double sh[4];
+    double v = 0.0;  // integers < 2^53: exact
+    for (int64_t i = threadIdx.x; i < nchunk; i += blockDim.x) v += (double)chunk_counts[i];
+    const double s = block_sum_d(v, sh);
+    if (threadIdx.x == 0) total[0] = (int64_t)s;
 }
 __global__ __launch_bounds__(64) void k_kth_zero(const int64_t* __restrict__ lbl, int64_t V,
                                                   const int* __restrict__ chunk_counts, int64_t nchunk,
@@ -705,7 +765,7 @@ extern "C" int tem_zero_count(const int64_t* lbl, int64_t V, int* chunk_counts, 
     TEM_REQUIRE(lbl && chunk_counts && total_out && V > 0, "tem_zero_count: null pointer or empty input");
     const int64_t nchunk = tem_cdiv(V, ZCH);
     hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)nchunk), dim3(256), 0, s, lbl, V, chunk_counts);
-    hipLaunchKernelGGL(k_zero_total, dim3(1), dim3(64), 0, s, chunk_counts, nchunk, total_out);
+    hipLaunchKernelGGL(k_zero_total, dim3(1), dim3(256), 0, s, chunk_counts, nchunk, total_out);
     TEM_CHECK_LAUNCH("tem_zero_count");
     return TEM_OK;
 }
@@ -795,13 +855,17 @@ __global__ __launch_bounds__(256) void k_consistency(const float* __restrict__ e
             } else {
                 // dq_pmap/de = pq * (-2/two_sigma) * (e - anchor); the anchor voxel receives the opposite
                 const float cf = grad_scale * (c_k * pk + c_q * pq) * pq * (-2.f * inv_two_sigma);
+                float gv[EM];
 #pragma unroll
-                for (int e = 0; e < EM; ++e)
-                    if (e < E) {
-                        const float g = cf * dq[e];
-                        ge[e] += g;
-                        const float sg = tem_wave_sum(g);
-                        if (lane == 0) wacc[(wv * A + a) * EM + e] -= sg;
+                for (int e = 0; e < EM; ++e) {
+                    gv[e] = cf * dq[e];
+                    ge[e] += gv[e];
+                }
+#pragma unroll
+                for (int e0 = 0; e0 < EM; e0 += 8)
+                    if (e0 < E) {
+                        const float tot = wave_reduce8(gv + e0, lane);
+                        if (lane < 8) wacc[(wv * A + a) * EM + e0 + reduce8_index(lane)] -= tot;
                     }
             }
         }
@@ -825,35 +889,42 @@ __global__ __launch_bounds__(256) void k_consistency(const float* __restrict__ e
         }
     }
 }
-__global__ void k_consistency_final(const float* __restrict__ part, int nz, double eps, double* __restrict__ zs,
-                                    float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double loss = 0.0;
-        for (int z = 0; z < nz; ++z) {
-            double n = 0.0, qq = 0.0, kk = 0.0;
-            for (int ch = 0; ch < SP_NCH; ++ch) {
-                const float* p = part + ((int64_t)z * SP_NCH + ch) * 3;
-                n += p[0];
-                qq += p[1];
-                kk += p[2];
-            }
-            const double d = qq + kk;
-            zs[z * 2] = n;
-            zs[z * 2 + 1] = d;
-            loss += 1.0 - 2.0 * (n / (d < eps ? eps : d));
+__global__ __launch_bounds__(256) void k_consistency_final(const float* __restrict__ part, int nz, double eps,
+                                                            double* __restrict__ zs, float* __restrict__ out) {
+    __shared__ double sh[4];
+    double loss = 0.0;
+    for (int z = threadIdx.x; z < nz; z += blockDim.x) {
+        double n = 0.0, qq = 0.0, kk = 0.0;
+        for (int ch = 0; ch < SP_NCH; ++ch) {
+            const float* p = part + ((int64_t)z * SP_NCH + ch) * 3;
+            n += p[0];
+            qq += p[1];
+            kk += p[2];
         }
-        out[0] = (float)loss;
+        const double d = qq + kk;
+        zs[z * 2] = n;
+        zs[z * 2 + 1] = d;
+        loss += 1.0 - 2.0 * (n / (d < eps ? eps : d));
     }
+    const double s = block_sum_d(loss, sh);
+    if (threadIdx.x == 0) out[0] = (float)s;
 }
-__global__ void k_anchor_scatter(const float* __restrict__ apart, int64_t nblk, const int64_t* __restrict__ idx, int A,
-                                 int E, float* __restrict__ grad, int64_t gcs) {
+// anchor gradients: block (a, e) sums the per-block partials, then ONE thread per channel adds them to the anchor
+// voxels sequentially (the same voxel may have been drawn twice).
+__global__ __launch_bounds__(256) void k_anchor_reduce(const float* __restrict__ apart, int64_t nblk, int A, int E,
+                                                        double* __restrict__ ganc /*[A][E]*/) {
+    __shared__ double sh[4];
+    const int a = blockIdx.x / E, e = blockIdx.x % E;
+    double v = 0.0;
+    for (int64_t b = threadIdx.x; b < nblk; b += blockDim.x) v += (double)apart[(b * A + a) * E + e];
+    const double s = block_sum_d(v, sh);
+    if (threadIdx.x == 0) ganc[a * E + e] = s;
+}
+__global__ void k_anchor_scatter(const double* __restrict__ ganc, const int64_t* __restrict__ idx, int A, int E,
+                                 float* __restrict__ grad, int64_t gcs) {
     const int e = threadIdx.x;
     if (e >= E) return;
-    for (int a = 0; a < A; ++a) {  // sequential: the same voxel may have been drawn twice
-        double sres = 0.0;
-        for (int64_t b = 0; b < nblk; ++b) sres += apart[(b * A + a) * E + e];
-        grad[(int64_t)e * gcs + idx[a]] += (float)sres;
-    }
+    for (int a = 0; a < A; ++a) grad[(int64_t)e * gcs + idx[a]] += (float)ganc[a * E + e];
 }
 
 extern "C" int tem_spoco_consistency(const float* emb_q, const float* emb_k, int64_t cs, int64_t V, int nz, int E,
@@ -869,6 +940,7 @@ extern "C" int tem_spoco_consistency(const float* emb_q, const float* emb_k, int
     float* part = (float*)ws_take(p, (int64_t)nz * SP_NCH * 3 * 4);
     double* zs = (double*)ws_take(p, (int64_t)nz * 16);
     float* apart = (float*)ws_take(p, (int64_t)nz * SP_NCH * A * E * 4);
+    double* ganc = (double*)ws_take(p, (int64_t)A * E * 8);
     TEM_REQUIRE(p - (char*)ws <= ws_bytes, "tem_spoco_consistency: workspace too small");
     hipLaunchKernelGGL(k_gather_anchors, dim3((unsigned)tem_cdiv((int64_t)A * E, 64)), dim3(64), 0, s, emb_q, emb_k, cs,
                        anchor_idx, A, E, anc);
@@ -878,12 +950,13 @@ extern "C" int tem_spoco_consistency(const float* emb_q, const float* emb_k, int
         hipLaunchKernelGGL((k_consistency<EMV, false>), dim3(SP_NCH, nz), dim3(256), (size_t)A * 2 * EMV * 4, s, emb_q, \
                            emb_k, cs, slice, E, A, anc, 1.f / two_sigma, part, (const double*)nullptr, (double)eps, 0.f, \
                            (float*)nullptr, (int64_t)0, (float*)nullptr);                                            \
-        hipLaunchKernelGGL(k_consistency_final, dim3(1), dim3(64), 0, s, part, nz, (double)eps, zs, value_out);       \
+        hipLaunchKernelGGL(k_consistency_final, dim3(1), dim3(256), 0, s, part, nz, (double)eps, zs, value_out);       \
         if (grad_q) {                                                                                                \
             hipLaunchKernelGGL((k_consistency<EMV, true>), dim3(SP_NCH, nz), dim3(256),                               \
                                (size_t)(A * 2 * EMV + 4 * A * EMV) * 4, s, emb_q, emb_k, cs, slice, E, A, anc,        \
                                1.f / two_sigma, part, (const double*)zs, (double)eps, grad_scale, grad_q, gcs, apart); \
-            hipLaunchKernelGGL(k_anchor_scatter, dim3(1), dim3(64), 0, s, apart, (int64_t)nz* SP_NCH, anchor_idx, A, E, \
+            hipLaunchKernelGGL(k_anchor_reduce, dim3(A* E), dim3(256), 0, s, apart, (int64_t)nz* SP_NCH, A, E, ganc);  \
+            hipLaunchKernelGGL(k_anchor_scatter, dim3(1), dim3(64), 0, s, (const double*)ganc, anchor_idx, A, E,      \
                                grad_q, gcs);                                                                         \
         }                                                                                                            \
     } while (0)
@@ -932,23 +1005,28 @@ __global__ __launch_bounds__(256) void k_aff_sums(const float* __restrict__ emb,
     block_sum<3>(acc, sh, o3);
     if (threadIdx.x < 3) part[((int64_t)k * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = o3[threadIdx.x];
 }
-__global__ void k_aff_final(const float* __restrict__ part, int K, int nb, double eps, double* __restrict__ ks,
-                            float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_aff_rows(const float* __restrict__ part, int nb, double eps,
+                                                   double* __restrict__ ks /*[K][3]*/) {
+    __shared__ double sh[4];
+    const int k = blockIdx.x;
+    double n = 0.0, d = 0.0;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        const float* p = part + ((int64_t)k * nb + b) * 3;
+        n += p[0];
+        d += (double)p[1] + (double)p[2];
+    }
+    n = block_sum_d(n, sh);
+    d = block_sum_d(d, sh);
+    if (threadIdx.x == 0) {
+        ks[k * 3] = n;
+        ks[k * 3 + 1] = d;
+        ks[k * 3 + 2] = 1.0 - 2.0 * (n / (d < eps ? eps : d));
+    }
+}
+__global__ void k_aff_final(const double* __restrict__ ks, int K, float* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double loss = 0.0;
-        for (int k = 0; k < K; ++k) {
-            double n = 0.0, aa = 0.0, tt = 0.0;
-            for (int b = 0; b < nb; ++b) {
-                const float* p = part + ((int64_t)k * nb + b) * 3;
-                n += p[0];
-                aa += p[1];
-                tt += p[2];
-            }
-            const double d = aa + tt;
-            ks[k * 2] = n;
-            ks[k * 2 + 1] = d;
-            loss += 1.0 - 2.0 * (n / (d < eps ? eps : d));
-        }
+        for (int k = 0; k < K; ++k) loss += ks[k * 3 + 2];
         out[0] = (float)loss;
     }
 }
@@ -989,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_aff_grad(const float* __restrict__ emb,
         const int64_t lu = lbl[u];
         for (int k = 0; k < K; ++k) {
             const int oz = offs.o[k][0], oy = offs.o[k][1], ox = offs.o[k][2];
-            const double n = ks[k * 2], dn = ks[k * 2 + 1];
+            const double n = ks[k * 3], dn = ks[k * 3 + 1];
             float c_t, c_a;  // dL/da = c_t * t + c_a * a
             if (dn > eps) {
                 c_t = (float)(-2.0 / dn);
@@ -1053,12 +1131,13 @@ extern "C" int tem_affinity_side(const float* emb, int64_t cs, const int64_t* lb
     const int nb = tem_grid_1d(V, 256, SP_MAXB);
     char* p = (char*)ws;
     float* part = (float*)ws_take(p, (int64_t)K * nb * 3 * 4);
-    double* ks = (double*)ws_take(p, (int64_t)K * 16);
+    double* ks = (double*)ws_take(p, (int64_t)K * 24);
     TEM_REQUIRE(p - (char*)ws <= ws_bytes, "tem_affinity_side: workspace too small");
 #define CALL(EMV)                                                                                                   \
     do {                                                                                                            \
         hipLaunchKernelGGL((k_aff_sums<EMV>), dim3(nb, K), dim3(256), 0, s, emb, cs, lbl, D, H, W, E, offs, delta, part); \
-        hipLaunchKernelGGL(k_aff_final, dim3(1), dim3(64), 0, s, part, K, nb, (double)eps, ks, value_out);            \
+        hipLaunchKernelGGL(k_aff_rows, dim3(K), dim3(256), 0, s, part, nb, (double)eps, ks);                        \
+        hipLaunchKernelGGL(k_aff_final, dim3(1), dim3(64), 0, s, (const double*)ks, K, value_out);                   \
         if (grad)                                                                                                   \
             hipLaunchKernelGGL((k_aff_grad<EMV>), dim3(tem_grid_1d(V, 256)), dim3(256), 0, s, emb, cs, lbl, D, H, W, E, \
                                K, offs, delta, (const double*)ks, (double)eps, grad_scale, grad, gcs);               \
