@@ -275,6 +275,20 @@ int tem_affinity_side(const float* emb, int64_t cs, const int64_t* labels, int D
                       const int* offsets_zyx, int K, float delta, float eps, float* value_out, float grad_scale,
                       float* grad, int64_t gcs, void* ws, int64_t ws_bytes, tem_stream_t stream);
 
+/* ---- on-device augmentations (transform/augmentation.py) ----------
+ * tem_flip3d: H/V/D flips of the default 3-D pipeline (:254-258) in ONE pass; 4-byte elements, src/dst
+ * [N][planes][D][H][W], flags_dev device int [N][3] (z,y,x).  2-D data: D == 1.
+ * tem_elastic_field / tem_elastic_warp2d: RandomElasticDeformation[Stacked] (:11-151) = kornia
+ * elastic_transform2d restated (kornia is not in this image: parity unpinned, see csrc/augment.hip):
+ * noise [2][H][W], gauss1d device [2][ksize] (row 0: sigma[0], row 1: sigma[1]), disp [2][H][W] in normalised
+ * grid units; the warp applies the same field to `planes` [H][W] planes (bilinear, or nearest for labels). */
+int tem_flip3d(const void* src, void* dst, const int* flags_dev, int N, int planes, int D, int H, int W,
+               tem_stream_t stream);
+int tem_elastic_field(const float* noise, const float* gauss1d, int ksize, int H, int W, float alpha0, float alpha1,
+                      float* disp, tem_stream_t stream);
+int tem_elastic_warp2d(const float* src, const float* disp, float* dst, int64_t planes, int H, int W, int nearest,
+                       tem_stream_t stream);
+
 /* ---- small utilities ---------------------------------------------------------- */
 /* NCDHW (contiguous) <-> NDHWC(ld) layout change at the module boundary. */
 int tem_nchw_to_nhwc(const float* src, float* dst, int64_t dst_ld, int N, int C, int64_t V, tem_stream_t stream);

@@ -222,3 +222,40 @@ def test_label_transform_classes_on_device():
     pred = torch.rand(2, 6, 8, 24, 20, device=DEV, requires_grad=True)
     LossWrapper(DiceLoss(), ApplyAndRemoveMask("multiply"))(pred, y).backward()
     assert float(pred.grad[y[:, 6:] == 0].abs().max()) == 0.0
+
+
+def test_trainer_with_on_device_augmentation(tmp_path):
+    """cfg-5 style loop: flips + stacked elastic deformation on the device batch, SPOCO loss, EMA teacher."""
+    from torch_em_amd.loss import SPOCOLoss
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.optim import FusedAdamW
+    from torch_em_amd.trainer import SPOCOTrainer
+    from torch_em_amd.transform import RandomElasticDeformationStacked, get_augmentations
+    from torch_em_amd.transform.augmentation import DEFAULT_3D_AUGMENTATIONS
+    g = torch.Generator().manual_seed(0)
+    xs = torch.randn(2, 1, 16, 32, 32, generator=g)
+    ys = torch.randint(0, 4, (2, 1, 4, 8, 8), generator=g).repeat_interleave(4, 2).repeat_interleave(4, 3) \
+        .repeat_interleave(4, 4)
+    ys[:, :, :, :8] = 0
+    seen = []
+
+    class Loss(SPOCOLoss):
+        def forward(self, preds, y):
+            seen.append(y.detach().clone())
+            return super().forward(preds, y)
+
+    train = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xs, ys), batch_size=1)
+    model = UNet3d(1, 4, depth=2, initial_features=4)
+    aug = get_augmentations(3, transforms=DEFAULT_3D_AUGMENTATIONS + [RandomElasticDeformationStacked(sigma=(6.0, 6.0))])
+    trainer = SPOCOTrainer(model=model, name="a", train_loader=train, val_loader=train, loss=Loss(0.75, 2.0, max_anchors=4),
+                           optimizer=FusedAdamW(model.parameters(), lr=1e-3),
+                           metric=lambda pred, y: pred.float().mean() * 0 + 1.0,
+                           device=DEV, save_root=str(tmp_path), logger=None, augmentation=aug)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    trainer.fit(iterations=2)
+    assert trainer.iteration == 2
+    y0 = seen[0]
+    assert y0.dtype == torch.int64 and y0.is_cuda and y0.shape == (1, 1, 16, 32, 32)
+    assert set(torch.unique(y0).tolist()) <= {0, 1, 2, 3}
+    assert not torch.equal(y0.cpu(), ys[:1])  # the batch the loss saw is the augmented one

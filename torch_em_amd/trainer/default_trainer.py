@@ -72,7 +72,7 @@ class DefaultTrainer:
                  logger=None, logger_kwargs: Optional[Dict[str, Any]] = None, id_: Optional[str] = None,
                  save_root: Optional[str] = None, compile_model: Optional[Union[bool, str]] = None,
                  rank: Optional[int] = None, mixed_precision_dtype: Optional[str] = None,
-                 target_transform: Optional[Callable] = None):
+                 target_transform: Optional[Callable] = None, augmentation: Optional[Callable] = None):
         if name is None:
             raise TypeError("Name cannot be None if not using the WandbLogger")
         self.name, self.id_ = name, id_ or name
@@ -93,6 +93,9 @@ class DefaultTrainer:
         # not in the reference: computes the training target from the label batch ON DEVICE (e.g.
         # transform.label.BatchTargets(AffinityTransform(...))) instead of in the CPU data-loader workers
         self.target_transform = target_transform
+        # not in the reference either: an on-device augmentation pipeline (transform.augmentation.get_augmentations)
+        # applied to the (x, y) TRAINING batch already in HBM; the reference augments in the CPU data-loader workers
+        self.augmentation = augmentation
 
     # ---- bookkeeping ------------------------------------------------------------------
     @property
@@ -287,6 +290,13 @@ class DefaultTrainer:
         pred = self.model(x)
         return pred, self.loss(pred, y)
 
+    def _augment(self, x, y):
+        aug = getattr(self, "augmentation", None)
+        if aug is None:
+            return x, y
+        xa, ya = aug(x, y)
+        return xa.to(x.dtype), ya.to(y.dtype)
+
     def _backprop(self, loss):
         loss.backward()
         self.optimizer.step()
@@ -297,6 +307,7 @@ class DefaultTrainer:
         n_iter, t0 = 0, time.time()
         for x, y in self.train_loader:
             x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
+            x, y = self._augment(x, y)
             self.optimizer.zero_grad()
             pred, loss = self._forward_and_loss(x, y)
             self._backprop(loss)

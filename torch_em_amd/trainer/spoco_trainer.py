@@ -76,6 +76,7 @@ class SPOCOTrainer(DefaultTrainer):
         n_iter, t0 = 0, time.time()
         for x, y in self.train_loader:
             x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
+            x, y = self._augment(x, y)
             prediction, loss = self._step(x, self.loss, y)
             if self.logger is not None:
                 lr = [pm["lr"] for pm in self.optimizer.param_groups][0]

@@ -1,0 +1,258 @@
+"""On-device augmentations for the MI355X path.
+
+Mirrors `torch_em.transform.augmentation` (reference transform/augmentation.py): `RandomElasticDeformationStacked`
+(:11-88), `RandomElasticDeformation` (:91-151), `KorniaAugmentationPipeline` (:156-228), `AUGMENTATIONS` /
+`DEFAULT_*_AUGMENTATIONS` (:233-265), `create_augmentation` / `get_augmentations` (:270-302).  The reference runs
+kornia on the CPU inside the data-loader workers; here the pipeline runs on the batch that is already in HBM, as
+hand-written HIP kernels (csrc/augment.hip): consecutive flips are fused into ONE pass per tensor, the elastic
+deformation is one small blur of the noise field plus one warp pass.  kornia itself is not a dependency; the flip
+classes carry kornia's names and (p, same_on_batch) arguments, random decisions come from the torch CPU generator
+(flips) and the global numpy generator (elastic noise, exactly as the reference :52-55).
+
+Parameter replay: like the reference (:212-220) the first tensor draws the parameters and every further tensor
+(labels) replays them, with NEAREST interpolation for non-float inputs; everything is returned as `dtype`.
+Only the augmentations of the reference's default pipelines and its two elastic classes exist here (affine /
+rotation augmentations raise NotImplementedError).
+"""
+from typing import List, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+
+
+def _as_batch(t: torch.Tensor, spatial: int) -> torch.Tensor:
+    """kornia's shape promotion: ([C,]*S) -> (1,C,*S); batched tensors pass through."""
+    while t.dim() < spatial + 2:
+        t = t[None]
+    if t.dim() != spatial + 2:
+        raise ValueError(f"expected a tensor with {spatial}..{spatial + 2} dimensions, got {t.dim()}")
+    return t
+
+
+class _RandomFlip(torch.nn.Module):
+    """Flip of one spatial axis with probability p per sample (kornia RandomHorizontalFlip[3D] and friends)."""
+    axis = -1
+    spatial = 3
+
+    def __init__(self, p: float = 0.5, same_on_batch: bool = False, keepdim: bool = False):
+        super().__init__()
+        self.p, self.same_on_batch, self.keepdim = p, same_on_batch, keepdim
+        self._params = None
+        self.flags = {}
+
+    def generate_parameters(self, batch_shape):
+        n = batch_shape[0]
+        if self.same_on_batch:
+            draw = (torch.rand(1) < self.p).expand(n)
+        else:
+            draw = torch.rand(n) < self.p
+        return {"batch_prob": draw.clone()}
+
+    def forward(self, input: torch.Tensor, params=None) -> torch.Tensor:
+        return KorniaAugmentationPipeline(self, dtype=input.dtype)._run([input], [params])[0]
+
+
+class RandomHorizontalFlip3D(_RandomFlip):
+    axis, spatial = -1, 3
+
+
+class RandomVerticalFlip3D(_RandomFlip):
+    axis, spatial = -2, 3
+
+
+class RandomDepthicalFlip3D(_RandomFlip):
+    axis, spatial = -3, 3
+
+
+class RandomHorizontalFlip(_RandomFlip):
+    axis, spatial = -1, 2
+
+
+class RandomVerticalFlip(_RandomFlip):
+    axis, spatial = -2, 2
+
+
+def _gauss1d(ksize: int, sigma: float) -> torch.Tensor:
+    x = torch.arange(ksize, dtype=torch.float32) - ksize // 2
+    g = torch.exp(-x.pow(2.0) / (2 * float(sigma) ** 2))
+    return g / g.sum()
+
+
+def _resize_order3(field: np.ndarray, shape) -> np.ndarray:
+    """skimage.transform.resize(order=3) of the control grid (reference :56-58): identity for spacing 1, else the
+    cubic-spline zoom skimage delegates to (scipy.ndimage.zoom, mode='reflect', grid_mode=True)."""
+    if tuple(field.shape) == tuple(shape):
+        return field
+    from scipy import ndimage
+    zoom = [s / f for s, f in zip(shape, field.shape)]
+    return ndimage.zoom(field, zoom, order=3, mode="reflect", grid_mode=True)
+
+
+class _ElasticBase(torch.nn.Module):
+    spatial = 2
+    kernel_size = 63  # kornia elastic_transform2d default
+
+    def __init__(self, control_point_spacing: Union[int, Sequence[int]] = 1, sigma: Tuple[float, float] = (32.0, 32.0),
+                 alpha: Tuple[float, float] = (4.0, 4.0), interpolation="bilinear", p: float = 0.5,
+                 keepdim: bool = False, same_on_batch: bool = True):
+        super().__init__()
+        if isinstance(control_point_spacing, int):
+            self.control_point_spacing = [control_point_spacing] * 2
+        else:
+            self.control_point_spacing = control_point_spacing
+        assert len(self.control_point_spacing) == 2
+        # the reference overrides __call__, so kornia's `p` gate never runs: the deformation is always applied
+        self.p, self.same_on_batch, self.keepdim = p, same_on_batch, keepdim
+        self.flags = dict(interpolation=interpolation, sigma=sigma, alpha=alpha)
+        self._params = None
+
+    def generate_parameters(self, batch_shape):
+        shape = tuple(batch_shape[-2:])
+        control_shape = tuple(sh // sp for sh, sp in zip(shape, self.control_point_spacing))
+        fields = [np.random.uniform(-1, 1, control_shape), np.random.uniform(-1, 1, control_shape)]
+        fields = [_resize_order3(df, shape)[None] for df in fields]
+        noise = np.concatenate(fields, axis=0)[None].astype("float32")
+        return {"noise": torch.from_numpy(noise)}
+
+    def displacement(self, noise: torch.Tensor, device) -> torch.Tensor:
+        """[1,2,H,W] noise -> [2,H,W] displacement field on the device (normalised grid units)."""
+        lib = _lib.load()
+        noise = noise.to(device=device, dtype=torch.float32).reshape(2, *noise.shape[-2:]).contiguous()
+        H, W = noise.shape[-2:]
+        sigma, alpha = self.flags["sigma"], self.flags["alpha"]
+        g = torch.stack([_gauss1d(self.kernel_size, sigma[0]), _gauss1d(self.kernel_size, sigma[1])]).to(device)
+        disp = torch.empty_like(noise)
+        _lib.check(lib.tem_elastic_field(ops._p(noise), ops._p(g), self.kernel_size, H, W, float(alpha[0]),
+                                         float(alpha[1]), ops._p(disp), ops._stream(noise)), "tem_elastic_field")
+        return disp
+
+    def forward(self, input: torch.Tensor, params=None) -> torch.Tensor:
+        return KorniaAugmentationPipeline(self, dtype=input.dtype)._run([input], [params])[0]
+
+
+class RandomElasticDeformationStacked(_ElasticBase):
+    """The same random 2-D elastic deformation applied to every plane of a 3-D volume (reference :11-88)."""
+    spatial = 3
+
+
+class RandomElasticDeformation(_ElasticBase):
+    """Random 2-D elastic deformation (reference :91-151; the reference calls the interpolation flag `resample`)."""
+    spatial = 2
+
+    def __init__(self, control_point_spacing=1, sigma=(32.0, 32.0), alpha=(4.0, 4.0), resample="bilinear", p=0.5,
+                 keepdim=False, same_on_batch=True):
+        super().__init__(control_point_spacing, sigma, alpha, resample, p, keepdim, same_on_batch)
+
+
+class KorniaAugmentationPipeline(torch.nn.Module):
+    """Applies a list of augmentations to several tensors with shared random parameters (reference :156-228)."""
+    interpolatable_torch_types = [torch.float16, torch.float32, torch.float64]
+    interpolatable_numpy_types = [np.dtype("float32"), np.dtype("float64")]
+
+    def __init__(self, *kornia_augmentations, dtype: Union[str, torch.dtype] = torch.float32):
+        super().__init__()
+        for aug in kornia_augmentations:
+            if not isinstance(aug, (_RandomFlip, _ElasticBase)):
+                raise NotImplementedError(f"{type(aug).__name__} has no MI355X kernel (flips and elastic deformations do)")
+        self.augmentations = torch.nn.ModuleList(kornia_augmentations)
+        self.dtype = dtype
+        self.halo = self.compute_halo()
+
+    def compute_halo(self):
+        return None  # only the rotation augmentations of the reference need one (:174-183)
+
+    def is_interpolatable(self, tensor):
+        if torch.is_tensor(tensor):
+            return tensor.dtype in self.interpolatable_torch_types
+        return tensor.dtype in self.interpolatable_numpy_types
+
+    def _run(self, tensors, params_in=None):
+        interp = [self.is_interpolatable(t) for t in tensors]
+        dtype = getattr(torch, self.dtype) if isinstance(self.dtype, str) else self.dtype
+        if dtype != torch.float32:
+            raise NotImplementedError("the MI355X augmentation kernels move 4-byte float32 elements")
+        work = []
+        for t in tensors:
+            t = torch.as_tensor(t)
+            if not t.is_cuda:
+                raise RuntimeError("torch_em_amd augmentations run on MI355X only (got a CPU tensor); no CPU fallback")
+            work.append(t.to(dtype))
+        lib = _lib.load()
+        augs = list(self.augmentations)
+        i = 0
+        while i < len(augs):
+            aug = augs[i]
+            spatial = aug.spatial
+            work = [_as_batch(t, spatial).contiguous() for t in work]
+            shape = work[0].shape
+            N = shape[0]
+            if isinstance(aug, _RandomFlip):
+                # fuse the run of consecutive flips into one pass per tensor
+                flags = torch.zeros(N, 3, dtype=torch.int32)
+                while i < len(augs) and isinstance(augs[i], _RandomFlip) and augs[i].spatial == spatial:
+                    a = augs[i]
+                    given = params_in[i] if params_in is not None and i < len(params_in) else None
+                    params = given if given is not None else a.generate_parameters(shape)
+                    a._params = params
+                    flags[:, 3 + a.axis] ^= params["batch_prob"].to(torch.int32)
+                    i += 1
+                fl = flags.to(work[0].device)
+                out = []
+                for t in work:
+                    assert t.shape[0] == N and t.shape[2:] == shape[2:], "all tensors must share batch and spatial shape"
+                    D = t.shape[2] if spatial == 3 else 1
+                    dst = torch.empty_like(t)
+                    _lib.check(lib.tem_flip3d(ops._p(t), ops._p(dst), ops._p(fl), N, t.shape[1], D, t.shape[-2],
+                                              t.shape[-1], ops._stream(t)), "tem_flip3d")
+                    out.append(dst)
+                work = out
+            else:
+                given = params_in[i] if params_in is not None and i < len(params_in) else None
+                params = given if given is not None else aug.generate_parameters(shape)
+                aug._params = params
+                disp = aug.displacement(params["noise"], work[0].device)
+                out = []
+                for t, ip in zip(work, interp):
+                    H, W = t.shape[-2:]
+                    assert (H, W) == tuple(disp.shape[-2:]), "all tensors must share the spatial shape"
+                    nearest = not (ip and aug.flags["interpolation"] in ("bilinear", 1))
+                    dst = torch.empty_like(t)
+                    _lib.check(lib.tem_elastic_warp2d(ops._p(t), ops._p(disp), ops._p(dst), t.numel() // (H * W), H, W,
+                                                      int(nearest), ops._stream(t)), "tem_elastic_warp2d")
+                    out.append(dst)
+                work = out
+                i += 1
+        return work
+
+    def forward(self, *tensors) -> List[torch.Tensor]:
+        return self._run(list(tensors))
+
+
+AUGMENTATIONS = {
+    "RandomDepthicalFlip3D": {},
+    "RandomHorizontalFlip": {},
+    "RandomHorizontalFlip3D": {},
+    "RandomVerticalFlip": {},
+    "RandomVerticalFlip3D": {},
+    "RandomElasticDeformation": {"alpha": [5, 5], "sigma": [30, 30]},
+    "RandomElasticDeformationStacked": {"alpha": [5, 5], "sigma": [30, 30]},
+}
+DEFAULT_2D_AUGMENTATIONS = ["RandomHorizontalFlip", "RandomVerticalFlip"]
+DEFAULT_3D_AUGMENTATIONS = ["RandomHorizontalFlip3D", "RandomVerticalFlip3D", "RandomDepthicalFlip3D"]
+DEFAULT_ANISOTROPIC_AUGMENTATIONS = ["RandomHorizontalFlip3D", "RandomVerticalFlip3D", "RandomDepthicalFlip3D"]
+
+
+def create_augmentation(trafo):
+    assert trafo in AUGMENTATIONS and trafo in globals(), f"Transformation {trafo} not defined"
+    return globals()[trafo](**AUGMENTATIONS[trafo])
+
+
+def get_augmentations(ndim: Union[int, str] = 2, transforms=None, dtype: Union[str, torch.dtype] = torch.float32):
+    """Augmentation pipeline for 2-D, 3-D or anisotropic data (reference :279-302)."""
+    if transforms is None:
+        assert ndim in (2, 3, "anisotropic"), f"Expect ndim to be one of (2, 3, 'anisotropic'), got {ndim}"
+        transforms = {2: DEFAULT_2D_AUGMENTATIONS, 3: DEFAULT_3D_AUGMENTATIONS}.get(ndim, DEFAULT_ANISOTROPIC_AUGMENTATIONS)
+    transforms = [create_augmentation(t) if isinstance(t, str) else t for t in transforms]
+    return KorniaAugmentationPipeline(*transforms, dtype=dtype)
