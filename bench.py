@@ -88,6 +88,12 @@ def cpu_baseline(max_threads):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  RCCL prints its version banner to fd 1 from C when the communicator is
+    # created, and libraries may print warnings: route fd 1 to stderr for the whole run and keep the real stdout
+    # for the final line only.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -233,7 +239,8 @@ def main():
                 "note": "5700.8 GFLOP and 25.58 GB algorithmic per step (SURVEY.md 8d); fp32 arithmetic => MFMA-bound"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
