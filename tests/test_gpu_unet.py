@@ -160,7 +160,8 @@ def test_inference_mode_and_determinism():
 
 def test_benchmark_config_full_size_properties():
     """cfg 2 at full size (2x1x128^3): size-independent checks -- finite, deterministic
-    (bitwise), and the oracle run on the same device (ATen) agrees on loss and a gradient sample."""
+    (bitwise), and the CPU oracle (fp32, a few seconds on 16 threads; ATen-on-GPU would spend minutes in MIOpen's
+    kernel search on a fresh box) agrees on prediction, loss and every parameter gradient."""
     from oracle import loss_ref, unet_ref
     from torch_em_amd.loss import DiceLoss
     from torch_em_amd.model import UNet3d
@@ -177,10 +178,15 @@ def test_benchmark_config_full_size_properties():
         vals.append(float(loss))
         grads.append(model.out_conv.weight.grad.clone())
     assert np.isfinite(vals[0]) and vals[0] == vals[1] and torch.equal(grads[0], grads[1])
-    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    pred = unet_ref.unet_forward(sd, x, [2, 2, 2, 2])
-    lo = loss_ref.dice_loss(pred, y)
-    lo.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(16)  # the oracle's sweet spot on the 2x64-core host (scripts/cpu_threads_probe.py)
+    try:
+        pred = unet_ref.unet_forward(sd, x.cpu(), [2, 2, 2, 2])
+        lo = loss_ref.dice_loss(pred, y.cpu())
+        lo.backward()
+    finally:
+        torch.set_num_threads(nthreads)
     assert rel_err(model(x).detach().cpu(), pred.detach().cpu()) < TOL
     assert abs(vals[0] - float(lo)) < 1e-4
     # Gradients: two fp32-class implementations of an ill-conditioned gradient (see _check_against_fp64; at this
