@@ -11,6 +11,14 @@
 #include "conv_internal.h"
 #include <stdlib.h>
 
+#ifndef TEM_PP_RING9
+#define TEM_PP_RING9 1
+#endif
+static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
+#ifndef TEM_ABLATE
+#define TEM_ABLATE 0  // developer ablations for profiling: 1 A reads at a fixed address, 2 no B loads, 4 no halo loads, 8 no stores, 16 no LDS writes; wgrad: 32 no global loads, 64 no LDS writes, 128 no MFMA phase
+#endif
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
             if (hv < HV) {
                 const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
                 const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
-                if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W && !(TEM_ABLATE & 4)) {
                     v = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld +
                                                          chunk * BCK + c4 * 4);
                     v.x = fmaf(v.x, sc4.x, sf4.x);
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     const unsigned h0 = pk_bf16(e[0], e[1]), h1 = pk_bf16(e[2], e[3]);
-                    *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
+                    if (!(TEM_ABLATE & 16)) *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
                     if (p + 1 < NS) {
                         e[0] -= __builtin_bit_cast(float, h0 << 16);
                         e[1] -= __builtin_bit_cast(float, h0 & 0xffff0000u);
@@ -215,13 +223,13 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
                     for (int nn = 0; nn < NR; ++nn)
 #pragma unroll
                         for (int p = 0; p < NS; ++p)
-                            bq[gp % RD][nn][p] = wq[nn][(int64_t)chunk * FR + (int64_t)gp * ts + p * 64];
+                            if (!(TEM_ABLATE & 2)) bq[gp % RD][nn][p] = wq[nn][(int64_t)chunk * FR + (int64_t)gp * ts + p * 64];
                 } else if (chunk + 1 < chunk_end) {
 #pragma unroll
                     for (int nn = 0; nn < NR; ++nn)
 #pragma unroll
                         for (int p = 0; p < NS; ++p)
-                            bq[gp % RD][nn][p] = wq[nn][(int64_t)(chunk + 1) * FR + (int64_t)(gp - NT) * ts + p * 64];
+                            if (!(TEM_ABLATE & 2)) bq[gp % RD][nn][p] = wq[nn][(int64_t)(chunk + 1) * FR + (int64_t)(gp - NT) * ts + p * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0x38F);
             } else {
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
-                    af[m][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + toff + p * 8));
+                    af[m][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + ((TEM_ABLATE & 1) ? 0 : toff) + p * 8));
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -273,10 +281,265 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
                     }
                     float o = act_apply_b(acc[m][nn][reg] + bv, act);
                     if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
-                    y[v * y_ld + co] = o;
+                    if (!(TEM_ABLATE & 8) || o == 12345.678f) y[v * y_ld + co] = o;
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward / dgrad, persistent + software-pipelined (the default).  Ablations of k_conv_fwd_bfsplit (2x128^3, 32->32,
+// bf16x6: 1.50 ms): without the halo loads 1.02, without the weight-fragment loads 1.19, without both 0.85, A reads at
+// a fixed LDS address 1.51 (bank conflicts are NOT the limiter).  The global-memory latencies are exposed: every
+// chunk starts with a full HBM round trip in front of a barrier, and a 2-tap weight ring is shorter than an L2 hit.
+// This variant
+//   * is persistent: gridDim = resident workgroups; a workgroup walks (unit, 16-channel chunk) steps, units dealt
+//     in contiguous per-XCD ranges (neighbouring patches share that XCD's L2);
+//   * issues the NEXT step's halo loads (raw, un-normalised, + in-bounds mask) right after the LDS tile of the
+//     current step is complete, so they fly during the 27-tap MFMA loop;
+//   * deepens the weight ring to RD = 9 taps where registers allow (32-column tiles): the ring entries of the first
+//     RD-1 taps of a step are older than that step's halo prefetch, so vmcnt never makes a weight wait queue behind
+//     halo loads until they have had RD-1 taps (>= 3K cycles) to land.
+// ---------------------------------------------------------------------------
+struct BfUnit {
+    int cot, n, ks, z0, y0, x0;
+};
+template <int TZ, int TY, int TX>
+__device__ __forceinline__ BfUnit bf_decode(int u, int ncot, int nX, int nY, int nZ, int N) {
+    BfUnit r;
+    r.cot = u % ncot; u /= ncot;
+    r.x0 = (u % nX) * TX; u /= nX;
+    r.y0 = (u % nY) * TY; u /= nY;
+    r.z0 = (u % nZ) * TZ; u /= nZ;
+    r.n = u % N;
+    r.ks = u / N;
+    return r;
+}
+
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, int RD>
+__global__ __launch_bounds__(256, (NR == 2 || NS == 3 || RD > 3) ? 2 : 3) void k_conv_fwd_bfsplit_pp(
+    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
+    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
+    int nY, int nX, int ksplit, float* __restrict__ part, int total_units) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
+    constexpr int HV = HZ * HY * HX;
+    constexpr int NIT = (HV * 4 + 255) / 256;
+    constexpr int LSV = NS * 8 + 4;
+    constexpr int FR = NS * 64;
+    static_assert(TZ * TY * TX == 256 && NT % RD == 0 && RD >= 2 && NIT <= 32, "geometry");
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [HV][LSV]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kh = lane >> 5, r = lane & 31;
+    const int c4 = tid & 3;
+    const int ncot = Cout / (32 * NR);
+    const int cin16 = Cin >> 4;
+    const int spu = cin16 / ksplit;
+
+    // contiguous unit range per XCD (workgroup b runs on XCD b % 8), dealt round-robin inside the XCD
+    const int G8 = gridDim.x >> 3, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int upx = (total_units + 7) >> 3;
+    const int ubeg = xcd * upx;
+    const int uend = ubeg + upx < total_units ? ubeg + upx : total_units;
+    if (ubeg + jb >= uend) return;
+    const int my_units = (uend - ubeg - jb + G8 - 1) / G8;
+    const int nsteps = my_units * spu;
+
+    int abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int p = wv * 64 + m * 32 + r;
+        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+        abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;
+    }
+    const uint4* wbase = wp + lane;
+    const int64_t wtile = (int64_t)NT * cin16 * FR;
+    const int tapstride = cin16 * FR;
+
+    floatx16 acc[2][NR];
+    uint4 bq[RD][NR][NS];
+    float4 tmp[NIT];
+    float sc16[16], sf16[16];  // wave-uniform (SGPRs)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sc16[i] = 1.f;
+        sf16[i] = 0.f;
+    }
+    unsigned inb = 0;
+    const bool has_scale = scale != nullptr;
+
+    BfUnit cur = bf_decode<TZ, TY, TX>(ubeg + jb, ncot, nX, nY, nZ, N);
+    int chunk = cur.ks * spu;
+
+    // branch-free: out-of-volume voxels load from a clamped (valid) address and are zeroed at conversion time via the
+    // `inb` mask -- divergent branches around the loads make the compiler's s_waitcnt placement conservative (vmcnt(0)
+    // in front of the tap loop), which would serialise the prefetch again.
+    auto issue_halo = [&](const BfUnit& u, int ch) {
+        // pre-norm scale/shift of the 16 channels of the chunk: wave-uniform addresses => scalar loads (lgkmcnt), which
+        // keeps them out of the in-order vmcnt queue of the halo / weight loads; the per-lane pick happens at
+        // conversion time
+        if (has_scale) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sc16[i] = scale[(int64_t)u.n * Cin + ch * BCK + i];
+                sf16[i] = shift[(int64_t)u.n * Cin + ch * BCK + i];
+            }
+        }
+        inb = 0;
+        const float* xb = x + (int64_t)u.n * D * H * W * x_ld + ch * BCK + c4 * 4;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int hv = (tid + it * 256) >> 2;
+            hv = hv < HV ? hv : HV - 1;
+            const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+            const int gz = u.z0 + hz - PZ, gy = u.y0 + hy - PY, gx = u.x0 + hx - PX;
+            // bitwise, not &&: short-circuit evaluation becomes exec-masked branches around the loads
+            const int ok = (int)(gz >= 0) & (int)(gz < D) & (int)(gy >= 0) & (int)(gy < H) & (int)(gx >= 0) & (int)(gx < W);
+            const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            tmp[it] = *reinterpret_cast<const float4*>(xb + (((int64_t)cz * H + cy) * W + cx) * x_ld);
+            inb |= (unsigned)ok << it;
+        }
+    };
+
+    // ring entries of the first RD-1 taps of step 0 (older than the first halo loads)
+#pragma unroll
+    for (int gp = 0; gp < RD - 1; ++gp)
+#pragma unroll
+        for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+                bq[gp][nn][p] = wbase[(int64_t)(cur.cot * NR + nn) * wtile + (int64_t)gp * tapstride + chunk * FR + p * 64];
+    issue_halo(cur, chunk);
+
+    for (int s = 0; s < nsteps; ++s) {
+        const bool first = (s % spu) == 0, last = (s % spu) == spu - 1;
+        const int s1 = s + 1;
+        const bool has_next = s1 < nsteps;
+        BfUnit nxt = cur;
+        if (last && has_next) nxt = bf_decode<TZ, TY, TX>(ubeg + jb + (s1 / spu) * G8, ncot, nX, nY, nZ, N);
+        const int chunk1 = nxt.ks * spu + s1 % spu;
+        if (first) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
+        }
+        __syncthreads();  // every wave is done reading the previous step's tile
+        float4 scs, sfs;
+        {
+            float a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = c4 == 0 ? sc16[j] : (c4 == 1 ? sc16[4 + j] : (c4 == 2 ? sc16[8 + j] : sc16[12 + j]));
+                b[j] = c4 == 0 ? sf16[j] : (c4 == 1 ? sf16[4 + j] : (c4 == 2 ? sf16[8 + j] : sf16[12 + j]));
+            }
+            scs = make_float4(a[0], a[1], a[2], a[3]);
+            sfs = make_float4(b[0], b[1], b[2], b[3]);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int hv = (tid + it * 256) >> 2;
+            if (hv < HV) {
+                const bool ok = inb & (1u << it);  // zero padding is applied AFTER the fused pre-norm
+                float e[4] = {ok ? fmaf(tmp[it].x, scs.x, sfs.x) : 0.f, ok ? fmaf(tmp[it].y, scs.y, sfs.y) : 0.f,
+                              ok ? fmaf(tmp[it].z, scs.z, sfs.z) : 0.f, ok ? fmaf(tmp[it].w, scs.w, sfs.w) : 0.f};
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+                    const unsigned h0 = pk_bf16(e[0], e[1]), h1 = pk_bf16(e[2], e[3]);
+                    *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
+                    if (p + 1 < NS) {
+                        e[0] -= __builtin_bit_cast(float, h0 << 16);
+                        e[1] -= __builtin_bit_cast(float, h0 & 0xffff0000u);
+                        e[2] -= __builtin_bit_cast(float, h1 << 16);
+                        e[3] -= __builtin_bit_cast(float, h1 & 0xffff0000u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (has_next) issue_halo(nxt, chunk1);  // flies during the tap loop below
+        __builtin_amdgcn_sched_barrier(0);
+
+        int ts = tapstride;
+        asm volatile("" : "+s"(ts));
+        const int64_t wo_c = (int64_t)(cur.cot * NR) * wtile + (int64_t)chunk * FR;
+        const int64_t wo_n = (int64_t)(nxt.cot * NR) * wtile + (int64_t)chunk1 * FR;
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+            const int toff = ((tz * HY + ty) * HX + tx) * LSV;
+            {
+                const int gp = tap + RD - 1;
+                if (gp < NT) {
+#pragma unroll
+                    for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                        for (int p = 0; p < NS; ++p)
+                            bq[gp % RD][nn][p] = wbase[wo_c + nn * wtile + (int64_t)gp * ts + p * 64];
+                } else if (has_next) {
+#pragma unroll
+                    for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                        for (int p = 0; p < NS; ++p)
+                            bq[gp % RD][nn][p] = wbase[wo_n + nn * wtile + (int64_t)(gp - NT) * ts + p * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bf16x8 af[2][NS];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    af[m][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + toff + p * 8));
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NR; ++nn) {
+#pragma unroll
+                    for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                        for (int i = 0; i <= sum; ++i) {
+                            const int j = sum - i;
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                af[m][i], __builtin_bit_cast(bf16x8, bq[tap % RD][nn][j]), acc[m][nn], 0, 0, 0);
+                        }
+                }
+        }
+        if (last) {
+#pragma unroll
+            for (int nn = 0; nn < NR; ++nn) {
+                const int co = (cur.cot * NR + nn) * 32 + r;
+                const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                        const int p = wv * 64 + m * 32 + row;
+                        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+                        const int gz = cur.z0 + pz, gy = cur.y0 + py, gx = cur.x0 + px;
+                        if (gz < D && gy < H && gx < W) {
+                            const int64_t v = (((int64_t)cur.n * D + gz) * H + gy) * W + gx;
+                            if (ksplit > 1) {
+                                part[((int64_t)cur.ks * N * D * H * W + v) * Cout + co] = acc[m][nn][reg];
+                            } else {
+                                float o = act_apply_b(acc[m][nn][reg] + bv, act);
+                                if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
+                                y[v * y_ld + co] = o;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        chunk = chunk1;
     }
 }
 
@@ -517,6 +780,37 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     constexpr size_t ldsb = (size_t)HV * (NS * 8 + 4) * sizeof(float);
     // measured slower than the 2-workgroups/CU kernel below (1 MFMA wave per SIMD cannot hide its own LDS-read
     // latency: 32->32 128^3 bf16x3 1.47 ms vs 1.00 ms); kept as an experiment switch, off by default
+    // measured equal to the plain kernel below (the limiter is not load latency): off by default
+    static const int ppmode = getenv("TEM_SPLIT_PP") ? atoi(getenv("TEM_SPLIT_PP")) : 0;
+    if constexpr ((KD * KH * KW) % 3 == 0) {
+        if (ppmode) {
+            constexpr int RD = (NR == 1 && NS == 2 && (KD * KH * KW) % 9 == 0 && ppmode_deep_ring) ? 9 : 3;  // NS == 3 would spill
+            constexpr int WPC = (NR == 2 || NS == 3 || RD > 3) ? 2 : 3;  // resident workgroups per CU (LDS / launch bounds)
+            static bool attrp = false;
+            if (!attrp && ldsb > 64 * 1024) {
+                (void)hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(&k_conv_fwd_bfsplit_pp<KD, KH, KW, TZ, TY, TX, NR, NS, RD>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+                attrp = true;
+            }
+            static int ncu = 0;
+            if (!ncu) {
+                ncu = tem_device_cus();
+                if (ncu <= 0) ncu = 256;
+            }
+            const int64_t upx = (nblk + 7) / 8;
+            int64_t g8 = (int64_t)WPC * ncu / 8;
+            if (g8 > upx) g8 = upx;
+            hipLaunchKernelGGL((k_conv_fwd_bfsplit_pp<KD, KH, KW, TZ, TY, TX, NR, NS, RD>), dim3((unsigned)(g8 * 8)),
+                               dim3(256), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp), bias, y, y_ld,
+                               ref, ref_ld, N, D, H, W, Cin, Cout, act, nZ, nY, nX, ksplit, part, (int)nblk);
+            if (ksplit > 1) {
+                const int64_t NV = (int64_t)N * D * H * W;
+                tem_splitk_epilogue(part, ksplit, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
+            }
+            return;
+        }
+    }
     static const int lcmode = getenv("TEM_SPLIT_LC") ? atoi(getenv("TEM_SPLIT_LC")) : 0;
     if constexpr ((KD * KH * KW) % 3 == 0) {
         if (lcmode) {
@@ -736,7 +1030,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
             if (rp < ROWS * XPAIRS) {                                                                              \
                 const int row = rp / XPAIRS, pr = rp % XPAIRS;                                                     \
                 const int gz = z0_ + row / HY - PZ, gy = y0_ + row % HY - PY, gx = x0_ + 2 * pr - PX;              \
-                if (gz >= 0 && gz < D && gy >= 0 && gy < H) {                                                      \
+                if (gz >= 0 && gz < D && gy >= 0 && gy < H && !(TEM_ABLATE & 32)) {                                \
                     const float* rowp = x + (((int64_t)n_ * D + gz) * H + gy) * W * x_ld + cit * 32 + xcq * 4;     \
                     if (gx >= 0 && gx < W) { xa[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * x_ld); inbA |= 1u << it; } \
                     if (gx + 1 >= 0 && gx + 1 < W) { xb[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * x_ld); inbB |= 1u << it; } \
@@ -750,7 +1044,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
             const int gz = z0_ + prow / WB_TY, gy = y0_ + prow % WB_TY, gx = x0_ + 2 * pr;                         \
             ga[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
             gb[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
-            if (gz < D && gy < H && cq < nco_here * 8) {                                                           \
+            if (gz < D && gy < H && cq < nco_here * 8 && !(TEM_ABLATE & 32)) {                                     \
                 const float* rowp = g + (((int64_t)n_ * D + gz) * H + gy) * W * g_ld + cog * NCO * 32 + cq * 4;    \
                 if (gx < W) ga[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * g_ld);                  \
                 if (gx + 1 < W) gb[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * g_ld);        \
@@ -777,8 +1071,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
                     unsigned hi, lo;
                     split2(va, vb, hi, lo);
                     const int off = (xcq * 4 + c) * CIS + row * 32 + pr * 4;
-                    *reinterpret_cast<unsigned*>(Xh + off) = hi;
-                    *reinterpret_cast<unsigned*>(Xl + off) = lo;
+                    if (!(TEM_ABLATE & 64)) {
+                        *reinterpret_cast<unsigned*>(Xh + off) = hi;
+                        *reinterpret_cast<unsigned*>(Xl + off) = lo;
+                    }
                 }
             }
         }
@@ -793,8 +1089,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
                 unsigned hi, lo;
                 split2(a[c], b[c], hi, lo);
                 const int off = (cq * 4 + c) * WB_GS + (prow * 8 + pr * 2) * 2;
-                *reinterpret_cast<unsigned*>(Gh + off) = hi;
-                *reinterpret_cast<unsigned*>(Gl + off) = lo;
+                if (!(TEM_ABLATE & 64)) {
+                    *reinterpret_cast<unsigned*>(Gh + off) = hi;
+                    *reinterpret_cast<unsigned*>(Gl + off) = lo;
+                }
                 dbacc[it][c] += a[c] + b[c];
             }
         }
@@ -805,7 +1103,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
         // unit 0 and drops it in the epilogue), so hipcc can hoist the ds_reads of the next (unit, slab) above the
         // MFMAs of the current one.  Per (unit, slab): 6 LDS reads + 8 v_alignbyte feed 9 MFMAs. ----
 #pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
+        for (int i = 0; i < ((TEM_ABLATE & 128) ? 0 : MAXU); ++i) {
 #pragma unroll 2
             for (int sl = 0; sl < SPU; ++sl) {
                 const int prow = 2 * (uhalf[i] * SPU + sl) + kh;  // this lane half's patch row
