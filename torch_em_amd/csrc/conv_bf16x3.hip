@@ -1191,6 +1191,265 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------
+// 3x3x3 weight gradient, z-sliding variant (the default for D >= 16).  Ablations of k_conv_wgrad_bf16x3 (2x128^3,
+// 32->32: 1.46 ms): MFMA phase alone 0.74 ms, staging alone (global loads, pre-norm, hi/lo split, transposed LDS
+// stores) 0.96 ms, and the two do not overlap (one workgroup per CU, every wave does both).  A 2x8x8 patch re-stages
+// 4x10x10 halo voxels per 128 outputs (3.1x); here a workgroup walks a z-COLUMN of 8x8 planes and keeps a ring of 4
+// halo planes in LDS, so each step stages ONE new 10x10 plane (1.56x) plus the 8x8 g plane, and
+//   * 8 waves, 18 work units (row group x {k-half | Cout tile}) dealt 3/3/2/2/2/2/2/2: a wave that finishes its
+//     MFMAs converts + stores its share of the NEXT planes into the free ring slot / g buffer right away and
+//     issues the loads after that -- staging of step t+1 overlaps the MFMAs of slower waves of step t;
+//   * ONE barrier per plane; a column accumulates over up to D planes, so far fewer partial slabs are written.
+// Ring slot of plane z is (z + 4) & 3; planes -1 and D are stored as zeros (padding applies after the pre-norm).
+// ---------------------------------------------------------------------------
+#define ZS_NPL 4
+#define ZS_PLB 320                       // bytes per ci per plane: 10 halo rows x 32 B (16 bf16 slots, 10 used)
+#define ZS_CIS (ZS_NPL * ZS_PLB + 16)    // bytes per ci (padded like the patch kernel: conflict-free b128 reads)
+#define ZS_GS 144                        // bytes per co row of one g plane: 64 bf16 + 16 pad
+
+template <int NCO>
+__global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restrict__ x, int64_t x_ld,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ g,
+                                                          int64_t g_ld, float* __restrict__ part,
+                                                          float* __restrict__ dbpart, int N, int D, int H, int W,
+                                                          int Cin, int Cout, int T, int nY, int nX, int zsegs) {
+    constexpr int NT = 27, NRG = 9, KW = 3;
+    constexpr int KS2 = (NCO == 1) ? 2 : 1;
+    constexpr int GC = 32 * NCO;
+    constexpr int XPL = 32 * ZS_CIS;       // bytes per (hi|lo) plane set of Xt
+    constexpr int GPL = GC * ZS_GS;        // bytes per (hi|lo) g plane
+    constexpr int MAXU = 3;                // 18 units over 8 waves
+    constexpr int SPU = (NCO == 1) ? 2 : 4;  // k-slabs per unit and plane
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char* Xh = ldsb;
+    unsigned char* Xl = ldsb + XPL;
+    unsigned char* Gb = ldsb + 2 * XPL;    // [buffer 2][hi|lo][GC][ZS_GS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kh = lane >> 5, r = lane & 31;
+    int bid = tem_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid % T;
+    bid /= T;
+    const int zseg = bid % zsegs;
+    bid /= zsegs;
+    const int sp = bid * zsegs + zseg;     // partial-slab index (column, z segment)
+    const int ptx = bid % nX;
+    bid /= nX;
+    const int pty = bid % nY;
+    const int n = bid / nY;
+    const int y0 = pty * 8, x0 = ptx * 8;
+    const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
+    const int ncit = Cin >> 5;
+    const int cit = tile % ncit, cog = tile / ncit;
+
+    floatx16 acc[MAXU][KW];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+#pragma unroll
+        for (int t = 0; t < KW; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][t][k] = 0.f;
+    // unit u = wv + 8 i: row group rg = u % 9, v = u / 9 (NCO == 1: k-half, NCO == 2: Cout tile)
+    int urg[MAXU], uv[MAXU];
+    bool uok[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = wv + 8 * i;
+        uok[i] = u < 18;
+        urg[i] = (uok[i] ? u : 0) % NRG;
+        uv[i] = (uok[i] ? u : 0) / NRG;
+    }
+
+    // staging items of this thread
+    const bool xit = tid < 400;                    // (halo row 10, x pair 5, channel quad 8)
+    const int xcq = tid & 7, xrp = tid >> 3, xrow = xrp / 5, xpr = xrp % 5;
+    const bool git = tid < 256 * NCO;              // (patch row 8, x pair 4, channel quad 8 NCO)
+    const int gcq = tid % (8 * NCO), grp = tid / (8 * NCO), gprow = grp >> 2, gpr = grp & 3;
+    float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa, ga = xa, gb = xa;
+    bool inA = false, inB = false;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale && xit) {
+        sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + xcq * 4);
+        sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + xcq * 4);
+    }
+    const bool do_db = (dbpart != nullptr) && (cit == 0);
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // iteration t: MFMA over plane t (if t >= za); store the pending registers (x plane t+2, g plane t+1); load the
+    // next pending set (x plane t+3, g plane t+2); barrier.
+    for (int t = za - 4; t < zb; ++t) {
+        if (t >= za) {
+            const unsigned char* Gh = Gb + (t & 1) * 2 * GPL;
+            const unsigned char* Gl = Gh + GPL;
+            int slot[3];
+#pragma unroll
+            for (int tz = 0; tz < 3; ++tz) slot[tz] = ((t + tz - 1 + 4) & 3) * ZS_PLB;
+#pragma unroll
+            for (int i = 0; i < MAXU; ++i) {
+                if (i == MAXU - 1 && !uok[i]) break;  // wave-uniform: waves 2..7 have two units
+                const int tz = urg[i] / 3, ty = urg[i] % 3;
+                const int ct = (NCO == 2) ? uv[i] : 0;
+                const int sl0 = (NCO == 1) ? uv[i] * SPU : 0;
+                const int xbase = r * ZS_CIS + (tz == 0 ? slot[0] : (tz == 1 ? slot[1] : slot[2])) + ty * 32;
+#pragma unroll
+                for (int sl = 0; sl < SPU; ++sl) {
+                    const int prow = 2 * (sl0 + sl) + kh;  // this lane half's patch row (0..7)
+                    const int goff = (ct * 32 + r) * ZS_GS + prow * 16;
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gh + goff));
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gl + goff));
+                    const int xoff = xbase + prow * 32;
+                    const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
+                    const uint4 wl = *reinterpret_cast<const uint4*>(Xl + xoff);
+                    const unsigned wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
+                    const unsigned wl4 = *reinterpret_cast<const unsigned*>(Xl + xoff + 16);
+#pragma unroll
+                    for (int tx = 0; tx < KW; ++tx) {
+                        uint4 fh, fl;
+                        if (tx == 0) {
+                            fh = wh;
+                            fl = wl;
+                        } else if (tx == 1) {
+                            fh = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
+                                            __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
+                            fl = make_uint4(__builtin_amdgcn_alignbyte(wl.y, wl.x, 2), __builtin_amdgcn_alignbyte(wl.z, wl.y, 2),
+                                            __builtin_amdgcn_alignbyte(wl.w, wl.z, 2), __builtin_amdgcn_alignbyte(wl4, wl.w, 2));
+                        } else {
+                            fh = make_uint4(wh.y, wh.z, wh.w, wh4);
+                            fl = make_uint4(wl.y, wl.z, wl.w, wl4);
+                        }
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, fh), al = __builtin_bit_cast(bf16x8, fl);
+                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][tx], 0, 0, 0);
+                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][tx], 0, 0, 0);
+                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][tx], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- pending registers -> LDS: x plane t+2 into its ring slot, g plane t+1 into buffer (t+1)&1 ----
+        if (t >= za - 3 && xit) {
+            const int sl = ((t + 2 + 4) & 3) * ZS_PLB;
+            const float a[4] = {xa.x, xa.y, xa.z, xa.w}, b[4] = {xb.x, xb.y, xb.z, xb.w};
+            const float s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, f4[4] = {sf4.x, sf4.y, sf4.z, sf4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float va = inA ? fmaf(a[c], s4[c], f4[c]) : 0.f;
+                const float vb = inB ? fmaf(b[c], s4[c], f4[c]) : 0.f;
+                unsigned hi, lo;
+                split2(va, vb, hi, lo);
+                const int off = (xcq * 4 + c) * ZS_CIS + sl + xrow * 32 + xpr * 4;
+                *reinterpret_cast<unsigned*>(Xh + off) = hi;
+                *reinterpret_cast<unsigned*>(Xl + off) = lo;
+            }
+        }
+        if (t + 1 >= za && t + 1 < zb && git) {
+            unsigned char* Gh = Gb + ((t + 1) & 1) * 2 * GPL;
+            unsigned char* Gl = Gh + GPL;
+            const float a[4] = {ga.x, ga.y, ga.z, ga.w}, b[4] = {gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned hi, lo;
+                split2(a[c], b[c], hi, lo);
+                const int off = (gcq * 4 + c) * ZS_GS + (gprow * 8 + gpr * 2) * 2;
+                *reinterpret_cast<unsigned*>(Gh + off) = hi;
+                *reinterpret_cast<unsigned*>(Gl + off) = lo;
+                dbacc[c] += a[c] + b[c];
+            }
+        }
+        // ---- loads for the next pending set: x plane t+3 (planes za-1 .. zb), g plane t+2 (za .. zb-1) ----
+        {
+            const int zx = t + 3;
+            xa = make_float4(0.f, 0.f, 0.f, 0.f);
+            xb = xa;
+            inA = inB = false;
+            if (xit && zx >= za - 1 && zx <= zb && zx >= 0 && zx < D) {
+                const int gy = y0 + xrow - 1, gx = x0 + 2 * xpr - 1;
+                if (gy >= 0 && gy < H) {
+                    const float* rowp = x + (((int64_t)n * D + zx) * H + gy) * W * x_ld + cit * 32 + xcq * 4;
+                    if (gx >= 0 && gx < W) {
+                        xa = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * x_ld);
+                        inA = true;
+                    }
+                    if (gx + 1 >= 0 && gx + 1 < W) {
+                        xb = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * x_ld);
+                        inB = true;
+                    }
+                }
+            }
+            const int zg = t + 2;
+            ga = make_float4(0.f, 0.f, 0.f, 0.f);
+            gb = ga;
+            if (git && zg >= za && zg < zb) {
+                const int gy = y0 + gprow, gx = x0 + 2 * gpr;
+                if (gy < H && gcq * 4 < Cout - cog * GC) {
+                    const float* rowp = g + (((int64_t)n * D + zg) * H + gy) * W * g_ld + cog * GC + gcq * 4;
+                    if (gx < W) ga = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * g_ld);
+                    if (gx + 1 < W) gb = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * g_ld);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- bias-gradient partial of this workgroup ----
+    if (do_db) {
+        float* red = reinterpret_cast<float*>(ldsb);  // [32][GC]
+        if (git) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[grp * GC + gcq * 4 + c] = dbacc[c];
+        }
+        __syncthreads();
+        if (tid < GC && cog * GC + tid < Cout) {
+            float a = 0.f;
+            for (int rr = 0; rr < 32; ++rr) a += red[rr * GC + tid];
+            dbpart[(int64_t)sp * Cout + cog * GC + tid] = a;
+        }
+    }
+    // ---- partial slabs: D[row = ci][col = co] ----
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        if (uok[i]) {
+            const int half = (NCO == 1) ? uv[i] : 0, ct = (NCO == 2) ? uv[i] : 0;
+            if ((cog * NCO + ct) * 32 < Cout) {
+#pragma unroll
+                for (int tx = 0; tx < KW; ++tx) {
+                    const int tap = urg[i] * KW + tx;
+                    float* dst = part + ((((int64_t)sp * KS2 + half) * NT + tap) * Cin + cit * 32) * Cout +
+                                 (cog * NCO + ct) * 32 + r;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                        dst[(int64_t)row * Cout] = acc[i][tx][reg];
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct ZsPlan {
+    bool use;
+    int nco, ks2, T, nY, nX, zsegs, S;
+};
+static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    ZsPlan p;
+    static const int enable = getenv("TEM_WGRAD_ZS") ? atoi(getenv("TEM_WGRAD_ZS")) : 1;
+    p.use = enable && kd == 3 && kh == 3 && kw == 3 && D >= 16;
+    const int ncot = Cout / 32;
+    p.nco = ncot >= 2 ? 2 : 1;
+    p.ks2 = p.nco == 1 ? 2 : 1;
+    p.T = (Cin / 32) * ((ncot + p.nco - 1) / p.nco);
+    p.nY = (H + 7) / 8;
+    p.nX = (W + 7) / 8;
+    int64_t cols = (int64_t)N * p.nY * p.nX;
+    int zs = 1;
+    while (p.T * cols * zs < 256 && D / (zs * 2) >= 8) zs *= 2;  // one workgroup per CU: fill the chip
+    p.zsegs = zs;
+    p.S = (int)(cols * zs);
+    return p;
+}
+
 struct WbPlan {
     int nco, ks2, T, S, P, nZ, nY, nX;
 };
@@ -1219,6 +1478,9 @@ static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) 
 }
 
 int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
+    if (z.use)
+        return tem_align_up((int64_t)z.S * z.ks2 * 27 * Cin * Cout, 64) * 4 + (int64_t)z.S * Cout * 4 + 256;
     WbPlan p = wb_plan(N, D, H, W, Cin, Cout, kd * kh * kw);
     return tem_align_up((int64_t)p.S * p.ks2 * kd * kh * kw * Cin * Cout, 64) * 4 + (int64_t)p.S * Cout * 4 + 256;
 }
@@ -1254,6 +1516,36 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
     if (ws_bytes < tem_conv_wgrad_bf16x3_ws(N, D, H, W, Cin, Cout, kd, kh, kw)) {
         tem_set_error("tem_conv3d_wgrad(bf16x3): workspace too small");
         return TEM_EWS;
+    }
+    const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
+    if (z.use) {
+        float* zpart = (float*)ws;
+        float* zdb = db ? zpart + tem_align_up((int64_t)z.S * z.ks2 * 27 * Cin * Cout, 64) : nullptr;
+        const unsigned nblk = (unsigned)((int64_t)z.T * z.S);
+        if (z.nco == 2) {
+            constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)64 * ZS_GS;
+            static bool a2 = false;
+            if (!a2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zs<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                a2 = true;
+            }
+            hipLaunchKernelGGL((k_conv_wgrad_zs<2>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
+                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs);
+        } else {
+            constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS;
+            static bool a1 = false;
+            if (!a1) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zs<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                a1 = true;
+            }
+            hipLaunchKernelGGL((k_conv_wgrad_zs<1>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
+                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs);
+        }
+        tem_reduce_slabs_w(zpart, z.S * z.ks2, 27, Cin, Cout, (int64_t)27 * Cin * Cout, dw, sd_layout, s);
+        if (db) tem_reduce_slabs(zdb, z.S, Cout, Cout, db, s);
+        return TEM_OK;
     }
     float* part = (float*)ws;
     float* dbpart = db ? part + tem_align_up((int64_t)p.S * p.ks2 * ntaps * Cin * Cout, 64) : nullptr;
