@@ -69,6 +69,7 @@ int tem_device_cus(void);
 #define TEM_WL_MFMA 1
 #define TEM_WL_BF16X3 2
 #define TEM_WL_BF16X6 3
+#define TEM_WL_F16X3 4  /* like BF16X3 with two fp16 terms per weight (22 mantissa bits) */
 #define TEM_ACT_NONE 0
 #define TEM_ACT_RELU 1
 #define TEM_ACT_SIGMOID 2
@@ -93,6 +94,10 @@ int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Ci
  *                accumulation, ~1e-5 relative per product (needs the TEM_WL_BF16X3 pack);
  *                3 = the same with three bf16 terms per operand and the six products of order
  *                <= 2^-16 ("bf16x6"): per-product error ~2^-23, the fp32 class (TEM_WL_BF16X6 pack);
+ *                4 = "fp16x3": x = hi + lo in fp16 (22 mantissa bits), hi*hi + hi*lo + lo*hi on
+ *                v_mfma_f32_32x32x16_f16: ~2^-22 per product at half the MFMAs of mode 3; operands
+ *                must stay far inside the fp16 range, i.e. pre-normalised activations (scale/shift
+ *                given) and weights -- not gradients (TEM_WL_F16X3 pack);
  *                0 = VALU kernel (TEM_WL_GENERIC pack).
  *   ws:          optional workspace of tem_conv3d_fwd_ws() bytes.  Spatially small, channel-rich
  *                layers (the 8^3/16^3 levels) cannot fill 256 CUs with (patch x Cout-tile)

@@ -50,8 +50,9 @@ extern "C" int tem_conv_pack_weights(const float* w, float* dst, int Cout, int C
     TEM_REQUIRE(w && dst && Cout > 0 && Cin > 0, "tem_conv_pack_weights: bad arguments");
     TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
                 "tem_conv_pack_weights: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
-    if (layout == TEM_WL_BF16X3 || layout == TEM_WL_BF16X6) {
-        int rc = tem_pack_weights_bf16x3(w, dst, Cout, Cin, kd, kh, kw, transpose, layout == TEM_WL_BF16X6 ? 3 : 2,
+    if (layout == TEM_WL_BF16X3 || layout == TEM_WL_BF16X6 || layout == TEM_WL_F16X3) {
+        int rc = tem_pack_weights_bf16x3(w, dst, Cout, Cin, kd, kh, kw, transpose,
+                                         layout == TEM_WL_BF16X6 ? 3 : (layout == TEM_WL_F16X3 ? 4 : 2),
                                          (hipStream_t)stream);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv_pack_weights(bf16x3)");
@@ -253,7 +254,7 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
     TEM_REQUIRE(act >= 0 && act <= 2, "tem_conv3d_fwd: Invalid activation: %d", act);
     TEM_REQUIRE(!ref || ref_ld >= Cout, "tem_conv3d_fwd: bad ref_ld");
     hipStream_t s = (hipStream_t)stream;
-    if (use_mfma == 2 || use_mfma == 3) {
+    if (use_mfma == 2 || use_mfma == 3 || use_mfma == 4) {
         int rc = tem_conv_fwd_bf16x3(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
                                      W, Cin, Cout, kd, kh, kw, act, use_mfma, s);
         if (rc != TEM_OK) return rc;

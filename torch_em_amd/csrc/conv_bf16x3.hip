@@ -37,6 +37,35 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     const float rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
     lo = pk_bf16(ra, rb);
 }
+// fp16 counterparts (forward of NORMALISED activations only: |x| << 65504).  x = h + l with two fp16 terms carries 22
+// mantissa bits, so hi*hi + hi*lo + lo*hi ("fp16x3") is fp32-class (~2^-22 per product) at HALF the MFMAs of bf16x6.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ unsigned pk16(float a, float b) {
+    if (F16) {
+        half2_t v = {(_Float16)a, (_Float16)b};  // round-to-nearest-even
+        return __builtin_bit_cast(unsigned, v);
+    }
+    return pk_bf16(a, b);
+}
+template <bool F16>
+__device__ __forceinline__ float lo16(unsigned h) {
+    if (F16) return (float)__builtin_bit_cast(half2_t, h).x;
+    return __builtin_bit_cast(float, h << 16);
+}
+template <bool F16>
+__device__ __forceinline__ float hi16(unsigned h) {
+    if (F16) return (float)__builtin_bit_cast(half2_t, h).y;
+    return __builtin_bit_cast(float, h & 0xffff0000u);
+}
+template <bool F16>
+__device__ __forceinline__ floatx16 mfma16(uint4 a, uint4 b, floatx16 c) {
+    if (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float act_apply_b(float v, int act) {
     if (act == TEM_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == TEM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
@@ -54,7 +83,7 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {
 
 __global__ __launch_bounds__(256) void k_pack_weights_bfsplit(const float* __restrict__ w, unsigned short* __restrict__ dst,
                                                               int Cout, int Cin, int KD, int KH, int KW, int transpose,
-                                                              int NS) {
+                                                              int NS, int fp16) {
     const int ntaps = KD * KH * KW;
     const int64_t total = (int64_t)Cout * Cin * ntaps;
     const int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
@@ -73,20 +102,28 @@ __global__ __launch_bounds__(256) void k_pack_weights_bfsplit(const float* __res
         const int64_t base = ((((int64_t)nt * ntaps + tap) * (CinL >> 4) + c16) * NS) * 512;  // 512 bf16 per plane
         float rem = val;
         for (int p = 0; p < NS; ++p) {
-            const unsigned short hb = bf16_bits(rem);
-            dst[base + p * 512 + (kh * 32 + col) * 8 + j] = hb;
-            rem -= __builtin_bit_cast(float, (unsigned)hb << 16);
+            if (fp16) {
+                const _Float16 hv = (_Float16)rem;
+                dst[base + p * 512 + (kh * 32 + col) * 8 + j] = __builtin_bit_cast(unsigned short, hv);
+                rem -= (float)hv;
+            } else {
+                const unsigned short hb = bf16_bits(rem);
+                dst[base + p * 512 + (kh * 32 + col) * 8 + j] = hb;
+                rem -= __builtin_bit_cast(float, (unsigned)hb << 16);
+            }
         }
     }
 }
 
 int tem_pack_weights_bf16x3(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw, int transpose,
                             int nsplit, hipStream_t s) {
+    const int fp16 = nsplit == 4;  // nsplit 4 = fp16x3: two fp16 planes
+    if (fp16) nsplit = 2;
     int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
     TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: split-bf16 layout needs Cin%%16==0, Cout%%32==0");
     int64_t total = (int64_t)Cout * Cin * kd * kh * kw;
     hipLaunchKernelGGL(k_pack_weights_bfsplit, dim3(tem_grid_1d(total, 256)), dim3(256), 0, s, w, (unsigned short*)dst,
-                       Cout, Cin, kd, kh, kw, transpose, nsplit);
+                       Cout, Cin, kd, kh, kw, transpose, nsplit, fp16);
     return TEM_OK;
 }
 
@@ -96,7 +133,7 @@ int tem_pack_weights_bf16x3(const float* w, float* dst, int Cout, int Cin, int k
 // (6 MFMAs) -- per-product error ~2^-23, i.e. the fp32 class, at 16/6 of the exact-fp32 MFMA rate;
 // used for the forward pass, whose rounding noise the gradient amplifies (engine.py, PRECISION).
 // ---------------------------------------------------------------------------
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS>
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false>
 __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_bfsplit(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
@@ -197,13 +234,13 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
                 float e[4] = {tmp[it].x, tmp[it].y, tmp[it].z, tmp[it].w};
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
-                    const unsigned h0 = pk_bf16(e[0], e[1]), h1 = pk_bf16(e[2], e[3]);
+                    const unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
                     if (!(TEM_ABLATE & 16)) *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
                     if (p + 1 < NS) {
-                        e[0] -= __builtin_bit_cast(float, h0 << 16);
-                        e[1] -= __builtin_bit_cast(float, h0 & 0xffff0000u);
-                        e[2] -= __builtin_bit_cast(float, h1 << 16);
-                        e[3] -= __builtin_bit_cast(float, h1 & 0xffff0000u);
+                        e[0] -= lo16<F16>(h0);
+                        e[1] -= hi16<F16>(h0);
+                        e[2] -= lo16<F16>(h1);
+                        e[3] -= hi16<F16>(h1);
                     }
                 }
             }
@@ -238,12 +275,12 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
 #pragma unroll
                     for (int p = 0; p < NS; ++p) bq[0][nn][p] = wq[nn][(int64_t)chunk * FR + (int64_t)tap * ts + p * 64];
             }
-            bf16x8 af[2][NS];
+            uint4 af[2][NS];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
-                    af[m][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + ((TEM_ABLATE & 1) ? 0 : toff) + p * 8));
+                    af[m][p] = *reinterpret_cast<const uint4*>(lds + abase[m] + ((TEM_ABLATE & 1) ? 0 : toff) + p * 8);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -254,8 +291,7 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
 #pragma unroll
                         for (int i = 0; i <= sum; ++i) {
                             const int j = sum - i;
-                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                af[m][i], __builtin_bit_cast(bf16x8, bq[tap % RD][nn][j]), acc[m][nn], 0, 0, 0);
+                            acc[m][nn] = mfma16<F16>(af[m][i], bq[tap % RD][nn][j], acc[m][nn]);
                         }
                 }
         }
@@ -770,7 +806,7 @@ __global__ __launch_bounds__((4 + NL) * 64, 1) void k_conv_fwd_bfsplit_lc(
     }
 }
 
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS>
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false>
 static void launch_b(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
                      int W, int Cin, int Cout, int act, int ksplit, float* part, hipStream_t s) {
@@ -782,7 +818,7 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     // latency: 32->32 128^3 bf16x3 1.47 ms vs 1.00 ms); kept as an experiment switch, off by default
     // measured equal to the plain kernel below (the limiter is not load latency): off by default
     static const int ppmode = getenv("TEM_SPLIT_PP") ? atoi(getenv("TEM_SPLIT_PP")) : 0;
-    if constexpr ((KD * KH * KW) % 3 == 0) {
+    if constexpr ((KD * KH * KW) % 3 == 0 && !F16) {
         if (ppmode) {
             constexpr int RD = (NR == 1 && NS == 2 && (KD * KH * KW) % 9 == 0 && ppmode_deep_ring) ? 9 : 3;  // NS == 3 would spill
             constexpr int WPC = (NR == 2 || NS == 3 || RD > 3) ? 2 : 3;  // resident workgroups per CU (LDS / launch bounds)
@@ -812,7 +848,7 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
         }
     }
     static const int lcmode = getenv("TEM_SPLIT_LC") ? atoi(getenv("TEM_SPLIT_LC")) : 0;
-    if constexpr ((KD * KH * KW) % 3 == 0) {
+    if constexpr ((KD * KH * KW) % 3 == 0 && !F16) {
         if (lcmode) {
             constexpr int NL = 2;
             constexpr size_t lds2 = 2 * ldsb;
@@ -841,11 +877,11 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     }
     static bool attr_done = false;
     if (!attr_done && ldsb > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS>), dim3((unsigned)nblk), dim3(256), ldsb, s, x,
+    hipLaunchKernelGGL((k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16>), dim3((unsigned)nblk), dim3(256), ldsb, s, x,
                        x_ld, scale, shift, reinterpret_cast<const uint4*>(wp), bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin,
                        Cout, act, nZ, nY, nX, ksplit, part);
     if (ksplit > 1) {
@@ -883,12 +919,19 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
             launch_b<KD, KH, KW, TZ, TY, TX, 1, NS>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
                                                     Cin, Cout, act, ks, part, s);                                   \
     } while (0)
-#define GO(KD, KH, KW, TZ, TY, TX)            \
-    do {                                      \
-        if (nsplit == 3)                      \
-            GO2(KD, KH, KW, TZ, TY, TX, 3);   \
-        else                                  \
-            GO2(KD, KH, KW, TZ, TY, TX, 2);   \
+#define GO(KD, KH, KW, TZ, TY, TX)                                                                                    \
+    do {                                                                                                              \
+        if (nsplit == 3)                                                                                              \
+            GO2(KD, KH, KW, TZ, TY, TX, 3);                                                                           \
+        else if (nsplit == 4) {                                                                                       \
+            if (nr2)                                                                                                  \
+                launch_b<KD, KH, KW, TZ, TY, TX, 2, 2, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                             W, Cin, Cout, act, ks, part, s);                         \
+            else                                                                                                      \
+                launch_b<KD, KH, KW, TZ, TY, TX, 1, 2, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                             W, Cin, Cout, act, ks, part, s);                         \
+        } else                                                                                                        \
+            GO2(KD, KH, KW, TZ, TY, TX, 2);                                                                           \
     } while (0)
     if (key == 7) {
         GO(3, 3, 3, 4, 8, 8);

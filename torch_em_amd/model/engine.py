@@ -50,7 +50,7 @@ PRECISION = os.environ.get("TEM_PRECISION", "split")
 
 def set_precision(mode: str):
     global PRECISION
-    if mode not in ("fp32", "mixed", "split", "bf16x3"):
+    if mode not in ("fp32", "mixed", "split", "split16", "bf16x3"):
         raise ValueError(f"unknown precision mode {mode}")
     PRECISION = mode
 
@@ -91,8 +91,10 @@ class ConvSpec:
         w = self.conv.weight
         ent = getattr(self.conv, "_tem_pack", None)
         if ent is None or ent["version"] != w._version or ent["ptr"] != w.data_ptr() or ent["prec"] != PRECISION:
-            mode_f = {"bf16x3": 2, "split": 3}.get(PRECISION, 1)
-            mode_d = 2 if PRECISION in ("bf16x3", "mixed", "split") else 1
+            mode_f = {"bf16x3": 2, "split": 3, "split16": 3}.get(PRECISION, 1)
+            if PRECISION == "split16" and self.norm is not None and self.k != (1, 1, 1):
+                mode_f = 4  # fp16x3: the conv reads pre-normalised activations (|x| of order 1..100 << 65504)
+            mode_d = 2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
             mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
             md = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k) else 0
             mw = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k, wgrad=True) else 0

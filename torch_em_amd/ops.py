@@ -126,7 +126,7 @@ def mfma_ok(cin: int, cout: int, k: Sequence[int], wgrad: bool = False) -> bool:
 
 def pack_weights(w: torch.Tensor, transpose: bool, mfma) -> torch.Tensor:
     """state_dict layout [Cout, Cin, (kd,) kh, kw] -> kernel layout (see tem_hip.h).
-    mfma: False/0 generic, True/1 exact-fp32 MFMA fragments, 2 split-bf16 fragments."""
+    mfma: False/0 generic, True/1 exact-fp32 MFMA fragments, 2 / 3 split-bf16 fragments (2 / 3 terms), 4 split-fp16."""
     _req_cuda(w)
     w = w.detach().contiguous()
     cout, cin = w.shape[:2]
@@ -156,7 +156,7 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
                                   ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma),
                                   _stream(x)), "tem_conv3d_fwd")
     if ev0 is not None:
-        kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6"}.get(int(mfma)) or
+        kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3"}.get(int(mfma)) or
                 ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu")) + \
             f"<{k[0]},{k[1]},{k[2]}"
         kind += (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
