@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int nn = 0; nn < NR; ++nn) {
-                    // smallest terms first: all plane pairs (i, j) with i + j <= NS - 1 (0-based)
+                    // smallest terms first: all plane pairs (i, j) with i + j <= NS - 1 (0-based).  (Product-major
+                    // issue, which helps the wgrad kernel, is 10 % SLOWER here: accumulator-major lets the MFMAs of
+                    // m = 0 start while the A fragments of m = 1 are still in flight.)
 #pragma unroll
                     for (int sum = NS - 1; sum >= 0; --sum)
 #pragma unroll
@@ -1323,7 +1325,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
     // iteration t: MFMA over plane t (if t >= za); store the pending registers (x plane t+2, g plane t+1); load the
     // next pending set (x plane t+3, g plane t+2); barrier.
     for (int t = za - 4; t < zb; ++t) {
-        if (t >= za) {
+        if (t >= za && !(TEM_ABLATE & 256)) {
             const unsigned char* Gh = Gb + (t & 1) * 2 * GPL;
             const unsigned char* Gl = Gh + GPL;
             int slot[3];
@@ -1347,31 +1349,30 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                     const uint4 wl = *reinterpret_cast<const uint4*>(Xl + xoff);
                     const unsigned wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
                     const unsigned wl4 = *reinterpret_cast<const unsigned*>(Xl + xoff + 16);
+                    // the three tx windows first, then product-major issue: consecutive MFMAs hit different accumulators
+                    uint4 fh[KW], fl[KW];
+                    fh[0] = wh;
+                    fl[0] = wl;
+                    fh[1] = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
+                                       __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
+                    fl[1] = make_uint4(__builtin_amdgcn_alignbyte(wl.y, wl.x, 2), __builtin_amdgcn_alignbyte(wl.z, wl.y, 2),
+                                       __builtin_amdgcn_alignbyte(wl.w, wl.z, 2), __builtin_amdgcn_alignbyte(wl4, wl.w, 2));
+                    fh[2] = make_uint4(wh.y, wh.z, wh.w, wh4);
+                    fl[2] = make_uint4(wl.y, wl.z, wl.w, wl4);
 #pragma unroll
-                    for (int tx = 0; tx < KW; ++tx) {
-                        uint4 fh, fl;
-                        if (tx == 0) {
-                            fh = wh;
-                            fl = wl;
-                        } else if (tx == 1) {
-                            fh = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
-                                            __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
-                            fl = make_uint4(__builtin_amdgcn_alignbyte(wl.y, wl.x, 2), __builtin_amdgcn_alignbyte(wl.z, wl.y, 2),
-                                            __builtin_amdgcn_alignbyte(wl.w, wl.z, 2), __builtin_amdgcn_alignbyte(wl4, wl.w, 2));
-                        } else {
-                            fh = make_uint4(wh.y, wh.z, wh.w, wh4);
-                            fl = make_uint4(wl.y, wl.z, wl.w, wl4);
-                        }
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, fh), al = __builtin_bit_cast(bf16x8, fl);
-                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][tx], 0, 0, 0);
-                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][tx], 0, 0, 0);
-                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][tx], 0, 0, 0);
-                    }
+                    for (int tx = 0; tx < KW; ++tx)
+                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl[tx]), bh, acc[i][tx], 0, 0, 0);
+#pragma unroll
+                    for (int tx = 0; tx < KW; ++tx)
+                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh[tx]), bl, acc[i][tx], 0, 0, 0);
+#pragma unroll
+                    for (int tx = 0; tx < KW; ++tx)
+                        acc[i][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh[tx]), bh, acc[i][tx], 0, 0, 0);
                 }
             }
         }
         // ---- pending registers -> LDS: x plane t+2 into its ring slot, g plane t+1 into buffer (t+1)&1 ----
-        if (t >= za - 3 && xit) {
+        if (t >= za - 3 && xit && !(TEM_ABLATE & 512)) {
             const int sl = ((t + 2 + 4) & 3) * ZS_PLB;
             const float a[4] = {xa.x, xa.y, xa.z, xa.w}, b[4] = {xb.x, xb.y, xb.z, xb.w};
             const float s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, f4[4] = {sf4.x, sf4.y, sf4.z, sf4.w};
@@ -1386,7 +1387,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                 *reinterpret_cast<unsigned*>(Xl + off) = lo;
             }
         }
-        if (t + 1 >= za && t + 1 < zb && git) {
+        if (t + 1 >= za && t + 1 < zb && git && !(TEM_ABLATE & 512)) {
             unsigned char* Gh = Gb + ((t + 1) & 1) * 2 * GPL;
             unsigned char* Gl = Gh + GPL;
             const float a[4] = {ga.x, ga.y, ga.z, ga.w}, b[4] = {gb.x, gb.y, gb.z, gb.w};
@@ -1406,7 +1407,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             xa = make_float4(0.f, 0.f, 0.f, 0.f);
             xb = xa;
             inA = inB = false;
-            if (xit && zx >= za - 1 && zx <= zb && zx >= 0 && zx < D) {
+            if (xit && zx >= za - 1 && zx <= zb && zx >= 0 && zx < D && !(TEM_ABLATE & 1024)) {
                 const int gy = y0 + xrow - 1, gx = x0 + 2 * xpr - 1;
                 if (gy >= 0 && gy < H) {
                     const float* rowp = x + (((int64_t)n * D + zx) * H + gy) * W * x_ld + cit * 32 + xcq * 4;
@@ -1423,7 +1424,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             const int zg = t + 2;
             ga = make_float4(0.f, 0.f, 0.f, 0.f);
             gb = ga;
-            if (git && zg >= za && zg < zb) {
+            if (git && zg >= za && zg < zb && !(TEM_ABLATE & 1024)) {
                 const int gy = y0 + gprow, gx = x0 + 2 * gpr;
                 if (gy < H && gcq * 4 < Cout - cog * GC) {
                     const float* rowp = g + (((int64_t)n * D + zg) * H + gy) * W * g_ld + cog * GC + gcq * 4;
