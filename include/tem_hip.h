@@ -77,6 +77,11 @@ int tem_device_cus(void);
 int64_t tem_conv_packed_size(int Cout, int Cin, int kd, int kh, int kw); /* floats */
 int tem_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw,
                           int transpose, int layout, tem_stream_t stream);
+/* All split-layout (TEM_WL_BF16X3 / BF16X6 / F16X3) packs of a model in ONE launch.  descs_dev: device array of n
+ * records { const float* w; void* dst; int32 Cout, Cin, kd, kh, kw, transpose, nsplit(2|3), fp16(0|1); int64 begin }
+ * (56 bytes each, `begin` = running offset in units of 8 weights, ascending); total = sum of Cout*Cin*taps/8.  Same result as n calls
+ * of tem_conv_pack_weights. */
+int tem_conv_pack_weights_batch(const void* descs_dev, int n, int64_t total, tem_stream_t stream);
 /* inverse of the GENERIC pack for weight gradients: [tap][ci][co] -> [Cout][Cin][kd][kh][kw] */
 int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Cin, int kd, int kh, int kw,
                           tem_stream_t stream);

@@ -21,6 +21,7 @@ sequenced MI355X-first:
   autograd), so the optimizer step and the data-parallel all-reduce are single launches.
 """
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -87,25 +88,73 @@ class ConvSpec:
         return self.cin, getattr(n, "weight", None), getattr(n, "bias", None), n.eps
 
     # --- packed weights (cached until the parameter changes) -----------------------
+    def _modes(self):
+        mode_f = {"bf16x3": 2, "split": 3, "split16": 3}.get(PRECISION, 1)
+        if PRECISION == "split16" and self.norm is not None and self.k != (1, 1, 1):
+            mode_f = 4  # fp16x3: the conv reads pre-normalised activations (|x| of order 1..100 << 65504)
+        mode_d = 2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
+        mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
+        md = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k) else 0
+        mw = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k, wgrad=True) else 0
+        return mf, md, mw
+
     def packed(self):
         w = self.conv.weight
         ent = getattr(self.conv, "_tem_pack", None)
-        if ent is None or ent["version"] != w._version or ent["ptr"] != w.data_ptr() or ent["prec"] != PRECISION:
-            mode_f = {"bf16x3": 2, "split": 3, "split16": 3}.get(PRECISION, 1)
-            if PRECISION == "split16" and self.norm is not None and self.k != (1, 1, 1):
-                mode_f = 4  # fp16x3: the conv reads pre-normalised activations (|x| of order 1..100 << 65504)
-            mode_d = 2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
-            mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
-            md = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k) else 0
-            mw = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k, wgrad=True) else 0
-            ent = {
-                "version": w._version, "ptr": w.data_ptr(), "prec": PRECISION,
-                "fwd": ops.pack_weights(w, transpose=False, mfma=mf), "fwd_mfma": mf,
-                "dgrad": ops.pack_weights(w, transpose=True, mfma=md), "dgrad_mfma": md,
-                "wgrad_mfma": mw,
-            }
-            object.__setattr__(self.conv, "_tem_pack", ent)
+        if ent is not None and ent["version"] == w._version and ent["ptr"] == w.data_ptr() and ent["prec"] == PRECISION:
+            return ent
+        if _PACK_BATCH and ent is not None and ent["ptr"] == w.data_ptr() and ent["prec"] == PRECISION:
+            # only the values changed (an optimizer step): refresh EVERY stale registered conv in one launch
+            _repack_stale()
+            ent = self.conv._tem_pack
+            if ent["version"] == w._version:
+                return ent
+        mf, md, mw = self._modes()
+        ent = {
+            "version": w._version, "ptr": w.data_ptr(), "prec": PRECISION,
+            "fwd": ops.pack_weights(w, transpose=False, mfma=mf), "fwd_mfma": mf,
+            "dgrad": ops.pack_weights(w, transpose=True, mfma=md), "dgrad_mfma": md,
+            "wgrad_mfma": mw,
+        }
+        object.__setattr__(self.conv, "_tem_pack", ent)
+        _PACKED_CONVS.add(self.conv)
         return ent
+
+
+_PACKED_CONVS = weakref.WeakSet()
+_PACK_BATCH = os.environ.get("TEM_PACK_BATCH", "1") != "0"
+_PACK_TABLES = {}
+
+
+def _repack_stale():
+    """Re-pack the weights of every registered conv whose parameter changed in place (same storage, new version):
+    all split-layout packs go into ONE tem_conv_pack_weights_batch launch, written into the existing buffers."""
+    jobs, rest = [], []
+    for conv in list(_PACKED_CONVS):
+        ent = getattr(conv, "_tem_pack", None)
+        w = conv.weight
+        if ent is None or not w.is_cuda or ent["ptr"] != w.data_ptr() or ent["prec"] != PRECISION \
+                or ent["version"] == w._version:
+            continue
+        k = _k3(conv.kernel_size)
+        for key, transpose in (("fwd", 0), ("dgrad", 1)):
+            mode = ent[key + "_mfma"]
+            if mode in (2, 3, 4):
+                jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose, 3 if mode == 3 else 2,
+                             1 if mode == 4 else 0))
+            else:
+                rest.append((ent, key, w, bool(transpose), mode))
+        ent["version"] = w._version
+    for ent, key, w, transpose, mode in rest:
+        ent[key] = ops.pack_weights(w, transpose=transpose, mfma=mode)
+    if jobs:
+        sig = tuple((j[0].data_ptr(), j[1].data_ptr()) for j in jobs)
+        tab = _PACK_TABLES.get(sig)
+        if tab is None:
+            _PACK_TABLES.clear()
+            tab = ops.pack_table(jobs)
+            _PACK_TABLES[sig] = tab
+        ops.pack_weights_batch(tab)
 
 
 def fused_activation(act: nn.Module) -> Optional[str]:

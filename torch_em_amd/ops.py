@@ -139,6 +139,25 @@ def pack_weights(w: torch.Tensor, transpose: bool, mfma) -> torch.Tensor:
     return dst
 
 
+def pack_table(jobs):
+    """Device descriptor table for tem_conv_pack_weights_batch.  jobs: (w, dst, cout, cin, k3, transpose, nsplit, fp16)."""
+    import struct
+    blob, begin = b"", 0
+    for w, dst, cout, cin, k, transpose, nsplit, fp16 in jobs:
+        blob += struct.pack("<qq8iq", w.data_ptr(), dst.data_ptr(), cout, cin, k[0], k[1], k[2], int(transpose), nsplit,
+                            fp16, begin)
+        begin += cout * cin * k[0] * k[1] * k[2] // 8
+    dev = jobs[0][0].device
+    table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    return {"table": table, "n": len(jobs), "total": begin, "keep": [(j[0], j[1]) for j in jobs]}
+
+
+def pack_weights_batch(tab):
+    lib = _lib.load()
+    _lib.check(lib.tem_conv_pack_weights_batch(_p(tab["table"]), tab["n"], tab["total"], _stream(tab["table"])),
+               "tem_conv_pack_weights_batch")
+
+
 def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=None, ref=None, mfma=False):
     _req_cuda(x, w_packed, y)
     N, D, H, W, C, x_ld = _act5(x)
