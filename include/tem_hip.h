@@ -299,6 +299,18 @@ int tem_elastic_field(const float* noise, const float* gauss1d, int ksize, int H
 int tem_elastic_warp2d(const float* src, const float* disp, float* dst, int64_t planes, int H, int W, int nearest,
                        tem_stream_t stream);
 
+/* ---- tiled inference with a halo (util/prediction.py:98-330) ----------
+ * The volume stays in HBM.  tem_block_load_reflect = `_load_block` (:98-142): the (block + halo) box clipped to the
+ * volume is the segment [seg_start, seg_start + seg_len); dst [C][out_shape] is that segment padded by numpy
+ * "reflect" (pad_left on the left, the rest on the right).  tem_block_store_inner = the write-back (:270-302):
+ * out[c][out_start + i] = pred[c][inner_start + i] for i < size, zero where mask (uint8 [D][H][W], nullable) is 0.
+ * src / out: [C][D][H][W] float32; all int arrays are HOST int[3] (z, y, x); 2-D data: D == 1. */
+int tem_block_load_reflect(const float* src, float* dst, int C, int D, int H, int W, const int* seg_start,
+                           const int* seg_len, const int* pad_left, const int* out_shape, tem_stream_t stream);
+int tem_block_store_inner(const float* pred, const int* pred_shape, float* out, int C, int D, int H, int W,
+                          const unsigned char* mask, const int* inner_start, const int* out_start, const int* size,
+                          tem_stream_t stream);
+
 /* ---- small utilities ---------------------------------------------------------- */
 /* NCDHW (contiguous) <-> NDHWC(ld) layout change at the module boundary. */
 int tem_nchw_to_nhwc(const float* src, float* dst, int64_t dst_ld, int N, int C, int64_t V, tem_stream_t stream);

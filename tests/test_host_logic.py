@@ -124,3 +124,19 @@ def test_augmentation_host_logic():
     assert bool(f.generate_parameters((3, 1, 2, 2, 2))["batch_prob"].all())
     with pytest.raises(RuntimeError):  # no CPU fallback
         pipe(torch.zeros(1, 1, 2, 2, 2))
+
+
+def test_prediction_blocking_matches_oracle_and_has_no_cpu_path():
+    from oracle import predict_ref
+    from torch_em_amd.util import predict_with_halo
+    from torch_em_amd.util.prediction import _Blocking
+    for start, stop, bs in [((0, 0, 0), (20, 36, 28), (8, 16, 16)), ((4, 0), (20, 33), (5, 32)), ((0,), (7,), (7,))]:
+        b = _Blocking(start, stop, bs)
+        want = list(predict_ref.blocks(list(start), list(stop), list(bs)))
+        assert b.number_of_blocks == len(want)
+        assert [b.get_block(i) for i in range(b.number_of_blocks)] == [(w[0], w[1]) for w in want]
+    model = UNet3d(1, 1, depth=1, initial_features=4)
+    with pytest.raises(RuntimeError):
+        predict_with_halo(np.zeros((8, 8, 8), "float32"), model, ["cpu"], (8, 8, 8), (0, 0, 0))
+    with pytest.raises(NotImplementedError):
+        predict_with_halo(np.zeros((8, 8, 8), "float32"), model, [0, 1], (8, 8, 8), (0, 0, 0))

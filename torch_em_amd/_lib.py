@@ -77,6 +77,9 @@ SIGNATURES = {
     "tem_flip3d": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tem_elastic_field": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_float, c_float, c_vp, c_vp]),
     "tem_elastic_warp2d": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
+    "tem_block_load_reflect": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int] + [ctypes.POINTER(c_int)] * 4 + [c_vp]),
+    "tem_block_store_inner": (c_int, [c_vp, ctypes.POINTER(c_int), c_vp, c_int, c_int, c_int, c_int, c_vp]
+                              + [ctypes.POINTER(c_int)] * 3 + [c_vp]),
     "tem_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
 }
 
