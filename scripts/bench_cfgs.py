@@ -53,3 +53,18 @@ for _ in range(n):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 print(f"cfg {cfg}: {ms:.2f} ms/step  {x.numel() / ms * 1e3:.3e} voxels/s  (target transform on device, loss {float(v):.4f})")
+
+if os.environ.get("TEM_TABLE"):
+    from torch_em_amd import ops
+    ops.PROFILER = []
+    step()
+    torch.cuda.synchronize()
+    tab = {}
+    for (tag, shape), flops, e0, e1 in ops.PROFILER:
+        d = tab.setdefault((tag, shape), [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+        d[2] += flops
+    for (tag, shape), d in sorted(tab.items(), key=lambda kv: -kv[1][1])[:24]:
+        print(f"{tag + '  ' + shape:80s} {d[0]:3d} {d[1] / d[0]:8.4f} ms {d[2] / d[1] / 1e9:8.1f} TF")
+    print("conv total", sum(d[1] for d in tab.values()))

@@ -1044,7 +1044,9 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
 #define WB_PV (WB_TZ * WB_TY * WB_TX)   // 128 patch voxels = 8 k-slabs
 #define WB_GS 272                        // bytes per co row of Gt: 128 bf16 + 16 pad
 
-template <int KD, int KH, int KW, int NCO, int KS2>
+// PTZ x PTY x 8 patch of 128 voxels: 2 x 8 x 8 for volumes, 1 x 16 x 8 for 2-D data (D == 1: a 2-plane patch would be
+// half padding)
+template <int KD, int KH, int KW, int NCO, int KS2, int PTZ = 2>
 __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __restrict__ x, int64_t x_ld,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
@@ -1055,7 +1057,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
     constexpr int NT = KD * KH * KW;
     constexpr int NRG = KD * KH;  // row groups (tz, ty)
     constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
-    constexpr int HZ = WB_TZ + KD - 1, HY = WB_TY + KH - 1, HX = WB_TX + KW - 1;
+    constexpr int PTY = 16 / PTZ;
+    constexpr int HZ = PTZ + KD - 1, HY = PTY + KH - 1, HX = WB_TX + KW - 1;
     constexpr int ROWS = HZ * HY;
     constexpr int CIS = ROWS * 32 + 16;          // bytes per ci plane of Xt (padded: conflict-free b128 reads)
     constexpr int XPL = 32 * CIS;                // bytes per (hi|lo) plane of Xt
@@ -1128,7 +1131,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
         const int pty_ = q_ % nY; q_ /= nY;                                                                        \
         const int ptz_ = q_ % nZ;                                                                                  \
         const int n_ = q_ / nZ;                                                                                    \
-        const int z0_ = ptz_ * WB_TZ, y0_ = pty_ * WB_TY, x0_ = ptx_ * WB_TX;                                      \
+        const int z0_ = ptz_ * PTZ, y0_ = pty_ * PTY, x0_ = ptx_ * WB_TX;                                              \
         if (scale) {                                                                                               \
             sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n_ * Cin + cit * 32 + xcq * 4);                \
             sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n_ * Cin + cit * 32 + xcq * 4);                \
@@ -1153,7 +1156,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
             const int item = tid + it * 256;                                                                       \
             const int cq = item % (GC / 4), rp = item / (GC / 4);                                                  \
             const int prow = rp >> 2, pr = rp & 3;                                                                 \
-            const int gz = z0_ + prow / WB_TY, gy = y0_ + prow % WB_TY, gx = x0_ + 2 * pr;                         \
+            const int gz = z0_ + prow / PTY, gy = y0_ + prow % PTY, gx = x0_ + 2 * pr;                             \
             ga[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
             gb[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
             if (gz < D && gy < H && cq < nco_here * 8 && !(TEM_ABLATE & 32)) {                                     \
@@ -1219,7 +1222,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
 #pragma unroll 2
             for (int sl = 0; sl < SPU; ++sl) {
                 const int prow = 2 * (uhalf[i] * SPU + sl) + kh;  // this lane half's patch row
-                const int pz = prow / WB_TY, py = prow % WB_TY;
+                const int pz = prow / PTY, py = prow % PTY;
                 const int goff = (uct[i] * 32 + r) * WB_GS + prow * 16;
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gh + goff));
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gl + goff));
@@ -1562,7 +1565,7 @@ static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int
 }
 
 struct WbPlan {
-    int nco, ks2, T, S, P, nZ, nY, nX;
+    int nco, ks2, T, S, P, nZ, nY, nX, ptz;
 };
 
 static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) {
@@ -1572,8 +1575,9 @@ static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) 
     p.ks2 = (ntaps > 1 && p.nco == 1) ? 2 : 1;  // single co tile: split the k-slabs between two units
     int ngroups = (ncot + p.nco - 1) / p.nco;
     p.T = (Cin / 32) * ngroups;
-    p.nZ = (D + WB_TZ - 1) / WB_TZ;
-    p.nY = (H + WB_TY - 1) / WB_TY;
+    p.ptz = (D == 1) ? 1 : 2;
+    p.nZ = (D + p.ptz - 1) / p.ptz;
+    p.nY = (H + 16 / p.ptz - 1) / (16 / p.ptz);
     p.nX = (W + WB_TX - 1) / WB_TX;
     int64_t P = (int64_t)N * p.nZ * p.nY * p.nX;
     p.P = (int)P;
@@ -1596,21 +1600,33 @@ int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, 
     return tem_align_up((int64_t)p.S * p.ks2 * kd * kh * kw * Cin * Cout, 64) * 4 + (int64_t)p.S * Cout * 4 + 256;
 }
 
-template <int KD, int KH, int KW, int NCO, int KS2 = 1>
-static void launch_wb(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
-                      float* part, float* dbpart, int N, int D, int H, int W, int Cin, int Cout, const WbPlan& p,
-                      hipStream_t s) {
-    constexpr int ROWS = (WB_TZ + KD - 1) * (WB_TY + KH - 1);
+template <int KD, int KH, int KW, int NCO, int KS2, int PTZ>
+static void launch_wb_t(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
+                        float* part, float* dbpart, int N, int D, int H, int W, int Cin, int Cout, const WbPlan& p,
+                        hipStream_t s) {
+    constexpr int ROWS = (PTZ + KD - 1) * (16 / PTZ + KH - 1);
     constexpr size_t ldsbytes = 2 * (size_t)32 * (ROWS * 32 + 16) + 2 * (size_t)32 * NCO * WB_GS;
     static_assert(ldsbytes <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2, PTZ>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2>), dim3((unsigned)(p.T * p.S)), dim3(256), ldsbytes, s, x,
-                       x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p.T, p.S, p.P, p.nZ, p.nY, p.nX);
+    hipLaunchKernelGGL((k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2, PTZ>), dim3((unsigned)(p.T * p.S)), dim3(256), ldsbytes, s,
+                       x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p.T, p.S, p.P, p.nZ, p.nY, p.nX);
+}
+template <int KD, int KH, int KW, int NCO, int KS2 = 1>
+static void launch_wb(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
+                      float* part, float* dbpart, int N, int D, int H, int W, int Cin, int Cout, const WbPlan& p,
+                      hipStream_t s) {
+    if constexpr (KD == 1) {
+        if (p.ptz == 1) {
+            launch_wb_t<KD, KH, KW, NCO, KS2, 1>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
+            return;
+        }
+    }
+    launch_wb_t<KD, KH, KW, NCO, KS2, 2>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
 }
 
 int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
