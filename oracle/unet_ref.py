@@ -57,6 +57,7 @@ def unet_forward(sd, x, scale_factors, norm="InstanceNorm", final_activation=Non
         f = scale_factors[l]
         x = pool(x, f if isinstance(f, int) else tuple(f))
     x = _block(sd, "base", x, norm)
+    dec_out = []
     for i in range(depth):
         f = scale_factors[depth - 1 - i]
         x = F.interpolate(x, scale_factor=f if isinstance(f, int) else tuple(float(v) for v in f), mode=mode,
@@ -64,6 +65,16 @@ def unet_forward(sd, x, scale_factors, norm="InstanceNorm", final_activation=Non
         x = _conv(x, sd[f"decoder.samplers.{i}.conv.weight"], sd[f"decoder.samplers.{i}.conv.bias"])
         x = torch.cat([x, skips[depth - 1 - i]], dim=1)
         x = _block(sd, f"decoder.blocks.{i}", x, norm)
+        dec_out.append(x)
+    if "out_conv.0.weight" in sd:
+        # return_side_outputs (UNetBase._apply_with_side_outputs, :211-228): one 1x1 conv per decoder level,
+        # activation on each, list reversed so that the full-resolution output comes first
+        outs = [_conv(d, sd[f"out_conv.{i}.weight"], sd[f"out_conv.{i}.bias"]) for i, d in enumerate(dec_out)]
+        if final_activation == "Sigmoid":
+            outs = [torch.sigmoid(o) for o in outs]
+        elif final_activation is not None:
+            raise ValueError(final_activation)
+        return outs[::-1]
     if "out_conv.weight" in sd:
         x = _conv(x, sd["out_conv.weight"], sd["out_conv.bias"])
     if final_activation == "Sigmoid":

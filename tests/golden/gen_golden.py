@@ -118,6 +118,23 @@ def main():
     out["kat_ones_ones"] = np.float32(dice.DiceLoss()(ones, ones).item())    # test/loss/test_dice.py:25-31
     out["kat_ones_zeros"] = np.float32(dice.DiceLoss()(ones, zeros).item())  # test/loss/test_dice.py:33-38
     np.savez_compressed(os.path.join(OUT, "g5_dice.npz"), **out)
+
+    # G4: side outputs (UNetBase._apply_with_side_outputs): list of per-level outputs, full resolution first
+    torch.manual_seed(0)
+    model = unet.UNet3d(1, 2, depth=2, initial_features=4, return_side_outputs=True, final_activation="Sigmoid")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 1, 8, 16, 16, generator=g)
+    ys = [(torch.rand(1, 2, 8 // f, 16 // f, 16 // f, generator=g) > 0.5).float() for f in (1, 2)]
+    model.zero_grad()
+    outs = model(x)
+    val = sum(dice.DiceLoss()(o, y) for o, y in zip(outs, ys))
+    val.backward()
+    res = dict(x=x.numpy(), loss=np.float32(val.item()))
+    for i, (o, y) in enumerate(zip(outs, ys)):
+        res[f"out{i}"], res[f"y{i}"] = o.detach().numpy(), y.numpy()
+    res.update({f"sd.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()})
+    res.update({f"grad.{k}": p.grad.detach().numpy().copy() for k, p in model.named_parameters()})
+    np.savez_compressed(os.path.join(OUT, "g4_side_outputs.npz"), **res)
     print("golden vectors written to", OUT)
 
 

@@ -206,3 +206,50 @@ def test_benchmark_config_full_size_properties():
         num += float(np.sum((a - r) ** 2))
         den += float(np.sum(r ** 2))
     assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
+
+
+def test_side_outputs_golden_and_mfma_size():
+    """return_side_outputs=True: the reference's golden case (narrow net), then an MFMA-width net against the float64
+    oracle (outputs TOL; gradients: every tensor within 1e-2 and the whole gradient within 2e-3 in relative L2 -- the
+    robust criteria of _check_against_fp64, fp32 gradients of ReLU/pool nets being ill-conditioned)."""
+    from oracle import loss_ref, unet_ref
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet2d, UNet3d
+    g = np.load(os.path.join(GOLDEN, "g4_side_outputs.npz"))
+    model = UNet3d(1, 2, depth=2, initial_features=4, return_side_outputs=True, final_activation="Sigmoid")
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+    model.to(DEV)
+    outs = model(torch.from_numpy(g["x"]).to(DEV))
+    assert isinstance(outs, list) and [tuple(o.shape) for o in outs] == [(1, 2, 8, 16, 16), (1, 2, 4, 8, 8)]
+    val = sum(DiceLoss()(o, torch.from_numpy(g[f"y{i}"]).to(DEV)) for i, o in enumerate(outs))
+    val.backward()
+    assert abs(float(val) - float(g["loss"])) < TOL
+    for i, o in enumerate(outs):
+        assert rel_err(o.detach().cpu(), torch.from_numpy(g[f"out{i}"])) < TOL
+    check_grads({k: p.grad.cpu() for k, p in model.named_parameters()},
+                {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad.")}, TOL)
+    # reference test/model/test_unet.py:32-43 (shapes), at a width that takes the MFMA kernels; one output unused
+    torch.manual_seed(1)
+    net = UNet2d(1, [3, 2, 1], depth=3, initial_features=32, return_side_outputs=True).to(DEV)
+    x = torch.rand(2, 1, 64, 64)
+    outs = net(x.to(DEV))
+    assert [tuple(o.shape) for o in outs] == [(2, 1, 64, 64), (2, 2, 32, 32), (2, 3, 16, 16)]
+    (outs[0].square().mean() + 2.0 * outs[2].mean()).backward()   # outs[1] receives no gradient
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    ro = unet_ref.unet_forward(sd, x.double(), [2, 2, 2])
+    (ro[0].square().mean() + 2.0 * ro[2].mean()).backward()
+    for a, b in zip(outs, ro):
+        assert rel_err(a.detach().cpu(), b.detach().float()) < TOL
+    num = den = 0.0
+    for k, p in net.named_parameters():
+        ref = sd[k].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, k   # out_conv.1 is unused
+            continue
+        if float(ref.abs().max()) < 1e-9:
+            continue
+        e = float((p.grad.cpu().double() - ref).norm() / ref.norm())
+        assert e < 1e-2, (k, e)
+        num += float((p.grad.cpu().double() - ref).square().sum())
+        den += float(ref.square().sum())
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5

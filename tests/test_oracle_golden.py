@@ -137,3 +137,21 @@ def test_adamw_oracle_matches_torch():
         opt.step()
         p, m, v = optim_ref.adamw_step(p, g, m, v, step)
         assert rel_err(p, p_t.detach().numpy()) < 1e-6
+
+
+def test_side_outputs_golden():
+    """return_side_outputs=True (reference model/unet.py:211-228): outputs, loss and every gradient."""
+    import torch
+    from oracle import loss_ref, unet_ref
+    g = np.load(os.path.join(GOLDEN, "g4_side_outputs.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("sd.")}
+    outs = unet_ref.unet_forward(sd, torch.from_numpy(g["x"]), [2, 2], final_activation="Sigmoid")
+    assert [tuple(o.shape) for o in outs] == [(1, 2, 8, 16, 16), (1, 2, 4, 8, 8)]  # full resolution first
+    val = sum(loss_ref.dice_loss(o, torch.from_numpy(g[f"y{i}"])) for i, o in enumerate(outs))
+    val.backward()
+    assert abs(float(val) - float(g["loss"])) < 1e-6
+    for i, o in enumerate(outs):
+        assert float((o.detach() - torch.from_numpy(g[f"out{i}"])).abs().max()) < 1e-6
+    for k in g.files:
+        if k.startswith("grad."):
+            assert float((sd[k[5:]].grad - torch.from_numpy(g[k])).abs().max()) < 1e-6, k

@@ -331,11 +331,26 @@ def _forward_impl(model, x: torch.Tensor, keep: bool):
         ops.upsample_fwd(t, cat[..., :lv["c_up"]], f)  # ... interpolated straight into the concat buffer
         out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev)
         bs = _block_fwd(blk, cat, out)
-        st["dec"].append({"low": cur, "sspec": sspec, "bs": bs, "f": f})
+        st["dec"].append({"low": cur, "sspec": sspec, "bs": bs, "f": f, "out": out})
         cur = out
     st["last"] = cur
     act = fused_activation(model.final_activation) if model.final_activation is not None else None
     st["act"] = act
+    if isinstance(model.out_conv, nn.ModuleList):
+        # return_side_outputs (reference model/unet.py:211-228): a 1x1 conv (+ activation) on every decoder level
+        if act == "sigmoid" and any(c is None for c in model.out_conv):
+            raise NotImplementedError("final Sigmoid without out_conv is not supported")
+        st["side"] = []
+        for i, conv in enumerate(model.out_conv):
+            if conv is None:
+                raise NotImplementedError("side outputs without an output convolution are not supported")
+            feat = st["dec"][i]["out"]
+            ospec = ConvSpec(conv, None)
+            yi = ops.new_act(N, feat.shape[1], feat.shape[2], feat.shape[3], ospec.cout, dev)
+            _conv(ospec, feat, yi, act=act)
+            st["side"].append({"ospec": ospec, "y": yi})
+        st["y"] = st["side"][-1]["y"]
+        return [sd["y"] for sd in st["side"]][::-1], (st if keep else None)  # full resolution first
     if model.out_conv is not None:
         ospec = ConvSpec(model.out_conv, None)
         y = ops.new_act(N, cur.shape[1], cur.shape[2], cur.shape[3], ospec.cout, dev)
@@ -376,6 +391,29 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
             for lo, hi in grads.take_new_ranges():
                 sync.ready(grads.flat, lo, hi)
 
+    side = st.get("side")
+    side_g = None
+    if side is not None:
+        # gy: gradients of the side outputs, full resolution first -> decoder order (coarse .. fine)
+        side_g = list(gy)[::-1]
+        gy = side_g[-1]
+        st = dict(st, ospec=side[-1]["ospec"])
+        if gy is None:
+            gy = torch.zeros_like(_to_logical(side[-1]["y"], dim))
+
+    def side_grad(i, feat):
+        """dL/d(decoder level i output) through its side conv (ReLU-masked like every gradient of a block output)."""
+        gi = side_g[i]
+        if gi is None:
+            return None
+        gs = _from_logical(gi.float(), dim)
+        if st["act"] is not None:
+            gs = ops.act_bwd(gs, side[i]["y"], st["act"])
+        _wgrad(side[i]["ospec"], feat, gs, grads)
+        out = torch.empty_like(feat)
+        _dgrad(side[i]["ospec"], gs, out, ref=feat)
+        return out
+
     g = _from_logical(gy.float(), dim)
     y = st["y"]
     if st["act"] is not None:
@@ -399,6 +437,10 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         _wgrad(sspec, low, g_t, grads)
         g_low = torch.empty_like(low)
         _dgrad(sspec, g_t, g_low, ref=low)  # `low` is the ReLU output of the previous block
+        if side is not None and i > 0:
+            extra = side_grad(i - 1, low)  # `low` is decoder level i-1's output
+            if extra is not None:
+                g_low.add_(extra)
         lv["g_skip"] = g_cat[..., lv["c_up"]:]
         g_cur = g_low
         stage_done()
@@ -438,10 +480,13 @@ class UNetFunction(torch.autograd.Function):
         y5, st = _forward_impl(model, x, keep=need_grad)
         ctx.model, ctx.st, ctx.nparams = model, st, len(params)
         ctx.params = list(params)
+        if isinstance(y5, list):
+            return tuple(_to_logical(y, _dim_of(model)) for y in y5)
         return _to_logical(y5, _dim_of(model))
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, *gys):
+        gy = gys if len(gys) > 1 or isinstance(ctx.model.out_conv, nn.ModuleList) else gys[0]
         st = ctx.st
         if st is None:
             raise RuntimeError("UNetFunction.backward called twice (activations were released)")
@@ -466,8 +511,11 @@ def unet_forward(model, x: torch.Tensor) -> torch.Tensor:
         )
     params = [p for p in model.parameters()]
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-        return UNetFunction.apply(model, x, *params)
+        out = UNetFunction.apply(model, x, *params)
+        return list(out) if isinstance(out, tuple) else out
     y5, _ = _forward_impl(model, x, keep=False)
+    if isinstance(y5, list):
+        return [_to_logical(y, _dim_of(model)) for y in y5]
     return _to_logical(y5, _dim_of(model))
 
 

@@ -232,9 +232,13 @@ class UNetBase(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if getattr(self, "check_shape", True):
             self._check_shape(x)
-        if self.return_decoder_outputs:
-            raise NotImplementedError("return_side_outputs=True is not yet supported by the MI355X engine")
         y = engine.unet_forward(self, x)
+        if isinstance(y, list):  # return_side_outputs: per-level outputs, full resolution first (reference :211-228)
+            if self.final_activation is not None and not engine.fused_activation(self.final_activation):
+                y = [self.final_activation(yy) for yy in y]
+            if self.postprocessing is not None:
+                y = [self.postprocessing(yy) for yy in y]
+            return y
         if self.final_activation is not None and not engine.fused_activation(self.final_activation):
             y = self.final_activation(y)
         if self.postprocessing is not None:
