@@ -21,9 +21,14 @@ def _conv(x, w, b):
     return (F.conv2d if w.dim() == 4 else F.conv3d)(x, w, b, padding=pad)
 
 
-def _norm(x, norm, gamma, beta, n_groups=32):
+def _norm(x, norm, gamma, beta, n_groups=32, buffers=None, training=True):
+    """buffers = (running_mean, running_var) for the stateful norms (updated in place in training mode, like torch)."""
     if norm is None:
         return x
+    if norm == "BatchNorm":  # nn.BatchNorm3d defaults: eps 1e-5, momentum 0.1, affine
+        return F.batch_norm(x, buffers[0], buffers[1], gamma, beta, training=training, momentum=0.1, eps=1e-5)
+    if norm == "InstanceNormTrackStats":  # reference model/unet.py:398-400: affine, running stats, momentum 0.01
+        return F.instance_norm(x, buffers[0], buffers[1], gamma, beta, use_input_stats=training, momentum=0.01, eps=1e-5)
     if norm == "InstanceNorm":
         return F.instance_norm(x, eps=1e-5)
     if norm == "GroupNorm":
@@ -32,18 +37,22 @@ def _norm(x, norm, gamma, beta, n_groups=32):
     raise ValueError(norm)
 
 
-def _block(sd, prefix, x, norm):
+def _block(sd, prefix, x, norm, training=True):
     idx = (1, 4) if norm is not None else (0, 2)
     nidx = (0, 3)
+    affine = norm in ("GroupNorm", "BatchNorm", "InstanceNormTrackStats")
     for j in range(2):
-        gamma = sd.get(f"{prefix}.block.{nidx[j]}.weight") if norm == "GroupNorm" else None
-        beta = sd.get(f"{prefix}.block.{nidx[j]}.bias") if norm == "GroupNorm" else None
-        x = _norm(x, norm, gamma, beta)
+        gamma = sd.get(f"{prefix}.block.{nidx[j]}.weight") if affine else None
+        beta = sd.get(f"{prefix}.block.{nidx[j]}.bias") if affine else None
+        buffers = None
+        if norm in ("BatchNorm", "InstanceNormTrackStats"):
+            buffers = (sd[f"{prefix}.block.{nidx[j]}.running_mean"], sd[f"{prefix}.block.{nidx[j]}.running_var"])
+        x = _norm(x, norm, gamma, beta, buffers=buffers, training=training)
         x = F.relu(_conv(x, sd[f"{prefix}.block.{idx[j]}.weight"], sd[f"{prefix}.block.{idx[j]}.bias"]))
     return x
 
 
-def unet_forward(sd, x, scale_factors, norm="InstanceNorm", final_activation=None):
+def unet_forward(sd, x, scale_factors, norm="InstanceNorm", final_activation=None, training=True):
     """sd: reference-layout state_dict (tensors, may require grad); x: [N,C,*spatial];
     scale_factors: per-level pooling factor (int or list), encoder order."""
     dim = x.dim() - 2
@@ -52,11 +61,11 @@ def unet_forward(sd, x, scale_factors, norm="InstanceNorm", final_activation=Non
     mode = "bilinear" if dim == 2 else "trilinear"
     skips = []
     for l in range(depth):
-        x = _block(sd, f"encoder.blocks.{l}", x, norm)
+        x = _block(sd, f"encoder.blocks.{l}", x, norm, training)
         skips.append(x)
         f = scale_factors[l]
         x = pool(x, f if isinstance(f, int) else tuple(f))
-    x = _block(sd, "base", x, norm)
+    x = _block(sd, "base", x, norm, training)
     dec_out = []
     for i in range(depth):
         f = scale_factors[depth - 1 - i]
@@ -64,7 +73,7 @@ def unet_forward(sd, x, scale_factors, norm="InstanceNorm", final_activation=Non
                           align_corners=False)
         x = _conv(x, sd[f"decoder.samplers.{i}.conv.weight"], sd[f"decoder.samplers.{i}.conv.bias"])
         x = torch.cat([x, skips[depth - 1 - i]], dim=1)
-        x = _block(sd, f"decoder.blocks.{i}", x, norm)
+        x = _block(sd, f"decoder.blocks.{i}", x, norm, training)
         dec_out.append(x)
     if "out_conv.0.weight" in sd:
         # return_side_outputs (UNetBase._apply_with_side_outputs, :211-228): one 1x1 conv per decoder level,

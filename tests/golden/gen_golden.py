@@ -135,6 +135,30 @@ def main():
     res.update({f"sd.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()})
     res.update({f"grad.{k}": p.grad.detach().numpy().copy() for k, p in model.named_parameters()})
     np.savez_compressed(os.path.join(OUT, "g4_side_outputs.npz"), **res)
+
+    # G1c: stateful norms (BatchNorm, InstanceNormTrackStats): training step (outputs, gradients, updated running
+    # statistics), then the eval-mode forward that uses them
+    for norm in ("BatchNorm", "InstanceNormTrackStats"):
+        torch.manual_seed(0)
+        model = unet.UNet3d(1, 2, depth=2, initial_features=4, norm=norm)
+        g = torch.Generator().manual_seed(11)
+        for m in model.modules():  # non-trivial affine parameters
+            if isinstance(m, (torch.nn.modules.batchnorm._NormBase,)) and m.weight is not None:
+                m.weight.data = 1.0 + 0.3 * torch.randn(m.weight.shape, generator=g)
+                m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=g)
+        x = torch.randn(2, 1, 8, 16, 16, generator=g) * 1.5 + 0.3
+        y = (torch.rand(2, 2, 8, 16, 16, generator=g) > 0.5).float()
+        sd0 = {f"sd.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        model.train()
+        res = run_model(model, x, y, dice.DiceLoss())
+        res = {k: v for k, v in res.items() if not k.startswith("sd.")}
+        res.update(sd0)
+        res.update({f"after.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()
+                    if "running" in k or "num_batches" in k})
+        model.eval()
+        with torch.no_grad():
+            res["pred_eval"] = model(x).numpy()
+        np.savez_compressed(os.path.join(OUT, f"g1c_unet3d_{norm}.npz"), **res)
     print("golden vectors written to", OUT)
 
 

@@ -253,3 +253,36 @@ def test_side_outputs_golden_and_mfma_size():
         num += float((p.grad.cpu().double() - ref).square().sum())
         den += float(ref.square().sum())
     assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("norm", ["BatchNorm", "InstanceNormTrackStats"])
+def test_stateful_norms_golden(norm):
+    """norm="BatchNorm" / "InstanceNormTrackStats": one training step (prediction, loss, gradients, running statistics
+    after the step) and the eval-mode forward, against the reference's golden vectors."""
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    g = np.load(os.path.join(GOLDEN, f"g1c_unet3d_{norm}.npz"))
+    model = UNet3d(1, 2, depth=2, initial_features=4, norm=norm)
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+    model.to(DEV).train()
+    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    pred = model(x)
+    val = DiceLoss()(pred, y)
+    val.backward()
+    assert rel_err(pred.detach().cpu(), g["pred"]) < TOL
+    assert abs(float(val) - float(g["loss"])) < TOL
+    check_grads({k: p.grad.cpu().numpy() for k, p in model.named_parameters()},
+                {k[5:]: g[k] for k in g.files if k.startswith("grad.")}, TOL)
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("after."):
+            if "running" in k:
+                assert rel_err(sd[k[6:]].cpu(), g[k]) < 1e-5, k
+            else:
+                assert int(sd[k[6:]]) == int(g[k]), k
+    model.eval()
+    with torch.no_grad():
+        pe = model(x)
+    assert rel_err(pe.cpu(), g["pred_eval"]) < TOL
+    with pytest.raises(NotImplementedError):   # frozen statistics have no backward here
+        model(x).sum().backward()

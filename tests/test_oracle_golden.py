@@ -155,3 +155,28 @@ def test_side_outputs_golden():
     for k in g.files:
         if k.startswith("grad."):
             assert float((sd[k[5:]].grad - torch.from_numpy(g[k])).abs().max()) < 1e-6, k
+
+
+@pytest.mark.parametrize("norm", ["BatchNorm", "InstanceNormTrackStats"])
+def test_stateful_norm_golden(norm):
+    """BatchNorm / InstanceNormTrackStats (reference get_norm_layer, model/unet.py:391-406): training forward,
+    gradients, the running statistics after the step, and the eval-mode forward that uses them."""
+    from oracle import loss_ref, unet_ref
+    g = np.load(os.path.join(GOLDEN, f"g1c_unet3d_{norm}.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd.")}
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and "running" not in k:
+            v.requires_grad_(True)
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    pred = unet_ref.unet_forward(sd, x, [2, 2], norm=norm)
+    val = loss_ref.dice_loss(pred, y)
+    val.backward()
+    assert float((pred.detach() - torch.from_numpy(g["pred"])).abs().max()) < 1e-6
+    for k in g.files:
+        if k.startswith("grad."):
+            assert float((sd[k[5:]].grad - torch.from_numpy(g[k])).abs().max()) < 1e-6, k
+        if k.startswith("after.") and "running" in k:
+            assert float((sd[k[6:]] - torch.from_numpy(g[k])).abs().max()) < 1e-6, k
+    with torch.no_grad():
+        pe = unet_ref.unet_forward(sd, x, [2, 2], norm=norm, training=False)
+    assert float((pe - torch.from_numpy(g["pred_eval"])).abs().max()) < 1e-6

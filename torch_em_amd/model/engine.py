@@ -224,12 +224,57 @@ def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None):
     ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
 
 
+def _is_batchnorm(n) -> bool:
+    return isinstance(n, nn.modules.batchnorm._BatchNorm)
+
+
+def _flat_batch(t):
+    """[N, D, H, W, C(ld)] -> [1, N*D, H, W, C] view: BatchNorm statistics run over the batch and the volume."""
+    N, D, H, W, C = t.shape
+    return t.as_strided((1, N * D, H, W, C), (N * D * t.stride(1), t.stride(1), t.stride(2), t.stride(3), t.stride(4)))
+
+
+def _update_running(n, mean, var_biased, count):
+    """running statistics of BatchNorm / InstanceNorm(track_running_stats=True), torch semantics: unbiased variance,
+    momentum None = cumulative average.  mean / var: [rows, C], averaged over rows (instances)."""
+    with torch.no_grad():
+        if _is_batchnorm(n):  # nn.InstanceNorm never touches the counter (torch/nn/modules/instancenorm.py)
+            n.num_batches_tracked += 1
+        m = n.momentum if n.momentum is not None else 1.0 / float(n.num_batches_tracked)
+        unbiased = var_biased * (count / max(count - 1, 1))
+        n.running_mean.mul_(1.0 - m).add_(mean.mean(0), alpha=m)
+        n.running_var.mul_(1.0 - m).add_(unbiased.mean(0), alpha=m)
+
+
 def _stats(spec: ConvSpec, x):
+    """Statistics of the norm in front of a conv -> (mean, rstd, scale[N,C], shift[N,C], mode).
+    mode "sample": InstanceNorm / GroupNorm per sample; "batch": BatchNorm in training mode (reference
+    `get_norm_layer`, model/unet.py:391-406); "frozen": a norm with running statistics in eval mode."""
     na = spec.norm_args()
     if na is None:
         return None
     groups, gamma, beta, eps = na
-    return ops.norm_stats(x, groups, gamma, beta, eps)
+    n = spec.norm
+    N = x.shape[0]
+    tracked = getattr(n, "track_running_stats", False) and getattr(n, "running_mean", None) is not None
+    if tracked and not n.training:
+        scale = torch.rsqrt(n.running_var.float() + eps)
+        if gamma is not None:
+            scale = scale * gamma.detach().float()
+        shift = -n.running_mean.float() * scale
+        if beta is not None:
+            shift = shift + beta.detach().float()
+        return None, None, scale.expand(N, -1).contiguous(), shift.expand(N, -1).contiguous(), "frozen"
+    if _is_batchnorm(n):
+        xb = _flat_batch(x)
+        mean, rstd, scale, shift = ops.norm_stats(xb, groups, gamma, beta, eps)
+        if tracked:
+            _update_running(n, mean, 1.0 / (rstd * rstd) - eps, xb.shape[1] * xb.shape[2] * xb.shape[3])
+        return mean, rstd, scale.expand(N, -1).contiguous(), shift.expand(N, -1).contiguous(), "batch"
+    mean, rstd, scale, shift = ops.norm_stats(x, groups, gamma, beta, eps)
+    if tracked:  # InstanceNormTrackStats: per-instance statistics, running averages of their batch means
+        _update_running(n, mean, 1.0 / (rstd * rstd) - eps, x.shape[1] * x.shape[2] * x.shape[3])
+    return mean, rstd, scale, shift, "sample"
 
 
 def _block_fwd(blk, xin, out):
@@ -248,6 +293,14 @@ def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads):
     groups, gamma, beta, _ = spec.norm_args()
     dgamma = grads.view(gamma) if gamma is not None else None
     dbeta = grads.view(beta) if beta is not None else None
+    mode = stats[4]
+    if mode == "frozen":
+        raise NotImplementedError("backward through a norm with frozen running statistics (model.eval()) is not "
+                                  "supported; call model.train() for training")
+    if mode == "batch":
+        gb = _flat_batch(g)
+        ops.norm_bwd(gb, _flat_batch(x), groups, gamma, stats[0], stats[1], relu_mask, gb, dgamma, dbeta)
+        return
     ops.norm_bwd(g, x, groups, gamma, stats[0], stats[1], relu_mask, g, dgamma, dbeta)
 
 

@@ -31,11 +31,11 @@ def get_norm_layer(norm, dim, channels, n_groups=32):
         return nn.InstanceNorm2d(channels) if dim == 2 else nn.InstanceNorm3d(channels)
     if norm == "GroupNorm":
         return nn.GroupNorm(min(n_groups, channels), channels)
-    if norm in ("InstanceNormTrackStats", "BatchNorm"):
-        raise NotImplementedError(
-            f"norm='{norm}' keeps running statistics across batches; the MI355X path implements the "
-            "stateless norms 'InstanceNorm' (reference default), 'GroupNorm' and None"
-        )
+    if norm == "InstanceNormTrackStats":
+        kwargs = {"affine": True, "track_running_stats": True, "momentum": 0.01}
+        return nn.InstanceNorm2d(channels, **kwargs) if dim == 2 else nn.InstanceNorm3d(channels, **kwargs)
+    if norm == "BatchNorm":
+        return nn.BatchNorm2d(channels) if dim == 2 else nn.BatchNorm3d(channels)
     raise ValueError(f"Invalid norm: expect one of 'InstanceNorm', 'BatchNorm' or 'GroupNorm', got {norm}")
 
 
@@ -65,7 +65,7 @@ class ConvBlock(nn.Module):
         mods = list(self.block)
         specs, pending_norm = [], None
         for m in mods:
-            if isinstance(m, (nn.GroupNorm, nn.InstanceNorm2d, nn.InstanceNorm3d)):
+            if isinstance(m, (nn.GroupNorm, nn.InstanceNorm2d, nn.InstanceNorm3d, nn.BatchNorm2d, nn.BatchNorm3d)):
                 pending_norm = m
             elif isinstance(m, (nn.Conv2d, nn.Conv3d)):
                 specs.append(engine.ConvSpec(m, pending_norm))
