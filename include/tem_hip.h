@@ -311,6 +311,11 @@ int tem_block_store_inner(const float* pred, const int* pred_shape, float* out, 
                           const unsigned char* mask, const int* inner_start, const int* out_start, const int* size,
                           tem_stream_t stream);
 
+/* AccumulateChannels (model/unet.py:15-44, export-time post-processing): out [N][(i1-i0)+1][V] contiguous =
+ * cat(x[:, i0:i1], reduce(x[:, c0:c1])), mode 0 mean / 1 min / 2 max; x element (n,c,v) at n*sn + c*sc + v*sv. */
+int tem_accumulate_channels(const float* x, int64_t sn, int64_t sc, int64_t sv, float* out, int N, int C, int64_t V,
+                            int i0, int i1, int c0, int c1, int mode, tem_stream_t stream);
+
 /* ---- small utilities ---------------------------------------------------------- */
 /* NCDHW (contiguous) <-> NDHWC(ld) layout change at the module boundary. */
 int tem_nchw_to_nhwc(const float* src, float* dst, int64_t dst_ld, int N, int C, int64_t V, tem_stream_t stream);

@@ -286,3 +286,29 @@ def test_stateful_norms_golden(norm):
     assert rel_err(pe.cpu(), g["pred_eval"]) < TOL
     with pytest.raises(NotImplementedError):   # frozen statistics have no backward here
         model(x).sum().backward()
+
+
+def test_postprocessing_accumulate_channels():
+    """`postprocessing="affinities_with_foreground_to_boundaries3d"` etc. (reference model/unet.py:15-95)."""
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.model.unet import POSTPROCESSING, AccumulateChannels
+    torch.manual_seed(0)
+    x = torch.randn(2, 5, 4, 6, 8)
+    for inv, acc, mode in [((0, 1), (1, 4), "max"), (None, (0, 3), "max"), ((1, 3), (0, 5), "mean"), (None, (2, 4), "min")]:
+        want = getattr(torch, mode)(x[:, acc[0]:acc[1]], dim=1, keepdim=True)
+        want = want if torch.is_tensor(want) else want.values
+        if inv is not None:
+            want = torch.cat([x[:, inv[0]:inv[1]], want], dim=1)
+        for xin in (x.to(DEV), x.to(DEV).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)):  # NCDHW, channels-last
+            got = AccumulateChannels(inv, acc, mode)(xin)
+            assert got.shape == want.shape and rel_err(got.cpu(), want) < 1e-6
+    assert sorted(POSTPROCESSING) == sorted(["affinities_to_boundaries_anisotropic", "affinities_to_boundaries2d",
+                                             "affinities_with_foreground_to_boundaries2d", "affinities_to_boundaries3d",
+                                             "affinities_with_foreground_to_boundaries3d"])
+    net = UNet3d(1, 4, depth=1, initial_features=4, final_activation="Sigmoid",
+                 postprocessing="affinities_with_foreground_to_boundaries3d").to(DEV).eval()
+    with torch.no_grad():
+        out = net(torch.randn(1, 1, 8, 8, 8, device=DEV))
+    assert out.shape == (1, 2, 8, 8, 8)
+    with pytest.raises(ValueError):
+        UNet3d(1, 4, depth=1, initial_features=4, postprocessing="nope")

@@ -80,6 +80,7 @@ SIGNATURES = {
     "tem_block_load_reflect": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int] + [ctypes.POINTER(c_int)] * 4 + [c_vp]),
     "tem_block_store_inner": (c_int, [c_vp, ctypes.POINTER(c_int), c_vp, c_int, c_int, c_int, c_int, c_vp]
                               + [ctypes.POINTER(c_int)] * 3 + [c_vp]),
+    "tem_accumulate_channels": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_i64] + [c_int] * 5 + [c_vp]),
     "tem_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
 }
 

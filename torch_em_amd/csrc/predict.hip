@@ -95,3 +95,36 @@ extern "C" int tem_block_store_inner(const float* pred, const int* pred_shape, f
     TEM_CHECK_LAUNCH("tem_block_store_inner");
     return TEM_OK;
 }
+
+// AccumulateChannels (reference model/unet.py:15-44): out = cat([x[:, i0:i1], reduce(x[:, c0:c1], dim=1)]) with reduce in
+// {mean 0, min 1, max 2}; export-time post-processing of affinity predictions.  x read through (sn, sc, sv) strides.
+__global__ __launch_bounds__(256) void k_accumulate_channels(const float* __restrict__ x, int64_t sn, int64_t sc, int64_t sv,
+                                                             float* __restrict__ out, int N, int64_t V, int i0, int i1,
+                                                             int c0, int c1, int mode) {
+    const int ninv = i1 - i0, cout = ninv + 1;
+    const int64_t total = (int64_t)N * V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / V);
+        const int64_t v = i % V;
+        const float* p = x + n * sn + v * sv;
+        for (int c = 0; c < ninv; ++c) out[((int64_t)n * cout + c) * V + v] = p[(int64_t)(i0 + c) * sc];
+        float acc = p[(int64_t)c0 * sc];
+        for (int c = c0 + 1; c < c1; ++c) {
+            const float t = p[(int64_t)c * sc];
+            acc = mode == 0 ? acc + t : (mode == 1 ? fminf(acc, t) : fmaxf(acc, t));
+        }
+        if (mode == 0) acc /= (float)(c1 - c0);
+        out[((int64_t)n * cout + ninv) * V + v] = acc;
+    }
+}
+
+extern "C" int tem_accumulate_channels(const float* x, int64_t sn, int64_t sc, int64_t sv, float* out, int N, int C,
+                                       int64_t V, int i0, int i1, int c0, int c1, int mode, tem_stream_t stream) {
+    TEM_REQUIRE(x && out && N > 0 && V > 0, "tem_accumulate_channels: bad arguments");
+    TEM_REQUIRE(0 <= i0 && i0 <= i1 && i1 <= C && 0 <= c0 && c0 < c1 && c1 <= C && mode >= 0 && mode <= 2,
+                "tem_accumulate_channels: bad channel ranges");
+    hipLaunchKernelGGL(k_accumulate_channels, dim3(tem_grid_1d((int64_t)N * V, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       sn, sc, sv, out, N, V, i0, i1, c0, c1, mode);
+    TEM_CHECK_LAUNCH("tem_accumulate_channels");
+    return TEM_OK;
+}

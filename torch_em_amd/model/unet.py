@@ -39,6 +39,49 @@ def get_norm_layer(norm, dim, channels, n_groups=32):
     raise ValueError(f"Invalid norm: expect one of 'InstanceNorm', 'BatchNorm' or 'GroupNorm', got {norm}")
 
 
+class AccumulateChannels(nn.Module):
+    """cat([x[:, i0:i1], reduce(x[:, c0:c1], dim=1)]) -- export-time post-processing of affinity predictions
+    (reference model/unet.py:15-44); one HIP pass over the (channels-last) prediction, inference only."""
+
+    def __init__(self, invariant_channels, accumulate_channels, accumulator):
+        super().__init__()
+        self.invariant_channels = invariant_channels
+        self.accumulate_channels = accumulate_channels
+        assert accumulator in ("mean", "min", "max")
+        self.accumulator = accumulator
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("torch_em_amd.model.AccumulateChannels runs on MI355X only; there is no CPU fallback")
+        if x.requires_grad:
+            raise NotImplementedError("AccumulateChannels is export-time post-processing (no backward)")
+        from .. import _lib, ops
+        x = x.float()
+        N, C = x.shape[:2]
+        V = x[0, 0].numel()
+        nst = ops._ncv_strides(x)
+        if nst is None:
+            x = x.contiguous()
+            nst = ops._ncv_strides(x)
+        sv = nst[2]
+        i0, i1 = (0, 0) if self.invariant_channels is None else self.invariant_channels
+        c0, c1 = self.accumulate_channels
+        out = torch.empty((N, i1 - i0 + 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().tem_accumulate_channels(
+            ops._p(x), x.stride(0), x.stride(1), sv, ops._p(out), N, C, V, i0, i1, c0, c1,
+            {"mean": 0, "min": 1, "max": 2}[self.accumulator], ops._stream(x)), "tem_accumulate_channels")
+        return out
+
+
+POSTPROCESSING = {
+    "affinities_to_boundaries_anisotropic": lambda: AccumulateChannels(None, (1, 3), "max"),
+    "affinities_to_boundaries2d": lambda: AccumulateChannels(None, (0, 2), "max"),
+    "affinities_with_foreground_to_boundaries2d": lambda: AccumulateChannels((0, 1), (1, 3), "max"),
+    "affinities_to_boundaries3d": lambda: AccumulateChannels(None, (0, 3), "max"),
+    "affinities_with_foreground_to_boundaries3d": lambda: AccumulateChannels((0, 1), (1, 4), "max"),
+}
+
+
 class ConvBlock(nn.Module):
     """[norm -> conv -> ReLU] x 2; `block` indices match the reference (0/3 norms, 1/4 convs)."""
 
@@ -212,6 +255,8 @@ class UNetBase(nn.Module):
             return None
         if isinstance(postprocessing, nn.Module):
             return postprocessing
+        if postprocessing in POSTPROCESSING:
+            return POSTPROCESSING[postprocessing]()
         raise ValueError(f"Invalid postprocessing: {postprocessing}")
 
     def load_encoder_state(self, state):
