@@ -216,12 +216,45 @@ class _Grads:
         return [tuple(r) for r in out]
 
 
+# Weight gradients are leaves of the backward pass (nothing downstream in it reads dw), so they CAN run on a second HIP
+# stream next to the dgrad / norm / pool kernels of the main stream.  Measured (scripts/ab_bench.sh TEM_OVERLAP_WGRAD):
+# +1.3 ms/step when every layer overlaps (the wgrad and dgrad workgroups cannot co-reside: 101 KB + 2 x 67 KB of LDS),
+# +-0 within noise when only the <= 32^3 levels overlap -- off by default.
+_OVERLAP_WGRAD = os.environ.get("TEM_OVERLAP_WGRAD", "0") != "0"
+_OVERLAP_MAX_VOXELS = int(os.environ.get("TEM_OVERLAP_MAX_VOXELS", str(2 * 32 ** 3)))
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _join_side(device):
+    """main stream waits for every weight gradient launched so far"""
+    if _OVERLAP_WGRAD and (device.index if device.index is not None else torch.cuda.current_device()) in _SIDE_STREAMS:
+        torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+
+
 def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None):
     ent = spec.packed()
     scale, shift = (stats[2], stats[3]) if stats is not None else (None, None)
     dw = grads.view(spec.conv.weight)
     db = grads.view(spec.conv.bias) if spec.conv.bias is not None else None
-    ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
+    vox = x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3]
+    if not _OVERLAP_WGRAD or vox > _OVERLAP_MAX_VOXELS:  # big layers fill the chip alone: concurrency only adds contention
+        ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
+        return
+    side = _side_stream(x.device)
+    side.wait_stream(torch.cuda.current_stream(x.device))  # x, g, scale/shift were produced on the main stream
+    with torch.cuda.stream(side):
+        ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
+    for t in (x, g, scale, shift):  # the caching allocator must not recycle them while the side stream reads
+        if t is not None:
+            t.record_stream(side)
 
 
 def _is_batchnorm(n) -> bool:
@@ -437,10 +470,12 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
     dim = st["dim"]
     depth = len(st["levels"])
     grads = _Grads(params)
+    gy_dev = params[0].device if params else (gy[0] if isinstance(gy, (list, tuple)) else gy).device
     sync = getattr(model, "_tem_grad_sync", None)  # data-parallel gradient exchange (multi_gpu_training.DDP)
 
     def stage_done():
         if sync is not None:
+            _join_side(gy_dev)  # the weight gradients of this stage run on the side stream
             for lo, hi in grads.take_new_ranges():
                 sync.ready(grads.flat, lo, hi)
 
@@ -514,6 +549,7 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         _block_bwd(lv["bs"], g_skip_full, g_in, grads)
         g_cur = g_in
         stage_done()
+    _join_side(gy_dev)  # the optimizer (main stream) reads every weight gradient
     if sync is not None:
         sync.finish(grads.flat)
     gx = None

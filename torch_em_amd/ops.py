@@ -187,8 +187,10 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """A per-device scratch buffer (grown on demand, reused across calls on the same stream)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """A per-(device, stream) scratch buffer (grown on demand, reused across calls on the same stream; kernels of
+    different streams may run concurrently, so they never share one)."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
