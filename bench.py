@@ -153,12 +153,38 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    # Live HIP-event timing costs host time and GPU bubbles (two events per launch, ~200 per step: 3.5-6 ms/step), so
+    # every conv launch is instrumented in ONE untimed step (the last warm-up step, or an extra one if --warmup 0) to
+    # build the kernel table and find the dominant kernel; inside the timed region only that kernel carries events.
+    noprof = os.environ.get("TEM_BENCH_NOPROF", "0") == "1"
+    # A freshly booted box runs its first seconds of GPU work ~9 % slower (clock / power-state ramp: three consecutive
+    # bench.py processes on one fresh box measured 31.9, 29.3, 28.5 ms/step).  Inference-only forward passes for a
+    # fixed wall-clock budget bring the GPU to its steady state; they are NOT training steps and are not counted in
+    # --warmup / --steps.
+    prewarm_s = float(os.environ.get("TEM_BENCH_PREWARM_S", "3"))
+    if prewarm_s > 0:
+        tw = time.perf_counter()
+        with torch.no_grad():
+            while time.perf_counter() - tw < prewarm_s:
+                net(x)
+                torch.cuda.synchronize()
+    for _ in range(max(args.warmup - 1, 0)):
         step()
+    ops.PROFILER = [] if (rank == 0 and not noprof) else None
+    step()
+    torch.cuda.synchronize()
+    table_prof, ops.PROFILER = ops.PROFILER or [], None
+    dom_tag = None
+    if table_prof:
+        per_tag = {}
+        for (tag, _shape), _fl, e0, e1 in table_prof:
+            per_tag[tag] = per_tag.get(tag, 0.0) + e0.elapsed_time(e1)
+        dom_tag = max(per_tag.items(), key=lambda kv: kv[1])[0]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.PROFILER = [] if rank == 0 else None
+    if rank == 0 and dom_tag is not None:
+        ops.PROFILER, ops.PROFILER_FILTER = [], {dom_tag}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -167,7 +193,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof, ops.PROFILER = ops.PROFILER, None
+    dom_prof, ops.PROFILER, ops.PROFILER_FILTER = ops.PROFILER or [], None, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -180,7 +206,7 @@ def main():
         value = world * voxels * args.steps / elapsed
         # ---- per-kernel table from the live HIP events ----
         table, detail = {}, {}
-        for (tag, shape), flops, e0, e1 in prof:
+        for (tag, shape), flops, e0, e1 in table_prof:
             dt = e0.elapsed_time(e1)
             for tab, key in ((table, tag), (detail, (tag, shape))):
                 d = tab.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0})
@@ -191,9 +217,9 @@ def main():
         lines = [f"{'kernel':58s} {'launches':>8s} {'avg_ms':>9s} {'total_ms/step':>13s} {'TFLOP/s':>9s}"]
         for tag, d in rows:
             lines.append(f"{tag:58s} {d['launches']:8d} {d['ms'] / d['launches']:9.4f} "
-                         f"{d['ms'] / args.steps:13.3f} {d['flops'] / d['ms'] / 1e9:9.2f}")
-        conv_ms = sum(d["ms"] for d in table.values()) / args.steps
-        lines.append(f"conv kernels {conv_ms:.2f} ms/step of {ms:.2f} ms/step")
+                         f"{d['ms']:13.3f} {d['flops'] / d['ms'] / 1e9:9.2f}")
+        conv_ms = sum(d["ms"] for d in table.values())
+        lines.append(f"conv kernels {conv_ms:.2f} ms in the instrumented warm-up step; timed region {ms:.2f} ms/step")
         lines.append("")
         lines.append(f"{'kernel / layer (NxDxHxW cin->cout)':78s} {'launches':>8s} {'avg_ms':>9s} {'TFLOP/s':>9s}")
         for (tag, shape), d in sorted(detail.items(), key=lambda kv: -kv[1]["ms"]):
@@ -203,7 +229,15 @@ def main():
         if args.kernel_table:
             with open(args.kernel_table, "w") as f:
                 f.write("\n".join(lines) + "\n")
-        dom_tag, dom = rows[0]
+        if not rows:  # TEM_BENCH_NOPROF=1 (A/B of the live-event overhead): no kernel table, no roofline
+            os.write(real_stdout, (json.dumps({"ms_per_step": ms, "value": value, "note": "live profiling disabled"}) + "\n").encode())
+            return
+        # the dominant kernel, timed live over the timed region (HIP events on its launch stream)
+        dom = {"launches": 0, "ms": 0.0, "flops": 0.0}
+        for (_tag, _shape), flops, e0, e1 in dom_prof:
+            dom["launches"] += 1
+            dom["ms"] += e0.elapsed_time(e1)
+            dom["flops"] += flops
         achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s (algorithmic: 2*MACs of the convolution)
         split = 6 if "bf16x6" in dom_tag else (3 if ("bf16x3" in dom_tag or "f16x3" in dom_tag) else 0)
         # split-bf16 kernels execute 3 (or 6) bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3 (6)

@@ -18,10 +18,26 @@ ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2}
 # Optional live kernel timing (bench.py): a list that receives (tag, flops, start_event, end_event)
 # for every convolution launch; events are recorded on the stream the kernel is launched on.
 PROFILER = None
+# When set, only launches whose kernel tag is in this set are timed: two HIP events per launch are not free (a
+# fully instrumented cfg-2 step has ~200 of them and runs 3.5-6 ms slower), so bench.py instruments everything in a
+# warm-up step and only the dominant kernel inside the timed region.
+PROFILER_FILTER = None
 
 
-def _prof_begin(t):
-    if PROFILER is None:
+def _fwd_tag(mfma, k, cout):
+    kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3"}.get(int(mfma)) or
+            ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu")) + f"<{k[0]},{k[1]},{k[2]}"
+    return kind + (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
+
+
+def _wgrad_tag(mfma, k, cout):
+    ntaps = k[0] * k[1] * k[2]
+    return ("k_conv_wgrad_bf16x3" if int(mfma) == 2 else "k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + \
+        f"<{k[0]},{k[1]},{k[2]}" + (f",NCO={2 if cout >= 64 else 1}" if int(mfma) == 2 and ntaps > 1 else "") + ">(+reduce)"
+
+
+def _prof_begin(t, tag=None):
+    if PROFILER is None or (PROFILER_FILTER is not None and tag not in PROFILER_FILTER):
         return None
     ev = torch.cuda.Event(enable_timing=True)
     ev.record(torch.cuda.current_stream(t.device))
@@ -170,15 +186,12 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     lib = _lib.load()
     nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 1) if mfma else 0
     ws = _workspace(nws, x.device) if nws else None
-    ev0 = _prof_begin(x)
+    kind = _fwd_tag(mfma, k, cout) if PROFILER is not None else None
+    ev0 = _prof_begin(x, kind)
     _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
                                   ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma),
                                   _stream(x)), "tem_conv3d_fwd")
     if ev0 is not None:
-        kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3"}.get(int(mfma)) or
-                ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu")) + \
-            f"<{k[0]},{k[1]},{k[2]}"
-        kind += (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return y
 
@@ -209,14 +222,12 @@ def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, 
     nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma))
     ntaps = k[0] * k[1] * k[2]
     ws = _workspace(nws, x.device)
-    ev0 = _prof_begin(x)
+    kind = _wgrad_tag(mfma, k, cout) if PROFILER is not None else None
+    ev0 = _prof_begin(x, kind)
     _lib.check(lib.tem_conv3d_wgrad(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(dw_out), _p(db_out), _p(ws), nws,
                                     N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma), 1, _stream(x)),
                "tem_conv3d_wgrad")
     if ev0 is not None:
-        kind = ("k_conv_wgrad_bf16x3" if int(mfma) == 2 else "k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + \
-            f"<{k[0]},{k[1]},{k[2]}" + (f",NCO={2 if cout >= 64 else 1}" if int(mfma) == 2 and ntaps > 1 else "") + \
-            ">(+reduce)"
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return dw_out
 
