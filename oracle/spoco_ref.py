@@ -210,3 +210,15 @@ def spoco_forward(emb_q, emb_k, target, delta_var, delta_dist, alpha=1.0, beta=1
         loss = loss + consistency_term_weight * consistency_term(emb_q[b], emb_k[b], mask, ts, max_anchors,
                                                                  volume_threshold, a)
     return loss
+
+
+def contrastive_loss(emb, target, delta_var, delta_dist, alpha=1.0, beta=1.0, gamma=0.001):
+    """ContrastiveLoss.forward with the scatter implementation (loss/contrastive.py:121-169): every sample counts."""
+    total = 0.0
+    for b in range(emb.shape[0]):
+        e, t = emb[b], target[b, 0]
+        ids, sizes = torch.unique(t, return_counts=True)
+        means = cluster_means(e, t, ids.shape[0])
+        total = total + alpha * variance_term(means, e, t, sizes, delta_var, False) \
+            + beta * distance_term(means, delta_dist, False) + gamma * regularizer_term(means)
+    return total / emb.shape[0]

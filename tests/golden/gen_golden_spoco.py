@@ -120,5 +120,30 @@ def main():
          (2, 4, 6, 16, 16), 4, 16, True)
 
 
+def contrastive_cases():
+    """ContrastiveLoss (loss/contrastive.py): both reference implementations must agree; store the expand result."""
+    spec = importlib.util.spec_from_file_location("torch_em.loss.contrastive", os.path.join(REF, "loss/contrastive.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["torch_em.loss.contrastive"] = mod
+    spec.loader.exec_module(mod)
+    for name, shape, n_ids, seed in (("g6g_contrastive_2d", (3, 6, 24, 20), 6, 21), ("g6h_contrastive_3d", (2, 8, 8, 16, 16), 5, 22)):
+        g = torch.Generator().manual_seed(seed)
+        emb = (torch.randn(shape, generator=g) * 1.5).requires_grad_(True)
+        tgt = labels((shape[0], 1) + tuple(shape[2:]), n_ids, seed + 1)
+        vals = {}
+        for impl in ("expand", "scatter"):
+            emb.grad = None
+            val = mod.ContrastiveLoss(delta_var=0.5, delta_dist=1.5, alpha=1.0, beta=0.7, gamma=0.01, impl=impl)(emb, tgt)
+            val.sum().backward()
+            vals[impl] = (val.detach().numpy().reshape(-1), emb.grad.numpy().copy())
+        assert np.allclose(vals["expand"][0], vals["scatter"][0], rtol=1e-5), (vals["expand"][0], vals["scatter"][0])
+        assert np.allclose(vals["expand"][1], vals["scatter"][1], rtol=1e-3, atol=1e-7)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), emb=emb.detach().numpy(), target=tgt.numpy(),
+                            loss=vals["scatter"][0], grad=vals["scatter"][1])
+        print(name, vals["scatter"][0])
+
+
 if __name__ == "__main__":
+    load_reference()
+    contrastive_cases()
     main()

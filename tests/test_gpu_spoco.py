@@ -176,3 +176,19 @@ def test_consistency_loss_module():
     got.backward()
     np.testing.assert_allclose(got.item(), want.item(), rtol=2e-5)
     assert _rel(qg.grad.cpu().numpy(), qd.grad.numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("name", ["g6g_contrastive_2d", "g6h_contrastive_3d"])
+def test_contrastive_loss_golden(name):
+    """ContrastiveLoss (reference loss/contrastive.py; both of its implementations agree on these vectors)."""
+    from torch_em_amd.loss import ContrastiveLoss
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    emb = torch.from_numpy(g["emb"]).cuda().requires_grad_(True)
+    for impl in (None, "scatter", "expand"):
+        emb.grad = None
+        val = ContrastiveLoss(delta_var=0.5, delta_dist=1.5, alpha=1.0, beta=0.7, gamma=0.01, impl=impl)(
+            emb, torch.from_numpy(g["target"]).cuda())
+        val.sum().backward()
+        np.testing.assert_allclose(val.detach().cpu().numpy().reshape(-1), g["loss"], rtol=2e-5)
+        assert _rel(emb.grad.cpu().numpy(), g["grad"]) < 1e-4
+    assert float(emb.grad[0].abs().max()) > 0  # every sample contributes (unlike the SPOCO base class)

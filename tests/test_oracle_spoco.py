@@ -61,3 +61,13 @@ def test_draw_order_matches_reference():
     val = spoco_ref.spoco_forward(q, torch.from_numpy(g["emb_k"]), torch.from_numpy(g["target"]), anchors=anchors,
                                   offsets=offsets, **kw)
     np.testing.assert_allclose(val.numpy(), g["loss"], rtol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["g6g_contrastive_2d", "g6h_contrastive_3d"])
+def test_contrastive_oracle_matches_reference(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    emb = torch.from_numpy(g["emb"]).requires_grad_(True)
+    val = spoco_ref.contrastive_loss(emb, torch.from_numpy(g["target"]), 0.5, 1.5, 1.0, 0.7, 0.01)
+    val.sum().backward()
+    np.testing.assert_allclose(val.detach().numpy().reshape(-1), g["loss"], rtol=2e-6)
+    assert np.linalg.norm(emb.grad.numpy() - g["grad"]) / np.linalg.norm(g["grad"]) < 2e-6

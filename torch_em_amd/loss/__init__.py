@@ -4,3 +4,4 @@ from .wrapper import ApplyAndRemoveMask, ApplyMask, LossWrapper, MaskIgnoreLabel
 from .affinity_side_loss import AffinitySideLoss
 from .spoco_loss import (ExtendedContrastiveLoss, GaussianKernel, SPOCOConsistencyLoss, SPOCOLoss,
                          compute_cluster_means)
+from .contrastive import ContrastiveLoss
