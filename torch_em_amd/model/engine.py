@@ -147,14 +147,16 @@ def _repack_stale():
         ent["version"] = w._version
     for ent, key, w, transpose, mode in rest:
         ent[key] = ops.pack_weights(w, transpose=transpose, mfma=mode)
-    if jobs:
-        sig = tuple((j[0].data_ptr(), j[1].data_ptr()) for j in jobs)
-        tab = _PACK_TABLES.get(sig)
-        if tab is None:
-            _PACK_TABLES.clear()
-            tab = ops.pack_table(jobs)
-            _PACK_TABLES[sig] = tab
-        ops.pack_weights_batch(tab)
+    by_dev = {}
+    for j in jobs:  # one table / launch per device (a process normally drives one GPU)
+        by_dev.setdefault(j[0].device, []).append(j)
+    for dev, dj in by_dev.items():
+        sig = tuple((j[0].data_ptr(), j[1].data_ptr()) for j in dj)
+        ent = _PACK_TABLES.get(dev)
+        if ent is None or ent[0] != sig:
+            ent = _PACK_TABLES[dev] = (sig, ops.pack_table(dj))
+        with torch.cuda.device(dev):
+            ops.pack_weights_batch(ent[1])
 
 
 def fused_activation(act: nn.Module) -> Optional[str]:
