@@ -33,10 +33,10 @@ STEP_GB = 25.58                 # conv-centric fp32 traffic of c
 
 # live-event tags -> kernel names as rocprofv3 prints them (dominant template instantiation of each tag)
 RP_NAMES = {
-    "k_conv_fwd_bf16x6<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 3>",
-    "k_conv_fwd_bf16x6<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 3>",
-    "k_conv_fwd_bf16x3<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 2>",
-    "k_conv_fwd_bf16x3<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 2>",
+    "k_conv_fwd_bf16x6<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 3, false>",
+    "k_conv_fwd_bf16x6<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 3, false>",
+    "k_conv_fwd_bf16x3<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 2, false>",
+    "k_conv_fwd_bf16x3<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 2, false>",
     "k_conv_fwd_f16x3<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 2, true>",
     "k_conv_fwd_f16x3<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 2, true>",
     "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_zs<2>",

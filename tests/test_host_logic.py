@@ -140,3 +140,18 @@ def test_prediction_blocking_matches_oracle_and_has_no_cpu_path():
         predict_with_halo(np.zeros((8, 8, 8), "float32"), model, ["cpu"], (8, 8, 8), (0, 0, 0))
     with pytest.raises(NotImplementedError):
         predict_with_halo(np.zeros((8, 8, 8), "float32"), model, [0, 1], (8, 8, 8), (0, 0, 0))
+
+
+def test_bench_kernel_names_match_committed_profiles():
+    """bench.py maps its live-event tags to rocprofv3 kernel names to look up the measured HBM traffic of the dominant
+    kernel in profiles/; a template-parameter change silently turned that into null once."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    traffic = json.load(open(os.path.join(root, "profiles", "r01_traffic_bytes_per_launch.json")))
+    for tag in ("k_conv_fwd_bf16x6<3,3,3,NR=1>", "k_conv_fwd_bf16x6<3,3,3,NR=2>", "k_conv_fwd_bf16x3<3,3,3,NR=2>",
+                "k_conv_wgrad_bf16x3<3,3,3,NCO=1>", "k_conv_wgrad_bf16x3<3,3,3,NCO=2>"):
+        assert mod.RP_NAMES[tag] in traffic, (tag, mod.RP_NAMES[tag])
