@@ -57,7 +57,8 @@ PRECISION_DTYPE = {
 
 
 def cpu_baseline(max_threads):
-    """Oracle fwd+bwd on the host cores; bounded sample: the benchmark model on 1x1x64^3.
+    """Oracle fwd+bwd on the host cores; bounded sample (10-20 s of CPU work): the benchmark model on ONE 1x128^3
+    volume, i.e. half of a cfg-2 batch at the real patch size (same cache behaviour per layer as the full batch).
     torch's CPU backend does not scale to every hardware thread of a large host (on the 2x64-core
     EPYC box 16 threads beat 64 by 3x and 256 by 600x), so the thread count is picked by a quick
     probe on a 32^3 input and the winner is what `cores` reports."""
@@ -78,18 +79,19 @@ def cpu_baseline(max_threads):
         if best_t is None or dt < best_t:
             best_t, threads = dt, th
     torch.set_num_threads(threads)
-    x = torch.randn(1, 1, 64, 64, 64, generator=g)
-    y = (torch.rand(1, 2, 64, 64, 64, generator=g) > 0.5).float()
+    x = torch.randn(1, 1, 128, 128, 128, generator=g)
+    y = (torch.rand(1, 2, 128, 128, 128, generator=g) > 0.5).float()
     times = []
     for i in range(3):
         t0 = time.perf_counter()
         unet_ref.unet_loss_and_grads(sd, x, y, [2, 2, 2, 2])
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
-    return {"value": 64 ** 3 / best, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": "oracle (torch-CPU fp32 restatement) fwd+DiceLoss+bwd of the same UNet3d on 1x1x64^3 "
-                      f"(1/16 of one cfg-2 batch), best of 2 after 1 warm-up: {best:.3f} s/step; thread count chosen "
-                      f"by a 32^3 probe over 8/16/32/64 of {max_threads} hardware threads"}
+    return {"value": 128 ** 3 / best, "unit": "voxels/s", "cores": threads, "kind": "port",
+            "sample": "oracle (torch-CPU fp32 restatement) fwd+DiceLoss+bwd of the same UNet3d on 1x1x128^3 "
+                      f"(half of one cfg-2 batch), best of 2 after 1 warm-up: {best:.3f} s/step "
+                      f"({sum(times):.1f} s of CPU work); thread count chosen by a 32^3 probe over 8/16/32/64 of "
+                      f"{max_threads} hardware threads"}
 
 
 def main():
