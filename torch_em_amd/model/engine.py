@@ -140,6 +140,10 @@ def _repack_stale():
         for key, transpose in (("fwd", 0), ("dgrad", 1), ("fwd_inf", 0)):
             if key not in ent:
                 continue
+            if key == "fwd_inf" and not ent.pop("fwd_inf_used", False):
+                # not used since the last refresh (a model that went back to training): drop it, it is re-packed lazily
+                del ent["fwd_inf"], ent["fwd_inf_mfma"]
+                continue
             mode = ent[key + "_mfma"]
             if mode in (2, 3, 4):
                 jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose, 3 if mode == 3 else 2,
@@ -187,6 +191,7 @@ def _conv(spec: ConvSpec, x, y, stats=None, act=None):
     if _NO_GRAD_FORWARD and _INFER_BF16X3 and mode == 3:
         if "fwd_inf" not in ent:  # packed on first use, refreshed with the others by _repack_stale
             ent["fwd_inf"], ent["fwd_inf_mfma"] = ops.pack_weights(spec.conv.weight, transpose=False, mfma=2), 2
+        ent["fwd_inf_used"] = True
         wpk, mode = ent["fwd_inf"], 2
     ops.conv_fwd(x, wpk, spec.conv.bias, y, spec.k, spec.cin, spec.cout, scale=scale, shift=shift, act=act, mfma=mode)
 
