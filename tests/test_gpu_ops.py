@@ -46,6 +46,8 @@ CONV_CASES = [
     (1, 1, 19, 21, 1, 16, (1, 3, 3)),    # Cin == 1, 2-D
     (2, 4, 9, 8, 32, 2, (1, 1, 1)),      # out_conv projection kernels
     (1, 3, 8, 8, 64, 12, (1, 1, 1)),     # projection to 12 affinity channels
+    (2, 9, 17, 10, 32, 1, (3, 3, 3)),    # Cout == 1: dgrad of a first layer (affine first norm)
+    (1, 1, 19, 21, 16, 1, (1, 3, 3)),    # Cout == 1, 2-D
     (2, 1, 40, 24, 32, 64, (1, 3, 3)),   # 2-D MFMA weight gradient (1x16x8 patches)
     (1, 20, 24, 17, 32, 32, (3, 3, 3)),  # z-sliding wgrad kernel, one Cout tile (k-halves), ragged H/W
     (1, 16, 16, 24, 64, 64, (3, 3, 3)),  # z-sliding wgrad kernel, two Cout tiles

@@ -274,6 +274,11 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(cin1)");
         return TEM_OK;
     }
+    if (tem_conv_fwd_cout1(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, N, D, H, W, Cin, Cout, kd, kh, kw, act,
+                           s)) {
+        TEM_CHECK_LAUNCH("tem_conv3d_fwd(cout1)");
+        return TEM_OK;
+    }
     if (kd == 1 && kh == 1 && kw == 1 &&
         tem_conv1x1_proj(x, x_ld, scale, w_packed, bias, y, y_ld, ref, NV, Cin, Cout, act, s)) {
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(proj)");

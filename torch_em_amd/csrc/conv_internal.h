@@ -23,6 +23,9 @@ int64_t tem_conv_wgrad_cin1_ws(int Cout, int ntaps);
 bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                          int64_t g_ld, float* dw, float* db, void* ws, int N, int D, int H, int W, int Cin, int Cout,
                          int kd, int kh, int kw, int sd_layout, hipStream_t s);
+bool tem_conv_fwd_cout1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
+                        const float* bias, float* y, int64_t y_ld, const float* ref, int N, int D, int H, int W,
+                        int Cin, int Cout, int kd, int kh, int kw, int act, hipStream_t s);
 bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const float* w, const float* bias, float* y,
                       int64_t y_ld, const float* ref, int64_t NV, int Cin, int Cout, int act, hipStream_t s);
 int64_t tem_conv1x1_proj_wgrad_ws(int Cin, int Cout);

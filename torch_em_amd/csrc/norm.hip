@@ -199,19 +199,22 @@ __global__ __launch_bounds__(256) void k_norm_bwd_finalize(const float* __restri
     }
 }
 
-// dgamma[c] = sum_{n,b} part[..][1], dbeta[c] = sum part[..][0]
+// dgamma[c] = sum_{n,b} part[..][1], dbeta[c] = sum part[..][0]; one block per channel (a single thread per channel
+// walking up to N*512 partials took 96 us per call, 1.7 ms per GroupNorm training step)
 __global__ __launch_bounds__(256) void k_norm_bwd_affine(const float* __restrict__ part, int N, int nblk, int C,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < N * nblk; ++i) {
+    for (int i = threadIdx.x; i < N * nblk; i += 256) {
         int64_t o = ((int64_t)i * C + c) * 2;
         s1 += (double)part[o];
         s2 += (double)part[o + 1];
     }
-    if (dbeta) dbeta[c] = (float)s1;
-    if (dgamma) dgamma[c] = (float)s2;
+    block_sum2_d(s1, s2);
+    if (threadIdx.x == 0) {
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+    }
 }
 
 template <int VEC>
@@ -310,7 +313,7 @@ extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int6
     hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, g.nblk, V, C, G,
                        gamma, mean, rstd, coef);
     if (dgamma || dbeta)
-        hipLaunchKernelGGL(k_norm_bwd_affine, dim3((unsigned)tem_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part,
+        hipLaunchKernelGGL(k_norm_bwd_affine, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, part,
                            N, g.nblk, C, dgamma, dbeta);
     bool v4 = (C % 4 == 0) && gy_ld % 4 == 0 && x_ld % 4 == 0 && gx_ld % 4 == 0 && (uintptr_t)gy % 16 == 0 &&
               (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0;
