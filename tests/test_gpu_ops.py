@@ -44,7 +44,13 @@ CONV_CASES = [
     (1, 4, 8, 8, 256, 64, (1, 1, 1)),    # split-K, 1x1x1
     (2, 9, 17, 10, 1, 32, (3, 3, 3)),    # Cin == 1 first-layer kernels
     (1, 1, 19, 21, 1, 16, (1, 3, 3)),    # Cin == 1, 2-D
+    (2, 9, 17, 10, 3, 32, (3, 3, 3)),    # Cin == 3 (RGB) through the small-Cin first-layer kernels
+    (1, 1, 19, 21, 2, 16, (1, 3, 3)),    # Cin == 2, 2-D
+    (1, 5, 9, 9, 4, 32, (3, 3, 3)),      # Cin == 4
     (2, 4, 9, 8, 32, 2, (1, 1, 1)),      # out_conv projection kernels
+    (1, 5, 9, 8, 32, 8, (1, 1, 1)),      # projection to 8 embedding channels (SPOCO): proj wgrad NJ=1
+    (1, 5, 9, 8, 32, 12, (1, 1, 1)),     # 12 affinity channels from 32 features
+    (1, 3, 9, 8, 128, 8, (1, 1, 1)),     # side-output projection from a deep level: proj wgrad NJ=4
     (1, 3, 8, 8, 64, 12, (1, 1, 1)),     # projection to 12 affinity channels
     (2, 9, 17, 10, 32, 1, (3, 3, 3)),    # Cout == 1: dgrad of a first layer (affine first norm)
     (1, 1, 19, 21, 16, 1, (1, 3, 3)),    # Cout == 1, 2-D

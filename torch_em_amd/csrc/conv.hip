@@ -455,7 +455,7 @@ extern "C" int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int 
     } else {
         int64_t b = p.part_floats * 4;
         int64_t c1 = tem_conv_wgrad_cin1_ws(Cout, ntaps), pj = tem_conv1x1_proj_wgrad_ws(Cin, Cout);
-        if (Cin == 1 && c1 > b) b = c1;
+        if (Cin <= 4 && c1 > b) b = c1;
         if (ntaps == 1 && pj > b) b = pj;
         bytes += b;
     }

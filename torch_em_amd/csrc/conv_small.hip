@@ -17,11 +17,11 @@ __device__ __forceinline__ float act_apply_s(float v, int act) {
 // live in LDS; thread <-> (voxel, 4 output channels): 27 LDS broadcasts + 27 float4 weight
 // reads + 108 FMA, one 16-byte store.
 // ---------------------------------------------------------------------------
-template <int KD, int KH, int KW>
+template <int KD, int KH, int KW, int CIN>
 __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__ x, int64_t x_ld,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
-                                                       const float* __restrict__ w /*[tap][co]*/,
+                                                       const float* __restrict__ w /*[tap][ci][co]*/,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        int64_t y_ld, int N, int D, int H, int W, int Cout, int act,
                                                        int nZ, int nY, int nX) {
@@ -29,9 +29,10 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
     constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
     constexpr int TZ = 4, TY = 8, TX = 8;
     constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1, HV = HZ * HY * HX;
+    constexpr int HVP = ((HV + 3) / 4) * 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lx = lds;                       // [HV]
-    float* lw = lds + ((HV + 3) / 4) * 4;  // [NT][Cout]
+    float* lx = lds;              // [CIN][HVP]
+    float* lw = lds + CIN * HVP;  // [NT][CIN][Cout]
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int ptx = bid % nX;
@@ -41,19 +42,17 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
     const int ptz = bid % nZ;
     const int n = bid / nZ;
     const int z0 = ptz * TZ, y0 = pty * TY, x0 = ptx * TX;
-    float sc = 1.f, sf = 0.f;
-    if (scale) {
-        sc = scale[n];
-        sf = shift[n];
-    }
-    for (int i = tid; i < NT * Cout; i += 256) lw[i] = w[i];
-    for (int hv = tid; hv < HV; hv += 256) {
+    for (int i = tid; i < NT * CIN * Cout; i += 256) lw[i] = w[i];
+    for (int item = tid; item < HV * CIN; item += 256) {
+        const int hv = item / CIN, ci = item % CIN;
         const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
         const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
         float v = 0.f;
-        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = fmaf(x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld], sc, sf);
-        lx[hv] = v;
+        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            v = x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld + ci];
+            if (scale) v = fmaf(v, scale[n * CIN + ci], shift[n * CIN + ci]);
+        }
+        lx[ci * HVP + hv] = v;
     }
     __syncthreads();
     const int cq = Cout >> 2;
@@ -67,12 +66,15 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
             const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
-            const float xv = xb[(tz * HY + ty) * HX + tx];
-            const float4 wv = *reinterpret_cast<const float4*>(lw + tap * Cout + q * 4);
-            acc.x = fmaf(xv, wv.x, acc.x);
-            acc.y = fmaf(xv, wv.y, acc.y);
-            acc.z = fmaf(xv, wv.z, acc.z);
-            acc.w = fmaf(xv, wv.w, acc.w);
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float xv = xb[ci * HVP + (tz * HY + ty) * HX + tx];
+                const float4 wv = *reinterpret_cast<const float4*>(lw + (tap * CIN + ci) * Cout + q * 4);
+                acc.x = fmaf(xv, wv.x, acc.x);
+                acc.y = fmaf(xv, wv.y, acc.y);
+                acc.z = fmaf(xv, wv.z, acc.z);
+                acc.w = fmaf(xv, wv.w, acc.w);
+            }
         }
         acc.x = act_apply_s(acc.x, act);
         acc.y = act_apply_s(acc.y, act);
@@ -86,22 +88,26 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
 bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
                        const float* bias, float* y, int64_t y_ld, const float* ref, int N, int D, int H, int W,
                        int Cin, int Cout, int kd, int kh, int kw, int act, hipStream_t s) {
-    if (Cin != 1 || Cout % 4 || Cout > 128 || ref || y_ld % 4 || ((uintptr_t)y % 16) ||
+    // Cin 2..4 (RGB / multi-channel raw data) share the kernel; weights stay in LDS, so Cin * Cout is bounded
+    if (Cin > 4 || Cout % 4 || Cin * Cout > 128 || ref || y_ld % 4 || ((uintptr_t)y % 16) ||
         (bias && ((uintptr_t)bias % 16)))
         return false;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     if (key != 7 && key != 3) return false;
     const int nZ = (D + 3) / 4, nY = (H + 7) / 8, nX = (W + 7) / 8;
     const int64_t nblk = (int64_t)N * nZ * nY * nX;
+#define C1(KD_, CI)                                                                                                   \
+    case CI: {                                                                                                        \
+        size_t ldsb = (size_t)(CI * ((((KD_ + 3) * 10 * 10 + 3) / 4) * 4) + KD_ * 9 * CI * Cout) * sizeof(float);     \
+        hipLaunchKernelGGL((k_conv_fwd_cin1<KD_, 3, 3, CI>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, \
+                           shift, w, bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX);                               \
+    } break;
     if (key == 7) {
-        size_t ldsb = (size_t)(((6 * 10 * 10 + 3) / 4) * 4 + 27 * Cout) * sizeof(float);
-        hipLaunchKernelGGL((k_conv_fwd_cin1<3, 3, 3>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, shift,
-                           w, bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX);
+        switch (Cin) { C1(3, 1) C1(3, 2) C1(3, 3) C1(3, 4) }
     } else {
-        size_t ldsb = (size_t)(((4 * 10 * 10 + 3) / 4) * 4 + 9 * Cout) * sizeof(float);
-        hipLaunchKernelGGL((k_conv_fwd_cin1<1, 3, 3>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, shift,
-                           w, bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX);
+        switch (Cin) { C1(1, 1) C1(1, 2) C1(1, 3) C1(1, 4) }
     }
+#undef C1
     return true;
 }
 
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
                                                          const float* __restrict__ g, int64_t g_ld,
                                                          float* __restrict__ part /*[grid][NT+1][Cout]*/, int N,
                                                          int D, int H, int W, int Cout, int P, int nZ, int nY,
-                                                         int nX) {
+                                                         int nX, int sstride /*Cin: scale[n*Cin] of this channel*/) {
     constexpr int NT = KD * KH * KW;
     constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
     constexpr int TZ = 4, TY = 8, TX = 8;
@@ -226,8 +232,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
         const int z0 = ptz * TZ, y0 = pty * TY, x0 = ptx * TX;
         float sc = 1.f, sf = 0.f;
         if (scale) {
-            sc = scale[n];
-            sf = shift[n];
+            sc = scale[n * sstride];
+            sf = shift[n * sstride];
         }
         __syncthreads();
         for (int hv = tid; hv < HV; hv += 256) {
@@ -340,6 +346,34 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_sd(const float* __restrict
     }
 }
 
+// one input channel (ci) of a [tap][CinT][co] (or state_dict [co][CinT][tap]) gradient from [chunk][tap][co] slabs
+__global__ __launch_bounds__(512) void k_reduce_slabs_ci(const float* __restrict__ part, int nchunks, int ntaps, int CinT,
+                                                         int ci, int Cout, int64_t chunk_stride, float* __restrict__ out,
+                                                         int sd_layout) {
+    __shared__ double sh[8][64];
+    const int64_t n = (int64_t)ntaps * Cout;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = i0 + tx;
+        double s = 0.0;
+        if (i < n)
+            for (int c = ty; c < nchunks; c += 8) s += (double)part[(int64_t)c * chunk_stride + i];
+        sh[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && i < n) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += sh[k][tx];
+            const int co = (int)(i % Cout), tap = (int)(i / Cout);
+            if (sd_layout)
+                out[((int64_t)co * CinT + ci) * ntaps + tap] = (float)a;
+            else
+                out[((int64_t)tap * CinT + ci) * Cout + co] = (float)a;
+        }
+        __syncthreads();
+    }
+}
+
 void tem_reduce_slabs_w(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
                         int sd_layout, hipStream_t s) {
     const int64_t n = (int64_t)ntaps * Cin * Cout;
@@ -361,7 +395,8 @@ bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const
                          int64_t g_ld, float* dw, float* db, void* ws, int N, int D, int H, int W, int Cin, int Cout,
                          int kd, int kh, int kw, int sd_layout, hipStream_t s) {
     const int cq = Cout / 4;
-    if (Cin != 1 || Cout % 4 || cq > 16 || (cq & (cq - 1)) || g_ld % 4 || ((uintptr_t)g % 16)) return false;
+    // Cin 2..4: one pass per input channel (g is re-read Cin times: still ~6x faster than the generic kernel)
+    if (Cin > 4 || Cout % 4 || cq > 16 || (cq & (cq - 1)) || g_ld % 4 || ((uintptr_t)g % 16)) return false;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     if (key != 7 && key != 3) return false;
     const int nZ = (D + 3) / 4, nY = (H + 7) / 8, nX = (W + 7) / 8;
@@ -370,18 +405,28 @@ bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const
     const int grid = P < CIN1_GRID ? P : CIN1_GRID;
     const int NT = kd * kh * kw;
     float* part = (float*)ws;
-    if (key == 7) {
-        size_t ldsf = 6 * 10 * 10 > 4 * (NT + 1) * Cout ? 6 * 10 * 10 : 4 * (NT + 1) * Cout;
-        hipLaunchKernelGGL((k_conv_wgrad_cin1<3, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x, x_ld, scale,
-                           shift, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX);
-    } else {
-        size_t ldsf = 4 * 10 * 10 > 4 * (NT + 1) * Cout ? 4 * 10 * 10 : 4 * (NT + 1) * Cout;
-        hipLaunchKernelGGL((k_conv_wgrad_cin1<1, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x, x_ld, scale,
-                           shift, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX);
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* sc = scale ? scale + ci : nullptr;
+        const float* sf = scale ? shift + ci : nullptr;
+        if (key == 7) {
+            size_t ldsf = 6 * 10 * 10 > 4 * (NT + 1) * Cout ? 6 * 10 * 10 : 4 * (NT + 1) * Cout;
+            hipLaunchKernelGGL((k_conv_wgrad_cin1<3, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x + ci, x_ld, sc,
+                               sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin);
+        } else {
+            size_t ldsf = 4 * 10 * 10 > 4 * (NT + 1) * Cout ? 4 * 10 * 10 : 4 * (NT + 1) * Cout;
+            hipLaunchKernelGGL((k_conv_wgrad_cin1<1, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x + ci, x_ld, sc,
+                               sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin);
+        }
+        // the first NT*Cout entries of a slab are dw[tap][ci][co]; the last Cout are db
+        if (Cin == 1) {
+            tem_reduce_slabs_w(part, grid, NT, 1, Cout, (int64_t)(NT + 1) * Cout, dw, sd_layout, s);
+        } else {
+            int64_t nb = tem_cdiv((int64_t)NT * Cout, 64);
+            hipLaunchKernelGGL(k_reduce_slabs_ci, dim3((unsigned)nb), dim3(512), 0, s, part, grid, NT, Cin, ci, Cout,
+                               (int64_t)(NT + 1) * Cout, dw, sd_layout);
+        }
+        if (db && ci == 0) tem_reduce_slabs(part + (int64_t)NT * Cout, grid, Cout, (int64_t)(NT + 1) * Cout, db, s);
     }
-    // dw[tap][ci=0][co] is exactly the first NT*Cout entries of a slab; db the last Cout
-    tem_reduce_slabs_w(part, grid, NT, 1, Cout, (int64_t)(NT + 1) * Cout, dw, sd_layout, s);
-    if (db) tem_reduce_slabs(part + (int64_t)NT * Cout, grid, Cout, (int64_t)(NT + 1) * Cout, db, s);
     return true;
 }
 
@@ -438,7 +483,7 @@ bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const fl
 }
 
 // weight gradient of the projection: dw[ci][co] = sum_v x[v][ci] * g[v][co], db[co] = sum_v g[v][co]
-template <int COUT>
+template <int COUT, int NJ>
 __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restrict__ x, int64_t x_ld,
                                                             const float* __restrict__ g, int64_t g_ld,
                                                             float* __restrict__ part /*[grid][Cin+1][COUT]*/,
@@ -446,11 +491,11 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restr
     extern __shared__ float lds[];  // [4][Cin+1][COUT]
     const int l8 = threadIdx.x & 7;
     const int64_t vstride = (int64_t)gridDim.x * 32;
-    const int nj = Cin / 32;        // 16-byte pieces per lane (<= 4 supported)
-    float acc[4][4][COUT];
+    constexpr int nj = NJ;          // = Cin / 32: 16-byte pieces per lane
+    float acc[NJ][4][COUT];
     float gacc[COUT];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NJ; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -466,7 +511,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restr
         }
         const float* xp = x + v * x_ld;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < NJ; ++a) {
             if (a < nj) {
                 const float4 t = *reinterpret_cast<const float4*>(xp + a * 32 + l8 * 4);
                 const float xv[4] = {t.x, t.y, t.z, t.w};
@@ -479,7 +524,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restr
     }
     // lanes with equal l8 inside a wave: xor 8, 16, 32
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NJ; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -502,7 +547,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restr
     const int slab = (Cin + 1) * COUT;
     if (lane < 8) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NJ; ++a)
             if (a < nj)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -524,19 +569,35 @@ int64_t tem_conv1x1_proj_wgrad_ws(int Cin, int Cout) { return (int64_t)PROJ_GRID
 bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, const float* g, int64_t g_ld, float* dw,
                             float* db, void* ws, int64_t NV, int Cin, int Cout, int sd_layout, hipStream_t s) {
     if (scale || Cin % 32 || Cin > 128 || x_ld % 4 || ((uintptr_t)x % 16)) return false;
+    const int njr = Cin / 32;
+    if (njr == 3 || njr * Cout > 32) return false;  // accumulators: NJ * 4 * COUT registers per lane
     int64_t nb = tem_cdiv(NV, 32);
     const int grid = (int)(nb < PROJ_GRID ? nb : PROJ_GRID);
     float* part = (float*)ws;
     size_t ldsb = (size_t)4 * (Cin + 1) * Cout * sizeof(float);
+#define PWJ(CO, J)                                                                                                \
+    hipLaunchKernelGGL((k_conv1x1_proj_wgrad<CO, J>), dim3(grid), dim3(256), ldsb, s, x, x_ld, g, g_ld, part, NV, Cin)
 #define PW(CO)                                                                                                    \
     case CO:                                                                                                      \
-        hipLaunchKernelGGL((k_conv1x1_proj_wgrad<CO>), dim3(grid), dim3(256), ldsb, s, x, x_ld, g, g_ld, part, NV, Cin); \
+        if (njr == 1) PWJ(CO, 1);                                                                                 \
+        else if (njr == 2) PWJ(CO, 2);                                                                            \
+        else PWJ(CO, 4);                                                                                          \
         break;
+#define PW2(CO)                                                                                                   \
+    case CO:                                                                                                      \
+        if (njr == 1) PWJ(CO, 1);                                                                                 \
+        else PWJ(CO, 2);                                                                                          \
+        break;
+#define PW1(CO)                                                                                                   \
+    case CO: PWJ(CO, 1); break;
     switch (Cout) {
-        PW(1) PW(2) PW(3) PW(4)
+        PW(1) PW(2) PW(3) PW(4) PW(6) PW(8) PW2(12) PW2(16) PW1(24) PW1(32)
         default: return false;
     }
 #undef PW
+#undef PW2
+#undef PW1
+#undef PWJ
     const int64_t slab = (int64_t)(Cin + 1) * Cout;
     tem_reduce_slabs_w(part, grid, 1, Cin, Cout, slab, dw, sd_layout, s);  // [tap=0][ci][co]
     if (db) tem_reduce_slabs(part + (int64_t)Cin * Cout, grid, Cout, slab, db, s);
