@@ -58,6 +58,7 @@ CONV_CASES = [
     (1, 20, 24, 17, 32, 32, (3, 3, 3)),  # z-sliding wgrad kernel, one Cout tile (k-halves), ragged H/W
     (1, 16, 16, 24, 64, 64, (3, 3, 3)),  # z-sliding wgrad kernel, two Cout tiles
     (2, 33, 8, 8, 32, 96, (3, 3, 3)),    # z-sliding, odd depth, Cout = 3 tiles (last group half empty)
+    (1, 16, 132, 136, 32, 32, (3, 3, 3)),  # z-sliding, 289 columns > 256 CUs: workgroups walk two columns each
 ]
 
 

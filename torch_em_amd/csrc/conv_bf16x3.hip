@@ -1329,7 +1329,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                                                           const float* __restrict__ shift, const float* __restrict__ g,
                                                           int64_t g_ld, float* __restrict__ part,
                                                           float* __restrict__ dbpart, int N, int D, int H, int W,
-                                                          int Cin, int Cout, int T, int nY, int nX, int zsegs) {
+                                                          int Cin, int Cout, int T, int nY, int nX, int zsegs,
+                                                          int S, int ncz) {
     constexpr int NT = 27, NRG = 9, KW = 3;
     constexpr int KS2 = (NCO == 1) ? 2 : 1;
     constexpr int GC = 32 * NCO;
@@ -1344,18 +1345,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
-    int bid = tem_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = bid % T;
-    bid /= T;
-    const int zseg = bid % zsegs;
-    bid /= zsegs;
-    const int sp = bid * zsegs + zseg;     // partial-slab index (column, z segment)
-    const int ptx = bid % nX;
-    bid /= nX;
-    const int pty = bid % nY;
-    const int n = bid / nY;
-    const int y0 = pty * 8, x0 = ptx * 8;
-    const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
+    const int bid0 = tem_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid0 % T;
+    const int sp = bid0 / T;               // partial-slab index: this workgroup walks column segments sp, sp+S, ...
     const int ncit = Cin >> 5;
     const int cit = tile % ncit, cog = tile / ncit;
 
@@ -1385,13 +1377,31 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
     float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa, ga = xa, gb = xa;
     bool inA = false, inB = false;
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_db = (dbpart != nullptr) && (cit == 0);
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // The accumulators live across column segments: a workgroup writes ONE partial slab however many columns it
+    // walks (a slab is 8 % of a column's own traffic, and the merge kernel reads every slab back).  The pipeline
+    // re-primes per segment; the barrier that ends a segment's last plane orders its LDS reads before the next
+    // segment's first stores.
+    for (int cz = sp; cz < ncz; cz += S) {
+    const int zseg = cz % zsegs;
+    int col = cz / zsegs;
+    const int ptx = col % nX;
+    col /= nX;
+    const int pty = col % nY;
+    const int n = col / nY;
+    const int y0 = pty * 8, x0 = ptx * 8;
+    const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
     if (scale && xit) {
         sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + xcq * 4);
         sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + xcq * 4);
     }
-    const bool do_db = (dbpart != nullptr) && (cit == 0);
-    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
-
+    xa = make_float4(0.f, 0.f, 0.f, 0.f);
+    xb = xa;
+    ga = xa;
+    gb = xa;
+    inA = inB = false;
     // iteration t: MFMA over plane t (if t >= za); store the pending registers (x plane t+2, g plane t+1); load the
     // next pending set (x plane t+3, g plane t+2); barrier.
     for (int t = za - 4; t < zb; ++t) {
@@ -1505,6 +1515,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
         }
         __syncthreads();
     }
+    }  // column segments
 
     // ---- bias-gradient partial of this workgroup ----
     if (do_db) {
@@ -1544,7 +1555,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
 
 struct ZsPlan {
     bool use;
-    int nco, ks2, T, nY, nX, zsegs, S;
+    int nco, ks2, T, nY, nX, zsegs, S, ncz;
 };
 static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     ZsPlan p;
@@ -1560,7 +1571,11 @@ static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int
     int zs = 1;
     while (p.T * cols * zs < 256 && D / (zs * 2) >= 8) zs *= 2;  // one workgroup per CU: fill the chip
     p.zsegs = zs;
-    p.S = (int)(cols * zs);
+    p.ncz = (int)(cols * zs);
+    // persistent over column segments: q segments per workgroup, T * S workgroups ~ one per CU
+    static const int persist = getenv("TEM_WGRAD_ZS_PERSIST") ? atoi(getenv("TEM_WGRAD_ZS_PERSIST")) : 1;
+    const int64_t q = persist ? ((int64_t)p.ncz * p.T + 255) / 256 : 1;
+    p.S = (int)((p.ncz + q - 1) / q);
     return p;
 }
 
@@ -1658,7 +1673,7 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
                 a2 = true;
             }
             hipLaunchKernelGGL((k_conv_wgrad_zs<2>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
-                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs);
+                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
         } else {
             constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS;
             static bool a1 = false;
@@ -1668,7 +1683,7 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
                 a1 = true;
             }
             hipLaunchKernelGGL((k_conv_wgrad_zs<1>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
-                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs);
+                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
         }
         tem_reduce_slabs_w(zpart, z.S * z.ks2, 27, Cin, Cout, (int64_t)27 * Cin * Cout, dw, sd_layout, s);
         if (db) tem_reduce_slabs(zdb, z.S, Cout, Cout, db, s);
