@@ -39,6 +39,10 @@ RP_NAMES = {
     "k_conv_fwd_bf16x3<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 2, false>",
     "k_conv_fwd_f16x3<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 2, true>",
     "k_conv_fwd_f16x3<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 2, true>",
+    "k_conv_fwd_f16<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 1, true>",
+    "k_conv_fwd_f16<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 1, true>",
+    "k_conv_wgrad_f16<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, true>",
+    "k_conv_wgrad_f16<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, true>",
     "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_zs<2>",
     "k_conv_wgrad_bf16x3<3,3,3,NCO=1>": "k_conv_wgrad_zs<1>",
 }
@@ -53,6 +57,9 @@ PRECISION_DTYPE = {
                "bits, 3 fp16 MFMAs per product; other forward convs 3 bf16 terms / 6 MFMAs; backward convs 2 bf16 terms / "
                "3 MFMAs; fp32 accumulate)",
     "bf16x3": "bf16x3 (all MFMA convs split-bf16, fp32 accumulate)",
+    "amp": "f16 operands (REDUCED PRECISION, not the headline configuration: conv operands rounded to fp16, one fp16 MFMA "
+           "per product, fp32 accumulate and storage -- the counterpart of the reference's torch.autocast(float16); no "
+           "loss scaling in this synthetic step)",
 }
 
 
@@ -109,7 +116,7 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--norm", default="InstanceNorm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "split", "split16", "bf16x3"],
+    ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "split", "split16", "bf16x3", "amp"],
                     help="MFMA conv arithmetic (default: engine default = split)")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table to this file")
     args = ap.parse_args()
@@ -241,7 +248,8 @@ def main():
             dom["ms"] += e0.elapsed_time(e1)
             dom["flops"] += flops
         achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s (algorithmic: 2*MACs of the convolution)
-        split = 6 if "bf16x6" in dom_tag else (3 if ("bf16x3" in dom_tag or "f16x3" in dom_tag) else 0)
+        split = 6 if "bf16x6" in dom_tag else (3 if ("bf16x3" in dom_tag or "f16x3" in dom_tag) else
+                                               1 if "_f16<" in dom_tag else 0)
         # split-bf16 kernels execute 3 (or 6) bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3 (6)
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
         standard = (args.batch == 2 and S == 128)

@@ -70,6 +70,7 @@ int tem_device_cus(void);
 #define TEM_WL_BF16X3 2
 #define TEM_WL_BF16X6 3
 #define TEM_WL_F16X3 4  /* like BF16X3 with two fp16 terms per weight (22 mantissa bits) */
+#define TEM_WL_F16 5    /* ONE fp16 term per weight (half the bytes): the mixed-precision mode, use_mfma 5 */
 #define TEM_ACT_NONE 0
 #define TEM_ACT_RELU 1
 #define TEM_ACT_SIGMOID 2
@@ -78,7 +79,7 @@ int64_t tem_conv_packed_size(int Cout, int Cin, int kd, int kh, int kw); /* floa
 int tem_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw,
                           int transpose, int layout, tem_stream_t stream);
 /* All split-layout (TEM_WL_BF16X3 / BF16X6 / F16X3) packs of a model in ONE launch.  descs_dev: device array of n
- * records { const float* w; void* dst; int32 Cout, Cin, kd, kh, kw, transpose, nsplit(2|3), fp16(0|1); int64 begin }
+ * records { const float* w; void* dst; int32 Cout, Cin, kd, kh, kw, transpose, nsplit(1|2|3), fp16(0|1); int64 begin }
  * (56 bytes each, `begin` = running offset in units of 8 weights, ascending); total = sum of Cout*Cin*taps/8.  Same result as n calls
  * of tem_conv_pack_weights. */
 int tem_conv_pack_weights_batch(const void* descs_dev, int n, int64_t total, tem_stream_t stream);
@@ -103,6 +104,11 @@ int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Ci
  *                v_mfma_f32_32x32x16_f16: ~2^-22 per product at half the MFMAs of mode 3; operands
  *                must stay far inside the fp16 range, i.e. pre-normalised activations (scale/shift
  *                given) and weights -- not gradients (TEM_WL_F16X3 pack);
+ *                5 = mixed precision: operands rounded to fp16 (round-to-nearest-even, overflow -> inf), ONE
+ *                v_mfma_f32_32x32x16_f16 per product, fp32 accumulation and fp32 output -- the arithmetic of
+ *                the reference's default GPU mode, torch.autocast(float16) around nn.Conv3d
+ *                (trainer/default_trainer.py:134-142,789-794); NOT parity-grade (2^-11 per operand), used only
+ *                when the trainer is created with mixed_precision=True (TEM_WL_F16 pack);
  *                0 = VALU kernel (TEM_WL_GENERIC pack).
  *   ws:          optional workspace of tem_conv3d_fwd_ws() bytes.  Spatially small, channel-rich
  *                layers (the 8^3/16^3 levels) cannot fill 256 CUs with (patch x Cout-tile)
@@ -120,7 +126,8 @@ int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float
  * db[co] = sum_v g[v][co] (optional).  ws: workspace of tem_conv3d_wgrad_ws() bytes.
  * sd_layout != 0: dw is written in the reference's state_dict order [Cout][Cin][kd][kh][kw]
  * (what param.grad needs); 0: tap-major [tap][ci][co] (tem_conv_unpack_wgrad converts).
- * use_mfma: 0 VALU, 1 exact-fp32 MFMA, 2 split-bf16 MFMA (tem_conv3d_fwd). */
+ * use_mfma: 0 VALU, 1 exact-fp32 MFMA, 2 split-bf16 MFMA (tem_conv3d_fwd), 5 mixed precision (x and g rounded to
+ * fp16, one MFMA per product, in the z-sliding 3x3x3 kernel; other shapes run mode 2). */
 int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const float* shift,
                      const float* g, int64_t g_ld, float* dw_tap_ci_co, float* db,
@@ -211,6 +218,10 @@ int tem_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float grad_scale, tem_stream_t stream);
 /* theta_k = m*theta_k + (1-m)*theta_q : SPOCOTrainer._momentum_update (trainer/spoco_trainer.py:45-47) */
 int tem_ema_update(float* theta_k, const float* theta_q, int64_t n, float momentum, tem_stream_t stream);
+/* Mixed-precision training (reference trainer/default_trainer.py:134-142,789-794: torch.amp.GradScaler): the unscale_
+ * step -- grad *= inv_scale in place, *found_inf (device float, zeroed by the caller) is set to 1 if any element is
+ * inf/NaN.  Replaces torch._amp_foreach_non_finite_check_and_unscale_ over the flat gradient arena. */
+int tem_amp_unscale(float* grad, int64_t n, float inv_scale, float* found_inf, tem_stream_t stream);
 
 /* ---- label targets (integer, bit-exact) -----------------------------------------
  * BoundaryTransform (transform/label.py:100-129; skimage find_boundaries mode="thick":

@@ -110,6 +110,61 @@ def test_conv_fwd_dgrad_wgrad(case, fused):
         assert rel_err(db.cpu(), br.grad) < 5e-5, f"bgrad mfma={mfma}"
 
 
+MIXED_CASES = [
+    (1, 8, 16, 16, 32, 64, (3, 3, 3)),    # patch wgrad kernel (D < 16): stays bf16x3
+    (1, 20, 24, 17, 32, 32, (3, 3, 3)),   # z-sliding wgrad, k-halves
+    (1, 16, 16, 24, 64, 64, (3, 3, 3)),   # z-sliding wgrad, two Cout tiles
+    (1, 1, 20, 33, 16, 64, (1, 3, 3)),    # 2-D
+    (2, 4, 8, 8, 64, 32, (1, 1, 1)),
+    (2, 8, 8, 8, 128, 128, (3, 3, 3)),    # split-K
+]
+
+
+@pytest.mark.parametrize("case", MIXED_CASES)
+def test_conv_mixed_precision_mode(case):
+    """use_mfma = 5 (mixed_precision=True): operands rounded to fp16, one MFMA per product, fp32 accumulation -- the
+    arithmetic of torch.autocast(float16) around nn.Conv3d (reference trainer/default_trainer.py:134-142).  Expected
+    values: the fp32 convolution of the fp16-ROUNDED operands, so only the summation order differs (2e-5)."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    scale = torch.rand(N, Cin, generator=g) + 0.5
+    shift = torch.randn(N, Cin, generator=g)
+    pad = tuple(v // 2 for v in k)
+    r16 = lambda t: t.half().float()
+    # the kernel applies the pre-norm as ONE fused multiply-add before rounding to fp16: float64 reproduces that
+    xn = (x.double() * scale[:, :, None, None, None].double() + shift[:, :, None, None, None].double()).float()
+    xh = r16(xn)
+    exp = F.relu(F.conv3d(xh, r16(w), b, padding=pad))
+    x5, wd = to5(x), w.to(DEV)
+    y5 = ops.new_act(N, D, H, W, Cout, DEV)
+    ops.conv_fwd(x5, ops.pack_weights(wd, transpose=False, mfma=5), b.to(DEV), y5, k, Cin, Cout, scale=scale.to(DEV),
+                 shift=shift.to(DEV), act="relu", mfma=5)
+    assert rel_err(from5(y5), exp) < 2e-5
+    # the same numbers are NOT the fp32 result: the mode really rounds (guards against a silent fp32 fallback)
+    exact = F.relu(F.conv3d(xn, w, b, padding=pad))
+    assert rel_err(from5(y5), exact) > 5e-5
+    gy = torch.randn(exp.shape, generator=g)
+    if ops.mfma_ok(Cout, Cin, k):
+        wr = r16(w).requires_grad_(False)
+        gxe = torch.nn.grad.conv3d_input(x.shape, wr, r16(gy), padding=pad)
+        gx5 = ops.new_act(N, D, H, W, Cin, DEV)
+        ops.conv_fwd(to5(gy), ops.pack_weights(wd, transpose=True, mfma=5), None, gx5, k, Cout, Cin, mfma=5)
+        assert rel_err(from5(gx5), gxe) < 2e-5
+    if ops.mfma_ok(Cin, Cout, k, wgrad=True):
+        dw = torch.empty(w.numel(), device=DEV)
+        db = torch.empty(Cout, device=DEV)
+        ops.conv_wgrad(x5, to5(gy), k, Cin, Cout, dw, db, scale=scale.to(DEV), shift=shift.to(DEV), mfma=5)
+        zs = k == (3, 3, 3) and D >= 16
+        xe = xh if zs else xn
+        dwe = torch.nn.grad.conv3d_weight(xe, w.shape, r16(gy) if zs else gy, padding=pad)
+        assert rel_err(dw.cpu().view(w.shape), dwe) < (2e-5 if zs else 1e-4)
+        assert rel_err(db.cpu(), gy.sum((0, 2, 3, 4))) < 5e-5   # bias gradient sums the fp32 values
+
+
 def test_conv_relu_mask_ref_and_channel_slices():
     """ref-mask epilogue and leading-dimension (concat-buffer slice) addressing."""
     ops = _ops()

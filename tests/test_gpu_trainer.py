@@ -259,3 +259,60 @@ def test_trainer_with_on_device_augmentation(tmp_path):
     assert y0.dtype == torch.int64 and y0.is_cuda and y0.shape == (1, 1, 16, 32, 32)
     assert set(torch.unique(y0).tolist()) <= {0, 1, 2, 3}
     assert not torch.equal(y0.cpu(), ys[:1])  # the batch the loss saw is the augmented one
+
+
+def test_mixed_precision_training(tmp_path):
+    """mixed_precision=True + mixed_precision_dtype="float16": the step runs in engine.precision_scope("amp") (fp16
+    operand rounding on the matrix cores, tem_conv3d_* use_mfma = 5) with optim.GradScaler -- reference
+    trainer/default_trainer.py:134-142 (scaler), :789-794 (_backprop_mixed), :595-596 (scaler_state)."""
+    import torch_em_amd
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d, engine
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 1, 32, 32, 32, generator=g).to(DEV)
+    y = (torch.rand(1, 2, 32, 32, 32, generator=g) > 0.5).float().to(DEV)
+    model = UNet3d(1, 2, depth=2, initial_features=32).to(DEV)
+    loss_fn = DiceLoss()
+
+    def grads(mode, scale=1.0):
+        model.zero_grad()
+        with engine.precision_scope(mode):
+            out = model(x)
+            (loss_fn(out, y) * scale).backward()
+        return out.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+
+    out32, g32 = grads("split")
+    out16, g16 = grads("amp", 1024.0)
+    assert engine.PRECISION == "split"                      # the scope restores the mode
+    assert 1e-5 < rel_err(out16.cpu(), out32.cpu()) < 5e-3  # really fp16 operands; close to the fp32-class result
+    e = float((g16 / 1024.0 - g32).norm() / g32.norm())
+    assert 1e-5 < e < 5e-2, e
+    # ---- the trainer: loss scaling, skipped step on overflow, checkpointed scaler ----
+    ds = torch.utils.data.TensorDataset(x.cpu().repeat(4, 1, 1, 1, 1), y.cpu().repeat(4, 1, 1, 1, 1))
+    loader = torch.utils.data.DataLoader(ds, batch_size=1)
+    trainer = torch_em_amd.default_segmentation_trainer("amp", model, loader, loader, device=DEV, logger=None,
+                                                        save_root=str(tmp_path), mixed_precision=True,
+                                                        mixed_precision_dtype="float16")
+    assert trainer.scaler is not None and trainer.scaler.get_scale() == 65536.0
+    with torch.no_grad():
+        l0 = float(loss_fn(model(x), y))
+    trainer.fit(iterations=8)
+    with torch.no_grad():
+        l1 = float(loss_fn(model(x), y))
+    assert np.isfinite(l1) and l1 < l0
+    ckpt = torch.load(os.path.join(trainer.checkpoint_folder, "latest.pt"), weights_only=False)
+    assert ckpt["scaler_state"]["scale"] == trainer.scaler.get_scale() and ckpt["init"]["mixed_precision_dtype"] == "float16"
+    # overflow: a scale beyond the fp16 range makes the rounded gradients inf -> step skipped, scale halved
+    before = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+    steps = {int(v["step"]) for v in trainer.optimizer.state_dict()["state"].values()}
+    trainer.scaler.update(new_scale=2.0 ** 100)
+    trainer.fit(iterations=1)
+    after = torch.cat([p.detach().flatten() for p in model.parameters()])
+    assert torch.equal(before, after)
+    assert trainer.scaler.get_scale() == 2.0 ** 99
+    assert {int(v["step"]) for v in trainer.optimizer.state_dict()["state"].values()} == steps
+    # default flags (the reference's mixed_precision=True alone) keep the fp32-class path: no scaler
+    t2 = torch_em_amd.default_segmentation_trainer("fp32", model, loader, loader, device=DEV, logger=None,
+                                                   save_root=str(tmp_path))
+    assert t2.scaler is None and not t2._amp

@@ -155,3 +155,33 @@ def test_bench_kernel_names_match_committed_profiles():
     for tag in ("k_conv_fwd_bf16x6<3,3,3,NR=1>", "k_conv_fwd_bf16x6<3,3,3,NR=2>", "k_conv_fwd_bf16x3<3,3,3,NR=2>",
                 "k_conv_wgrad_bf16x3<3,3,3,NCO=1>", "k_conv_wgrad_bf16x3<3,3,3,NCO=2>"):
         assert mod.RP_NAMES[tag] in traffic, (tag, mod.RP_NAMES[tag])
+
+
+def test_grad_scaler_policy():
+    """optim.GradScaler follows torch.amp.GradScaler's schedule (what the reference trainer instantiates,
+    trainer/default_trainer.py:140): halve after an overflow, double after `growth_interval` clean steps; same
+    state_dict keys."""
+    from torch_em_amd.optim import GradScaler
+    import inspect
+    ref = {k: v.default for k, v in inspect.signature(torch.amp.GradScaler.__init__).parameters.items()}
+    s = GradScaler(growth_interval=3)
+    assert s.get_scale() == ref["init_scale"] == 2.0 ** 16 and s.get_growth_factor() == ref["growth_factor"]
+    assert s.get_backoff_factor() == ref["backoff_factor"] and GradScaler().get_growth_interval() == ref["growth_interval"]
+    s._overflow = True
+    s.update()
+    assert s.get_scale() == 32768.0 and s._growth_tracker == 0 and not s._overflow
+    for _ in range(2):
+        s.update()
+    assert s.get_scale() == 32768.0
+    s.update()
+    assert s.get_scale() == 65536.0 and s._growth_tracker == 0
+    sd = s.state_dict()
+    assert set(sd) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    t = GradScaler()
+    t.load_state_dict(sd)
+    assert t.get_scale() == 65536.0 and t.get_growth_interval() == 3
+    assert float(t.scale(torch.tensor(2.0))) == 131072.0
+    off = GradScaler(enabled=False)
+    assert off.get_scale() == 1.0 and off.state_dict() == {} and float(off.scale(torch.tensor(2.0))) == 2.0
+    with pytest.raises(ValueError):
+        GradScaler(growth_factor=1.0)

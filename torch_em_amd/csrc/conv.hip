@@ -50,9 +50,9 @@ extern "C" int tem_conv_pack_weights(const float* w, float* dst, int Cout, int C
     TEM_REQUIRE(w && dst && Cout > 0 && Cin > 0, "tem_conv_pack_weights: bad arguments");
     TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
                 "tem_conv_pack_weights: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
-    if (layout == TEM_WL_BF16X3 || layout == TEM_WL_BF16X6 || layout == TEM_WL_F16X3) {
+    if (layout == TEM_WL_BF16X3 || layout == TEM_WL_BF16X6 || layout == TEM_WL_F16X3 || layout == TEM_WL_F16) {
         int rc = tem_pack_weights_bf16x3(w, dst, Cout, Cin, kd, kh, kw, transpose,
-                                         layout == TEM_WL_BF16X6 ? 3 : (layout == TEM_WL_F16X3 ? 4 : 2),
+                                         layout == TEM_WL_BF16X6 ? 3 : (layout == TEM_WL_F16X3 ? 4 : (layout == TEM_WL_F16 ? 5 : 2)),
                                          (hipStream_t)stream);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv_pack_weights(bf16x3)");
@@ -254,7 +254,7 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
     TEM_REQUIRE(act >= 0 && act <= 2, "tem_conv3d_fwd: Invalid activation: %d", act);
     TEM_REQUIRE(!ref || ref_ld >= Cout, "tem_conv3d_fwd: bad ref_ld");
     hipStream_t s = (hipStream_t)stream;
-    if (use_mfma == 2 || use_mfma == 3 || use_mfma == 4) {
+    if (use_mfma >= 2 && use_mfma <= 5) {
         int rc = tem_conv_fwd_bf16x3(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
                                      W, Cin, Cout, kd, kh, kw, act, use_mfma, s);
         if (rc != TEM_OK) return rc;
@@ -448,7 +448,7 @@ extern "C" int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int 
     int ntaps = kd * kh * kw;
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
     int64_t bytes = tem_align_up(p.db_floats, 64) * 4;
-    if (use_mfma == 2) {
+    if (use_mfma == 2 || use_mfma == 5) {
         bytes += tem_conv_wgrad_bf16x3_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
     } else if (use_mfma) {
         bytes += tem_conv_wgrad_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
@@ -492,10 +492,11 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
     float* dbpart = (float*)ws;
     float* rest = dbpart + tem_align_up(p.db_floats, 64);
-    if (use_mfma == 2) {
+    if (use_mfma == 2 || use_mfma == 5) {
+        // 5: single fp16 product in the z-sliding kernel (autocast-equivalent); the other shapes keep bf16x3
         int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                        ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
-                                       sd_layout, s);
+                                       sd_layout, use_mfma == 5, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(bf16x3)");
         return TEM_OK;

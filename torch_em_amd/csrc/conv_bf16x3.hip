@@ -15,6 +15,9 @@
 #define TEM_PP_RING9 1
 #endif
 static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
+#ifndef TEM_NS1_WPC
+#define TEM_NS1_WPC 4  // resident workgroups per CU of the single-product (mixed precision) forward kernel
+#endif
 #ifndef TEM_ABLATE
 #define TEM_ABLATE 0  // developer ablations for profiling: 1 A reads at a fixed address, 2 no B loads, 4 no halo loads, 8 no stores, 16 no LDS writes; wgrad: 32 no global loads, 64 no LDS writes, 128 no MFMA phase
 #endif
@@ -117,8 +120,8 @@ __global__ __launch_bounds__(256) void k_pack_weights_bfsplit(const float* __res
 
 int tem_pack_weights_bf16x3(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw, int transpose,
                             int nsplit, hipStream_t s) {
-    const int fp16 = nsplit == 4;  // nsplit 4 = fp16x3: two fp16 planes
-    if (fp16) nsplit = 2;
+    const int fp16 = nsplit == 4 || nsplit == 5;  // nsplit 4 = fp16x3: two fp16 planes; 5 = fp16: one plane
+    if (fp16) nsplit = nsplit == 4 ? 2 : 1;
     int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
     TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: split-bf16 layout needs Cin%%16==0, Cout%%32==0");
     int64_t total = (int64_t)Cout * Cin * kd * kh * kw;
@@ -201,7 +204,7 @@ extern "C" int tem_conv_pack_weights_batch(const void* descs_dev, int n, int64_t
 // used for the forward pass, whose rounding noise the gradient amplifies (engine.py, PRECISION).
 // ---------------------------------------------------------------------------
 template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false>
-__global__ __launch_bounds__(256, (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_bfsplit(
+__global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_bfsplit(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
@@ -999,6 +1002,13 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
             else                                                                                                      \
                 launch_b<KD, KH, KW, TZ, TY, TX, 1, 2, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
                                                              W, Cin, Cout, act, ks, part, s);                         \
+        } else if (nsplit == 5) {                                                                                     \
+            if (nr2)                                                                                                  \
+                launch_b<KD, KH, KW, TZ, TY, TX, 2, 1, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                             W, Cin, Cout, act, ks, part, s);                         \
+            else                                                                                                      \
+                launch_b<KD, KH, KW, TZ, TY, TX, 1, 1, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                             W, Cin, Cout, act, ks, part, s);                         \
         } else                                                                                                        \
             GO2(KD, KH, KW, TZ, TY, TX, 2);                                                                           \
     } while (0)
@@ -1323,7 +1333,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
 #define ZS_CIS (ZS_NPL * ZS_PLB + 16)    // bytes per ci (padded like the patch kernel: conflict-free b128 reads)
 #define ZS_GS 144                        // bytes per co row of one g plane: 64 bf16 + 16 pad
 
-template <int NCO>
+template <int NCO, bool H16 = false>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restrict__ x, int64_t x_ld,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ g,
@@ -1422,9 +1432,22 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                 for (int sl = 0; sl < SPU; ++sl) {
                     const int prow = 2 * (sl0 + sl) + kh;  // this lane half's patch row (0..7)
                     const int goff = (ct * 32 + r) * ZS_GS + prow * 16;
+                    const int xoff = xbase + prow * 32;
+                    if constexpr (H16) {
+                        // single fp16 product (the autocast-equivalent mode): hi planes only
+                        const uint4 bh = *reinterpret_cast<const uint4*>(Gh + goff);
+                        const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
+                        const unsigned wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
+                        const uint4 f1 = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
+                                                    __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
+                        const uint4 f2 = make_uint4(wh.y, wh.z, wh.w, wh4);
+                        acc[i][0] = mfma16<true>(wh, bh, acc[i][0]);
+                        acc[i][1] = mfma16<true>(f1, bh, acc[i][1]);
+                        acc[i][2] = mfma16<true>(f2, bh, acc[i][2]);
+                        continue;
+                    }
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gh + goff));
                     const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gl + goff));
-                    const int xoff = xbase + prow * 32;
                     const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
                     const uint4 wl = *reinterpret_cast<const uint4*>(Xl + xoff);
                     const unsigned wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
@@ -1460,11 +1483,15 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             for (int c = 0; c < 4; ++c) {
                 const float va = inA ? fmaf(a[c], s4[c], f4[c]) : 0.f;
                 const float vb = inB ? fmaf(b[c], s4[c], f4[c]) : 0.f;
-                unsigned hi, lo;
-                split2(va, vb, hi, lo);
                 const int off = (xcq * 4 + c) * ZS_CIS + sl + xrow * 32 + xpr * 4;
-                *reinterpret_cast<unsigned*>(Xh + off) = hi;
-                *reinterpret_cast<unsigned*>(Xl + off) = lo;
+                if constexpr (H16) {
+                    *reinterpret_cast<unsigned*>(Xh + off) = pk16<true>(va, vb);
+                } else {
+                    unsigned hi, lo;
+                    split2(va, vb, hi, lo);
+                    *reinterpret_cast<unsigned*>(Xh + off) = hi;
+                    *reinterpret_cast<unsigned*>(Xl + off) = lo;
+                }
             }
         }
         if (t + 1 >= za && t + 1 < zb && git && !(TEM_ABLATE & 512)) {
@@ -1473,11 +1500,15 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             const float a[4] = {ga.x, ga.y, ga.z, ga.w}, b[4] = {gb.x, gb.y, gb.z, gb.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                unsigned hi, lo;
-                split2(a[c], b[c], hi, lo);
                 const int off = (gcq * 4 + c) * ZS_GS + (gprow * 8 + gpr * 2) * 2;
-                *reinterpret_cast<unsigned*>(Gh + off) = hi;
-                *reinterpret_cast<unsigned*>(Gl + off) = lo;
+                if constexpr (H16) {
+                    *reinterpret_cast<unsigned*>(Gh + off) = pk16<true>(a[c], b[c]);
+                } else {
+                    unsigned hi, lo;
+                    split2(a[c], b[c], hi, lo);
+                    *reinterpret_cast<unsigned*>(Gh + off) = hi;
+                    *reinterpret_cast<unsigned*>(Gl + off) = lo;
+                }
                 dbacc[c] += a[c] + b[c];
             }
         }
@@ -1646,7 +1677,7 @@ static void launch_wb(const float* x, int64_t x_ld, const float* scale, const fl
 
 int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                           int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
-                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, hipStream_t s) {
+                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, int h16, hipStream_t s) {
     TEM_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "tem_conv3d_wgrad(bf16x3): needs Cin%%32==0 and Cout%%32==0 (got %d,%d)",
                 Cin, Cout);
     TEM_REQUIRE(x_ld % 4 == 0 && g_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0),
@@ -1672,6 +1703,16 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
                 a2 = true;
             }
+            static bool a2h = false;
+            if (h16 && !a2h) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zs<2, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                a2h = true;
+            }
+            if (h16)
+                hipLaunchKernelGGL((k_conv_wgrad_zs<2, true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
+                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
+            else
             hipLaunchKernelGGL((k_conv_wgrad_zs<2>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
                                N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
         } else {
@@ -1682,6 +1723,16 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
                 a1 = true;
             }
+            static bool a1h = false;
+            if (h16 && !a1h) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zs<1, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                a1h = true;
+            }
+            if (h16)
+                hipLaunchKernelGGL((k_conv_wgrad_zs<1, true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
+                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
+            else
             hipLaunchKernelGGL((k_conv_wgrad_zs<1>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
                                N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
         }

@@ -52,4 +52,4 @@ void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, co
 int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                           int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
-                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, hipStream_t s);
+                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, int h16, hipStream_t s);

@@ -77,3 +77,36 @@ extern "C" int tem_ema_update(float* theta_k, const float* theta_q, int64_t n, f
     TEM_CHECK_LAUNCH("tem_ema_update");
     return TEM_OK;
 }
+
+// GradScaler.unscale_ of the mixed-precision path (reference trainer/default_trainer.py:789-794 drives
+// torch.amp.GradScaler: _amp_foreach_non_finite_check_and_unscale_): g *= inv_scale in place; *found_inf = 1 when any
+// element is inf/NaN (the fp16 operand rounding of use_mfma = 5 overflowed).  Every writer stores the same value.
+__global__ __launch_bounds__(256) void k_amp_unscale(float* __restrict__ g, int64_t n, int64_t n4, float inv_scale,
+                                                     float* __restrict__ found_inf) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<float4*>(g)[i];
+        v.x *= inv_scale;
+        v.y *= inv_scale;
+        v.z *= inv_scale;
+        v.w *= inv_scale;
+        bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+        reinterpret_cast<float4*>(g)[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = g[i] * inv_scale;
+        bad |= !isfinite(v);
+        g[i] = v;
+    }
+    if (bad) *found_inf = 1.f;
+}
+
+extern "C" int tem_amp_unscale(float* grad, int64_t n, float inv_scale, float* found_inf, tem_stream_t stream) {
+    TEM_REQUIRE(grad && found_inf && n > 0, "tem_amp_unscale: bad arguments");
+    const int64_t n4 = ((uintptr_t)grad % 16 == 0) ? (n >> 2) : 0;  // unaligned views take the scalar path
+    hipLaunchKernelGGL(k_amp_unscale, dim3(tem_grid_1d(n4 ? n / 4 + 1 : n, 256)), dim3(256), 0, (hipStream_t)stream, grad,
+                       n, n4, inv_scale, found_inf);
+    TEM_CHECK_LAUNCH("tem_amp_unscale");
+    return TEM_OK;
+}

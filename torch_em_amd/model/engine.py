@@ -40,6 +40,10 @@ _FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
 #            24 mantissa bits) and the six products of order <= 2^-16 -- per-product error ~2^-23,
 #            the fp32 class, at 16/6 of the exact-fp32 MFMA rate (417 TFLOP/s effective peak).
 #   "bf16x3" forward in bf16x3 too (forward noise 1e-5: NOT parity-grade, see below).
+#   "amp"    mixed precision, the counterpart of the reference's torch.autocast(float16) default on GPUs: conv operands
+#            rounded to fp16, ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation, fp32 storage; needs loss
+#            scaling (optim.GradScaler).  2^-11 per operand: NOT parity-grade; the trainers select it only when asked
+#            (mixed_precision=True with an explicit mixed_precision_dtype="float16", or TEM_MIXED_PRECISION=1).
 # Why the forward keeps fp32-class products ("split" is the default; "mixed"/"fp32" use the exact MFMA): the U-Net's gradient is ill-conditioned w.r.t. the FORWARD values -- a
 # 1e-7 relative forward perturbation flips ReLU masks / pooling arg-maxes of near-ties and moves
 # gradient entries by ~1e-4..1e-3 (that is the fp32 reference's own distance from the float64
@@ -51,9 +55,27 @@ PRECISION = os.environ.get("TEM_PRECISION", "split")
 
 def set_precision(mode: str):
     global PRECISION
-    if mode not in ("fp32", "mixed", "split", "split16", "bf16x3"):
+    if mode not in ("fp32", "mixed", "split", "split16", "bf16x3", "amp"):
         raise ValueError(f"unknown precision mode {mode}")
     PRECISION = mode
+
+
+class precision_scope:
+    """`with precision_scope("amp"):` -- the arithmetic of every engine call inside (the role torch.autocast plays
+    in the reference trainer, trainer/default_trainer.py:800-803).  Forward AND backward of a step must run in the
+    same scope: the packed weights are keyed on the mode."""
+
+    def __init__(self, mode: str):
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        self.prev = PRECISION
+        set_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_precision(self.prev)
+        return False
 
 
 def _k3(k):
@@ -89,10 +111,10 @@ class ConvSpec:
 
     # --- packed weights (cached until the parameter changes) -----------------------
     def _modes(self):
-        mode_f = {"bf16x3": 2, "split": 3, "split16": 3}.get(PRECISION, 1)
+        mode_f = {"bf16x3": 2, "split": 3, "split16": 3, "amp": 5}.get(PRECISION, 1)
         if PRECISION == "split16" and self.norm is not None and self.k != (1, 1, 1):
             mode_f = 4  # fp16x3: the conv reads pre-normalised activations (|x| of order 1..100 << 65504)
-        mode_d = 2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
+        mode_d = 5 if PRECISION == "amp" else 2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
         mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
         md = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k) else 0
         mw = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k, wgrad=True) else 0
@@ -145,9 +167,9 @@ def _repack_stale():
                 del ent["fwd_inf"], ent["fwd_inf_mfma"]
                 continue
             mode = ent[key + "_mfma"]
-            if mode in (2, 3, 4):
-                jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose, 3 if mode == 3 else 2,
-                             1 if mode == 4 else 0))
+            if mode in (2, 3, 4, 5):
+                jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
+                             3 if mode == 3 else 1 if mode == 5 else 2, 1 if mode in (4, 5) else 0))
             else:
                 rest.append((ent, key, w, bool(transpose), mode))
         ent["version"] = w._version

@@ -25,15 +25,16 @@ PROFILER_FILTER = None
 
 
 def _fwd_tag(mfma, k, cout):
-    kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3"}.get(int(mfma)) or
+    kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3", 5: "k_conv_fwd_f16"}.get(int(mfma)) or
             ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu")) + f"<{k[0]},{k[1]},{k[2]}"
     return kind + (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
 
 
 def _wgrad_tag(mfma, k, cout):
     ntaps = k[0] * k[1] * k[2]
-    return ("k_conv_wgrad_bf16x3" if int(mfma) == 2 else "k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + \
-        f"<{k[0]},{k[1]},{k[2]}" + (f",NCO={2 if cout >= 64 else 1}" if int(mfma) == 2 and ntaps > 1 else "") + ">(+reduce)"
+    return ("k_conv_wgrad_bf16x3" if int(mfma) == 2 else "k_conv_wgrad_f16" if int(mfma) == 5 else
+            "k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + \
+        f"<{k[0]},{k[1]},{k[2]}" + (f",NCO={2 if cout >= 64 else 1}" if int(mfma) in (2, 5) and ntaps > 1 else "") + ">(+reduce)"
 
 
 def _prof_begin(t, tag=None):
@@ -142,7 +143,8 @@ def mfma_ok(cin: int, cout: int, k: Sequence[int], wgrad: bool = False) -> bool:
 
 def pack_weights(w: torch.Tensor, transpose: bool, mfma) -> torch.Tensor:
     """state_dict layout [Cout, Cin, (kd,) kh, kw] -> kernel layout (see tem_hip.h).
-    mfma: False/0 generic, True/1 exact-fp32 MFMA fragments, 2 / 3 split-bf16 fragments (2 / 3 terms), 4 split-fp16."""
+    mfma: False/0 generic, True/1 exact-fp32 MFMA fragments, 2 / 3 split-bf16 fragments (2 / 3 terms), 4 split-fp16,
+    5 one fp16 term (mixed precision)."""
     _req_cuda(w)
     w = w.detach().contiguous()
     cout, cin = w.shape[:2]
@@ -419,6 +421,14 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
     lib = _lib.load()
     _lib.check(lib.tem_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2,
                                   eps, weight_decay, int(step), grad_scale, _stream(param)), "tem_adamw_step")
+
+
+def amp_unscale(grad, inv_scale, found_inf):
+    """grad *= inv_scale in place; found_inf[0] = 1 if any element is not finite (GradScaler.unscale_)."""
+    _req_cuda(grad, found_inf)
+    lib = _lib.load()
+    _lib.check(lib.tem_amp_unscale(_p(grad), grad.numel(), float(inv_scale), _p(found_inf), _stream(grad)),
+               "tem_amp_unscale")
 
 
 def ema_update(theta_k, theta_q, momentum):

@@ -4,6 +4,8 @@ default_segmentation_trainer, segmentation.py:543) as ONE HIP launch over flat a
 state_dict() has the torch.optim.AdamW layout (per-parameter `step`, `exp_avg`, `exp_avg_sq`;
 the tensors are views of the arenas), so optimizer checkpoints are interchangeable with the reference's.
 """
+from typing import Dict
+
 import torch
 
 from . import ops
@@ -86,3 +88,129 @@ class FusedAdamW(torch.optim.Optimizer):
                                int(st["step"].item()), self.grad_scale)
                 ops.bump_versions([p])
         return loss
+
+
+class GradScaler:
+    """Dynamic loss scaling for the mixed-precision path -- the interface and policy of `torch.amp.GradScaler` as the
+    reference trainer drives it (trainer/default_trainer.py:134-142: created when `mixed_precision` and dtype float16;
+    `_backprop_mixed` :789-794: `scale(loss).backward(); step(optimizer); update()`).
+
+    Why it is needed here although activations and gradients are stored in fp32: in mixed-precision mode the MFMA
+    convolutions round their OPERANDS to fp16 (tem_conv3d_fwd / _wgrad use_mfma = 5), so an incoming gradient below
+    6e-8 would vanish and one above 65504 becomes inf.  The loss is multiplied by `scale` before backward; `step`
+    divides the gradients by it again with one HIP launch over the flat gradient arena (`tem_amp_unscale`, which also
+    raises the found-inf flag), reads that flag (the one host sync per step, as in torch) and skips the optimizer
+    step on overflow; `update` halves the scale after an overflow and doubles it after `growth_interval` clean steps.
+    """
+
+    def __init__(self, init_scale: float = 2.0 ** 16, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000, enabled: bool = True):
+        if growth_factor <= 1.0:
+            raise ValueError("The growth factor must be > 1.0.")
+        if backoff_factor >= 1.0:
+            raise ValueError("The backoff factor must be < 1.0.")
+        self._enabled = enabled
+        self._scale, self._growth_tracker = float(init_scale), 0
+        self._growth_factor, self._backoff_factor, self._growth_interval = growth_factor, backoff_factor, growth_interval
+        self._found_inf: Dict[torch.device, torch.Tensor] = {}
+        self._unscaled = set()       # id(optimizer) already unscaled since the last update()
+        self._overflow = False       # any optimizer saw inf/NaN since the last update()
+        self._scale_dev = {}
+
+    # -- queries ---------------------------------------------------------------------------
+    def is_enabled(self) -> bool:
+        return self._enabled
+
+    def get_scale(self) -> float:
+        return self._scale if self._enabled else 1.0
+
+    def get_growth_factor(self):
+        return self._growth_factor
+
+    def get_backoff_factor(self):
+        return self._backoff_factor
+
+    def get_growth_interval(self):
+        return self._growth_interval
+
+    # -- the three calls of the training loop ----------------------------------------------------
+    def scale(self, outputs):
+        if not self._enabled:
+            return outputs
+        if isinstance(outputs, (list, tuple)):
+            return type(outputs)(self.scale(o) for o in outputs)
+        return outputs * self._scale
+
+    def _flag(self, device):
+        f = self._found_inf.get(device)
+        if f is None:
+            f = self._found_inf[device] = torch.zeros(1, dtype=torch.float32, device=device)
+        return f
+
+    def unscale_(self, optimizer):
+        if not self._enabled:
+            return
+        if id(optimizer) in self._unscaled:
+            raise RuntimeError("unscale_() has already been called on this optimizer since the last update().")
+        self._unscaled.add(id(optimizer))
+        inv = 1.0 / self._scale
+        flat = None
+        if isinstance(optimizer, FusedAdamW):
+            optimizer._ensure_arena()
+            flat = optimizer._arena.grads_flat()
+        if flat is not None:
+            ops.amp_unscale(flat, inv, self._flag(flat.device))
+            return
+        for group in optimizer.param_groups:
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
+                    raise RuntimeError("GradScaler: gradients must be contiguous fp32 CUDA tensors")
+                ops.amp_unscale(g.view(-1), inv, self._flag(g.device))
+
+    def step(self, optimizer, *args, **kwargs):
+        if not self._enabled:
+            return optimizer.step(*args, **kwargs)
+        if id(optimizer) not in self._unscaled:
+            self.unscale_(optimizer)
+        found = any(float(f.item()) != 0.0 for f in self._found_inf.values())   # host sync, like torch's _maybe_opt_step
+        if found:
+            self._overflow = True
+            return None
+        return optimizer.step(*args, **kwargs)
+
+    def update(self, new_scale=None):
+        if not self._enabled:
+            return
+        if new_scale is not None:
+            self._scale = float(new_scale)
+        elif self._overflow:
+            self._scale *= self._backoff_factor
+            self._growth_tracker = 0
+        else:
+            self._growth_tracker += 1
+            if self._growth_tracker == self._growth_interval:
+                self._scale *= self._growth_factor
+                self._growth_tracker = 0
+        for f in self._found_inf.values():
+            f.zero_()
+        self._unscaled.clear()
+        self._overflow = False
+
+    # -- checkpointing (torch.amp.GradScaler's keys) -------------------------------------------
+    def state_dict(self):
+        if not self._enabled:
+            return {}
+        return {"scale": self._scale, "growth_factor": self._growth_factor, "backoff_factor": self._backoff_factor,
+                "growth_interval": self._growth_interval, "_growth_tracker": self._growth_tracker}
+
+    def load_state_dict(self, state_dict):
+        if not self._enabled:
+            return
+        if len(state_dict) == 0:
+            raise RuntimeError("The source state dict is empty, possibly because it was saved from a disabled GradScaler.")
+        self._scale = float(state_dict["scale"])
+        self._growth_factor, self._backoff_factor = state_dict["growth_factor"], state_dict["backoff_factor"]
+        self._growth_interval, self._growth_tracker = state_dict["growth_interval"], state_dict["_growth_tracker"]

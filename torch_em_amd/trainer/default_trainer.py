@@ -8,13 +8,20 @@ checkpoints (`iteration, epoch, best_epoch, best_metric, current_metric, model_s
 init, train_time, timestamp[, scheduler_state]`).
 
 Differences that follow from the MI355X-first design:
-  * arithmetic is exact fp32 on the matrix cores, so `mixed_precision` is accepted (and recorded) but
-    no autocast/GradScaler is applied -- there is no fp16 overflow to guard against;
+  * the default arithmetic is fp32-class on the matrix cores (the 1e-3 parity contract), so the reference's
+    DEFAULT `mixed_precision=True` alone changes nothing.  Mixed precision is engaged when it is asked for
+    explicitly -- `mixed_precision=True` together with `mixed_precision_dtype="float16"` (or TEM_MIXED_PRECISION=1 in
+    the environment): the step then runs inside `engine.precision_scope("amp")` (conv operands rounded to fp16, one
+    MFMA per product: what `torch.autocast(float16)` does to `nn.Conv3d`, reference :134-142, :800-803) with
+    `optim.GradScaler` doing `scale(loss).backward(); step(optimizer); update()` exactly as `_backprop_mixed`
+    (:789-794), `scaler_state` saved / restored like the reference (:595-596, :636-638).  `"bfloat16"` has no
+    counterpart here and keeps the fp32-class path (more precise than requested, no scaler -- as the reference);
   * `compile_model` is accepted and ignored: the model is already one hand-scheduled autograd node,
     there is no tracing compiler in this path;
   * the hot loop never synchronises the host: loss values are kept on device and only read at
     validation / logging time.
 """
+import contextlib
 import os
 import time
 import warnings
@@ -85,7 +92,16 @@ class DefaultTrainer:
         self._iteration = self._epoch = self._best_epoch = 0
         self.mixed_precision = mixed_precision
         self.mixed_precision_dtype = mixed_precision_dtype or "float16"
-        self.scaler = None  # exact-fp32 path: no loss scaling
+        # see the module docstring: explicit float16 request (or TEM_MIXED_PRECISION=1) on a GPU => "amp" arithmetic
+        asked = mixed_precision_dtype == "float16" or (mixed_precision_dtype is None and
+                                                        os.environ.get("TEM_MIXED_PRECISION", "0") == "1")
+        self._amp = bool(mixed_precision) and asked and self.device.type == "cuda"
+        self._mixed_precision_explicit = mixed_precision_dtype is not None
+        if self._amp:
+            from ..optim import GradScaler
+            self.scaler = GradScaler()
+        else:
+            self.scaler = None  # fp32-class path: no loss scaling
         self.early_stopping = early_stopping
         self.train_time = 0.0
         self.logger_class, self.logger_kwargs = logger, logger_kwargs
@@ -113,6 +129,7 @@ class DefaultTrainer:
             "name": self.name, "id_": self.id_, "device": str(self.device), "rank": self.rank,
             "save_root": self.save_root, "compile_model": self.compile_model,
             "mixed_precision": self.mixed_precision, "mixed_precision_dtype": self.mixed_precision_dtype,
+            "mixed_precision_explicit": self._mixed_precision_explicit,
             "early_stopping": self.early_stopping, "log_image_interval": self.log_image_interval,
             "logger_class": None if self.logger_class is None else _class_path(self.logger_class),
             "logger_kwargs": self.logger_kwargs,
@@ -171,6 +188,8 @@ class DefaultTrainer:
         save_dict.update(**extra_save_dict)
         if self.lr_scheduler is not None:
             save_dict["scheduler_state"] = self.lr_scheduler.state_dict()
+        if self.scaler is not None:
+            save_dict["scaler_state"] = self.scaler.state_dict()
         if self.rank is None or self.rank == 0:  # rank-0 only, as the reference (:600-602)
             torch.save(save_dict, os.path.join(self.checkpoint_folder, f"{name}.pt"))
 
@@ -197,6 +216,9 @@ class DefaultTrainer:
         self.optimizer.load_state_dict(save_dict["optimizer_state"])
         if self.lr_scheduler is not None and "scheduler_state" in save_dict:
             self.lr_scheduler.load_state_dict(save_dict["scheduler_state"])
+        scaler_state = save_dict.get("scaler_state")
+        if self.scaler is not None and scaler_state:
+            self.scaler.load_state_dict(scaler_state)
         return save_dict
 
     @classmethod
@@ -221,7 +243,8 @@ class DefaultTrainer:
                       log_image_interval=init["log_image_interval"], mixed_precision=init["mixed_precision"],
                       early_stopping=init["early_stopping"], logger=None, id_=init["id_"],
                       save_root=init["save_root"], rank=init.get("rank"),
-                      mixed_precision_dtype=init["mixed_precision_dtype"])
+                      mixed_precision_dtype=init["mixed_precision_dtype"]
+                      if init.get("mixed_precision_explicit", False) else None)
         trainer._initialize(0, save_dict)
         trainer._is_initialized = True
         return trainer
@@ -297,7 +320,19 @@ class DefaultTrainer:
         xa, ya = aug(x, y)
         return xa.to(x.dtype), ya.to(y.dtype)
 
+    def _precision(self):
+        """The counterpart of the reference's autocast context (:800-803)."""
+        if getattr(self, "_amp", False):
+            from ..model.engine import precision_scope
+            return precision_scope("amp")
+        return contextlib.nullcontext()
+
     def _backprop(self, loss):
+        if self.scaler is not None:  # reference `_backprop_mixed` (:789-794)
+            self.scaler.scale(loss).backward()
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+            return
         loss.backward()
         self.optimizer.step()
 
@@ -309,8 +344,9 @@ class DefaultTrainer:
             x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
             x, y = self._augment(x, y)
             self.optimizer.zero_grad()
-            pred, loss = self._forward_and_loss(x, y)
-            self._backprop(loss)
+            with self._precision():
+                pred, loss = self._forward_and_loss(x, y)
+                self._backprop(loss)
             if self.logger is not None:
                 lr = [pm["lr"] for pm in self.optimizer.param_groups][0]
                 self.logger.log_train(self._iteration, loss, lr, x, y, pred, log_gradients=True)
@@ -325,7 +361,7 @@ class DefaultTrainer:
         """Mean metric over the validation loader (reference :841-861)."""
         self.model.eval()
         metric_val = loss_val = None
-        with torch.no_grad():
+        with torch.no_grad(), self._precision():
             for x, y in self.val_loader:
                 x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
                 pred, loss = self._forward_and_loss(x, y)

@@ -61,11 +61,12 @@ class SPOCOTrainer(DefaultTrainer):
     # ---- loops --------------------------------------------------------------------------------
     def _step(self, x, loss_fn, y=None):
         self.optimizer.zero_grad()
-        prediction = self.model(x)
-        with torch.no_grad():
-            prediction2 = self.model2(x)
-        loss = loss_fn(prediction, prediction2) if y is None else loss_fn((prediction, prediction2), y)
-        self._backprop(loss)
+        with self._precision():
+            prediction = self.model(x)
+            with torch.no_grad():
+                prediction2 = self.model2(x)
+            loss = loss_fn(prediction, prediction2) if y is None else loss_fn((prediction, prediction2), y)
+            self._backprop(loss)
         with torch.no_grad():
             self._momentum_update()
         return prediction, loss
@@ -97,7 +98,7 @@ class SPOCOTrainer(DefaultTrainer):
         self.model.eval()
         self.model2.eval()
         metric = loss = None
-        with torch.no_grad():
+        with torch.no_grad(), self._precision():
             for x, y in self.val_loader:
                 x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
                 prediction, prediction2 = self.model(x), self.model2(x)
