@@ -54,8 +54,9 @@ PRECISION_DTYPE = {
     "split": "f32-class (forward: fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product = 24-bit products; "
              "backward convs: 2 terms / 3 MFMAs; fp32 accumulate)",
     "split16": "f32-class (forward convs on normalised activations: fp32 operands split into 2 fp16 terms = 22 mantissa "
-               "bits, 3 fp16 MFMAs per product; other forward convs 3 bf16 terms / 6 MFMAs; backward convs 2 bf16 terms / "
-               "3 MFMAs; fp32 accumulate)",
+               "bits, lo plane scaled by 2^12 with its own fp32 accumulator, 3 fp16 MFMAs per product; other forward "
+               "convs 3 bf16 terms / 6 MFMAs; backward convs 2 bf16 terms / 3 MFMAs; fp32 accumulate; gradient error vs "
+               "float64 = that of the fp32 reference path, tests/test_gpu_unet.py)",
     "bf16x3": "bf16x3 (all MFMA convs split-bf16, fp32 accumulate)",
     "amp": "f16 operands (REDUCED PRECISION, not the headline configuration: conv operands rounded to fp16, one fp16 MFMA "
            "per product, fp32 accumulate and storage -- the counterpart of the reference's torch.autocast(float16); no "
@@ -117,7 +118,7 @@ def main():
     ap.add_argument("--norm", default="InstanceNorm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "split", "split16", "bf16x3", "amp"],
-                    help="MFMA conv arithmetic (default: engine default = split)")
+                    help="MFMA conv arithmetic (default: engine default = split16)")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table to this file")
     args = ap.parse_args()
 

@@ -69,7 +69,7 @@ int tem_device_cus(void);
 #define TEM_WL_MFMA 1
 #define TEM_WL_BF16X3 2
 #define TEM_WL_BF16X6 3
-#define TEM_WL_F16X3 4  /* like BF16X3 with two fp16 terms per weight (22 mantissa bits) */
+#define TEM_WL_F16X3 4  /* like BF16X3 with two fp16 terms per weight (22 mantissa bits), lo plane stored x 2^12 */
 #define TEM_WL_F16 5    /* ONE fp16 term per weight (half the bytes): the mixed-precision mode, use_mfma 5 */
 #define TEM_ACT_NONE 0
 #define TEM_ACT_RELU 1
@@ -79,7 +79,7 @@ int64_t tem_conv_packed_size(int Cout, int Cin, int kd, int kh, int kw); /* floa
 int tem_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw,
                           int transpose, int layout, tem_stream_t stream);
 /* All split-layout (TEM_WL_BF16X3 / BF16X6 / F16X3) packs of a model in ONE launch.  descs_dev: device array of n
- * records { const float* w; void* dst; int32 Cout, Cin, kd, kh, kw, transpose, nsplit(1|2|3), fp16(0|1); int64 begin }
+ * records { const float* w; void* dst; int32 Cout, Cin, kd, kh, kw, transpose, nsplit(1|2|3), fp16(0 bf16 | 1 fp16 | 2 fp16 with the lo plane scaled by 2^12 = TEM_WL_F16X3); int64 begin }
  * (56 bytes each, `begin` = running offset in units of 8 weights, ascending); total = sum of Cout*Cin*taps/8.  Same result as n calls
  * of tem_conv_pack_weights. */
 int tem_conv_pack_weights_batch(const void* descs_dev, int n, int64_t total, tem_stream_t stream);

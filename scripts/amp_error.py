@@ -18,12 +18,12 @@ def run(mode, scale):
         l = loss_fn(out, y)
         (l * scale).backward()
     return out.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone() / scale, float(l)
-o32, g32, l32 = run("split", 1.0)
+o32, g32, l32 = run("split16", 1.0)
 for s in (1.0, 1024.0, 65536.0):
     o16, g16, l16 = run("amp", s)
     print(f"scale {s:8.0f}: out rel L2 {float((o16 - o32).norm() / o32.norm()):.2e}  loss {l16:.6f} vs {l32:.6f}  "
           f"grad rel L2 {float((g16 - g32).norm() / g32.norm()):.2e}  finite {bool(torch.isfinite(g16).all())}")
-for mode in ("split", "amp"):
+for mode in ("split16", "amp"):
     for _ in range(3):
         run(mode, 1024.0)
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -282,9 +282,10 @@ def test_mixed_precision_training(tmp_path):
             (loss_fn(out, y) * scale).backward()
         return out.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
 
-    out32, g32 = grads("split")
+    default = engine.PRECISION
+    out32, g32 = grads(default)
     out16, g16 = grads("amp", 1024.0)
-    assert engine.PRECISION == "split"                      # the scope restores the mode
+    assert engine.PRECISION == default                      # the scope restores the mode
     assert 1e-5 < rel_err(out16.cpu(), out32.cpu()) < 5e-3  # really fp16 operands; close to the fp32-class result
     e = float((g16 / 1024.0 - g32).norm() / g32.norm())
     assert 1e-5 < e < 5e-2, e

@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtem_hip.so")
+# TEM_LIB: developer override for A/B builds of the same C-ABI (scripts/ab_lib.sh); the product path is the in-tree file
+LIB_PATH = os.environ.get("TEM_LIB") or os.path.join(_HERE, "lib", "libtem_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 c_f32p = ctypes.c_void_p

@@ -15,6 +15,12 @@
 #define TEM_PP_RING9 1
 #endif
 static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
+#ifndef TEM_SC_WPC
+#define TEM_SC_WPC 3   // resident workgroups per CU of the fp16x3 forward kernel with 32-column tiles
+#endif
+#ifndef TEM_SC_CLAMP
+#define TEM_SC_CLAMP 1
+#endif
 #ifndef TEM_NS1_WPC
 #define TEM_NS1_WPC 4  // resident workgroups per CU of the single-product (mixed precision) forward kernel
 #endif
@@ -42,6 +48,10 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 }
 // fp16 counterparts (forward of NORMALISED activations only: |x| << 65504).  x = h + l with two fp16 terms carries 22
 // mantissa bits, so hi*hi + hi*lo + lo*hi ("fp16x3") is fp32-class (~2^-22 per product) at HALF the MFMAs of bf16x6.
+// The lo term of an O(1) operand is O(2^-12) and that of a 0.05-sized weight is 2^-16: deep in fp16's subnormal range
+// (spacing 6e-8), where it would keep only a few bits.  Both lo planes are therefore stored SCALED by 2^12 (exact), the
+// cross products hi*lo' + lo'*hi accumulate in their own fp32 accumulators and the epilogue adds them back times 2^-12.
+#define F16_LO_SCALE 4096.f
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 template <bool F16>
@@ -109,6 +119,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_bfsplit(const float* __res
                 const _Float16 hv = (_Float16)rem;
                 dst[base + p * 512 + (kh * 32 + col) * 8 + j] = __builtin_bit_cast(unsigned short, hv);
                 rem -= (float)hv;
+                if (fp16 == 2) rem *= F16_LO_SCALE;
             } else {
                 const unsigned short hb = bf16_bits(rem);
                 dst[base + p * 512 + (kh * 32 + col) * 8 + j] = hb;
@@ -120,7 +131,8 @@ __global__ __launch_bounds__(256) void k_pack_weights_bfsplit(const float* __res
 
 int tem_pack_weights_bf16x3(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw, int transpose,
                             int nsplit, hipStream_t s) {
-    const int fp16 = nsplit == 4 || nsplit == 5;  // nsplit 4 = fp16x3: two fp16 planes; 5 = fp16: one plane
+    // nsplit 4 = fp16x3: two fp16 planes, the lo plane scaled by 2^12 (fp16 = 2); 5 = fp16: one plane (fp16 = 1)
+    const int fp16 = nsplit == 4 ? 2 : (nsplit == 5 ? 1 : 0);
     if (fp16) nsplit = nsplit == 4 ? 2 : 1;
     int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
     TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: split-bf16 layout needs Cin%%16==0, Cout%%32==0");
@@ -178,6 +190,10 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const PackDesc* __re
                     pk[q] = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
                     rem[2 * q] -= (float)a;
                     rem[2 * q + 1] -= (float)b;
+                    if (d.fp16 == 2) {
+                        rem[2 * q] *= F16_LO_SCALE;
+                        rem[2 * q + 1] *= F16_LO_SCALE;
+                    }
                 } else {
                     const unsigned short a = bf16_bits(rem[2 * q]), b = bf16_bits(rem[2 * q + 1]);
                     pk[q] = (unsigned)a | ((unsigned)b << 16);
@@ -204,7 +220,7 @@ extern "C" int tem_conv_pack_weights_batch(const void* descs_dev, int n, int64_t
 // used for the forward pass, whose rounding noise the gradient amplifies (engine.py, PRECISION).
 // ---------------------------------------------------------------------------
 template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false>
-__global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_bfsplit(
+__global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM_SC_WPC : (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_bfsplit(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
@@ -243,13 +259,18 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (NR == 2 || NS == 3) ?
         const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
         abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;  // + 8 floats (32 B) per further plane
     }
+    constexpr bool SC = F16 && NS == 2;        // fp16x3: scaled lo planes, cross products in their own accumulators
     floatx16 acc[2][NR];
+    floatx16 accl[SC ? 2 : 1][SC ? NR : 1];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int nn = 0; nn < NR; ++nn)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
+            for (int i = 0; i < 16; ++i) {
+                acc[m][nn][i] = 0.f;
+                if (SC) accl[SC ? m : 0][SC ? nn : 0][i] = 0.f;
+            }
 
     const int cin16 = Cin >> 4;
     const int c4 = tid & 3;
@@ -302,6 +323,12 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (NR == 2 || NS == 3) ?
             const int hv = (tid + it * 256) >> 2;
             if (hv < HV) {
                 float e[4] = {tmp[it].x, tmp[it].y, tmp[it].z, tmp[it].w};
+                if (F16 && TEM_SC_CLAMP) {
+                    // an activation beyond the fp16 range (|x^| > 6e4 after the norm: not a training state) saturates
+                    // instead of turning the whole receptive field into NaN
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) e[c] = __builtin_amdgcn_fmed3f(e[c], -60000.f, 60000.f);
+                }
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     const unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
@@ -311,6 +338,12 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (NR == 2 || NS == 3) ?
                         e[1] -= hi16<F16>(h0);
                         e[2] -= lo16<F16>(h1);
                         e[3] -= hi16<F16>(h1);
+                        if (SC) {
+                            e[0] *= F16_LO_SCALE;
+                            e[1] *= F16_LO_SCALE;
+                            e[2] *= F16_LO_SCALE;
+                            e[3] *= F16_LO_SCALE;
+                        }
                     }
                 }
             }
@@ -363,12 +396,24 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (NR == 2 || NS == 3) ?
 #pragma unroll
                         for (int i = 0; i <= sum; ++i) {
                             const int j = sum - i;
-                            acc[m][nn] = mfma16<F16>(af[m][i], bq[tap % RD][nn][j], acc[m][nn]);
+                            if (SC && sum == 1)
+                                accl[SC ? m : 0][SC ? nn : 0] = mfma16<F16>(af[m][i], bq[tap % RD][nn][j], accl[SC ? m : 0][SC ? nn : 0]);
+                            else
+                                acc[m][nn] = mfma16<F16>(af[m][i], bq[tap % RD][nn][j], acc[m][nn]);
                         }
                 }
         }
     }
 
+    if (SC) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    acc[m][nn][i] = fmaf(accl[SC ? m : 0][SC ? nn : 0][i], 1.f / F16_LO_SCALE, acc[m][nn][i]);
+    }
 #pragma unroll
     for (int nn = 0; nn < NR; ++nn) {
         const int co = (cot * NR + nn) * 32 + r;

@@ -39,6 +39,14 @@ _FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
 #   "split"  as "mixed", but the forward convolutions use "bf16x6": three bf16 terms per operand (all
 #            24 mantissa bits) and the six products of order <= 2^-16 -- per-product error ~2^-23,
 #            the fp32 class, at 16/6 of the exact-fp32 MFMA rate (417 TFLOP/s effective peak).
+#   "split16" (DEFAULT) as "split", except that forward convolutions whose input is PRE-NORMALISED (fused InstanceNorm /
+#            GroupNorm / BatchNorm in front, i.e. every 3x3x3 conv of a ConvBlock) use "fp16x3": x = hi + lo' * 2^-12 with
+#            two fp16 terms (22 mantissa bits; the lo plane is stored scaled by 2^12 so that it stays out of fp16's
+#            subnormal range), hi*hi in one fp32 accumulator and hi*lo' + lo'*hi in a second one that the epilogue adds
+#            back times 2^-12 -- per-product error ~2^-22, still the fp32 class, at HALF the MFMAs of bf16x6 (833
+#            TFLOP/s effective peak).  Gradient error against float64 equals the fp32 reference path's own
+#            (tests/test_gpu_unet.py: 3.5e-4 / 5.9e-6 / 1.3e-3 vs 3.8e-4 / 8.6e-5 / 1.3e-3).  Raw-activation inputs
+#            (norm=None nets, 1x1x1 convs) keep bf16x6: no range assumption there.
 #   "bf16x3" forward in bf16x3 too (forward noise 1e-5: NOT parity-grade, see below).
 #   "amp"    mixed precision, the counterpart of the reference's torch.autocast(float16) default on GPUs: conv operands
 #            rounded to fp16, ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation, fp32 storage; needs loss
@@ -50,7 +58,7 @@ _FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
 # gradient; tests/test_gpu_unet.py) -- so 1e-5 forward noise would cost ~5e-3 in the gradients.
 # The backward convolutions are LINEAR in the incoming gradient with masks fixed by the forward
 # pass, so their 1e-5 error is not amplified.
-PRECISION = os.environ.get("TEM_PRECISION", "split")
+PRECISION = os.environ.get("TEM_PRECISION", "split16")
 
 
 def set_precision(mode: str):
@@ -113,7 +121,7 @@ class ConvSpec:
     def _modes(self):
         mode_f = {"bf16x3": 2, "split": 3, "split16": 3, "amp": 5}.get(PRECISION, 1)
         if PRECISION == "split16" and self.norm is not None and self.k != (1, 1, 1):
-            mode_f = 4  # fp16x3: the conv reads pre-normalised activations (|x| of order 1..100 << 65504)
+            mode_f = 4  # fp16x3: the conv reads pre-normalised activations (|x^| of order 1..100 << 65504; clamped at 6e4)
         mode_d = 5 if PRECISION == "amp" else 2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
         mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
         md = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k) else 0
@@ -169,7 +177,7 @@ def _repack_stale():
             mode = ent[key + "_mfma"]
             if mode in (2, 3, 4, 5):
                 jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
-                             3 if mode == 3 else 1 if mode == 5 else 2, 1 if mode in (4, 5) else 0))
+                             3 if mode == 3 else 1 if mode == 5 else 2, 2 if mode == 4 else 1 if mode == 5 else 0))
             else:
                 rest.append((ent, key, w, bool(transpose), mode))
         ent["version"] = w._version
