@@ -22,6 +22,8 @@ w = torch.randn(Cout, Cin, 3, 3, 3, device=dev) * 0.05
 b = torch.randn(Cout, device=dev)
 scale = torch.rand(N, Cin, device=dev) + 0.5
 shift = torch.randn(N, Cin, device=dev)
+if os.environ.get("TEM_NOSCALE"):  # dgrad-like launch: no fused pre-norm
+    scale = shift = None
 y = torch.empty(N, D, H, W, Cout, device=dev)
 g = torch.randn(N, D, H, W, Cout, device=dev)
 MODE = int(os.environ.get("TEM_MODE", "1"))

@@ -331,7 +331,12 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                 }
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
-                    const unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
+                    unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
+                    if (TEM_ABLATE & 2048) {  // what a pre-split (hi|lo packed) operand would cost: one v_perm per pair
+                        const unsigned sel = p == 0 ? 0x07060302u : 0x05040100u;
+                        h0 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, tmp[it].y), __builtin_bit_cast(unsigned, tmp[it].x), sel);
+                        h1 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, tmp[it].w), __builtin_bit_cast(unsigned, tmp[it].z), sel);
+                    }
                     if (!(TEM_ABLATE & 16)) *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
                     if (p + 1 < NS) {
                         e[0] -= lo16<F16>(h0);
