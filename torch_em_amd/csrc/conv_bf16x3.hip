@@ -15,6 +15,9 @@
 #define TEM_PP_RING9 1
 #endif
 static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
+#ifndef TEM_SPLIT_N
+#define TEM_SPLIT_N 1  // NR == 2 workgroups: waves tiled 2 (voxel halves) x 2 (column tiles) instead of 4 x (64 voxels, 64 columns)
+#endif
 #ifndef TEM_SC_WPC
 #define TEM_SC_WPC 3   // resident workgroups per CU of the fp16x3 forward kernel with 32-column tiles
 #endif
@@ -232,6 +235,14 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
     constexpr int NIT = (HV * 4 + 255) / 256;
     constexpr int RD = (NT % 3 == 0) ? 3 : 1;  // weight-fragment ring depth over taps
     constexpr int LSV = NS * 8 + 4;            // LDS floats per halo voxel: NS planes of 16 bf16 (32 B) + 16 B pad
+    // Wave tiling.  The vector-memory pipe (TA) is as loaded as the matrix pipe: per 16-channel chunk a workgroup pulls
+    // 38 KB of halo but 27 taps x NS KB of weight fragments PER WAVE through it.  With two 32-column tiles per workgroup
+    // (NR == 2) the waves are arranged 2 (voxel halves) x 2 (column tiles): a wave owns 4 M-tiles x 1 column tile, so it
+    // loads HALF the weight fragments per MFMA and reads twice the A fragments from LDS instead (LDS reads are not the
+    // limiter: serving the three tx taps from one read changed nothing).  NR == 1: 4 waves x (2 M-tiles x 1 tile).
+    constexpr bool SN = (NR == 2) && TEM_SPLIT_N;
+    constexpr int MT = SN ? 4 : 2;             // M-tiles (32 voxels) per wave
+    constexpr int NW = SN ? 1 : NR;            // column tiles per wave
     static_assert(TZ * TY * TX == 256, "patch must hold 256 voxels");
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [HV][LSV]
 
@@ -252,20 +263,22 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
     const int ks = bid / N;
     const int z0 = ptz * TZ, y0 = pty * TY, x0 = ptx * TX;
 
-    int abase[2];
+    const int pw0 = SN ? (wv & 1) * 128 : wv * 64;  // first patch voxel of this wave
+    const int nw0 = SN ? (wv >> 1) : 0;             // first column tile of this wave
+    int abase[MT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int p = wv * 64 + m * 32 + r;
+    for (int m = 0; m < MT; ++m) {
+        const int p = pw0 + m * 32 + r;
         const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
         abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;  // + 8 floats (32 B) per further plane
     }
     constexpr bool SC = F16 && NS == 2;        // fp16x3: scaled lo planes, cross products in their own accumulators
-    floatx16 acc[2][NR];
-    floatx16 accl[SC ? 2 : 1][SC ? NR : 1];
+    floatx16 acc[MT][NW];
+    floatx16 accl[SC ? MT : 1][SC ? NW : 1];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int nn = 0; nn < NR; ++nn)
+        for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 acc[m][nn][i] = 0.f;
@@ -279,15 +292,15 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
     // uint4 index of this lane's slot: ((((nt*NT + tap)*cin16 + c16)*NS + plane)*64 + lane)
     constexpr int FR = NS * 64;                // uint4s per (tap, c16) fragment group
     const int tapstride = cin16 * FR;
-    const uint4* wq[NR];
+    const uint4* wq[NW];
 #pragma unroll
-    for (int nn = 0; nn < NR; ++nn) wq[nn] = wp + (int64_t)(cot * NR + nn) * NT * cin16 * FR + lane;
-    uint4 bq[RD][NR][NS];
+    for (int nn = 0; nn < NW; ++nn) wq[nn] = wp + (int64_t)(cot * NR + nw0 + nn) * NT * cin16 * FR + lane;
+    uint4 bq[RD][NW][NS];
     if (RD > 1) {
 #pragma unroll
         for (int gp = 0; gp < RD - 1; ++gp)
 #pragma unroll
-            for (int nn = 0; nn < NR; ++nn)
+            for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
                 for (int p = 0; p < NS; ++p) bq[gp][nn][p] = wq[nn][(int64_t)chunk_begin * FR + gp * tapstride + p * 64];
     }
@@ -365,13 +378,13 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                 const int gp = tap + RD - 1;
                 if (gp < NT) {
 #pragma unroll
-                    for (int nn = 0; nn < NR; ++nn)
+                    for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
                         for (int p = 0; p < NS; ++p)
                             if (!(TEM_ABLATE & 2)) bq[gp % RD][nn][p] = wq[nn][(int64_t)chunk * FR + (int64_t)gp * ts + p * 64];
                 } else if (chunk + 1 < chunk_end) {
 #pragma unroll
-                    for (int nn = 0; nn < NR; ++nn)
+                    for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
                         for (int p = 0; p < NS; ++p)
                             if (!(TEM_ABLATE & 2)) bq[gp % RD][nn][p] = wq[nn][(int64_t)(chunk + 1) * FR + (int64_t)(gp - NT) * ts + p * 64];
@@ -379,20 +392,20 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                 __builtin_amdgcn_sched_barrier(0x38F);
             } else {
 #pragma unroll
-                for (int nn = 0; nn < NR; ++nn)
+                for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
                     for (int p = 0; p < NS; ++p) bq[0][nn][p] = wq[nn][(int64_t)chunk * FR + (int64_t)tap * ts + p * 64];
             }
-            uint4 af[2][NS];
+            uint4 af[MT][NS];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
                     af[m][p] = *reinterpret_cast<const uint4*>(lds + abase[m] + ((TEM_ABLATE & 1) ? 0 : toff) + p * 8);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int nn = 0; nn < NR; ++nn) {
+                for (int nn = 0; nn < NW; ++nn) {
                     // smallest terms first: all plane pairs (i, j) with i + j <= NS - 1 (0-based).  (Product-major
                     // issue, which helps the wgrad kernel, is 10 % SLOWER here: accumulator-major lets the MFMAs of
                     // m = 0 start while the A fragments of m = 1 are still in flight.)
@@ -412,23 +425,23 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
 
     if (SC) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int nn = 0; nn < NR; ++nn)
+            for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     acc[m][nn][i] = fmaf(accl[SC ? m : 0][SC ? nn : 0][i], 1.f / F16_LO_SCALE, acc[m][nn][i]);
     }
 #pragma unroll
-    for (int nn = 0; nn < NR; ++nn) {
-        const int co = (cot * NR + nn) * 32 + r;
+    for (int nn = 0; nn < NW; ++nn) {
+        const int co = (cot * NR + nw0 + nn) * 32 + r;
         const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                const int p = wv * 64 + m * 32 + row;
+                const int p = pw0 + m * 32 + row;
                 const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
                 const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
                 if (gz < D && gy < H && gx < W) {
