@@ -43,8 +43,8 @@ RP_NAMES = {
     "k_conv_fwd_f16<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 1, true>",
     "k_conv_wgrad_f16<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, true>",
     "k_conv_wgrad_f16<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, true>",
-    "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_zs<2>",
-    "k_conv_wgrad_bf16x3<3,3,3,NCO=1>": "k_conv_wgrad_zs<1>",
+    "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, false>",
+    "k_conv_wgrad_bf16x3<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, false>",
 }
 
 PRECISION_DTYPE = {

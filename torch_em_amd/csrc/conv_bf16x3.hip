@@ -18,6 +18,18 @@ static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
 #ifndef TEM_SPLIT_N
 #define TEM_SPLIT_N 1  // NR == 2 workgroups: waves tiled 2 (voxel halves) x 2 (column tiles) instead of 4 x (64 voxels, 64 columns)
 #endif
+#ifndef TEM_SC_RD
+#define TEM_SC_RD 1   // weight ring depth of that kernel (must divide the tap count: 1, 3 or 9); 3 spills 11 VGPRs: +1.5 % step time
+#endif
+#ifndef TEM_X3_RD1
+#define TEM_X3_RD1 3   // bf16x3 kernel (dgrad / no-grad forward), 32-column tiles
+#endif
+#ifndef TEM_X3_RD2
+#define TEM_X3_RD2 3   // bf16x3 kernel, 64-column tiles
+#endif
+#ifndef TEM_SC2_RD
+#define TEM_SC2_RD 3
+#endif
 #ifndef TEM_SC_WPC
 #define TEM_SC_WPC 3   // resident workgroups per CU of the fp16x3 forward kernel with 32-column tiles
 #endif
@@ -233,7 +245,8 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
     constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
     constexpr int HV = HZ * HY * HX;
     constexpr int NIT = (HV * 4 + 255) / 256;
-    constexpr int RD = (NT % 3 == 0) ? 3 : 1;  // weight-fragment ring depth over taps
+    constexpr int RD = (NT % 3 == 0) ? ((F16 && NS == 2) ? (NR == 1 ? TEM_SC_RD : TEM_SC2_RD) : (NS == 2 ? (NR == 1 ? TEM_X3_RD1 : TEM_X3_RD2) : 3)) : 1;  // weight-fragment ring depth over taps
+    static_assert(NT % RD == 0, "the ring slot of a tap must not depend on the chunk");
     constexpr int LSV = NS * 8 + 4;            // LDS floats per halo voxel: NS planes of 16 bf16 (32 B) + 16 B pad
     // Wave tiling.  The vector-memory pipe (TA) is as loaded as the matrix pipe: per 16-channel chunk a workgroup pulls
     // 38 KB of halo but 27 taps x NS KB of weight fragments PER WAVE through it.  With two 32-column tiles per workgroup
