@@ -193,10 +193,17 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if rank == 0 and dom_tag is not None:
-        ops.PROFILER, ops.PROFILER_FILTER = [], {dom_tag}
+    # Events on the dominant kernel's launches in a SAMPLE of the timed steps (default 2 of them, evenly spaced): an
+    # event pair costs ~35 us of dispatch overlap, and the kernel that leads the step now has 14 launches per step
+    # (0.5 ms/step = 2 % of `value` if every step carried them).  TEM_BENCH_EVENT_STEPS=<n> samples n steps (>= steps: all).
+    n_ev = max(1, min(args.steps, int(os.environ.get("TEM_BENCH_EVENT_STEPS", "2"))))
+    ev_steps = {(i * args.steps) // n_ev for i in range(n_ev)} if (rank == 0 and dom_tag is not None) else set()
+    if ev_steps:
+        ops.PROFILER = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if ev_steps:
+            ops.PROFILER_FILTER = {dom_tag} if i in ev_steps else set()
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -278,7 +285,8 @@ def main():
                          "peak_note": (f"dense bf16 MFMA peak 2500 TFLOP/s / {split} MFMAs per product (split-bf16, fp32 "
                                        "accumulate); executed-MFMA fraction of 2500 = frac" if split else
                                        "exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
-                         "launches_per_step": dom["launches"] // args.steps,
+                         "launches_per_step": dom["launches"] // max(len(ev_steps), 1),
+                         "event_steps": sorted(ev_steps),
                          "avg_launch_ms": dom["ms"] / dom["launches"],
                          "flops_per_launch_avg": dom["flops"] / dom["launches"]},
         }
