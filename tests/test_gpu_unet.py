@@ -211,6 +211,50 @@ def test_benchmark_config_full_size_properties():
     assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
 
 
+def test_affinity_config_full_size_properties():
+    """BASELINE cfg 3 at its full size (AnisotropicUNet 1->12 + Sigmoid, 2x1x64x256x256, masked Dice on 12 affinity
+    channels): the CPU oracle needs minutes there, so the size-independent properties of the path are checked instead
+    -- bitwise determinism; samples are independent (InstanceNorm: sample 0 of the batch == sample 0 alone); the
+    backward pass is linear in the incoming gradient (scaling the loss by 2 scales every gradient by exactly 2); the
+    masked loss sends no gradient into masked-out voxels; the device-side affinity targets equal the numpy oracle."""
+    from oracle import label_ref
+    from torch_em_amd.loss import ApplyAndRemoveMask, DiceLoss, LossWrapper
+    from torch_em_amd.model import AnisotropicUNet
+    from torch_em_amd.transform.label import AffinityTransform, BatchTargets
+    torch.manual_seed(0)
+    sf = [[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]]
+    model = AnisotropicUNet(1, 12, scale_factors=sf, initial_features=32, final_activation="Sigmoid").to(DEV)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 1, 64, 256, 256, generator=g).to(DEV)
+    lbl = torch.randint(0, 50, (2, 1, 8, 16, 16), generator=g).repeat_interleave(8, 2).repeat_interleave(16, 3) \
+        .repeat_interleave(16, 4)
+    offsets = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0], [0, 0, -3], [-3, 0, 0], [0, -9, 0], [0, 0, -9],
+               [-4, 0, 0], [0, -27, 0], [0, 0, -27]]
+    target = BatchTargets(AffinityTransform(offsets=offsets, add_mask=True))(lbl.to(DEV))
+    assert np.array_equal(target[0].cpu().numpy(), label_ref.affinities(lbl[0, 0].numpy(), offsets, add_mask=True))
+    loss_fn = LossWrapper(DiceLoss(), ApplyAndRemoveMask(masking_method="multiply"))
+
+    def run(scale=1.0, xin=x, tgt=target, keep_pred_grad=False):
+        model.zero_grad()
+        pred = model(xin)
+        got = {}
+        if keep_pred_grad:
+            pred.register_hook(lambda gr: got.setdefault("g", gr.detach().clone()))
+        loss = loss_fn(pred, tgt)
+        (loss * scale).backward()
+        return pred.detach().clone(), float(loss), [p.grad.clone() for p in model.parameters()], got.get("g")
+
+    p1, l1, g1, gp = run(keep_pred_grad=True)
+    p2, l2, g2, _ = run()
+    assert np.isfinite(l1) and l1 == l2 and torch.equal(p1, p2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert float(p1.min()) >= 0.0 and float(p1.max()) <= 1.0                      # Sigmoid epilogue
+    assert float((gp * (1.0 - target[:, 12:])).abs().max()) == 0.0                # masked voxels get no gradient
+    _, _, g4, _ = run(scale=2.0)
+    assert all(torch.equal(2.0 * a, b) for a, b in zip(g1, g4))                    # backward is linear, bit for bit
+    p0, _, _, _ = run(xin=x[:1], tgt=target[:1])
+    assert rel_err(p0[0].cpu(), p1[0].cpu()) < 1e-5                                # per-sample statistics only
+
+
 def test_side_outputs_golden_and_mfma_size():
     """return_side_outputs=True: the reference's golden case (narrow net), then an MFMA-width net against the float64
     oracle (outputs TOL; gradients: every tensor within 1e-2 and the whole gradient within 2e-3 in relative L2 -- the
