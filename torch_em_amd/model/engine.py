@@ -226,11 +226,6 @@ def _conv(spec: ConvSpec, x, y, stats=None, act=None):
     ops.conv_fwd(x, wpk, spec.conv.bias, y, spec.k, spec.cin, spec.cout, scale=scale, shift=shift, act=act, mfma=mode)
 
 
-def _dgrad(spec: ConvSpec, g, gx, ref=None):
-    ent = spec.packed()
-    ops.conv_fwd(g, ent["dgrad"], None, gx, spec.k, spec.cout, spec.cin, ref=ref, mfma=ent["dgrad_mfma"])
-
-
 class _Grads:
     """Flat fp32 gradient arena (layout: torch_em_amd.arena.arena_layout, `model.parameters()` order).
     Tracks which element ranges backward has produced so that a data-parallel `GradSync` can
@@ -266,12 +261,19 @@ class _Grads:
         return [tuple(r) for r in out]
 
 
-# Weight gradients are leaves of the backward pass (nothing downstream in it reads dw), so they CAN run on a second HIP
-# stream next to the dgrad / norm / pool kernels of the main stream.  Measured (scripts/ab_bench.sh TEM_OVERLAP_WGRAD):
-# +1.3 ms/step when every layer overlaps (the wgrad and dgrad workgroups cannot co-reside: 101 KB + 2 x 67 KB of LDS),
-# +-0 within noise when only the <= 32^3 levels overlap -- off by default.
-_OVERLAP_WGRAD = os.environ.get("TEM_OVERLAP_WGRAD", "0") != "0"
-_OVERLAP_MAX_VOXELS = int(os.environ.get("TEM_OVERLAP_MAX_VOXELS", str(2 * 32 ** 3)))
+# Weight gradients are leaves of the backward pass (nothing downstream in it reads dw), so they can run on a second HIP
+# stream.  Two schedules were measured (TEM_OVERLAP_WGRAD):
+#   1  "free": wgrad starts as soon as its inputs exist, i.e. next to the dgrad of the same layer: +1.3 ms/step -- the
+#      two MFMA kernels cannot co-reside on a CU (101 KB + 2 x 67 KB of LDS) and fight for the same pipes;
+#   2  "deferred": a layer's dgrad runs first, ALONE; its wgrad then runs on the side stream next to the HBM-bound
+#      kernels that follow on the main stream (norm backward: two passes; pool / upsample backward), which need neither
+#      LDS nor the matrix pipe; the next dgrad waits for the side stream.  On paper the critical path becomes
+#      sum(dgrad) + sum(max(wgrad, norm/pool backward)); measured +0.4 ms/step (24.9 vs 24.5): the z-sliding wgrad
+#      kernel owns a CU's whole register file (2 waves/SIMD x 256 VGPRs) and >100 KB of its LDS, so no norm-kernel
+#      wave can co-reside -- the two kernels time-slice CUs instead of sharing them;
+#   0  (default) everything on one stream.
+_OVERLAP_WGRAD = int(os.environ.get("TEM_OVERLAP_WGRAD", "0"))
+_OVERLAP_MAX_VOXELS = int(os.environ.get("TEM_OVERLAP_MAX_VOXELS", str(2 * 32 ** 3)))  # mode 1 only
 _SIDE_STREAMS = {}
 
 
@@ -289,17 +291,26 @@ def _join_side(device):
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
+def _dgrad(spec: ConvSpec, g, gx, ref=None):
+    if _OVERLAP_WGRAD == 2:
+        _join_side(g.device)  # MFMA kernels never overlap each other: wait for the weight gradient in flight
+    ent = spec.packed()
+    ops.conv_fwd(g, ent["dgrad"], None, gx, spec.k, spec.cout, spec.cin, ref=ref, mfma=ent["dgrad_mfma"])
+
+
 def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None):
     ent = spec.packed()
     scale, shift = (stats[2], stats[3]) if stats is not None else (None, None)
     dw = grads.view(spec.conv.weight)
     db = grads.view(spec.conv.bias) if spec.conv.bias is not None else None
     vox = x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3]
-    if not _OVERLAP_WGRAD or vox > _OVERLAP_MAX_VOXELS:  # big layers fill the chip alone: concurrency only adds contention
+    if not _OVERLAP_WGRAD or (_OVERLAP_WGRAD == 1 and vox > _OVERLAP_MAX_VOXELS):
         ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
         return
     side = _side_stream(x.device)
-    side.wait_stream(torch.cuda.current_stream(x.device))  # x, g, scale/shift were produced on the main stream
+    # x, g, scale/shift were produced on the main stream; in mode 2 this also orders the wgrad BEHIND the dgrad of the
+    # same layer, which the callers launch first
+    side.wait_stream(torch.cuda.current_stream(x.device))
     with torch.cuda.stream(side):
         ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
     for t in (x, g, scale, shift):  # the caching allocator must not recycle them while the side stream reads
@@ -391,21 +402,24 @@ def _block_bwd(bs, gout, gin, grads: _Grads):
     """gout: gradient w.r.t. the block's pre-ReLU conv2 output (i.e. already ReLU-masked).
     gin: buffer for the gradient w.r.t. the block input, or None when not needed."""
     c1, c2, xin, a1 = bs["c1"], bs["c2"], bs["xin"], bs["a1"]
-    _wgrad(c2, a1, gout, grads, bs["s2"])
+    # per layer: dgrad first (alone), then the weight gradient (side stream, see _OVERLAP_WGRAD) next to the norm backward
     ga1 = torch.empty_like(a1)
     if bs["s2"] is not None:
         _dgrad(c2, gout, ga1)
+        _wgrad(c2, a1, gout, grads, bs["s2"])
         _norm_bwd_inplace(c2, ga1, a1, bs["s2"], True, grads)  # a1 is a ReLU output: mask fused
     else:
         _dgrad(c2, gout, ga1, ref=a1)
-    _wgrad(c1, xin, ga1, grads, bs["s1"])
+        _wgrad(c2, a1, gout, grads, bs["s2"])
     affine1 = bs["s1"] is not None and c1.norm_args()[1] is not None
     if gin is None and not affine1:
+        _wgrad(c1, xin, ga1, grads, bs["s1"])
         return
     if gin is None:
         N, D, H, W, _ = xin.shape
         gin = ops.new_act(N, D, H, W, c1.cin, xin.device)
     _dgrad(c1, ga1, gin)
+    _wgrad(c1, xin, ga1, grads, bs["s1"])
     if bs["s1"] is not None:
         _norm_bwd_inplace(c1, gin, xin, bs["s1"], False, grads)
 
@@ -556,9 +570,9 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         gs = _from_logical(gi.float(), dim)
         if st["act"] is not None:
             gs = ops.act_bwd(gs, side[i]["y"], st["act"])
-        _wgrad(side[i]["ospec"], feat, gs, grads)
         out = torch.empty_like(feat)
         _dgrad(side[i]["ospec"], gs, out, ref=feat)
+        _wgrad(side[i]["ospec"], feat, gs, grads)
         return out
 
     g = _from_logical(gy.float(), dim)
@@ -567,9 +581,9 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         g = ops.act_bwd(g, y, st["act"])
     last = st["last"]
     if "ospec" in st:
-        _wgrad(st["ospec"], last, g, grads)
         g_cur = torch.empty_like(last)
         _dgrad(st["ospec"], g, g_cur, ref=last)
+        _wgrad(st["ospec"], last, g, grads)
     else:
         g_cur = torch.empty_like(last)
         ops.maxpool_bwd(g, last, g_cur, (1, 1, 1), relu_mask=True)
@@ -581,9 +595,9 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         low, sspec = d["low"], d["sspec"]
         g_t = ops.new_act(low.shape[0], low.shape[1], low.shape[2], low.shape[3], sspec.cout, low.device)
         ops.upsample_bwd(g_cat[..., :lv["c_up"]], g_t, d["f"])
-        _wgrad(sspec, low, g_t, grads)
         g_low = torch.empty_like(low)
         _dgrad(sspec, g_t, g_low, ref=low)  # `low` is the ReLU output of the previous block
+        _wgrad(sspec, low, g_t, grads)
         if side is not None and i > 0:
             extra = side_grad(i - 1, low)  # `low` is decoder level i-1's output
             if extra is not None:
