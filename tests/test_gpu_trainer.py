@@ -72,6 +72,13 @@ def test_default_trainer_matches_oracle_training(tmp_path):
     # the reference class can read what we wrote
     sd = torch.load(os.path.join(trainer.checkpoint_folder, "best.pt"), weights_only=False)["model_state"]
     assert all(torch.is_tensor(v) for v in sd.values())
+    # util.load_model / get_trainer (reference util/util.py:366-460): class + kwargs from the `init` record
+    from torch_em_amd import util
+    loaded = util.load_model(trainer.checkpoint_folder, name="latest", device=DEV)
+    ref = torch.load(os.path.join(trainer.checkpoint_folder, "latest.pt"), weights_only=False)
+    assert isinstance(loaded, UNet3d)
+    assert all(torch.equal(v.cpu(), ref["model_state"][k].cpu()) for k, v in loaded.state_dict().items())
+    assert util.get_trainer(trainer.checkpoint_folder, name="latest", device=DEV).iteration == ref["iteration"]
 
 
 def test_fused_adamw_single_launch_path_and_state_dict():

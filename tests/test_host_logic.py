@@ -185,3 +185,41 @@ def test_grad_scaler_policy():
     assert off.get_scale() == 1.0 and off.state_dict() == {} and float(off.scale(torch.tensor(2.0))) == 2.0
     with pytest.raises(ValueError):
         GradScaler(growth_factor=1.0)
+
+
+def test_util_helpers(tmp_path):
+    """torch_em_amd.util mirrors the reference helpers that consume checkpoints and normalise array ranks
+    (util/util.py:77-229, 299-469); the rank cases follow the reference's assertions."""
+    from torch_em_amd import util
+    a = np.arange(24, dtype="uint16").reshape(2, 3, 4)
+    t = util.ensure_tensor(a)
+    assert t.dtype == torch.int32 and torch.equal(t, torch.arange(24, dtype=torch.int32).reshape(2, 3, 4))
+    assert util.ensure_tensor(a.astype(">f4")).dtype == torch.float32           # foreign byte order
+    ro = np.zeros((2, 2), "float32")
+    ro.flags.writeable = False
+    assert util.ensure_tensor(ro, torch.float64).dtype == torch.float64
+    cases = [((5, 6), 2, (1, 5, 6)), ((3, 5, 6), 2, (3, 5, 6)), ((1, 3, 5, 6), 2, (3, 5, 6)), ((1, 1, 3, 5, 6), 2, (3, 5, 6)),
+             ((4, 5, 6), 3, (1, 4, 5, 6)), ((2, 4, 5, 6), 3, (2, 4, 5, 6)), ((1, 2, 4, 5, 6), 3, (2, 4, 5, 6)),
+             ((2, 4, 5, 6), 4, (2, 4, 5, 6)), ((1, 2, 4, 5, 6), 4, (2, 4, 5, 6))]
+    for shape, nd, want in cases:
+        assert tuple(util.ensure_tensor_with_channels(np.zeros(shape, "float32"), nd).shape) == want, (shape, nd)
+    with pytest.raises(AssertionError):
+        util.ensure_tensor_with_channels(np.zeros((2, 3, 5, 6), "float32"), 2)
+    assert util.ensure_spatial_array(torch.zeros(1, 1, 5, 6), 2).shape == (5, 6)
+    assert util.ensure_spatial_array(np.zeros((1, 4, 5, 6)), 3, "float32").dtype == np.float32
+    with pytest.raises(AssertionError):
+        util.ensure_spatial_array(np.zeros((2, 5, 6)), 2)
+    # checkpoints: bare state file, trainer-style file with `model_state`, compiled-model prefixes
+    m1, m2 = UNet3d(1, 2, depth=1, initial_features=4), UNet3d(1, 2, depth=1, initial_features=4)
+    assert not util.model_is_equal(m1, m2)
+    torch.save({"model_state": {"_orig_mod." + k: v for k, v in m1.state_dict().items()}}, tmp_path / "best.pt")
+    util.load_model(str(tmp_path), m2)
+    assert util.model_is_equal(m1, m2)
+    torch.save(m1.state_dict(), tmp_path / "bare.pt")
+    m3 = util.load_model(str(tmp_path / "bare.pt"), UNet3d(1, 2, depth=1, initial_features=4), state_key=None)
+    assert util.model_is_equal(m1, m3)
+    assert util.get_constructor_arguments(m1) == m1.init_kwargs
+    dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(torch.zeros(4, 1)), batch_size=2, shuffle=True)
+    kw = util.get_constructor_arguments(dl)
+    assert kw["batch_size"] == 2 and kw["shuffle"] is True and kw["num_workers"] == 0
+    assert util.get_constructor_arguments(torch.optim.SGD(m1.parameters(), lr=0.1)) == {}
