@@ -407,13 +407,16 @@ def dice_grad(p, t, mask, ca, cb, gout, gout_per_channel, channels_last: bool):
 def bump_versions(tensors):
     """The kernels below write parameters through raw pointers, which autograd's version counters do not see;
     consumers that cache derived data per `tensor._version` (the engine's packed weight fragments) must be
-    told.  One host call per tensor, no device work."""
+    told.  ONE host call for all of them, no device work.  (`_increment_version` takes an iterable of tensors: handing
+    it a single tensor makes it iterate over the tensor's ROWS -- 512 view objects for a [512, 512, 3, 3, 3] weight;
+    46 such calls were 6.5 ms of host time per optimizer step.)"""
+    tensors = list(tensors)
     inc = getattr(torch._C, "_increment_version", None)
-    for t in tensors:
-        if inc is not None:
-            inc(t)
-        else:  # pragma: no cover -- very old torch: a no-op in-place op bumps the counter
-            t.add_(0)
+    if inc is not None:
+        inc(tensors)
+        return
+    for t in tensors:  # pragma: no cover -- very old torch: a no-op in-place op bumps the counter
+        t.add_(0)
 
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
