@@ -7,6 +7,33 @@
 #include "tem_common.h"
 
 #define NORM_MAX_BLOCKS 512
+#ifndef TEM_NORM_NT
+#define TEM_NORM_NT 1   // nontemporal loads / stores in the backward apply pass (streams 3 tensors once): -0.1 ms/step
+#endif
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+    floatx4_t v = __builtin_nontemporal_load(reinterpret_cast<const floatx4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float* p, float4 v) {
+    floatx4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<floatx4_t*>(p));
+}
+#ifndef TEM_NORM_NT2
+#define TEM_NORM_NT2 0
+#endif
+#if TEM_NORM_NT2
+#define NT2_LOAD4(p) nt_load4(p)
+#else
+#define NT2_LOAD4(p) (*reinterpret_cast<const float4*>(p))
+#endif
+#if TEM_NORM_NT
+#define NT_LOAD4(p) nt_load4(p)
+#define NT_STORE4(p, v) nt_store4(p, v)
+#else
+#define NT_LOAD4(p) (*reinterpret_cast<const float4*>(p))
+#define NT_STORE4(p, v) (*reinterpret_cast<float4*>(p) = (v))
+#endif
 #define NORM_MAX_C 1024
 
 struct NormGeom {
@@ -82,8 +109,8 @@ __global__ __launch_bounds__(VEC == 4 ? 256 : 1024) void k_norm_partial(const fl
             float4 t[4], u[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                t[k] = *reinterpret_cast<const float4*>(xb + (vs + k * (int64_t)rows) * x_ld + c0);
-                if constexpr (MODE == 1) u[k] = *reinterpret_cast<const float4*>(gb + (vs + k * (int64_t)rows) * g_ld + c0);
+                t[k] = NT2_LOAD4(xb + (vs + k * (int64_t)rows) * x_ld + c0);
+                if constexpr (MODE == 1) u[k] = NT2_LOAD4(gb + (vs + k * (int64_t)rows) * g_ld + c0);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -273,12 +300,12 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
             for (int j = 0; j < 4; ++j) k[j] = *reinterpret_cast<const float4*>(cf + (int64_t)(c0 + j) * 4);
             for (; i < items; i += 2 * stride, v += 2 * dv) {
                 const bool two = i + stride < items;
-                const float4 g4 = *reinterpret_cast<const float4*>(gb + v * gy_ld + c0);
-                const float4 x4 = *reinterpret_cast<const float4*>(xb + v * x_ld + c0);
+                const float4 g4 = NT_LOAD4(gb + v * gy_ld + c0);
+                const float4 x4 = NT_LOAD4(xb + v * x_ld + c0);
                 float4 g5 = g4, x5 = x4;
                 if (two) {
-                    g5 = *reinterpret_cast<const float4*>(gb + (v + dv) * gy_ld + c0);
-                    x5 = *reinterpret_cast<const float4*>(xb + (v + dv) * x_ld + c0);
+                    g5 = NT_LOAD4(gb + (v + dv) * gy_ld + c0);
+                    x5 = NT_LOAD4(xb + (v + dv) * x_ld + c0);
                 }
                 const float ga[4] = {g4.x, g4.y, g4.z, g4.w}, xa[4] = {x4.x, x4.y, x4.z, x4.w};
                 const float gb2[4] = {g5.x, g5.y, g5.z, g5.w}, xb2[4] = {x5.x, x5.y, x5.z, x5.w};
@@ -290,8 +317,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
                     oa[j] = (relu_mask && !(xa[j] > 0.f)) ? 0.f : ra;
                     ob2[j] = (relu_mask && !(xb2[j] > 0.f)) ? 0.f : rb;
                 }
-                *reinterpret_cast<float4*>(ob + v * gx_ld + c0) = make_float4(oa[0], oa[1], oa[2], oa[3]);
-                if (two) *reinterpret_cast<float4*>(ob + (v + dv) * gx_ld + c0) = make_float4(ob2[0], ob2[1], ob2[2], ob2[3]);
+                NT_STORE4(ob + v * gx_ld + c0, make_float4(oa[0], oa[1], oa[2], oa[3]));
+                if (two) NT_STORE4(ob + (v + dv) * gx_ld + c0, make_float4(ob2[0], ob2[1], ob2[2], ob2[3]));
             }
             return;
         }
