@@ -246,11 +246,16 @@ def test_affinity_config_full_size_properties():
 
     p1, l1, g1, gp = run(keep_pred_grad=True)
     p2, l2, g2, _ = run()
-    assert np.isfinite(l1) and l1 == l2 and torch.equal(p1, p2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert np.isfinite(l1) and l1 == l2, ("loss not reproducible", l1, l2)
+    assert torch.equal(p1, p2), ("prediction not reproducible", float((p1 - p2).abs().max()))
+    names = [k for k, _ in model.named_parameters()]
+    bad = [(k, float((a - b).abs().max())) for k, a, b in zip(names, g1, g2) if not torch.equal(a, b)]
+    assert not bad, ("gradients not reproducible", bad)
     assert float(p1.min()) >= 0.0 and float(p1.max()) <= 1.0                      # Sigmoid epilogue
     assert float((gp * (1.0 - target[:, 12:])).abs().max()) == 0.0                # masked voxels get no gradient
     _, _, g4, _ = run(scale=2.0)
-    assert all(torch.equal(2.0 * a, b) for a, b in zip(g1, g4))                    # backward is linear, bit for bit
+    bad = [(k, float((2.0 * a - b).abs().max())) for k, a, b in zip(names, g1, g4) if not torch.equal(2.0 * a, b)]
+    assert not bad, ("backward not linear bit for bit", bad)
     p0, _, _, _ = run(xin=x[:1], tgt=target[:1])
     assert rel_err(p0[0].cpu(), p1[0].cpu()) < 1e-5                                # per-sample statistics only
 

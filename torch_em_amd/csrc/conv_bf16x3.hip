@@ -30,6 +30,9 @@ static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
 #ifndef TEM_SC2_RD
 #define TEM_SC2_RD 3
 #endif
+#ifndef TEM_NT_STORE
+#define TEM_NT_STORE 1   // epilogue stores bypass the write-allocate path: the output is not re-read by this kernel (-0.3 ms/step)
+#endif
 #ifndef TEM_SC_WPC
 #define TEM_SC_WPC 3   // resident workgroups per CU of the fp16x3 forward kernel with 32-column tiles
 #endif
@@ -465,7 +468,12 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                     }
                     float o = act_apply_b(acc[m][nn][reg] + bv, act);
                     if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
-                    if (!(TEM_ABLATE & 8) || o == 12345.678f) y[v * y_ld + co] = o;
+                    if (!(TEM_ABLATE & 8) || o == 12345.678f) {
+                        if (TEM_NT_STORE)
+                            __builtin_nontemporal_store(o, y + v * y_ld + co);
+                        else
+                            y[v * y_ld + co] = o;
+                    }
                 }
             }
         }

@@ -6,6 +6,19 @@
 #include "tem_common.h"
 #include "conv_internal.h"
 
+#ifndef TEM_SMALL_NT
+#define TEM_SMALL_NT 0
+#endif
+__device__ __forceinline__ void ST4(float* p, float4 v) {
+#if TEM_SMALL_NT
+    typedef float fx4 __attribute__((ext_vector_type(4)));
+    fx4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<fx4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 __device__ __forceinline__ float act_apply_s(float v, int act) {
     if (act == TEM_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == TEM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
         acc.z = act_apply_s(acc.z, act);
         acc.w = act_apply_s(acc.w, act);
         const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
-        *reinterpret_cast<float4*>(y + v * y_ld + q * 4) = acc;
+        ST4(y + v * y_ld + q * 4, acc);
     }
 }
 
@@ -646,7 +659,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_expand(const float* __restrict_
             if (!(rr.z > 0.f)) a.z = 0.f;
             if (!(rr.w > 0.f)) a.w = 0.f;
         }
-        *reinterpret_cast<float4*>(y + v * y_ld + q * 4) = a;
+        ST4(y + v * y_ld + q * 4, a);
     }
 }
 

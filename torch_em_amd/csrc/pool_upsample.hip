@@ -15,6 +15,9 @@ struct VecT<1> {
     typedef float type;
 };
 
+#ifndef TEM_POOL_NT
+#define TEM_POOL_NT 0
+#endif
 template <int VEC>
 __device__ __forceinline__ void ld_vec(const float* p, float (&v)[VEC]) {
     if constexpr (VEC == 4) {
@@ -27,7 +30,13 @@ __device__ __forceinline__ void ld_vec(const float* p, float (&v)[VEC]) {
 template <int VEC>
 __device__ __forceinline__ void st_vec(float* p, const float (&v)[VEC]) {
     if constexpr (VEC == 4) {
+#if TEM_POOL_NT
+        typedef float fx4 __attribute__((ext_vector_type(4)));
+        fx4 t = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<fx4*>(p));
+#else
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
     } else {
         *p = v[0];
     }
