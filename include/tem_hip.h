@@ -122,6 +122,19 @@ int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float
                    int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                    int act, int use_mfma, tem_stream_t stream);
 
+/* tem_conv3d_fwd that ALSO emits the first stage of the next layer's normalisation statistics: per (sample, output
+ * patch, channel) partial sums (sum y, sum y^2) of the stored output, taken from the accumulators in the epilogue --
+ * the 2 x 128^3 x 32 output of a level-0 conv is not read back for `nn.InstanceNorm3d` / `GroupNorm` / `BatchNorm3d`
+ * (reference ConvBlock, model/unet.py:429-438: norm(conv(x))).  stat_part: [N][stat_blocks][Cout][2] floats with
+ * stat_blocks = tem_conv3d_fwd_stat_blocks(...), which returns 0 for launches that cannot provide them (VALU / exact
+ * fp32 kernels, split-K shapes): use tem_norm_stats there.  tem_norm_finalize_partials (below) merges them. */
+int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
+int tem_conv3d_fwd_stats(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                         const float* w_packed, const float* bias, float* y, int64_t y_ld,
+                         const float* ref, int64_t ref_ld, void* ws, int64_t ws_bytes,
+                         int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                         int act, int use_mfma, float* stat_part, int64_t stat_blocks, tem_stream_t stream);
+
 /* dw = sum_v xhat[v+tap][ci] * g[v][co]  (xhat = x*scale+shift, zero padded)
  * db[co] = sum_v g[v][co] (optional).  ws: workspace of tem_conv3d_wgrad_ws() bytes.
  * sd_layout != 0: dw is written in the reference's state_dict order [Cout][Cin][kd][kh][kw]
@@ -148,6 +161,12 @@ int tem_norm_stats(const float* x, int64_t x_ld, int N, int64_t V, int C, int G,
                    const float* gamma, const float* beta, float eps,
                    float* mean, float* rstd, float* scale, float* shift,
                    void* ws, int64_t ws_bytes, tem_stream_t stream);
+/* Second stage alone, for statistics whose first stage was fused into the producer (tem_conv3d_fwd_stats):
+ * part = [N][nblk][C][2] partial sums (sum x, sum x^2) over disjoint voxel blocks; same outputs as tem_norm_stats.
+ * BatchNorm: call with N = 1, nblk = N*blocks, V = N*V (the partial layout is contiguous over samples). */
+int tem_norm_finalize_partials(const float* part, int64_t nblk, int N, int64_t V, int C, int G,
+                               const float* gamma, const float* beta, float eps,
+                               float* mean, float* rstd, float* scale, float* shift, tem_stream_t stream);
 /* Backward of y = norm(x)*gamma+beta given gy:
  *   gx = rstd*(gy*gamma - mean_grp(gy*gamma) - xn*mean_grp(gy*gamma*xn)),  xn=(x-mean)*rstd
  *   [gx *= (x > 0) when relu_mask != 0: x is itself a ReLU output]

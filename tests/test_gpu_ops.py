@@ -166,6 +166,49 @@ def test_conv_mixed_precision_mode(case):
         assert rel_err(db.cpu(), gy.sum((0, 2, 3, 4))) < 5e-5   # bias gradient sums the fp32 values
 
 
+@pytest.mark.parametrize("case", [      # >= 384 workgroups each: smaller launches run split-K and cannot fuse
+    (2, 17, 50, 66, 32, 32, (3, 3, 3), 32),   # ragged patches, one column tile
+    (1, 24, 64, 64, 32, 64, (3, 3, 3), 32),   # 2x2 wave tiling, GroupNorm(32, 64)
+    (2, 8, 48, 48, 64, 96, (1, 3, 3), 96),    # three column tiles
+    (1, 1, 330, 400, 16, 64, (1, 3, 3), 64),  # 2-D patches
+    (2, 16, 64, 64, 64, 32, (1, 1, 1), 1),    # 1x1x1, a single group
+])
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_conv_fused_forward_statistics(case, mode):
+    """tem_conv3d_fwd_stats + tem_norm_finalize_partials == tem_norm_stats of the stored output (what the next
+    InstanceNorm / GroupNorm / BatchNorm of a ConvBlock needs, reference model/unet.py:429-438), without reading it."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout, k, groups = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, *k, generator=g) * 0.2).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    scale, shift = (torch.rand(N, Cin, generator=g) + 0.5).to(DEV), torch.randn(N, Cin, generator=g).to(DEV)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    x5 = to5(x)
+    y5 = ops.new_act(N, D, H, W, Cout, DEV)
+    wp = ops.pack_weights(w, transpose=False, mfma=mode)
+    got = ops.conv_fwd(x5, wp, b, y5, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=mode, want_stats=True)
+    assert got is not None
+    part, nblk = got
+    y_ref = ops.new_act(N, D, H, W, Cout, DEV)
+    ops.conv_fwd(x5, wp, b, y_ref, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=mode)
+    assert torch.equal(y5, y_ref)                                     # the output itself is unchanged
+    V = D * H * W
+    for rows in (N, 1):                                               # per-sample statistics / BatchNorm over the batch
+        if rows == 1:
+            yb = y5.reshape(1, N * D, H, W, Cout)
+            want = ops.norm_stats(yb, groups, gamma, beta, 1e-5)
+        else:
+            want = ops.norm_stats(y5, groups, gamma, beta, 1e-5)
+        have = ops.norm_stats_from_partials(part, rows, V, Cout, groups, gamma, beta, 1e-5)
+        for a, c, name in zip(have, want, ("mean", "rstd", "scale", "shift")):
+            assert a.shape == c.shape and rel_err(a.cpu(), c.cpu()) < 2e-6, (name, rows)
+    # launches that cannot provide them say so: the VALU kernels here, split-K shapes in the model tests
+    assert ops.conv_fwd(x5, ops.pack_weights(w, transpose=False, mfma=0), b, y_ref, k, Cin, Cout, scale=scale,
+                        shift=shift, act="relu", mfma=0, want_stats=True) is None
+
+
 def test_conv_relu_mask_ref_and_channel_slices():
     """ref-mask epilogue and leading-dimension (concat-buffer slice) addressing."""
     ops = _ops()

@@ -32,11 +32,16 @@ SIGNATURES = {
     "tem_conv3d_fwd_ws": (c_i64, [c_int] * 10),
     "tem_conv3d_fwd": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64]
                        + [c_int] * 11 + [c_vp]),
+    "tem_conv3d_fwd_stat_blocks": (c_i64, [c_int] * 10),
+    "tem_conv3d_fwd_stats": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64]
+                             + [c_int] * 11 + [c_vp, c_i64, c_vp]),
     "tem_conv3d_wgrad_ws": (c_i64, [c_int] * 10),
     "tem_conv3d_wgrad": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 11 + [c_vp]),
     "tem_norm_ws": (c_i64, [c_int, c_i64, c_int]),
     "tem_norm_stats": (c_int, [c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_float,
                                c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "tem_norm_finalize_partials": (c_int, [c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_float,
+                                           c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tem_norm_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
                              c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tem_maxpool3d_fwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),

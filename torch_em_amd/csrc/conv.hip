@@ -241,10 +241,10 @@ extern "C" int64_t tem_conv3d_fwd_ws(int N, int D, int H, int W, int Cin, int Co
     return tem_conv_fwd_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
 }
 
-extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift,
-                              const float* w_packed, const float* bias, float* y, int64_t y_ld, const float* ref,
-                              int64_t ref_ld, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout,
-                              int kd, int kh, int kw, int act, int use_mfma, tem_stream_t stream) {
+static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                           const float* w_packed, const float* bias, float* y, int64_t y_ld, const float* ref,
+                           int64_t ref_ld, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout,
+                           int kd, int kh, int kw, int act, int use_mfma, float* stat, tem_stream_t stream) {
     TEM_REQUIRE(x && w_packed && y, "tem_conv3d_fwd: null pointer");
     TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= Cin && y_ld >= Cout,
                 "tem_conv3d_fwd: bad shape");
@@ -256,11 +256,12 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
     hipStream_t s = (hipStream_t)stream;
     if (use_mfma >= 2 && use_mfma <= 5) {
         int rc = tem_conv_fwd_bf16x3(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
-                                     W, Cin, Cout, kd, kh, kw, act, use_mfma, s);
+                                     W, Cin, Cout, kd, kh, kw, act, use_mfma, stat, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(bf16x3)");
         return TEM_OK;
     }
+    TEM_REQUIRE(!stat, "tem_conv3d_fwd_stats: only the split-layout MFMA kernels (use_mfma 2..5) write statistics");
     if (use_mfma) {
         int rc = tem_conv_fwd_mfma(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
                                    W, Cin, Cout, kd, kh, kw, act, s);
@@ -310,6 +311,32 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
 #undef CALL
     TEM_CHECK_LAUNCH("tem_conv3d_fwd(generic)");
     return TEM_OK;
+}
+
+extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                              const float* w_packed, const float* bias, float* y, int64_t y_ld, const float* ref,
+                              int64_t ref_ld, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout,
+                              int kd, int kh, int kw, int act, int use_mfma, tem_stream_t stream) {
+    return conv3d_fwd_impl(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin,
+                           Cout, kd, kh, kw, act, use_mfma, nullptr, stream);
+}
+
+extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                                              int use_mfma) {
+    if (use_mfma < 2 || use_mfma > 5) return 0;
+    return tem_conv_fwd_bf16x3_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw);
+}
+
+extern "C" int tem_conv3d_fwd_stats(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                                    const float* w_packed, const float* bias, float* y, int64_t y_ld, const float* ref,
+                                    int64_t ref_ld, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin,
+                                    int Cout, int kd, int kh, int kw, int act, int use_mfma, float* stat_part,
+                                    int64_t stat_blocks, tem_stream_t stream) {
+    TEM_REQUIRE(stat_part, "tem_conv3d_fwd_stats: null statistics buffer");
+    TEM_REQUIRE(stat_blocks > 0 && stat_blocks == tem_conv3d_fwd_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma),
+                "tem_conv3d_fwd_stats: stat_blocks must be tem_conv3d_fwd_stat_blocks() of this launch (and > 0)");
+    return conv3d_fwd_impl(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin,
+                           Cout, kd, kh, kw, act, use_mfma, stat_part, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
-    int nY, int nX, int ksplit, float* __restrict__ part) {
+    int nY, int nX, int ksplit, float* __restrict__ part, float* __restrict__ stat) {
     constexpr int NT = KD * KH * KW;
     constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
     constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
@@ -448,6 +448,11 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                 for (int i = 0; i < 16; ++i)
                     acc[m][nn][i] = fmaf(accl[SC ? m : 0][SC ? nn : 0][i], 1.f / F16_LO_SCALE, acc[m][nn][i]);
     }
+    // optional fused forward statistics of the STORED output (the next layer's InstanceNorm / GroupNorm / BatchNorm):
+    // per (sample, patch, channel) partial sums (sum y, sum y^2); merged in fp64 by tem_norm_finalize_partials
+    float ssum[NW], ssq[NW];
+#pragma unroll
+    for (int nn = 0; nn < NW; ++nn) ssum[nn] = ssq[nn] = 0.f;
 #pragma unroll
     for (int nn = 0; nn < NW; ++nn) {
         const int co = (cot * NR + nw0 + nn) * 32 + r;
@@ -468,6 +473,8 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                     }
                     float o = act_apply_b(acc[m][nn][reg] + bv, act);
                     if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
+                    ssum[nn] += o;
+                    ssq[nn] = fmaf(o, o, ssq[nn]);
                     if (!(TEM_ABLATE & 8) || o == 12345.678f) {
                         if (TEM_NT_STORE)
                             __builtin_nontemporal_store(o, y + v * y_ld + co);
@@ -476,6 +483,39 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                     }
                 }
             }
+        }
+    }
+    if (stat) {  // grid-uniform
+#pragma unroll
+        for (int nn = 0; nn < NW; ++nn) {
+            ssum[nn] += __shfl_xor(ssum[nn], 32, 64);  // the two lane halves hold different rows of the same column
+            ssq[nn] += __shfl_xor(ssq[nn], 32, 64);
+        }
+        __syncthreads();  // every wave is done with the halo tile
+        float* red = lds;  // [wave 4][NW][32][2]
+        if (kh == 0) {
+#pragma unroll
+            for (int nn = 0; nn < NW; ++nn) {
+                red[((wv * NW + nn) * 32 + r) * 2 + 0] = ssum[nn];
+                red[((wv * NW + nn) * 32 + r) * 2 + 1] = ssq[nn];
+            }
+        }
+        __syncthreads();
+        if (tid < NR * 32) {
+            const int j = tid >> 5, rr = tid & 31;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                if (SN && (w4 >> 1) != j) continue;
+                const int nn = SN ? 0 : j;
+                a += red[((w4 * NW + nn) * 32 + rr) * 2 + 0];
+                b += red[((w4 * NW + nn) * 32 + rr) * 2 + 1];
+            }
+            const int64_t patch = ((int64_t)ptz * nY + pty) * nX + ptx;
+            const int64_t nblk = (int64_t)nZ * nY * nX;
+            float* dst = stat + (((int64_t)n * nblk + patch) * Cout + (cot * NR + j) * 32 + rr) * 2;
+            dst[0] = a;
+            dst[1] = b;
         }
     }
 }
@@ -965,7 +1005,7 @@ __global__ __launch_bounds__((4 + NL) * 64, 1) void k_conv_fwd_bfsplit_lc(
 template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false>
 static void launch_b(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
-                     int W, int Cin, int Cout, int act, int ksplit, float* part, hipStream_t s) {
+                     int W, int Cin, int Cout, int act, int ksplit, float* part, float* stat, hipStream_t s) {
     constexpr int HV = (TZ + KD - 1) * (TY + KH - 1) * (TX + KW - 1);
     const int nZ = (D + TZ - 1) / TZ, nY = (H + TY - 1) / TY, nX = (W + TX - 1) / TX;
     const int64_t nblk = (int64_t)N * nZ * nY * nX * (Cout / (32 * NR)) * ksplit;
@@ -975,7 +1015,7 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     // measured equal to the plain kernel below (the limiter is not load latency): off by default
     static const int ppmode = getenv("TEM_SPLIT_PP") ? atoi(getenv("TEM_SPLIT_PP")) : 0;
     if constexpr ((KD * KH * KW) % 3 == 0 && !F16) {
-        if (ppmode) {
+        if (ppmode && !stat) {
             constexpr int RD = (NR == 1 && NS == 2 && (KD * KH * KW) % 9 == 0 && ppmode_deep_ring) ? 9 : 3;  // NS == 3 would spill
             constexpr int WPC = (NR == 2 || NS == 3 || RD > 3) ? 2 : 3;  // resident workgroups per CU (LDS / launch bounds)
             static bool attrp = false;
@@ -1005,7 +1045,7 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     }
     static const int lcmode = getenv("TEM_SPLIT_LC") ? atoi(getenv("TEM_SPLIT_LC")) : 0;
     if constexpr ((KD * KH * KW) % 3 == 0 && !F16) {
-        if (lcmode) {
+        if (lcmode && !stat) {
             constexpr int NL = 2;
             constexpr size_t lds2 = 2 * ldsb;
             static_assert(lds2 <= 160 * 1024, "LDS budget");
@@ -1039,7 +1079,7 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     }
     hipLaunchKernelGGL((k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16>), dim3((unsigned)nblk), dim3(256), ldsb, s, x,
                        x_ld, scale, shift, reinterpret_cast<const uint4*>(wp), bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin,
-                       Cout, act, nZ, nY, nX, ksplit, part);
+                       Cout, act, nZ, nY, nX, ksplit, part, ksplit > 1 ? nullptr : stat);
     if (ksplit > 1) {
         const int64_t NV = (int64_t)N * D * H * W;
         tem_splitk_epilogue(part, ksplit, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
@@ -1049,7 +1089,7 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
 int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                         const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
                         int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
-                        int nsplit, hipStream_t s) {
+                        int nsplit, float* stat, hipStream_t s) {
     TEM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0, "tem_conv3d_fwd(split-bf16): needs Cin%%16==0 and Cout%%32==0 (got %d,%d)",
                 Cin, Cout);
     TEM_REQUIRE(x_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)wp % 16 == 0),
@@ -1065,15 +1105,16 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
     const bool vec_ok = (y_ld % 4 == 0) && ((uintptr_t)y % 16 == 0) &&
                         (!ref || (ref_ld % 4 == 0 && (uintptr_t)ref % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0);
     if (ks > 1 && (!ws || !vec_ok || ws_bytes < (int64_t)ks * N * D * H * W * Cout * 4)) ks = 1;
+    TEM_REQUIRE(!stat || ks == 1, "tem_conv3d_fwd_stats: this shape runs split-K (tem_conv3d_fwd_stat_blocks() == 0)");
     float* part = (float*)ws;
 #define GO2(KD, KH, KW, TZ, TY, TX, NS)                                                                             \
     do {                                                                                                            \
         if (nr2)                                                                                                    \
             launch_b<KD, KH, KW, TZ, TY, TX, 2, NS>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
-                                                    Cin, Cout, act, ks, part, s);                                   \
+                                                    Cin, Cout, act, ks, part, stat, s);                                   \
         else                                                                                                        \
             launch_b<KD, KH, KW, TZ, TY, TX, 1, NS>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
-                                                    Cin, Cout, act, ks, part, s);                                   \
+                                                    Cin, Cout, act, ks, part, stat, s);                                   \
     } while (0)
 #define GO(KD, KH, KW, TZ, TY, TX)                                                                                    \
     do {                                                                                                              \
@@ -1082,17 +1123,17 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
         else if (nsplit == 4) {                                                                                       \
             if (nr2)                                                                                                  \
                 launch_b<KD, KH, KW, TZ, TY, TX, 2, 2, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
-                                                             W, Cin, Cout, act, ks, part, s);                         \
+                                                             W, Cin, Cout, act, ks, part, stat, s);                         \
             else                                                                                                      \
                 launch_b<KD, KH, KW, TZ, TY, TX, 1, 2, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
-                                                             W, Cin, Cout, act, ks, part, s);                         \
+                                                             W, Cin, Cout, act, ks, part, stat, s);                         \
         } else if (nsplit == 5) {                                                                                     \
             if (nr2)                                                                                                  \
                 launch_b<KD, KH, KW, TZ, TY, TX, 2, 1, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
-                                                             W, Cin, Cout, act, ks, part, s);                         \
+                                                             W, Cin, Cout, act, ks, part, stat, s);                         \
             else                                                                                                      \
                 launch_b<KD, KH, KW, TZ, TY, TX, 1, 1, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
-                                                             W, Cin, Cout, act, ks, part, s);                         \
+                                                             W, Cin, Cout, act, ks, part, stat, s);                         \
         } else                                                                                                        \
             GO2(KD, KH, KW, TZ, TY, TX, 2);                                                                           \
     } while (0)
@@ -1115,6 +1156,22 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
 #undef GO
 #undef GO2
     return TEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+
+// number of per-sample statistic blocks (= patches) the fused-statistics forward writes, 0 when this shape cannot
+// produce them (split-K over the input channels, or no MFMA instantiation)
+int64_t tem_conv_fwd_bf16x3_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    if (Cin % 16 || Cout % 32) return 0;
+    const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
+    if (key != 7 && key != 3 && key != 0) return 0;
+    const bool flat = (D == 1 && kd == 1);
+    const int TZ = flat ? 1 : 4, TY = flat ? 16 : 8, TX = flat ? 16 : 8;
+    const bool nr2 = (Cout % 64 == 0);
+    const int64_t per = (int64_t)((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
+    if (tem_fwd_ksplit((int64_t)N * per * (Cout / (nr2 ? 64 : 32)), Cin / BCK) > 1) return 0;
+    return per;
 }
 
 // ---------------------------------------------------------------------------

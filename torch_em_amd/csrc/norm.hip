@@ -375,6 +375,20 @@ extern "C" int tem_norm_stats(const float* x, int64_t x_ld, int N, int64_t V, in
     return TEM_OK;
 }
 
+// Second stage only: the per-(sample, block, channel) partial sums (sum x, sum x^2) were written by the producer of x
+// (tem_conv3d_fwd_stats), so x is not read again.  part: [N][nblk][C][2].
+extern "C" int tem_norm_finalize_partials(const float* part, int64_t nblk, int N, int64_t V, int C, int G,
+                                          const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                                          float* scale, float* shift, tem_stream_t stream) {
+    TEM_REQUIRE(part && mean && rstd && scale && shift, "tem_norm_finalize_partials: null pointer");
+    TEM_REQUIRE(N > 0 && V > 0 && C > 0 && nblk > 0 && nblk < (1ll << 31) / 2, "tem_norm_finalize_partials: bad shape");
+    TEM_REQUIRE(G > 0 && C % G == 0, "tem_norm_finalize_partials: C=%d not divisible by G=%d", C, G);
+    hipLaunchKernelGGL(k_norm_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, V, C, G, gamma,
+                       beta, eps, mean, rstd, scale, shift);
+    TEM_CHECK_LAUNCH("tem_norm_finalize_partials");
+    return TEM_OK;
+}
+
 extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C,
                             int G, const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx,
                             int64_t gx_ld, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,

@@ -214,7 +214,12 @@ _INFER_BF16X3 = os.environ.get("TEM_INFER_BF16X3", "1") != "0"
 _NO_GRAD_FORWARD = False
 
 
-def _conv(spec: ConvSpec, x, y, stats=None, act=None):
+# Forward statistics of a conv output that feeds the next norm directly (conv1 -> norm2 of every ConvBlock) come out of
+# the conv's epilogue instead of a separate pass over the tensor (tem_conv3d_fwd_stats); TEM_FUSE_STATS=0 disables.
+_FUSE_STATS = os.environ.get("TEM_FUSE_STATS", "1") != "0"
+
+
+def _conv(spec: ConvSpec, x, y, stats=None, act=None, want_stats=False):
     ent = spec.packed()
     scale, shift = (stats[2], stats[3]) if stats is not None else (None, None)
     wpk, mode = ent["fwd"], ent["fwd_mfma"]
@@ -223,7 +228,8 @@ def _conv(spec: ConvSpec, x, y, stats=None, act=None):
             ent["fwd_inf"], ent["fwd_inf_mfma"] = ops.pack_weights(spec.conv.weight, transpose=False, mfma=2), 2
         ent["fwd_inf_used"] = True
         wpk, mode = ent["fwd_inf"], 2
-    ops.conv_fwd(x, wpk, spec.conv.bias, y, spec.k, spec.cin, spec.cout, scale=scale, shift=shift, act=act, mfma=mode)
+    return ops.conv_fwd(x, wpk, spec.conv.bias, y, spec.k, spec.cin, spec.cout, scale=scale, shift=shift, act=act,
+                        mfma=mode, want_stats=want_stats)
 
 
 class _Grads:
@@ -340,8 +346,9 @@ def _update_running(n, mean, var_biased, count):
         n.running_var.mul_(1.0 - m).add_(unbiased.mean(0), alpha=m)
 
 
-def _stats(spec: ConvSpec, x):
+def _stats(spec: ConvSpec, x, partials=None):
     """Statistics of the norm in front of a conv -> (mean, rstd, scale[N,C], shift[N,C], mode).
+    partials: (part, nblk) from the producing conv's epilogue (ops.conv_fwd(want_stats=True)) or None.
     mode "sample": InstanceNorm / GroupNorm per sample; "batch": BatchNorm in training mode (reference
     `get_norm_layer`, model/unet.py:391-406); "frozen": a norm with running statistics in eval mode."""
     na = spec.norm_args()
@@ -359,13 +366,20 @@ def _stats(spec: ConvSpec, x):
         if beta is not None:
             shift = shift + beta.detach().float()
         return None, None, scale.expand(N, -1).contiguous(), shift.expand(N, -1).contiguous(), "frozen"
+    vox = x.shape[1] * x.shape[2] * x.shape[3]
     if _is_batchnorm(n):
         xb = _flat_batch(x)
-        mean, rstd, scale, shift = ops.norm_stats(xb, groups, gamma, beta, eps)
+        if partials is not None:
+            mean, rstd, scale, shift = ops.norm_stats_from_partials(partials[0], 1, vox, x.shape[4], groups, gamma, beta, eps)
+        else:
+            mean, rstd, scale, shift = ops.norm_stats(xb, groups, gamma, beta, eps)
         if tracked:
             _update_running(n, mean, 1.0 / (rstd * rstd) - eps, xb.shape[1] * xb.shape[2] * xb.shape[3])
         return mean, rstd, scale.expand(N, -1).contiguous(), shift.expand(N, -1).contiguous(), "batch"
-    mean, rstd, scale, shift = ops.norm_stats(x, groups, gamma, beta, eps)
+    if partials is not None:
+        mean, rstd, scale, shift = ops.norm_stats_from_partials(partials[0], N, vox, x.shape[4], groups, gamma, beta, eps)
+    else:
+        mean, rstd, scale, shift = ops.norm_stats(x, groups, gamma, beta, eps)
     if tracked:  # InstanceNormTrackStats: per-instance statistics, running averages of their batch means
         _update_running(n, mean, 1.0 / (rstd * rstd) - eps, x.shape[1] * x.shape[2] * x.shape[3])
     return mean, rstd, scale, shift, "sample"
@@ -377,8 +391,11 @@ def _block_fwd(blk, xin, out):
     N, D, H, W, _ = xin.shape
     s1 = _stats(c1, xin)
     a1 = ops.new_act(N, D, H, W, c1.cout, xin.device)
-    _conv(c1, xin, a1, s1, act="relu")
-    s2 = _stats(c2, a1)
+    n2 = c2.norm
+    live = n2 is not None and not (getattr(n2, "track_running_stats", False) and
+                                   getattr(n2, "running_mean", None) is not None and not n2.training)
+    part = _conv(c1, xin, a1, s1, act="relu", want_stats=_FUSE_STATS and live)
+    s2 = _stats(c2, a1, partials=part if (_FUSE_STATS and live) else None)
     _conv(c2, a1, out, s2, act="relu")
     return {"xin": xin, "a1": a1, "out": out, "s1": s1, "s2": s2, "c1": c1, "c2": c2}
 

@@ -176,7 +176,10 @@ def pack_weights_batch(tab):
                "tem_conv_pack_weights_batch")
 
 
-def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=None, ref=None, mfma=False):
+def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=None, ref=None, mfma=False,
+             want_stats=False):
+    """want_stats: also emit the first stage of the statistics of y (tem_conv3d_fwd_stats) when this launch can; returns
+    (partials [N, nblk, cout, 2], nblk) then, else y (and `None` for launches that cannot: use norm_stats)."""
     _req_cuda(x, w_packed, y)
     N, D, H, W, C, x_ld = _act5(x)
     Ny, Dy, Hy, Wy, Cy, y_ld = _act5(y)
@@ -189,12 +192,22 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 1) if mfma else 0
     ws = _workspace(nws, x.device) if nws else None
     kind = _fwd_tag(mfma, k, cout) if PROFILER is not None else None
+    nblk = lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if want_stats else 0
     ev0 = _prof_begin(x, kind)
-    _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
-                                  ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma),
-                                  _stream(x)), "tem_conv3d_fwd")
+    part = None
+    if nblk > 0:
+        part = torch.empty((N, nblk, cout, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.tem_conv3d_fwd_stats(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld,
+                                            _p(ref), ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2],
+                                            ACT[act], int(mfma), _p(part), nblk, _stream(x)), "tem_conv3d_fwd_stats")
+    else:
+        _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
+                                      ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma),
+                                      _stream(x)), "tem_conv3d_fwd")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
+    if want_stats:
+        return None if part is None else (part, int(nblk))
     return y
 
 
@@ -250,6 +263,28 @@ def norm_stats(x, groups: int, gamma=None, beta=None, eps: float = 1e-5):
     ws = _workspace(nws, dev)
     _lib.check(lib.tem_norm_stats(_p(x), ld, N, V, C, groups, _p(gamma), _p(beta), eps, _p(mean), _p(rstd), _p(scale),
                                   _p(shift), _p(ws), nws, _stream(x)), "tem_norm_stats")
+    return mean, rstd, scale, shift
+
+
+def norm_stats_from_partials(part, rows: int, voxels: int, C: int, groups: int, gamma=None, beta=None,
+                             eps: float = 1e-5):
+    """Second stage of norm_stats on partial sums written by conv_fwd(want_stats=True).  part: [N, nblk, C, 2];
+    rows = N for per-sample statistics, 1 for BatchNorm (then every sample's blocks merge into one row)."""
+    _req_cuda(part)
+    N, nblk = part.shape[0], part.shape[1]
+    if rows == 1:
+        nblk, voxels = N * nblk, N * voxels
+    elif rows != N:
+        raise ValueError("norm_stats_from_partials: rows must be N or 1")
+    dev = part.device
+    mean = torch.empty((rows, groups), dtype=torch.float32, device=dev)
+    rstd = torch.empty((rows, groups), dtype=torch.float32, device=dev)
+    scale = torch.empty((rows, C), dtype=torch.float32, device=dev)
+    shift = torch.empty((rows, C), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.tem_norm_finalize_partials(_p(part), nblk, rows, voxels, C, groups, _p(gamma), _p(beta), eps,
+                                              _p(mean), _p(rstd), _p(scale), _p(shift), _stream(part)),
+               "tem_norm_finalize_partials")
     return mean, rstd, scale, shift
 
 
