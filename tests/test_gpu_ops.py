@@ -209,6 +209,28 @@ def test_conv_fused_forward_statistics(case, mode):
                         shift=shift, act="relu", mfma=0, want_stats=True) is None
 
 
+@pytest.mark.parametrize("case", [(2, 9, 17, 10, 1, 32, (3, 3, 3)), (1, 1, 19, 21, 1, 16, (1, 3, 3)),
+                                  (2, 5, 9, 12, 3, 32, (3, 3, 3))])
+def test_first_layer_fused_forward_statistics(case):
+    """the small-Cin first-layer kernel (VALU, HBM-bound) provides the same per-patch partial sums"""
+    ops = _ops()
+    N, D, H, W, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(4)
+    x5 = to5(torch.randn(N, Cin, D, H, W, generator=g))
+    w = (torch.randn(Cout, Cin, *k, generator=g) * 0.3).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    scale, shift = (torch.rand(N, Cin, generator=g) + 0.5).to(DEV), torch.randn(N, Cin, generator=g).to(DEV)
+    wp = ops.pack_weights(w, transpose=False, mfma=0)
+    y5, y_ref = ops.new_act(N, D, H, W, Cout, DEV), ops.new_act(N, D, H, W, Cout, DEV)
+    part, nblk = ops.conv_fwd(x5, wp, b, y5, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=0, want_stats=True)
+    ops.conv_fwd(x5, wp, b, y_ref, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=0)
+    assert torch.equal(y5, y_ref) and nblk == ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8)
+    want = ops.norm_stats(y5, Cout, None, None, 1e-5)
+    have = ops.norm_stats_from_partials(part, N, D * H * W, Cout, Cout, None, None, 1e-5)
+    for a, c in zip(have, want):
+        assert rel_err(a.cpu(), c.cpu()) < 2e-6
+
+
 def test_conv_relu_mask_ref_and_channel_slices():
     """ref-mask epilogue and leading-dimension (concat-buffer slice) addressing."""
     ops = _ops()

@@ -261,7 +261,7 @@ static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, con
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(bf16x3)");
         return TEM_OK;
     }
-    TEM_REQUIRE(!stat, "tem_conv3d_fwd_stats: only the split-layout MFMA kernels (use_mfma 2..5) write statistics");
+    TEM_REQUIRE(!stat || !use_mfma, "tem_conv3d_fwd_stats: the exact-fp32 MFMA kernel writes no statistics");
     if (use_mfma) {
         int rc = tem_conv_fwd_mfma(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
                                    W, Cin, Cout, kd, kh, kw, act, s);
@@ -271,10 +271,11 @@ static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, con
     }
     const int64_t NV = (int64_t)N * D * H * W;
     if (tem_conv_fwd_cin1(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, N, D, H, W, Cin, Cout, kd, kh, kw, act,
-                          s)) {
+                          stat, s)) {
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(cin1)");
         return TEM_OK;
     }
+    TEM_REQUIRE(!stat, "tem_conv3d_fwd_stats: this launch cannot write statistics (tem_conv3d_fwd_stat_blocks() == 0)");
     if (tem_conv_fwd_cout1(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, N, D, H, W, Cin, Cout, kd, kh, kw, act,
                            s)) {
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(cout1)");
@@ -321,8 +322,12 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
                            Cout, kd, kh, kw, act, use_mfma, nullptr, stream);
 }
 
+static inline bool ref_free_cin1_ok(int Cout) { return Cout % 4 == 0; }
+
 extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                               int use_mfma) {
+    if (use_mfma == 0)  // VALU kernels: only the small-Cin first-layer kernel (conv_small.hip) provides them
+        return (ref_free_cin1_ok(Cout)) ? tem_conv_fwd_cin1_stat_blocks(D, H, W, Cin, Cout, kd, kh, kw) : 0;
     if (use_mfma < 2 || use_mfma > 5) return 0;
     return tem_conv_fwd_bf16x3_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw);
 }

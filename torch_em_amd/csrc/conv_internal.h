@@ -18,7 +18,8 @@ int tem_conv_wgrad_mfma(const float* x, int64_t x_ld, const float* scale, const 
 // conv_small.hip: HBM-bound special cases (return false when the shape is not covered)
 bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
                        const float* bias, float* y, int64_t y_ld, const float* ref, int N, int D, int H, int W,
-                       int Cin, int Cout, int kd, int kh, int kw, int act, hipStream_t s);
+                       int Cin, int Cout, int kd, int kh, int kw, int act, float* stat, hipStream_t s);
+int64_t tem_conv_fwd_cin1_stat_blocks(int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int64_t tem_conv_wgrad_cin1_ws(int Cout, int ntaps);
 bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                          int64_t g_ld, float* dw, float* db, void* ws, int N, int D, int H, int W, int Cin, int Cout,

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
                                                        const float* __restrict__ w /*[tap][ci][co]*/,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        int64_t y_ld, int N, int D, int H, int W, int Cout, int act,
-                                                       int nZ, int nY, int nX) {
+                                                       int nZ, int nY, int nX, float* __restrict__ stat) {
     constexpr int NT = KD * KH * KW;
     constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
     constexpr int TZ = 4, TY = 8, TX = 8;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
     }
     __syncthreads();
     const int cq = Cout >> 2;
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;  // fused statistics (cq divides 64: a thread keeps its quad)
     for (int item = tid; item < 256 * cq; item += 256) {
         const int p = item / cq, q = item % cq;
         const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
@@ -95,12 +96,50 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
         acc.w = act_apply_s(acc.w, act);
         const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
         ST4(y + v * y_ld + q * 4, acc);
+        ssum.x += acc.x; ssum.y += acc.y; ssum.z += acc.z; ssum.w += acc.w;
+        ssq.x = fmaf(acc.x, acc.x, ssq.x); ssq.y = fmaf(acc.y, acc.y, ssq.y);
+        ssq.z = fmaf(acc.z, acc.z, ssq.z); ssq.w = fmaf(acc.w, acc.w, ssq.w);
     }
+    if (stat) {  // per (sample, patch, channel) partial sums for the next norm (see tem_conv3d_fwd_stats)
+        float vals[8] = {ssum.x, ssum.y, ssum.z, ssum.w, ssq.x, ssq.y, ssq.z, ssq.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            for (int o = cq; o < 64; o <<= 1) vals[j] += __shfl_xor(vals[j], o, 64);  // lanes sharing q sit cq apart
+        __syncthreads();
+        float* red = lds;  // [4 waves][cq][8]
+        const int wv = tid >> 6, lane = tid & 63;
+        if (lane < cq)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(wv * cq + lane) * 8 + j] = vals[j];
+        __syncthreads();
+        if (tid < Cout) {
+            const int q = tid >> 2, j = tid & 3;
+            float a = 0.f, b = 0.f;
+            for (int w4 = 0; w4 < 4; ++w4) {
+                a += red[(w4 * cq + q) * 8 + j];
+                b += red[(w4 * cq + q) * 8 + 4 + j];
+            }
+            const int64_t patch = ((int64_t)ptz * nY + pty) * nX + ptx;
+            float* dst = stat + ((((int64_t)n * nZ * nY * nX) + patch) * Cout + tid) * 2;
+            dst[0] = a;
+            dst[1] = b;
+        }
+    }
+}
+
+// blocks per sample of the fused statistics, 0 when the cin1 kernel does not take this shape / cannot keep a channel
+// quad per thread
+int64_t tem_conv_fwd_cin1_stat_blocks(int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    const int cq = Cout / 4;
+    if (Cin > 4 || Cout % 4 || Cin * Cout > 128 || cq > 64 || (cq & (cq - 1))) return 0;
+    const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
+    if (key != 7 && key != 3) return 0;
+    return (int64_t)((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
 }
 
 bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
                        const float* bias, float* y, int64_t y_ld, const float* ref, int N, int D, int H, int W,
-                       int Cin, int Cout, int kd, int kh, int kw, int act, hipStream_t s) {
+                       int Cin, int Cout, int kd, int kh, int kw, int act, float* stat, hipStream_t s) {
     // Cin 2..4 (RGB / multi-channel raw data) share the kernel; weights stay in LDS, so Cin * Cout is bounded
     if (Cin > 4 || Cout % 4 || Cin * Cout > 128 || ref || y_ld % 4 || ((uintptr_t)y % 16) ||
         (bias && ((uintptr_t)bias % 16)))
@@ -113,7 +152,7 @@ bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const f
     case CI: {                                                                                                        \
         size_t ldsb = (size_t)(CI * ((((KD_ + 3) * 10 * 10 + 3) / 4) * 4) + KD_ * 9 * CI * Cout) * sizeof(float);     \
         hipLaunchKernelGGL((k_conv_fwd_cin1<KD_, 3, 3, CI>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, \
-                           shift, w, bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX);                               \
+                           shift, w, bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat);                         \
     } break;
     if (key == 7) {
         switch (Cin) { C1(3, 1) C1(3, 2) C1(3, 3) C1(3, 4) }
