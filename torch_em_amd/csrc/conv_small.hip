@@ -351,8 +351,19 @@ __global__ __launch_bounds__(512) void k_reduce_slabs(const float* __restrict__ 
     for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
         const int64_t i = i0 + tx;
         double s = 0.0;
-        if (i < n)
-            for (int c = ty; c < nchunks; c += 8) s += (double)part[(int64_t)c * chunk_stride + i];
+        if (i < n) {
+            // four independent loads in flight per thread (fixed order: still deterministic)
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int c = ty;
+            for (; c + 24 < nchunks; c += 32) {
+                s += (double)part[(int64_t)c * chunk_stride + i];
+                s1 += (double)part[(int64_t)(c + 8) * chunk_stride + i];
+                s2 += (double)part[(int64_t)(c + 16) * chunk_stride + i];
+                s3 += (double)part[(int64_t)(c + 24) * chunk_stride + i];
+            }
+            for (; c < nchunks; c += 8) s += (double)part[(int64_t)c * chunk_stride + i];
+            s = (s + s1) + (s2 + s3);
+        }
         sh[ty][tx] = s;
         __syncthreads();
         if (ty == 0 && i < n) {
@@ -381,8 +392,19 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_sd(const float* __restrict
     for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
         const int64_t i = i0 + tx;
         double s = 0.0;
-        if (i < n)
-            for (int c = ty; c < nchunks; c += 8) s += (double)part[(int64_t)c * chunk_stride + i];
+        if (i < n) {
+            // four independent loads in flight per thread (fixed order: still deterministic)
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int c = ty;
+            for (; c + 24 < nchunks; c += 32) {
+                s += (double)part[(int64_t)c * chunk_stride + i];
+                s1 += (double)part[(int64_t)(c + 8) * chunk_stride + i];
+                s2 += (double)part[(int64_t)(c + 16) * chunk_stride + i];
+                s3 += (double)part[(int64_t)(c + 24) * chunk_stride + i];
+            }
+            for (; c < nchunks; c += 8) s += (double)part[(int64_t)c * chunk_stride + i];
+            s = (s + s1) + (s2 + s3);
+        }
         sh[ty][tx] = s;
         __syncthreads();
         if (ty == 0 && i < n) {
@@ -408,8 +430,19 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_ci(const float* __restrict
     for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
         const int64_t i = i0 + tx;
         double s = 0.0;
-        if (i < n)
-            for (int c = ty; c < nchunks; c += 8) s += (double)part[(int64_t)c * chunk_stride + i];
+        if (i < n) {
+            // four independent loads in flight per thread (fixed order: still deterministic)
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int c = ty;
+            for (; c + 24 < nchunks; c += 32) {
+                s += (double)part[(int64_t)c * chunk_stride + i];
+                s1 += (double)part[(int64_t)(c + 8) * chunk_stride + i];
+                s2 += (double)part[(int64_t)(c + 16) * chunk_stride + i];
+                s3 += (double)part[(int64_t)(c + 24) * chunk_stride + i];
+            }
+            for (; c < nchunks; c += 8) s += (double)part[(int64_t)c * chunk_stride + i];
+            s = (s + s1) + (s2 + s3);
+        }
         sh[ty][tx] = s;
         __syncthreads();
         if (ty == 0 && i < n) {
