@@ -30,6 +30,19 @@ static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
 #ifndef TEM_SC2_RD
 #define TEM_SC2_RD 3
 #endif
+#ifndef TEM_ZS_NT
+#define TEM_ZS_NT 0
+#endif
+typedef float floatx4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+    floatx4n v = __builtin_nontemporal_load(reinterpret_cast<const floatx4n*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#if TEM_ZS_NT
+#define ZS_GLOAD(p) ld4_nt(p)
+#else
+#define ZS_GLOAD(p) (*reinterpret_cast<const float4*>(p))
+#endif
 #ifndef TEM_NT_STORE
 #define TEM_NT_STORE 1   // epilogue stores bypass the write-allocate path: the output is not re-read by this kernel (-0.3 ms/step)
 #endif
@@ -1680,8 +1693,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                 const int gy = y0 + gprow, gx = x0 + 2 * gpr;
                 if (gy < H && gcq * 4 < Cout - cog * GC) {
                     const float* rowp = g + (((int64_t)n * D + zg) * H + gy) * W * g_ld + cog * GC + gcq * 4;
-                    if (gx < W) ga = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * g_ld);
-                    if (gx + 1 < W) gb = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * g_ld);
+                    if (gx < W) ga = ZS_GLOAD(rowp + (int64_t)gx * g_ld);
+                    if (gx + 1 < W) gb = ZS_GLOAD(rowp + (int64_t)(gx + 1) * g_ld);
                 }
             }
         }

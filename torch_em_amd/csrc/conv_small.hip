@@ -70,6 +70,43 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
     __syncthreads();
     const int cq = Cout >> 2;
     float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;  // fused statistics (cq divides 64: a thread keeps its quad)
+    if constexpr (CIN == 1) {
+        if ((256 % cq) == 0) {
+            // A thread keeps its channel quad (item % cq == tid % cq): its 27 weight quads live in registers, which
+            // removes the per-tap 16-byte LDS read that bounded this kernel (27 x 8 LDS cycles per item-wave).
+            const int q = tid % cq;
+            float4 wr[NT];
+#pragma unroll
+            for (int tap = 0; tap < NT; ++tap) wr[tap] = *reinterpret_cast<const float4*>(lw + tap * Cout + q * 4);
+            const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = tid / cq; p < 256; p += 256 / cq) {
+                const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+                const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+                if (gz >= D || gy >= H || gx >= W) continue;
+                float4 acc = b4;
+                const float* xb = lx + (pz * HY + py) * HX + px;
+#pragma unroll
+                for (int tap = 0; tap < NT; ++tap) {
+                    const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+                    const float xv = xb[(tz * HY + ty) * HX + tx];
+                    acc.x = fmaf(xv, wr[tap].x, acc.x);
+                    acc.y = fmaf(xv, wr[tap].y, acc.y);
+                    acc.z = fmaf(xv, wr[tap].z, acc.z);
+                    acc.w = fmaf(xv, wr[tap].w, acc.w);
+                }
+                acc.x = act_apply_s(acc.x, act);
+                acc.y = act_apply_s(acc.y, act);
+                acc.z = act_apply_s(acc.z, act);
+                acc.w = act_apply_s(acc.w, act);
+                const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
+                ST4(y + v * y_ld + q * 4, acc);
+                ssum.x += acc.x; ssum.y += acc.y; ssum.z += acc.z; ssum.w += acc.w;
+                ssq.x = fmaf(acc.x, acc.x, ssq.x); ssq.y = fmaf(acc.y, acc.y, ssq.y);
+                ssq.z = fmaf(acc.z, acc.z, ssq.z); ssq.w = fmaf(acc.w, acc.w, ssq.w);
+            }
+            goto stats;
+        }
+    }
     for (int item = tid; item < 256 * cq; item += 256) {
         const int p = item / cq, q = item % cq;
         const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
@@ -100,6 +137,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
         ssq.x = fmaf(acc.x, acc.x, ssq.x); ssq.y = fmaf(acc.y, acc.y, ssq.y);
         ssq.z = fmaf(acc.z, acc.z, ssq.z); ssq.w = fmaf(acc.w, acc.w, ssq.w);
     }
+stats:
     if (stat) {  // per (sample, patch, channel) partial sums for the next norm (see tem_conv3d_fwd_stats)
         float vals[8] = {ssum.x, ssum.y, ssum.z, ssum.w, ssq.x, ssq.y, ssq.z, ssq.w};
 #pragma unroll
