@@ -30,6 +30,9 @@ static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
 #ifndef TEM_SC2_RD
 #define TEM_SC2_RD 3
 #endif
+#ifndef TEM_SETPRIO
+#define TEM_SETPRIO 0
+#endif
 #ifndef TEM_ZS_NT
 #define TEM_ZS_NT 0
 #endif
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
 
         int ts = tapstride;
         asm volatile("" : "+s"(ts));
+        if (TEM_SETPRIO) __builtin_amdgcn_s_setprio(TEM_SETPRIO);
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
             const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
@@ -450,6 +454,7 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                         }
                 }
         }
+        if (TEM_SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
 
     if (SC) {
