@@ -1553,13 +1553,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
     // walks (a slab is 8 % of a column's own traffic, and the merge kernel reads every slab back).  The pipeline
     // re-primes per segment; the barrier that ends a segment's last plane orders its LDS reads before the next
     // segment's first stores.
-    for (int cz = sp; cz < ncz; cz += S) {
+    // slabs are grouped per SAMPLE (S = Ss slabs for each of the N samples; `ncz` = column segments of one sample), so
+    // that the merge kernel can also form per-sample weight gradients (tem_conv3d_wgrad_sums)
+    const int n = sp / S;
+    for (int cz = sp % S; cz < ncz; cz += S) {
     const int zseg = cz % zsegs;
-    int col = cz / zsegs;
+    const int col = cz / zsegs;
     const int ptx = col % nX;
-    col /= nX;
-    const int pty = col % nY;
-    const int n = col / nY;
+    const int pty = col / nX;
     const int y0 = pty * 8, x0 = ptx * 8;
     const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
     if (scale && xit) {
@@ -1745,7 +1746,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
 
 struct ZsPlan {
     bool use;
-    int nco, ks2, T, nY, nX, zsegs, S, ncz;
+    int nco, ks2, T, nY, nX, zsegs, S, Ss, ncz;
 };
 static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     ZsPlan p;
@@ -1761,11 +1762,13 @@ static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int
     int zs = 1;
     while (p.T * cols * zs < 256 && D / (zs * 2) >= 8) zs *= 2;  // one workgroup per CU: fill the chip
     p.zsegs = zs;
-    p.ncz = (int)(cols * zs);
-    // persistent over column segments: q segments per workgroup, T * S workgroups ~ one per CU
+    p.ncz = p.nY * p.nX * zs;  // column segments per sample
+    // persistent over column segments: q segments per workgroup, T * S workgroups ~ one per CU; a workgroup stays
+    // inside one sample (Ss slabs per sample, S = N * Ss)
     static const int persist = getenv("TEM_WGRAD_ZS_PERSIST") ? atoi(getenv("TEM_WGRAD_ZS_PERSIST")) : 1;
-    const int64_t q = persist ? ((int64_t)p.ncz * p.T + 255) / 256 : 1;
-    p.S = (int)((p.ncz + q - 1) / q);
+    const int64_t q = persist ? ((int64_t)N * p.ncz * p.T + 255) / 256 : 1;
+    p.Ss = (int)((p.ncz + q - 1) / q);
+    p.S = N * p.Ss;
     return p;
 }
 
@@ -1870,10 +1873,10 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
             }
             if (h16)
                 hipLaunchKernelGGL((k_conv_wgrad_zs<2, true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
-                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
+                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz);
             else
             hipLaunchKernelGGL((k_conv_wgrad_zs<2>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
-                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
+                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz);
         } else {
             constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS;
             static bool a1 = false;
@@ -1890,10 +1893,10 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
             }
             if (h16)
                 hipLaunchKernelGGL((k_conv_wgrad_zs<1, true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
-                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
+                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz);
             else
             hipLaunchKernelGGL((k_conv_wgrad_zs<1>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
-                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.S, z.ncz);
+                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz);
         }
         tem_reduce_slabs_w(zpart, z.S * z.ks2, 27, Cin, Cout, (int64_t)27 * Cin * Cout, dw, sd_layout, s);
         if (db) tem_reduce_slabs(zdb, z.S, Cout, Cout, db, s);
