@@ -148,6 +148,22 @@ int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const flo
                      int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                      int use_mfma, int sd_layout, tem_stream_t stream);
 
+/* tem_conv3d_wgrad that ALSO delivers the first stage of the backward of the norm in front of this conv -- per (sample,
+ * input channel) sums[n][ci] = (sum_v gz, sum_v gz * xn), gz = the data gradient of this conv (tem_conv3d_fwd with the
+ * transposed pack), xn = the normalised input -- WITHOUT reading gz or x: sum_v gz*z = sum_{tap,co} w * dw_n (the
+ * per-sample weight gradient, which the slab merge has anyway) and sum_v gz = sum_{tap,co} w * T_n[tap][co] with T_n the
+ * per-sample bias gradient minus boundary faces (csrc/wgrad_sums.hip).  Replaces the reduction pass of
+ * aten::native_group_norm_backward / native_batch_norm_backward for nn.InstanceNorm3d / nn.GroupNorm (reference
+ * model/unet.py:391-406, 429-438).  w: the weights in state_dict layout; gamma/beta: the norm's affine parameters or
+ * NULL; dw is written in state_dict layout; db is required.  Only where tem_conv3d_wgrad_sums_ok() != 0 (z-sliding
+ * 3x3x3 kernel, N <= 4, Cout <= 128); workspace: tem_conv3d_wgrad_ws().  Feed `norm_sums` to tem_norm_bwd_from_sums. */
+int tem_conv3d_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
+int tem_conv3d_wgrad_sums(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                          const float* g, int64_t g_ld, const float* w, const float* gamma, const float* beta,
+                          float* dw, float* db, float* norm_sums, void* ws, int64_t ws_bytes,
+                          int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                          int use_mfma, tem_stream_t stream);
+
 /* ---- normalisation ------------------------------------------------------
  * Replaces nn.InstanceNorm3d / nn.GroupNorm from get_norm_layer
  * (model/unet.py:391-406): statistics per (sample, group) over V*(C/G) values,
@@ -177,6 +193,13 @@ int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld,
                  const float* mean, const float* rstd, int relu_mask,
                  float* gx, int64_t gx_ld, float* dgamma, float* dbeta,
                  void* ws, int64_t ws_bytes, tem_stream_t stream);
+
+/* tem_norm_bwd with the reduction stage replaced by sums[N][C][2] from tem_conv3d_wgrad_sums */
+int tem_norm_bwd_from_sums(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld,
+                           int N, int64_t V, int C, int G, const float* gamma,
+                           const float* mean, const float* rstd, int relu_mask,
+                           float* gx, int64_t gx_ld, float* dgamma, float* dbeta,
+                           const float* sums, void* ws, int64_t ws_bytes, tem_stream_t stream);
 
 /* ---- pooling / upsampling ------------------------------------------------
  * nn.MaxPool3d(factor) (model/unet.py:300-302,645): kernel == stride == factor.

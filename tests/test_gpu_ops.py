@@ -231,6 +231,63 @@ def test_first_layer_fused_forward_statistics(case):
         assert rel_err(a.cpu(), c.cpu()) < 2e-6
 
 
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, 24, 32, 32, True),     # k-halves kernel, affine norm (GroupNorm-style gamma / beta)
+    (1, 20, 24, 17, 32, 32, False),    # ragged H / W, two z segments, InstanceNorm (no affine)
+    (2, 16, 16, 16, 64, 64, True),     # two Cout tiles
+    (3, 17, 9, 10, 64, 32, False),     # Cin tiles > 1, odd depth, three samples
+])
+def test_wgrad_delivers_norm_backward_sums(case):
+    """tem_conv3d_wgrad_sums: (sum_v gz, sum_v gz*xn) of the norm in front of a conv from the per-sample weight
+    gradient and the boundary shell of g -- against the definition evaluated in float64 (gz = conv data gradient)."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout, affine = case
+    k = (3, 3, 3)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Cin, D, H, W, generator=g).double() * 1.5 + 0.3
+    w = (torch.randn(Cout, Cin, *k, generator=g) * 0.1).double()
+    gout = torch.randn(N, Cout, D, H, W, generator=g).double()
+    gamma = (torch.rand(Cin, generator=g) + 0.5).double() if affine else torch.ones(Cin, dtype=torch.float64)
+    beta = torch.randn(Cin, generator=g).double() if affine else torch.zeros(Cin, dtype=torch.float64)
+    mean = x.mean((2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var((2, 3, 4), unbiased=False) + 1e-5)
+    xn = (x - mean[:, :, None, None, None]) * rstd[:, :, None, None, None]
+    z = xn * gamma[None, :, None, None, None] + beta[None, :, None, None, None]
+    gz = torch.nn.grad.conv3d_input(x.shape, w, gout, padding=1)
+    A_ref, B_ref = gz.sum((2, 3, 4)), (gz * xn).sum((2, 3, 4))
+    dw_ref = torch.nn.grad.conv3d_weight(z, w.shape, gout, padding=1)
+    scale = (rstd * gamma[None]).float().to(DEV)
+    shift = (beta[None] - mean * rstd * gamma[None]).float().to(DEV)
+    x5, g5 = to5(x.float()), to5(gout.float())
+    assert ops.conv_wgrad_sums_ok(x5, k, Cin, Cout, 2)
+    dw = torch.empty(w.numel(), device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    sums = ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=2,
+                          sums_from=(w.float().to(DEV), gamma.float().to(DEV) if affine else None,
+                                     beta.float().to(DEV) if affine else None))
+    assert rel_err(dw.cpu().view(w.shape), dw_ref) < 1e-4 and rel_err(db.cpu(), gout.sum((0, 2, 3, 4))) < 5e-5
+    A, B = sums[..., 0].cpu().double(), sums[..., 1].cpu().double()
+    # both are sums of ~V signed terms: judge them against the size of the terms, sqrt(V) * rms
+    sa = float(gz.pow(2).sum((2, 3, 4)).sqrt().max())
+    sb = float((gz * xn).pow(2).sum((2, 3, 4)).sqrt().max())
+    assert float((A - A_ref).abs().max()) < 1e-4 * sa, float((A - A_ref).abs().max()) / sa
+    assert float((B - B_ref).abs().max()) < 1e-4 * sb, float((B - B_ref).abs().max()) / sb
+    # and through the norm backward: same result as the two-pass path
+    gz5, xx5 = to5(gz.float()), to5(x.float())
+    outs = []
+    for sm in (None, sums):
+        gx = torch.empty_like(gz5)
+        dgam = torch.zeros(Cin, device=DEV) if affine else None
+        dbet = torch.zeros(Cin, device=DEV) if affine else None
+        ops.norm_bwd(gz5, xx5, Cin, gamma.float().to(DEV) if affine else None, mean.float().to(DEV),
+                     rstd.float().to(DEV), True, gx, dgam, dbet, sums=sm)
+        outs.append((gx, dgam, dbet))
+    assert rel_err(outs[1][0].cpu(), outs[0][0].cpu()) < 2e-5
+    if affine:
+        assert float((outs[1][1] - outs[0][1]).abs().max()) < 1e-4 * sb and \
+            float((outs[1][2] - outs[0][2]).abs().max()) < 1e-4 * sa
+
+
 def test_conv_relu_mask_ref_and_channel_slices():
     """ref-mask epilogue and leading-dimension (concat-buffer slice) addressing."""
     ops = _ops()

@@ -38,6 +38,11 @@ SIGNATURES = {
     "tem_conv3d_wgrad_ws": (c_i64, [c_int] * 10),
     "tem_conv3d_wgrad": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 11 + [c_vp]),
     "tem_norm_ws": (c_i64, [c_int, c_i64, c_int]),
+    "tem_conv3d_wgrad_sums_ok": (c_int, [c_int] * 10),
+    "tem_conv3d_wgrad_sums": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]
+                              + [c_int] * 10 + [c_vp]),
+    "tem_norm_bwd_from_sums": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
+                                       c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tem_norm_stats": (c_int, [c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_float,
                                c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tem_norm_finalize_partials": (c_int, [c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_float,

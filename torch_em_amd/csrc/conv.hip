@@ -504,10 +504,11 @@ static void launch_wgrad_generic(const float* x, int64_t x_ld, const float* scal
                        shift, g, g_ld, N, D, H, W, Cin, Cout, p.npairs_blk, p.rows, p.vper, part);
 }
 
-extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
-                                int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H,
-                                int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma, int sd_layout,
-                                tem_stream_t stream) {
+static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                             int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H,
+                             int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma, int sd_layout,
+                             const float* w_sd, const float* gamma, const float* beta, float* norm_sums,
+                             tem_stream_t stream) {
     TEM_REQUIRE(x && g && dw && ws, "tem_conv3d_wgrad: null pointer");
     TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= Cin && g_ld >= Cout,
                 "tem_conv3d_wgrad: bad shape");
@@ -528,11 +529,12 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
         // 5: single fp16 product in the z-sliding kernel (autocast-equivalent); the other shapes keep bf16x3
         int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                        ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
-                                       sd_layout, use_mfma == 5, s);
+                                       sd_layout, use_mfma == 5, w_sd, gamma, beta, norm_sums, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(bf16x3)");
         return TEM_OK;
     }
+    TEM_REQUIRE(!norm_sums, "tem_conv3d_wgrad_sums: only the split-bf16 z-sliding kernel delivers the norm sums");
     if (use_mfma) {
         int rc = tem_conv_wgrad_mfma(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                      ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
@@ -565,4 +567,30 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
     tem_reduce_slabs_w(rest, p.nchunks, ntaps, Cin, Cout, n, dw, sd_layout, s);
     TEM_CHECK_LAUNCH("tem_conv3d_wgrad(generic)");
     return TEM_OK;
+}
+
+extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                                int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H,
+                                int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma, int sd_layout,
+                                tem_stream_t stream) {
+    return conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw,
+                             use_mfma, sd_layout, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int tem_conv3d_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                                        int use_mfma) {
+    if (use_mfma != 2 && use_mfma != 5) return 0;
+    return tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
+}
+
+extern "C" int tem_conv3d_wgrad_sums(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                                     const float* g, int64_t g_ld, const float* w, const float* gamma,
+                                     const float* beta, float* dw, float* db, float* norm_sums, void* ws,
+                                     int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh,
+                                     int kw, int use_mfma, tem_stream_t stream) {
+    TEM_REQUIRE(w && norm_sums && db, "tem_conv3d_wgrad_sums: null pointer (weights, sums and bias gradient are required)");
+    TEM_REQUIRE(tem_conv3d_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma),
+                "tem_conv3d_wgrad_sums: tem_conv3d_wgrad_sums_ok() == 0 for this layer");
+    return conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw,
+                             use_mfma, 1, w, gamma, beta, norm_sums, stream);
 }

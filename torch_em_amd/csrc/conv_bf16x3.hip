@@ -1800,10 +1800,26 @@ static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) 
     return p;
 }
 
+// Can this weight gradient also deliver the norm-backward sums (wgrad_sums.hip)?  z-sliding kernel, a few samples,
+// widths whose [27][Cout] tables fit a block's LDS
+int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    static const int enable = getenv("TEM_WGRAD_SUMS") ? atoi(getenv("TEM_WGRAD_SUMS")) : 1;
+    if (!enable || Cin % 32 || Cout % 32) return 0;
+    const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
+    const int cq = Cout / 4;
+    // four small launches replace one pass over gz and x: only worth it where that pass is long (>= 256 MB tensors)
+    static const int64_t min_bytes = getenv("TEM_WGRAD_SUMS_MIN_MB") ? atoll(getenv("TEM_WGRAD_SUMS_MIN_MB")) << 20 : 256ll << 20;
+    const int64_t bytes = (int64_t)N * D * H * W * Cin * 4;
+    return z.use && N <= 4 && Cout <= 128 && Cin <= 256 && (cq & (cq - 1)) == 0 && H >= 3 && W >= 3 && D >= 3 &&
+           bytes >= min_bytes;
+}
+
 int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
     if (z.use)
-        return tem_align_up((int64_t)z.S * z.ks2 * 27 * Cin * Cout, 64) * 4 + (int64_t)z.S * Cout * 4 + 256;
+        return tem_align_up((int64_t)z.S * z.ks2 * 27 * Cin * Cout, 64) * 4 + tem_align_up((int64_t)z.S * Cout, 64) * 4 +
+               (tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw) ? tem_wgrad_sums_ws_floats(N, D, H, Cin, Cout) * 4 : 0) +
+               256;
     WbPlan p = wb_plan(N, D, H, W, Cin, Cout, kd * kh * kw);
     return tem_align_up((int64_t)p.S * p.ks2 * kd * kh * kw * Cin * Cout, 64) * 4 + (int64_t)p.S * Cout * 4 + 256;
 }
@@ -1839,7 +1855,8 @@ static void launch_wb(const float* x, int64_t x_ld, const float* scale, const fl
 
 int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                           int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
-                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, int h16, hipStream_t s) {
+                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, int h16, const float* w_sd,
+                          const float* gamma, const float* beta, float* norm_sums, hipStream_t s) {
     TEM_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "tem_conv3d_wgrad(bf16x3): needs Cin%%32==0 and Cout%%32==0 (got %d,%d)",
                 Cin, Cout);
     TEM_REQUIRE(x_ld % 4 == 0 && g_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0),
@@ -1856,6 +1873,8 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
     if (z.use) {
         float* zpart = (float*)ws;
         float* zdb = db ? zpart + tem_align_up((int64_t)z.S * z.ks2 * 27 * Cin * Cout, 64) : nullptr;
+        TEM_REQUIRE(!norm_sums || (db && w_sd && sd_layout && tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw)),
+                    "tem_conv3d_wgrad_sums: this layer cannot deliver the norm sums (tem_conv3d_wgrad_sums_ok() == 0)");
         const unsigned nblk = (unsigned)((int64_t)z.T * z.S);
         if (z.nco == 2) {
             constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)64 * ZS_GS;
@@ -1898,10 +1917,17 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
             hipLaunchKernelGGL((k_conv_wgrad_zs<1>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
                                N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz);
         }
-        tem_reduce_slabs_w(zpart, z.S * z.ks2, 27, Cin, Cout, (int64_t)27 * Cin * Cout, dw, sd_layout, s);
+        if (norm_sums) {
+            float* extra = zdb + tem_align_up((int64_t)z.S * Cout, 64);
+            tem_wgrad_sums_launch(zpart, z.Ss, z.ks2, zdb, g, g_ld, w_sd, gamma, beta, dw, extra, N, D, H, W, Cin, Cout,
+                                  norm_sums, s);
+        } else {
+            tem_reduce_slabs_w(zpart, z.S * z.ks2, 27, Cin, Cout, (int64_t)27 * Cin * Cout, dw, sd_layout, s);
+        }
         if (db) tem_reduce_slabs(zdb, z.S, Cout, Cout, db, s);
         return TEM_OK;
     }
+    TEM_REQUIRE(!norm_sums, "tem_conv3d_wgrad_sums: this layer cannot deliver the norm sums (tem_conv3d_wgrad_sums_ok() == 0)");
     float* part = (float*)ws;
     float* dbpart = db ? part + tem_align_up((int64_t)p.S * p.ks2 * ntaps * Cin * Cout, 64) : nullptr;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);

@@ -54,4 +54,11 @@ void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, co
 int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                           int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
-                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, int h16, hipStream_t s);
+                          int Cin, int Cout, int kd, int kh, int kw, int sd_layout, int h16, const float* w_sd,
+                          const float* gamma, const float* beta, float* norm_sums, hipStream_t s);
+// wgrad_sums.hip: norm-backward sums from the weight gradient
+int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
+int64_t tem_wgrad_sums_ws_floats(int N, int D, int H, int Cin, int Cout);
+void tem_wgrad_sums_launch(const float* zpart, int Ss, int ks2, const float* zdb, const float* g, int64_t g_ld,
+                           const float* w, const float* gamma, const float* beta, float* dw, float* extra, int N, int D,
+                           int H, int W, int Cin, int Cout, float* sums, hipStream_t s);

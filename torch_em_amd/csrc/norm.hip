@@ -389,10 +389,10 @@ extern "C" int tem_norm_finalize_partials(const float* part, int64_t nblk, int N
     return TEM_OK;
 }
 
-extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C,
-                            int G, const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx,
-                            int64_t gx_ld, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
-                            tem_stream_t stream) {
+static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C,
+                         int G, const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx,
+                         int64_t gx_ld, float* dgamma, float* dbeta, const float* sums, void* ws, int64_t ws_bytes,
+                         tem_stream_t stream) {
     TEM_REQUIRE(gy && x && mean && rstd && gx && ws, "tem_norm_bwd: null pointer");
     TEM_REQUIRE(N > 0 && V > 0 && C > 0 && C <= NORM_MAX_C && x_ld >= C && gy_ld >= C && gx_ld >= C,
                 "tem_norm_bwd: bad shape (C=%d)", C);
@@ -406,17 +406,21 @@ extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int6
     float* coef = part + (int64_t)N * NORM_MAX_BLOCKS * C * 2;
     size_t lds = (size_t)g.rows * C * 2 * sizeof(float);
     dim3 grid(g.nblk, N);
-    if (g.vec == 4)
+    int nblk = g.nblk;
+    if (sums) {  // first stage delivered by the weight gradient (tem_conv3d_wgrad_sums): [N][1][C][2]
+        part = const_cast<float*>(sums);
+        nblk = 1;
+    } else if (g.vec == 4)
         hipLaunchKernelGGL((k_norm_partial<4, 1>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, gy, gy_ld,
                            V, C, G, mean, rstd, g.cq, g.rows, g.vper, part);
     else
         hipLaunchKernelGGL((k_norm_partial<1, 1>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, gy, gy_ld,
                            V, C, G, mean, rstd, g.cq, g.rows, g.vper, part);
-    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, g.nblk, V, C, G,
+    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, nblk, V, C, G,
                        gamma, mean, rstd, coef);
     if (dgamma || dbeta)
         hipLaunchKernelGGL(k_norm_bwd_affine, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, part,
-                           N, g.nblk, C, dgamma, dbeta);
+                           N, nblk, C, dgamma, dbeta);
     bool v4 = (C % 4 == 0) && gy_ld % 4 == 0 && x_ld % 4 == 0 && gx_ld % 4 == 0 && (uintptr_t)gy % 16 == 0 &&
               (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0;
     int64_t items = V * (v4 ? C / 4 : C);
@@ -429,4 +433,22 @@ extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int6
                            gx_ld, V, C, coef, relu_mask);
     TEM_CHECK_LAUNCH("tem_norm_bwd");
     return TEM_OK;
+}
+
+extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C,
+                            int G, const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx,
+                            int64_t gx_ld, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
+                            tem_stream_t stream) {
+    return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, nullptr,
+                         ws, ws_bytes, stream);
+}
+
+// tem_norm_bwd whose first stage -- sums[n][c] = (sum_v gy, sum_v gy * xn) -- was delivered by tem_conv3d_wgrad_sums
+extern "C" int tem_norm_bwd_from_sums(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V,
+                                      int C, int G, const float* gamma, const float* mean, const float* rstd,
+                                      int relu_mask, float* gx, int64_t gx_ld, float* dgamma, float* dbeta,
+                                      const float* sums, void* ws, int64_t ws_bytes, tem_stream_t stream) {
+    TEM_REQUIRE(sums, "tem_norm_bwd_from_sums: null sums");
+    return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, sums, ws,
+                         ws_bytes, stream);
 }

@@ -1,0 +1,256 @@
+// wgrad_sums.hip -- the first stage of the NORM BACKWARD without a pass over the tensors.
+//
+// The norm in front of a conv (z = gamma * xn + beta, fused into the conv as scale/shift) needs, per (sample, channel),
+//   A = sum_v gz[v][c]            B = sum_v gz[v][c] * xn[v][c]
+// where gz is the data gradient of the conv (dgrad output).  Both follow from quantities the WEIGHT gradient already
+// has, because gz[v][c] = sum_{tap,co} w[co][c][tap] * g[v - tap][co]  (g = gradient w.r.t. the conv output, zero
+// outside the volume):
+//   sum_v gz[v][c] z[v][c] = sum_{tap,co} w[co][c][tap] * dw_n[co][c][tap]     dw_n = weight gradient of sample n
+//   sum_v gz[v][c]         = sum_{tap,co} w[co][c][tap] * T_n[tap][co]         T_n[tap][co] = sum of g[.][co] over the
+//                                                                              voxels u with u + tap inside the volume
+// and B = (sum gz z - beta * A) / gamma.  T_n is the per-sample bias gradient minus boundary faces / edges / corners.
+// The tensor pass k_norm_partial<.,1> (two reads of a 0.5-1 GB tensor per level-0 layer, 1.06 ms of a 24 ms step)
+// becomes: per-sample sums in the slab merge that runs anyway, a pass over the boundary shell of g (1.5 % of it), and
+// one block per sample of arithmetic on [27][Cout] numbers.
+#include "tem_common.h"
+#include "conv_internal.h"
+
+// ---------------------------------------------------------------------------
+// slab merge (as k_reduce_slabs_sd) that also emits, per sample and per group of 32 output channels,
+//   P[n][i / 32] = sum_{co in group} w[co][ci][tap] * dw_n[tap][ci][co]
+// chunks are grouped per sample: chunk c belongs to sample c / cps
+// ---------------------------------------------------------------------------
+#define WS_MAXN 4
+__global__ __launch_bounds__(512) void k_reduce_slabs_wsum(const float* __restrict__ part, int cps, int N, int ntaps,
+                                                           int Cin, int Cout, int64_t chunk_stride,
+                                                           float* __restrict__ out, const float* __restrict__ w,
+                                                           float* __restrict__ P) {
+    __shared__ double sh[WS_MAXN][8][64];
+    const int64_t n_out = (int64_t)ntaps * Cin * Cout;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n_out; i0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = i0 + tx;
+#pragma unroll
+        for (int n = 0; n < WS_MAXN; ++n) {
+            double s = 0.0;
+            if (n < N && i < n_out) {
+                double s1 = 0.0;
+                int c = n * cps + ty;
+                const int ce = (n + 1) * cps;
+                for (; c + 8 < ce; c += 16) {
+                    s += (double)part[(int64_t)c * chunk_stride + i];
+                    s1 += (double)part[(int64_t)(c + 8) * chunk_stride + i];
+                }
+                if (c < ce) s += (double)part[(int64_t)c * chunk_stride + i];
+                s += s1;
+            }
+            sh[n][ty][tx] = s;
+        }
+        __syncthreads();
+        if (ty == 0) {  // wave 0: one lane per output
+            double tot = 0.0;
+            const bool ok = i < n_out;
+            const int co = ok ? (int)(i % Cout) : 0;
+            const int64_t r = ok ? i / Cout : 0;
+            const int ci = (int)(r % Cin), tap = (int)(r / Cin);
+            const int64_t widx = ((int64_t)co * Cin + ci) * ntaps + tap;
+            const double wv = ok ? (double)w[widx] : 0.0;
+#pragma unroll
+            for (int n = 0; n < WS_MAXN; ++n) {
+                if (n < N) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a += sh[n][k][tx];
+                    tot += a;
+                    double v = wv * a;  // lanes of a 32-group share (tap, ci): Cout % 32 == 0, i0 % 64 == 0
+                    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+                    if ((tx & 31) == 0 && ok) P[(int64_t)n * (n_out >> 5) + (i >> 5)] = (float)v;
+                }
+            }
+            if (ok) out[widx] = (float)tot;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// boundary shell of g: sums over the 9 (y class, x class) position classes (class 0 = first index, 1 = middle, 2 = last)
+// per "slot": slot s < D-2 is the RING of middle plane z = s+1 (rows 0 / H-1, columns 0 / W-1; its (1,1) entry stays
+// 0: the interior total comes from the bias gradient); slots D-2 .. D-2+H-1 are the rows of plane 0, the next H those
+// of plane D-1 (full rows).  planepart: [N][nslot][9][C], nslot = D-2 + 2H.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_shell_plane_sums(const float* __restrict__ g, int64_t g_ld, int D, int H, int W,
+                                                          int C, float* __restrict__ planepart) {
+    extern __shared__ float lsh[];  // [4 waves][9][C]
+    const int slot = blockIdx.x, n = blockIdx.y, nslot = D - 2 + 2 * H;
+    const int cq = C >> 2;          // power of two <= 64 (checked by the launcher)
+    const int q = threadIdx.x % cq, lanev = threadIdx.x / cq, nlv = 256 / cq;
+    const bool ringmode = slot < D - 2;
+    const int z = ringmode ? slot + 1 : ((slot - (D - 2)) < H ? 0 : D - 1);
+    const int yrow = ringmode ? 0 : (slot - (D - 2)) % H;
+    const int count = ringmode ? 2 * W + 2 * (H - 2) : W;
+    float4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* gp = g + ((int64_t)n * D + z) * H * W * g_ld + q * 4;
+    for (int idx = lanev; idx < count; idx += nlv) {
+        int y, x;
+        if (!ringmode) {
+            y = yrow;
+            x = idx;
+        } else if (idx < W) {
+            y = 0;
+            x = idx;
+        } else if (idx < 2 * W) {
+            y = H - 1;
+            x = idx - W;
+        } else {
+            const int j = idx - 2 * W;
+            y = 1 + (j >> 1);
+            x = (j & 1) ? W - 1 : 0;
+        }
+        const int cls = ((y == 0) ? 0 : (y == H - 1) ? 2 : 1) * 3 + ((x == 0) ? 0 : (x == W - 1) ? 2 : 1);
+        const float4 v = *reinterpret_cast<const float4*>(gp + ((int64_t)y * W + x) * g_ld);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float m = (k == cls) ? 1.f : 0.f;
+            acc[k].x = fmaf(m, v.x, acc[k].x);
+            acc[k].y = fmaf(m, v.y, acc[k].y);
+            acc[k].z = fmaf(m, v.z, acc[k].z);
+            acc[k].w = fmaf(m, v.w, acc[k].w);
+        }
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float vals[4] = {acc[k].x, acc[k].y, acc[k].z, acc[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            for (int o = cq; o < 64; o <<= 1) vals[j] += __shfl_xor(vals[j], o, 64);  // lanes sharing q sit cq apart
+            if (lane < cq) lsh[(wv * 9 + k) * C + lane * 4 + j] = vals[j];
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 9 * C; t += 256) {
+        float a = 0.f;
+        for (int w4 = 0; w4 < 4; ++w4) a += lsh[w4 * 9 * C + t];
+        planepart[(((int64_t)n * nslot + slot) * 9) * C + t] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// block (ci group of 32, sample): class totals -> T[tap][co] -> A[ci], B[ci]  -> sums[n][ci][2] = (A, B)
+//   taps are indexed as the kernels do: tap = (tz*3 + ty)*3 + tx, the conv reads x[v + (t - 1)], so dw[tap] pairs g[u]
+//   with z[u + (t - 1)] and T[tap] sums g[u] over the u with u + (t - 1) inside the volume.
+// Every reduction runs 4 lanes wide (slots) resp. 8 lanes wide (tap x co) with shuffles: no serial 100-step loops.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __restrict__ planepart,
+                                                              const float* __restrict__ dbpart, int Ss, int D, int H,
+                                                              int Cin, int Cout, const float* __restrict__ w,
+                                                              const float* __restrict__ P, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ sums) {
+    extern __shared__ float lt[];        // cls[27][Cout] then T[27][Cout]
+    float* cls = lt;
+    float* T = lt + 27 * Cout;
+    const int n = blockIdx.y, nslot = D - 2 + 2 * H;
+    const int l4 = threadIdx.x & 3, e4 = threadIdx.x >> 2;  // 256 entries per round, 4 slot lanes each (1024 threads)
+    for (int e0 = 0; e0 < 27 * Cout; e0 += 256) {
+        const int t = e0 + e4;
+        float a = 0.f;
+        if (t < 27 * Cout) {
+            const int cz = t / (9 * Cout), rem = t % (9 * Cout);
+            const int s0 = cz == 1 ? 0 : (cz == 0 ? D - 2 : D - 2 + H), s1 = cz == 1 ? D - 2 : s0 + H;
+            float a1 = 0.f;
+            int sl = s0 + l4;
+            for (; sl + 4 < s1; sl += 8) {
+                a += planepart[((int64_t)n * nslot + sl) * 9 * Cout + rem];
+                a1 += planepart[((int64_t)n * nslot + sl + 4) * 9 * Cout + rem];
+            }
+            if (sl < s1) a += planepart[((int64_t)n * nslot + sl) * 9 * Cout + rem];
+            a += a1;
+        }
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (l4 == 0 && t < 27 * Cout) cls[t] = a;
+    }
+    __syncthreads();
+    // the interior class (1,1,1) = total - everything else; total = per-sample bias gradient (Ss partial rows)
+    for (int c0 = 0; c0 < Cout; c0 += 256) {
+        const int co = c0 + e4;
+        float tot = 0.f;
+        if (co < Cout)
+            for (int sp = l4; sp < Ss; sp += 4) tot += dbpart[((int64_t)n * Ss + sp) * Cout + co];
+        tot += __shfl_xor(tot, 1, 64);
+        tot += __shfl_xor(tot, 2, 64);
+        if (l4 == 0 && co < Cout) {
+            float rest = 0.f;
+            for (int k = 0; k < 27; ++k)
+                if (k != 13) rest += cls[k * Cout + co];
+            cls[13 * Cout + co] = tot - rest;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 27 * Cout; t += 1024) {
+        const int tap = t / Cout, co = t % Cout;
+        const int d[3] = {tap / 9 - 1, (tap / 3) % 3 - 1, tap % 3 - 1};
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const int c3[3] = {k / 9, (k / 3) % 3, k % 3};
+            bool ok = true;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (d[ax] == 1 && c3[ax] == 2) ok = false;   // u is the last index: u + 1 is outside
+                if (d[ax] == -1 && c3[ax] == 0) ok = false;  // u is the first index: u - 1 is outside
+            }
+            a += ok ? cls[k * Cout + co] : 0.f;
+        }
+        T[t] = a;
+    }
+    __syncthreads();
+    const int64_t n_out = (int64_t)27 * Cin * Cout;
+    const int cg = Cout >> 5;
+    const int ci = blockIdx.x * 32 + (threadIdx.x >> 5), l8 = threadIdx.x & 31;  // 32 lanes per input channel
+    double A = 0.0, S2 = 0.0;
+    if (ci < Cin) {
+        for (int j = l8; j < 27 * Cout; j += 32) {  // j = tap * Cout + co
+            const int tap = j / Cout, co = j % Cout;
+            A += (double)w[((int64_t)co * Cin + ci) * 27 + tap] * (double)T[j];
+        }
+        for (int j = l8; j < 27 * cg; j += 32) {
+            const int tap = j / cg, k = j % cg;
+            S2 += (double)P[(int64_t)n * (n_out >> 5) + ((int64_t)tap * Cin + ci) * cg + k];
+        }
+    }
+    for (int o = 1; o < 32; o <<= 1) {
+        A += __shfl_xor(A, o, 64);
+        S2 += __shfl_xor(S2, o, 64);
+    }
+    if (ci < Cin && l8 == 0) {
+        const double ga = gamma ? (double)gamma[ci] : 1.0, be = beta ? (double)beta[ci] : 0.0;
+        const double B = fabs(ga) > 1e-30 ? (S2 - be * A) / ga : 0.0;
+        sums[((int64_t)n * Cin + ci) * 2 + 0] = (float)A;
+        sums[((int64_t)n * Cin + ci) * 2 + 1] = (float)B;
+    }
+}
+
+// workspace (floats) behind the slab workspace: P [N][27*Cin*Cout/32] + planepart [N][D-2+2H][9][Cout]
+int64_t tem_wgrad_sums_ws_floats(int N, int D, int H, int Cin, int Cout) {
+    return tem_align_up((int64_t)N * 27 * Cin * Cout / 32, 64) + (int64_t)N * (D - 2 + 2 * H) * 9 * Cout;
+}
+
+void tem_wgrad_sums_launch(const float* zpart, int Ss, int ks2, const float* zdb, const float* g, int64_t g_ld,
+                           const float* w, const float* gamma, const float* beta, float* dw, float* extra, int N, int D,
+                           int H, int W, int Cin, int Cout, float* sums, hipStream_t s) {
+    float* P = extra;
+    float* planepart = extra + tem_align_up((int64_t)N * 27 * Cin * Cout / 32, 64);
+    const int64_t n_out = (int64_t)27 * Cin * Cout;
+    int64_t nb = tem_cdiv(n_out, 64);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_reduce_slabs_wsum, dim3((unsigned)nb), dim3(512), 0, s, zpart, Ss * ks2, N, 27, Cin, Cout, n_out,
+                       dw, w, P);
+    hipLaunchKernelGGL(k_shell_plane_sums, dim3(D - 2 + 2 * H, N), dim3(256), (size_t)4 * 9 * Cout * sizeof(float), s, g,
+                       g_ld, D, H, W, Cout, planepart);
+    hipLaunchKernelGGL(k_norm_sums_from_wgrad, dim3((Cin + 31) / 32, N), dim3(1024), (size_t)2 * 27 * Cout * sizeof(float),
+                       s, planepart, zdb, Ss, D, H, Cin, Cout, w, P, gamma, beta, sums);
+}

@@ -304,12 +304,20 @@ def _dgrad(spec: ConvSpec, g, gx, ref=None):
     ops.conv_fwd(g, ent["dgrad"], None, gx, spec.k, spec.cout, spec.cin, ref=ref, mfma=ent["dgrad_mfma"])
 
 
-def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None):
+# Norm-backward sums from the weight gradient (csrc/wgrad_sums.hip, tem_conv3d_wgrad_sums): the reduction pass over the
+# data gradient and the norm input disappears for the layers that qualify.  TEM_WGRAD_SUMS=0 disables (C side).
+def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None, want_sums=False):
+    """-> sums[N, Cin, 2] for _norm_bwd_inplace when want_sums and the layer qualifies, else None"""
     ent = spec.packed()
     scale, shift = (stats[2], stats[3]) if stats is not None else (None, None)
     dw = grads.view(spec.conv.weight)
     db = grads.view(spec.conv.bias) if spec.conv.bias is not None else None
     vox = x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3]
+    if want_sums and stats is not None and stats[4] == "sample" and db is not None and not _OVERLAP_WGRAD and \
+            ops.conv_wgrad_sums_ok(x, spec.k, spec.cin, spec.cout, ent["wgrad_mfma"]):
+        _, gamma, beta, _ = spec.norm_args()
+        return ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"],
+                              sums_from=(spec.conv.weight, gamma, beta))
     if not _OVERLAP_WGRAD or (_OVERLAP_WGRAD == 1 and vox > _OVERLAP_MAX_VOXELS):
         ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
         return
@@ -400,7 +408,7 @@ def _block_fwd(blk, xin, out):
     return {"xin": xin, "a1": a1, "out": out, "s1": s1, "s2": s2, "c1": c1, "c2": c2}
 
 
-def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads):
+def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sums=None):
     groups, gamma, beta, _ = spec.norm_args()
     dgamma = grads.view(gamma) if gamma is not None else None
     dbeta = grads.view(beta) if beta is not None else None
@@ -412,7 +420,7 @@ def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads):
         gb = _flat_batch(g)
         ops.norm_bwd(gb, _flat_batch(x), groups, gamma, stats[0], stats[1], relu_mask, gb, dgamma, dbeta)
         return
-    ops.norm_bwd(g, x, groups, gamma, stats[0], stats[1], relu_mask, g, dgamma, dbeta)
+    ops.norm_bwd(g, x, groups, gamma, stats[0], stats[1], relu_mask, g, dgamma, dbeta, sums=sums)
 
 
 def _block_bwd(bs, gout, gin, grads: _Grads):
@@ -423,8 +431,8 @@ def _block_bwd(bs, gout, gin, grads: _Grads):
     ga1 = torch.empty_like(a1)
     if bs["s2"] is not None:
         _dgrad(c2, gout, ga1)
-        _wgrad(c2, a1, gout, grads, bs["s2"])
-        _norm_bwd_inplace(c2, ga1, a1, bs["s2"], True, grads)  # a1 is a ReLU output: mask fused
+        sums = _wgrad(c2, a1, gout, grads, bs["s2"], want_sums=True)
+        _norm_bwd_inplace(c2, ga1, a1, bs["s2"], True, grads, sums=sums)  # a1 is a ReLU output: mask fused
     else:
         _dgrad(c2, gout, ga1, ref=a1)
         _wgrad(c2, a1, gout, grads, bs["s2"])
@@ -436,9 +444,9 @@ def _block_bwd(bs, gout, gin, grads: _Grads):
         N, D, H, W, _ = xin.shape
         gin = ops.new_act(N, D, H, W, c1.cin, xin.device)
     _dgrad(c1, ga1, gin)
-    _wgrad(c1, xin, ga1, grads, bs["s1"])
+    sums = _wgrad(c1, xin, ga1, grads, bs["s1"], want_sums=bs["s1"] is not None)
     if bs["s1"] is not None:
-        _norm_bwd_inplace(c1, gin, xin, bs["s1"], False, grads)
+        _norm_bwd_inplace(c1, gin, xin, bs["s1"], False, grads, sums=sums)
 
 
 # -----------------------------------------------------------------------------------

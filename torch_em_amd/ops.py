@@ -226,7 +226,39 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
-def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, mfma=False):
+def conv_wgrad_sums_ok(x, k, cin, cout, mfma) -> bool:
+    N, D, H, W, _, _ = _act5(x)
+    return bool(_lib.load().tem_conv3d_wgrad_sums_ok(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
+
+
+def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, mfma=False, sums_from=None):
+    """sums_from = (weight [state_dict layout], gamma, beta): also return sums[N, cin, 2] = (sum gz, sum gz*xn) of the
+    norm in front of this conv (tem_conv3d_wgrad_sums; check conv_wgrad_sums_ok first)."""
+    if sums_from is not None:
+        return _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sums_from)
+    return _conv_wgrad(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma)
+
+
+def _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sums_from):
+    _req_cuda(x, g, dw_out, db_out)
+    w, gamma, beta = sums_from
+    N, D, H, W, C, x_ld = _act5(x)
+    g_ld = _act5(g)[5]
+    lib = _lib.load()
+    nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma))
+    ws = _workspace(nws, x.device)
+    sums = torch.empty((N, cin, 2), dtype=torch.float32, device=x.device)
+    kind = _wgrad_tag(mfma, k, cout) if PROFILER is not None else None
+    ev0 = _prof_begin(x, kind)
+    _lib.check(lib.tem_conv3d_wgrad_sums(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w.detach()), _p(gamma), _p(beta),
+                                         _p(dw_out), _p(db_out), _p(sums), _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1],
+                                         k[2], int(mfma), _stream(x)), "tem_conv3d_wgrad_sums")
+    if ev0 is not None:
+        _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
+    return sums
+
+
+def _conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, mfma=False):
     """dw_out: flat [ntaps*cin*cout] in the reference's [Cout,Cin,kd,kh,kw] order; db_out: [cout]."""
     _req_cuda(x, g, dw_out)
     N, D, H, W, C, x_ld = _act5(x)
@@ -288,7 +320,8 @@ def norm_stats_from_partials(part, rows: int, voxels: int, C: int, groups: int, 
     return mean, rstd, scale, shift
 
 
-def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None, dbeta=None):
+def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None, dbeta=None, sums=None):
+    """sums: [N, C, 2] from conv_wgrad(sums_from=...) -- skips the reduction pass over gy and x"""
     _req_cuda(gy, x, gx)
     N, D, H, W, C, x_ld = _act5(x)
     gy_ld = _act5(gy)[5]
@@ -297,6 +330,11 @@ def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None,
     V = D * H * W
     nws = lib.tem_norm_ws(N, V, C)
     ws = _workspace(nws, x.device)
+    if sums is not None:
+        _lib.check(lib.tem_norm_bwd_from_sums(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd),
+                                              int(relu_mask), _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(sums), _p(ws), nws,
+                                              _stream(x)), "tem_norm_bwd_from_sums")
+        return gx
     _lib.check(lib.tem_norm_bwd(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd),
                                 int(relu_mask), _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(ws), nws, _stream(x)),
                "tem_norm_bwd")
