@@ -201,6 +201,16 @@ int tem_norm_bwd_from_sums(const float* gy, int64_t gy_ld, const float* x, int64
                            float* gx, int64_t gx_ld, float* dgamma, float* dbeta,
                            const float* sums, void* ws, int64_t ws_bytes, tem_stream_t stream);
 
+/* Reduction stage of tem_norm_bwd only: coef[n][c] = {a, m1, m2r, mean}, gx = a*gy - m1 - (x - mean)*m2r (plus dgamma /
+ * dbeta).  For the norm in front of a decoder block (its input is the concat of an upsampled tensor and a skip tensor,
+ * reference Decoder._concat model/unet.py:363-373) the elementwise stage is then applied by the two kernels that read
+ * the gradient next -- tem_upsample_bwd_norm and tem_maxpool3d_bwd_norm -- and the 3-tensor pass over the concat
+ * buffer disappears.  sums: optional first stage from tem_conv3d_wgrad_sums. */
+int tem_norm_bwd_coef(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld,
+                      int N, int64_t V, int C, int G, const float* gamma,
+                      const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                      const float* sums, float* coef, void* ws, int64_t ws_bytes, tem_stream_t stream);
+
 /* ---- pooling / upsampling ------------------------------------------------
  * nn.MaxPool3d(factor) (model/unet.py:300-302,645): kernel == stride == factor.
  * Backward routes the gradient to the first maximum in (z,y,x) scan order (ATen's
@@ -213,6 +223,13 @@ int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_
                       const float* gskip, int64_t gskip_ld, int relu_mask,
                       float* gx, int64_t gx_ld,
                       int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
+/* ... where gskip is still the RAW data gradient behind a norm whose input is x: gskip := a*gskip - m1 - (x - mean)*m2r
+ * with gcoef = tem_norm_bwd_coef()'s rows for these C channels (gcoef_ld floats per sample) -- see tem_norm_bwd_coef */
+int tem_maxpool3d_bwd_norm(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld,
+                           const float* gskip, int64_t gskip_ld, int relu_mask,
+                           float* gx, int64_t gx_ld,
+                           int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                           const float* gcoef, int64_t gcoef_ld, tem_stream_t stream);
 /* F.interpolate(mode="trilinear"/"bilinear", align_corners=False, integer scale
  * factors) (model/unet.py:456).  (D,H,W) are the INPUT dims; output is (D*fz,H*fy,W*fx).
  * bwd is the exact adjoint (upsample_trilinear3d_backward). */
@@ -220,6 +237,11 @@ int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld,
                      int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
 int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld,
                      int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
+/* ... of the RAW data gradient gy behind a norm whose input was upsample(u) (u: the low-resolution tensor, same shape
+ * as gx): gx = a*U^T gy - m1*U^T 1 - m2r*(U^T U u - mean*U^T 1), ncoef as for tem_maxpool3d_bwd_norm */
+int tem_upsample_bwd_norm(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld,
+                          int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                          const float* u, int64_t u_ld, const float* ncoef, int64_t ncoef_ld, tem_stream_t stream);
 
 /* ---- Dice ------------------------------------------------------------------
  * dice_score / DiceLoss (loss/dice.py:34-133) and the masked variant

@@ -288,6 +288,47 @@ def test_wgrad_delivers_norm_backward_sums(case):
             float((outs[1][2] - outs[0][2]).abs().max()) < 1e-4 * sa
 
 
+@pytest.mark.parametrize("case", [((2, 2, 2), (2, 6, 5, 7), 32, 32, 32), ((1, 2, 2), (1, 5, 6, 4), 64, 64, 32),
+                                  ((1, 2, 2), (2, 1, 9, 8), 32, 32, 1), ((2, 2, 2), (1, 3, 4, 4), 8, 24, 8)])
+def test_deferred_concat_norm_backward(case):
+    """The backward of the norm in front of a decoder block (input = concat(upsample(u), skip), reference
+    Decoder._concat model/unet.py:363-373) without its elementwise pass: tem_norm_bwd_coef + tem_upsample_bwd_norm
+    (27-point stencil on the low-resolution u) + tem_maxpool3d_bwd_norm must equal norm_bwd followed by the plain
+    upsample / max-pool backward."""
+    ops = _ops()
+    f, (N, d, h, w), cup, cskip, groups = case
+    C = cup + cskip
+    D, H, W = d * f[0], h * f[1], w * f[2]
+    g = torch.Generator().manual_seed(11)
+    u = torch.randn(N, d, h, w, cup, generator=g).to(DEV)
+    cat = torch.empty(N, D, H, W, C, device=DEV)
+    ops.upsample_fwd(u, cat[..., :cup], f)
+    cat[..., cup:] = torch.relu(torch.randn(N, D, H, W, cskip, generator=g)).to(DEV)
+    gcat = torch.randn(N, D, H, W, C, generator=g).to(DEV)
+    gpool = torch.randn(N, d, h, w, cskip, generator=g).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = torch.randn(C, generator=g).to(DEV)
+    mean, rstd, _, _ = ops.norm_stats(cat, groups, gamma, beta, 1e-5)
+    # reference: apply pass, then the plain consumers
+    gapp = gcat.clone()
+    dg0, db0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.norm_bwd(gapp, cat, groups, gamma, mean, rstd, False, gapp, dg0, db0)
+    gt0 = torch.empty_like(u)
+    ops.upsample_bwd(gapp[..., :cup], gt0, f)
+    gs0 = torch.empty(N, D, H, W, cskip, device=DEV)
+    ops.maxpool_bwd(gpool, cat[..., cup:], gs0, f, gskip=gapp[..., cup:], relu_mask=True)
+    # deferred: coefficients only, the consumers apply them
+    dg1, db1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    coef = ops.norm_bwd_coef(gcat, cat, groups, gamma, mean, rstd, dg1, db1)
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    gt1 = torch.empty_like(u)
+    ops.upsample_bwd(gcat[..., :cup], gt1, f, norm=(u, coef[:, :cup]))
+    gs1 = torch.empty(N, D, H, W, cskip, device=DEV)
+    ops.maxpool_bwd(gpool, cat[..., cup:], gs1, f, gskip=gcat[..., cup:], relu_mask=True, gskip_coef=coef[:, cup:])
+    assert rel_err(gs1.cpu(), gs0.cpu()) < 1e-6
+    assert rel_err(gt1.cpu(), gt0.cpu()) < 2e-5
+
+
 def test_conv_relu_mask_ref_and_channel_slices():
     """ref-mask epilogue and leading-dimension (concat-buffer slice) addressing."""
     ops = _ops()

@@ -391,9 +391,10 @@ extern "C" int tem_norm_finalize_partials(const float* part, int64_t nblk, int N
 
 static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C,
                          int G, const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx,
-                         int64_t gx_ld, float* dgamma, float* dbeta, const float* sums, void* ws, int64_t ws_bytes,
-                         tem_stream_t stream) {
-    TEM_REQUIRE(gy && x && mean && rstd && gx && ws, "tem_norm_bwd: null pointer");
+                         int64_t gx_ld, float* dgamma, float* dbeta, const float* sums, float* coef_out, void* ws,
+                         int64_t ws_bytes, tem_stream_t stream) {
+    TEM_REQUIRE(gy && x && mean && rstd && (gx || coef_out) && ws, "tem_norm_bwd: null pointer");
+    if (coef_out) gx_ld = C;
     TEM_REQUIRE(N > 0 && V > 0 && C > 0 && C <= NORM_MAX_C && x_ld >= C && gy_ld >= C && gx_ld >= C,
                 "tem_norm_bwd: bad shape (C=%d)", C);
     TEM_REQUIRE(G > 0 && C % G == 0, "tem_norm_bwd: C=%d not divisible by G=%d", C, G);
@@ -403,7 +404,7 @@ static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t
     }
     NormGeom g = norm_geom(x, gy, x_ld, gy_ld, V, C);
     float* part = (float*)ws;
-    float* coef = part + (int64_t)N * NORM_MAX_BLOCKS * C * 2;
+    float* coef = coef_out ? coef_out : part + (int64_t)N * NORM_MAX_BLOCKS * C * 2;
     size_t lds = (size_t)g.rows * C * 2 * sizeof(float);
     dim3 grid(g.nblk, N);
     int nblk = g.nblk;
@@ -421,6 +422,10 @@ static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t
     if (dgamma || dbeta)
         hipLaunchKernelGGL(k_norm_bwd_affine, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, part,
                            N, nblk, C, dgamma, dbeta);
+    if (coef_out) {  // the consumers of the gradient apply gx = a*gy - m1 - (x - mean)*m2r themselves
+        TEM_CHECK_LAUNCH("tem_norm_bwd_coef");
+        return TEM_OK;
+    }
     bool v4 = (C % 4 == 0) && gy_ld % 4 == 0 && x_ld % 4 == 0 && gx_ld % 4 == 0 && (uintptr_t)gy % 16 == 0 &&
               (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0;
     int64_t items = V * (v4 ? C / 4 : C);
@@ -440,7 +445,7 @@ extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int6
                             int64_t gx_ld, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
                             tem_stream_t stream) {
     return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, nullptr,
-                         ws, ws_bytes, stream);
+                         nullptr, ws, ws_bytes, stream);
 }
 
 // tem_norm_bwd whose first stage -- sums[n][c] = (sum_v gy, sum_v gy * xn) -- was delivered by tem_conv3d_wgrad_sums
@@ -449,6 +454,19 @@ extern "C" int tem_norm_bwd_from_sums(const float* gy, int64_t gy_ld, const floa
                                       int relu_mask, float* gx, int64_t gx_ld, float* dgamma, float* dbeta,
                                       const float* sums, void* ws, int64_t ws_bytes, tem_stream_t stream) {
     TEM_REQUIRE(sums, "tem_norm_bwd_from_sums: null sums");
-    return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, sums, ws,
+    return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, sums,
+                         nullptr, ws, ws_bytes, stream);
+}
+
+// Reduction stage only: coef[n][c] = {a, m1, m2r, mean} with gx = a*gy - m1 - (x - mean)*m2r (and dgamma / dbeta).  The
+// elementwise apply is left to the kernels that read the gradient next: tem_maxpool3d_bwd_norm (skip half of a decoder
+// concat) and tem_upsample_bwd_norm (its upsampled half) -- the 3-tensor apply pass over the concat buffer disappears.
+// sums: optional first stage from tem_conv3d_wgrad_sums (then gy / x are not read at all).
+extern "C" int tem_norm_bwd_coef(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C,
+                                 int G, const float* gamma, const float* mean, const float* rstd, float* dgamma,
+                                 float* dbeta, const float* sums, float* coef, void* ws, int64_t ws_bytes,
+                                 tem_stream_t stream) {
+    TEM_REQUIRE(coef, "tem_norm_bwd_coef: null coef");
+    return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, 0, nullptr, C, dgamma, dbeta, sums, coef, ws,
                          ws_bytes, stream);
 }

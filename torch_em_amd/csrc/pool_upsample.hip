@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
                                                      const float* __restrict__ x, int64_t x_ld,
                                                      const float* __restrict__ gskip, int64_t gskip_ld, int relu_mask,
                                                      float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
-                                                     int fz, int fy, int fx) {
+                                                     int fz, int fy, int fx, const float* __restrict__ gcoef,
+                                                     int64_t gcoef_ld) {
     const int Do = D / fz, Ho = H / fy, Wo = W / fx;
     const int cq = C / VEC;
     int row = blockIdx.x;
@@ -136,7 +137,16 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
                         for (int j = 0; j < VEC; ++j) o[j] = 0.f;
                     }
                     float t[VEC];
-                    if (relu_mask) ld_vec<VEC>(x + v * x_ld + c0, t);
+                    if (relu_mask || gcoef) ld_vec<VEC>(x + v * x_ld + c0, t);
+                    if (gcoef) {
+                        // gskip is the RAW data gradient of the decoder conv behind the concat norm: apply that norm's
+                        // backward here (x is its input: the skip tensor) instead of in a pass of its own
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            const float4 kc = *reinterpret_cast<const float4*>(gcoef + (int64_t)n * gcoef_ld + (c0 + j) * 4);
+                            o[j] = kc.x * o[j] - kc.y - (t[j] - kc.w) * kc.z;
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
                         if (am[j] == k) o[j] += g[j];
@@ -164,9 +174,9 @@ extern "C" int tem_maxpool3d_fwd(const float* x, int64_t x_ld, float* y, int64_t
     return TEM_OK;
 }
 
-extern "C" int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, const float* gskip,
-                                 int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H, int W,
-                                 int C, int fz, int fy, int fx, tem_stream_t stream) {
+static int maxpool3d_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, const float* gskip,
+                              int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H, int W,
+                              int C, int fz, int fy, int fx, const float* gcoef, int64_t gcoef_ld, tem_stream_t stream) {
     TEM_REQUIRE(gy && x && gx && N > 0 && C > 0 && x_ld >= C && gy_ld >= C && gx_ld >= C,
                 "tem_maxpool3d_bwd: bad arguments");
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0 && D % fz == 0 && H % fy == 0 && W % fx == 0,
@@ -175,12 +185,32 @@ extern "C" int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x,
     TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_bwd: too many rows");
     if (vec4_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}))
         hipLaunchKernelGGL((k_maxpool_bwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
-                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx);
+                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld);
     else
         hipLaunchKernelGGL((k_maxpool_bwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
-                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx);
+                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld);
     TEM_CHECK_LAUNCH("tem_maxpool3d_bwd");
     return TEM_OK;
+}
+
+extern "C" int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, const float* gskip,
+                                 int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H, int W,
+                                 int C, int fz, int fy, int fx, tem_stream_t stream) {
+    return maxpool3d_bwd_impl(gy, gy_ld, x, x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, N, D, H, W, C, fz, fy, fx, nullptr,
+                              0, stream);
+}
+
+// tem_maxpool3d_bwd whose skip gradient is still the RAW data gradient of the decoder conv behind the concat norm: that
+// norm's backward (coefficients from tem_norm_bwd_coef, rows of gcoef_ld floats per sample, this tensor's channels
+// first) is applied on the fly -- x, its input, is the tensor this kernel reads anyway.
+extern "C" int tem_maxpool3d_bwd_norm(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, const float* gskip,
+                                      int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H,
+                                      int W, int C, int fz, int fy, int fx, const float* gcoef, int64_t gcoef_ld,
+                                      tem_stream_t stream) {
+    TEM_REQUIRE(gskip && gcoef && gcoef_ld >= 4 * C && ((uintptr_t)gcoef % 16 == 0) && gcoef_ld % 4 == 0,
+                "tem_maxpool3d_bwd_norm: bad coefficient arguments");
+    return maxpool3d_bwd_impl(gy, gy_ld, x, x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, N, D, H, W, C, fz, fy, fx, gcoef,
+                              gcoef_ld, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -249,10 +279,26 @@ __device__ __forceinline__ float lin_w(int o, int f, int in, int i) {
     return w;
 }
 
+// (U^T U)[i][i+d], d = -1, 0, 1, and (U^T 1)[i] of the 1-D interpolation operator U (lin_w)
+__device__ __forceinline__ void utu_axis(int i, int f, int in, float (&a)[3], float& s) {
+    a[0] = a[1] = a[2] = 0.f;
+    s = 0.f;
+    const int olo = max(0, f * i - f), ohi = min(in * f - 1, f * i + 2 * f - 1);
+    for (int o = olo; o <= ohi; ++o) {
+        const float w = lin_w(o, f, in, i);
+        if (w == 0.f) continue;
+        s += w;
+#pragma unroll
+        for (int d = -1; d <= 1; ++d)
+            if (i + d >= 0 && i + d < in) a[d + 1] = fmaf(w, lin_w(o, f, in, i + d), a[d + 1]);
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ gy, int64_t gy_ld,
                                                       float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
-                                                      int fz, int fy, int fx) {
+                                                      int fz, int fy, int fx, const float* __restrict__ u, int64_t u_ld,
+                                                      const float* __restrict__ ncoef, int64_t ncoef_ld) {
     const int Do = D * fz, Ho = H * fy, Wo = W * fx;
     const int cq = C / VEC;
     int row = blockIdx.x;  // (n, z, y) of the INPUT grid
@@ -287,6 +333,38 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
             }
         }
         int64_t v = (((int64_t)n * D + zi) * H + yi) * W + xi;
+        if (ncoef) {
+            // gy is the RAW data gradient g of the conv behind a norm whose input was upsample(u); the norm backward
+            // g' = a*g - m1 - (x - mean)*m2r is linear and x = U u, so  U^T g' = a*U^T g - m1*U^T 1 - m2r*(U^T U u - mean*U^T 1):
+            // a 27-point stencil on the LOW-RESOLUTION tensor u replaces a pass over the fine tensors
+            float az[3], ay[3], ax[3], sz, sy, sx;
+            utu_axis(zi, fz, D, az, sz);
+            utu_axis(yi, fy, H, ay, sy);
+            utu_axis(xi, fx, W, ax, sx);
+            const float S = sz * sy * sx;
+            float q[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) q[j] = 0.f;
+            for (int dz = -1; dz <= 1; ++dz) {
+                if (az[dz + 1] == 0.f) continue;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    if (ay[dy + 1] == 0.f) continue;
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const float wq = az[dz + 1] * ay[dy + 1] * ax[dx + 1];
+                        if (wq == 0.f) continue;
+                        float t[VEC];
+                        ld_vec<VEC>(u + ((((int64_t)n * D + zi + dz) * H + yi + dy) * W + xi + dx) * u_ld + c0, t);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) q[j] = fmaf(wq, t[j], q[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float4 kc = *reinterpret_cast<const float4*>(ncoef + (int64_t)n * ncoef_ld + (c0 + j) * 4);
+                acc[j] = kc.x * acc[j] - kc.y * S - kc.z * (q[j] - kc.w * S);
+            }
+        }
         st_vec<VEC>(gx + v * gx_ld + c0, acc);
     }
 }
@@ -308,8 +386,9 @@ extern "C" int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t 
     return TEM_OK;
 }
 
-extern "C" int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld, int N, int D, int H, int W,
-                                int C, int fz, int fy, int fx, tem_stream_t stream) {
+static int upsample_bwd_impl(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld, int N, int D, int H, int W,
+                             int C, int fz, int fy, int fx, const float* u, int64_t u_ld, const float* ncoef,
+                             int64_t ncoef_ld, tem_stream_t stream) {
     TEM_REQUIRE(gy && gx && N > 0 && C > 0 && gy_ld >= C && gx_ld >= C && D > 0 && H > 0 && W > 0,
                 "tem_upsample_bwd: bad arguments");
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0, "tem_upsample_bwd: bad factors");
@@ -317,10 +396,26 @@ extern "C" int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64
     TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_bwd: too many rows");
     if (vec4_ok(C, {gy, gx}, {gy_ld, gx_ld}))
         hipLaunchKernelGGL((k_upsample_bwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
-                           gx_ld, D, H, W, C, fz, fy, fx);
+                           gx_ld, D, H, W, C, fz, fy, fx, u, u_ld, ncoef, ncoef_ld);
     else
         hipLaunchKernelGGL((k_upsample_bwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
-                           gx_ld, D, H, W, C, fz, fy, fx);
+                           gx_ld, D, H, W, C, fz, fy, fx, u, u_ld, ncoef, ncoef_ld);
     TEM_CHECK_LAUNCH("tem_upsample_bwd");
     return TEM_OK;
+}
+
+extern "C" int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld, int N, int D, int H, int W,
+                                int C, int fz, int fy, int fx, tem_stream_t stream) {
+    return upsample_bwd_impl(gy, gy_ld, gx, gx_ld, N, D, H, W, C, fz, fy, fx, nullptr, 0, nullptr, 0, stream);
+}
+
+// tem_upsample_bwd of the RAW data gradient behind a norm whose input was upsample(u): U^T(norm backward(g)) =
+// a*U^T g - m1*U^T 1 - m2r*(U^T U u - mean*U^T 1), evaluated with a 27-point stencil on the low-resolution u.
+extern "C" int tem_upsample_bwd_norm(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld, int N, int D, int H,
+                                     int W, int C, int fz, int fy, int fx, const float* u, int64_t u_ld,
+                                     const float* ncoef, int64_t ncoef_ld, tem_stream_t stream) {
+    TEM_REQUIRE(u && ncoef && u_ld >= C && ncoef_ld >= 4 * C && ((uintptr_t)ncoef % 16 == 0) && ncoef_ld % 4 == 0,
+                "tem_upsample_bwd_norm: bad arguments");
+    TEM_REQUIRE(C % 4 || (u_ld % 4 == 0 && (uintptr_t)u % 16 == 0), "tem_upsample_bwd_norm: u must be 16-byte aligned");
+    return upsample_bwd_impl(gy, gy_ld, gx, gx_ld, N, D, H, W, C, fz, fy, fx, u, u_ld, ncoef, ncoef_ld, stream);
 }

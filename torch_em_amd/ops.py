@@ -320,6 +320,22 @@ def norm_stats_from_partials(part, rows: int, voxels: int, C: int, groups: int, 
     return mean, rstd, scale, shift
 
 
+def norm_bwd_coef(gy, x, groups, gamma, mean, rstd, dgamma=None, dbeta=None, sums=None):
+    """Reduction stage of norm_bwd only -> coef[N, C, 4] = (a, m1, m2r, mean) per (sample, channel)."""
+    _req_cuda(gy, x)
+    N, D, H, W, C, x_ld = _act5(x)
+    gy_ld = _act5(gy)[5]
+    lib = _lib.load()
+    V = D * H * W
+    nws = lib.tem_norm_ws(N, V, C)
+    ws = _workspace(nws, x.device)
+    coef = torch.empty((N, C, 4), dtype=torch.float32, device=x.device)
+    _lib.check(lib.tem_norm_bwd_coef(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd),
+                                     _p(dgamma), _p(dbeta), _p(sums), _p(coef), _p(ws), nws, _stream(x)),
+               "tem_norm_bwd_coef")
+    return coef
+
+
 def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None, dbeta=None, sums=None):
     """sums: [N, C, 2] from conv_wgrad(sums_from=...) -- skips the reduction pass over gy and x"""
     _req_cuda(gy, x, gx)
@@ -352,13 +368,20 @@ def maxpool_fwd(x, y, f):
     return y
 
 
-def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False):
+def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None):
+    """gskip_coef: [N, C, 4] view (row stride = multiple of 4 floats) of norm_bwd_coef() -- gskip is then the raw data
+    gradient behind that norm and the norm backward is applied on the fly (tem_maxpool3d_bwd_norm)."""
     _req_cuda(gy, x, gx)
     N, D, H, W, C, x_ld = _act5(x)
     gy_ld = _act5(gy)[5]
     gx_ld = _act5(gx)[5]
     gs_ld = _act5(gskip)[5] if gskip is not None else 0
     lib = _lib.load()
+    if gskip_coef is not None:
+        _lib.check(lib.tem_maxpool3d_bwd_norm(_p(gy), gy_ld, _p(x), x_ld, _p(gskip), gs_ld, int(relu_mask), _p(gx), gx_ld,
+                                              N, D, H, W, C, f[0], f[1], f[2], _p(gskip_coef), gskip_coef.stride(0),
+                                              _stream(x)), "tem_maxpool3d_bwd_norm")
+        return gx
     _lib.check(lib.tem_maxpool3d_bwd(_p(gy), gy_ld, _p(x), x_ld, _p(gskip), gs_ld, int(relu_mask), _p(gx), gx_ld,
                                      N, D, H, W, C, f[0], f[1], f[2], _stream(x)), "tem_maxpool3d_bwd")
     return gx
@@ -374,12 +397,18 @@ def upsample_fwd(x, y, f):
     return y
 
 
-def upsample_bwd(gy, gx, f):
-    """gx has the low-resolution shape; gy = gx's shape scaled by f."""
+def upsample_bwd(gy, gx, f, norm=None):
+    """gx has the low-resolution shape; gy = gx's shape scaled by f.
+    norm = (u, coef[N, C, 4] view): gy is the raw data gradient behind a norm whose input was upsample(u)."""
     _req_cuda(gy, gx)
     N, D, H, W, C, gx_ld = _act5(gx)
     gy_ld = _act5(gy)[5]
     lib = _lib.load()
+    if norm is not None:
+        u, coef = norm
+        _lib.check(lib.tem_upsample_bwd_norm(_p(gy), gy_ld, _p(gx), gx_ld, N, D, H, W, C, f[0], f[1], f[2], _p(u),
+                                             _act5(u)[5], _p(coef), coef.stride(0), _stream(gx)), "tem_upsample_bwd_norm")
+        return gx
     _lib.check(lib.tem_upsample_bwd(_p(gy), gy_ld, _p(gx), gx_ld, N, D, H, W, C, f[0], f[1], f[2], _stream(gx)),
                "tem_upsample_bwd")
     return gx
