@@ -408,11 +408,22 @@ def _block_fwd(blk, xin, out):
     return {"xin": xin, "a1": a1, "out": out, "s1": s1, "s2": s2, "c1": c1, "c2": c2}
 
 
-def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sums=None):
+# The norm in front of a decoder block reads concat(upsample(u), skip).  Its backward needs no elementwise pass over that
+# (largest) tensor: the two kernels that consume the gradient next -- upsample backward and the encoder's max-pool
+# backward -- apply gx = a*g - m1 - (x - mean)*m2r on the fly (ops.norm_bwd_coef / tem_upsample_bwd_norm /
+# tem_maxpool3d_bwd_norm).  TEM_DEFER_CONCAT_NORM=0 restores the in-place pass.
+_DEFER_CONCAT_NORM = os.environ.get("TEM_DEFER_CONCAT_NORM", "1") != "0"
+
+
+def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sums=None, coef_only=False):
+    """coef_only: return the [N, C, 4] coefficients instead of applying them (g stays the raw data gradient)"""
     groups, gamma, beta, _ = spec.norm_args()
     dgamma = grads.view(gamma) if gamma is not None else None
     dbeta = grads.view(beta) if beta is not None else None
     mode = stats[4]
+    if coef_only:
+        assert mode == "sample"
+        return ops.norm_bwd_coef(g, x, groups, gamma, stats[0], stats[1], dgamma, dbeta, sums=sums)
     if mode == "frozen":
         raise NotImplementedError("backward through a norm with frozen running statistics (model.eval()) is not "
                                   "supported; call model.train() for training")
@@ -423,9 +434,11 @@ def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sum
     ops.norm_bwd(g, x, groups, gamma, stats[0], stats[1], relu_mask, g, dgamma, dbeta, sums=sums)
 
 
-def _block_bwd(bs, gout, gin, grads: _Grads):
+def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
     """gout: gradient w.r.t. the block's pre-ReLU conv2 output (i.e. already ReLU-masked).
-    gin: buffer for the gradient w.r.t. the block input, or None when not needed."""
+    gin: buffer for the gradient w.r.t. the block input, or None when not needed.
+    defer_input_norm: leave the backward of the block's FIRST norm to the consumers of gin: returns its coefficients
+    ([N, C, 4], see _DEFER_CONCAT_NORM) and gin holds the raw data gradient; returns None when it was applied here."""
     c1, c2, xin, a1 = bs["c1"], bs["c2"], bs["xin"], bs["a1"]
     # per layer: dgrad first (alone), then the weight gradient (side stream, see _OVERLAP_WGRAD) next to the norm backward
     ga1 = torch.empty_like(a1)
@@ -446,7 +459,10 @@ def _block_bwd(bs, gout, gin, grads: _Grads):
     _dgrad(c1, ga1, gin)
     sums = _wgrad(c1, xin, ga1, grads, bs["s1"], want_sums=bs["s1"] is not None)
     if bs["s1"] is not None:
+        if defer_input_norm and _DEFER_CONCAT_NORM and bs["s1"][4] == "sample":
+            return _norm_bwd_inplace(c1, gin, xin, bs["s1"], False, grads, sums=sums, coef_only=True)
         _norm_bwd_inplace(c1, gin, xin, bs["s1"], False, grads, sums=sums)
+    return None
 
 
 # -----------------------------------------------------------------------------------
@@ -515,7 +531,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         ops.upsample_fwd(t, cat[..., :lv["c_up"]], f)  # ... interpolated straight into the concat buffer
         out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev)
         bs = _block_fwd(blk, cat, out)
-        st["dec"].append({"low": cur, "sspec": sspec, "bs": bs, "f": f, "out": out})
+        st["dec"].append({"low": cur, "sspec": sspec, "bs": bs, "f": f, "out": out, "t": t})
         cur = out
     st["last"] = cur
     act = fused_activation(model.final_activation) if model.final_activation is not None else None
@@ -616,10 +632,12 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         d = st["dec"][i]
         lv = st["levels"][depth - 1 - i]
         g_cat = torch.empty_like(lv["cat"])
-        _block_bwd(d["bs"], g_cur, g_cat, grads)
+        coef = _block_bwd(d["bs"], g_cur, g_cat, grads, defer_input_norm=True)
         low, sspec = d["low"], d["sspec"]
         g_t = ops.new_act(low.shape[0], low.shape[1], low.shape[2], low.shape[3], sspec.cout, low.device)
-        ops.upsample_bwd(g_cat[..., :lv["c_up"]], g_t, d["f"])
+        ops.upsample_bwd(g_cat[..., :lv["c_up"]], g_t, d["f"],
+                         norm=None if coef is None else (d["t"], coef[:, :lv["c_up"]]))
+        lv["g_skip_coef"] = None if coef is None else coef[:, lv["c_up"]:]
         g_low = torch.empty_like(low)
         _dgrad(sspec, g_t, g_low, ref=low)  # `low` is the ReLU output of the previous block
         _wgrad(sspec, low, g_t, grads)
@@ -640,7 +658,8 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         skip = lv["skip"]
         g_skip_full = ops.new_act(skip.shape[0], skip.shape[1], skip.shape[2], skip.shape[3], skip.shape[4],
                                   skip.device)
-        ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True)
+        ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True,
+                        gskip_coef=lv.get("g_skip_coef"))
         need_in = (l > 0) or need_input_grad
         xin = lv["bs"]["xin"]
         g_in = torch.empty_like(xin) if need_in else None
