@@ -308,6 +308,11 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
     const int n = row / D;
     const int zlo = max(0, fz * zi - fz), zhi = min(Do - 1, fz * zi + 2 * fz - 1);
     const int ylo = max(0, fy * yi - fy), yhi = min(Ho - 1, fy * yi + 2 * fy - 1);
+    float az[3] = {0.f, 0.f, 0.f}, ay[3] = {0.f, 0.f, 0.f}, sz = 0.f, sy = 0.f;  // the row's (z, y) stencil weights
+    if (ncoef) {
+        utu_axis(zi, fz, D, az, sz);
+        utu_axis(yi, fy, H, ay, sy);
+    }
     for (int i = threadIdx.x; i < W * cq; i += 256) {
         const int xi = i / cq, c0 = (i % cq) * VEC;
         const int xlo = max(0, fx * xi - fx), xhi = min(Wo - 1, fx * xi + 2 * fx - 1);
@@ -337,9 +342,7 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
             // gy is the RAW data gradient g of the conv behind a norm whose input was upsample(u); the norm backward
             // g' = a*g - m1 - (x - mean)*m2r is linear and x = U u, so  U^T g' = a*U^T g - m1*U^T 1 - m2r*(U^T U u - mean*U^T 1):
             // a 27-point stencil on the LOW-RESOLUTION tensor u replaces a pass over the fine tensors
-            float az[3], ay[3], ax[3], sz, sy, sx;
-            utu_axis(zi, fz, D, az, sz);
-            utu_axis(yi, fy, H, ay, sy);
+            float ax[3], sx;
             utu_axis(xi, fx, W, ax, sx);
             const float S = sz * sy * sx;
             float q[VEC];
