@@ -183,6 +183,12 @@ int tem_norm_stats(const float* x, int64_t x_ld, int N, int64_t V, int C, int G,
 int tem_norm_finalize_partials(const float* part, int64_t nblk, int N, int64_t V, int C, int G,
                                const float* gamma, const float* beta, float eps,
                                float* mean, float* rstd, float* scale, float* shift, tem_stream_t stream);
+/* ... for a tensor concatenated from two producers along the channels (Decoder._concat, model/unet.py:363-373): channels
+ * [0, CA) are summarised by partA [N][nblkA][CA][2] (tem_upsample_stats), channels [CA, C) by partB [N][nblkB][C-CA][2]
+ * (tem_conv3d_fwd_stats of the skip tensor); a group must lie inside one half. */
+int tem_norm_finalize_partials2(const float* partA, int64_t nblkA, int CA, const float* partB, int64_t nblkB,
+                                int N, int64_t V, int C, int G, const float* gamma, const float* beta, float eps,
+                                float* mean, float* rstd, float* scale, float* shift, tem_stream_t stream);
 /* Backward of y = norm(x)*gamma+beta given gy:
  *   gx = rstd*(gy*gamma - mean_grp(gy*gamma) - xn*mean_grp(gy*gamma*xn)),  xn=(x-mean)*rstd
  *   [gx *= (x > 0) when relu_mask != 0: x is itself a ReLU output]
@@ -237,6 +243,11 @@ int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld,
                      int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
 int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld,
                      int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
+/* First stage of the statistics of y = upsample(u) from the LOW-RESOLUTION u alone (the interpolation U is linear:
+ * sum y = sum_i (U^T 1)[i] u[i], sum y^2 = sum_i u[i] (U^T U u)[i]): part [N][D*H][C][2], one block per input row.
+ * (D,H,W) are u's dims; C = 4 * 2^k <= 256.  Merged by tem_norm_finalize_partials2 with V = D*fz*H*fy*W*fx. */
+int tem_upsample_stats(const float* u, int64_t u_ld, int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                       float* part, tem_stream_t stream);
 /* ... of the RAW data gradient gy behind a norm whose input was upsample(u) (u: the low-resolution tensor, same shape
  * as gx): gx = a*U^T gy - m1*U^T 1 - m2r*(U^T U u - mean*U^T 1), ncoef as for tem_maxpool3d_bwd_norm */
 int tem_upsample_bwd_norm(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld,

@@ -329,6 +329,36 @@ def test_deferred_concat_norm_backward(case):
     assert rel_err(gt1.cpu(), gt0.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("case", [((2, 2, 2), (2, 6, 5, 7), 32, 32, 64), ((1, 2, 2), (1, 5, 6, 4), 64, 64, 32),
+                                  ((1, 2, 2), (2, 1, 9, 8), 32, 32, 2), ((2, 2, 2), (1, 3, 4, 4), 8, 24, 8)])
+def test_concat_statistics_without_reading_the_concat(case):
+    """Statistics of concat(upsample(u), skip) for the first norm of a decoder block (reference Decoder._concat +
+    ConvBlock, model/unet.py:363-373, 429-438): tem_upsample_stats (low-resolution stencil) + per-block partial sums of
+    the skip half, merged by tem_norm_finalize_partials2, equal tem_norm_stats of the materialised concat."""
+    ops = _ops()
+    f, (N, d, h, w), cup, cskip, groups = case
+    C = cup + cskip
+    D, H, W = d * f[0], h * f[1], w * f[2]
+    g = torch.Generator().manual_seed(12)
+    u = (torch.randn(N, d, h, w, cup, generator=g) * 2.0 + 0.5).to(DEV)
+    cat = torch.empty(N, D, H, W, C, device=DEV)
+    ops.upsample_fwd(u, cat[..., :cup], f)
+    skip = torch.relu(torch.randn(N, D, H, W, cskip, generator=g) + 0.3).to(DEV)
+    cat[..., cup:] = skip
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    # partial sums of the skip half as a producer would emit them: here 3 voxel blocks per sample
+    sk = skip.reshape(N, -1, cskip)
+    cuts = [0, sk.shape[1] // 3, 2 * sk.shape[1] // 3, sk.shape[1]]
+    part_b = torch.stack([torch.stack([sk[:, a:b].sum(1), (sk[:, a:b] ** 2).sum(1)], -1) for a, b in zip(cuts, cuts[1:])], 1)
+    assert ops.upsample_stats_ok(u)
+    part_a = ops.upsample_stats(u, f)
+    for rows in (N, 1):
+        want = ops.norm_stats(cat if rows == N else cat.reshape(1, N * D, H, W, C), groups, gamma, beta, 1e-5)
+        have = ops.norm_stats_from_partials2(part_a, part_b.contiguous(), rows, D * H * W, groups, gamma, beta, 1e-5)
+        for a, c, name in zip(have, want, ("mean", "rstd", "scale", "shift")):
+            assert a.shape == c.shape and rel_err(a.cpu(), c.cpu()) < 5e-6, (name, rows, rel_err(a.cpu(), c.cpu()))
+
+
 def test_conv_relu_mask_ref_and_channel_slices():
     """ref-mask epilogue and leading-dimension (concat-buffer slice) addressing."""
     ops = _ops()

@@ -56,6 +56,9 @@ SIGNATURES = {
     "tem_upsample_bwd_norm": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp, c_i64, c_vp, c_i64, c_vp]),
     "tem_norm_bwd_coef": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "tem_upsample_stats": (c_int, [c_vp, c_i64] + [c_int] * 8 + [c_vp, c_vp]),
+    "tem_norm_finalize_partials2": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_float,
+                                            c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tem_upsample_fwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
     "tem_upsample_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
     "tem_dice_ws": (c_i64, [c_int, c_i64, c_int]),

@@ -224,6 +224,45 @@ __global__ __launch_bounds__(256) void k_norm_finalize(const float* __restrict__
     }
 }
 
+// stage 2 (forward) for a tensor whose channel halves have different producers (decoder concat): channels [0, CA) from
+// partA [n][nblkA][CA][2], channels [CA, C) from partB [n][nblkB][C-CA][2]; a group lies inside one half
+__global__ __launch_bounds__(256) void k_norm_finalize2(const float* __restrict__ partA, int nblkA, int CA,
+                                                        const float* __restrict__ partB, int nblkB, int64_t V, int C,
+                                                        int G, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, float* __restrict__ scale,
+                                                        float* __restrict__ shift) {
+    const int n = blockIdx.x / G, grp = blockIdx.x % G;
+    const int cg = C / G;
+    const bool inA = grp * cg < CA;
+    const float* part = inA ? partA : partB;
+    const int nblk = inA ? nblkA : nblkB, Cs = inA ? CA : C - CA, cbase = inA ? grp * cg : grp * cg - CA;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < nblk * cg; i += 256) {
+        int b = i / cg, c = cbase + i % cg;
+        int64_t o = (((int64_t)n * nblk + b) * Cs + c) * 2;
+        s += (double)part[o];
+        ss += (double)part[o + 1];
+    }
+    block_sum2_d(s, ss);
+    double cnt = (double)V * (double)cg;
+    double m = s / cnt;
+    double var = ss / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    double r = 1.0 / sqrt(var + (double)eps);
+    if (threadIdx.x == 0) {
+        mean[n * G + grp] = (float)m;
+        rstd[n * G + grp] = (float)r;
+    }
+    for (int i = threadIdx.x; i < cg; i += 256) {
+        int c = grp * cg + i;
+        double ga = gamma ? (double)gamma[c] : 1.0;
+        double be = beta ? (double)beta[c] : 0.0;
+        scale[(int64_t)n * C + c] = (float)(r * ga);
+        shift[(int64_t)n * C + c] = (float)(be - m * r * ga);
+    }
+}
+
 // stage 2 (backward): one block per (n, group) -> coef[n][c] = {a, m1, m2r, mean}
 //   gx = a*g - m1 - (x - mean)*m2r
 __global__ __launch_bounds__(256) void k_norm_bwd_finalize(const float* __restrict__ part, int nblk, int64_t V, int C,
@@ -386,6 +425,24 @@ extern "C" int tem_norm_finalize_partials(const float* part, int64_t nblk, int N
     hipLaunchKernelGGL(k_norm_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, V, C, G, gamma,
                        beta, eps, mean, rstd, scale, shift);
     TEM_CHECK_LAUNCH("tem_norm_finalize_partials");
+    return TEM_OK;
+}
+
+// tem_norm_finalize_partials for a concatenated tensor: channels [0, CA) summarised by partA ([N][nblkA][CA][2], e.g.
+// tem_upsample_stats), channels [CA, C) by partB ([N][nblkB][C-CA][2], e.g. tem_conv3d_fwd_stats of the skip tensor)
+extern "C" int tem_norm_finalize_partials2(const float* partA, int64_t nblkA, int CA, const float* partB, int64_t nblkB,
+                                           int N, int64_t V, int C, int G, const float* gamma, const float* beta,
+                                           float eps, float* mean, float* rstd, float* scale, float* shift,
+                                           tem_stream_t stream) {
+    TEM_REQUIRE(partA && partB && mean && rstd && scale && shift, "tem_norm_finalize_partials2: null pointer");
+    TEM_REQUIRE(N > 0 && V > 0 && C > 0 && CA > 0 && CA < C && nblkA > 0 && nblkB > 0 && nblkA < (1ll << 30) &&
+                    nblkB < (1ll << 30),
+                "tem_norm_finalize_partials2: bad shape");
+    TEM_REQUIRE(G > 0 && C % G == 0 && CA % (C / G) == 0,
+                "tem_norm_finalize_partials2: groups of %d channels must not straddle the split at %d", C / (G > 0 ? G : 1), CA);
+    hipLaunchKernelGGL(k_norm_finalize2, dim3(N * G), dim3(256), 0, (hipStream_t)stream, partA, (int)nblkA, CA, partB,
+                       (int)nblkB, V, C, G, gamma, beta, eps, mean, rstd, scale, shift);
+    TEM_CHECK_LAUNCH("tem_norm_finalize_partials2");
     return TEM_OK;
 }
 

@@ -372,6 +372,89 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
     }
 }
 
+// Statistics of y = upsample(u) WITHOUT reading y: sum_o y[o] = sum_i (U^T 1)[i] u[i] and sum_o y[o]^2 = sum_i u[i] (U^T U u)[i]
+// -- the same low-resolution 27-point stencil as tem_upsample_bwd_norm.  One block per low-resolution row (n, z, y);
+// part: [N][D*H][C][2] partial sums (sum y, sum y^2) in the layout tem_norm_finalize_partials2 merges.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_upsample_stats(const float* __restrict__ u, int64_t u_ld, int D, int H, int W,
+                                                        int C, int fz, int fy, int fx, float* __restrict__ part) {
+    extern __shared__ float lsu[];  // [4 waves][C][2]
+    const int cq = C / VEC;         // VEC == 4: power of two <= 64 (launcher); a thread keeps its channel quad
+    int row = blockIdx.x;
+    const int yi = row % H;
+    row /= H;
+    const int zi = row % D;
+    const int n = row / D;
+    float az[3], ay[3], sz, sy;
+    utu_axis(zi, fz, D, az, sz);
+    utu_axis(yi, fy, H, ay, sy);
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
+    for (int i = threadIdx.x; i < W * cq; i += 256) {
+        const int xi = i / cq, c0 = (i % cq) * VEC;
+        float ax[3], sx;
+        utu_axis(xi, fx, W, ax, sx);
+        const float S = sz * sy * sx;
+        float q[VEC], uc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) q[j] = 0.f;
+        ld_vec<VEC>(u + ((((int64_t)n * D + zi) * H + yi) * W + xi) * u_ld + c0, uc);
+        for (int dz = -1; dz <= 1; ++dz) {
+            if (az[dz + 1] == 0.f) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                if (ay[dy + 1] == 0.f) continue;
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const float wq = az[dz + 1] * ay[dy + 1] * ax[dx + 1];
+                    if (wq == 0.f) continue;
+                    float t[VEC];
+                    ld_vec<VEC>(u + ((((int64_t)n * D + zi + dz) * H + yi + dy) * W + xi + dx) * u_ld + c0, t);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) q[j] = fmaf(wq, t[j], q[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            s1[j] = fmaf(S, uc[j], s1[j]);
+            s2[j] = fmaf(uc[j], q[j], s2[j]);
+        }
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        for (int o = cq; o < 64; o <<= 1) {  // lanes sharing a quad sit cq apart (256 % cq == 0)
+            s1[j] += __shfl_xor(s1[j], o, 64);
+            s2[j] += __shfl_xor(s2[j], o, 64);
+        }
+        if (lane < cq) {
+            lsu[(wv * C + lane * VEC + j) * 2 + 0] = s1[j];
+            lsu[(wv * C + lane * VEC + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+        float a = 0.f;
+        for (int w4 = 0; w4 < 4; ++w4) a += lsu[w4 * 2 * C + t];
+        part[((int64_t)n * D * H + (int64_t)zi * H + yi) * 2 * C + t] = a;
+    }
+}
+
+extern "C" int tem_upsample_stats(const float* u, int64_t u_ld, int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                                  float* part, tem_stream_t stream) {
+    TEM_REQUIRE(u && part && N > 0 && C > 0 && u_ld >= C && D > 0 && H > 0 && W > 0 && fz > 0 && fy > 0 && fx > 0,
+                "tem_upsample_stats: bad arguments");
+    const int cq = C / 4;
+    TEM_REQUIRE(C % 4 == 0 && cq <= 64 && (cq & (cq - 1)) == 0 && u_ld % 4 == 0 && ((uintptr_t)u % 16 == 0),
+                "tem_upsample_stats: needs C = 4 * 2^k <= 256 channels, 16-byte aligned rows (got C=%d)", C);
+    int64_t rows = (int64_t)N * D * H;
+    TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_stats: too many rows");
+    hipLaunchKernelGGL((k_upsample_stats<4>), dim3((unsigned)rows), dim3(256), (size_t)4 * C * 2 * sizeof(float),
+                       (hipStream_t)stream, u, u_ld, D, H, W, C, fz, fy, fx, part);
+    TEM_CHECK_LAUNCH("tem_upsample_stats");
+    return TEM_OK;
+}
+
 extern "C" int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C,
                                 int fz, int fy, int fx, tem_stream_t stream) {
     TEM_REQUIRE(x && y && N > 0 && C > 0 && x_ld >= C && y_ld >= C && D > 0 && H > 0 && W > 0,

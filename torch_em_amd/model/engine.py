@@ -217,6 +217,7 @@ _NO_GRAD_FORWARD = False
 # Forward statistics of a conv output that feeds the next norm directly (conv1 -> norm2 of every ConvBlock) come out of
 # the conv's epilogue instead of a separate pass over the tensor (tem_conv3d_fwd_stats); TEM_FUSE_STATS=0 disables.
 _FUSE_STATS = os.environ.get("TEM_FUSE_STATS", "1") != "0"
+_FUSE_CONCAT_STATS = os.environ.get("TEM_FUSE_CONCAT_STATS", "1") != "0"
 
 
 def _conv(spec: ConvSpec, x, y, stats=None, act=None, want_stats=False):
@@ -354,7 +355,7 @@ def _update_running(n, mean, var_biased, count):
         n.running_var.mul_(1.0 - m).add_(unbiased.mean(0), alpha=m)
 
 
-def _stats(spec: ConvSpec, x, partials=None):
+def _stats(spec: ConvSpec, x, partials=None, partials2=None):
     """Statistics of the norm in front of a conv -> (mean, rstd, scale[N,C], shift[N,C], mode).
     partials: (part, nblk) from the producing conv's epilogue (ops.conv_fwd(want_stats=True)) or None.
     mode "sample": InstanceNorm / GroupNorm per sample; "batch": BatchNorm in training mode (reference
@@ -377,14 +378,18 @@ def _stats(spec: ConvSpec, x, partials=None):
     vox = x.shape[1] * x.shape[2] * x.shape[3]
     if _is_batchnorm(n):
         xb = _flat_batch(x)
-        if partials is not None:
+        if partials2 is not None:
+            mean, rstd, scale, shift = ops.norm_stats_from_partials2(partials2[0], partials2[1], 1, vox, groups, gamma, beta, eps)
+        elif partials is not None:
             mean, rstd, scale, shift = ops.norm_stats_from_partials(partials[0], 1, vox, x.shape[4], groups, gamma, beta, eps)
         else:
             mean, rstd, scale, shift = ops.norm_stats(xb, groups, gamma, beta, eps)
         if tracked:
             _update_running(n, mean, 1.0 / (rstd * rstd) - eps, xb.shape[1] * xb.shape[2] * xb.shape[3])
         return mean, rstd, scale.expand(N, -1).contiguous(), shift.expand(N, -1).contiguous(), "batch"
-    if partials is not None:
+    if partials2 is not None:
+        mean, rstd, scale, shift = ops.norm_stats_from_partials2(partials2[0], partials2[1], N, vox, groups, gamma, beta, eps)
+    elif partials is not None:
         mean, rstd, scale, shift = ops.norm_stats_from_partials(partials[0], N, vox, x.shape[4], groups, gamma, beta, eps)
     else:
         mean, rstd, scale, shift = ops.norm_stats(x, groups, gamma, beta, eps)
@@ -393,19 +398,26 @@ def _stats(spec: ConvSpec, x, partials=None):
     return mean, rstd, scale, shift, "sample"
 
 
-def _block_fwd(blk, xin, out):
-    """ConvBlock (reference model/unet.py:429-438): [norm->conv->ReLU] x 2.  Returns what backward needs."""
+def _norm_is_live(n) -> bool:
+    """does this norm compute statistics of its input in the current mode?"""
+    return n is not None and not (getattr(n, "track_running_stats", False) and
+                                  getattr(n, "running_mean", None) is not None and not n.training)
+
+
+def _block_fwd(blk, xin, out, in_partials2=None, out_stats=False):
+    """ConvBlock (reference model/unet.py:429-438): [norm->conv->ReLU] x 2.  Returns what backward needs.
+    in_partials2: first-stage statistics of the two channel halves of xin (decoder concat) or None.
+    out_stats: also return the first-stage statistics of `out` (key "out_part"; None when conv2 cannot provide them)."""
     c1, c2 = blk.conv_specs()
     N, D, H, W, _ = xin.shape
-    s1 = _stats(c1, xin)
+    s1 = _stats(c1, xin, partials2=in_partials2)
     a1 = ops.new_act(N, D, H, W, c1.cout, xin.device)
-    n2 = c2.norm
-    live = n2 is not None and not (getattr(n2, "track_running_stats", False) and
-                                   getattr(n2, "running_mean", None) is not None and not n2.training)
+    live = _norm_is_live(c2.norm)
     part = _conv(c1, xin, a1, s1, act="relu", want_stats=_FUSE_STATS and live)
     s2 = _stats(c2, a1, partials=part if (_FUSE_STATS and live) else None)
-    _conv(c2, a1, out, s2, act="relu")
-    return {"xin": xin, "a1": a1, "out": out, "s1": s1, "s2": s2, "c1": c1, "c2": c2}
+    out_part = _conv(c2, a1, out, s2, act="relu", want_stats=bool(out_stats))
+    return {"xin": xin, "a1": a1, "out": out, "s1": s1, "s2": s2, "c1": c1, "c2": c2,
+            "out_part": out_part if out_stats else None}
 
 
 # The norm in front of a decoder block reads concat(upsample(u), skip).  Its backward needs no elementwise pass over that
@@ -505,7 +517,10 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
             raise ValueError(f"Invalid shape for U-Net: {(D, H, W)[3 - dim:]} is not divisible by {f[3 - dim:]}")
         cat = ops.new_act(N, D, H, W, c_up + blk.out_channels, dev)
         skip = cat[..., c_up:]
-        bs = _block_fwd(blk, cur, skip)
+        # the skip tensor feeds the norm in front of the decoder block of this level: its statistics come out of the
+        # epilogue of this block's second conv (with the upsampled half's from the low-resolution tensor, see below)
+        dnorm = dec.blocks[depth - 1 - l].conv_specs()[0].norm
+        bs = _block_fwd(blk, cur, skip, out_stats=_FUSE_STATS and _FUSE_CONCAT_STATS and _norm_is_live(dnorm))
         pooled = ops.new_act(N, D // f[0], H // f[1], W // f[2], blk.out_channels, dev)
         ops.maxpool_fwd(skip, pooled, f)
         st["levels"].append({"cat": cat, "skip": skip, "bs": bs, "f": f, "c_up": c_up})
@@ -530,7 +545,17 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
             raise NotImplementedError("skip connections that need cropping are not supported")
         ops.upsample_fwd(t, cat[..., :lv["c_up"]], f)  # ... interpolated straight into the concat buffer
         out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev)
-        bs = _block_fwd(blk, cat, out)
+        # statistics of the concat for the block's first norm without reading it: the skip half's partial sums were
+        # written by the encoder conv that produced it, the upsampled half's follow from the low-resolution t
+        # (sum y = sum (U^T 1) t, sum y^2 = sum t (U^T U t): tem_upsample_stats)
+        p2 = None
+        skip_part = lv["bs"].get("out_part")
+        if skip_part is not None:
+            na = blk.conv_specs()[0].norm_args()
+            cpg = cat.shape[4] // na[0]
+            if lv["c_up"] % cpg == 0 and ops.upsample_stats_ok(t):
+                p2 = (ops.upsample_stats(t, f), skip_part[0])
+        bs = _block_fwd(blk, cat, out, in_partials2=p2)
         st["dec"].append({"low": cur, "sspec": sspec, "bs": bs, "f": f, "out": out, "t": t})
         cur = out
     st["last"] = cur

@@ -397,6 +397,47 @@ def upsample_fwd(x, y, f):
     return y
 
 
+def upsample_stats_ok(u) -> bool:
+    C = u.shape[4]
+    cq = C // 4
+    return C % 4 == 0 and 0 < cq <= 64 and (cq & (cq - 1)) == 0 and _act5(u)[5] % 4 == 0 and u.data_ptr() % 16 == 0
+
+
+def upsample_stats(u, f):
+    """First stage of the statistics of upsample(u, f), from u alone -> part [N, D*H, C, 2] (tem_upsample_stats)."""
+    _req_cuda(u)
+    N, D, H, W, C, u_ld = _act5(u)
+    part = torch.empty((N, D * H, C, 2), dtype=torch.float32, device=u.device)
+    lib = _lib.load()
+    _lib.check(lib.tem_upsample_stats(_p(u), u_ld, N, D, H, W, C, f[0], f[1], f[2], _p(part), _stream(u)),
+               "tem_upsample_stats")
+    return part
+
+
+def norm_stats_from_partials2(part_a, part_b, rows: int, voxels: int, groups: int, gamma=None, beta=None,
+                              eps: float = 1e-5):
+    """norm_stats of a channel-concatenated tensor: channels [0, CA) summarised by part_a [N, nblkA, CA, 2], the rest by
+    part_b [N, nblkB, CB, 2] (tem_norm_finalize_partials2).  rows = N, or 1 for BatchNorm."""
+    _req_cuda(part_a, part_b)
+    N, nba, ca = part_a.shape[0], part_a.shape[1], part_a.shape[2]
+    nbb, cb = part_b.shape[1], part_b.shape[2]
+    C = ca + cb
+    if rows == 1:
+        nba, nbb, voxels = N * nba, N * nbb, N * voxels
+    elif rows != N:
+        raise ValueError("norm_stats_from_partials2: rows must be N or 1")
+    dev = part_a.device
+    mean = torch.empty((rows, groups), dtype=torch.float32, device=dev)
+    rstd = torch.empty((rows, groups), dtype=torch.float32, device=dev)
+    scale = torch.empty((rows, C), dtype=torch.float32, device=dev)
+    shift = torch.empty((rows, C), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.tem_norm_finalize_partials2(_p(part_a), nba, ca, _p(part_b), nbb, rows, voxels, C, groups, _p(gamma),
+                                               _p(beta), eps, _p(mean), _p(rstd), _p(scale), _p(shift), _stream(part_a)),
+               "tem_norm_finalize_partials2")
+    return mean, rstd, scale, shift
+
+
 def upsample_bwd(gy, gx, f, norm=None):
     """gx has the low-resolution shape; gy = gx's shape scaled by f.
     norm = (u, coef[N, C, 4] view): gy is the raw data gradient behind a norm whose input was upsample(u)."""
