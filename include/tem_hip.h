@@ -148,6 +148,17 @@ int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const flo
                      int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                      int use_mfma, int sd_layout, tem_stream_t stream);
 
+/* tem_conv3d_wgrad of a first layer (Cin <= 4, VALU kernel) whose g is still the RAW data gradient behind the norm that
+ * follows this conv's ReLU (the second norm of the first ConvBlock, model/unet.py:429-438): the norm backward
+ * g := (y > 0) ? a*g - m1 - (y - mean)*m2r : 0 (gcoef[N][Cout][4] from tem_norm_bwd_coef, y = this conv's output) is
+ * applied while g is loaded, instead of a pass that rewrites g.  Only where tem_conv3d_wgrad_gnorm_ok() != 0. */
+int tem_conv3d_wgrad_gnorm_ok(int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
+int tem_conv3d_wgrad_gnorm(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                           const float* g, int64_t g_ld, const float* y, int64_t y_ld, const float* gcoef,
+                           float* dw, float* db, void* ws, int64_t ws_bytes,
+                           int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                           int sd_layout, tem_stream_t stream);
+
 /* tem_conv3d_wgrad that ALSO delivers the first stage of the backward of the norm in front of this conv -- per (sample,
  * input channel) sums[n][ci] = (sum_v gz, sum_v gz * xn), gz = the data gradient of this conv (tem_conv3d_fwd with the
  * transposed pack), xn = the normalised input -- WITHOUT reading gz or x: sum_v gz*z = sum_{tap,co} w * dw_n (the

@@ -508,7 +508,7 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
                              int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H,
                              int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma, int sd_layout,
                              const float* w_sd, const float* gamma, const float* beta, float* norm_sums,
-                             tem_stream_t stream) {
+                             const float* gnx, int64_t gnx_ld, const float* gcoef, tem_stream_t stream) {
     TEM_REQUIRE(x && g && dw && ws, "tem_conv3d_wgrad: null pointer");
     TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= Cin && g_ld >= Cout,
                 "tem_conv3d_wgrad: bad shape");
@@ -525,6 +525,7 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
     float* dbpart = (float*)ws;
     float* rest = dbpart + tem_align_up(p.db_floats, 64);
+    TEM_REQUIRE(!gcoef || !use_mfma, "tem_conv3d_wgrad_gnorm: use_mfma must be 0");
     if (use_mfma == 2 || use_mfma == 5) {
         // 5: single fp16 product in the z-sliding kernel (autocast-equivalent); the other shapes keep bf16x3
         int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
@@ -544,10 +545,11 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
         return TEM_OK;
     }
     if (tem_conv_wgrad_cin1(x, x_ld, scale, shift, g, g_ld, dw, db, rest, N, D, H, W, Cin, Cout, kd, kh, kw, sd_layout,
-                            s)) {
+                            gnx, gnx_ld, gcoef, s)) {
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(cin1)");
         return TEM_OK;
     }
+    TEM_REQUIRE(!gcoef, "tem_conv3d_wgrad_gnorm: only the small-Cin first-layer kernel applies a norm backward to g");
     if (ntaps == 1 && tem_conv1x1_proj_wgrad(x, x_ld, scale, g, g_ld, dw, db, rest, NV, Cin, Cout, sd_layout, s)) {
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(proj)");
         return TEM_OK;
@@ -574,7 +576,7 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
                                 int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma, int sd_layout,
                                 tem_stream_t stream) {
     return conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw,
-                             use_mfma, sd_layout, nullptr, nullptr, nullptr, nullptr, stream);
+                             use_mfma, sd_layout, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int tem_conv3d_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
@@ -592,5 +594,23 @@ extern "C" int tem_conv3d_wgrad_sums(const float* x, int64_t x_ld, const float* 
     TEM_REQUIRE(tem_conv3d_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma),
                 "tem_conv3d_wgrad_sums: tem_conv3d_wgrad_sums_ok() == 0 for this layer");
     return conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw,
-                             use_mfma, 1, w, gamma, beta, norm_sums, stream);
+                             use_mfma, 1, w, gamma, beta, norm_sums, nullptr, 0, nullptr, stream);
+}
+
+// tem_conv3d_wgrad of a FIRST layer (small Cin, VALU kernel) whose output gradient g is still the raw data gradient
+// behind the norm that follows this conv's ReLU: the norm backward (coefficients from tem_norm_bwd_coef) and the ReLU
+// mask are applied while g is loaded -- y (this conv's output, the norm's input) is read instead of a rewritten g.
+extern "C" int tem_conv3d_wgrad_gnorm_ok(int Cin, int Cout, int kd, int kh, int kw, int use_mfma) {
+    const int cq = Cout / 4, key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
+    return use_mfma == 0 && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && cq <= 16 && (cq & (cq - 1)) == 0 && (key == 7 || key == 3);
+}
+
+extern "C" int tem_conv3d_wgrad_gnorm(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                                      const float* g, int64_t g_ld, const float* y, int64_t y_ld, const float* gcoef,
+                                      float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
+                                      int Cin, int Cout, int kd, int kh, int kw, int sd_layout, tem_stream_t stream) {
+    TEM_REQUIRE(y && gcoef && y_ld >= Cout, "tem_conv3d_wgrad_gnorm: null pointer");
+    TEM_REQUIRE(tem_conv3d_wgrad_gnorm_ok(Cin, Cout, kd, kh, kw, 0), "tem_conv3d_wgrad_gnorm: tem_conv3d_wgrad_gnorm_ok() == 0");
+    return conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw, 0,
+                             sd_layout, nullptr, nullptr, nullptr, nullptr, y, y_ld, gcoef, stream);
 }

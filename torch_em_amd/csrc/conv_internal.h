@@ -23,7 +23,8 @@ int64_t tem_conv_fwd_cin1_stat_blocks(int D, int H, int W, int Cin, int Cout, in
 int64_t tem_conv_wgrad_cin1_ws(int Cout, int ntaps);
 bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                          int64_t g_ld, float* dw, float* db, void* ws, int N, int D, int H, int W, int Cin, int Cout,
-                         int kd, int kh, int kw, int sd_layout, hipStream_t s);
+                         int kd, int kh, int kw, int sd_layout, const float* gnx, int64_t gnx_ld, const float* gcoef,
+                         hipStream_t s);
 bool tem_conv_fwd_cout1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
                         const float* bias, float* y, int64_t y_ld, const float* ref, int N, int D, int H, int W,
                         int Cin, int Cout, int kd, int kh, int kw, int act, hipStream_t s);

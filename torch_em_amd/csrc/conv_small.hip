@@ -298,7 +298,9 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
                                                          const float* __restrict__ g, int64_t g_ld,
                                                          float* __restrict__ part /*[grid][NT+1][Cout]*/, int N,
                                                          int D, int H, int W, int Cout, int P, int nZ, int nY,
-                                                         int nX, int sstride /*Cin: scale[n*Cin] of this channel*/) {
+                                                         int nX, int sstride /*Cin: scale[n*Cin] of this channel*/,
+                                                         const float* __restrict__ gnx, int64_t gnx_ld,
+                                                         const float* __restrict__ gcoef) {
     constexpr int NT = KD * KH * KW;
     constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
     constexpr int TZ = 4, TY = 8, TX = 8;
@@ -325,6 +327,13 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
             sc = scale[n * sstride];
             sf = shift[n * sstride];
         }
+        // g may still be the RAW data gradient behind the norm that follows this conv's ReLU (tem_conv3d_wgrad_gnorm):
+        // g := (y > 0) ? a*g - m1 - (y - mean)*m2r : 0 with y = this conv's output (gnx), applied while loading
+        float4 kc[4];
+        if (gcoef) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kc[j] = *reinterpret_cast<const float4*>(gcoef + ((int64_t)n * Cout + q * 4 + j) * 4);
+        }
         __syncthreads();
         for (int hv = tid; hv < HV; hv += 256) {
             const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
@@ -340,7 +349,14 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
             const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
             if (gz >= D || gy >= H || gx >= W) continue;
             const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
-            const float4 gv = *reinterpret_cast<const float4*>(g + v * g_ld + q * 4);
+            float4 gv = *reinterpret_cast<const float4*>(g + v * g_ld + q * 4);
+            if (gcoef) {
+                const float4 yv = *reinterpret_cast<const float4*>(gnx + v * gnx_ld + q * 4);
+                gv.x = yv.x > 0.f ? kc[0].x * gv.x - kc[0].y - (yv.x - kc[0].w) * kc[0].z : 0.f;
+                gv.y = yv.y > 0.f ? kc[1].x * gv.y - kc[1].y - (yv.y - kc[1].w) * kc[1].z : 0.f;
+                gv.z = yv.z > 0.f ? kc[2].x * gv.z - kc[2].y - (yv.z - kc[2].w) * kc[2].z : 0.f;
+                gv.w = yv.w > 0.f ? kc[3].x * gv.w - kc[3].y - (yv.w - kc[3].w) * kc[3].z : 0.f;
+            }
             const float* xb = lds + (pz * HY + py) * HX + px;
 #pragma unroll
             for (int tap = 0; tap < NT; ++tap) {
@@ -516,8 +532,10 @@ int64_t tem_conv_wgrad_cin1_ws(int Cout, int ntaps) { return (int64_t)CIN1_GRID 
 
 bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                          int64_t g_ld, float* dw, float* db, void* ws, int N, int D, int H, int W, int Cin, int Cout,
-                         int kd, int kh, int kw, int sd_layout, hipStream_t s) {
+                         int kd, int kh, int kw, int sd_layout, const float* gnx, int64_t gnx_ld, const float* gcoef,
+                         hipStream_t s) {
     const int cq = Cout / 4;
+    if (gcoef && (gnx_ld % 4 || ((uintptr_t)gnx % 16) || ((uintptr_t)gcoef % 16))) return false;
     // Cin 2..4: one pass per input channel (g is re-read Cin times: still ~6x faster than the generic kernel)
     if (Cin > 4 || Cout % 4 || cq > 16 || (cq & (cq - 1)) || g_ld % 4 || ((uintptr_t)g % 16)) return false;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
@@ -534,11 +552,11 @@ bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const
         if (key == 7) {
             size_t ldsf = 6 * 10 * 10 > 4 * (NT + 1) * Cout ? 6 * 10 * 10 : 4 * (NT + 1) * Cout;
             hipLaunchKernelGGL((k_conv_wgrad_cin1<3, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x + ci, x_ld, sc,
-                               sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin);
+                               sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin, gnx, gnx_ld, gcoef);
         } else {
             size_t ldsf = 4 * 10 * 10 > 4 * (NT + 1) * Cout ? 4 * 10 * 10 : 4 * (NT + 1) * Cout;
             hipLaunchKernelGGL((k_conv_wgrad_cin1<1, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x + ci, x_ld, sc,
-                               sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin);
+                               sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin, gnx, gnx_ld, gcoef);
         }
         // the first NT*Cout entries of a slab are dw[tap][ci][co]; the last Cout are db
         if (Cin == 1) {

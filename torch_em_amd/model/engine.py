@@ -454,14 +454,24 @@ def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
     c1, c2, xin, a1 = bs["c1"], bs["c2"], bs["xin"], bs["a1"]
     # per layer: dgrad first (alone), then the weight gradient (side stream, see _OVERLAP_WGRAD) next to the norm backward
     ga1 = torch.empty_like(a1)
+    affine1 = bs["s1"] is not None and c1.norm_args()[1] is not None
     if bs["s2"] is not None:
         _dgrad(c2, gout, ga1)
         sums = _wgrad(c2, a1, gout, grads, bs["s2"], want_sums=True)
+        if gin is None and not affine1 and _DEFER_CONCAT_NORM and bs["s2"][4] == "sample" and not _OVERLAP_WGRAD and \
+                c1.conv.bias is not None and ops.conv_wgrad_gnorm_ok(c1.k, c1.cin, c1.cout, c1.packed()["wgrad_mfma"]):
+            # first block of the net: nothing but conv1's weight gradient reads the gradient behind norm2, and that
+            # kernel applies norm2's backward (+ the ReLU mask of a1) while it loads g: no pass that rewrites ga1
+            coef = _norm_bwd_inplace(c2, ga1, a1, bs["s2"], True, grads, sums=sums, coef_only=True)
+            s1 = bs["s1"]
+            ops.conv_wgrad_gnorm(xin, ga1, a1, coef, c1.k, c1.cin, c1.cout, grads.view(c1.conv.weight),
+                                 grads.view(c1.conv.bias), scale=None if s1 is None else s1[2],
+                                 shift=None if s1 is None else s1[3])
+            return None
         _norm_bwd_inplace(c2, ga1, a1, bs["s2"], True, grads, sums=sums)  # a1 is a ReLU output: mask fused
     else:
         _dgrad(c2, gout, ga1, ref=a1)
         _wgrad(c2, a1, gout, grads, bs["s2"])
-    affine1 = bs["s1"] is not None and c1.norm_args()[1] is not None
     if gin is None and not affine1:
         _wgrad(c1, xin, ga1, grads, bs["s1"])
         return

@@ -226,6 +226,28 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
+def conv_wgrad_gnorm_ok(k, cin, cout, mfma) -> bool:
+    return bool(_lib.load().tem_conv3d_wgrad_gnorm_ok(cin, cout, k[0], k[1], k[2], int(mfma)))
+
+
+def conv_wgrad_gnorm(x, g, y, coef, k, cin, cout, dw_out, db_out=None, scale=None, shift=None):
+    """First-layer weight gradient with the backward of the norm behind this conv's ReLU applied to g on load
+    (tem_conv3d_wgrad_gnorm): g raw data gradient, y this conv's output, coef from norm_bwd_coef."""
+    _req_cuda(x, g, y, coef, dw_out)
+    N, D, H, W, C, x_ld = _act5(x)
+    g_ld, y_ld = _act5(g)[5], _act5(y)[5]
+    lib = _lib.load()
+    nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 0)
+    ws = _workspace(nws, x.device)
+    kind = _wgrad_tag(0, k, cout) if PROFILER is not None else None
+    ev0 = _prof_begin(x, kind)
+    _lib.check(lib.tem_conv3d_wgrad_gnorm(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(y), y_ld, _p(coef), _p(dw_out),
+                                          _p(db_out), _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], 1, _stream(x)),
+               "tem_conv3d_wgrad_gnorm")
+    if ev0 is not None:
+        _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
+
+
 def conv_wgrad_sums_ok(x, k, cin, cout, mfma) -> bool:
     N, D, H, W, _, _ = _act5(x)
     return bool(_lib.load().tem_conv3d_wgrad_sums_ok(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
