@@ -1921,10 +1921,10 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
             float* extra = zdb + tem_align_up((int64_t)z.S * Cout, 64);
             tem_wgrad_sums_launch(zpart, z.Ss, z.ks2, zdb, g, g_ld, w_sd, gamma, beta, dw, extra, N, D, H, W, Cin, Cout,
                                   norm_sums, s);
+            if (db) tem_reduce_slabs(zdb, z.S, Cout, Cout, db, s);
         } else {
-            tem_reduce_slabs_w(zpart, z.S * z.ks2, 27, Cin, Cout, (int64_t)27 * Cin * Cout, dw, sd_layout, s);
+            tem_reduce_slabs_w_db(zpart, z.S * z.ks2, 27, Cin, Cout, (int64_t)27 * Cin * Cout, dw, sd_layout, zdb, z.S, db, s);
         }
-        if (db) tem_reduce_slabs(zdb, z.S, Cout, Cout, db, s);
         return TEM_OK;
     }
     TEM_REQUIRE(!norm_sums, "tem_conv3d_wgrad_sums: this layer cannot deliver the norm sums (tem_conv3d_wgrad_sums_ok() == 0)");
@@ -1958,7 +1958,6 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
     }
 #undef WGO
     const int64_t n = (int64_t)ntaps * Cin * Cout;
-    tem_reduce_slabs_w(part, p.S * p.ks2, ntaps, Cin, Cout, n, dw, sd_layout, s);
-    if (db) tem_reduce_slabs(dbpart, p.S, Cout, Cout, db, s);
+    tem_reduce_slabs_w_db(part, p.S * p.ks2, ntaps, Cin, Cout, n, dw, sd_layout, dbpart, p.S, db, s);
     return TEM_OK;
 }

@@ -439,11 +439,28 @@ void tem_reduce_slabs(const float* part, int nchunks, int64_t n, int64_t chunk_s
 // weight-gradient merge that also converts the kernels' [tap][ci][co] order into the reference's
 // state_dict order [co][ci][tap] (fuses the former k_unpack_wgrad pass)
 __global__ __launch_bounds__(512) void k_reduce_slabs_sd(const float* __restrict__ part, int nchunks, int ntaps, int Cin,
-                                                         int Cout, int64_t chunk_stride, float* __restrict__ out) {
+                                                         int Cout, int64_t chunk_stride, float* __restrict__ out,
+                                                         int nb_w, const float* __restrict__ dbpart, int db_chunks,
+                                                         float* __restrict__ db) {
     __shared__ double sh[8][64];
     const int64_t n = (int64_t)ntaps * Cin * Cout;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
+    if ((int)blockIdx.x >= nb_w) {  // the bias gradient rides along: db[co] = sum_c dbpart[c][co] (one launch less)
+        const int co = ((int)blockIdx.x - nb_w) * 64 + tx;
+        double s = 0.0;
+        if (co < Cout)
+            for (int c = ty; c < db_chunks; c += 8) s += (double)dbpart[(int64_t)c * Cout + co];
+        sh[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && co < Cout) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += sh[k][tx];
+            db[co] = (float)a;
+        }
+        return;
+    }
+    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)nb_w * 64) {
         const int64_t i = i0 + tx;
         double s = 0.0;
         if (i < n) {
@@ -513,17 +530,24 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_ci(const float* __restrict
     }
 }
 
-void tem_reduce_slabs_w(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
-                        int sd_layout, hipStream_t s) {
+void tem_reduce_slabs_w_db(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
+                           int sd_layout, const float* dbpart, int db_chunks, float* db, hipStream_t s) {
     const int64_t n = (int64_t)ntaps * Cin * Cout;
     if (!sd_layout) {
         tem_reduce_slabs(part, nchunks, n, chunk_stride, dw, s);
+        if (db) tem_reduce_slabs(dbpart, db_chunks, Cout, Cout, db, s);
         return;
     }
     int64_t nb = tem_cdiv(n, 64);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(k_reduce_slabs_sd, dim3((unsigned)nb), dim3(512), 0, s, part, nchunks, ntaps, Cin, Cout,
-                       chunk_stride, dw);
+    const int64_t nbd = db ? tem_cdiv((int64_t)Cout, 64) : 0;
+    hipLaunchKernelGGL(k_reduce_slabs_sd, dim3((unsigned)(nb + nbd)), dim3(512), 0, s, part, nchunks, ntaps, Cin, Cout,
+                       chunk_stride, dw, (int)nb, dbpart, db_chunks, db);
+}
+
+void tem_reduce_slabs_w(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
+                        int sd_layout, hipStream_t s) {
+    tem_reduce_slabs_w_db(part, nchunks, ntaps, Cin, Cout, chunk_stride, dw, sd_layout, nullptr, 0, nullptr, s);
 }
 
 #define CIN1_GRID 1024
