@@ -241,12 +241,14 @@ int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_
                       float* gx, int64_t gx_ld,
                       int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
 /* ... where gskip is still the RAW data gradient behind a norm whose input is x: gskip := a*gskip - m1 - (x - mean)*m2r
- * with gcoef = tem_norm_bwd_coef()'s rows for these C channels (gcoef_ld floats per sample) -- see tem_norm_bwd_coef */
+ * with gcoef = tem_norm_bwd_coef()'s rows for these C channels (gcoef_ld floats per sample) -- see tem_norm_bwd_coef.
+ * ycoef (optional, dense [N][C][4]; gcoef may then be NULL): gy is raw as well -- the gradient behind the norm whose
+ * input is the POOLED tensor (first norm of the next level's block); x there is the maximum the kernel recomputes. */
 int tem_maxpool3d_bwd_norm(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld,
                            const float* gskip, int64_t gskip_ld, int relu_mask,
                            float* gx, int64_t gx_ld,
                            int N, int D, int H, int W, int C, int fz, int fy, int fx,
-                           const float* gcoef, int64_t gcoef_ld, tem_stream_t stream);
+                           const float* gcoef, int64_t gcoef_ld, const float* ycoef, tem_stream_t stream);
 /* F.interpolate(mode="trilinear"/"bilinear", align_corners=False, integer scale
  * factors) (model/unet.py:456).  (D,H,W) are the INPUT dims; output is (D*fz,H*fy,W*fx).
  * bwd is the exact adjoint (upsample_trilinear3d_backward). */

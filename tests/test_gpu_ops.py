@@ -327,6 +327,25 @@ def test_deferred_concat_norm_backward(case):
     ops.maxpool_bwd(gpool, cat[..., cup:], gs1, f, gskip=gcat[..., cup:], relu_mask=True, gskip_coef=coef[:, cup:])
     assert rel_err(gs1.cpu(), gs0.cpu()) < 1e-6
     assert rel_err(gt1.cpu(), gt0.cpu()) < 2e-5
+    # the same for the norm whose input is the POOLED tensor (first norm of the next level's block): max-pool backward
+    # applies it to the incoming gradient, using the maximum it recomputes
+    skipt = cat[..., cup:]
+    pooled = torch.empty(N, d, h, w, cskip, device=DEV)
+    ops.maxpool_fwd(skipt, pooled, f)
+    gp = min(groups, cskip)
+    gam2, bet2 = gamma[:cskip].contiguous(), beta[:cskip].contiguous()
+    mean2, rstd2, _, _ = ops.norm_stats(pooled, gp, gam2, bet2, 1e-5)
+    gapp2 = gpool.clone()
+    ops.norm_bwd(gapp2, pooled, gp, gam2, mean2, rstd2, False, gapp2, None, None)
+    ref = torch.empty(N, D, H, W, cskip, device=DEV)
+    ops.maxpool_bwd(gapp2, skipt, ref, f, gskip=gapp[..., cup:], relu_mask=True)
+    coef2 = ops.norm_bwd_coef(gpool, pooled, gp, gam2, mean2, rstd2)
+    got = torch.empty(N, D, H, W, cskip, device=DEV)
+    ops.maxpool_bwd(gpool, skipt, got, f, gskip=gcat[..., cup:], relu_mask=True, gskip_coef=coef[:, cup:], gy_coef=coef2)
+    assert rel_err(got.cpu(), ref.cpu()) < 1e-6
+    got2 = torch.empty(N, D, H, W, cskip, device=DEV)
+    ops.maxpool_bwd(gpool, skipt, got2, f, gskip=gapp[..., cup:], relu_mask=True, gy_coef=coef2)
+    assert rel_err(got2.cpu(), ref.cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("case", [((2, 2, 2), (2, 6, 5, 7), 32, 32, 64), ((1, 2, 2), (1, 5, 6, 4), 64, 64, 32),

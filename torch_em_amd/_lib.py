@@ -55,7 +55,7 @@ SIGNATURES = {
     "tem_maxpool3d_fwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
     "tem_maxpool3d_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
     "tem_maxpool3d_bwd_norm": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64] + [c_int] * 8
-                               + [c_vp, c_i64, c_vp]),
+                               + [c_vp, c_i64, c_vp, c_vp]),
     "tem_upsample_bwd_norm": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp, c_i64, c_vp, c_i64, c_vp]),
     "tem_norm_bwd_coef": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp, c_i64, c_vp]),

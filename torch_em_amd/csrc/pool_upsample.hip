@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
                                                      const float* __restrict__ gskip, int64_t gskip_ld, int relu_mask,
                                                      float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
                                                      int fz, int fy, int fx, const float* __restrict__ gcoef,
-                                                     int64_t gcoef_ld) {
+                                                     int64_t gcoef_ld, const float* __restrict__ ycoef) {
     const int Do = D / fz, Ho = H / fy, Wo = W / fx;
     const int cq = C / VEC;
     int row = blockIdx.x;
@@ -124,6 +124,15 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
         int64_t vo = (((int64_t)n * Do + zo) * Ho + yo) * Wo + xo;
         float g[VEC];
         ld_vec<VEC>(gy + vo * gy_ld + c0, g);
+        if (ycoef) {
+            // gy is the RAW data gradient behind the norm whose input is the POOLED tensor (first norm of the next
+            // level's block): its backward is applied here -- the pooled value is the maximum m[j] just recomputed
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float4 kc = *reinterpret_cast<const float4*>(ycoef + ((int64_t)n * C + c0 + j) * 4);
+                g[j] = kc.x * g[j] - kc.y - (m[j] - kc.w) * kc.z;
+            }
+        }
         k = 0;
         for (int dz = 0; dz < fz; ++dz)
             for (int dy = 0; dy < fy; ++dy)
@@ -176,7 +185,8 @@ extern "C" int tem_maxpool3d_fwd(const float* x, int64_t x_ld, float* y, int64_t
 
 static int maxpool3d_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, const float* gskip,
                               int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H, int W,
-                              int C, int fz, int fy, int fx, const float* gcoef, int64_t gcoef_ld, tem_stream_t stream) {
+                              int C, int fz, int fy, int fx, const float* gcoef, int64_t gcoef_ld, const float* ycoef,
+                              tem_stream_t stream) {
     TEM_REQUIRE(gy && x && gx && N > 0 && C > 0 && x_ld >= C && gy_ld >= C && gx_ld >= C,
                 "tem_maxpool3d_bwd: bad arguments");
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0 && D % fz == 0 && H % fy == 0 && W % fx == 0,
@@ -185,10 +195,10 @@ static int maxpool3d_bwd_impl(const float* gy, int64_t gy_ld, const float* x, in
     TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_bwd: too many rows");
     if (vec4_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}))
         hipLaunchKernelGGL((k_maxpool_bwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
-                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld);
+                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef);
     else
         hipLaunchKernelGGL((k_maxpool_bwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
-                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld);
+                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef);
     TEM_CHECK_LAUNCH("tem_maxpool3d_bwd");
     return TEM_OK;
 }
@@ -197,20 +207,24 @@ extern "C" int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x,
                                  int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H, int W,
                                  int C, int fz, int fy, int fx, tem_stream_t stream) {
     return maxpool3d_bwd_impl(gy, gy_ld, x, x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, N, D, H, W, C, fz, fy, fx, nullptr,
-                              0, stream);
+                              0, nullptr, stream);
 }
 
 // tem_maxpool3d_bwd whose skip gradient is still the RAW data gradient of the decoder conv behind the concat norm: that
 // norm's backward (coefficients from tem_norm_bwd_coef, rows of gcoef_ld floats per sample, this tensor's channels
 // first) is applied on the fly -- x, its input, is the tensor this kernel reads anyway.
+// ycoef (optional, [N][C][4] dense): gy is likewise raw -- the gradient behind the norm whose input is the POOLED tensor
+// (the first norm of the next level's block); its backward uses the maximum this kernel recomputes.
 extern "C" int tem_maxpool3d_bwd_norm(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, const float* gskip,
                                       int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H,
                                       int W, int C, int fz, int fy, int fx, const float* gcoef, int64_t gcoef_ld,
-                                      tem_stream_t stream) {
-    TEM_REQUIRE(gskip && gcoef && gcoef_ld >= 4 * C && ((uintptr_t)gcoef % 16 == 0) && gcoef_ld % 4 == 0,
-                "tem_maxpool3d_bwd_norm: bad coefficient arguments");
+                                      const float* ycoef, tem_stream_t stream) {
+    TEM_REQUIRE(gcoef || ycoef, "tem_maxpool3d_bwd_norm: no coefficients given");
+    TEM_REQUIRE(!gcoef || (gskip && gcoef_ld >= 4 * C && ((uintptr_t)gcoef % 16 == 0) && gcoef_ld % 4 == 0),
+                "tem_maxpool3d_bwd_norm: bad skip coefficient arguments");
+    TEM_REQUIRE(!ycoef || ((uintptr_t)ycoef % 16 == 0), "tem_maxpool3d_bwd_norm: ycoef must be 16-byte aligned");
     return maxpool3d_bwd_impl(gy, gy_ld, x, x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, N, D, H, W, C, fz, fy, fx, gcoef,
-                              gcoef_ld, stream);
+                              gcoef_ld, ycoef, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -685,7 +685,9 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         stage_done()
     bb = st["base"]
     g_pooled = torch.empty_like(bb["xin"])
-    _block_bwd(bb, g_cur, g_pooled, grads)
+    # the input of this block (and of every encoder block below level 0) is a max-pooled tensor: the backward of its
+    # first norm is applied by the max-pool backward that consumes the gradient (it recomputes the pooled value anyway)
+    pool_coef = _block_bwd(bb, g_cur, g_pooled, grads, defer_input_norm=True)
     g_cur = g_pooled
     stage_done()
     for l in reversed(range(depth)):
@@ -694,11 +696,11 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         g_skip_full = ops.new_act(skip.shape[0], skip.shape[1], skip.shape[2], skip.shape[3], skip.shape[4],
                                   skip.device)
         ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True,
-                        gskip_coef=lv.get("g_skip_coef"))
+                        gskip_coef=lv.get("g_skip_coef"), gy_coef=pool_coef)
         need_in = (l > 0) or need_input_grad
         xin = lv["bs"]["xin"]
         g_in = torch.empty_like(xin) if need_in else None
-        _block_bwd(lv["bs"], g_skip_full, g_in, grads)
+        pool_coef = _block_bwd(lv["bs"], g_skip_full, g_in, grads, defer_input_norm=l > 0)
         g_cur = g_in
         stage_done()
     _join_side(gy_dev)  # the optimizer (main stream) reads every weight gradient

@@ -390,7 +390,7 @@ def maxpool_fwd(x, y, f):
     return y
 
 
-def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None):
+def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None, gy_coef=None):
     """gskip_coef: [N, C, 4] view (row stride = multiple of 4 floats) of norm_bwd_coef() -- gskip is then the raw data
     gradient behind that norm and the norm backward is applied on the fly (tem_maxpool3d_bwd_norm)."""
     _req_cuda(gy, x, gx)
@@ -399,9 +399,13 @@ def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None):
     gx_ld = _act5(gx)[5]
     gs_ld = _act5(gskip)[5] if gskip is not None else 0
     lib = _lib.load()
-    if gskip_coef is not None:
+    if gskip_coef is not None or gy_coef is not None:
+        # gy_coef: dense [N, C, 4] coefficients of the norm whose input is the pooled tensor (gy raw as well)
+        if gy_coef is not None and not gy_coef.is_contiguous():
+            raise ValueError("maxpool_bwd: gy_coef must be contiguous")
         _lib.check(lib.tem_maxpool3d_bwd_norm(_p(gy), gy_ld, _p(x), x_ld, _p(gskip), gs_ld, int(relu_mask), _p(gx), gx_ld,
-                                              N, D, H, W, C, f[0], f[1], f[2], _p(gskip_coef), gskip_coef.stride(0),
+                                              N, D, H, W, C, f[0], f[1], f[2], _p(gskip_coef),
+                                              gskip_coef.stride(0) if gskip_coef is not None else 0, _p(gy_coef),
                                               _stream(x)), "tem_maxpool3d_bwd_norm")
         return gx
     _lib.check(lib.tem_maxpool3d_bwd(_p(gy), gy_ld, _p(x), x_ld, _p(gskip), gs_ld, int(relu_mask), _p(gx), gx_ld,
