@@ -293,6 +293,30 @@ __device__ __forceinline__ float lin_w(int o, int f, int in, int i) {
     return w;
 }
 
+// the fine positions lo..hi that read coarse index i with a non-zero weight, compacted into (index, weight) lists of 4
+// (factor <= 2); unused entries repeat a valid index with weight 0.  Returns the count.
+__device__ __forceinline__ int upb_taps(int lo, int hi, int f, int in, int i, int (&idx)[4], float (&wt)[4]) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        idx[k] = lo;
+        wt[k] = 0.f;
+    }
+    for (int o = lo; o <= hi; ++o) {
+        const float w = lin_w(o, f, in, i);
+        if (w != 0.f && cnt < 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k == cnt) {
+                    idx[k] = o;
+                    wt[k] = w;
+                }
+            ++cnt;
+        }
+    }
+    return cnt;
+}
+
 // (U^T U)[i][i+d], d = -1, 0, 1, and (U^T 1)[i] of the 1-D interpolation operator U (lin_w)
 __device__ __forceinline__ void utu_axis(int i, int f, int in, float (&a)[3], float& s) {
     a[0] = a[1] = a[2] = 0.f;
@@ -322,6 +346,14 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
     const int n = row / D;
     const int zlo = max(0, fz * zi - fz), zhi = min(Do - 1, fz * zi + 2 * fz - 1);
     const int ylo = max(0, fy * yi - fy), yhi = min(Ho - 1, fy * yi + 2 * fy - 1);
+    const bool fast = fz <= 2 && fy <= 2 && fx <= 2;  // <= 4 contributing positions per axis
+    int zidx[4], yidx[4];
+    float zw[4], yw[4];
+    int nzt = 0;
+    if (fast) {
+        nzt = upb_taps(zlo, zhi, fz, D, zi, zidx, zw);
+        upb_taps(ylo, yhi, fy, H, yi, yidx, yw);
+    }
     float az[3] = {0.f, 0.f, 0.f}, ay[3] = {0.f, 0.f, 0.f}, sz = 0.f, sy = 0.f;  // the row's (z, y) stencil weights
     if (ncoef) {
         utu_axis(zi, fz, D, az, sz);
@@ -333,6 +365,30 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
         float acc[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        if (fast) {
+            // the (<= 4) contributing fine positions per axis as compact (index, weight) lists: 16 independent loads per
+            // z tap without a branch in between (the weight test per gathered element serialised the loads: this kernel
+            // ran at the latency of ~90 dependent loads per item)
+            int xidx[4];
+            float xw[4];
+            upb_taps(xlo, xhi, fx, W, xi, xidx, xw);
+            for (int kz = 0; kz < nzt; ++kz) {
+                const int64_t rz = ((int64_t)n * Do + zidx[kz]) * Ho;
+                float t[4][4][VEC];
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) ld_vec<VEC>(gy + ((rz + yidx[ky]) * Wo + xidx[kx]) * gy_ld + c0, t[ky][kx]);
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const float w = zw[kz] * yw[ky] * xw[kx];
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(w, t[ky][kx][j], acc[j]);
+                    }
+            }
+        } else
         for (int zo = zlo; zo <= zhi; ++zo) {
             float wz = lin_w(zo, fz, D, zi);
             if (wz == 0.f) continue;
