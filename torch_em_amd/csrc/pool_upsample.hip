@@ -418,19 +418,28 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
             float q[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) q[j] = 0.f;
-            for (int dz = -1; dz <= 1; ++dz) {
-                if (az[dz + 1] == 0.f) continue;
-                for (int dy = -1; dy <= 1; ++dy) {
-                    if (ay[dy + 1] == 0.f) continue;
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const float wq = az[dz + 1] * ay[dy + 1] * ax[dx + 1];
-                        if (wq == 0.f) continue;
-                        float t[VEC];
-                        ld_vec<VEC>(u + ((((int64_t)n * D + zi + dz) * H + yi + dy) * W + xi + dx) * u_ld + c0, t);
+            // all 27 taps unconditionally (out-of-range neighbours: clamped address, weight 0): independent loads
 #pragma unroll
-                        for (int j = 0; j < VEC; ++j) q[j] = fmaf(wq, t[j], q[j]);
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int zc = min(max(zi + dz, 0), D - 1);
+                float t[3][3][VEC];
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int yc = min(max(yi + dy, 0), H - 1);
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int xc = min(max(xi + dx, 0), W - 1);
+                        ld_vec<VEC>(u + ((((int64_t)n * D + zc) * H + yc) * W + xc) * u_ld + c0, t[dy + 1][dx + 1]);
                     }
                 }
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const float wq = az[dz + 1] * ay[dy + 1] * ax[dx + 1];
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) q[j] = fmaf(wq, t[dy + 1][dx + 1][j], q[j]);
+                    }
             }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -470,19 +479,27 @@ __global__ __launch_bounds__(256) void k_upsample_stats(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < VEC; ++j) q[j] = 0.f;
         ld_vec<VEC>(u + ((((int64_t)n * D + zi) * H + yi) * W + xi) * u_ld + c0, uc);
-        for (int dz = -1; dz <= 1; ++dz) {
-            if (az[dz + 1] == 0.f) continue;
-            for (int dy = -1; dy <= 1; ++dy) {
-                if (ay[dy + 1] == 0.f) continue;
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const float wq = az[dz + 1] * ay[dy + 1] * ax[dx + 1];
-                    if (wq == 0.f) continue;
-                    float t[VEC];
-                    ld_vec<VEC>(u + ((((int64_t)n * D + zi + dz) * H + yi + dy) * W + xi + dx) * u_ld + c0, t);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) q[j] = fmaf(wq, t[j], q[j]);
+        for (int dz = -1; dz <= 1; ++dz) {  // all 27 taps unconditionally (clamped address, weight 0 outside)
+            const int zc = min(max(zi + dz, 0), D - 1);
+            float t[3][3][VEC];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yc = min(max(yi + dy, 0), H - 1);
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xc = min(max(xi + dx, 0), W - 1);
+                    ld_vec<VEC>(u + ((((int64_t)n * D + zc) * H + yc) * W + xc) * u_ld + c0, t[dy + 1][dx + 1]);
                 }
             }
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const float wq = az[dz + 1] * ay[dy + 1] * ax[dx + 1];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) q[j] = fmaf(wq, t[dy + 1][dx + 1][j], q[j]);
+                }
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
