@@ -98,6 +98,72 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
     row /= Ho;
     const int zo = row % Do;
     const int n = row / Do;
+    const int nwin = fz * fy * fx;
+    if (nwin <= 8) {
+        // windows of <= 8 voxels (every pooling factor of the reference nets): the window is read ONCE into registers,
+        // all loads independent (the runtime-bounded triple loops issued them one by one and read x twice)
+        for (int i = threadIdx.x; i < Wo * cq; i += 256) {
+            const int xo = i / cq, c0 = (i % cq) * VEC;
+            int64_t vk[8];
+            float t[8][VEC], o[8][VEC];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < nwin ? k : 0;
+                const int dx = kk % fx, dy = (kk / fx) % fy, dz = kk / (fx * fy);
+                vk[k] = (((int64_t)n * D + zo * fz + dz) * H + yo * fy + dy) * W + xo * fx + dx;
+                ld_vec<VEC>(x + vk[k] * x_ld + c0, t[k]);
+                if (gskip) {
+                    ld_vec<VEC>(gskip + vk[k] * gskip_ld + c0, o[k]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) o[k][j] = 0.f;
+                }
+            }
+            float m[VEC];
+            int am[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                m[j] = -INFINITY;
+                am[j] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < nwin) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        if (t[k][j] > m[j] || t[k][j] != t[k][j]) {
+                            m[j] = t[k][j];
+                            am[j] = k;
+                        }
+                }
+            const int64_t vo = (((int64_t)n * Do + zo) * Ho + yo) * Wo + xo;
+            float g[VEC];
+            ld_vec<VEC>(gy + vo * gy_ld + c0, g);
+            float4 kg[VEC], ky[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                if (gcoef) kg[j] = *reinterpret_cast<const float4*>(gcoef + (int64_t)n * gcoef_ld + (c0 + j) * 4);
+                if (ycoef) {
+                    ky[j] = *reinterpret_cast<const float4*>(ycoef + ((int64_t)n * C + c0 + j) * 4);
+                    g[j] = ky[j].x * g[j] - ky[j].y - (m[j] - ky[j].w) * ky[j].z;  // see the general path below
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < nwin) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        float v = o[k][j];
+                        if (gcoef) v = kg[j].x * v - kg[j].y - (t[k][j] - kg[j].w) * kg[j].z;
+                        if (am[j] == k) v += g[j];
+                        if (relu_mask && !(t[k][j] > 0.f)) v = 0.f;
+                        o[k][j] = v;
+                    }
+                    st_vec<VEC>(gx + vk[k] * gx_ld + c0, o[k]);
+                }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < Wo * cq; i += 256) {
         const int xo = i / cq, c0 = (i % cq) * VEC;
         float m[VEC];
