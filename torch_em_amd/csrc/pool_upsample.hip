@@ -64,6 +64,30 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x
     row /= Ho;
     const int zo = row % Do;
     const int n = row / Do;
+    const int nwin = fz * fy * fx;
+    if (nwin <= 8) {  // the window as 8 independent loads (see k_maxpool_bwd)
+        for (int i = threadIdx.x; i < Wo * cq; i += 256) {
+            const int xo = i / cq, c0 = (i % cq) * VEC;
+            float t[8][VEC], m[VEC];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = k < nwin ? k : 0;
+                const int dx = kk % fx, dy = (kk / fx) % fy, dz = kk / (fx * fy);
+                ld_vec<VEC>(x + ((((int64_t)n * D + zo * fz + dz) * H + yo * fy + dy) * W + xo * fx + dx) * x_ld + c0, t[k]);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < nwin) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        if (t[k][j] > m[j] || t[k][j] != t[k][j]) m[j] = t[k][j];
+                }
+            st_vec<VEC>(y + ((((int64_t)n * Do + zo) * Ho + yo) * Wo + xo) * y_ld + c0, m);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < Wo * cq; i += 256) {
         const int xo = i / cq, c0 = (i % cq) * VEC;
         float m[VEC];
