@@ -344,14 +344,31 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
             lds[hv] = v;
         }
         __syncthreads();
-        for (int p = vl; p < 256; p += nvl) {
+        // software pipeline over the patch voxels of this lane: the loads of voxel p + nvl are issued before the 27-tap
+        // FMA block of voxel p (they used to sit behind it: one exposed HBM round trip per voxel)
+        auto load_g = [&](int p, float4& gv, float4& yv, bool& ok) {
             const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
             const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
-            if (gz >= D || gy >= H || gx >= W) continue;
-            const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
-            float4 gv = *reinterpret_cast<const float4*>(g + v * g_ld + q * 4);
+            ok = p < 256 && gz < D && gy < H && gx < W;
+            gv = make_float4(0.f, 0.f, 0.f, 0.f);
+            yv = gv;
+            if (ok) {
+                const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
+                gv = *reinterpret_cast<const float4*>(g + v * g_ld + q * 4);
+                if (gcoef) yv = *reinterpret_cast<const float4*>(gnx + v * gnx_ld + q * 4);
+            }
+        };
+        float4 gv_n, yv_n;
+        bool ok_n;
+        load_g(vl, gv_n, yv_n, ok_n);
+        for (int p = vl; p < 256; p += nvl) {
+            const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+            float4 gv = gv_n;
+            const float4 yv = yv_n;
+            const bool ok = ok_n;
+            load_g(p + nvl, gv_n, yv_n, ok_n);
+            if (!ok) continue;
             if (gcoef) {
-                const float4 yv = *reinterpret_cast<const float4*>(gnx + v * gnx_ld + q * 4);
                 gv.x = yv.x > 0.f ? kc[0].x * gv.x - kc[0].y - (yv.x - kc[0].w) * kc[0].z : 0.f;
                 gv.y = yv.y > 0.f ? kc[1].x * gv.y - kc[1].y - (yv.y - kc[1].w) * kc[1].z : 0.f;
                 gv.z = yv.z > 0.f ? kc[2].x * gv.z - kc[2].y - (yv.z - kc[2].w) * kc[2].z : 0.f;
