@@ -1791,6 +1791,9 @@ static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) 
     p.P = (int)P;
     int64_t S = (768 + p.T - 1) / p.T;  // one workgroup per CU: ~3 waves of workgroups
     int64_t slab = (int64_t)ntaps * Cin * Cout * 4 * p.ks2;
+    // channel-rich, spatially tiny layers (the 8^3 level: 28 MB per slab for 512 -> 512): every slab is written and read
+    // back by the merge, which then dominates -- one workgroup per CU (a single wave of workgroups) instead of three
+    if (slab >= (8ll << 20)) S = (256 + p.T - 1) / p.T;
     int64_t cap = (256ll << 20) / slab;
     if (cap < 1) cap = 1;
     if (S > cap) S = cap;

@@ -547,6 +547,73 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_ci(const float* __restrict
     }
 }
 
+// the same with 16-byte loads: a thread owns 4 consecutive outputs (the 4-byte version ran at 2.4 TB/s)
+__global__ __launch_bounds__(512) void k_reduce_slabs_sd4(const float* __restrict__ part, int nchunks, int ntaps, int Cin,
+                                                          int Cout, int64_t chunk_stride, float* __restrict__ out,
+                                                          int nb_w, const float* __restrict__ dbpart, int db_chunks,
+                                                          float* __restrict__ db) {
+    __shared__ double sh[8][64][4];
+    const int64_t n = (int64_t)ntaps * Cin * Cout;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= nb_w) {
+        const int co = ((int)blockIdx.x - nb_w) * 64 + tx;
+        double s = 0.0;
+        if (co < Cout)
+            for (int c = ty; c < db_chunks; c += 8) s += (double)dbpart[(int64_t)c * Cout + co];
+        sh[ty][tx][0] = s;
+        __syncthreads();
+        if (ty == 0 && co < Cout) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += sh[k][tx][0];
+            db[co] = (float)a;
+        }
+        return;
+    }
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)nb_w * 256) {
+        const int64_t i = i0 + tx * 4;
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, r[4] = {0.0, 0.0, 0.0, 0.0};
+        if (i < n) {
+            int c = ty;
+            for (; c + 56 < nchunks; c += 64) {  // eight 16-byte loads in flight: the loop is latency-bound
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(part + (int64_t)(c + 8 * k) * chunk_stride + i);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    s[0] += (double)v[k].x; s[1] += (double)v[k].y; s[2] += (double)v[k].z; s[3] += (double)v[k].w;
+                    r[0] += (double)v[k + 1].x; r[1] += (double)v[k + 1].y; r[2] += (double)v[k + 1].z; r[3] += (double)v[k + 1].w;
+                }
+            }
+            for (; c + 8 < nchunks; c += 16) {
+                const float4 a = *reinterpret_cast<const float4*>(part + (int64_t)c * chunk_stride + i);
+                const float4 b = *reinterpret_cast<const float4*>(part + (int64_t)(c + 8) * chunk_stride + i);
+                s[0] += (double)a.x; s[1] += (double)a.y; s[2] += (double)a.z; s[3] += (double)a.w;
+                r[0] += (double)b.x; r[1] += (double)b.y; r[2] += (double)b.z; r[3] += (double)b.w;
+            }
+            if (c < nchunks) {
+                const float4 a = *reinterpret_cast<const float4*>(part + (int64_t)c * chunk_stride + i);
+                s[0] += (double)a.x; s[1] += (double)a.y; s[2] += (double)a.z; s[3] += (double)a.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[ty][tx][j] = s[j] + r[j];
+        __syncthreads();
+        if (ty < 4 && i < n) {  // wave ty finishes output j = ty of every thread's quad
+            const int j = ty;
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += sh[k][tx][j];
+            const int64_t ii = i + j;
+            const int co = (int)(ii % Cout);
+            const int64_t rr = ii / Cout;
+            const int ci = (int)(rr % Cin), tap = (int)(rr / Cin);
+            out[((int64_t)co * Cin + ci) * ntaps + tap] = (float)a;
+        }
+        __syncthreads();
+    }
+}
+
 void tem_reduce_slabs_w_db(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
                            int sd_layout, const float* dbpart, int db_chunks, float* db, hipStream_t s) {
     const int64_t n = (int64_t)ntaps * Cin * Cout;
@@ -558,6 +625,13 @@ void tem_reduce_slabs_w_db(const float* part, int nchunks, int ntaps, int Cin, i
     int64_t nb = tem_cdiv(n, 64);
     if (nb > 4096) nb = 4096;
     const int64_t nbd = db ? tem_cdiv((int64_t)Cout, 64) : 0;
+    if (n % 4 == 0 && chunk_stride % 4 == 0 && ((uintptr_t)part % 16 == 0)) {
+        int64_t nb4 = tem_cdiv(n, 256);
+        if (nb4 > 4096) nb4 = 4096;
+        hipLaunchKernelGGL(k_reduce_slabs_sd4, dim3((unsigned)(nb4 + nbd)), dim3(512), 0, s, part, nchunks, ntaps, Cin, Cout,
+                           chunk_stride, dw, (int)nb4, dbpart, db_chunks, db);
+        return;
+    }
     hipLaunchKernelGGL(k_reduce_slabs_sd, dim3((unsigned)(nb + nbd)), dim3(512), 0, s, part, nchunks, ntaps, Cin, Cout,
                        chunk_stride, dw, (int)nb, dbpart, db_chunks, db);
 }
