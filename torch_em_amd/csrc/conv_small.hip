@@ -614,6 +614,40 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_sd4(const float* __restric
     }
 }
 
+// Large weight tensors (>= 1M entries): the [tap][ci][co] -> [co][ci][tap] transposition goes through LDS so that both
+// sides are coalesced (128-byte reads of 32 consecutive co, 108-byte writes of 27 consecutive taps); the element-wise
+// version scattered 4-byte writes 55 KB apart (94 us for the 512 -> 512 layer).  Block <-> (ci, 32-co group).
+__global__ __launch_bounds__(256) void k_reduce_slabs_sd_t(const float* __restrict__ part, int nchunks, int Cin, int Cout,
+                                                           int64_t chunk_stride, float* __restrict__ out, int nb_w,
+                                                           const float* __restrict__ dbpart, int db_chunks,
+                                                           float* __restrict__ db) {
+    __shared__ float tile[27][33];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nb_w) {  // bias gradient (see k_reduce_slabs_sd)
+        const int co = ((int)blockIdx.x - nb_w) * 256 + tid;
+        if (co < Cout) {
+            double a = 0.0;
+            for (int c = 0; c < db_chunks; ++c) a += (double)dbpart[(int64_t)c * Cout + co];
+            db[co] = (float)a;
+        }
+        return;
+    }
+    const int cg = Cout >> 5;
+    const int ci = (int)blockIdx.x / cg, co0 = ((int)blockIdx.x % cg) * 32;
+    for (int e = tid; e < 27 * 32; e += 256) {
+        const int tap = e >> 5, col = e & 31;
+        const int64_t i = ((int64_t)tap * Cin + ci) * Cout + co0 + col;
+        double a = 0.0;
+        for (int c = 0; c < nchunks; ++c) a += (double)part[(int64_t)c * chunk_stride + i];
+        tile[tap][col] = (float)a;
+    }
+    __syncthreads();
+    for (int e = tid; e < 27 * 32; e += 256) {
+        const int col = e / 27, tap = e % 27;
+        out[((int64_t)(co0 + col) * Cin + ci) * 27 + tap] = tile[tap][col];
+    }
+}
+
 void tem_reduce_slabs_w_db(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
                            int sd_layout, const float* dbpart, int db_chunks, float* db, hipStream_t s) {
     const int64_t n = (int64_t)ntaps * Cin * Cout;
@@ -625,6 +659,12 @@ void tem_reduce_slabs_w_db(const float* part, int nchunks, int ntaps, int Cin, i
     int64_t nb = tem_cdiv(n, 64);
     if (nb > 4096) nb = 4096;
     const int64_t nbd = db ? tem_cdiv((int64_t)Cout, 64) : 0;
+    if (ntaps == 27 && Cout % 32 == 0 && n >= (1 << 20) && nchunks <= 64) {
+        const int64_t nbt = (int64_t)Cin * (Cout / 32), nbdt = db ? tem_cdiv((int64_t)Cout, 256) : 0;
+        hipLaunchKernelGGL(k_reduce_slabs_sd_t, dim3((unsigned)(nbt + nbdt)), dim3(256), 0, s, part, nchunks, Cin, Cout,
+                           chunk_stride, dw, (int)nbt, dbpart, db_chunks, db);
+        return;
+    }
     if (n % 4 == 0 && chunk_stride % 4 == 0 && ((uintptr_t)part % 16 == 0)) {
         int64_t nb4 = tem_cdiv(n, 256);
         if (nb4 > 4096) nb4 = 4096;
