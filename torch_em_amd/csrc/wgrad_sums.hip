@@ -160,14 +160,14 @@ __global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __re
         if (t < 27 * Cout) {
             const int cz = t / (9 * Cout), rem = t % (9 * Cout);
             const int s0 = cz == 1 ? 0 : (cz == 0 ? D - 2 : D - 2 + H), s1 = cz == 1 ? D - 2 : s0 + H;
-            float a1 = 0.f;
             int sl = s0 + l4;
-            for (; sl + 4 < s1; sl += 8) {
-                a += planepart[((int64_t)n * nslot + sl) * 9 * Cout + rem];
-                a1 += planepart[((int64_t)n * nslot + sl + 4) * 9 * Cout + rem];
+            for (; sl + 28 < s1; sl += 32) {  // eight independent loads in flight: these loops are pure latency
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = planepart[((int64_t)n * nslot + sl + 4 * k) * 9 * Cout + rem];
+                a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
             }
-            if (sl < s1) a += planepart[((int64_t)n * nslot + sl) * 9 * Cout + rem];
-            a += a1;
+            for (; sl < s1; sl += 4) a += planepart[((int64_t)n * nslot + sl) * 9 * Cout + rem];
         }
         a += __shfl_xor(a, 1, 64);
         a += __shfl_xor(a, 2, 64);
@@ -178,8 +178,16 @@ __global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __re
     for (int c0 = 0; c0 < Cout; c0 += 256) {
         const int co = c0 + e4;
         float tot = 0.f;
-        if (co < Cout)
-            for (int sp = l4; sp < Ss; sp += 4) tot += dbpart[((int64_t)n * Ss + sp) * Cout + co];
+        if (co < Cout) {
+            int sp = l4;
+            for (; sp + 28 < Ss; sp += 32) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = dbpart[((int64_t)n * Ss + sp + 4 * k) * Cout + co];
+                tot += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; sp < Ss; sp += 4) tot += dbpart[((int64_t)n * Ss + sp) * Cout + co];
+        }
         tot += __shfl_xor(tot, 1, 64);
         tot += __shfl_xor(tot, 2, 64);
         if (l4 == 0 && co < Cout) {
@@ -213,7 +221,18 @@ __global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __re
     const int ci = blockIdx.x * 32 + (threadIdx.x >> 5), l8 = threadIdx.x & 31;  // 32 lanes per input channel
     double A = 0.0, S2 = 0.0;
     if (ci < Cin) {
-        for (int j = l8; j < 27 * Cout; j += 32) {  // j = tap * Cout + co
+        int j = l8;
+        for (; j + 96 < 27 * Cout; j += 128) {  // j = tap * Cout + co; four weight loads in flight
+            float wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int jj = j + 32 * k;
+                wv[k] = w[((int64_t)(jj % Cout) * Cin + ci) * 27 + jj / Cout];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) A += (double)wv[k] * (double)T[j + 32 * k];
+        }
+        for (; j < 27 * Cout; j += 32) {
             const int tap = j / Cout, co = j % Cout;
             A += (double)w[((int64_t)co * Cin + ci) * 27 + tap] * (double)T[j];
         }
