@@ -30,6 +30,9 @@ static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
 #ifndef TEM_SC2_RD
 #define TEM_SC2_RD 3
 #endif
+#ifndef TEM_STAGE_BRANCHFREE
+#define TEM_STAGE_BRANCHFREE 1
+#endif
 #ifndef TEM_SETPRIO
 #define TEM_SETPRIO 0
 #endif
@@ -344,6 +347,30 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
             sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + chunk * BCK + c4 * 4);
         }
         float4 tmp[NIT];
+        if (TEM_STAGE_BRANCHFREE) {
+            // every halo load of this thread is issued from straight-line code (clamped address, result masked afterwards):
+            // a load + its norm FMA inside a per-element bounds branch made the ten loads wait for one another
+            bool inb[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int hv = min((tid + it * 256) >> 2, HV - 1);
+                const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+                const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
+                inb[it] = (gz >= 0) & (gz < D) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (((tid + it * 256) >> 2) < HV);
+                const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+                tmp[it] = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + cz) * H + cy) * W + cx) * x_ld +
+                                                           chunk * BCK + c4 * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                float4 v = tmp[it];
+                v.x = inb[it] ? fmaf(v.x, sc4.x, sf4.x) : 0.f;
+                v.y = inb[it] ? fmaf(v.y, sc4.y, sf4.y) : 0.f;
+                v.z = inb[it] ? fmaf(v.z, sc4.z, sf4.z) : 0.f;
+                v.w = inb[it] ? fmaf(v.w, sc4.w, sf4.w) : 0.f;
+                tmp[it] = v;
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int hv = (tid + it * 256) >> 2;
@@ -361,6 +388,7 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                 }
             }
             tmp[it] = v;
+        }
         }
         __syncthreads();
 #pragma unroll
