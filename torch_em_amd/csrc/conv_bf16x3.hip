@@ -30,6 +30,9 @@ static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
 #ifndef TEM_SC2_RD
 #define TEM_SC2_RD 3
 #endif
+#ifndef TEM_PREFETCH_HALO
+#define TEM_PREFETCH_HALO 0
+#endif
 #ifndef TEM_STAGE_BRANCHFREE
 #define TEM_STAGE_BRANCHFREE 1
 #endif
@@ -339,6 +342,20 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
 #pragma unroll
                 for (int p = 0; p < NS; ++p) bq[gp][nn][p] = wq[nn][(int64_t)chunk_begin * FR + gp * tapstride + p * 64];
     }
+#if TEM_PREFETCH_HALO
+    float4 pre[NIT];
+    bool pinb[NIT];
+#define HALO_PREFETCH(CH)                                                                                              \
+    _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                               \
+        const int hv = min((tid + it * 256) >> 2, HV - 1);                                                              \
+        const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;                              \
+        const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;                                               \
+        pinb[it] = (gz >= 0) & (gz < D) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (((tid + it * 256) >> 2) < HV);  \
+        const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);                  \
+        pre[it] = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + cz) * H + cy) * W + cx) * x_ld + (CH) * BCK + c4 * 4); \
+    }
+    HALO_PREFETCH(chunk_begin)
+#endif
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         // ---- stage: global fp32 -> fused pre-norm -> NS bf16 planes -> LDS ----
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -347,6 +364,21 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
             sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + chunk * BCK + c4 * 4);
         }
         float4 tmp[NIT];
+#if TEM_PREFETCH_HALO
+        // the raw halo loads of this chunk were issued before the previous chunk's tap loop (or before the loop for the
+        // first chunk): only the norm FMA + masking happens here
+        {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                float4 v = pre[it];
+                v.x = pinb[it] ? fmaf(v.x, sc4.x, sf4.x) : 0.f;
+                v.y = pinb[it] ? fmaf(v.y, sc4.y, sf4.y) : 0.f;
+                v.z = pinb[it] ? fmaf(v.z, sc4.z, sf4.z) : 0.f;
+                v.w = pinb[it] ? fmaf(v.w, sc4.w, sf4.w) : 0.f;
+                tmp[it] = v;
+            }
+        }
+#else
         if (TEM_STAGE_BRANCHFREE) {
             // every halo load of this thread is issued from straight-line code (clamped address, result masked afterwards):
             // a load + its norm FMA inside a per-element bounds branch made the ten loads wait for one another
@@ -390,6 +422,7 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
             tmp[it] = v;
         }
         }
+#endif
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -427,6 +460,11 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
             }
         }
         __syncthreads();
+#if TEM_PREFETCH_HALO
+        if (chunk + 1 < chunk_end) {  // the next chunk's halo flies during this chunk's 27-tap MFMA loop
+            HALO_PREFETCH(chunk + 1)
+        }
+#endif
 
         int ts = tapstride;
         asm volatile("" : "+s"(ts));
