@@ -14,8 +14,9 @@
  *     workspaces) is owned by the caller and is DEVICE memory on the current
  *     HIP device; the library allocates nothing persistent;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no
- *     implicit device synchronisation, re-entrant, no global mutable state
- *     except the thread-local last-error string;
+ *     implicit device synchronisation, re-entrant; the only global state is the
+ *     thread-local last-error string and the dispatch options of
+ *     tem_set_option() (the library never reads the environment);
  *   - return 0 on success, negative TEM_E* on failure (never throws);
  *     tem_last_error() gives the message for the calling thread;
  *   - activations are fp32, channels-last "NDHWC": element (n,z,y,x,c) of a
@@ -45,6 +46,18 @@ const char* tem_last_error(void);
 int tem_version(void);
 /* number of CUs of the current device (used by callers to size split-K). */
 int tem_device_cus(void);
+/* Dispatch options: process-wide switches between kernel variants that compute the same result (used by
+ * profiling scripts and A/B tests; the defaults are the measured-fastest choices).  No reference counterpart
+ * (the reference selects nothing: it calls ATen).  Names:
+ *   "conv_fwd_variant"   -1 auto | 0 one-patch-per-workgroup kernel | 1 ping-pong team kernel
+ *   "wgrad_zs"            1 | 0   z-sliding weight-gradient kernel (3x3x3, D >= 16)
+ *   "wgrad_zs_persist"    1 | 0   persistent column segments of that kernel
+ *   "wgrad_sums"          1 | 0   norm-backward sums taken from the weight gradient
+ *   "wgrad_sums_min_mb"   256     ... for layers whose replaced pass reads at least this many MiB
+ *   "fwd_persistent"     -1 | 0 | 1   exact-fp32 forward: persistent variant (-1: 64-column tiles only)
+ * Unknown names return TEM_EINVAL. */
+int tem_set_option(const char* name, int64_t value);
+int tem_get_option(const char* name, int64_t* value);
 
 /* ---- convolution -------------------------------------------------------
  * Replaces nn.Conv3d / nn.Conv2d as used by ConvBlock (model/unet.py:417-438),

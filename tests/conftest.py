@@ -2,7 +2,7 @@ import os
 
 # exercise the weight-gradient-derived norm sums (csrc/wgrad_sums.hip) on every layer that qualifies, not only on the
 # >= 256 MB tensors where the product path switches them on
-os.environ.setdefault("TEM_WGRAD_SUMS_MIN_MB", "0")
+os.environ.setdefault("TEM_OPT_WGRAD_SUMS_MIN_MB", "0")  # applied through tem_set_option() when the library loads
 import sys
 
 import pytest

@@ -260,7 +260,7 @@ def test_wgrad_delivers_norm_backward_sums(case):
     shift = (beta[None] - mean * rstd * gamma[None]).float().to(DEV)
     x5, g5 = to5(x.float()), to5(gout.float())
     if not ops.conv_wgrad_sums_ok(x5, k, Cin, Cout, 2):
-        pytest.skip("TEM_WGRAD_SUMS_MIN_MB / TEM_WGRAD_SUMS exclude this size (tests/conftest.py sets the threshold to 0)")
+        pytest.skip("the wgrad_sums options exclude this size (tests/conftest.py sets the threshold to 0)")
     dw = torch.empty(w.numel(), device=DEV)
     db = torch.empty(Cout, device=DEV)
     sums = ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=2,

@@ -25,6 +25,8 @@ SIGNATURES = {
     "tem_last_error": (ctypes.c_char_p, []),
     "tem_version": (c_int, []),
     "tem_device_cus": (c_int, []),
+    "tem_set_option": (c_int, [ctypes.c_char_p, c_i64]),
+    "tem_get_option": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "tem_conv_packed_size": (c_i64, [c_int] * 5),
     "tem_conv_pack_weights": (c_int, [c_vp, c_vp] + [c_int] * 7 + [c_vp]),
     "tem_conv_pack_weights_batch": (c_int, [c_vp, c_int, c_i64, c_vp]),
@@ -144,7 +146,23 @@ def load():
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib
+    # dispatch options of the library (tem_set_option) can be preset from the HOST environment as TEM_OPT_<NAME>=<int>;
+    # the library itself never reads the environment
+    for key, val in os.environ.items():
+        if key.startswith("TEM_OPT_"):
+            check(lib.tem_set_option(key[8:].lower().encode(), int(val)), key)
     return lib
+
+
+def set_option(name, value):
+    """Select a kernel variant (names: include/tem_hip.h, tem_set_option)."""
+    check(load().tem_set_option(name.encode(), int(value)), "tem_set_option")
+
+
+def get_option(name):
+    out = c_i64(0)
+    check(load().tem_get_option(name.encode(), ctypes.byref(out)), "tem_get_option")
+    return int(out.value)
 
 
 def check(rc, what=""):

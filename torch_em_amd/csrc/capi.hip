@@ -13,6 +13,50 @@ void tem_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* tem_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------
+// dispatch options: explicit, process-wide switches between kernel variants (the library never reads the
+// environment).  Plain relaxed atomics: an option is read once per launch on the calling thread.
+// ---------------------------------------------------------------------------
+struct TemOption {
+    const char* name;
+    long long def;
+};
+static const TemOption g_opt_table[TEM_OPT_COUNT] = {
+    {"wgrad_zs", 1},            // TEM_OPT_WGRAD_ZS: z-sliding weight-gradient kernel for 3x3x3, D >= 16
+    {"wgrad_zs_persist", 1},    // TEM_OPT_WGRAD_ZS_PERSIST: persistent column segments (one slab per workgroup)
+    {"wgrad_sums", 1},          // TEM_OPT_WGRAD_SUMS: norm-backward sums from the weight gradient
+    {"wgrad_sums_min_mb", 256}, // TEM_OPT_WGRAD_SUMS_MIN_MB: ... for layers whose replaced pass reads at least this much
+    {"fwd_persistent", -1},     // TEM_OPT_FWD_PERSISTENT: exact-fp32 forward, persistent variant (-1 = 64-column tiles only)
+    {"conv_fwd_variant", -1},   // TEM_OPT_CONV_FWD_VARIANT: split-precision forward/dgrad kernel (-1 auto, 0 patch kernel, 1 ping-pong)
+};
+static long long g_opt_val[TEM_OPT_COUNT];
+static bool g_opt_set[TEM_OPT_COUNT];
+
+long long tem_option(int id) {
+    if (id < 0 || id >= TEM_OPT_COUNT) return 0;
+    return __atomic_load_n(&g_opt_set[id], __ATOMIC_RELAXED) ? __atomic_load_n(&g_opt_val[id], __ATOMIC_RELAXED)
+                                                            : g_opt_table[id].def;
+}
+static int opt_find(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < TEM_OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_table[i].name)) return i;
+    return -1;
+}
+extern "C" int tem_set_option(const char* name, int64_t value) {
+    const int id = opt_find(name);
+    TEM_REQUIRE(id >= 0, "tem_set_option: unknown option '%s'", name ? name : "(null)");
+    __atomic_store_n(&g_opt_val[id], (long long)value, __ATOMIC_RELAXED);
+    __atomic_store_n(&g_opt_set[id], true, __ATOMIC_RELAXED);
+    return TEM_OK;
+}
+extern "C" int tem_get_option(const char* name, int64_t* value) {
+    const int id = opt_find(name);
+    TEM_REQUIRE(id >= 0 && value, "tem_get_option: unknown option '%s'", name ? name : "(null)");
+    *value = (int64_t)tem_option(id);
+    return TEM_OK;
+}
 extern "C" int tem_version(void) { return 100; }
 
 extern "C" int tem_device_cus(void) {

@@ -9,12 +9,7 @@
 // hi/lo happens once per staged element on the way into LDS, and once per weight at pack time.
 #include "tem_common.h"
 #include "conv_internal.h"
-#include <stdlib.h>
 
-#ifndef TEM_PP_RING9
-#define TEM_PP_RING9 1
-#endif
-static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
 #ifndef TEM_SPLIT_N
 #define TEM_SPLIT_N 1  // NR == 2 workgroups: waves tiled 2 (voxel halves) x 2 (column tiles) instead of 4 x (64 voxels, 64 columns)
 #endif
@@ -29,12 +24,6 @@ static constexpr bool ppmode_deep_ring = TEM_PP_RING9;
 #endif
 #ifndef TEM_SC2_RD
 #define TEM_SC2_RD 3
-#endif
-#ifndef TEM_PREFETCH_HALO
-#define TEM_PREFETCH_HALO 0
-#endif
-#ifndef TEM_STAGE_BRANCHFREE
-#define TEM_STAGE_BRANCHFREE 1
 #endif
 #ifndef TEM_SETPRIO
 #define TEM_SETPRIO 0
@@ -63,9 +52,6 @@ __device__ __forceinline__ float4 ld4_nt(const float* p) {
 #endif
 #ifndef TEM_NS1_WPC
 #define TEM_NS1_WPC 4  // resident workgroups per CU of the single-product (mixed precision) forward kernel
-#endif
-#ifndef TEM_ABLATE
-#define TEM_ABLATE 0  // developer ablations for profiling: 1 A reads at a fixed address, 2 no B loads, 4 no halo loads, 8 no stores, 16 no LDS writes; wgrad: 32 no global loads, 64 no LDS writes, 128 no MFMA phase
 #endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -342,20 +328,6 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
 #pragma unroll
                 for (int p = 0; p < NS; ++p) bq[gp][nn][p] = wq[nn][(int64_t)chunk_begin * FR + gp * tapstride + p * 64];
     }
-#if TEM_PREFETCH_HALO
-    float4 pre[NIT];
-    bool pinb[NIT];
-#define HALO_PREFETCH(CH)                                                                                              \
-    _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                               \
-        const int hv = min((tid + it * 256) >> 2, HV - 1);                                                              \
-        const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;                              \
-        const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;                                               \
-        pinb[it] = (gz >= 0) & (gz < D) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (((tid + it * 256) >> 2) < HV);  \
-        const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);                  \
-        pre[it] = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + cz) * H + cy) * W + cx) * x_ld + (CH) * BCK + c4 * 4); \
-    }
-    HALO_PREFETCH(chunk_begin)
-#endif
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         // ---- stage: global fp32 -> fused pre-norm -> NS bf16 planes -> LDS ----
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -364,65 +336,28 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
             sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + chunk * BCK + c4 * 4);
         }
         float4 tmp[NIT];
-#if TEM_PREFETCH_HALO
-        // the raw halo loads of this chunk were issued before the previous chunk's tap loop (or before the loop for the
-        // first chunk): only the norm FMA + masking happens here
-        {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                float4 v = pre[it];
-                v.x = pinb[it] ? fmaf(v.x, sc4.x, sf4.x) : 0.f;
-                v.y = pinb[it] ? fmaf(v.y, sc4.y, sf4.y) : 0.f;
-                v.z = pinb[it] ? fmaf(v.z, sc4.z, sf4.z) : 0.f;
-                v.w = pinb[it] ? fmaf(v.w, sc4.w, sf4.w) : 0.f;
-                tmp[it] = v;
-            }
-        }
-#else
-        if (TEM_STAGE_BRANCHFREE) {
-            // every halo load of this thread is issued from straight-line code (clamped address, result masked afterwards):
-            // a load + its norm FMA inside a per-element bounds branch made the ten loads wait for one another
-            bool inb[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int hv = min((tid + it * 256) >> 2, HV - 1);
-                const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
-                const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
-                inb[it] = (gz >= 0) & (gz < D) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (((tid + it * 256) >> 2) < HV);
-                const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-                tmp[it] = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + cz) * H + cy) * W + cx) * x_ld +
-                                                           chunk * BCK + c4 * 4);
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                float4 v = tmp[it];
-                v.x = inb[it] ? fmaf(v.x, sc4.x, sf4.x) : 0.f;
-                v.y = inb[it] ? fmaf(v.y, sc4.y, sf4.y) : 0.f;
-                v.z = inb[it] ? fmaf(v.z, sc4.z, sf4.z) : 0.f;
-                v.w = inb[it] ? fmaf(v.w, sc4.w, sf4.w) : 0.f;
-                tmp[it] = v;
-            }
-        } else {
+        // every halo load of this thread is issued from straight-line code (clamped address, result masked afterwards):
+        // a load + its norm FMA inside a per-element bounds branch made the ten loads wait for one another
+        bool inb[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int hv = (tid + it * 256) >> 2;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hv < HV) {
-                const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
-                const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
-                if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W && !(TEM_ABLATE & 4)) {
-                    v = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld +
-                                                         chunk * BCK + c4 * 4);
-                    v.x = fmaf(v.x, sc4.x, sf4.x);
-                    v.y = fmaf(v.y, sc4.y, sf4.y);
-                    v.z = fmaf(v.z, sc4.z, sf4.z);
-                    v.w = fmaf(v.w, sc4.w, sf4.w);
-                }
-            }
+            const int hv = min((tid + it * 256) >> 2, HV - 1);
+            const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+            const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
+            inb[it] = (gz >= 0) & (gz < D) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (((tid + it * 256) >> 2) < HV);
+            const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            tmp[it] = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + cz) * H + cy) * W + cx) * x_ld +
+                                                       chunk * BCK + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            float4 v = tmp[it];
+            v.x = inb[it] ? fmaf(v.x, sc4.x, sf4.x) : 0.f;
+            v.y = inb[it] ? fmaf(v.y, sc4.y, sf4.y) : 0.f;
+            v.z = inb[it] ? fmaf(v.z, sc4.z, sf4.z) : 0.f;
+            v.w = inb[it] ? fmaf(v.w, sc4.w, sf4.w) : 0.f;
             tmp[it] = v;
         }
-        }
-#endif
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -438,12 +373,7 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
-                    if (TEM_ABLATE & 2048) {  // what a pre-split (hi|lo packed) operand would cost: one v_perm per pair
-                        const unsigned sel = p == 0 ? 0x07060302u : 0x05040100u;
-                        h0 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, tmp[it].y), __builtin_bit_cast(unsigned, tmp[it].x), sel);
-                        h1 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, tmp[it].w), __builtin_bit_cast(unsigned, tmp[it].z), sel);
-                    }
-                    if (!(TEM_ABLATE & 16)) *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
                     if (p + 1 < NS) {
                         e[0] -= lo16<F16>(h0);
                         e[1] -= hi16<F16>(h0);
@@ -460,11 +390,6 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
             }
         }
         __syncthreads();
-#if TEM_PREFETCH_HALO
-        if (chunk + 1 < chunk_end) {  // the next chunk's halo flies during this chunk's 27-tap MFMA loop
-            HALO_PREFETCH(chunk + 1)
-        }
-#endif
 
         int ts = tapstride;
         asm volatile("" : "+s"(ts));
@@ -480,13 +405,13 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                     for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
                         for (int p = 0; p < NS; ++p)
-                            if (!(TEM_ABLATE & 2)) bq[gp % RD][nn][p] = wq[nn][(int64_t)chunk * FR + (int64_t)gp * ts + p * 64];
+                            bq[gp % RD][nn][p] = wq[nn][(int64_t)chunk * FR + (int64_t)gp * ts + p * 64];
                 } else if (chunk + 1 < chunk_end) {
 #pragma unroll
                     for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
                         for (int p = 0; p < NS; ++p)
-                            if (!(TEM_ABLATE & 2)) bq[gp % RD][nn][p] = wq[nn][(int64_t)(chunk + 1) * FR + (int64_t)(gp - NT) * ts + p * 64];
+                            bq[gp % RD][nn][p] = wq[nn][(int64_t)(chunk + 1) * FR + (int64_t)(gp - NT) * ts + p * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0x38F);
             } else {
@@ -500,7 +425,7 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
-                    af[m][p] = *reinterpret_cast<const uint4*>(lds + abase[m] + ((TEM_ABLATE & 1) ? 0 : toff) + p * 8);
+                    af[m][p] = *reinterpret_cast<const uint4*>(lds + abase[m] + toff + p * 8);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -559,12 +484,10 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                     if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
                     ssum[nn] += o;
                     ssq[nn] = fmaf(o, o, ssq[nn]);
-                    if (!(TEM_ABLATE & 8) || o == 12345.678f) {
-                        if (TEM_NT_STORE)
-                            __builtin_nontemporal_store(o, y + v * y_ld + co);
-                        else
-                            y[v * y_ld + co] = o;
-                    }
+                    if (TEM_NT_STORE)
+                        __builtin_nontemporal_store(o, y + v * y_ld + co);
+                    else
+                        y[v * y_ld + co] = o;
                 }
             }
         }
@@ -604,488 +527,6 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
     }
 }
 
-// ---------------------------------------------------------------------------
-// forward / dgrad, persistent + software-pipelined (the default).  Ablations of k_conv_fwd_bfsplit (2x128^3, 32->32,
-// bf16x6: 1.50 ms): without the halo loads 1.02, without the weight-fragment loads 1.19, without both 0.85, A reads at
-// a fixed LDS address 1.51 (bank conflicts are NOT the limiter).  The global-memory latencies are exposed: every
-// chunk starts with a full HBM round trip in front of a barrier, and a 2-tap weight ring is shorter than an L2 hit.
-// This variant
-//   * is persistent: gridDim = resident workgroups; a workgroup walks (unit, 16-channel chunk) steps, units dealt
-//     in contiguous per-XCD ranges (neighbouring patches share that XCD's L2);
-//   * issues the NEXT step's halo loads (raw, un-normalised, + in-bounds mask) right after the LDS tile of the
-//     current step is complete, so they fly during the 27-tap MFMA loop;
-//   * deepens the weight ring to RD = 9 taps where registers allow (32-column tiles): the ring entries of the first
-//     RD-1 taps of a step are older than that step's halo prefetch, so vmcnt never makes a weight wait queue behind
-//     halo loads until they have had RD-1 taps (>= 3K cycles) to land.
-// ---------------------------------------------------------------------------
-struct BfUnit {
-    int cot, n, ks, z0, y0, x0;
-};
-template <int TZ, int TY, int TX>
-__device__ __forceinline__ BfUnit bf_decode(int u, int ncot, int nX, int nY, int nZ, int N) {
-    BfUnit r;
-    r.cot = u % ncot; u /= ncot;
-    r.x0 = (u % nX) * TX; u /= nX;
-    r.y0 = (u % nY) * TY; u /= nY;
-    r.z0 = (u % nZ) * TZ; u /= nZ;
-    r.n = u % N;
-    r.ks = u / N;
-    return r;
-}
-
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, int RD>
-__global__ __launch_bounds__(256, (NR == 2 || NS == 3 || RD > 3) ? 2 : 3) void k_conv_fwd_bfsplit_pp(
-    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
-    const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
-    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
-    int nY, int nX, int ksplit, float* __restrict__ part, int total_units) {
-    constexpr int NT = KD * KH * KW;
-    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
-    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
-    constexpr int HV = HZ * HY * HX;
-    constexpr int NIT = (HV * 4 + 255) / 256;
-    constexpr int LSV = NS * 8 + 4;
-    constexpr int FR = NS * 64;
-    static_assert(TZ * TY * TX == 256 && NT % RD == 0 && RD >= 2 && NIT <= 32, "geometry");
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [HV][LSV]
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int kh = lane >> 5, r = lane & 31;
-    const int c4 = tid & 3;
-    const int ncot = Cout / (32 * NR);
-    const int cin16 = Cin >> 4;
-    const int spu = cin16 / ksplit;
-
-    // contiguous unit range per XCD (workgroup b runs on XCD b % 8), dealt round-robin inside the XCD
-    const int G8 = gridDim.x >> 3, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int upx = (total_units + 7) >> 3;
-    const int ubeg = xcd * upx;
-    const int uend = ubeg + upx < total_units ? ubeg + upx : total_units;
-    if (ubeg + jb >= uend) return;
-    const int my_units = (uend - ubeg - jb + G8 - 1) / G8;
-    const int nsteps = my_units * spu;
-
-    int abase[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int p = wv * 64 + m * 32 + r;
-        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-        abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;
-    }
-    const uint4* wbase = wp + lane;
-    const int64_t wtile = (int64_t)NT * cin16 * FR;
-    const int tapstride = cin16 * FR;
-
-    floatx16 acc[2][NR];
-    uint4 bq[RD][NR][NS];
-    float4 tmp[NIT];
-    float sc16[16], sf16[16];  // wave-uniform (SGPRs)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        sc16[i] = 1.f;
-        sf16[i] = 0.f;
-    }
-    unsigned inb = 0;
-    const bool has_scale = scale != nullptr;
-
-    BfUnit cur = bf_decode<TZ, TY, TX>(ubeg + jb, ncot, nX, nY, nZ, N);
-    int chunk = cur.ks * spu;
-
-    // branch-free: out-of-volume voxels load from a clamped (valid) address and are zeroed at conversion time via the
-    // `inb` mask -- divergent branches around the loads make the compiler's s_waitcnt placement conservative (vmcnt(0)
-    // in front of the tap loop), which would serialise the prefetch again.
-    auto issue_halo = [&](const BfUnit& u, int ch) {
-        // pre-norm scale/shift of the 16 channels of the chunk: wave-uniform addresses => scalar loads (lgkmcnt), which
-        // keeps them out of the in-order vmcnt queue of the halo / weight loads; the per-lane pick happens at
-        // conversion time
-        if (has_scale) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                sc16[i] = scale[(int64_t)u.n * Cin + ch * BCK + i];
-                sf16[i] = shift[(int64_t)u.n * Cin + ch * BCK + i];
-            }
-        }
-        inb = 0;
-        const float* xb = x + (int64_t)u.n * D * H * W * x_ld + ch * BCK + c4 * 4;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            int hv = (tid + it * 256) >> 2;
-            hv = hv < HV ? hv : HV - 1;
-            const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
-            const int gz = u.z0 + hz - PZ, gy = u.y0 + hy - PY, gx = u.x0 + hx - PX;
-            // bitwise, not &&: short-circuit evaluation becomes exec-masked branches around the loads
-            const int ok = (int)(gz >= 0) & (int)(gz < D) & (int)(gy >= 0) & (int)(gy < H) & (int)(gx >= 0) & (int)(gx < W);
-            const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            tmp[it] = *reinterpret_cast<const float4*>(xb + (((int64_t)cz * H + cy) * W + cx) * x_ld);
-            inb |= (unsigned)ok << it;
-        }
-    };
-
-    // ring entries of the first RD-1 taps of step 0 (older than the first halo loads)
-#pragma unroll
-    for (int gp = 0; gp < RD - 1; ++gp)
-#pragma unroll
-        for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-            for (int p = 0; p < NS; ++p)
-                bq[gp][nn][p] = wbase[(int64_t)(cur.cot * NR + nn) * wtile + (int64_t)gp * tapstride + chunk * FR + p * 64];
-    issue_halo(cur, chunk);
-
-    for (int s = 0; s < nsteps; ++s) {
-        const bool first = (s % spu) == 0, last = (s % spu) == spu - 1;
-        const int s1 = s + 1;
-        const bool has_next = s1 < nsteps;
-        BfUnit nxt = cur;
-        if (last && has_next) nxt = bf_decode<TZ, TY, TX>(ubeg + jb + (s1 / spu) * G8, ncot, nX, nY, nZ, N);
-        const int chunk1 = nxt.ks * spu + s1 % spu;
-        if (first) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
-        }
-        __syncthreads();  // every wave is done reading the previous step's tile
-        float4 scs, sfs;
-        {
-            float a[4], b[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a[j] = c4 == 0 ? sc16[j] : (c4 == 1 ? sc16[4 + j] : (c4 == 2 ? sc16[8 + j] : sc16[12 + j]));
-                b[j] = c4 == 0 ? sf16[j] : (c4 == 1 ? sf16[4 + j] : (c4 == 2 ? sf16[8 + j] : sf16[12 + j]));
-            }
-            scs = make_float4(a[0], a[1], a[2], a[3]);
-            sfs = make_float4(b[0], b[1], b[2], b[3]);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int hv = (tid + it * 256) >> 2;
-            if (hv < HV) {
-                const bool ok = inb & (1u << it);  // zero padding is applied AFTER the fused pre-norm
-                float e[4] = {ok ? fmaf(tmp[it].x, scs.x, sfs.x) : 0.f, ok ? fmaf(tmp[it].y, scs.y, sfs.y) : 0.f,
-                              ok ? fmaf(tmp[it].z, scs.z, sfs.z) : 0.f, ok ? fmaf(tmp[it].w, scs.w, sfs.w) : 0.f};
-#pragma unroll
-                for (int p = 0; p < NS; ++p) {
-                    const unsigned h0 = pk_bf16(e[0], e[1]), h1 = pk_bf16(e[2], e[3]);
-                    *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
-                    if (p + 1 < NS) {
-                        e[0] -= __builtin_bit_cast(float, h0 << 16);
-                        e[1] -= __builtin_bit_cast(float, h0 & 0xffff0000u);
-                        e[2] -= __builtin_bit_cast(float, h1 << 16);
-                        e[3] -= __builtin_bit_cast(float, h1 & 0xffff0000u);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (has_next) issue_halo(nxt, chunk1);  // flies during the tap loop below
-        __builtin_amdgcn_sched_barrier(0);
-
-        int ts = tapstride;
-        asm volatile("" : "+s"(ts));
-        const int64_t wo_c = (int64_t)(cur.cot * NR) * wtile + (int64_t)chunk * FR;
-        const int64_t wo_n = (int64_t)(nxt.cot * NR) * wtile + (int64_t)chunk1 * FR;
-#pragma unroll
-        for (int tap = 0; tap < NT; ++tap) {
-            const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
-            const int toff = ((tz * HY + ty) * HX + tx) * LSV;
-            {
-                const int gp = tap + RD - 1;
-                if (gp < NT) {
-#pragma unroll
-                    for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-                        for (int p = 0; p < NS; ++p)
-                            bq[gp % RD][nn][p] = wbase[wo_c + nn * wtile + (int64_t)gp * ts + p * 64];
-                } else if (has_next) {
-#pragma unroll
-                    for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-                        for (int p = 0; p < NS; ++p)
-                            bq[gp % RD][nn][p] = wbase[wo_n + nn * wtile + (int64_t)(gp - NT) * ts + p * 64];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            bf16x8 af[2][NS];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int p = 0; p < NS; ++p)
-                    af[m][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + abase[m] + toff + p * 8));
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nn = 0; nn < NR; ++nn) {
-#pragma unroll
-                    for (int sum = NS - 1; sum >= 0; --sum)
-#pragma unroll
-                        for (int i = 0; i <= sum; ++i) {
-                            const int j = sum - i;
-                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                af[m][i], __builtin_bit_cast(bf16x8, bq[tap % RD][nn][j]), acc[m][nn], 0, 0, 0);
-                        }
-                }
-        }
-        if (last) {
-#pragma unroll
-            for (int nn = 0; nn < NR; ++nn) {
-                const int co = (cur.cot * NR + nn) * 32 + r;
-                const float bv = bias ? bias[co] : 0.f;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                        const int p = wv * 64 + m * 32 + row;
-                        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-                        const int gz = cur.z0 + pz, gy = cur.y0 + py, gx = cur.x0 + px;
-                        if (gz < D && gy < H && gx < W) {
-                            const int64_t v = (((int64_t)cur.n * D + gz) * H + gy) * W + gx;
-                            if (ksplit > 1) {
-                                part[((int64_t)cur.ks * N * D * H * W + v) * Cout + co] = acc[m][nn][reg];
-                            } else {
-                                float o = act_apply_b(acc[m][nn][reg] + bv, act);
-                                if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
-                                y[v * y_ld + co] = o;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        cur = nxt;
-        chunk = chunk1;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// forward / dgrad, wave-specialised: NL loader waves + 4 MFMA waves per workgroup, one workgroup per CU,
-// double-buffered LDS tile.  PMC on k_conv_fwd_bfsplit: the resident waves spend ~50 % of their time in
-// s_waitcnt / s_barrier (halo loads -> conversion -> LDS write -> barrier in front of every chunk) and the
-// matrix pipe is 33-56 % busy.  Here the loader waves own that whole chain for step s+1 (fp32 halo loads,
-// fused pre-norm, split into NS bf16 planes, LDS writes into the other buffer) while the MFMA waves run step s;
-// the MFMA waves' only VMEM traffic is the weight-fragment ring, so its counted vmcnt waits never queue behind
-// halo loads, and there is ONE barrier per (patch, Cout tile, 16-channel chunk) step.
-// ---------------------------------------------------------------------------
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, int NL>
-__global__ __launch_bounds__((4 + NL) * 64, 1) void k_conv_fwd_bfsplit_lc(
-    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
-    const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
-    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
-    int nY, int nX, int ksplit, float* __restrict__ part, int total_units) {
-    constexpr int NT = KD * KH * KW;
-    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
-    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
-    constexpr int HV = HZ * HY * HX;
-    constexpr int RD = 3;
-    constexpr int LSV = NS * 8 + 4;
-    constexpr int LTH = NL * 64;
-    constexpr int LIT = (HV * 4 + LTH - 1) / LTH;
-    constexpr int FR = NS * 64;
-    static_assert(TZ * TY * TX == 256 && NT % RD == 0, "geometry");
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][HV][LSV]
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ncot = Cout / (32 * NR);
-    const int cin16 = Cin >> 4;
-    const int spu = cin16 / ksplit;  // steps (16-channel chunks) per unit
-    const int unit0 = blockIdx.x;
-    if (unit0 >= total_units) return;
-    const int my_units = (total_units - 1 - unit0) / gridDim.x + 1;
-    const int nsteps = my_units * spu;
-    const int pvol = nX * nY * nZ;
-
-    if (wv >= 4) {
-        // ================= loader waves =================
-        const int ltid = tid - 256;
-        const int c4 = ltid & 3;
-        for (int s = 0; s < nsteps; ++s) {
-            const int u = unit0 + (s / spu) * gridDim.x;
-            int b = u / ncot;
-            const int x0 = (b % nX) * TX; b /= nX;
-            const int y0 = (b % nY) * TY; b /= nY;
-            const int z0 = (b % nZ) * TZ; b /= nZ;
-            const int n = b % N;
-            const int c16 = (b / N) * spu + s % spu;
-            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (scale) {
-                sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + c16 * 16 + c4 * 4);
-                sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + c16 * 16 + c4 * 4);
-            }
-            float4 t[LIT];
-            unsigned inb = 0;
-#pragma unroll
-            for (int it = 0; it < LIT; ++it) {
-                const int hv = (ltid + it * LTH) >> 2;
-                t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (hv < HV) {
-                    const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
-                    const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
-                    if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                        t[it] = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld +
-                                                                 c16 * 16 + c4 * 4);
-                        inb |= 1u << it;
-                    }
-                }
-            }
-            float* buf = lds + (s & 1) * (HV * LSV);
-#pragma unroll
-            for (int it = 0; it < LIT; ++it) {
-                const int hv = (ltid + it * LTH) >> 2;
-                if (hv < HV) {
-                    float e[4] = {t[it].x, t[it].y, t[it].z, t[it].w};
-                    if (inb & (1u << it)) {
-                        e[0] = fmaf(e[0], sc4.x, sf4.x);
-                        e[1] = fmaf(e[1], sc4.y, sf4.y);
-                        e[2] = fmaf(e[2], sc4.z, sf4.z);
-                        e[3] = fmaf(e[3], sc4.w, sf4.w);
-                    }
-#pragma unroll
-                    for (int p = 0; p < NS; ++p) {
-                        const unsigned h0 = pk_bf16(e[0], e[1]), h1 = pk_bf16(e[2], e[3]);
-                        *reinterpret_cast<uint2*>(buf + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
-                        if (p + 1 < NS) {
-                            e[0] -= __builtin_bit_cast(float, h0 << 16);
-                            e[1] -= __builtin_bit_cast(float, h0 & 0xffff0000u);
-                            e[2] -= __builtin_bit_cast(float, h1 << 16);
-                            e[3] -= __builtin_bit_cast(float, h1 & 0xffff0000u);
-                        }
-                    }
-                }
-            }
-            __syncthreads();  // tile s complete; consumers are done with the buffer tile s+1 will use
-        }
-        return;
-    }
-
-    // ================= MFMA waves =================
-    const int kh = lane >> 5, r = lane & 31;
-    int abase[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int p = wv * 64 + m * 32 + r;
-        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-        abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;
-    }
-    const uint4* wbase = wp + lane;
-    const int64_t wtile = (int64_t)NT * cin16 * FR;  // uint4s per 32-column tile
-    const int tapstride = cin16 * FR;
-
-    floatx16 acc[2][NR];
-    uint4 bq[RD][NR][NS];
-    {
-        const int cot0 = unit0 % ncot;
-        const int c160 = ((unit0 / ncot) / pvol / N) * spu;
-#pragma unroll
-        for (int gp = 0; gp < RD - 1; ++gp)
-#pragma unroll
-            for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-                for (int p = 0; p < NS; ++p)
-                    bq[gp][nn][p] = wbase[(int64_t)(cot0 * NR + nn) * wtile + (int64_t)gp * tapstride + c160 * FR + p * 64];
-    }
-    for (int s = 0; s < nsteps; ++s) {
-        const int u = unit0 + (s / spu) * gridDim.x;
-        const int cot = u % ncot;
-        const int ksl = (u / ncot) / pvol / N;
-        const int c16 = ksl * spu + s % spu;
-        const bool first = (s % spu) == 0, last = (s % spu) == spu - 1;
-        const int s1 = s + 1;
-        const int u1 = unit0 + (s1 / spu) * gridDim.x;
-        const int cot1 = u1 % ncot;
-        const int c161 = ((u1 / ncot) / pvol / N) * spu + s1 % spu;
-        const bool has_next = s1 < nsteps;
-        if (first) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
-        }
-        __syncthreads();  // tile s has landed
-        const float* buf = lds + (s & 1) * (HV * LSV);
-        int ts = tapstride;
-        asm volatile("" : "+s"(ts));
-        const int64_t wo_c = (int64_t)(cot * NR) * wtile + (int64_t)c16 * FR;
-        const int64_t wo_n = (int64_t)(cot1 * NR) * wtile + (int64_t)c161 * FR;
-#pragma unroll
-        for (int tap = 0; tap < NT; ++tap) {
-            const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
-            const int toff = ((tz * HY + ty) * HX + tx) * LSV;
-            {
-                const int gp = tap + RD - 1;
-                if (gp < NT) {
-#pragma unroll
-                    for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-                        for (int p = 0; p < NS; ++p)
-                            bq[gp % RD][nn][p] = wbase[wo_c + nn * wtile + (int64_t)gp * ts + p * 64];
-                } else if (has_next) {
-#pragma unroll
-                    for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-                        for (int p = 0; p < NS; ++p)
-                            bq[gp % RD][nn][p] = wbase[wo_n + nn * wtile + (int64_t)(gp - NT) * ts + p * 64];
-                }
-                __builtin_amdgcn_sched_barrier(0x38F);
-            }
-            bf16x8 af[2][NS];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int p = 0; p < NS; ++p)
-                    af[m][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + abase[m] + toff + p * 8));
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nn = 0; nn < NR; ++nn) {
-#pragma unroll
-                    for (int sum = NS - 1; sum >= 0; --sum)
-#pragma unroll
-                        for (int i = 0; i <= sum; ++i) {
-                            const int j = sum - i;
-                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                af[m][i], __builtin_bit_cast(bf16x8, bq[tap % RD][nn][j]), acc[m][nn], 0, 0, 0);
-                        }
-                }
-        }
-        if (last) {
-            int b = u / ncot;
-            const int x0 = (b % nX) * TX; b /= nX;
-            const int y0 = (b % nY) * TY; b /= nY;
-            const int z0 = (b % nZ) * TZ; b /= nZ;
-            const int n = b % N;
-#pragma unroll
-            for (int nn = 0; nn < NR; ++nn) {
-                const int co = (cot * NR + nn) * 32 + r;
-                const float bv = bias ? bias[co] : 0.f;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                        const int p = wv * 64 + m * 32 + row;
-                        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-                        const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
-                        if (gz < D && gy < H && gx < W) {
-                            const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
-                            if (ksplit > 1) {
-                                part[((int64_t)ksl * N * D * H * W + v) * Cout + co] = acc[m][nn][reg];
-                            } else {
-                                float o = act_apply_b(acc[m][nn][reg] + bv, act);
-                                if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
-                                y[v * y_ld + co] = o;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
 template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false>
 static void launch_b(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
@@ -1094,67 +535,6 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     const int nZ = (D + TZ - 1) / TZ, nY = (H + TY - 1) / TY, nX = (W + TX - 1) / TX;
     const int64_t nblk = (int64_t)N * nZ * nY * nX * (Cout / (32 * NR)) * ksplit;
     constexpr size_t ldsb = (size_t)HV * (NS * 8 + 4) * sizeof(float);
-    // measured slower than the 2-workgroups/CU kernel below (1 MFMA wave per SIMD cannot hide its own LDS-read
-    // latency: 32->32 128^3 bf16x3 1.47 ms vs 1.00 ms); kept as an experiment switch, off by default
-    // measured equal to the plain kernel below (the limiter is not load latency): off by default
-    static const int ppmode = getenv("TEM_SPLIT_PP") ? atoi(getenv("TEM_SPLIT_PP")) : 0;
-    if constexpr ((KD * KH * KW) % 3 == 0 && !F16) {
-        if (ppmode && !stat) {
-            constexpr int RD = (NR == 1 && NS == 2 && (KD * KH * KW) % 9 == 0 && ppmode_deep_ring) ? 9 : 3;  // NS == 3 would spill
-            constexpr int WPC = (NR == 2 || NS == 3 || RD > 3) ? 2 : 3;  // resident workgroups per CU (LDS / launch bounds)
-            static bool attrp = false;
-            if (!attrp && ldsb > 64 * 1024) {
-                (void)hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(&k_conv_fwd_bfsplit_pp<KD, KH, KW, TZ, TY, TX, NR, NS, RD>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-                attrp = true;
-            }
-            static int ncu = 0;
-            if (!ncu) {
-                ncu = tem_device_cus();
-                if (ncu <= 0) ncu = 256;
-            }
-            const int64_t upx = (nblk + 7) / 8;
-            int64_t g8 = (int64_t)WPC * ncu / 8;
-            if (g8 > upx) g8 = upx;
-            hipLaunchKernelGGL((k_conv_fwd_bfsplit_pp<KD, KH, KW, TZ, TY, TX, NR, NS, RD>), dim3((unsigned)(g8 * 8)),
-                               dim3(256), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp), bias, y, y_ld,
-                               ref, ref_ld, N, D, H, W, Cin, Cout, act, nZ, nY, nX, ksplit, part, (int)nblk);
-            if (ksplit > 1) {
-                const int64_t NV = (int64_t)N * D * H * W;
-                tem_splitk_epilogue(part, ksplit, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
-            }
-            return;
-        }
-    }
-    static const int lcmode = getenv("TEM_SPLIT_LC") ? atoi(getenv("TEM_SPLIT_LC")) : 0;
-    if constexpr ((KD * KH * KW) % 3 == 0 && !F16) {
-        if (lcmode && !stat) {
-            constexpr int NL = 2;
-            constexpr size_t lds2 = 2 * ldsb;
-            static_assert(lds2 <= 160 * 1024, "LDS budget");
-            static bool attr2 = false;
-            if (!attr2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit_lc<KD, KH, KW, TZ, TY, TX, NR, NS, NL>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                attr2 = true;
-            }
-            static int ncu = 0;
-            if (!ncu) {
-                ncu = tem_device_cus();
-                if (ncu <= 0) ncu = 256;
-            }
-            const int64_t grid = nblk < ncu ? nblk : ncu;
-            hipLaunchKernelGGL((k_conv_fwd_bfsplit_lc<KD, KH, KW, TZ, TY, TX, NR, NS, NL>), dim3((unsigned)grid),
-                               dim3((4 + NL) * 64), lds2, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp), bias,
-                               y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, nZ, nY, nX, ksplit, part, (int)nblk);
-            if (ksplit > 1) {
-                const int64_t NV = (int64_t)N * D * H * W;
-                tem_splitk_epilogue(part, ksplit, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
-            }
-            return;
-        }
-    }
     static bool attr_done = false;
     if (!attr_done && ldsb > 64 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16>),
@@ -1380,7 +760,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
             if (rp < ROWS * XPAIRS) {                                                                              \
                 const int row = rp / XPAIRS, pr = rp % XPAIRS;                                                     \
                 const int gz = z0_ + row / HY - PZ, gy = y0_ + row % HY - PY, gx = x0_ + 2 * pr - PX;              \
-                if (gz >= 0 && gz < D && gy >= 0 && gy < H && !(TEM_ABLATE & 32)) {                                \
+                if (gz >= 0 && gz < D && gy >= 0 && gy < H) {                                \
                     const float* rowp = x + (((int64_t)n_ * D + gz) * H + gy) * W * x_ld + cit * 32 + xcq * 4;     \
                     if (gx >= 0 && gx < W) { xa[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * x_ld); inbA |= 1u << it; } \
                     if (gx + 1 >= 0 && gx + 1 < W) { xb[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * x_ld); inbB |= 1u << it; } \
@@ -1394,7 +774,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
             const int gz = z0_ + prow / PTY, gy = y0_ + prow % PTY, gx = x0_ + 2 * pr;                             \
             ga[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
             gb[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
-            if (gz < D && gy < H && cq < nco_here * 8 && !(TEM_ABLATE & 32)) {                                     \
+            if (gz < D && gy < H && cq < nco_here * 8) {                                     \
                 const float* rowp = g + (((int64_t)n_ * D + gz) * H + gy) * W * g_ld + cog * NCO * 32 + cq * 4;    \
                 if (gx < W) ga[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * g_ld);                  \
                 if (gx + 1 < W) gb[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * g_ld);        \
@@ -1421,10 +801,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
                     unsigned hi, lo;
                     split2(va, vb, hi, lo);
                     const int off = (xcq * 4 + c) * CIS + row * 32 + pr * 4;
-                    if (!(TEM_ABLATE & 64)) {
-                        *reinterpret_cast<unsigned*>(Xh + off) = hi;
-                        *reinterpret_cast<unsigned*>(Xl + off) = lo;
-                    }
+                    *reinterpret_cast<unsigned*>(Xh + off) = hi;
+                    *reinterpret_cast<unsigned*>(Xl + off) = lo;
                 }
             }
         }
@@ -1439,10 +817,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
                 unsigned hi, lo;
                 split2(a[c], b[c], hi, lo);
                 const int off = (cq * 4 + c) * WB_GS + (prow * 8 + pr * 2) * 2;
-                if (!(TEM_ABLATE & 64)) {
-                    *reinterpret_cast<unsigned*>(Gh + off) = hi;
-                    *reinterpret_cast<unsigned*>(Gl + off) = lo;
-                }
+                *reinterpret_cast<unsigned*>(Gh + off) = hi;
+                *reinterpret_cast<unsigned*>(Gl + off) = lo;
                 dbacc[it][c] += a[c] + b[c];
             }
         }
@@ -1453,7 +829,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
         // unit 0 and drops it in the epilogue), so hipcc can hoist the ds_reads of the next (unit, slab) above the
         // MFMAs of the current one.  Per (unit, slab): 6 LDS reads + 8 v_alignbyte feed 9 MFMAs. ----
 #pragma unroll
-        for (int i = 0; i < ((TEM_ABLATE & 128) ? 0 : MAXU); ++i) {
+        for (int i = 0; i < MAXU; ++i) {
 #pragma unroll 2
             for (int sl = 0; sl < SPU; ++sl) {
                 const int prow = 2 * (uhalf[i] * SPU + sl) + kh;  // this lane half's patch row
@@ -1641,7 +1017,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
     // iteration t: MFMA over plane t (if t >= za); store the pending registers (x plane t+2, g plane t+1); load the
     // next pending set (x plane t+3, g plane t+2); barrier.
     for (int t = za - 4; t < zb; ++t) {
-        if (t >= za && !(TEM_ABLATE & 256)) {
+        if (t >= za) {
             const unsigned char* Gh = Gb + (t & 1) * 2 * GPL;
             const unsigned char* Gl = Gh + GPL;
             int slot[3];
@@ -1701,7 +1077,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             }
         }
         // ---- pending registers -> LDS: x plane t+2 into its ring slot, g plane t+1 into buffer (t+1)&1 ----
-        if (t >= za - 3 && xit && !(TEM_ABLATE & 512)) {
+        if (t >= za - 3 && xit) {
             const int sl = ((t + 2 + 4) & 3) * ZS_PLB;
             const float a[4] = {xa.x, xa.y, xa.z, xa.w}, b[4] = {xb.x, xb.y, xb.z, xb.w};
             const float s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, f4[4] = {sf4.x, sf4.y, sf4.z, sf4.w};
@@ -1720,7 +1096,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                 }
             }
         }
-        if (t + 1 >= za && t + 1 < zb && git && !(TEM_ABLATE & 512)) {
+        if (t + 1 >= za && t + 1 < zb && git) {
             unsigned char* Gh = Gb + ((t + 1) & 1) * 2 * GPL;
             unsigned char* Gl = Gh + GPL;
             const float a[4] = {ga.x, ga.y, ga.z, ga.w}, b[4] = {gb.x, gb.y, gb.z, gb.w};
@@ -1744,7 +1120,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             xa = make_float4(0.f, 0.f, 0.f, 0.f);
             xb = xa;
             inA = inB = false;
-            if (xit && zx >= za - 1 && zx <= zb && zx >= 0 && zx < D && !(TEM_ABLATE & 1024)) {
+            if (xit && zx >= za - 1 && zx <= zb && zx >= 0 && zx < D) {
                 const int gy = y0 + xrow - 1, gx = x0 + 2 * xpr - 1;
                 if (gy >= 0 && gy < H) {
                     const float* rowp = x + (((int64_t)n * D + zx) * H + gy) * W * x_ld + cit * 32 + xcq * 4;
@@ -1761,7 +1137,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             const int zg = t + 2;
             ga = make_float4(0.f, 0.f, 0.f, 0.f);
             gb = ga;
-            if (git && zg >= za && zg < zb && !(TEM_ABLATE & 1024)) {
+            if (git && zg >= za && zg < zb) {
                 const int gy = y0 + gprow, gx = x0 + 2 * gpr;
                 if (gy < H && gcq * 4 < Cout - cog * GC) {
                     const float* rowp = g + (((int64_t)n * D + zg) * H + gy) * W * g_ld + cog * GC + gcq * 4;
@@ -1816,7 +1192,7 @@ struct ZsPlan {
 };
 static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     ZsPlan p;
-    static const int enable = getenv("TEM_WGRAD_ZS") ? atoi(getenv("TEM_WGRAD_ZS")) : 1;
+    const int enable = (int)tem_option(TEM_OPT_WGRAD_ZS);
     p.use = enable && kd == 3 && kh == 3 && kw == 3 && D >= 16;
     const int ncot = Cout / 32;
     p.nco = ncot >= 2 ? 2 : 1;
@@ -1831,7 +1207,7 @@ static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int
     p.ncz = p.nY * p.nX * zs;  // column segments per sample
     // persistent over column segments: q segments per workgroup, T * S workgroups ~ one per CU; a workgroup stays
     // inside one sample (Ss slabs per sample, S = N * Ss)
-    static const int persist = getenv("TEM_WGRAD_ZS_PERSIST") ? atoi(getenv("TEM_WGRAD_ZS_PERSIST")) : 1;
+    const int persist = (int)tem_option(TEM_OPT_WGRAD_ZS_PERSIST);
     const int64_t q = persist ? ((int64_t)N * p.ncz * p.T + 255) / 256 : 1;
     p.Ss = (int)((p.ncz + q - 1) / q);
     p.S = N * p.Ss;
@@ -1872,12 +1248,12 @@ static WbPlan wb_plan(int N, int D, int H, int W, int Cin, int Cout, int ntaps) 
 // Can this weight gradient also deliver the norm-backward sums (wgrad_sums.hip)?  z-sliding kernel, a few samples,
 // widths whose [27][Cout] tables fit a block's LDS
 int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
-    static const int enable = getenv("TEM_WGRAD_SUMS") ? atoi(getenv("TEM_WGRAD_SUMS")) : 1;
+    const int enable = (int)tem_option(TEM_OPT_WGRAD_SUMS);
     if (!enable || Cin % 32 || Cout % 32) return 0;
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
     const int cq = Cout / 4;
     // four small launches replace one pass over gz and x: only worth it where that pass is long (>= 256 MB tensors)
-    static const int64_t min_bytes = getenv("TEM_WGRAD_SUMS_MIN_MB") ? atoll(getenv("TEM_WGRAD_SUMS_MIN_MB")) << 20 : 256ll << 20;
+    const int64_t min_bytes = (int64_t)tem_option(TEM_OPT_WGRAD_SUMS_MIN_MB) << 20;
     const int64_t bytes = (int64_t)N * D * H * W * Cin * 4;
     return z.use && N <= 4 && Cout <= 128 && Cin <= 256 && (cq & (cq - 1)) == 0 && H >= 3 && W >= 3 && D >= 3 &&
            bytes >= min_bytes;

@@ -21,13 +21,9 @@
 //   merged by a deterministic fp64 reduction (no atomics).
 #include "tem_common.h"
 #include "conv_internal.h"
-#include <stdlib.h>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-#ifndef TEM_ABLATE
-#define TEM_ABLATE 0   // developer ablations for profiling: 1 no A reads, 2 no B loads, 4 no staging loads, 8 no stores
-#endif
 #define CK 16      // input channels per staged chunk (fwd)
 #define LSF 20     // LDS floats per halo voxel (16 + 4 pad -> 80 B, keeps b128 alignment)
 
@@ -120,7 +116,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? 2 : 3)) void k_co
             const int item = tid + it * NTH;
             const int hv = item >> 2;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hv < HV && !(TEM_ABLATE & 4)) {
+            if (hv < HV) {
                 const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
                 const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
                 if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
@@ -157,8 +153,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? 2 : 3)) void k_co
             const int toff = ((tz * HY + ty) * HX + tx) * LSF;
             {   // prefetch
                 const int gp = g + RD - 1;
-                if (TEM_ABLATE & 2) {
-                } else if (gp < NG) {
+                if (gp < NG) {
 #pragma unroll
                     for (int nn = 0; nn < NR; ++nn)
                         bq[gp % RD][nn] = wq[nn][(int64_t)chunk * 128 + (gp >> 1) * ts + (gp & 1) * 64];
@@ -172,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? 2 : 3)) void k_co
             float4 a[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-                a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + ((TEM_ABLATE & 1) ? 0 : toff + kg * 8));
+                a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff + kg * 8);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -207,7 +202,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? 2 : 3)) void k_co
                     }
                     float o = act_apply(acc[m][nn][reg] + bv, act);
                     if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
-                    if (!(TEM_ABLATE & 8) || o == 12345.678f) y[v * y_ld + co] = o;
+                    y[v * y_ld + co] = o;
                 }
             }
         }
@@ -438,210 +433,6 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_conv_fwd_mfma_p(
 #undef LOAD_HALO
 }
 
-// ---------------------------------------------------------------------------
-// forward / dgrad, loader/consumer variant (3x3x3 and 1x3x3 kernels).
-// PMC on the kernels above: matrix pipe 76% busy at 2.08 GHz.  Every workgroup of the chip stages its
-// halo tile at the same moment (identical work => lockstep), so HBM sees bursts it needs ~7 us to
-// serve while all MFMA pipes wait, then idles while they compute.  Here a 5th wave per workgroup
-// does nothing but fetch: it loads the halo tile of step s+1 (8 input channels, possibly the next
-// patch) and writes it -- fused pre-norm applied -- into the other half of a double-buffered LDS
-// tile while waves 0-3 run the MFMAs of step s.  One barrier per step; the consumers' only VMEM
-// traffic is the weight-fragment ring, so its counted vmcnt waits never queue behind halo loads.
-// ---------------------------------------------------------------------------
-#define LC_CK 8
-#define LC_LS 12  // LDS floats per halo voxel: 8 channels + 4 pad (48 B: 16-B aligned, odd multiple of 16 B)
-
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR>
-__global__ __launch_bounds__(320, 2) void k_conv_fwd_mfma_lc(
-    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
-    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
-    int nY, int nX, int ksplit, float* __restrict__ part, int total_units) {
-    constexpr int NT = KD * KH * KW;
-    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
-    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
-    constexpr int HV = HZ * HY * HX;
-    constexpr int RD = 3;                       // weight-fragment ring depth (NT % 3 == 0)
-    constexpr int LIT = (HV * 2 + 63) / 64;     // 16-byte staging items per loader lane
-    static_assert(TZ * TY * TX == 256 && NT % RD == 0, "geometry");
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][HV][LC_LS]
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ncot = Cout / (32 * NR);
-    const int cin8 = Cin >> 3;
-    const int spu = cin8 / ksplit;  // steps (8-channel chunks) per unit
-
-    int unit = blockIdx.x;
-    if (unit >= total_units) return;
-    // number of steps this workgroup will run (same on every wave)
-    const int my_units = (total_units - 1 - unit) / gridDim.x + 1;
-    const int nsteps = my_units * spu;
-
-    if (wv == 4) {
-        // ================= loader wave =================
-        const int c2 = lane & 1;  // which 16-byte half of the 8-channel row
-        for (int s = 0; s < nsteps; ++s) {
-            const int u = unit + (s / spu) * gridDim.x;
-            int b = u / ncot;
-            const int x0 = (b % nX) * TX; b /= nX;
-            const int y0 = (b % nY) * TY; b /= nY;
-            const int z0 = (b % nZ) * TZ; b /= nZ;
-            const int n = b % N;
-            const int c8 = (b / N) * spu + s % spu;
-            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (scale) {
-                sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + c8 * 8 + c2 * 4);
-                sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + c8 * 8 + c2 * 4);
-            }
-            float4 t[LIT];
-            unsigned long long inb = 0;
-#pragma unroll
-            for (int it = 0; it < LIT; ++it) {
-                const int hv = (lane + it * 64) >> 1;
-                t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (hv < HV) {
-                    const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
-                    const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
-                    if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                        t[it] = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld +
-                                                                 c8 * 8 + c2 * 4);
-                        inb |= 1ull << it;
-                    }
-                }
-            }
-            float* buf = lds + (s & 1) * (HV * LC_LS);
-#pragma unroll
-            for (int it = 0; it < LIT; ++it) {
-                const int hv = (lane + it * 64) >> 1;
-                if (hv < HV) {
-                    float4 v = t[it];
-                    if (inb & (1ull << it)) {
-                        v.x = fmaf(v.x, sc4.x, sf4.x);
-                        v.y = fmaf(v.y, sc4.y, sf4.y);
-                        v.z = fmaf(v.z, sc4.z, sf4.z);
-                        v.w = fmaf(v.w, sc4.w, sf4.w);
-                    }
-                    *reinterpret_cast<float4*>(buf + hv * LC_LS + c2 * 4) = v;
-                }
-            }
-            __syncthreads();  // tile s is complete; the consumers are done with the buffer tile s+1 will use
-        }
-        return;
-    }
-
-    // ================= consumer waves (MFMA) =================
-    const int kh = lane >> 5, r = lane & 31;
-    int abase[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int p = wv * 64 + m * 32 + r;
-        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-        abase[m] = ((pz * HY + py) * HX + px) * LC_LS + kh * 4;
-    }
-    const float4* wbase = reinterpret_cast<const float4*>(wp) + lane;
-    const int64_t wtile = (int64_t)NT * cin8 * 64;  // float4s per 32-column tile
-    const int tapstride = cin8 * 64;
-
-    floatx16 acc[2][NR];
-    float4 bq[RD][NR];
-    {   // ring heads of step 0
-        const int cot0 = unit % ncot;
-        const int c80 = ((unit / ncot) / (nX * nY * nZ) / N) * spu;
-#pragma unroll
-        for (int gp = 0; gp < RD - 1; ++gp)
-#pragma unroll
-            for (int nn = 0; nn < NR; ++nn)
-                bq[gp][nn] = wbase[(int64_t)(cot0 * NR + nn) * wtile + (int64_t)gp * tapstride + c80 * 64];
-    }
-    for (int s = 0; s < nsteps; ++s) {
-        const int u = unit + (s / spu) * gridDim.x;
-        const int cot = u % ncot;
-        const int ksl = (u / ncot) / (nX * nY * nZ) / N;
-        const int c8 = ksl * spu + s % spu;
-        const bool first = (s % spu) == 0, last = (s % spu) == spu - 1;
-        // descriptor of the step after this one (for the ring heads)
-        const int s1 = s + 1;
-        const int u1 = unit + (s1 / spu) * gridDim.x;
-        const int cot1 = u1 % ncot;
-        const int c81 = ((u1 / ncot) / (nX * nY * nZ) / N) * spu + s1 % spu;
-        const bool has_next = s1 < nsteps;
-        if (first) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
-        }
-        __syncthreads();  // tile s has landed
-        const float* buf = lds + (s & 1) * (HV * LC_LS);
-        int ts = tapstride;
-        asm volatile("" : "+s"(ts));
-        const int64_t wo_c = (int64_t)(cot * NR) * wtile + c8 * 64;
-        const int64_t wo_n = (int64_t)(cot1 * NR) * wtile + c81 * 64;
-#pragma unroll
-        for (int tap = 0; tap < NT; ++tap) {
-            const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
-            const int toff = ((tz * HY + ty) * HX + tx) * LC_LS;
-            {
-                const int gp = tap + RD - 1;
-                if (gp < NT) {
-#pragma unroll
-                    for (int nn = 0; nn < NR; ++nn) bq[gp % RD][nn] = wbase[wo_c + nn * wtile + (int64_t)gp * ts];
-                } else if (has_next) {
-#pragma unroll
-                    for (int nn = 0; nn < NR; ++nn) bq[gp % RD][nn] = wbase[wo_n + nn * wtile + (int64_t)(gp - NT) * ts];
-                }
-                __builtin_amdgcn_sched_barrier(0x38F);
-            }
-            float4 a[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const float4*>(buf + abase[m] + toff);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nn = 0; nn < NR; ++nn) {
-                    const float4 bb = bq[tap % RD][nn];
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bb.x, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bb.y, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bb.z, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bb.w, acc[m][nn], 0, 0, 0);
-                }
-        }
-        if (last) {
-            int b = u / ncot;
-            const int x0 = (b % nX) * TX; b /= nX;
-            const int y0 = (b % nY) * TY; b /= nY;
-            const int z0 = (b % nZ) * TZ; b /= nZ;
-            const int n = b % N;
-#pragma unroll
-            for (int nn = 0; nn < NR; ++nn) {
-                const int co = (cot * NR + nn) * 32 + r;
-                const float bv = bias ? bias[co] : 0.f;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                        const int p = wv * 64 + m * 32 + row;
-                        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-                        const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
-                        if (gz < D && gy < H && gx < W) {
-                            const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
-                            if (ksplit > 1) {
-                                part[((int64_t)ksl * N * D * H * W + v) * Cout + co] = acc[m][nn][reg];
-                            } else {
-                                float o = act_apply(acc[m][nn][reg] + bv, act);
-                                if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
-                                y[v * y_ld + co] = o;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
 
 // y = act(sum_ks part[ks] + bias) [* (ref > 0)]
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict__ part, int ksplit, int64_t NV,
@@ -723,28 +514,7 @@ static void launch_fwd(const float* x, int64_t x_ld, const float* scale, const f
     const int64_t nblk = (int64_t)N * nZ * nY * nX * (Cout / (32 * NR)) * ksplit;
     size_t ldsb = (size_t)HV * LSF * sizeof(float);
     // persistent pipelining pays for the 64-column tiles (measured +5%), not for the 32-column ones
-    static const int pmode = getenv("TEM_FWD_PERSISTENT") ? atoi(getenv("TEM_FWD_PERSISTENT")) : -1;
-    static const int lcmode = getenv("TEM_FWD_LC") ? atoi(getenv("TEM_FWD_LC")) : 0;  // measured: no gain
-    if constexpr (NW == 4 && (KD * KH * KW) % 3 == 0) {
-        if (lcmode) {
-            static int ncu2 = 0;
-            if (!ncu2) {
-                ncu2 = tem_device_cus();
-                if (ncu2 <= 0) ncu2 = 256;
-            }
-            const int64_t grid = nblk < (int64_t)ncu2 * 2 ? nblk : (int64_t)ncu2 * 2;
-            const size_t lds2 = (size_t)2 * HV * LC_LS * sizeof(float);
-            hipLaunchKernelGGL((k_conv_fwd_mfma_lc<KD, KH, KW, TZ, TY, TX, NR>), dim3((unsigned)grid), dim3(320), lds2, s,
-                               x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, nZ, nY,
-                               nX, ksplit, part, (int)nblk);
-            if (ksplit > 1) {
-                const int64_t NV = (int64_t)N * D * H * W;
-                hipLaunchKernelGGL(k_splitk_epilogue, dim3(tem_grid_1d(NV * (Cout / 4), 256)), dim3(256), 0, s, part,
-                                   ksplit, NV, Cout, bias, act, ref, ref_ld, y, y_ld);
-            }
-            return;
-        }
-    }
+    const int pmode = (int)tem_option(TEM_OPT_FWD_PERSISTENT);
     const bool persistent = NW == 4 && (pmode < 0 ? NR == 2 : pmode != 0);
     if constexpr (NW == 4) if (persistent) {
         static int ncu = 0;
@@ -800,12 +570,7 @@ int tem_conv_fwd_mfma(const float* x, int64_t x_ld, const float* scale, const fl
             launch_fwd<KD, KH, KW, TZ, TY, TX, 1>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, \
                                                   Cin, Cout, act, ks, part, s);                                    \
     } while (0)
-    static const int bigpatch = getenv("TEM_FWD_BIGPATCH") ? atoi(getenv("TEM_FWD_BIGPATCH")) : 0;  // measured: no gain
-    if (key == 7 && !nr2 && bigpatch && D >= 8 && ks == 1) {
-        // 32-column tiles (the 128^3 level): 8x8x8 patch, 8 waves, 2 workgroups/CU = 4 waves/SIMD
-        launch_fwd<3, 3, 3, 8, 8, 8, 1, 8>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout,
-                                           act, 1, part, s);
-    } else if (key == 7) {
+    if (key == 7) {
         GO(3, 3, 3, 4, 8, 8);
     } else if (key == 3) {
         if (flat)

@@ -7,6 +7,18 @@
 
 void tem_set_error(const char* fmt, ...);
 
+// dispatch options (capi.hip; set through tem_set_option(), never through the environment)
+enum {
+    TEM_OPT_WGRAD_ZS = 0,
+    TEM_OPT_WGRAD_ZS_PERSIST,
+    TEM_OPT_WGRAD_SUMS,
+    TEM_OPT_WGRAD_SUMS_MIN_MB,
+    TEM_OPT_FWD_PERSISTENT,
+    TEM_OPT_CONV_FWD_VARIANT,
+    TEM_OPT_COUNT
+};
+long long tem_option(int id);
+
 #define TEM_REQUIRE(cond, ...)                 \
     do {                                       \
         if (!(cond)) {                         \

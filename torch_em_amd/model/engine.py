@@ -306,7 +306,7 @@ def _dgrad(spec: ConvSpec, g, gx, ref=None):
 
 
 # Norm-backward sums from the weight gradient (csrc/wgrad_sums.hip, tem_conv3d_wgrad_sums): the reduction pass over the
-# data gradient and the norm input disappears for the layers that qualify.  TEM_WGRAD_SUMS=0 disables (C side).
+# data gradient and the norm input disappears for the layers that qualify.  tem_set_option("wgrad_sums", 0) disables.
 def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None, want_sums=False):
     """-> sums[N, Cin, 2] for _norm_bwd_inplace when want_sums and the layer qualifies, else None"""
     ent = spec.packed()
