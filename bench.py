@@ -102,7 +102,29 @@ def cpu_baseline(max_threads):
                       f"{max_threads} hardware threads"}
 
 
+def self_launch(args_gpus):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run with one rank per GPU on
+    127.0.0.1 (what the reference's train_multi_gpu does with mp.spawn, multi_gpu_training.py:172-190).  The ranks
+    inherit stdout, so rank 0's JSON line is this process's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
+    if "WORLD_SIZE" not in os.environ:
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--gpus", type=int, default=1)
+        n = pre.parse_known_args()[0].gpus
+        if n > 1:
+            sys.exit(self_launch(n))
     # The contract is ONE JSON line on stdout.  RCCL prints its version banner to fd 1 from C when the communicator is
     # created, and libraries may print warnings: route fd 1 to stderr for the whole run and keep the real stdout
     # for the final line only.

@@ -84,6 +84,8 @@ int tem_get_option(const char* name, int64_t* value);
 #define TEM_WL_BF16X6 3
 #define TEM_WL_F16X3 4  /* like BF16X3 with two fp16 terms per weight (22 mantissa bits), lo plane stored x 2^12 */
 #define TEM_WL_F16 5    /* ONE fp16 term per weight (half the bytes): the mixed-precision mode, use_mfma 5 */
+#define TEM_WL_F16X3S 6 /* two fp16 terms of the weight x 2^7 (both terms carry the prescale; activations are staged x 2^5,
+                           the kernel's epilogue multiplies by 2^-12): one accumulator for all three products, use_mfma 6 */
 #define TEM_ACT_NONE 0
 #define TEM_ACT_RELU 1
 #define TEM_ACT_SIGMOID 2

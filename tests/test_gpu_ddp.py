@@ -71,3 +71,96 @@ def test_ddp_two_ranks_one_gpu():
         assert err < 1e-5, (rank, err)      # averaged gradient == mean of the two local gradients
         assert same                          # both ranks hold bit-identical parameters after the step
         assert moved > 0
+
+
+def _worker_bn(rank, world, port, q):
+    """norm="BatchNorm" under DDP: rank 0's running statistics are what every rank holds when a forward pass starts."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.multi_gpu_training import DDP, cleanup, setup
+    setup(rank, world, backend="gloo", port=port)
+    try:
+        dev = "cuda:0"
+        torch.manual_seed(0)
+        net = UNet3d(1, 2, depth=2, initial_features=16, norm="BatchNorm").to(dev)
+        ddp = DDP(net, device_ids=[0])
+        g = torch.Generator().manual_seed(7 + rank)
+        x = torch.randn(2, 1, 16, 16, 16, generator=g).to(dev)
+        y = (torch.rand(2, 2, 16, 16, 16, generator=g) > 0.5).float().to(dev)
+        DiceLoss()(ddp(x), y).backward()          # the ranks now hold DIFFERENT running statistics (different batches)
+        mine = torch.cat([b.detach().float().reshape(-1) for b in net.buffers()]).clone()
+        allb = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allb, mine)
+        differ = not torch.equal(allb[0], allb[1])
+        seen = {}
+        h = net.register_forward_pre_hook(lambda m, a: seen.setdefault(
+            "b", torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).clone()))
+        ddp(x)                                    # second forward: starts from rank 0's buffers on every rank
+        h.remove()
+        q.put((rank, differ, bool(torch.equal(seen["b"], allb[0]))))
+    finally:
+        cleanup()
+
+
+def test_ddp_broadcasts_buffers_every_forward():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    for rank, differ, synced in res:
+        assert differ          # the test is meaningful: local statistics had diverged
+        assert synced, rank    # and the next forward saw rank 0's
+
+
+def _worker_nccl(port, q):
+    """ONE rank over the real RCCL communicator: init_process_group("nccl"), GradSync's in-place ReduceOp.AVG ranges on
+    the collective stream, finish() before the fused optimizer (N > 1 on hardware is the driver's scaling run)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.multi_gpu_training import DDP, cleanup, setup
+    from torch_em_amd.optim import FusedAdamW
+    setup(0, 1, backend="nccl", port=port)
+    try:
+        dev = "cuda:0"
+        torch.manual_seed(0)
+        net = UNet3d(1, 2, depth=2, initial_features=32).to(dev)
+        x = torch.randn(1, 1, 32, 32, 32).to(dev)
+        y = (torch.rand(1, 2, 32, 32, 32) > 0.5).float().to(dev)
+        DiceLoss()(net(x), y).backward()
+        local = torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+        net.zero_grad()
+        ddp = DDP(net, device_ids=[0], bucket_mb=0.25)   # small ranges: several overlapped collectives per step
+        opt = FusedAdamW(net.parameters(), lr=1e-3)
+        opt.zero_grad()
+        DiceLoss()(ddp(x), y).backward()
+        got = torch.cat([p.grad.flatten() for p in net.parameters()])
+        before = torch.cat([p.detach().flatten() for p in net.parameters()]).clone()
+        opt.step()
+        torch.cuda.synchronize()
+        after = torch.cat([p.detach().flatten() for p in net.parameters()])
+        q.put((bool(torch.equal(got, local)), float((after - before).abs().max()), bool(ddp.sync._avg)))
+    finally:
+        cleanup()
+
+
+def test_ddp_one_rank_over_rccl():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl, args=(_free_port(), q))
+    p.start()
+    same, moved, avg = q.get(timeout=300)
+    p.join(60)
+    assert avg            # the NCCL (= RCCL) backend averages in the collective
+    assert same           # AVG over one rank is the identity, bit for bit
+    assert moved > 0

@@ -43,7 +43,16 @@ def _worker(rank, world, port, q):
         ok_bcast = all(torch.equal(gathered[0], t) for t in gathered)
         ok_attr = ddp.out_channels == 2 and ddp.init_kwargs["depth"] == 1 and \
             all(k.startswith("module.") for k in ddp.state_dict())
-        q.put((rank, ok_sync, ok_bcast, ok_attr, getattr(net, "_tem_grad_sync", None) is ddp.sync))
+        # per-forward buffer broadcast (torch DDP's broadcast_buffers=True): rank 0's running statistics win
+        bn = torch.nn.Sequential(torch.nn.Conv3d(1, 3, 1), torch.nn.BatchNorm3d(3))
+        dbn = DDP(bn, device_ids=None)
+        with torch.no_grad():
+            bn[1].running_mean.fill_(float(rank + 1))
+            bn[1].num_batches_tracked.fill_(10 * (rank + 1))
+        dbn.eval()
+        dbn(torch.zeros(1, 1, 2, 2, 2))
+        ok_buf = bool((bn[1].running_mean == 1.0).all()) and int(bn[1].num_batches_tracked) == 10
+        q.put((rank, ok_sync, ok_bcast, ok_attr, getattr(net, "_tem_grad_sync", None) is ddp.sync, ok_buf))
     finally:
         cleanup()
 

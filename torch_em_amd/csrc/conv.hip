@@ -50,9 +50,9 @@ extern "C" int tem_conv_pack_weights(const float* w, float* dst, int Cout, int C
     TEM_REQUIRE(w && dst && Cout > 0 && Cin > 0, "tem_conv_pack_weights: bad arguments");
     TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
                 "tem_conv_pack_weights: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
-    if (layout == TEM_WL_BF16X3 || layout == TEM_WL_BF16X6 || layout == TEM_WL_F16X3 || layout == TEM_WL_F16) {
+    if (layout == TEM_WL_BF16X3 || layout == TEM_WL_BF16X6 || layout == TEM_WL_F16X3 || layout == TEM_WL_F16 || layout == TEM_WL_F16X3S) {
         int rc = tem_pack_weights_bf16x3(w, dst, Cout, Cin, kd, kh, kw, transpose,
-                                         layout == TEM_WL_BF16X6 ? 3 : (layout == TEM_WL_F16X3 ? 4 : (layout == TEM_WL_F16 ? 5 : 2)),
+                                         layout == TEM_WL_BF16X6 ? 3 : (layout == TEM_WL_F16X3 ? 4 : (layout == TEM_WL_F16 ? 5 : (layout == TEM_WL_F16X3S ? 6 : 2))),
                                          (hipStream_t)stream);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv_pack_weights(bf16x3)");
@@ -254,7 +254,7 @@ static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, con
     TEM_REQUIRE(act >= 0 && act <= 2, "tem_conv3d_fwd: Invalid activation: %d", act);
     TEM_REQUIRE(!ref || ref_ld >= Cout, "tem_conv3d_fwd: bad ref_ld");
     hipStream_t s = (hipStream_t)stream;
-    if (use_mfma >= 2 && use_mfma <= 5) {
+    if (use_mfma >= 2 && use_mfma <= 6) {
         int rc = tem_conv_fwd_bf16x3(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
                                      W, Cin, Cout, kd, kh, kw, act, use_mfma, stat, s);
         if (rc != TEM_OK) return rc;
@@ -328,8 +328,8 @@ extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Ci
                                               int use_mfma) {
     if (use_mfma == 0)  // VALU kernels: only the small-Cin first-layer kernel (conv_small.hip) provides them
         return (ref_free_cin1_ok(Cout)) ? tem_conv_fwd_cin1_stat_blocks(D, H, W, Cin, Cout, kd, kh, kw) : 0;
-    if (use_mfma < 2 || use_mfma > 5) return 0;
-    return tem_conv_fwd_bf16x3_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw);
+    if (use_mfma < 2 || use_mfma > 6) return 0;
+    return tem_conv_fwd_bf16x3_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma);
 }
 
 extern "C" int tem_conv3d_fwd_stats(const float* x, int64_t x_ld, const float* scale, const float* shift,

@@ -54,62 +54,7 @@ __device__ __forceinline__ float4 ld4_nt(const float* p) {
 #define TEM_NS1_WPC 4  // resident workgroups per CU of the single-product (mixed precision) forward kernel
 #endif
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-#define BCK 16   // input channels per staged chunk = K of one MFMA
-#define BLS 20   // LDS floats per halo voxel: 16 hi bf16 (32 B) + 16 lo bf16 (32 B) + 16 B pad
-
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-    bf16x2 v = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32, round-to-nearest-even
-    return __builtin_bit_cast(unsigned, v);
-}
-// (hi, lo) split of two floats: hi = bf16(x), lo = bf16(x - hi)
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-    hi = pk_bf16(a, b);
-    const float ra = a - __builtin_bit_cast(float, hi << 16);
-    const float rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
-    lo = pk_bf16(ra, rb);
-}
-// fp16 counterparts (forward of NORMALISED activations only: |x| << 65504).  x = h + l with two fp16 terms carries 22
-// mantissa bits, so hi*hi + hi*lo + lo*hi ("fp16x3") is fp32-class (~2^-22 per product) at HALF the MFMAs of bf16x6.
-// The lo term of an O(1) operand is O(2^-12) and that of a 0.05-sized weight is 2^-16: deep in fp16's subnormal range
-// (spacing 6e-8), where it would keep only a few bits.  Both lo planes are therefore stored SCALED by 2^12 (exact), the
-// cross products hi*lo' + lo'*hi accumulate in their own fp32 accumulators and the epilogue adds them back times 2^-12.
-#define F16_LO_SCALE 4096.f
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-template <bool F16>
-__device__ __forceinline__ unsigned pk16(float a, float b) {
-    if (F16) {
-        half2_t v = {(_Float16)a, (_Float16)b};  // round-to-nearest-even
-        return __builtin_bit_cast(unsigned, v);
-    }
-    return pk_bf16(a, b);
-}
-template <bool F16>
-__device__ __forceinline__ float lo16(unsigned h) {
-    if (F16) return (float)__builtin_bit_cast(half2_t, h).x;
-    return __builtin_bit_cast(float, h << 16);
-}
-template <bool F16>
-__device__ __forceinline__ float hi16(unsigned h) {
-    if (F16) return (float)__builtin_bit_cast(half2_t, h).y;
-    return __builtin_bit_cast(float, h & 0xffff0000u);
-}
-template <bool F16>
-__device__ __forceinline__ floatx16 mfma16(uint4 a, uint4 b, floatx16 c) {
-    if (F16)
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float act_apply_b(float v, int act) {
-    if (act == TEM_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == TEM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-    return v;
-}
+#include "conv_split.h"
 
 // ---------------------------------------------------------------------------
 // weight packing: [Cout][Cin][kd][kh][kw] fp32 -> [co/32][tap][ci/16][NS planes][64 lanes][8 bf16]
@@ -140,6 +85,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_bfsplit(const float* __res
         const int nt = co >> 5, col = co & 31, c16 = ci >> 4, kh = (ci >> 3) & 1, j = ci & 7;
         const int64_t base = ((((int64_t)nt * ntaps + tap) * (CinL >> 4) + c16) * NS) * 512;  // 512 bf16 per plane
         float rem = val;
+        if (fp16 == 3) rem = __builtin_amdgcn_fmed3f(val * F16_W_PRESCALE, -64000.f, 64000.f);
         for (int p = 0; p < NS; ++p) {
             if (fp16) {
                 const _Float16 hv = (_Float16)rem;
@@ -157,9 +103,10 @@ __global__ __launch_bounds__(256) void k_pack_weights_bfsplit(const float* __res
 
 int tem_pack_weights_bf16x3(const float* w, float* dst, int Cout, int Cin, int kd, int kh, int kw, int transpose,
                             int nsplit, hipStream_t s) {
-    // nsplit 4 = fp16x3: two fp16 planes, the lo plane scaled by 2^12 (fp16 = 2); 5 = fp16: one plane (fp16 = 1)
-    const int fp16 = nsplit == 4 ? 2 : (nsplit == 5 ? 1 : 0);
-    if (fp16) nsplit = nsplit == 4 ? 2 : 1;
+    // nsplit 4 = fp16x3: two fp16 planes, the lo plane scaled by 2^12 (fp16 = 2); 5 = fp16: one plane (fp16 = 1);
+    // 6 = fp16x3 with the whole weight prescaled by 2^7 (fp16 = 3, conv_split.h)
+    const int fp16 = nsplit == 4 ? 2 : (nsplit == 5 ? 1 : (nsplit == 6 ? 3 : 0));
+    if (fp16) nsplit = nsplit == 5 ? 1 : 2;
     int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
     TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: split-bf16 layout needs Cin%%16==0, Cout%%32==0");
     int64_t total = (int64_t)Cout * Cin * kd * kh * kw;
@@ -205,6 +152,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const PackDesc* __re
         for (int j = 0; j < 8; ++j) {
             const int ci = ci0 + j;
             rem[j] = d.transpose ? d.w[((long long)ci * d.Cin + co) * ntaps + ftap] : d.w[((long long)co * d.Cin + ci) * ntaps + tap];
+            if (d.fp16 == 3) rem[j] = __builtin_amdgcn_fmed3f(rem[j] * F16_W_PRESCALE, -64000.f, 64000.f);
         }
         uint4* out = reinterpret_cast<uint4*>(d.dst) + ((((long long)nt * ntaps + tap) * c16n + c16) * d.NS) * 64 + lane;
         for (int p = 0; p < d.NS; ++p) {
@@ -245,7 +193,7 @@ extern "C" int tem_conv_pack_weights_batch(const void* descs_dev, int n, int64_t
 // (6 MFMAs) -- per-product error ~2^-23, i.e. the fp32 class, at 16/6 of the exact-fp32 MFMA rate;
 // used for the forward pass, whose rounding noise the gradient amplifies (engine.py, PRECISION).
 // ---------------------------------------------------------------------------
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false>
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false, bool PS = false>
 __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM_SC_WPC : (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_bfsplit(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
@@ -296,7 +244,8 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
         const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
         abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;  // + 8 floats (32 B) per further plane
     }
-    constexpr bool SC = F16 && NS == 2;        // fp16x3: scaled lo planes, cross products in their own accumulators
+    constexpr bool SC = F16 && NS == 2 && !PS; // fp16x3: scaled lo planes, cross products in their own accumulators
+                                               // (PS: whole operands prescaled instead, one accumulator, conv_split.h)
     floatx16 acc[MT][NW];
     floatx16 accl[SC ? MT : 1][SC ? NW : 1];
 #pragma unroll
@@ -364,6 +313,10 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
             const int hv = (tid + it * 256) >> 2;
             if (hv < HV) {
                 float e[4] = {tmp[it].x, tmp[it].y, tmp[it].z, tmp[it].w};
+                if (PS) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) e[c] *= F16_A_PRESCALE;
+                }
                 if (F16 && TEM_SC_CLAMP) {
                     // an activation beyond the fp16 range (|x^| > 6e4 after the norm: not a training state) saturates
                     // instead of turning the whole receptive field into NaN
@@ -457,6 +410,14 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                 for (int i = 0; i < 16; ++i)
                     acc[m][nn][i] = fmaf(accl[SC ? m : 0][SC ? nn : 0][i], 1.f / F16_LO_SCALE, acc[m][nn][i]);
     }
+    if (PS) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NW; ++nn)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][nn][i] *= F16_PRESCALE_INV;
+    }
     // optional fused forward statistics of the STORED output (the next layer's InstanceNorm / GroupNorm / BatchNorm):
     // per (sample, patch, channel) partial sums (sum y, sum y^2); merged in fp64 by tem_norm_finalize_partials
     float ssum[NW], ssq[NW];
@@ -527,7 +488,7 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
     }
 }
 
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false>
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false, bool PS = false>
 static void launch_b(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
                      int W, int Cin, int Cout, int act, int ksplit, float* part, float* stat, hipStream_t s) {
@@ -537,11 +498,11 @@ static void launch_b(const float* x, int64_t x_ld, const float* scale, const flo
     constexpr size_t ldsb = (size_t)HV * (NS * 8 + 4) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done && ldsb > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16, PS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16>), dim3((unsigned)nblk), dim3(256), ldsb, s, x,
+    hipLaunchKernelGGL((k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16, PS>), dim3((unsigned)nblk), dim3(256), ldsb, s, x,
                        x_ld, scale, shift, reinterpret_cast<const uint4*>(wp), bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin,
                        Cout, act, nZ, nY, nX, ksplit, part, ksplit > 1 ? nullptr : stat);
     if (ksplit > 1) {
@@ -560,6 +521,9 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
                 "tem_conv3d_fwd(split-bf16): x / packed weights must be 16-byte aligned with ld%%4==0");
     TEM_REQUIRE(!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)),
                 "tem_conv3d_fwd(split-bf16): scale/shift must be 16-byte aligned");
+    if (tem_conv_fwd_pp(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, kd, kh, kw, act, nsplit,
+                        stat, s))
+        return TEM_OK;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     const bool flat = (D == 1 && kd == 1);
     const int TZ = flat ? 1 : 4, TY = flat ? 16 : 8, TX = flat ? 16 : 8;
@@ -591,6 +555,13 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
             else                                                                                                      \
                 launch_b<KD, KH, KW, TZ, TY, TX, 1, 2, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
                                                              W, Cin, Cout, act, ks, part, stat, s);                         \
+        } else if (nsplit == 6) {                                                                                     \
+            if (nr2)                                                                                                  \
+                launch_b<KD, KH, KW, TZ, TY, TX, 2, 2, true, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, \
+                                                                   H, W, Cin, Cout, act, ks, part, stat, s);               \
+            else                                                                                                      \
+                launch_b<KD, KH, KW, TZ, TY, TX, 1, 2, true, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, \
+                                                                   H, W, Cin, Cout, act, ks, part, stat, s);               \
         } else if (nsplit == 5) {                                                                                     \
             if (nr2)                                                                                                  \
                 launch_b<KD, KH, KW, TZ, TY, TX, 2, 1, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
@@ -626,8 +597,10 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
 
 // number of per-sample statistic blocks (= patches) the fused-statistics forward writes, 0 when this shape cannot
 // produce them (split-K over the input channels, or no MFMA instantiation)
-int64_t tem_conv_fwd_bf16x3_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+int64_t tem_conv_fwd_bf16x3_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
     if (Cin % 16 || Cout % 32) return 0;
+    const int64_t ppb = tem_conv_pp_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit);
+    if (ppb >= 0) return ppb;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     if (key != 7 && key != 3 && key != 0) return 0;
     const bool flat = (D == 1 && kd == 1);

@@ -1,0 +1,409 @@
+// conv_pp.hip -- split-precision implicit-GEMM 3-D convolution (forward and data gradient), "ping-pong teams".
+//
+// Replaces aten::convolution / the dgrad half of convolution_backward behind ConvBlock (model/unet.py:417-438) for
+// the layers with many patches (128^3 ... 32^3 levels).  Same arithmetic and operand layouts as k_conv_fwd_bfsplit
+// (conv_bf16x3.hip): fp32 NDHWC activations, fused pre-norm while staging, operands split into two 16-bit terms,
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_{bf16,f16}, bias / ReLU / mask / statistics epilogue.
+//
+// What is different is the schedule.  In the one-patch-per-workgroup kernel every workgroup alternates between a
+// staging phase (global loads -> norm -> split -> LDS, matrix pipe idle) and a 27-tap MFMA phase; identical
+// workgroups started together stay in lockstep, so the co-resident workgroups of a CU stage at the same time and
+// compete for the matrix pipe at the same time (measured: the phases add up, matrix pipe 41-45 % busy).  Here a
+// workgroup is TWO teams of four waves -- one wave of each team per SIMD -- that are forced into opposite phases
+// by the workgroup barrier: while team A runs the tap loop of its (patch, 16-channel chunk) step out of its LDS
+// tile, team B writes back the previous patch, loads / normalises / splits the halo of its next step into its own
+// tile and primes its weight-fragment ring; at the barrier they swap roles.  Each SIMD therefore always has exactly
+// one wave issuing MFMAs, with the whole VALU / VMEM side of the partner hidden beside it, as long as a staging
+// phase is shorter than a tap loop (it has 5-10 thousand cycles).  Workgroups are persistent (one per CU) and walk
+// contiguous unit ranges per XCD.
+#include "tem_common.h"
+#include "conv_internal.h"
+#include "conv_split.h"
+
+#ifndef TEM_PP_RD
+#define TEM_PP_RD 3      // weight-fragment ring depth over taps
+#endif
+#ifndef TEM_PP_PRIO
+#define TEM_PP_PRIO 1    // s_setprio of the team in its MFMA phase
+#endif
+
+struct PpUnit {
+    int cot, n, z0, y0, x0;
+};
+
+// KD,KH,KW kernel; TZ,TY,TX voxel patch of a TEAM; CT 32-column tiles per team; WN waves side by side over the
+// columns (WM = 4 / WN waves over the voxels); NS planes per operand; F16: fp16 terms with prescaled operands
+// (TEM_WL_F16X3S, conv_split.h), else bf16 terms.
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int CT, int WN, int NS, bool F16>
+__global__ __launch_bounds__(512, 2) void k_conv_pp(
+    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
+    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
+    int nY, int nX, float* __restrict__ stat, int nunits) {
+    constexpr int NT = KD * KH * KW;
+    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1;
+    constexpr int HV = HZ * HY * HX;
+    constexpr int PV = TZ * TY * TX;
+    constexpr int WM = 4 / WN;
+    constexpr int MT = PV / (32 * WM);          // 32-voxel M-tiles per wave
+    constexpr int NW = CT / WN;                 // 32-column tiles per wave
+    constexpr int NIT = (HV * 4 + 255) / 256;   // float4 slots (4 per halo voxel and chunk) per thread of a team
+    constexpr int LSV = NS * 8 + 4;             // LDS floats per halo voxel: NS planes of 16 x 16 bit + 16 B pad
+    constexpr int RD = NT >= TEM_PP_RD ? TEM_PP_RD : 1;  // weight ring: the slot of a tap is tap % RD (the ring restarts every phase)
+    constexpr int FR = NS * 64;                 // uint4s per (tap, 16-channel chunk) fragment group
+    static_assert(PV % (32 * WM) == 0 && CT % WN == 0 && WN * WM == 4, "team tiling");
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];  // [2 teams][HV][LSV]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wv >> 2, tw = wv & 3, tl = tid & 255;
+    const int kh = lane >> 5, r = lane & 31;
+    const int wm = tw % WM, wn = tw / WM;
+    float* lds = lds_all + team * (HV * LSV);
+
+    // units: (column group, patch) pairs; a team takes every G-th unit starting at its logical slot.  Logical slots
+    // are contiguous per XCD (dispatch places block b on XCD b % 8), so the 64 units an XCD works on at any time are
+    // neighbouring patches that share halo lines in that XCD's L2.
+    const int G = 2 * gridDim.x;
+    const int slot = tem_xcd_remap(blockIdx.x, gridDim.x) * 2 + team;
+    const int ncot = Cout / (32 * CT);
+    const int nch = Cin >> 4;
+    const int my_units = slot < nunits ? (nunits - slot + G - 1) / G : 0;
+    const int my_steps = my_units * nch;
+    const int P = ((nunits + G - 1) / G) * nch;  // steps of the busiest team: every wave runs 2P + 2 phases
+
+    auto decode = [&](int ui) {
+        int u = slot + ui * G;
+        PpUnit t;
+        t.cot = u % ncot; u /= ncot;
+        t.x0 = (u % nX) * TX; u /= nX;
+        t.y0 = (u % nY) * TY; u /= nY;
+        t.z0 = (u % nZ) * TZ; u /= nZ;
+        t.n = u;
+        return t;
+    };
+
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int p = (wm * MT + m) * 32 + r;
+        const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+        abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;  // + 8 floats (32 B) per further plane
+    }
+    floatx16 acc[MT][NW];
+    const int tapstride = nch * FR;
+    uint4 bq[RD][NW][NS];
+    const uint4* wq[NW];
+#pragma unroll
+    for (int nn = 0; nn < NW; ++nn) wq[nn] = wp + lane;
+
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NW; ++nn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
+
+    // Both teams run the same straight-line sequence  stage(s) | barrier | taps(s) | barrier ;  team 1 passes one extra
+    // barrier first (and team 0 one at the end), which shifts it by one phase: its staging runs beside team 0's tap loop.
+    if (team) __syncthreads();
+    for (int s = 0; s <= P; ++s) {
+        {
+            // ================= staging phase (the partner team runs its tap loop) =================
+            const bool do_epi = s >= 1 && s - 1 < my_steps && (s - 1) % nch == nch - 1;
+            const bool do_stage = s < my_steps;
+            // ---- issue the halo loads of step s first: they fly during the epilogue of the previous unit ----
+            float4 tmp[NIT];
+            unsigned inb = 0;
+            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c4 = tl & 3;
+            PpUnit su;
+            int schunk = 0;
+            if (do_stage) {
+                su = decode(s / nch);
+                schunk = s % nch;
+                if (scale) {
+                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)su.n * Cin + schunk * BCK + c4 * 4);
+                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)su.n * Cin + schunk * BCK + c4 * 4);
+                }
+                // one uniform base pointer per step + 32-bit offsets: a load is "global_load v, voff, s[base]" (one address VGPR)
+                const int zlo = max(su.z0 - PZ, 0);
+                const float* xb = x + (((int64_t)su.n * D + zlo) * H * W) * x_ld + schunk * BCK;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int hv = min((tl + it * 256) >> 2, HV - 1);
+                    const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+                    const int gz = su.z0 + hz - PZ, gy = su.y0 + hy - PY, gx = su.x0 + hx - PX;
+                    const bool ok = (gz >= 0) & (gz < D) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) &
+                                    (((tl + it * 256) >> 2) < HV);
+                    inb |= ok ? (1u << it) : 0u;
+                    const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+                    const unsigned off = (unsigned)(((cz - zlo) * H + cy) * W + cx) * (unsigned)x_ld + (unsigned)(c4 * 4);
+                    tmp[it] = *reinterpret_cast<const float4*>(xb + off);
+                }
+            }
+            // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
+            if (do_epi) {
+                const PpUnit eu = decode((s - 1) / nch);
+                float* yb = y + (((int64_t)eu.n * D + eu.z0) * H * W) * y_ld;
+                const float* rb = ref ? ref + (((int64_t)eu.n * D + eu.z0) * H * W) * ref_ld : nullptr;
+                float ssum[NW], ssq[NW];
+#pragma unroll
+                for (int nn = 0; nn < NW; ++nn) {
+                    ssum[nn] = ssq[nn] = 0.f;
+                    const int co = ((eu.cot * WN + wn) * NW + nn) * 32 + r;
+                    const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        // straight-line loads of the ReLU-mask reference (clamped addresses): inside a per-element bounds
+                        // branch they would wait for one another
+                        float rv[16];
+                        unsigned vox[16];  // voxel index relative to the first plane of the patch
+                        unsigned okm = 0;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                            const int p = (wm * MT + m) * 32 + row;
+                            const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
+                            const int gz = eu.z0 + pz, gy = eu.y0 + py, gx = eu.x0 + px;
+                            okm |= (gz < D && gy < H && gx < W) ? (1u << reg) : 0u;
+                            vox[reg] = (unsigned)(((min(gz, D - 1) - eu.z0) * H + min(gy, H - 1)) * W + min(gx, W - 1));
+                            rv[reg] = ref ? rb[vox[reg] * (unsigned)ref_ld + (unsigned)co] : 1.f;
+                        }
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            float a = acc[m][nn][reg];
+                            if (F16) a *= F16_PRESCALE_INV;
+                            float o = act_apply_b(a + bv, act);
+                            if (!(rv[reg] > 0.f)) o = 0.f;
+                            if ((okm >> reg) & 1u) {
+                                ssum[nn] += o;
+                                ssq[nn] = fmaf(o, o, ssq[nn]);
+                                __builtin_nontemporal_store(o, yb + (vox[reg] * (unsigned)y_ld + (unsigned)co));
+                            }
+                            acc[m][nn][reg] = 0.f;  // the next unit of this team starts from zero
+                        }
+                    }
+                }
+                if (stat) {  // grid-uniform: per (sample, patch, voxel-wave, channel) partial sums of the stored output
+#pragma unroll
+                    for (int nn = 0; nn < NW; ++nn) {
+                        ssum[nn] += __shfl_xor(ssum[nn], 32, 64);  // the lane halves hold different rows of one column
+                        ssq[nn] += __shfl_xor(ssq[nn], 32, 64);
+                        if (kh == 0) {
+                            const int64_t patch = ((int64_t)(eu.z0 / TZ) * nY + eu.y0 / TY) * nX + eu.x0 / TX;
+                            const int64_t nblk = (int64_t)nZ * nY * nX * WM;
+                            const int co = ((eu.cot * WN + wn) * NW + nn) * 32 + r;
+                            float* dst = stat + (((int64_t)eu.n * nblk + patch * WM + wm) * Cout + co) * 2;
+                            dst[0] = ssum[nn];
+                            dst[1] = ssq[nn];
+                        }
+                    }
+                }
+            }
+            // ---- norm, split, LDS tile; then prime the weight-fragment ring of the coming tap loop ----
+            if (do_stage) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int hv = (tl + it * 256) >> 2;
+                    if (hv < HV) {
+                        const bool ok = (inb >> it) & 1u;
+                        float e[4] = {ok ? fmaf(tmp[it].x, sc4.x, sf4.x) : 0.f, ok ? fmaf(tmp[it].y, sc4.y, sf4.y) : 0.f,
+                                      ok ? fmaf(tmp[it].z, sc4.z, sf4.z) : 0.f, ok ? fmaf(tmp[it].w, sc4.w, sf4.w) : 0.f};
+                        if (F16) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                e[c] = __builtin_amdgcn_fmed3f(e[c] * F16_A_PRESCALE, -64000.f, 64000.f);
+                        }
+#pragma unroll
+                        for (int p = 0; p < NS; ++p) {
+                            const unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
+                            *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
+                            if (p + 1 < NS) {
+                                e[0] -= lo16<F16>(h0);
+                                e[1] -= hi16<F16>(h0);
+                                e[2] -= lo16<F16>(h1);
+                                e[3] -= hi16<F16>(h1);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int nn = 0; nn < NW; ++nn)
+                    wq[nn] = wp + (int64_t)((su.cot * WN + wn) * NW + nn) * NT * nch * FR + (int64_t)schunk * FR + lane;
+                if (RD > 1) {
+#pragma unroll
+                    for (int gp = 0; gp < RD - 1; ++gp)
+#pragma unroll
+                        for (int nn = 0; nn < NW; ++nn)
+#pragma unroll
+                            for (int p = 0; p < NS; ++p) bq[gp][nn][p] = wq[nn][gp * tapstride + p * 64];
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // ================= MFMA phase: 27 taps of one 16-channel chunk out of this team's tile =================
+            if (s < my_steps) {
+                int ts = tapstride;
+                asm volatile("" : "+s"(ts));
+                if (TEM_PP_PRIO) __builtin_amdgcn_s_setprio(TEM_PP_PRIO);
+                // Software pipeline, pinned with sched_barrier: this wave is the only one of its SIMD that issues MFMAs in
+                // this phase, so nothing else hides its LDS / L2 latencies.  While the MFMAs of tap t run, the A fragments
+                // of tap t+1 are already on their way from LDS (double-buffered registers) and the weight fragments of tap
+                // t+RD-1 on their way from L2 (ring of RD slots; slots 0..RD-2 were primed by the staging phase).
+                uint4 af[2][MT][NS];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) af[0][m][p] = *reinterpret_cast<const uint4*>(lds + abase[m] + p * 8);
+#pragma unroll
+                for (int tap = 0; tap < NT; ++tap) {
+                    if (tap + 1 < NT) {
+                        const int t1 = tap + 1;
+                        const int tz = t1 / (KH * KW), ty = (t1 / KW) % KH, tx = t1 % KW;
+                        const int toff = ((tz * HY + ty) * HX + tx) * LSV;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int p = 0; p < NS; ++p)
+                                af[t1 & 1][m][p] = *reinterpret_cast<const uint4*>(lds + abase[m] + toff + p * 8);
+                    }
+                    if (tap + RD - 1 < NT) {
+                        const int gp = tap + RD - 1;
+#pragma unroll
+                        for (int nn = 0; nn < NW; ++nn)
+#pragma unroll
+                            for (int p = 0; p < NS; ++p) bq[gp % RD][nn][p] = wq[nn][(int64_t)gp * ts + p * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int nn = 0; nn < NW; ++nn) {
+                            // smallest terms first: plane pairs (i, j) with i + j <= NS - 1
+#pragma unroll
+                            for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                                for (int i = 0; i <= sum; ++i)
+                                    acc[m][nn] = mfma16<F16>(af[tap & 1][m][i], bq[tap % RD][nn][sum - i], acc[m][nn]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (TEM_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        __syncthreads();
+    }
+    if (!team) __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct PpGeom {
+    int variant;  // 0: not handled here; 1: team patch 4x8x8; 2: team patch 8x8x8
+    int TZ, TY, TX, CT, WM;
+    int nZ, nY, nX;
+    int64_t nunits;
+};
+
+// Which shapes run on the ping-pong kernel: 3x3x3 (and 1x3x3 with depth) kernels, two 16-bit planes per operand, and
+// enough (patch, column group) units to give every team of every CU at least one.
+static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
+    PpGeom g = {};
+    const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
+    if (opt == 0) return g;
+    if (!(nsplit == 2 || nsplit == 6)) return g;
+    if (!(kh == 3 && kw == 3 && (kd == 3 || kd == 1))) return g;
+    if (D < 4 || Cin % 16 || Cout % 32) return g;
+    if ((int64_t)H * W * 10 * 4 * 1024 >= (1ll << 31)) return g;  // 32-bit byte offsets inside a step (ld <= 1024 floats)
+    static int ncu = 0;
+    if (!ncu) {
+        ncu = tem_device_cus();
+        if (ncu <= 0) ncu = 256;
+    }
+    g.CT = (Cout % 64 == 0) ? 2 : 1;
+    g.TY = g.TX = 8;
+    auto units = [&](int TZ) {
+        return (int64_t)N * ((D + TZ - 1) / TZ) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / (32 * g.CT));
+    };
+    const int64_t need = opt > 0 ? 1 : 2ll * ncu;
+    if ((opt == 2 && g.CT == 1) || (opt < 0 && g.CT == 1 && D % 8 == 0 && units(8) >= 2 * need)) {
+        g.variant = 2;
+        g.TZ = 8;
+    } else if (units(4) >= need) {
+        g.variant = 1;
+        g.TZ = 4;
+    } else {
+        return g;
+    }
+    g.WM = (g.CT == 2) ? 2 : 4;
+    g.nZ = (D + g.TZ - 1) / g.TZ;
+    g.nY = (H + 7) / 8;
+    g.nX = (W + 7) / 8;
+    g.nunits = units(g.TZ);
+    return g;
+}
+
+int64_t tem_conv_pp_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
+    const PpGeom g = pp_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit);
+    if (!g.variant) return -1;
+    return (int64_t)g.nZ * g.nY * g.nX * g.WM;
+}
+
+template <int KD, int KH, int KW, int TZ, int CT, bool F16>
+static void pp_launch(const PpGeom& g, const float* x, int64_t x_ld, const float* scale, const float* shift,
+                      const float* wp, const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld,
+                      int N, int D, int H, int W, int Cin, int Cout, int act, float* stat, hipStream_t s) {
+    constexpr int WN = CT;  // 64-column teams: 2 x 2 waves; 32-column teams: 4 x 1
+    constexpr int HV = (TZ + KD - 1) * 10 * 10;
+    constexpr size_t ldsb = (size_t)2 * HV * (2 * 8 + 4) * sizeof(float);
+    static_assert(ldsb <= 160 * 1024, "LDS budget");
+    auto kern = &k_conv_pp<KD, KH, KW, TZ, 8, 8, CT, WN, 2, F16>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        attr = true;
+    }
+    static int ncu = 0;
+    if (!ncu) {
+        ncu = tem_device_cus();
+        if (ncu <= 0) ncu = 256;
+    }
+    int64_t grid = (g.nunits + 1) / 2;
+    if (grid > ncu) grid = ncu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, s, x, x_ld, scale, shift,
+                       reinterpret_cast<const uint4*>(wp), bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ,
+                       g.nY, g.nX, stat, (int)g.nunits);
+}
+
+// -> true when the launch was taken
+bool tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                     const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
+                     int W, int Cin, int Cout, int kd, int kh, int kw, int act, int nsplit, float* stat, hipStream_t s) {
+    const PpGeom g = pp_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit);
+    if (!g.variant) return false;
+    const bool f16 = nsplit == 6;
+#define PPGO(KD, TZ, CT)                                                                                              \
+    do {                                                                                                              \
+        if (f16)                                                                                                      \
+            pp_launch<KD, 3, 3, TZ, CT, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, \
+                                              Cout, act, stat, s);                                                    \
+        else                                                                                                          \
+            pp_launch<KD, 3, 3, TZ, CT, false>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, \
+                                               Cout, act, stat, s);                                                   \
+    } while (0)
+    if (kd == 3) {
+        if (g.TZ == 8) PPGO(3, 8, 1);
+        else if (g.CT == 1) PPGO(3, 4, 1);
+        else PPGO(3, 4, 2);
+    } else {
+        if (g.TZ == 8) PPGO(1, 8, 1);
+        else if (g.CT == 1) PPGO(1, 4, 1);
+        else PPGO(1, 4, 2);
+    }
+#undef PPGO
+    return true;
+}

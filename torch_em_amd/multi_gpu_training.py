@@ -108,19 +108,40 @@ class DDP(torch.nn.Module):
     to it (`ddp_model.init_kwargs`, `.out_channels`, ...), keeps the `module.` state_dict prefix."""
 
     def __init__(self, module: torch.nn.Module, device_ids=None, find_unused_parameters: bool = True,
-                 process_group=None, bucket_mb: float = 8.0, broadcast_parameters: bool = True):
+                 process_group=None, bucket_mb: float = 8.0, broadcast_parameters: bool = True,
+                 broadcast_buffers: bool = True):
         super().__init__()
         self.module = module
         self.device_ids = device_ids
         self.find_unused_parameters = find_unused_parameters  # accepted for signature parity; nothing to search:
         # the engine computes every parameter gradient in one autograd node
+        self.process_group = process_group
+        self.broadcast_buffers = broadcast_buffers
         self.sync = GradSync(process_group, bucket_mb)
         if broadcast_parameters:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0, group=process_group)
         object.__setattr__(module, "_tem_grad_sync", self.sync)
 
+    def _sync_buffers(self):
+        """torch DDP's `broadcast_buffers=True` (its default, which the reference keeps, multi_gpu_training.py:79): rank
+        0's module buffers -- the running statistics of norm="BatchNorm" / "InstanceNormTrackStats" -- overwrite every
+        other rank's at the start of each forward pass.  One flat broadcast per dtype."""
+        by_dtype = {}
+        for b in self.module.buffers():
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for bufs in by_dtype.values():
+            flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=0, group=self.process_group)
+            pos = 0
+            for b in bufs:
+                n = b.numel()
+                b.data.copy_(flat[pos:pos + n].view_as(b))
+                pos += n
+
     def forward(self, *args, **kwargs):
+        if self.broadcast_buffers and self.sync.world > 1 and next(self.module.buffers(), None) is not None:
+            self._sync_buffers()
         return self.module(*args, **kwargs)
 
     def __getattr__(self, name):
