@@ -96,8 +96,10 @@ def _worker_bn(rank, world, port, q):
         dist.all_gather(allb, mine)
         differ = not torch.equal(allb[0], allb[1])
         seen = {}
-        h = net.register_forward_pre_hook(lambda m, a: seen.setdefault(
-            "b", torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).clone()))
+        def snapshot(m, a):  # (returns None: a pre-hook's return value would replace the input)
+            seen["b"] = torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).clone()
+
+        h = net.register_forward_pre_hook(snapshot)
         ddp(x)                                    # second forward: starts from rank 0's buffers on every rank
         h.remove()
         q.put((rank, differ, bool(torch.equal(seen["b"], allb[0]))))

@@ -569,3 +569,21 @@ def test_label_targets_bit_exact():
             exp = label_ref.boundaries(lab, add_bin)
             got = ops.boundary_target(ld, add_bin).cpu().numpy()
             assert np.array_equal(got, exp), (shape, add_bin)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_affinity_targets_match_the_reference_definitions(tag):
+    """G8 (tests/golden/gen_golden_trainer.py): what the reference's own tests require AffinityTransform to return --
+    outputs of its affs_brute_force / affs_brute_force_with_mask (test/transform/test_label_transforms.py:5-55) -- bit
+    for bit from the HIP kernel, through the ops wrapper and through the drop-in AffinityTransform class."""
+    from torch_em_amd.transform import AffinityTransform
+    ops = _ops()
+    g = dict(np.load(os.path.join(GOLDEN, "g8_affinities_bruteforce.npz")))
+    seg, offs = g[f"{tag}_seg"].astype("int64"), [list(map(int, o)) for o in g[f"{tag}_offsets"]]
+    n = len(offs)
+    ld = torch.from_numpy(seg).to(DEV)
+    assert np.array_equal(ops.affinity_target(ld, offs).cpu().numpy(), g[f"{tag}_affs"])
+    out = ops.affinity_target(ld, offs, ignore_label=0, add_mask=True).cpu().numpy()
+    assert np.array_equal(out[:n], g[f"{tag}_affs_ignore0"]) and np.array_equal(out[n:], g[f"{tag}_mask_ignore0"])
+    out = AffinityTransform(offs, ignore_label=0, add_mask=True, include_ignore_transitions=True)(ld).cpu().numpy()
+    assert np.array_equal(out[:n], g[f"{tag}_affs_trans"]) and np.array_equal(out[n:], g[f"{tag}_mask_trans"])

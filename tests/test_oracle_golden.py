@@ -180,3 +180,59 @@ def test_stateful_norm_golden(norm):
     with torch.no_grad():
         pe = unet_ref.unet_forward(sd, x, [2, 2], norm=norm, training=False)
     assert float((pe - torch.from_numpy(g["pred_eval"])).abs().max()) < 1e-6
+
+
+def _g7_oracle_run(g):
+    """The oracle's training loop (what tests/test_gpu_trainer.py runs beside the HIP trainer): oracle/unet_ref.py +
+    oracle/loss_ref.py + torch.optim.AdamW / ReduceLROnPlateau as default_segmentation_trainer configures them
+    (reference segmentation.py:543-544), over G7's batches in G7's order."""
+    params = {k[4:]: torch.from_numpy(v).clone().requires_grad_(v.dtype.kind == "f") for k, v in g.items()
+              if k.startswith("sd0.")}
+    opt = torch.optim.AdamW([p for p in params.values() if p.requires_grad], lr=float(g["learning_rate"]))
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=5)
+    xt, yt, xv, yv = (torch.from_numpy(g[k]) for k in ("xt", "yt", "xv", "yv"))
+    losses, lrs, metrics = [], [], []
+    for _epoch in range(2):
+        for i in range(0, xt.shape[0], 2):
+            opt.zero_grad()
+            loss = loss_ref.dice_loss(unet_ref.unet_forward(params, xt[i:i + 2], [2, 2]), yt[i:i + 2])
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+            lrs.append(opt.param_groups[0]["lr"])
+        with torch.no_grad():
+            m = np.mean([float(loss_ref.dice_loss(unet_ref.unet_forward(params, xv[i:i + 2], [2, 2], training=False),
+                                                  yv[i:i + 2])) for i in range(0, xv.shape[0], 2)])
+        metrics.append(m)
+        sched.step(m)
+    return losses, lrs, metrics, params
+
+
+def test_oracle_training_loop_matches_reference_trainer():
+    """G7: the reference's DefaultTrainer.fit(8) run by tests/golden/gen_golden_trainer.py (route-B import of torch_em):
+    loss of every iteration, learning rate, validation metric of every epoch, final parameters."""
+    g = _load("g7_trainer_unet2d.npz")
+    losses, lrs, metrics, params = _g7_oracle_run(g)
+    assert np.allclose(losses, g["train_loss"], rtol=0, atol=2e-5), (losses, g["train_loss"])
+    assert np.allclose(lrs, g["lr"])
+    assert np.allclose(metrics, g["val_metric"], atol=2e-5)
+    for k, v in params.items():
+        if "samplers" in k and k.endswith("bias"):
+            continue  # mathematically zero gradient in front of an InstanceNorm: Adam turns round-off into +-lr steps
+        a, b = v.detach().double(), torch.from_numpy(g[f"sd1.{k}"]).double()
+        assert float((a - b).norm() / b.norm()) < 2e-3, k
+    assert int(g["iteration"]) == 8 and int(g["epoch"]) == 1  # the checkpoint is written before the epoch counter moves
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_oracle_affinities_match_the_reference_definitions(tag):
+    """G8: outputs of the reference's own affs_brute_force / affs_brute_force_with_mask
+    (test/transform/test_label_transforms.py:5-55), which its tests require AffinityTransform to reproduce."""
+    g = _load("g8_affinities_bruteforce.npz")
+    seg, offs = g[f"{tag}_seg"], [list(map(int, o)) for o in g[f"{tag}_offsets"]]
+    n = len(offs)
+    assert np.array_equal(label_ref.affinities(seg, offs), g[f"{tag}_affs"])
+    out = label_ref.affinities(seg, offs, ignore_label=0, add_mask=True)
+    assert np.array_equal(out[:n], g[f"{tag}_affs_ignore0"]) and np.array_equal(out[n:], g[f"{tag}_mask_ignore0"])
+    out = label_ref.affinities(seg, offs, ignore_label=0, add_mask=True, include_ignore_transitions=True)
+    assert np.array_equal(out[:n], g[f"{tag}_affs_trans"]) and np.array_equal(out[n:], g[f"{tag}_mask_trans"])

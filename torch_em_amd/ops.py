@@ -54,6 +54,13 @@ def _prof_end(t, ev0, tag, flops):
 
 
 def _stream(t: torch.Tensor):
+    """The stream the launch goes to: torch's current stream of the TENSOR's device.  A HIP launch is issued on the
+    calling thread's current device, so that device is made current first (one process drives one GPU in this design;
+    a process that touches several -- `DefaultTrainer(device="cuda:1")`, `predict_with_halo(gpu_ids=[1])` -- gets the
+    device of the tensors it passes, like a torch op would)."""
+    idx = t.device.index
+    if idx is not None and idx != torch.cuda.current_device():
+        torch.cuda.set_device(idx)
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
@@ -217,8 +224,9 @@ _ws_cache = {}
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """A per-(device, stream) scratch buffer (grown on demand, reused across calls on the same stream; kernels of
     different streams may run concurrently, so they never share one)."""
+    device = torch.device(device)
     dev = device.index if device.index is not None else torch.cuda.current_device()
-    key = (dev, torch.cuda.current_stream(device).cuda_stream)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

@@ -307,9 +307,14 @@ class DefaultTrainer:
         print(f"The best epoch is number {self._best_epoch}.")
         self.train_time = total_train_time
 
+    def _targets(self, y):
+        """On-device target generation (transform/label.py `BatchTargets`): applied ONCE per batch, so that the loss, the
+        metric and the logger all see the same transformed targets (as they do when the reference's datasets apply
+        `label_transform` in the loader workers, data/segmentation_dataset.py:226-249)."""
+        tt = getattr(self, "target_transform", None)
+        return y if tt is None else tt(y)
+
     def _forward_and_loss(self, x, y):
-        if getattr(self, "target_transform", None) is not None:
-            y = self.target_transform(y)
         pred = self.model(x)
         return pred, self.loss(pred, y)
 
@@ -343,6 +348,7 @@ class DefaultTrainer:
         for x, y in self.train_loader:
             x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
             x, y = self._augment(x, y)
+            y = self._targets(y)
             self.optimizer.zero_grad()
             with self._precision():
                 pred, loss = self._forward_and_loss(x, y)
@@ -364,6 +370,7 @@ class DefaultTrainer:
         with torch.no_grad(), self._precision():
             for x, y in self.val_loader:
                 x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
+                y = self._targets(y)
                 pred, loss = self._forward_and_loss(x, y)
                 metric = self.metric(pred, y)
                 loss_val = loss.detach() if loss_val is None else loss_val + loss.detach()

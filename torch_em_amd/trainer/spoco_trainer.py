@@ -36,12 +36,29 @@ class SPOCOTrainer(DefaultTrainer):
         p1 = [p for p in self.model.parameters()]
         if not p1 or not p1[0].is_cuda:
             raise RuntimeError("SPOCOTrainer._momentum_update runs on MI355X only (parameters are on the CPU)")
-        if self._arena1 is None or not self._arena1.is_current():
-            self._arena1 = ParamArena(self.model)
         if self._arena2 is None or not self._arena2.is_current():
             self._arena2 = ParamArena(self.model2)
-        ops.ema_update(self._arena2.flat, self._arena1.flat, float(self.momentum))
+        src = self._student_flat(p1)
+        if src is not None:
+            ops.ema_update(self._arena2.flat, src, float(self.momentum))
+        else:  # no shared flat buffer (foreign optimizer layout): one launch per tensor, nothing is re-homed
+            for q, p in zip(self._arena2.params, p1):
+                ops.ema_update(q.data.view(-1), p.data.contiguous().view(-1), float(self.momentum))
         ops.bump_versions(self._arena2.params)
+
+    def _student_flat(self, params):
+        """The student's flat parameter buffer WITHOUT re-homing its parameters a second time: FusedAdamW already keeps
+        them in one arena (optim.py); building another ParamArena over the same tensors would invalidate that one, and
+        the two would rebuild each other (and every packed weight) on every step."""
+        ar = getattr(self.optimizer, "_arena", None)
+        if ar is not None and ar.is_current() and len(ar.params) == len(params) and \
+                all(a is b for a, b in zip(ar.params, params)):
+            return ar.flat
+        if hasattr(self.optimizer, "_ensure_arena"):
+            return None  # a FusedAdamW over a different parameter list: leave its arena alone
+        if self._arena1 is None or not self._arena1.is_current():
+            self._arena1 = ParamArena(self.model)
+        return self._arena1.flat
 
     def save_checkpoint(self, name, current_metric, best_metric, **extra_save_dict):
         super().save_checkpoint(name, current_metric, best_metric, model2_state=self.model2.state_dict(),
@@ -78,6 +95,7 @@ class SPOCOTrainer(DefaultTrainer):
         for x, y in self.train_loader:
             x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
             x, y = self._augment(x, y)
+            y = self._targets(y)
             prediction, loss = self._step(x, self.loss, y)
             if self.logger is not None:
                 lr = [pm["lr"] for pm in self.optimizer.param_groups][0]
@@ -101,6 +119,7 @@ class SPOCOTrainer(DefaultTrainer):
         with torch.no_grad(), self._precision():
             for x, y in self.val_loader:
                 x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
+                y = self._targets(y)
                 prediction, prediction2 = self.model(x), self.model2(x)
                 lv = self.loss((prediction, prediction2), y).detach()
                 mv = self.metric(prediction, y).detach()
