@@ -408,6 +408,12 @@ int tem_affinity_side(const float* emb, int64_t cs, const int64_t* labels, int D
  * grid units; the warp applies the same field to `planes` [H][W] planes (bilinear, or nearest for labels). */
 int tem_flip3d(const void* src, void* dst, const int* flags_dev, int N, int planes, int D, int H, int W,
                tem_stream_t stream);
+/* tem_affine_warp3d: the resampling pass of kornia RandomAffine3D / RandomRotation3D (transform/augmentation.py:235,240;
+ * kornia absent: parity unpinned).  src/dst [N][planes][D][H][W] float; mat_dev device float [N][12]: the 3x4 row-major
+ * map from an OUTPUT voxel (x, y, z, 1) to its SOURCE position (sx, sy, sz), composed on the host from the drawn
+ * angles / scales; trilinear (nearest != 0: nearest neighbour, for labels), zeros outside the volume. */
+int tem_affine_warp3d(const float* src, const float* mat_dev, float* dst, int N, int planes, int D, int H, int W,
+                      int nearest, tem_stream_t stream);
 int tem_elastic_field(const float* noise, const float* gauss1d, int ksize, int H, int W, float alpha0, float alpha1,
                       float* disp, tem_stream_t stream);
 int tem_elastic_warp2d(const float* src, const float* disp, float* dst, int64_t planes, int H, int W, int nearest,

@@ -46,3 +46,22 @@ def elastic_warp(planes, disp, nearest=False):
 def flip(x, fz, fy, fx):
     dims = [d for d, f in zip((-3, -2, -1), (fz, fy, fx)) if f]
     return torch.flip(x, dims) if dims else x.clone()
+
+
+def affine_warp3d(x, inv_mats, nearest=False):
+    """x [N,C,D,H,W], inv_mats [N,3,4] (output voxel (x,y,z,1) -> source position, voxel units) -> warped x.
+    PARITY UNPINNED (kornia's warp_affine3d is absent).  Independent of the HIP kernel's arithmetic: the voxel-space map
+    is re-expressed in normalised coordinates and resampled by F.affine_grid + F.grid_sample(align_corners=True,
+    padding_mode="zeros"), for which x_norm = 2 x / (size - 1) - 1."""
+    n, c, d, h, w = x.shape
+    size = torch.tensor([w, h, d], dtype=torch.float64)
+    to_norm = torch.diag(torch.cat([2.0 / (size - 1).clamp(min=1), torch.ones(1, dtype=torch.float64)]))
+    to_norm[:3, 3] = -1.0
+    from_norm = torch.linalg.inv(to_norm)
+    theta = []
+    for i in range(n):
+        a = torch.eye(4, dtype=torch.float64)
+        a[:3] = inv_mats[i].double()
+        theta.append((to_norm @ a @ from_norm)[:3])
+    grid = F.affine_grid(torch.stack(theta).float(), [n, c, d, h, w], align_corners=True)
+    return F.grid_sample(x, grid, mode="nearest" if nearest else "bilinear", padding_mode="zeros", align_corners=True)

@@ -68,3 +68,33 @@ def test_elastic_2d_runs_like_reference_test():
     x = torch.rand(1, 1, 64, 64)
     xt = KorniaAugmentationPipeline(deform)(x.cuda())[0]
     assert xt.shape == x.shape and torch.isfinite(xt).all()
+
+
+def test_affine3d_warp_vs_oracle_and_replay_on_labels():
+    """RandomAffine3D / RandomRotation3D (reference transform/augmentation.py:235,240): one trilinear pass for the image,
+    the same drawn parameters replayed with nearest interpolation on the labels; against the torch-CPU restatement."""
+    from oracle import augment_ref
+    from torch_em_amd.transform import KorniaAugmentationPipeline, RandomAffine3D, RandomRotation3D, get_augmentations
+    torch.manual_seed(3)
+    x = torch.randn(3, 2, 12, 20, 16)
+    lbl = torch.randint(0, 7, (3, 1, 12, 20, 16))
+    aug = RandomAffine3D((90, 90, 90), scale=(0.6, 1.1), p=1.0)
+    xt, lt = KorniaAugmentationPipeline(aug)(x.cuda(), lbl.cuda())
+    inv = RandomAffine3D.inverse_matrices(aug._params, x.shape)
+    assert float((inv[:, :, :3] - torch.eye(3, dtype=torch.float64)).abs().max()) > 0.1   # not the identity
+    want = augment_ref.affine_warp3d(x, inv)
+    assert float((xt.cpu() - want).abs().max()) < 2e-4      # fp32 coordinates x image gradient, like the elastic warp
+    want_l = augment_ref.affine_warp3d(lbl.float(), inv, nearest=True)
+    assert float((lt.cpu() != want_l).float().mean()) < 5e-3      # rounding ties of the nearest neighbour
+    assert set(torch.unique(lt).tolist()) <= set(range(7))
+    # p = 0: identity, bit for bit; rotation by 90 degrees about z maps the volume onto itself exactly (W == H)
+    same = KorniaAugmentationPipeline(RandomRotation3D((90, 90, 90), p=0.0))(x.cuda())[0]
+    assert torch.equal(same.cpu(), x)
+    sq = torch.randn(1, 1, 4, 9, 9)
+    rot = RandomRotation3D(((90, 90), (0, 0), (0, 0)), p=1.0)
+    got = KorniaAugmentationPipeline(rot)(sq.cuda())[0].cpu()
+    assert float((got - torch.rot90(sq, 1, (-2, -1))).abs().max()) < 1e-5 or \
+        float((got - torch.rot90(sq, -1, (-2, -1))).abs().max()) < 1e-5
+    # by name, as the reference's get_augmentations does
+    pipe = get_augmentations(3, transforms=["RandomRotation3D", "RandomHorizontalFlip3D"])
+    assert pipe(x.cuda())[0].shape == x.shape and pipe.halo == [32, 32, 32]

@@ -587,3 +587,30 @@ def test_affinity_targets_match_the_reference_definitions(tag):
     assert np.array_equal(out[:n], g[f"{tag}_affs_ignore0"]) and np.array_equal(out[n:], g[f"{tag}_mask_ignore0"])
     out = AffinityTransform(offs, ignore_label=0, add_mask=True, include_ignore_transitions=True)(ld).cpu().numpy()
     assert np.array_equal(out[:n], g[f"{tag}_affs_trans"]) and np.array_equal(out[n:], g[f"{tag}_mask_trans"])
+
+
+def test_masked_dice_broadcast_mask_and_ignore_label():
+    """The fused DiceLoss-behind-a-multiply-mask path accepts what the reference broadcasts: a mask with a singleton channel
+    axis, and MaskIgnoreLabel's boolean mask of a non-contiguous target (test/loss/test_loss_wrapper.py:36-87)."""
+    from torch_em_amd.loss import ApplyMask, DiceLoss, LossWrapper, MaskIgnoreLabel
+    torch.manual_seed(0)
+    p = torch.rand(2, 3, 8, 12, 12, device=DEV, requires_grad=True)
+    t = torch.rand(2, 3, 8, 12, 12, device=DEV)
+    m1 = (torch.rand(2, 1, 8, 12, 12, device=DEV) > 0.4)
+    got = LossWrapper(DiceLoss(), ApplyMask("multiply"))(p, t, mask=m1)
+    got.backward()
+    pr = p.detach().cpu().double().requires_grad_(True)
+    mm = m1.cpu().double()
+    num = ((pr * mm) * (t.cpu().double() * mm)).transpose(0, 1).flatten(1).sum(1)
+    den = ((pr * mm) ** 2).transpose(0, 1).flatten(1).sum(1) + ((t.cpu().double() * mm) ** 2).transpose(0, 1).flatten(1).sum(1)
+    want = (1.0 - 2 * num / den.clamp(min=1e-7)).sum()
+    want.backward()
+    assert abs(float(got) - float(want)) < 1e-5
+    assert rel_err(p.grad.cpu(), pr.grad) < 1e-4 and float(p.grad[(~m1).expand_as(p)].abs().max()) == 0.0
+    # MaskIgnoreLabel on a channel-sliced (non-contiguous) target
+    big = torch.rand(2, 5, 8, 12, 12, device=DEV)
+    tt = big[:, 1:4]
+    tt[torch.rand_like(tt) > 0.7] = -1
+    p.grad = None
+    LossWrapper(DiceLoss(), MaskIgnoreLabel(-1, "multiply"))(p, tt).backward()
+    assert float(p.grad[tt == -1].abs().max()) == 0.0 and float(p.grad[tt != -1].abs().max()) > 0.0

@@ -223,3 +223,33 @@ def test_util_helpers(tmp_path):
     kw = util.get_constructor_arguments(dl)
     assert kw["batch_size"] == 2 and kw["shuffle"] is True and kw["num_workers"] == 0
     assert util.get_constructor_arguments(torch.optim.SGD(m1.parameters(), lr=0.1)) == {}
+
+
+def test_mask_transforms_return_tensors_like_the_reference():
+    """ApplyMask / ApplyAndRemoveMask / MaskIgnoreLabel used directly or behind a non-Dice loss hand over REAL masked
+    tensors (reference loss/wrapper.py:68-183, test/loss/test_loss_wrapper.py); plain torch, so it runs on the CPU."""
+    import torch
+    from torch_em_amd.loss import ApplyAndRemoveMask, ApplyMask, LossWrapper, MaskIgnoreLabel
+    torch.manual_seed(0)
+    shape = (1, 1, 16, 16)
+    x, y = torch.rand(shape, requires_grad=True), torch.rand(shape)
+    mask = torch.rand(shape) > 0.5
+    for method in ApplyMask.MASKING_FUNCS:
+        p, t = ApplyMask(method)(x, y, mask=mask)
+        assert torch.is_tensor(p) and torch.is_tensor(t)
+        if method == "multiply":
+            assert torch.equal(p, x * mask) and torch.equal(t, y * mask)
+        else:
+            assert p.shape == (int(mask.sum()), 1)
+        loss = LossWrapper(torch.nn.MSELoss(), ApplyAndRemoveMask(method))
+        x.grad = None
+        loss(x, torch.cat([y, mask.to(y.dtype)], 1)).backward()
+        assert (x.grad[~mask] == 0).all() and not (x.grad[mask] == 0).all()
+        yi = y.clone()
+        yi[mask] = -1
+        x.grad = None
+        LossWrapper(torch.nn.MSELoss(), MaskIgnoreLabel(-1, method))(x, yi).backward()
+        assert (x.grad[mask] == 0).all() and not (x.grad[~mask] == 0).all()
+        x.grad = None
+        LossWrapper(torch.nn.L1Loss(), ApplyMask(method))(x, y, mask=mask).backward()
+        assert (x.grad[~mask] == 0).all()

@@ -100,6 +100,7 @@ SIGNATURES = {
     "tem_affinity_side": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int, c_float,
                                   c_float, c_vp, c_float, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "tem_flip3d": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tem_affine_warp3d": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tem_elastic_field": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_float, c_float, c_vp, c_vp]),
     "tem_elastic_warp2d": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
     "tem_block_load_reflect": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int] + [ctypes.POINTER(c_int)] * 4 + [c_vp]),

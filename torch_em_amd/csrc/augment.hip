@@ -141,3 +141,71 @@ extern "C" int tem_elastic_warp2d(const float* src, const float* disp, float* ds
     TEM_CHECK_LAUNCH("tem_elastic_warp2d");
     return TEM_OK;
 }
+
+// ---------------------------------------------------------------------------
+// 3-D affine warp: kornia RandomAffine3D / RandomRotation3D (reference transform/augmentation.py:235,240 configures them
+// with degrees=(90,90,90), scale=(0.0,1.1)).  kornia draws the parameters, composes a 4x4 matrix about the volume
+// centre and resamples with warp_affine3d; here the host composes the matrix from the drawn (or injected) parameters
+// and hands over its INVERSE in voxel coordinates: mat[n] = 3x4 row-major, (sx, sy, sz) = A * (x, y, z, 1) maps an
+// output voxel to its source position.  One pass: trilinear for images, nearest for labels, zeros outside
+// (kornia's padding_mode="zeros").  kornia is not in this image: parity unpinned (oracle/augment_ref.py:affine_warp3d
+// restates the resampling with F.affine_grid / F.grid_sample).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_affine_warp3d(const float* __restrict__ src, const float* __restrict__ mat,
+                                                       float* __restrict__ dst, int planes, int D, int H, int W,
+                                                       int nearest, int64_t total) {
+    const int64_t dhw = (int64_t)D * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        int64_t r = i / W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int z = (int)(r % D);
+        const int n = (int)(r / D);
+        const float* A = mat + n * 12;
+        const float sx = fmaf(A[0], x, fmaf(A[1], y, fmaf(A[2], z, A[3])));
+        const float sy = fmaf(A[4], x, fmaf(A[5], y, fmaf(A[6], z, A[7])));
+        const float sz = fmaf(A[8], x, fmaf(A[9], y, fmaf(A[10], z, A[11])));
+        const float* s0 = src + (int64_t)n * planes * dhw;
+        float* d0 = dst + (int64_t)n * planes * dhw + ((int64_t)z * H + y) * W + x;
+        if (nearest) {
+            const int nx = (int)nearbyintf(sx), ny = (int)nearbyintf(sy), nz = (int)nearbyintf(sz);
+            const bool in = nx >= 0 && nx < W && ny >= 0 && ny < H && nz >= 0 && nz < D;
+            const int64_t off = in ? ((int64_t)nz * H + ny) * W + nx : 0;
+            for (int c = 0; c < planes; ++c) d0[c * dhw] = in ? s0[c * dhw + off] : 0.f;
+            continue;
+        }
+        const float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+        const float wx = sx - fx, wy = sy - fy, wz = sz - fz;
+        // 8 corners: clamped addresses + zero weights outside, so the loads of one voxel are independent
+        float wgt[8];
+        int64_t off[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cx = x0 + (k & 1), cy = y0 + ((k >> 1) & 1), cz = z0 + (k >> 2);
+            const bool in = cx >= 0 && cx < W && cy >= 0 && cy < H && cz >= 0 && cz < D;
+            wgt[k] = in ? ((k & 1) ? wx : 1.f - wx) * (((k >> 1) & 1) ? wy : 1.f - wy) * ((k >> 2) ? wz : 1.f - wz) : 0.f;
+            off[k] = ((int64_t)min(max(cz, 0), D - 1) * H + min(max(cy, 0), H - 1)) * W + min(max(cx, 0), W - 1);
+        }
+        for (int c = 0; c < planes; ++c) {
+            const float* s = s0 + c * dhw;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v = fmaf(s[off[k]], wgt[k], v);
+            d0[c * dhw] = v;
+        }
+    }
+}
+
+extern "C" int tem_affine_warp3d(const float* src, const float* mat_dev, float* dst, int N, int planes, int D, int H, int W,
+                                 int nearest, tem_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TEM_REQUIRE(src && mat_dev && dst && src != dst, "tem_affine_warp3d: null pointer or in-place call");
+    TEM_REQUIRE(N > 0 && planes > 0 && D > 0 && H > 0 && W > 0, "tem_affine_warp3d: bad sizes");
+    const int64_t total = (int64_t)N * D * H * W;
+    hipLaunchKernelGGL(k_affine_warp3d, dim3(tem_grid_1d(total, 256)), dim3(256), 0, s, src, mat_dev, dst, planes, D, H, W,
+                       nearest, total);
+    TEM_CHECK_LAUNCH("tem_affine_warp3d");
+    return TEM_OK;
+}

@@ -26,10 +26,30 @@
 #ifndef TEM_PP_PRIO
 #define TEM_PP_PRIO 1    // s_setprio of the team in its MFMA phase
 #endif
+#ifndef TEM_PP_ABL
+#define TEM_PP_ABL 0     // harness-only ablations (scripts/pp_harness.cpp): 1 no halo loads, 2 no stores, 4 no weight loads in
+#endif                   // the tap loop, 8 no split / LDS writes, 16 no MFMAs
 
 struct PpUnit {
     int cot, n, z0, y0, x0;
 };
+
+#ifdef TEM_PP_TRACE   // developer build (scripts/pp_harness.cpp): shader-clock stamps of the phases of one workgroup
+#ifndef TEM_PP_TRACE_BLOCK
+#define TEM_PP_TRACE_BLOCK 0
+#endif
+__device__ unsigned long long tem_pp_trace_buf[2][64][8];
+#define PP_STAMP(i)                                                                           \
+    do {                                                                                      \
+        if (blockIdx.x == TEM_PP_TRACE_BLOCK && tw == 0 && lane == 0 && s < 64)               \
+            tem_pp_trace_buf[team][s][i] = __builtin_amdgcn_s_memtime();                      \
+    } while (0)
+void tem_pp_trace_read(unsigned long long* dst) {
+    (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(tem_pp_trace_buf), sizeof(unsigned long long) * 2 * 64 * 8);
+}
+#else
+#define PP_STAMP(i)
+#endif
 
 // KD,KH,KW kernel; TZ,TY,TX voxel patch of a TEAM; CT 32-column tiles per team; WN waves side by side over the
 // columns (WM = 4 / WN waves over the voxels); NS planes per operand; F16: fp16 terms with prescaled operands
@@ -113,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
             // ================= staging phase (the partner team runs its tap loop) =================
             const bool do_epi = s >= 1 && s - 1 < my_steps && (s - 1) % nch == nch - 1;
             const bool do_stage = s < my_steps;
+            PP_STAMP(0);
             // ---- issue the halo loads of step s first: they fly during the epilogue of the previous unit ----
             float4 tmp[NIT];
             unsigned inb = 0;
@@ -140,7 +161,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                     inb |= ok ? (1u << it) : 0u;
                     const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
                     const unsigned off = (unsigned)(((cz - zlo) * H + cy) * W + cx) * (unsigned)x_ld + (unsigned)(c4 * 4);
-                    tmp[it] = *reinterpret_cast<const float4*>(xb + off);
+                    if (TEM_PP_ABL & 1)
+                        tmp[it] = make_float4(0.5f + it, 0.25f, -1.f, 2.f);
+                    else
+                        tmp[it] = *reinterpret_cast<const float4*>(xb + off);
                 }
             }
             // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
@@ -180,7 +204,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                             if ((okm >> reg) & 1u) {
                                 ssum[nn] += o;
                                 ssq[nn] = fmaf(o, o, ssq[nn]);
-                                __builtin_nontemporal_store(o, yb + (vox[reg] * (unsigned)y_ld + (unsigned)co));
+                                if (!(TEM_PP_ABL & 2) || o == 12345.678f)
+                                    __builtin_nontemporal_store(o, yb + (vox[reg] * (unsigned)y_ld + (unsigned)co));
                             }
                             acc[m][nn][reg] = 0.f;  // the next unit of this team starts from zero
                         }
@@ -202,6 +227,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                     }
                 }
             }
+            PP_STAMP(1);
             // ---- norm, split, LDS tile; then prime the weight-fragment ring of the coming tap loop ----
             if (do_stage) {
 #pragma unroll
@@ -219,7 +245,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
 #pragma unroll
                         for (int p = 0; p < NS; ++p) {
                             const unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
-                            *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
+                            if (!(TEM_PP_ABL & 8) || h0 == 0x12345678u)
+                                *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
                             if (p + 1 < NS) {
                                 e[0] -= lo16<F16>(h0);
                                 e[1] -= hi16<F16>(h0);
@@ -241,9 +268,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                             for (int p = 0; p < NS; ++p) bq[gp][nn][p] = wq[nn][gp * tapstride + p * 64];
                 }
             }
+            PP_STAMP(2);
         }
         __syncthreads();
         {
+            PP_STAMP(3);
             // ================= MFMA phase: 27 taps of one 16-channel chunk out of this team's tile =================
             if (s < my_steps) {
                 int ts = tapstride;
@@ -270,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                             for (int p = 0; p < NS; ++p)
                                 af[t1 & 1][m][p] = *reinterpret_cast<const uint4*>(lds + abase[m] + toff + p * 8);
                     }
-                    if (tap + RD - 1 < NT) {
+                    if (tap + RD - 1 < NT && !(TEM_PP_ABL & 4)) {
                         const int gp = tap + RD - 1;
 #pragma unroll
                         for (int nn = 0; nn < NW; ++nn)
@@ -286,15 +315,23 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
 #pragma unroll
                             for (int sum = NS - 1; sum >= 0; --sum)
 #pragma unroll
-                                for (int i = 0; i <= sum; ++i)
+                                for (int i = 0; i <= sum; ++i) {
+                                    if (TEM_PP_ABL & 16) {
+                                        asm volatile("" ::"v"(af[tap & 1][m][i].x), "v"(af[tap & 1][m][i].w),
+                                                     "v"(bq[tap % RD][nn][sum - i].x), "v"(bq[tap % RD][nn][sum - i].w));
+                                        continue;
+                                    }
                                     acc[m][nn] = mfma16<F16>(af[tap & 1][m][i], bq[tap % RD][nn][sum - i], acc[m][nn]);
+                                }
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (TEM_PP_PRIO) __builtin_amdgcn_s_setprio(0);
             }
+            PP_STAMP(4);
         }
         __syncthreads();
+        PP_STAMP(5);
     }
     if (!team) __syncthreads();
 }

@@ -16,13 +16,6 @@ import torch.nn as nn
 from .dice import DiceLoss
 
 
-class _Masked:
-    """prediction/target pair plus a multiplicative mask that the loss kernel applies itself."""
-
-    def __init__(self, prediction, target, mask):
-        self.prediction, self.target, self.mask = prediction, target, mask
-
-
 def _crop(prediction, target, mask, channel_dim):
     if mask.shape[channel_dim] != 1:
         raise ValueError(
@@ -35,7 +28,9 @@ def _crop(prediction, target, mask, channel_dim):
 
 
 def _multiply(prediction, target, mask, channel_dim):
-    return _Masked(prediction, target, mask), None
+    prediction = prediction * mask
+    target = target * mask
+    return prediction, target
 
 
 class ApplyMask:
@@ -50,7 +45,14 @@ class ApplyMask:
         self.channel_dim = channel_dim
         self.init_kwargs = {"masking_method": masking_method, "channel_dim": channel_dim}
 
-    def __call__(self, prediction, target, mask):
+    def split(self, prediction, target, mask=None):
+        """(prediction, target, mask) BEFORE masking: what LossWrapper hands to a loss kernel that multiplies on the fly."""
+        if mask is None:
+            raise TypeError("ApplyMask needs a mask: loss(prediction, target, mask=...)")
+        return prediction, target, mask
+
+    def __call__(self, prediction, target, mask=None):
+        prediction, target, mask = self.split(prediction, target, mask)
         mask.requires_grad = False
         return self.masking_func(prediction, target, mask, self.channel_dim)
 
@@ -58,12 +60,12 @@ class ApplyMask:
 class ApplyAndRemoveMask(ApplyMask):
     """The target carries the mask in its second half of channels (reference :129-152)."""
 
-    def __call__(self, prediction, target):
+    def split(self, prediction, target, mask=None):
         assert target.dim() == prediction.dim(), f"{target.dim()}, {prediction.dim()}"
         assert target.size(1) == 2 * prediction.size(1), f"{target.size(1)}, {prediction.size(1)}"
         assert target.shape[2:] == prediction.shape[2:], f"{str(target.shape)}, {str(prediction.shape)}"
         sep = target.size(1) // 2
-        return super().__call__(prediction, target[:, :sep], target[:, sep:])
+        return prediction, target[:, :sep], target[:, sep:]
 
 
 class MaskIgnoreLabel(ApplyMask):
@@ -74,9 +76,8 @@ class MaskIgnoreLabel(ApplyMask):
         self.ignore_label = ignore_label
         self.init_kwargs["ignore_label"] = ignore_label
 
-    def __call__(self, prediction, target):
-        mask = (target != self.ignore_label)
-        return super().__call__(prediction, target, mask)
+    def split(self, prediction, target, mask=None):
+        return prediction, target, (target != self.ignore_label)
 
 
 class LossWrapper(nn.Module):
@@ -90,15 +91,17 @@ class LossWrapper(nn.Module):
         self.transform = transform
         self.init_kwargs = {"loss": loss, "transform": transform}
 
-    def _call_loss(self, prediction, target):
-        if isinstance(prediction, _Masked):
-            m = prediction
-            if isinstance(self.loss, DiceLoss):
-                return self.loss(m.prediction, m.target, mask=m.mask.to(m.prediction.dtype))
-            # any other loss: materialise the masked tensors like the reference does
-            mask = m.mask.to(m.prediction.dtype)
-            return self.loss(m.prediction * mask, m.target * mask)
-        return self.loss(prediction, target)
+    def _fused(self, prediction, target, kwargs):
+        """DiceLoss behind a multiply-mask transform: the Dice kernel applies the mask itself (no masked temporaries)."""
+        if not (isinstance(self.loss, DiceLoss) and isinstance(self.transform, ApplyMask) and
+                self.transform.masking_method == "multiply" and torch.is_tensor(prediction) and prediction.is_cuda):
+            return None
+        prediction, target, mask = self.transform.split(prediction, target, **kwargs)
+        mask = mask.to(prediction.dtype)
+        if mask.shape != target.shape or mask.stride() != target.stride():
+            # a broadcast mask (singleton channel) or a differently laid out one: give it the target's layout
+            mask = torch.empty_like(target).copy_(mask.expand_as(target))
+        return self.loss(prediction, target, mask=mask)
 
     def apply_transform(self, prediction, target, **kwargs):
         if isinstance(prediction, (list, tuple)):
@@ -108,7 +111,8 @@ class LossWrapper(nn.Module):
         return self.transform(prediction, target, **kwargs)
 
     def forward(self, prediction, target, **kwargs):
+        fused = self._fused(prediction, target, kwargs)
+        if fused is not None:
+            return fused
         prediction, target = self.apply_transform(prediction, target, **kwargs)
-        if isinstance(prediction, list):
-            raise NotImplementedError("list-valued predictions need a loss that accepts lists (as in the reference)")
-        return self._call_loss(prediction, target)
+        return self.loss(prediction, target)

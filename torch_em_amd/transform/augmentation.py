@@ -11,8 +11,9 @@ classes carry kornia's names and (p, same_on_batch) arguments, random decisions 
 
 Parameter replay: like the reference (:212-220) the first tensor draws the parameters and every further tensor
 (labels) replays them, with NEAREST interpolation for non-float inputs; everything is returned as `dtype`.
-Only the augmentations of the reference's default pipelines and its two elastic classes exist here (affine /
-rotation augmentations raise NotImplementedError).
+Besides the reference's default pipelines and its two elastic classes, the 3-D affine / rotation augmentations it lists
+(`RandomAffine3D`, `RandomRotation3D`, :235,240) run as one trilinear / nearest warp pass per tensor (`tem_affine_warp3d`);
+the 2-D `RandomAffine` / `RandomRotation` raise NotImplementedError.
 """
 from typing import List, Sequence, Tuple, Union
 
@@ -72,6 +73,93 @@ class RandomHorizontalFlip(_RandomFlip):
 
 class RandomVerticalFlip(_RandomFlip):
     axis, spatial = -2, 2
+
+
+def _pair(v, name):
+    if isinstance(v, (int, float)):
+        return (-float(v), float(v))
+    v = tuple(float(a) for a in v)
+    if len(v) != 2:
+        raise ValueError(f"{name}: expected a number or a (min, max) pair, got {v}")
+    return v
+
+
+class RandomAffine3D(torch.nn.Module):
+    """Random 3-D rotation about the volume centre + isotropic scaling, one pass on the device (kornia's
+    `RandomAffine3D(degrees, translate=None, scale=None, ...)`; the reference configures degrees=(90,90,90),
+    scale=(0.0,1.1), transform/augmentation.py:235).  `degrees`: one number d (each angle in [-d, d]), a triple of such
+    numbers, or a triple of (min, max) pairs, for yaw (about z = the D axis), pitch (about y) and roll (about x);
+    `scale`: (min, max) of the isotropic zoom or None; `translate`: fractions of (W, H, D) or None.  Parameters are drawn
+    per sample from the torch CPU generator (`same_on_batch=False`) and replayed on the label tensors with nearest
+    interpolation.  kornia is not in this image: the composition order (R = Rz(yaw) Ry(pitch) Rx(roll), centre (size-1)/2,
+    zeros outside) is this build's definition -- parity unpinned."""
+    spatial = 3
+    min_scale = 1e-3  # a drawn scale of 0 (allowed by the reference's (0.0, 1.1)) has no inverse map
+
+    def __init__(self, degrees, translate=None, scale=None, shears=None, resample="bilinear", same_on_batch: bool = False,
+                 align_corners: bool = False, p: float = 0.5, keepdim: bool = False):
+        super().__init__()
+        if shears is not None:
+            raise NotImplementedError("RandomAffine3D: shears have no MI355X kernel parameters")
+        if isinstance(degrees, (int, float)):
+            degrees = (degrees,) * 3
+        self.degrees = tuple(_pair(d, "degrees") for d in degrees)
+        if len(self.degrees) != 3:
+            raise ValueError("degrees: expected 3 entries (yaw, pitch, roll)")
+        self.scale = None if scale is None else _pair(scale, "scale")
+        self.translate = None if translate is None else tuple(float(t) for t in translate)
+        self.p, self.same_on_batch, self.keepdim = p, same_on_batch, keepdim
+        self.flags = dict(interpolation=resample, align_corners=align_corners)
+        self._params = None
+
+    def generate_parameters(self, batch_shape):
+        n = batch_shape[0]
+        m = 1 if self.same_on_batch else n
+
+        def draw(lo, hi):
+            return (torch.rand(m, dtype=torch.float64) * (hi - lo) + lo).expand(n).clone()
+        apply = (torch.rand(m) < self.p).expand(n).clone()
+        angles = torch.stack([draw(*d) for d in self.degrees], 1)
+        scale = draw(*self.scale) if self.scale is not None else torch.ones(n, dtype=torch.float64)
+        if self.translate is not None:
+            dims = (batch_shape[-1], batch_shape[-2], batch_shape[-3])
+            trans = torch.stack([draw(-t * s, t * s) for t, s in zip(self.translate, dims)], 1)
+        else:
+            trans = torch.zeros(n, 3, dtype=torch.float64)
+        return {"batch_prob": apply, "angles": angles, "scale": scale, "translations": trans}
+
+    @classmethod
+    def inverse_matrices(cls, params, shape) -> torch.Tensor:
+        """[N, 3, 4] float64: output voxel (x, y, z, 1) -> source position, for the drawn parameters."""
+        D, H, W = shape[-3:]
+        n = params["angles"].shape[0]
+        out = torch.zeros(n, 3, 4, dtype=torch.float64)
+        c = torch.tensor([(W - 1) / 2.0, (H - 1) / 2.0, (D - 1) / 2.0], dtype=torch.float64)
+        for i in range(n):
+            if not bool(params["batch_prob"][i]):
+                out[i, :, :3] = torch.eye(3, dtype=torch.float64)
+                continue
+            yaw, pitch, roll = [float(a) * np.pi / 180.0 for a in params["angles"][i]]
+            cz, sz, cy, sy, cx, sx = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+            rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=torch.float64)
+            ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=torch.float64)
+            rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=torch.float64)
+            fwd = (rz @ ry @ rx) * max(float(params["scale"][i]), cls.min_scale)   # dst = fwd (src - c) + c + t
+            inv = torch.linalg.inv(fwd)
+            out[i, :, :3] = inv
+            out[i, :, 3] = c - inv @ (c + params["translations"][i])
+        return out
+
+    def forward(self, input: torch.Tensor, params=None) -> torch.Tensor:
+        return KorniaAugmentationPipeline(self, dtype=input.dtype)._run([input], [params])[0]
+
+
+class RandomRotation3D(RandomAffine3D):
+    """kornia `RandomRotation3D(degrees)` (reference :240: degrees=(90,90,90)): RandomAffine3D without scale / shift."""
+
+    def __init__(self, degrees, resample="bilinear", same_on_batch: bool = False, align_corners: bool = False,
+                 p: float = 0.5, keepdim: bool = False):
+        super().__init__(degrees, None, None, None, resample, same_on_batch, align_corners, p, keepdim)
 
 
 def _gauss1d(ksize: int, sigma: float) -> torch.Tensor:
@@ -154,14 +242,19 @@ class KorniaAugmentationPipeline(torch.nn.Module):
     def __init__(self, *kornia_augmentations, dtype: Union[str, torch.dtype] = torch.float32):
         super().__init__()
         for aug in kornia_augmentations:
-            if not isinstance(aug, (_RandomFlip, _ElasticBase)):
-                raise NotImplementedError(f"{type(aug).__name__} has no MI355X kernel (flips and elastic deformations do)")
+            if not isinstance(aug, (_RandomFlip, _ElasticBase, RandomAffine3D)):
+                raise NotImplementedError(f"{type(aug).__name__} has no MI355X kernel (flips, elastic deformations and "
+                                          "3-D affine / rotation warps do)")
         self.augmentations = torch.nn.ModuleList(kornia_augmentations)
         self.dtype = dtype
         self.halo = self.compute_halo()
 
     def compute_halo(self):
-        return None  # only the rotation augmentations of the reference need one (:174-183)
+        """The fixed 32-pixel hint the reference gives for rotations (:174-183; unused by its datasets)."""
+        for aug in self.augmentations:
+            if isinstance(aug, RandomAffine3D):
+                return [32, 32, 32]
+        return None
 
     def is_interpolatable(self, tensor):
         if torch.is_tensor(tensor):
@@ -208,6 +301,22 @@ class KorniaAugmentationPipeline(torch.nn.Module):
                                               t.shape[-1], ops._stream(t)), "tem_flip3d")
                     out.append(dst)
                 work = out
+            elif isinstance(aug, RandomAffine3D):
+                given = params_in[i] if params_in is not None and i < len(params_in) else None
+                params = given if given is not None else aug.generate_parameters(shape)
+                aug._params = params
+                mats = aug.inverse_matrices(params, shape).to(torch.float32).reshape(N, 12).to(work[0].device)
+                out = []
+                for t, ip in zip(work, interp):
+                    assert t.shape[0] == N and t.shape[2:] == shape[2:], "all tensors must share batch and spatial shape"
+                    nearest = not (ip and aug.flags["interpolation"] in ("bilinear", 1))
+                    dst = torch.empty_like(t)
+                    _lib.check(lib.tem_affine_warp3d(ops._p(t), ops._p(mats), ops._p(dst), N, t.shape[1], t.shape[2],
+                                                     t.shape[3], t.shape[4], int(nearest), ops._stream(t)),
+                               "tem_affine_warp3d")
+                    out.append(dst)
+                work = out
+                i += 1
             else:
                 given = params_in[i] if params_in is not None and i < len(params_in) else None
                 params = given if given is not None else aug.generate_parameters(shape)
@@ -231,6 +340,8 @@ class KorniaAugmentationPipeline(torch.nn.Module):
 
 
 AUGMENTATIONS = {
+    "RandomAffine3D": {"degrees": (90, 90, 90), "scale": (0.0, 1.1)},
+    "RandomRotation3D": {"degrees": (90, 90, 90)},
     "RandomDepthicalFlip3D": {},
     "RandomHorizontalFlip": {},
     "RandomHorizontalFlip3D": {},
