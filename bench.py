@@ -65,11 +65,10 @@ PRECISION_DTYPE = {
 
 
 def cpu_baseline(max_threads):
-    """Oracle fwd+bwd on the host cores; bounded sample (10-20 s of CPU work): the benchmark model on ONE 1x128^3
-    volume, i.e. half of a cfg-2 batch at the real patch size (same cache behaviour per layer as the full batch).
-    torch's CPU backend does not scale to every hardware thread of a large host (on the 2x64-core
-    EPYC box 16 threads beat 64 by 3x and 256 by 600x), so the thread count is picked by a quick
-    probe on a 32^3 input and the winner is what `cores` reports."""
+    """Oracle fwd+bwd on the host cores on the FULL cfg-2 batch (2x1x128^3): one timed step after a 32^3 thread-count
+    probe (about 20-30 s of CPU work in total).  torch's CPU backend does not scale to every hardware thread of a large
+    host (on the 2x64-core EPYC box 16 threads beat 64 by 3x and 256 by 600x), so the thread count is picked by the
+    probe and the winner is what `cores` reports."""
     from oracle import unet_ref
     from torch_em_amd.model import UNet3d
     torch.manual_seed(0)
@@ -87,19 +86,57 @@ def cpu_baseline(max_threads):
         if best_t is None or dt < best_t:
             best_t, threads = dt, th
     torch.set_num_threads(threads)
-    x = torch.randn(1, 1, 128, 128, 128, generator=g)
-    y = (torch.rand(1, 2, 128, 128, 128, generator=g) > 0.5).float()
-    times = []
-    for i in range(3):
+    x = torch.randn(2, 1, 128, 128, 128, generator=g)
+    y = (torch.rand(2, 2, 128, 128, 128, generator=g) > 0.5).float()
+    t0 = time.perf_counter()
+    unet_ref.unet_loss_and_grads(sd, x, y, [2, 2, 2, 2])
+    dt = time.perf_counter() - t0
+    return {"value": 2 * 128 ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
+            "sample": "oracle (torch-CPU fp32 restatement) zero_grad+fwd+DiceLoss+bwd of the same UNet3d on the full cfg-2 "
+                      f"batch 2x1x128^3, one step, no warm-up at this size: {dt:.2f} s/step (no optimizer step: AdamW is "
+                      "~3 % of the reference's CPU step, BASELINE.md section 2); thread count chosen by a 32^3 probe over "
+                      f"8/16/32/64 of {max_threads} hardware threads"}
+
+
+def extra_measurements(step, args, engine):
+    """Driver-visible numbers for what DESIGN.md claims besides the headline (rank 0, N = 1, after the timed region):
+    the SAME cfg-2 step with exact-fp32 MFMA arithmetic and with the opt-in mixed-precision arithmetic (3 steps each
+    after 2 warm-ups; `step` is the benchmark's own closure, the packed weights follow the precision switch), and the
+    training steps of the other BASELINE configs (scripts/bench_workloads.py).  None of these is `value`."""
+    import importlib.util
+    out = {}
+    prev = engine.PRECISION
+
+    def timed(n=3, w=2):
+        for _ in range(w):
+            step()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        unet_ref.unet_loss_and_grads(sd, x, y, [2, 2, 2, 2])
-        times.append(time.perf_counter() - t0)
-    best = min(times[1:])
-    return {"value": 128 ** 3 / best, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": "oracle (torch-CPU fp32 restatement) fwd+DiceLoss+bwd of the same UNet3d on 1x1x128^3 "
-                      f"(half of one cfg-2 batch), best of 2 after 1 warm-up: {best:.3f} s/step "
-                      f"({sum(times):.1f} s of CPU work); thread count chosen by a 32^3 probe over 8/16/32/64 of "
-                      f"{max_threads} hardware threads"}
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    try:
+        if args.batch == 2 and args.size == 128:
+            for prec, key in (("fp32", "exact_fp32_ms_per_step"), ("amp", "amp_ms_per_step")):
+                engine.set_precision(prec)
+                out[key] = timed()
+        engine.set_precision(prev)
+        spec = importlib.util.spec_from_file_location("bench_workloads", os.path.join(ROOT, "scripts", "bench_workloads.py"))
+        wl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(wl)
+        torch.cuda.empty_cache()
+        for key, fn in (("cfg1_ms_per_step", wl.cfg1), ("cfg3_ms_per_step", wl.cfg3), ("cfg5_ms_per_step", wl.cfg5)):
+            out[key] = fn()["ms_per_step"]
+            torch.cuda.empty_cache()
+        out["extras_note"] = ("exact_fp32 / amp: the cfg-2 step of this run under engine.set_precision('fp32' / 'amp'), 3 steps "
+                              "after 2 warm-ups; cfg1/cfg3/cfg5: BASELINE configs 1, 3, 5 (per-GPU step incl. on-device "
+                              "targets), scripts/bench_workloads.py; all at the engine's default precision unless named")
+    except Exception as e:  # the headline must survive a failing extra
+        out["extras_error"] = f"{type(e).__name__}: {e}"
+    finally:
+        engine.set_precision(prev)
+    return out
 
 
 def self_launch(args_gpus):
@@ -139,6 +176,8 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--norm", default="InstanceNorm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra keys (exact-fp32 / mixed-precision step times of cfg 2, cfg 1/3/5 step times)")
     ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "split", "split16", "bf16x3", "amp"],
                     help="MFMA conv arithmetic (default: engine default = split16)")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table to this file")
@@ -317,6 +356,8 @@ def main():
                 "flops_frac_fp32_mfma": STEP_GFLOP / ms / PEAK_FP32_MFMA_TFLOPS,
                 "hbm_frac_8TBs": (STEP_GB / (ms / 1e3)) / (PEAK_HBM_TBS * 1e3),
                 "note": "5700.8 GFLOP and 25.58 GB algorithmic per step (SURVEY.md 8d); fp32 arithmetic => MFMA-bound"}
+        if world == 1 and not args.no_extras:
+            out.update(extra_measurements(step, args, engine))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
         sys.stdout.flush()

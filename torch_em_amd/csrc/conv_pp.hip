@@ -19,6 +19,7 @@
 #include "tem_common.h"
 #include "conv_internal.h"
 #include "conv_split.h"
+#include <type_traits>
 
 #ifndef TEM_PP_RD
 #define TEM_PP_RD 3      // weight-fragment ring depth over taps
@@ -33,6 +34,7 @@
 struct PpUnit {
     int cot, n, z0, y0, x0;
 };
+typedef float floatx4s __attribute__((ext_vector_type(4)));
 
 #ifdef TEM_PP_TRACE   // developer build (scripts/pp_harness.cpp): shader-clock stamps of the phases of one workgroup
 #ifndef TEM_PP_TRACE_BLOCK
@@ -51,9 +53,17 @@ void tem_pp_trace_read(unsigned long long* dst) {
 #define PP_STAMP(i)
 #endif
 
-// KD,KH,KW kernel; TZ,TY,TX voxel patch of a TEAM; CT 32-column tiles per team; WN waves side by side over the
-// columns (WM = 4 / WN waves over the voxels); NS planes per operand; F16: fp16 terms with prescaled operands
+// KD,KH,KW kernel; TZ,TY,TX voxel patch of a TEAM (TX == 8); CT 32-column tiles per team; WN waves side by side over
+// the columns (WM = 4 / WN waves over the voxels); NS planes per operand; F16: fp16 terms with prescaled operands
 // (TEM_WL_F16X3S, conv_split.h), else bf16 terms.
+//
+// Instruction budget.  A staging phase runs on ONE wave per SIMD (its partner issues MFMAs), so nothing hides its issue
+// latency: the first version spent ~1000 VALU + ~1000 SALU instructions per phase on index arithmetic (halo coordinates,
+// bounds, 64-bit addresses, one 4-byte store per accumulator register) and was bound by exactly that -- the kernel took
+// the same time with the MFMAs removed.  Hence: halo offsets are per-thread constants computed once; a load is
+// "global_load_dwordx4 v, voff, s[base]"; interior patches (72 % at 128^3) skip every bounds operation; the unit is decoded
+// once per patch, not per step; and the epilogue transposes each 32 x 32 accumulator tile through a wave-private LDS
+// scratch so that a lane stores 16 bytes (4 channels of one voxel): 4 coalesced stores per tile instead of 16 partial ones.
 template <int KD, int KH, int KW, int TZ, int TY, int TX, int CT, int WN, int NS, bool F16>
 __global__ __launch_bounds__(512, 2) void k_conv_pp(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -72,8 +82,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
     constexpr int LSV = NS * 8 + 4;             // LDS floats per halo voxel: NS planes of 16 x 16 bit + 16 B pad
     constexpr int RD = NT >= TEM_PP_RD ? TEM_PP_RD : 1;  // weight ring: the slot of a tap is tap % RD (the ring restarts every phase)
     constexpr int FR = NS * 64;                 // uint4s per (tap, 16-channel chunk) fragment group
-    static_assert(PV % (32 * WM) == 0 && CT % WN == 0 && WN * WM == 4, "team tiling");
-    extern __shared__ __attribute__((aligned(16))) float lds_all[];  // [2 teams][HV][LSV]
+    constexpr int SCP = 36;                     // floats per row of the transpose scratch (32 + 4: 16-byte aligned rows)
+    static_assert(PV % (32 * WM) == 0 && CT % WN == 0 && WN * WM == 4 && TX == 8, "team tiling");
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];  // [2 teams][HV][LSV] tiles, [8 waves][32][SCP] scratch
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,6 +92,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
     const int kh = lane >> 5, r = lane & 31;
     const int wm = tw % WM, wn = tw / WM;
     float* lds = lds_all + team * (HV * LSV);
+    float* scr = lds_all + 2 * HV * LSV + wv * (32 * SCP);
 
     // units: (column group, patch) pairs; a team takes every G-th unit starting at its logical slot.  Logical slots
     // are contiguous per XCD (dispatch places block b on XCD b % 8), so the 64 units an XCD works on at any time are
@@ -90,8 +102,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
     const int ncot = Cout / (32 * CT);
     const int nch = Cin >> 4;
     const int my_units = slot < nunits ? (nunits - slot + G - 1) / G : 0;
-    const int my_steps = my_units * nch;
-    const int P = ((nunits + G - 1) / G) * nch;  // steps of the busiest team: every wave runs 2P + 2 phases
+    const int P = ((nunits + G - 1) / G) * nch;  // steps of the busiest team: every wave runs 2P + 3 barriers
 
     auto decode = [&](int ui) {
         int u = slot + ui * G;
@@ -104,6 +115,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
         return t;
     };
 
+    // ---- per-thread constants ----
+    // staging: slot it of this thread is halo voxel hv0 + 64 it, channels c4*4 .. c4*4+3 of the chunk
+    const int c4 = tl & 3, hv0 = tl >> 2;
+    unsigned hoff[NIT], hpk[NIT];   // element offset from the halo origin (z0-PZ, y0-PY, x0-PX); packed (hz, hy, hx)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int hv = min(hv0 + 64 * it, HV - 1);
+        const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+        hoff[it] = (unsigned)((hz * H + hy) * W + hx) * (unsigned)x_ld + (unsigned)(c4 * 4);
+        hpk[it] = (unsigned)hz | ((unsigned)hy << 8) | ((unsigned)hx << 16);
+    }
+    const unsigned ctr_off = (unsigned)((PZ * H + PY) * W + PX) * (unsigned)x_ld + (unsigned)(c4 * 4);  // always inside
+    // tap loop: A-fragment rows of this lane
     int abase[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -111,13 +135,22 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
         const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
         abase[m] = ((pz * HY + py) * HX + px) * LSV + kh * 4;  // + 8 floats (32 B) per further plane
     }
+    // epilogue: after the transpose a lane holds channels cq*4 .. cq*4+3 of the voxels (x = rr, y-row j) of a tile
+    const int rr = lane >> 3, cq = lane & 7;
+    float* scr_w = scr + (4 * kh) * SCP + r;     // accumulator register reg -> row (reg & 3) + 8 (reg >> 2) + 4 kh, column r
+    const float* scr_r = scr + rr * SCP + cq * 4;
+    const unsigned yoff_lane = (unsigned)rr * (unsigned)y_ld + (unsigned)(cq * 4);
+    const unsigned roff_lane = (unsigned)rr * (unsigned)ref_ld + (unsigned)(cq * 4);
+
+    // ReLU / no activation as one v_max (the sigmoid of a final activation never sits behind these layers: the host side
+    // sends such a launch to the patch kernel)
+    const float act_floor = act == TEM_ACT_RELU ? 0.f : -__builtin_inff();
     floatx16 acc[MT][NW];
     const int tapstride = nch * FR;
     uint4 bq[RD][NW][NS];
     const uint4* wq[NW];
 #pragma unroll
     for (int nn = 0; nn < NW; ++nn) wq[nn] = wp + lane;
-
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -125,140 +158,176 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
 
+    // step cursor of this team: (unit index, chunk), advanced once per loop trip; `cu` is the unit being staged /
+    // computed, `eu` the one whose accumulators wait for their epilogue
+    int ui = 0, ci = 0;
+    PpUnit cu = decode(0), eu = cu;
+    bool epi_pending = false;
+
     // Both teams run the same straight-line sequence  stage(s) | barrier | taps(s) | barrier ;  team 1 passes one extra
     // barrier first (and team 0 one at the end), which shifts it by one phase: its staging runs beside team 0's tap loop.
     if (team) __syncthreads();
     for (int s = 0; s <= P; ++s) {
+        const bool do_stage = ui < my_units;
         {
             // ================= staging phase (the partner team runs its tap loop) =================
-            const bool do_epi = s >= 1 && s - 1 < my_steps && (s - 1) % nch == nch - 1;
-            const bool do_stage = s < my_steps;
             PP_STAMP(0);
-            // ---- issue the halo loads of step s first: they fly during the epilogue of the previous unit ----
+            // ---- issue the halo loads of this step first: they fly during the epilogue of the previous unit ----
             float4 tmp[NIT];
-            unsigned inb = 0;
+            unsigned inb = 0xffffffffu;
             float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int c4 = tl & 3;
-            PpUnit su;
-            int schunk = 0;
+            bool interior = true;
             if (do_stage) {
-                su = decode(s / nch);
-                schunk = s % nch;
                 if (scale) {
-                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)su.n * Cin + schunk * BCK + c4 * 4);
-                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)su.n * Cin + schunk * BCK + c4 * 4);
+                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
+                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
                 }
-                // one uniform base pointer per step + 32-bit offsets: a load is "global_load v, voff, s[base]" (one address VGPR)
-                const int zlo = max(su.z0 - PZ, 0);
-                const float* xb = x + (((int64_t)su.n * D + zlo) * H * W) * x_ld + schunk * BCK;
+                // one uniform base pointer per step (the halo origin: may lie outside the tensor for border patches, where
+                // only in-range voxels are dereferenced) + per-thread constant 32-bit offsets
+                const float* xb = x + ((((int64_t)cu.n * D + (cu.z0 - PZ)) * H + (cu.y0 - PY)) * W + (cu.x0 - PX)) * x_ld + ci * BCK;
+                interior = (cu.z0 >= PZ) & (cu.z0 + HZ - PZ <= D) & (cu.y0 >= PY) & (cu.y0 + HY - PY <= H) & (cu.x0 >= PX) &
+                           (cu.x0 + HX - PX <= W);
+                if (interior) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int hv = min((tl + it * 256) >> 2, HV - 1);
-                    const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
-                    const int gz = su.z0 + hz - PZ, gy = su.y0 + hy - PY, gx = su.x0 + hx - PX;
-                    const bool ok = (gz >= 0) & (gz < D) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) &
-                                    (((tl + it * 256) >> 2) < HV);
-                    inb |= ok ? (1u << it) : 0u;
-                    const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-                    const unsigned off = (unsigned)(((cz - zlo) * H + cy) * W + cx) * (unsigned)x_ld + (unsigned)(c4 * 4);
-                    if (TEM_PP_ABL & 1)
-                        tmp[it] = make_float4(0.5f + it, 0.25f, -1.f, 2.f);
-                    else
-                        tmp[it] = *reinterpret_cast<const float4*>(xb + off);
-                }
-            }
-            // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
-            if (do_epi) {
-                const PpUnit eu = decode((s - 1) / nch);
-                float* yb = y + (((int64_t)eu.n * D + eu.z0) * H * W) * y_ld;
-                const float* rb = ref ? ref + (((int64_t)eu.n * D + eu.z0) * H * W) * ref_ld : nullptr;
-                float ssum[NW], ssq[NW];
-#pragma unroll
-                for (int nn = 0; nn < NW; ++nn) {
-                    ssum[nn] = ssq[nn] = 0.f;
-                    const int co = ((eu.cot * WN + wn) * NW + nn) * 32 + r;
-                    const float bv = bias ? bias[co] : 0.f;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        // straight-line loads of the ReLU-mask reference (clamped addresses): inside a per-element bounds
-                        // branch they would wait for one another
-                        float rv[16];
-                        unsigned vox[16];  // voxel index relative to the first plane of the patch
-                        unsigned okm = 0;
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                            const int p = (wm * MT + m) * 32 + row;
-                            const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-                            const int gz = eu.z0 + pz, gy = eu.y0 + py, gx = eu.x0 + px;
-                            okm |= (gz < D && gy < H && gx < W) ? (1u << reg) : 0u;
-                            vox[reg] = (unsigned)(((min(gz, D - 1) - eu.z0) * H + min(gy, H - 1)) * W + min(gx, W - 1));
-                            rv[reg] = ref ? rb[vox[reg] * (unsigned)ref_ld + (unsigned)co] : 1.f;
-                        }
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            float a = acc[m][nn][reg];
-                            if (F16) a *= F16_PRESCALE_INV;
-                            float o = act_apply_b(a + bv, act);
-                            if (!(rv[reg] > 0.f)) o = 0.f;
-                            if ((okm >> reg) & 1u) {
-                                ssum[nn] += o;
-                                ssq[nn] = fmaf(o, o, ssq[nn]);
-                                if (!(TEM_PP_ABL & 2) || o == 12345.678f)
-                                    __builtin_nontemporal_store(o, yb + (vox[reg] * (unsigned)y_ld + (unsigned)co));
-                            }
-                            acc[m][nn][reg] = 0.f;  // the next unit of this team starts from zero
-                        }
+                    for (int it = 0; it < NIT; ++it) {
+                        if (TEM_PP_ABL & 1)
+                            tmp[it] = make_float4(0.5f + it, 0.25f, -1.f, 2.f);
+                        else
+                            tmp[it] = *reinterpret_cast<const float4*>(xb + hoff[it]);
                     }
-                }
-                if (stat) {  // grid-uniform: per (sample, patch, voxel-wave, channel) partial sums of the stored output
+                } else {
+                    inb = 0;
+                    const unsigned zlim = (unsigned)D, ylim = (unsigned)H, xlim = (unsigned)W;
+                    const int bz = cu.z0 - PZ, by = cu.y0 - PY, bx = cu.x0 - PX;
 #pragma unroll
-                    for (int nn = 0; nn < NW; ++nn) {
-                        ssum[nn] += __shfl_xor(ssum[nn], 32, 64);  // the lane halves hold different rows of one column
-                        ssq[nn] += __shfl_xor(ssq[nn], 32, 64);
-                        if (kh == 0) {
-                            const int64_t patch = ((int64_t)(eu.z0 / TZ) * nY + eu.y0 / TY) * nX + eu.x0 / TX;
-                            const int64_t nblk = (int64_t)nZ * nY * nX * WM;
-                            const int co = ((eu.cot * WN + wn) * NW + nn) * 32 + r;
-                            float* dst = stat + (((int64_t)eu.n * nblk + patch * WM + wm) * Cout + co) * 2;
-                            dst[0] = ssum[nn];
-                            dst[1] = ssq[nn];
-                        }
+                    for (int it = 0; it < NIT; ++it) {
+                        const unsigned gz = (unsigned)(bz + (int)(hpk[it] & 255u)), gy = (unsigned)(by + (int)((hpk[it] >> 8) & 255u)),
+                                       gx = (unsigned)(bx + (int)(hpk[it] >> 16));
+                        const bool ok = (gz < zlim) & (gy < ylim) & (gx < xlim);   // unsigned: negative coordinates are huge
+                        inb |= ok ? (1u << it) : 0u;
+                        tmp[it] = *reinterpret_cast<const float4*>(xb + (ok ? hoff[it] : ctr_off));
                     }
                 }
             }
             PP_STAMP(1);
-            // ---- norm, split, LDS tile; then prime the weight-fragment ring of the coming tap loop ----
-            if (do_stage) {
+            // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
+            if (epi_pending) {
+                float* yb = y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld;
+                const float* rb = ref ? ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld : nullptr;
+                const bool full = (eu.z0 + TZ <= D) & (eu.y0 + TY <= H) & (eu.x0 + TX <= W);
+                const float inv = F16 ? F16_PRESCALE_INV : 1.f;
+                // FULL: the patch lies inside the volume (no per-element bounds); else its outside voxels count as zero in
+                // the statistics and are not stored.  One uniform branch, two straight-line bodies.
+                auto body = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int hv = (tl + it * 256) >> 2;
-                    if (hv < HV) {
-                        const bool ok = (inb >> it) & 1u;
-                        float e[4] = {ok ? fmaf(tmp[it].x, sc4.x, sf4.x) : 0.f, ok ? fmaf(tmp[it].y, sc4.y, sf4.y) : 0.f,
-                                      ok ? fmaf(tmp[it].z, sc4.z, sf4.z) : 0.f, ok ? fmaf(tmp[it].w, sc4.w, sf4.w) : 0.f};
-                        if (F16) {
+                    for (int nn = 0; nn < NW; ++nn) {
+                        const int cb = ((eu.cot * WN + wn) * NW + nn) * 32;   // first channel of this column tile
+                        const float bv = bias ? bias[cb + r] : 0.f;
+                        float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                e[c] = __builtin_amdgcn_fmed3f(e[c] * F16_A_PRESCALE, -64000.f, 64000.f);
+                        for (int m = 0; m < MT; ++m) {
+                            const int yy0 = (wm * MT + m) * 4;   // combined (z, y) row index of the tile's first y-row
+#pragma unroll
+                            for (int reg = 0; reg < 16; ++reg) {
+                                float o = fmaxf(fmaf(acc[m][nn][reg], inv, bv), act_floor);
+                                if (!FULL) {
+                                    const int yy = yy0 + (reg >> 2);
+                                    const bool ok = (eu.z0 + yy / TY < D) & (eu.y0 + yy % TY < H) & (eu.x0 + (reg & 3) + 4 * kh < W);
+                                    o = ok ? o : 0.f;
+                                }
+                                ssum += o;
+                                ssq = fmaf(o, o, ssq);
+                                scr_w[((reg & 3) + 8 * (reg >> 2)) * SCP] = o;
+                                acc[m][nn][reg] = 0.f;  // the next unit of this team starts from zero
+                            }
+                            // transposed read-back: 4 x (8 voxels x 128 B) per tile, one 16-byte store per lane each
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float4 v = *reinterpret_cast<const float4*>(scr_r + 8 * j * SCP);
+                                const int yy = yy0 + j, pz = yy / TY, py = yy % TY;
+                                const int64_t srow = ((int64_t)pz * H + py) * W;   // scalar: voxel offset of this y-row
+                                bool ok = true;
+                                if (!FULL) ok = (eu.z0 + pz < D) & (eu.y0 + py < H) & (eu.x0 + rr < W);
+                                if (rb) {
+                                    if (FULL || ok) {
+                                        const float4 q = *reinterpret_cast<const float4*>(rb + srow * ref_ld + cb + roff_lane);
+                                        v.x = q.x > 0.f ? v.x : 0.f;
+                                        v.y = q.y > 0.f ? v.y : 0.f;
+                                        v.z = q.z > 0.f ? v.z : 0.f;
+                                        v.w = q.w > 0.f ? v.w : 0.f;
+                                    }
+                                }
+                                if ((FULL || ok) && (!(TEM_PP_ABL & 2) || v.x == 12345.678f)) {
+                                    floatx4s vv = {v.x, v.y, v.z, v.w};
+                                    __builtin_nontemporal_store(vv, reinterpret_cast<floatx4s*>(yb + srow * y_ld + cb + yoff_lane));
+                                }
+                            }
                         }
-#pragma unroll
-                        for (int p = 0; p < NS; ++p) {
-                            const unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
-                            if (!(TEM_PP_ABL & 8) || h0 == 0x12345678u)
-                                *reinterpret_cast<uint2*>(lds + hv * LSV + p * 8 + c4 * 2) = make_uint2(h0, h1);
-                            if (p + 1 < NS) {
-                                e[0] -= lo16<F16>(h0);
-                                e[1] -= hi16<F16>(h0);
-                                e[2] -= lo16<F16>(h1);
-                                e[3] -= hi16<F16>(h1);
+                        if (stat) {  // grid-uniform: per (sample, patch, voxel-wave, channel) partial sums of the stored output
+                            ssum += __shfl_xor(ssum, 32, 64);  // the lane halves hold different rows of one column
+                            ssq += __shfl_xor(ssq, 32, 64);
+                            if (kh == 0) {
+                                const int64_t patch = ((int64_t)(eu.z0 / TZ) * nY + eu.y0 / TY) * nX + eu.x0 / TX;
+                                const int64_t nblk = (int64_t)nZ * nY * nX * WM;
+                                float* dst = stat + (((int64_t)eu.n * nblk + patch * WM + wm) * Cout + cb + r) * 2;
+                                dst[0] = ssum;
+                                dst[1] = ssq;
                             }
                         }
                     }
+                };
+                if (full)
+                    body(std::true_type{});
+                else
+                    body(std::false_type{});
+                epi_pending = false;
+            }
+            // ---- norm, split, LDS tile; then prime the weight-fragment ring of the coming tap loop ----
+            if (do_stage) {
+                if (F16) {  // the activation prescale rides on the norm's scale / shift
+                    sc4.x *= F16_A_PRESCALE; sc4.y *= F16_A_PRESCALE; sc4.z *= F16_A_PRESCALE; sc4.w *= F16_A_PRESCALE;
+                    sf4.x *= F16_A_PRESCALE; sf4.y *= F16_A_PRESCALE; sf4.z *= F16_A_PRESCALE; sf4.w *= F16_A_PRESCALE;
                 }
+                float* lw = lds + hv0 * LSV + c4 * 2;
+                auto convert = [&](auto interior_tag) {
+                    constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        if (hv0 + 64 * it < HV) {
+                            float e[4] = {fmaf(tmp[it].x, sc4.x, sf4.x), fmaf(tmp[it].y, sc4.y, sf4.y),
+                                          fmaf(tmp[it].z, sc4.z, sf4.z), fmaf(tmp[it].w, sc4.w, sf4.w)};
+                            if (!INTERIOR) {  // zero padding comes after the norm (model/unet.py:429-438)
+                                const bool ok = (inb >> it) & 1u;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) e[c] = ok ? e[c] : 0.f;
+                            }
+                            if (F16) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) e[c] = __builtin_amdgcn_fmed3f(e[c], -64000.f, 64000.f);
+                            }
+#pragma unroll
+                            for (int p = 0; p < NS; ++p) {
+                                const unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
+                                if (!(TEM_PP_ABL & 8) || h0 == 0x12345678u)
+                                    *reinterpret_cast<uint2*>(lw + 64 * it * LSV + p * 8) = make_uint2(h0, h1);
+                                if (p + 1 < NS) {
+                                    e[0] -= lo16<F16>(h0);
+                                    e[1] -= hi16<F16>(h0);
+                                    e[2] -= lo16<F16>(h1);
+                                    e[3] -= hi16<F16>(h1);
+                                }
+                            }
+                        }
+                    }
+                };
+                if (interior)
+                    convert(std::true_type{});
+                else
+                    convert(std::false_type{});
 #pragma unroll
                 for (int nn = 0; nn < NW; ++nn)
-                    wq[nn] = wp + (int64_t)((su.cot * WN + wn) * NW + nn) * NT * nch * FR + (int64_t)schunk * FR + lane;
+                    wq[nn] = wp + (int64_t)((cu.cot * WN + wn) * NW + nn) * NT * nch * FR + (int64_t)ci * FR + lane;
                 if (RD > 1) {
 #pragma unroll
                     for (int gp = 0; gp < RD - 1; ++gp)
@@ -274,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
         {
             PP_STAMP(3);
             // ================= MFMA phase: 27 taps of one 16-channel chunk out of this team's tile =================
-            if (s < my_steps) {
+            if (do_stage) {
                 int ts = tapstride;
                 asm volatile("" : "+s"(ts));
                 if (TEM_PP_PRIO) __builtin_amdgcn_s_setprio(TEM_PP_PRIO);
@@ -330,6 +399,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
             }
             PP_STAMP(4);
         }
+        // advance the cursor: the unit is complete after its last chunk (its epilogue runs in the next staging phase)
+        if (do_stage) {
+            if (++ci == nch) {
+                ci = 0;
+                eu = cu;
+                epi_pending = true;
+                if (++ui < my_units) cu = decode(ui);
+            }
+        }
         __syncthreads();
         PP_STAMP(5);
     }
@@ -340,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
 // host side
 // ---------------------------------------------------------------------------
 struct PpGeom {
-    int variant;  // 0: not handled here; 1: team patch 4x8x8; 2: team patch 8x8x8
+    int variant;  // 0: not handled here; 1: ping-pong teams, 4 x 8 x 8 voxel patch per team
     int TZ, TY, TX, CT, WM;
     int nZ, nY, nX;
     int64_t nunits;
@@ -348,44 +426,34 @@ struct PpGeom {
 
 // Which shapes run on the ping-pong kernel: 3x3x3 (and 1x3x3 with depth) kernels, two 16-bit planes per operand, and
 // enough (patch, column group) units to give every team of every CU at least one.
-static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
+static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit, int64_t max_ld) {
     PpGeom g = {};
     const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
     if (opt == 0) return g;
     if (!(nsplit == 2 || nsplit == 6)) return g;
     if (!(kh == 3 && kw == 3 && (kd == 3 || kd == 1))) return g;
     if (D < 4 || Cin % 16 || Cout % 32) return g;
-    if ((int64_t)H * W * 10 * 4 * 1024 >= (1ll << 31)) return g;  // 32-bit byte offsets inside a step (ld <= 1024 floats)
+    if ((int64_t)H * W * 8 * 4 * max_ld >= (1ll << 31)) return g;  // 32-bit byte offsets inside one halo / one patch
     static int ncu = 0;
     if (!ncu) {
         ncu = tem_device_cus();
         if (ncu <= 0) ncu = 256;
     }
     g.CT = (Cout % 64 == 0) ? 2 : 1;
+    g.TZ = 4;
     g.TY = g.TX = 8;
-    auto units = [&](int TZ) {
-        return (int64_t)N * ((D + TZ - 1) / TZ) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / (32 * g.CT));
-    };
-    const int64_t need = opt > 0 ? 1 : 2ll * ncu;
-    if ((opt == 2 && g.CT == 1) || (opt < 0 && g.CT == 1 && D % 8 == 0 && units(8) >= 2 * need)) {
-        g.variant = 2;
-        g.TZ = 8;
-    } else if (units(4) >= need) {
-        g.variant = 1;
-        g.TZ = 4;
-    } else {
-        return g;
-    }
     g.WM = (g.CT == 2) ? 2 : 4;
     g.nZ = (D + g.TZ - 1) / g.TZ;
     g.nY = (H + 7) / 8;
     g.nX = (W + 7) / 8;
-    g.nunits = units(g.TZ);
+    g.nunits = (int64_t)N * g.nZ * g.nY * g.nX * (Cout / (32 * g.CT));
+    if (g.nunits < (opt > 0 ? 1 : 2ll * ncu)) return g;
+    g.variant = 1;
     return g;
 }
 
 int64_t tem_conv_pp_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
-    const PpGeom g = pp_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit);
+    const PpGeom g = pp_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, 1);
     if (!g.variant) return -1;
     return (int64_t)g.nZ * g.nY * g.nX * g.WM;
 }
@@ -396,7 +464,7 @@ static void pp_launch(const PpGeom& g, const float* x, int64_t x_ld, const float
                       int N, int D, int H, int W, int Cin, int Cout, int act, float* stat, hipStream_t s) {
     constexpr int WN = CT;  // 64-column teams: 2 x 2 waves; 32-column teams: 4 x 1
     constexpr int HV = (TZ + KD - 1) * 10 * 10;
-    constexpr size_t ldsb = (size_t)2 * HV * (2 * 8 + 4) * sizeof(float);
+    constexpr size_t ldsb = ((size_t)2 * HV * (2 * 8 + 4) + 8 * 32 * 36) * sizeof(float);  // two halo tiles + 8 wave scratches
     static_assert(ldsb <= 160 * 1024, "LDS budget");
     auto kern = &k_conv_pp<KD, KH, KW, TZ, 8, 8, CT, WN, 2, F16>;
     static bool attr = false;
@@ -420,26 +488,30 @@ static void pp_launch(const PpGeom& g, const float* x, int64_t x_ld, const float
 bool tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
                      int W, int Cin, int Cout, int kd, int kh, int kw, int act, int nsplit, float* stat, hipStream_t s) {
-    const PpGeom g = pp_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit);
+    int64_t max_ld = x_ld > y_ld ? x_ld : y_ld;
+    if (ref && ref_ld > max_ld) max_ld = ref_ld;
+    const PpGeom g = pp_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, max_ld);
     if (!g.variant) return false;
+    // 16-byte epilogue accesses; statistics of a masked output are the patch kernel's business (never asked for together)
+    if ((y_ld % 4) || ((uintptr_t)y % 16) || (ref && ((ref_ld % 4) || ((uintptr_t)ref % 16))) || (stat && ref) ||
+        act == TEM_ACT_SIGMOID)
+        return false;
     const bool f16 = nsplit == 6;
-#define PPGO(KD, TZ, CT)                                                                                              \
+#define PPGO(KD, CT)                                                                                                  \
     do {                                                                                                              \
         if (f16)                                                                                                      \
-            pp_launch<KD, 3, 3, TZ, CT, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, \
-                                              Cout, act, stat, s);                                                    \
+            pp_launch<KD, 3, 3, 4, CT, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin,  \
+                                             Cout, act, stat, s);                                                     \
         else                                                                                                          \
-            pp_launch<KD, 3, 3, TZ, CT, false>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, \
-                                               Cout, act, stat, s);                                                   \
+            pp_launch<KD, 3, 3, 4, CT, false>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, \
+                                              Cout, act, stat, s);                                                    \
     } while (0)
     if (kd == 3) {
-        if (g.TZ == 8) PPGO(3, 8, 1);
-        else if (g.CT == 1) PPGO(3, 4, 1);
-        else PPGO(3, 4, 2);
+        if (g.CT == 1) PPGO(3, 1);
+        else PPGO(3, 2);
     } else {
-        if (g.TZ == 8) PPGO(1, 8, 1);
-        else if (g.CT == 1) PPGO(1, 4, 1);
-        else PPGO(1, 4, 2);
+        if (g.CT == 1) PPGO(1, 1);
+        else PPGO(1, 2);
     }
 #undef PPGO
     return true;

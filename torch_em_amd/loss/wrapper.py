@@ -99,8 +99,10 @@ class LossWrapper(nn.Module):
         prediction, target, mask = self.transform.split(prediction, target, **kwargs)
         mask = mask.to(prediction.dtype)
         if mask.shape != target.shape or mask.stride() != target.stride():
-            # a broadcast mask (singleton channel) or a differently laid out one: give it the target's layout
-            mask = torch.empty_like(target).copy_(mask.expand_as(target))
+            # a broadcast mask (singleton channel) or a differently laid out one: the kernel reads target and mask with one
+            # set of strides, so both become dense tensors of the same layout
+            target = target.contiguous()
+            mask = mask.expand_as(target).contiguous()
         return self.loss(prediction, target, mask=mask)
 
     def apply_transform(self, prediction, target, **kwargs):

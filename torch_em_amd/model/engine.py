@@ -59,6 +59,7 @@ _FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
 # The backward convolutions are LINEAR in the incoming gradient with masks fixed by the forward
 # pass, so their 1e-5 error is not amplified.
 PRECISION = os.environ.get("TEM_PRECISION", "split16")
+_F16X3_MODE = int(os.environ.get("TEM_F16X3_LAYOUT", "6"))
 
 
 def set_precision(mode: str):
@@ -121,7 +122,9 @@ class ConvSpec:
     def _modes(self):
         mode_f = {"bf16x3": 2, "split": 3, "split16": 3, "amp": 5}.get(PRECISION, 1)
         if PRECISION == "split16" and self.norm is not None and self.k != (1, 1, 1):
-            mode_f = 4  # fp16x3: the conv reads pre-normalised activations (|x^| of order 1..100 << 65504; clamped at 6e4)
+            # fp16x3 with prescaled operands (TEM_WL_F16X3S, csrc/conv_split.h): the conv reads pre-normalised activations
+            # (|x^| <= sqrt(voxels); clamped at 2000).  TEM_F16X3_LAYOUT=4 selects the older scaled-lo-plane variant.
+            mode_f = _F16X3_MODE
         mode_d = 5 if PRECISION == "amp" else 2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
         mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
         md = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k) else 0
@@ -175,9 +178,9 @@ def _repack_stale():
                 del ent["fwd_inf"], ent["fwd_inf_mfma"]
                 continue
             mode = ent[key + "_mfma"]
-            if mode in (2, 3, 4, 5):
+            if mode in (2, 3, 4, 5, 6):
                 jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
-                             3 if mode == 3 else 1 if mode == 5 else 2, 2 if mode == 4 else 1 if mode == 5 else 0))
+                             3 if mode == 3 else 1 if mode == 5 else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
             else:
                 rest.append((ent, key, w, bool(transpose), mode))
         ent["version"] = w._version

@@ -25,7 +25,8 @@ PROFILER_FILTER = None
 
 
 def _fwd_tag(mfma, k, cout):
-    kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3", 5: "k_conv_fwd_f16"}.get(int(mfma)) or
+    kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3", 5: "k_conv_fwd_f16",
+             6: "k_conv_fwd_f16x3"}.get(int(mfma)) or
             ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu")) + f"<{k[0]},{k[1]},{k[2]}"
     return kind + (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
 
@@ -150,8 +151,8 @@ def mfma_ok(cin: int, cout: int, k: Sequence[int], wgrad: bool = False) -> bool:
 
 def pack_weights(w: torch.Tensor, transpose: bool, mfma) -> torch.Tensor:
     """state_dict layout [Cout, Cin, (kd,) kh, kw] -> kernel layout (see tem_hip.h).
-    mfma: False/0 generic, True/1 exact-fp32 MFMA fragments, 2 / 3 split-bf16 fragments (2 / 3 terms), 4 split-fp16,
-    5 one fp16 term (mixed precision)."""
+    mfma: False/0 generic, True/1 exact-fp32 MFMA fragments, 2 / 3 split-bf16 fragments (2 / 3 terms), 4 split-fp16
+    (lo plane scaled), 5 one fp16 term (mixed precision), 6 split-fp16 with prescaled operands."""
     _req_cuda(w)
     w = w.detach().contiguous()
     cout, cin = w.shape[:2]
