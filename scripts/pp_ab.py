@@ -60,9 +60,9 @@ def check():
     shapes = [(1, 20, 24, 40, 32, 32), (2, 9, 17, 33, 32, 64), (1, 16, 16, 16, 64, 32), (1, 8, 32, 32, 16, 96)]
     for (N, D, H, W, cin, cout) in shapes:
         for k in ((3, 3, 3), (1, 3, 3)):
-            for mode, tol in ((6, 3e-6), (4, 3e-6), (2, 1e-4)):
+            for mode, tol in ((4, 3e-6), (6, 3e-6), (2, 1e-4)):
                 for variant in VARIANTS:
-                    if mode == 4 and variant != 0:
+                    if mode == 6 and variant != 0:
                         continue
                     for (use_norm, use_ref, want_stats) in ((True, False, True), (False, True, False)):
                         err, serr = run_case(N, D, H, W, cin, cout, k, mode, variant, use_norm, use_ref, want_stats)
@@ -94,7 +94,7 @@ def bench():
         for mode in (4, 6, 2):
             wp = ops.pack_weights(w, False, mode)
             for variant in VARIANTS:
-                if mode == 4 and variant != 0:
+                if mode == 6 and variant != 0:
                     continue
                 arms.append((mode, variant, wp))
         res = {(m, v): [] for m, v, _ in arms}

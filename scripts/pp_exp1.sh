@@ -2,7 +2,7 @@
 # GPU experiment 1: phase timeline + ablations of the ping-pong kernel
 cd "$(dirname "$0")/.."
 out=gpurun_out/r2b; mkdir -p $out
-A="2 128 128 128 32 32 6"; B="2 64 64 64 64 64 6"
+A="2 128 128 128 32 32 4"; B="2 64 64 64 64 64 4"
 scripts/pp_harness.sh base
 scripts/pp_harness.sh trace -DTEM_PP_TRACE
 {

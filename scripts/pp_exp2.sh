@@ -2,7 +2,7 @@
 # GPU experiment 2: correctness of the rewritten kernel, timeline, a few ablations
 cd "$(dirname "$0")/.."
 out=gpurun_out/r2c; mkdir -p $out
-A="2 128 128 128 32 32 6"; B="2 64 64 64 64 64 6"; C="2 128 128 128 64 32 6"; Dd="2 128 128 128 32 32 2"
+A="2 128 128 128 32 32 4"; B="2 64 64 64 64 64 4"; C="2 128 128 128 64 32 4"; Dd="2 128 128 128 32 32 2"
 PP_VARIANTS=0,1 python scripts/pp_ab.py check > $out/check.log 2>&1; tail -1 $out/check.log
 scripts/pp_harness.sh base
 scripts/pp_harness.sh trace -DTEM_PP_TRACE

@@ -83,12 +83,13 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> tr(2 * 64 * 8);
     tem_pp_trace_read(tr.data());
     for (int team = 0; team < 2; ++team) {
-        printf("team %d: step  stage_issue  stage_rest  bar1   taps   bar2   (shader cycles; t0 relative to team 0 step 0)\n", team);
+        printf("team %d: step  loads_issue  epilogue  convert  prime  bar1   taps   bar2   (shader cycles; t0 relative to team 0 step 0)\n", team);
         const unsigned long long base = tr[0];
         for (int st = 0; st < 20; ++st) {
             const unsigned long long* t = &tr[(team * 64 + st) * 8];
             if (!t[0]) break;
-            printf("  %2d @%8llu: %6lld %6lld %6lld %6lld %6lld\n", st, t[0] - base, (long long)(t[1] - t[0]), (long long)(t[2] - t[1]),
+            printf("  %2d @%8llu: %6lld %6lld %6lld %6lld %6lld %6lld %6lld\n", st, t[0] - base, (long long)(t[1] - t[0]),
+                   (long long)(t[6] - t[1]), (long long)(t[7] ? t[7] - t[6] : 0), (long long)(t[7] ? t[2] - t[7] : t[2] - t[6]),
                    (long long)(t[3] - t[2]), (long long)(t[4] - t[3]), (long long)(t[5] - t[4]));
         }
     }

@@ -27,6 +27,9 @@
 #ifndef TEM_PP_PRIO
 #define TEM_PP_PRIO 1    // s_setprio of the team in its MFMA phase
 #endif
+#ifndef TEM_PP_SCHED
+#define TEM_PP_SCHED 1   // tap loop: 0 = loads of the next tap | MFMAs of this tap, pinned; 1 = one load between two MFMAs
+#endif
 #ifndef TEM_PP_ABL
 #define TEM_PP_ABL 0     // harness-only ablations (scripts/pp_harness.cpp): 1 no halo loads, 2 no stores, 4 no weight loads in
 #endif                   // the tap loop, 8 no split / LDS writes, 16 no MFMAs
@@ -35,6 +38,31 @@ struct PpUnit {
     int cot, n, z0, y0, x0;
 };
 typedef float floatx4s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer accesses: "buffer_load_dwordx4 v, voff, s[rsrc], soff offen" -- a wave-uniform 48-bit base in four SGPRs,
+// ONE 32-bit VGPR byte offset per lane (a per-thread constant here) and a scalar byte offset.  Plain pointer arithmetic
+// made hipcc build a 64-bit VGPR address per access (v_lshl_add_u64 + v_mov, two VGPRs each) and, short of registers,
+// wait for the first loads of a step before it could form the addresses of the last ones (two memory latencies per step).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pp_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 pp_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    // whole-vector bit cast: __builtin_bit_cast(float, v.x) on the ELEMENTS makes hipcc (ROCm 7.2) narrow the access to one
+    // buffer_load_dword and hand out element 0 four times
+    const floatx4s f = __builtin_bit_cast(floatx4s, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ uint4 pp_load4u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void pp_store4_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
+    const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
+                     __builtin_bit_cast(unsigned, v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 2);  // aux 2 = nt: the output is not re-read by this kernel
+}
 
 #ifdef TEM_PP_TRACE   // developer build (scripts/pp_harness.cpp): shader-clock stamps of the phases of one workgroup
 #ifndef TEM_PP_TRACE_BLOCK
@@ -54,8 +82,11 @@ void tem_pp_trace_read(unsigned long long* dst) {
 #endif
 
 // KD,KH,KW kernel; TZ,TY,TX voxel patch of a TEAM (TX == 8); CT 32-column tiles per team; WN waves side by side over
-// the columns (WM = 4 / WN waves over the voxels); NS planes per operand; F16: fp16 terms with prescaled operands
-// (TEM_WL_F16X3S, conv_split.h), else bf16 terms.
+// the columns (WM = 4 / WN waves over the voxels); NS planes per operand; F16: fp16 terms, lo planes stored x 2^12 and the
+// cross products hi*lo' + lo'*hi in their own accumulators (TEM_WL_F16X3, conv_split.h), else bf16 terms.
+// (A single-accumulator variant with prescaled operands -- TEM_WL_F16X3S -- was built and measured: the matrix core
+// truncates small addends against a large accumulator, a one-sided error of ~1e-5 per output that the sums of a
+// GroupNorm backward turn into 4e-3; rejected, the layout stays available to the patch kernel for experiments.)
 //
 // Instruction budget.  A staging phase runs on ONE wave per SIMD (its partner issues MFMAs), so nothing hides its issue
 // latency: the first version spent ~1000 VALU + ~1000 SALU instructions per phase on index arithmetic (halo coordinates,
@@ -118,15 +149,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
     // ---- per-thread constants ----
     // staging: slot it of this thread is halo voxel hv0 + 64 it, channels c4*4 .. c4*4+3 of the chunk
     const int c4 = tl & 3, hv0 = tl >> 2;
-    unsigned hoff[NIT], hpk[NIT];   // element offset from the halo origin (z0-PZ, y0-PY, x0-PX); packed (hz, hy, hx)
+    unsigned hoff[NIT];             // BYTE offset from the halo origin (z0-PZ, y0-PY, x0-PX)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int hv = min(hv0 + 64 * it, HV - 1);
         const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
-        hoff[it] = (unsigned)((hz * H + hy) * W + hx) * (unsigned)x_ld + (unsigned)(c4 * 4);
-        hpk[it] = (unsigned)hz | ((unsigned)hy << 8) | ((unsigned)hx << 16);
+        hoff[it] = ((unsigned)((hz * H + hy) * W + hx) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u;
     }
-    const unsigned ctr_off = (unsigned)((PZ * H + PY) * W + PX) * (unsigned)x_ld + (unsigned)(c4 * 4);  // always inside
+    const unsigned ctr_off = ((unsigned)((PZ * H + PY) * W + PX) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u;  // always inside
     // tap loop: A-fragment rows of this lane
     int abase[MT];
 #pragma unroll
@@ -139,30 +169,43 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
     const int rr = lane >> 3, cq = lane & 7;
     float* scr_w = scr + (4 * kh) * SCP + r;     // accumulator register reg -> row (reg & 3) + 8 (reg >> 2) + 4 kh, column r
     const float* scr_r = scr + rr * SCP + cq * 4;
-    const unsigned yoff_lane = (unsigned)rr * (unsigned)y_ld + (unsigned)(cq * 4);
-    const unsigned roff_lane = (unsigned)rr * (unsigned)ref_ld + (unsigned)(cq * 4);
+    const unsigned yoff_lane = ((unsigned)rr * (unsigned)y_ld + (unsigned)(cq * 4)) * 4u;     // bytes
+    const unsigned roff_lane = ((unsigned)rr * (unsigned)ref_ld + (unsigned)(cq * 4)) * 4u;
+    const __amdgpu_buffer_rsrc_t rw = pp_rsrc(wp);
+    const unsigned woff_lane = (unsigned)lane * 16u;
 
     // ReLU / no activation as one v_max (the sigmoid of a final activation never sits behind these layers: the host side
     // sends such a launch to the patch kernel)
     const float act_floor = act == TEM_ACT_RELU ? 0.f : -__builtin_inff();
+    constexpr bool SC = F16 && NS == 2;   // second accumulator set for the scaled cross products
     floatx16 acc[MT][NW];
+    floatx16 accl[SC ? MT : 1][SC ? NW : 1];
     const int tapstride = nch * FR;
     uint4 bq[RD][NW][NS];
-    const uint4* wq[NW];
+    unsigned wsoff[NW];
 #pragma unroll
-    for (int nn = 0; nn < NW; ++nn) wq[nn] = wp + lane;
+    for (int nn = 0; nn < NW; ++nn) wsoff[nn] = 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
+            for (int i = 0; i < 16; ++i) {
+                acc[m][nn][i] = 0.f;
+                if (SC) accl[SC ? m : 0][SC ? nn : 0][i] = 0.f;
+            }
 
     // step cursor of this team: (unit index, chunk), advanced once per loop trip; `cu` is the unit being staged /
     // computed, `eu` the one whose accumulators wait for their epilogue
     int ui = 0, ci = 0;
     PpUnit cu = decode(0), eu = cu;
     bool epi_pending = false;
+    float bvc[NW], bve[NW];   // bias of this lane's column in the unit being computed / awaiting its epilogue
+#pragma unroll
+    for (int nn = 0; nn < NW; ++nn) {
+        bvc[nn] = (bias && my_units > 0) ? bias[((cu.cot * WN + wn) * NW + nn) * 32 + r] : 0.f;
+        bve[nn] = 0.f;
+    }
 
     // Both teams run the same straight-line sequence  stage(s) | barrier | taps(s) | barrier ;  team 1 passes one extra
     // barrier first (and team 0 one at the end), which shifts it by one phase: its staging runs beside team 0's tap loop.
@@ -177,7 +220,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
             unsigned inb = 0xffffffffu;
             float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
             bool interior = true;
-            if (do_stage) {
+            // With 2 M-tiles per wave the loads go first and fly during the epilogue; with 4 the tap loop of the partner is
+            // twice as long as a staging phase, so the epilogue runs first and the 40 load registers are not live beside it.
+            constexpr bool LOADS_FIRST = MT <= 2;
+            auto issue_loads = [&]() {
                 if (scale) {
                     sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
                     sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
@@ -185,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                 // one uniform base pointer per step (the halo origin: may lie outside the tensor for border patches, where
                 // only in-range voxels are dereferenced) + per-thread constant 32-bit offsets
                 const float* xb = x + ((((int64_t)cu.n * D + (cu.z0 - PZ)) * H + (cu.y0 - PY)) * W + (cu.x0 - PX)) * x_ld + ci * BCK;
+                const __amdgpu_buffer_rsrc_t rx = pp_rsrc(xb);
                 interior = (cu.z0 >= PZ) & (cu.z0 + HZ - PZ <= D) & (cu.y0 >= PY) & (cu.y0 + HY - PY <= H) & (cu.x0 >= PX) &
                            (cu.x0 + HX - PX <= W);
                 if (interior) {
@@ -193,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                         if (TEM_PP_ABL & 1)
                             tmp[it] = make_float4(0.5f + it, 0.25f, -1.f, 2.f);
                         else
-                            tmp[it] = *reinterpret_cast<const float4*>(xb + hoff[it]);
+                            tmp[it] = pp_load4(rx, hoff[it], 0);
                     }
                 } else {
                     inb = 0;
@@ -201,94 +248,104 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                     const int bz = cu.z0 - PZ, by = cu.y0 - PY, bx = cu.x0 - PX;
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
-                        const unsigned gz = (unsigned)(bz + (int)(hpk[it] & 255u)), gy = (unsigned)(by + (int)((hpk[it] >> 8) & 255u)),
-                                       gx = (unsigned)(bx + (int)(hpk[it] >> 16));
+                        // halo coordinates recomputed here (border patches only) rather than kept in registers
+                        const int hv = min(hv0 + 64 * it, HV - 1);
+                        const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+                        const unsigned gz = (unsigned)(bz + hz), gy = (unsigned)(by + hy), gx = (unsigned)(bx + hx);
                         const bool ok = (gz < zlim) & (gy < ylim) & (gx < xlim);   // unsigned: negative coordinates are huge
                         inb |= ok ? (1u << it) : 0u;
-                        tmp[it] = *reinterpret_cast<const float4*>(xb + (ok ? hoff[it] : ctr_off));
+                        tmp[it] = pp_load4(rx, ok ? hoff[it] : ctr_off, 0);
                     }
                 }
-            }
+            };
+            if (LOADS_FIRST && do_stage) issue_loads();
             PP_STAMP(1);
             // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
             if (epi_pending) {
-                float* yb = y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld;
-                const float* rb = ref ? ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld : nullptr;
+                const __amdgpu_buffer_rsrc_t ry = pp_rsrc(y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld);
+                const bool has_ref = ref != nullptr;
+                const __amdgpu_buffer_rsrc_t rr_ = pp_rsrc(has_ref ? ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld : y);
                 const bool full = (eu.z0 + TZ <= D) & (eu.y0 + TY <= H) & (eu.x0 + TX <= W);
-                const float inv = F16 ? F16_PRESCALE_INV : 1.f;
                 // FULL: the patch lies inside the volume (no per-element bounds); else its outside voxels count as zero in
                 // the statistics and are not stored.  One uniform branch, two straight-line bodies.
-                auto body = [&](auto full_tag) {
-                    constexpr bool FULL = decltype(full_tag)::value;
+                auto body = [&](auto full_tag, auto ref_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value, HASREF = decltype(ref_tag)::value;
 #pragma unroll
                     for (int nn = 0; nn < NW; ++nn) {
                         const int cb = ((eu.cot * WN + wn) * NW + nn) * 32;   // first channel of this column tile
-                        const float bv = bias ? bias[cb + r] : 0.f;
-                        float ssum = 0.f, ssq = 0.f;
+                        const float bv = bve[nn];   // loaded when the unit was decoded: a load issued HERE would sit behind the
+                                                    // halo loads in vmcnt order and stall the epilogue for their whole latency
+                        float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};     // two chains: the adds of a tile are independent
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
                             const int yy0 = (wm * MT + m) * 4;   // combined (z, y) row index of the tile's first y-row
 #pragma unroll
                             for (int reg = 0; reg < 16; ++reg) {
-                                float o = fmaxf(fmaf(acc[m][nn][reg], inv, bv), act_floor);
+                                float a = acc[m][nn][reg];
+                                if (SC) {
+                                    a = fmaf(accl[SC ? m : 0][SC ? nn : 0][reg], 1.f / F16_LO_SCALE, a);
+                                    accl[SC ? m : 0][SC ? nn : 0][reg] = 0.f;
+                                }
+                                float o = fmaxf(a + bv, act_floor);
                                 if (!FULL) {
                                     const int yy = yy0 + (reg >> 2);
                                     const bool ok = (eu.z0 + yy / TY < D) & (eu.y0 + yy % TY < H) & (eu.x0 + (reg & 3) + 4 * kh < W);
                                     o = ok ? o : 0.f;
                                 }
-                                ssum += o;
-                                ssq = fmaf(o, o, ssq);
+                                ssum[reg & 1] += o;
+                                ssq[reg & 1] = fmaf(o, o, ssq[reg & 1]);
                                 scr_w[((reg & 3) + 8 * (reg >> 2)) * SCP] = o;
                                 acc[m][nn][reg] = 0.f;  // the next unit of this team starts from zero
                             }
                             // transposed read-back: 4 x (8 voxels x 128 B) per tile, one 16-byte store per lane each
+                            float4 v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(scr_r + 8 * j * SCP);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                float4 v = *reinterpret_cast<const float4*>(scr_r + 8 * j * SCP);
                                 const int yy = yy0 + j, pz = yy / TY, py = yy % TY;
-                                const int64_t srow = ((int64_t)pz * H + py) * W;   // scalar: voxel offset of this y-row
+                                const unsigned srow = (unsigned)((pz * H + py) * W);   // scalar: voxel offset of this y-row
                                 bool ok = true;
                                 if (!FULL) ok = (eu.z0 + pz < D) & (eu.y0 + py < H) & (eu.x0 + rr < W);
-                                if (rb) {
-                                    if (FULL || ok) {
-                                        const float4 q = *reinterpret_cast<const float4*>(rb + srow * ref_ld + cb + roff_lane);
-                                        v.x = q.x > 0.f ? v.x : 0.f;
-                                        v.y = q.y > 0.f ? v.y : 0.f;
-                                        v.z = q.z > 0.f ? v.z : 0.f;
-                                        v.w = q.w > 0.f ? v.w : 0.f;
-                                    }
+                                if (HASREF) {
+                                    const float4 q = pp_load4(rr_, (FULL || ok) ? roff_lane + (unsigned)cb * 4u : 0u,
+                                                              (FULL || ok) ? srow * (unsigned)ref_ld * 4u : 0u);
+                                    v[j].x = q.x > 0.f ? v[j].x : 0.f;
+                                    v[j].y = q.y > 0.f ? v[j].y : 0.f;
+                                    v[j].z = q.z > 0.f ? v[j].z : 0.f;
+                                    v[j].w = q.w > 0.f ? v[j].w : 0.f;
                                 }
-                                if ((FULL || ok) && (!(TEM_PP_ABL & 2) || v.x == 12345.678f)) {
-                                    floatx4s vv = {v.x, v.y, v.z, v.w};
-                                    __builtin_nontemporal_store(vv, reinterpret_cast<floatx4s*>(yb + srow * y_ld + cb + yoff_lane));
-                                }
+                                if ((FULL || ok) && (!(TEM_PP_ABL & 2) || v[j].x == 12345.678f))
+                                    pp_store4_nt(ry, yoff_lane + (unsigned)cb * 4u, srow * (unsigned)y_ld * 4u, v[j]);
                             }
                         }
                         if (stat) {  // grid-uniform: per (sample, patch, voxel-wave, channel) partial sums of the stored output
-                            ssum += __shfl_xor(ssum, 32, 64);  // the lane halves hold different rows of one column
-                            ssq += __shfl_xor(ssq, 32, 64);
+                            float sa = ssum[0] + ssum[1], sb = ssq[0] + ssq[1];
+                            sa += __shfl_xor(sa, 32, 64);  // the lane halves hold different rows of one column
+                            sb += __shfl_xor(sb, 32, 64);
                             if (kh == 0) {
                                 const int64_t patch = ((int64_t)(eu.z0 / TZ) * nY + eu.y0 / TY) * nX + eu.x0 / TX;
                                 const int64_t nblk = (int64_t)nZ * nY * nX * WM;
                                 float* dst = stat + (((int64_t)eu.n * nblk + patch * WM + wm) * Cout + cb + r) * 2;
-                                dst[0] = ssum;
-                                dst[1] = ssq;
+                                dst[0] = sa;
+                                dst[1] = sb;
                             }
                         }
                     }
                 };
-                if (full)
-                    body(std::true_type{});
-                else
-                    body(std::false_type{});
+                if (full) {
+                    if (has_ref) body(std::true_type{}, std::true_type{});
+                    else body(std::true_type{}, std::false_type{});
+                } else {
+                    if (has_ref) body(std::false_type{}, std::true_type{});
+                    else body(std::false_type{}, std::false_type{});
+                }
                 epi_pending = false;
             }
+            if (!LOADS_FIRST && do_stage) issue_loads();
+            PP_STAMP(6);
             // ---- norm, split, LDS tile; then prime the weight-fragment ring of the coming tap loop ----
             if (do_stage) {
-                if (F16) {  // the activation prescale rides on the norm's scale / shift
-                    sc4.x *= F16_A_PRESCALE; sc4.y *= F16_A_PRESCALE; sc4.z *= F16_A_PRESCALE; sc4.w *= F16_A_PRESCALE;
-                    sf4.x *= F16_A_PRESCALE; sf4.y *= F16_A_PRESCALE; sf4.z *= F16_A_PRESCALE; sf4.w *= F16_A_PRESCALE;
-                }
                 float* lw = lds + hv0 * LSV + c4 * 2;
                 auto convert = [&](auto interior_tag) {
                     constexpr bool INTERIOR = decltype(interior_tag)::value;
@@ -304,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                             }
                             if (F16) {
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) e[c] = __builtin_amdgcn_fmed3f(e[c], -64000.f, 64000.f);
+                                for (int c = 0; c < 4; ++c) e[c] = __builtin_amdgcn_fmed3f(e[c], -60000.f, 60000.f);
                             }
 #pragma unroll
                             for (int p = 0; p < NS; ++p) {
@@ -316,6 +373,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                                     e[1] -= hi16<F16>(h0);
                                     e[2] -= lo16<F16>(h1);
                                     e[3] -= hi16<F16>(h1);
+                                    if (SC) {
+#pragma unroll
+                                        for (int c = 0; c < 4; ++c) e[c] *= F16_LO_SCALE;
+                                    }
                                 }
                             }
                         }
@@ -325,16 +386,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                     convert(std::true_type{});
                 else
                     convert(std::false_type{});
+                PP_STAMP(7);
 #pragma unroll
-                for (int nn = 0; nn < NW; ++nn)
-                    wq[nn] = wp + (int64_t)((cu.cot * WN + wn) * NW + nn) * NT * nch * FR + (int64_t)ci * FR + lane;
+                for (int nn = 0; nn < NW; ++nn)   // scalar byte offset of (column tile, tap 0, chunk ci) in the packed weights
+                    wsoff[nn] = (unsigned)((((cu.cot * WN + wn) * NW + nn) * NT * nch + ci) * FR) * 16u;
                 if (RD > 1) {
 #pragma unroll
                     for (int gp = 0; gp < RD - 1; ++gp)
 #pragma unroll
                         for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
-                            for (int p = 0; p < NS; ++p) bq[gp][nn][p] = wq[nn][gp * tapstride + p * 64];
+                            for (int p = 0; p < NS; ++p)
+                                bq[gp][nn][p] = pp_load4u(rw, woff_lane, wsoff[nn] + (unsigned)(gp * tapstride + p * 64) * 16u);
                 }
             }
             PP_STAMP(2);
@@ -373,9 +436,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
 #pragma unroll
                         for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
-                            for (int p = 0; p < NS; ++p) bq[gp % RD][nn][p] = wq[nn][(int64_t)gp * ts + p * 64];
+                            for (int p = 0; p < NS; ++p)
+                                bq[gp % RD][nn][p] = pp_load4u(rw, woff_lane, wsoff[nn] + (unsigned)(gp * ts + p * 64) * 16u);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (TEM_PP_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -390,9 +454,26 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                                                      "v"(bq[tap % RD][nn][sum - i].x), "v"(bq[tap % RD][nn][sum - i].w));
                                         continue;
                                     }
-                                    acc[m][nn] = mfma16<F16>(af[tap & 1][m][i], bq[tap % RD][nn][sum - i], acc[m][nn]);
+                                    if (SC && sum == 1)
+                                        accl[SC ? m : 0][SC ? nn : 0] = mfma16<F16>(af[tap & 1][m][i], bq[tap % RD][nn][sum - i],
+                                                                                    accl[SC ? m : 0][SC ? nn : 0]);
+                                    else
+                                        acc[m][nn] = mfma16<F16>(af[tap & 1][m][i], bq[tap % RD][nn][sum - i], acc[m][nn]);
                                 }
                         }
+                    if (TEM_PP_SCHED == 1) {
+                        // an in-order wave issues the next tap's loads in the shadow of this tap's MFMAs only if they sit
+                        // BETWEEN them: a block of 6+ memory instructions after the last MFMA outlasts its 32 cycles
+                        constexpr int NM = MT * NW * (NS * (NS + 1) / 2), NL = MT * NS, NV = NW * NS;
+#pragma unroll
+                        for (int k = 0; k < NM; ++k) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (k < NL)
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            else if (k - NL < NV)
+                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (TEM_PP_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -405,7 +486,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
                 ci = 0;
                 eu = cu;
                 epi_pending = true;
-                if (++ui < my_units) cu = decode(ui);
+#pragma unroll
+                for (int nn = 0; nn < NW; ++nn) bve[nn] = bvc[nn];
+                if (++ui < my_units) {
+                    cu = decode(ui);
+                    if (bias) {
+#pragma unroll
+                        for (int nn = 0; nn < NW; ++nn) bvc[nn] = bias[((cu.cot * WN + wn) * NW + nn) * 32 + r];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -430,7 +519,7 @@ static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     PpGeom g = {};
     const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
     if (opt == 0) return g;
-    if (!(nsplit == 2 || nsplit == 6)) return g;
+    if (!(nsplit == 2 || nsplit == 4)) return g;
     if (!(kh == 3 && kw == 3 && (kd == 3 || kd == 1))) return g;
     if (D < 4 || Cin % 16 || Cout % 32) return g;
     if ((int64_t)H * W * 8 * 4 * max_ld >= (1ll << 31)) return g;  // 32-bit byte offsets inside one halo / one patch
@@ -496,7 +585,7 @@ bool tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const flo
     if ((y_ld % 4) || ((uintptr_t)y % 16) || (ref && ((ref_ld % 4) || ((uintptr_t)ref % 16))) || (stat && ref) ||
         act == TEM_ACT_SIGMOID)
         return false;
-    const bool f16 = nsplit == 6;
+    const bool f16 = nsplit == 4;
 #define PPGO(KD, CT)                                                                                                  \
     do {                                                                                                              \
         if (f16)                                                                                                      \

@@ -67,6 +67,9 @@ __device__ __forceinline__ float act_apply_b(float v, int act) {
 // does drop into the subnormal range (|x^| < 2^-7, |w| < 2^-9) its absolute error is <= 2^-25 in scaled units, i.e.
 // <= 1e-9 of an O(1) activation / 2.4e-10 of a weight: below the fp32 rounding of the typical terms of the same dot
 // product.  All three products hi*hi + hi*lo + lo*hi share ONE accumulator; the epilogue multiplies by 2^-12.
+// MEASURED AND REJECTED as the default: the matrix core aligns the small cross products to the large accumulator and
+// truncates, a one-sided error of ~1e-5 per output; harmless per element, but the GroupNorm backward sums it over all
+// voxels (tests/test_gpu_unet.py: 4e-3 on the first norm's bias gradient vs 5e-5 for the two-accumulator layout).
 // Range: |x^| <= 2000 (an InstanceNorm output is bounded by sqrt(voxels); clamped beyond), |w| <= 500 (clamped).
 #define F16_A_PRESCALE 32.f
 #define F16_W_PRESCALE 128.f

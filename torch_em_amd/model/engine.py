@@ -59,7 +59,7 @@ _FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
 # The backward convolutions are LINEAR in the incoming gradient with masks fixed by the forward
 # pass, so their 1e-5 error is not amplified.
 PRECISION = os.environ.get("TEM_PRECISION", "split16")
-_F16X3_MODE = int(os.environ.get("TEM_F16X3_LAYOUT", "6"))
+_F16X3_MODE = int(os.environ.get("TEM_F16X3_LAYOUT", "4"))
 
 
 def set_precision(mode: str):
@@ -122,8 +122,9 @@ class ConvSpec:
     def _modes(self):
         mode_f = {"bf16x3": 2, "split": 3, "split16": 3, "amp": 5}.get(PRECISION, 1)
         if PRECISION == "split16" and self.norm is not None and self.k != (1, 1, 1):
-            # fp16x3 with prescaled operands (TEM_WL_F16X3S, csrc/conv_split.h): the conv reads pre-normalised activations
-            # (|x^| <= sqrt(voxels); clamped at 2000).  TEM_F16X3_LAYOUT=4 selects the older scaled-lo-plane variant.
+            # fp16x3: the conv reads pre-normalised activations (|x^| of order 1..100 << 65504; clamped at 6e4).
+            # TEM_F16X3_LAYOUT=6 selects the single-accumulator variant with prescaled operands (csrc/conv_split.h), which
+            # fails the GroupNorm parity test (one-sided accumulation error): experiments only.
             mode_f = _F16X3_MODE
         mode_d = 5 if PRECISION == "amp" else 2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
         mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
