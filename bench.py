@@ -33,6 +33,10 @@ STEP_GB = 25.58                 # conv-centric fp32 traffic of c
 
 # live-event tags -> kernel names as rocprofv3 prints them (dominant template instantiation of each tag)
 RP_NAMES = {
+    "k_conv_pp_bf16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, false>",
+    "k_conv_pp_bf16x3<3,3,3,CT=1>": "k_conv_pp<3, 3, 3, 4, 8, 8, 1, 1, 2, false>",
+    "k_conv_pp_f16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, true>",
+    "k_conv_pp_f16x3<3,3,3,CT=1>": "k_conv_pp<3, 3, 3, 4, 8, 8, 1, 1, 2, true>",
     "k_conv_fwd_bf16x6<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 3, false>",
     "k_conv_fwd_bf16x6<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 3, false>",
     "k_conv_fwd_bf16x3<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 2, false>",
@@ -319,14 +323,17 @@ def main():
         achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s (algorithmic: 2*MACs of the convolution)
         split = 6 if "bf16x6" in dom_tag else (3 if ("bf16x3" in dom_tag or "f16x3" in dom_tag) else
                                                1 if "_f16<" in dom_tag else 0)
+        traffic_file = os.path.join(ROOT, "profiles", "r02_traffic_bytes_per_launch.json")
+        if not os.path.exists(traffic_file):
+            traffic_file = os.path.join(ROOT, "profiles", "r01_traffic_bytes_per_launch.json")
         # split-bf16 kernels execute 3 (or 6) bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3 (6)
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
         standard = (args.batch == 2 and S == 128)
         # HBM bytes per launch of the dominant kernel: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-        # passes (scripts/summarize_profiles.py -> profiles/r01_traffic_bytes_per_launch.json; gfx950 x2 FETCH correction)
+        # passes (scripts/summarize_profiles.py -> profiles/r02_traffic_bytes_per_launch.json; gfx950 x2 FETCH correction)
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_bytes_per_launch.json")))
+            tj = json.load(open(traffic_file))
             key = RP_NAMES.get(dom_tag.split("(")[0])
             if key in tj:
                 traffic = tj[key]

@@ -144,6 +144,10 @@ int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float
  * stat_blocks = tem_conv3d_fwd_stat_blocks(...), which returns 0 for launches that cannot provide them (VALU / exact
  * fp32 kernels, split-K shapes): use tem_norm_stats there.  tem_norm_finalize_partials (below) merges them. */
 int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
+/* Which kernel family a tem_conv3d_fwd launch of this shape selects under the current options: 1 = the ping-pong team
+ * kernel (csrc/conv_pp.hip: 3x3x3 / 1x3x3, two-plane layouts, enough patches to fill the chip), 0 = everything else.
+ * Profiling aid (kernel tables of bench.py); alignment fall-backs of an individual launch are not reflected. */
+int tem_conv3d_fwd_kernel(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 int tem_conv3d_fwd_stats(const float* x, int64_t x_ld, const float* scale, const float* shift,
                          const float* w_packed, const float* bias, float* y, int64_t y_ld,
                          const float* ref, int64_t ref_ld, void* ws, int64_t ws_bytes,

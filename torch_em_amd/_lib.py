@@ -35,6 +35,7 @@ SIGNATURES = {
     "tem_conv3d_fwd": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64]
                        + [c_int] * 11 + [c_vp]),
     "tem_conv3d_fwd_stat_blocks": (c_i64, [c_int] * 10),
+    "tem_conv3d_fwd_kernel": (c_int, [c_int] * 10),
     "tem_conv3d_fwd_stats": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64]
                              + [c_int] * 11 + [c_vp, c_i64, c_vp]),
     "tem_conv3d_wgrad_ws": (c_i64, [c_int] * 10),

@@ -332,6 +332,13 @@ extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Ci
     return tem_conv_fwd_bf16x3_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma);
 }
 
+extern "C" int tem_conv3d_fwd_kernel(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma) {
+    if (use_mfma >= 2 && use_mfma <= 6 && Cin % 16 == 0 && Cout % 32 == 0 &&
+        tem_conv_pp_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) >= 0)
+        return 1;
+    return 0;
+}
+
 extern "C" int tem_conv3d_fwd_stats(const float* x, int64_t x_ld, const float* scale, const float* shift,
                                     const float* w_packed, const float* bias, float* y, int64_t y_ld, const float* ref,
                                     int64_t ref_ld, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin,

@@ -30,6 +30,12 @@
 #ifndef TEM_PP_SCHED
 #define TEM_PP_SCHED 1   // tap loop: 0 = loads of the next tap | MFMAs of this tap, pinned; 1 = one load between two MFMAs
 #endif
+#ifndef TEM_PP_LF
+#define TEM_PP_LF -1     // staging order: 1 halo loads before the epilogue, 0 after it, -1 by tile size (see LOADS_FIRST)
+#endif
+#ifndef TEM_PP_ST_AUX
+#define TEM_PP_ST_AUX 2  // cache policy of the epilogue stores: 2 = nt (the output is not re-read by this kernel), 0 = default
+#endif
 #ifndef TEM_PP_ABL
 #define TEM_PP_ABL 0     // harness-only ablations (scripts/pp_harness.cpp): 1 no halo loads, 2 no stores, 4 no weight loads in
 #endif                   // the tap loop, 8 no split / LDS writes, 16 no MFMAs
@@ -61,7 +67,7 @@ __device__ __forceinline__ uint4 pp_load4u(__amdgpu_buffer_rsrc_t r, unsigned vo
 __device__ __forceinline__ void pp_store4_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
     const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
                      __builtin_bit_cast(unsigned, v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 2);  // aux 2 = nt: the output is not re-read by this kernel
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, TEM_PP_ST_AUX);
 }
 
 #ifdef TEM_PP_TRACE   // developer build (scripts/pp_harness.cpp): shader-clock stamps of the phases of one workgroup
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
             bool interior = true;
             // With 2 M-tiles per wave the loads go first and fly during the epilogue; with 4 the tap loop of the partner is
             // twice as long as a staging phase, so the epilogue runs first and the 40 load registers are not live beside it.
-            constexpr bool LOADS_FIRST = MT <= 2;
+            constexpr bool LOADS_FIRST = TEM_PP_LF < 0 ? (MT <= 2) : (TEM_PP_LF != 0);
             auto issue_loads = [&]() {
                 if (scale) {
                     sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);

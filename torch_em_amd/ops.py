@@ -24,7 +24,9 @@ PROFILER = None
 PROFILER_FILTER = None
 
 
-def _fwd_tag(mfma, k, cout):
+def _fwd_tag(mfma, k, cout, pp=False):
+    if pp:  # the ping-pong team kernel (csrc/conv_pp.hip)
+        return f"k_conv_pp_{'f16x3' if int(mfma) == 4 else 'bf16x3'}<{k[0]},{k[1]},{k[2]},CT={2 if cout % 64 == 0 else 1}>"
     kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3", 5: "k_conv_fwd_f16",
              6: "k_conv_fwd_f16x3"}.get(int(mfma)) or
             ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu")) + f"<{k[0]},{k[1]},{k[2]}"
@@ -199,7 +201,10 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     lib = _lib.load()
     nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 1) if mfma else 0
     ws = _workspace(nws, x.device) if nws else None
-    kind = _fwd_tag(mfma, k, cout) if PROFILER is not None else None
+    kind = None
+    if PROFILER is not None:
+        pp = bool(mfma) and bool(lib.tem_conv3d_fwd_kernel(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
+        kind = _fwd_tag(mfma, k, cout, pp)
     nblk = lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if want_stats else 0
     ev0 = _prof_begin(x, kind)
     part = None
