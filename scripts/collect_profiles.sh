@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export TEM_BENCH_PREWARM_S=0
-CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof -o bench -- $CMD > $OUT/rocprof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- $CMD > $OUT/pmc_$c.log 2>&1

@@ -20,7 +20,7 @@ def short(name):
 rows = list(csv.DictReader(open(os.path.join(src, "rocprof", "bench_kernel_stats.csv"))))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(dst + "_kernel_stats.txt", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline  ({steps} steps incl. warm-up)\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras  ({steps} steps incl. warm-up)\n")
     f.write(f"# GPU busy {tot / 1e6 / steps:.2f} ms/step\n")
     f.write(f"{'kernel':80s} {'calls':>6s} {'avg_us':>10s} {'ms/step':>9s} {'%':>6s}\n")
     for r in rows[:45]:

@@ -1,0 +1,67 @@
+// wg_harness.cpp -- developer harness for the weight-gradient kernel (no torch); see scripts/wg_harness.sh.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../torch_em_amd/csrc/tem_common.h"
+#include "../torch_em_amd/csrc/conv_internal.h"
+#ifdef TEM_ZS_TRACE
+void tem_zs_trace_read(unsigned long long* dst);
+#endif
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+static float frand(uint64_t& s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (float)((s >> 40) & 0xffffff) / 8388608.f - 1.f; }
+
+int main(int argc, char** argv) {
+    if (argc < 7) { printf("usage: %s N D H W Cin Cout [iters]\n", argv[0]); return 1; }
+    const int N = atoi(argv[1]), D = atoi(argv[2]), H = atoi(argv[3]), W = atoi(argv[4]), Cin = atoi(argv[5]), Cout = atoi(argv[6]);
+    const int iters = argc > 7 ? atoi(argv[7]) : 10;
+    const size_t V = (size_t)N * D * H * W;
+    uint64_t seed = 99;
+    std::vector<float> hx(V * Cin), hg(V * Cout), hs((size_t)N * Cin), hf((size_t)N * Cin);
+    for (auto& v : hx) v = 2.f * frand(seed);
+    for (auto& v : hg) v = frand(seed);
+    for (auto& v : hs) v = 1.f + 0.5f * frand(seed);
+    for (auto& v : hf) v = frand(seed);
+    float *x, *g, *sc, *sf, *dw, *db;
+    CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&g, hg.size() * 4)); CK(hipMalloc(&sc, hs.size() * 4)); CK(hipMalloc(&sf, hf.size() * 4));
+    CK(hipMalloc(&dw, (size_t)Cin * Cout * 27 * 4)); CK(hipMalloc(&db, Cout * 4));
+    CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(g, hg.data(), hg.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(sc, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(sf, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+    const int64_t wsb = tem_conv_wgrad_bf16x3_ws(N, D, H, W, Cin, Cout, 3, 3, 3);
+    void* ws; CK(hipMalloc(&ws, wsb));
+    hipStream_t s = 0;
+    auto run = [&]() {
+        int rc = tem_conv_wgrad_bf16x3(x, Cin, sc, sf, g, Cout, dw, db, ws, wsb, N, D, H, W, Cin, Cout, 3, 3, 3, 1, 0, nullptr, nullptr,
+                                       nullptr, nullptr, s);
+        if (rc) { printf("launch failed: %s\n", tem_last_error()); exit(1); }
+    };
+    for (int i = 0; i < 3; ++i) run();
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) run();
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters; if (ms < best) best = ms;
+    }
+    const double fl = 2.0 * V * Cin * Cout * 27;
+    printf("wgrad %dx%dx%dx%d %d->%d: min %.4f ms (kernel + slab merge)  %.0f TF alg  mfma_frac(2500) %.3f\n", N, D, H, W, Cin, Cout, best,
+           fl / best / 1e9, fl * 3 / best / 1e9 / 2500);
+#ifdef TEM_ZS_TRACE
+    std::vector<unsigned long long> tr(8 * 64 * 8);
+    tem_zs_trace_read(tr.data());
+    const unsigned long long base = tr[0];
+    for (int wv : {0, 1, 4, 7}) {
+        printf("wave %d: iter   mfma  stores  loads  barrier   (shader cycles)\n", wv);
+        for (int it = 0; it < 24; ++it) {
+            const unsigned long long* t = &tr[(wv * 64 + it) * 8];
+            if (!t[0]) break;
+            printf("  %2d @%8llu: %6lld %6lld %6lld %6lld\n", it, t[0] - base, (long long)(t[1] - t[0]), (long long)(t[2] - t[1]),
+                   (long long)(t[3] - t[2]), (long long)(t[4] - t[3]));
+        }
+    }
+#endif
+    return 0;
+}

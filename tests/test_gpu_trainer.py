@@ -426,3 +426,37 @@ def test_default_trainer_matches_the_reference_trainer_run(tmp_path):
         a, b = v.cpu().double(), torch.from_numpy(g[f"sd1.{k}"]).double()
         assert float((a - b).norm() / b.norm()) < 0.15, k   # 8 Adam steps of lr 1e-2 (10x the default) on two fp32 trajectories:
         # sign(g)-sized steps wherever |g| is at round-off level; the loss / metric trajectory above is the tight check
+
+
+def test_device_prepass_and_prefetch_match_the_serial_loop(tmp_path):
+    """trainer/input_pipeline.py: raw volume + int labels from a DataLoader, standardize / flips / boundary targets on the
+    device one batch ahead on a side stream -- the trained parameters are bit-identical to the serial (no side stream)
+    loop and the batches are what the pre-pass kernels produce when called directly."""
+    import functools
+    import torch_em_amd
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.transform import BoundaryTransform, standardize
+    from torch_em_amd.transform.label import BatchTargets
+    rng = np.random.RandomState(0)
+    raw = torch.from_numpy((rng.rand(6, 1, 16, 16, 16) * 255).astype("float32"))
+    lab = torch.from_numpy(rng.randint(0, 5, size=(6, 1, 16, 16, 16)).astype("int32"))
+    ds = torch.utils.data.TensorDataset(raw, lab)
+    finals = []
+    for prefetch in (True, False):
+        torch.manual_seed(0)
+        model = UNet3d(1, 2, depth=2, initial_features=4)
+        loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, pin_memory=prefetch)
+        trainer = torch_em_amd.default_segmentation_trainer(
+            "pf", model, loader, loader, device=DEV, logger=None, save_root=str(tmp_path / str(prefetch)),
+            raw_transform=functools.partial(standardize, per_sample=True), prefetch=prefetch,
+            target_transform=BatchTargets(BoundaryTransform(add_binary_target=True, ndim=3)))
+        seen = [(x.clone(), y.clone()) for x, y in trainer._batches(loader, train=False)]
+        assert len(seen) == 3
+        x0 = standardize(raw[:2].to(DEV), per_sample=True)
+        assert torch.equal(seen[0][0], x0) and tuple(seen[0][1].shape) == (2, 2, 16, 16, 16)
+        m = raw[0].double().mean()
+        s = raw[0].double().std(unbiased=False)
+        assert rel_err(seen[0][0][0].cpu(), ((raw[0].double() - m) / (s + 1e-7)).float()) < 1e-5
+        trainer.fit(iterations=6)
+        finals.append(torch.cat([p.detach().flatten() for p in model.parameters()]).cpu())
+    assert torch.equal(finals[0], finals[1])

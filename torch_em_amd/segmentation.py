@@ -64,7 +64,9 @@ def default_segmentation_trainer(name: str, model: torch.nn.Module, train_loader
                                  optimizer_kwargs: Dict[str, Any] = {}, trainer_class=DefaultTrainer,
                                  id_: Optional[str] = None, save_root: Optional[str] = None,
                                  compile_model: Optional[Union[bool, str]] = None, rank: Optional[int] = None,
-                                 mixed_precision_dtype: Optional[str] = None, optimizer=None, lr_scheduler=None):
+                                 mixed_precision_dtype: Optional[str] = None, optimizer=None, lr_scheduler=None,
+                                 target_transform: Optional[Callable] = None, augmentation: Optional[Callable] = None,
+                                 raw_transform: Optional[Callable] = None, prefetch: bool = True):
     """Trainer with the reference's defaults (reference :466-577)."""
     if optimizer is None:
         optimizer = FusedAdamW(model.parameters(), lr=learning_rate, **optimizer_kwargs)
@@ -81,4 +83,5 @@ def default_segmentation_trainer(name: str, model: torch.nn.Module, train_loader
                          mixed_precision=mixed_precision, early_stopping=early_stopping,
                          log_image_interval=log_image_interval, logger=logger, logger_kwargs=logger_kwargs, id_=id_,
                          save_root=save_root, compile_model=compile_model, rank=rank,
-                         mixed_precision_dtype=mixed_precision_dtype)
+                         mixed_precision_dtype=mixed_precision_dtype, target_transform=target_transform,
+                         augmentation=augmentation, raw_transform=raw_transform, prefetch=prefetch)

@@ -79,7 +79,8 @@ class DefaultTrainer:
                  logger=None, logger_kwargs: Optional[Dict[str, Any]] = None, id_: Optional[str] = None,
                  save_root: Optional[str] = None, compile_model: Optional[Union[bool, str]] = None,
                  rank: Optional[int] = None, mixed_precision_dtype: Optional[str] = None,
-                 target_transform: Optional[Callable] = None, augmentation: Optional[Callable] = None):
+                 target_transform: Optional[Callable] = None, augmentation: Optional[Callable] = None,
+                 raw_transform: Optional[Callable] = None, prefetch: bool = True):
         if name is None:
             raise TypeError("Name cannot be None if not using the WandbLogger")
         self.name, self.id_ = name, id_ or name
@@ -112,6 +113,11 @@ class DefaultTrainer:
         # not in the reference either: an on-device augmentation pipeline (transform.augmentation.get_augmentations)
         # applied to the (x, y) TRAINING batch already in HBM; the reference augments in the CPU data-loader workers
         self.augmentation = augmentation
+        # not in the reference: a raw transform applied to the device batch (e.g. functools.partial(standardize,
+        # per_sample=True): the reference standardises each sample in the loader workers, transform/raw.py:40-65), and
+        # `prefetch`: copy + pre-pass of batch k+1 run on a side stream during step k (trainer/input_pipeline.py)
+        self.raw_transform = raw_transform
+        self.prefetch = prefetch
 
     # ---- bookkeeping ------------------------------------------------------------------
     @property
@@ -314,6 +320,22 @@ class DefaultTrainer:
         tt = getattr(self, "target_transform", None)
         return y if tt is None else tt(y)
 
+    def _prepass(self, train: bool):
+        """(x, y) -> (x, y) on the device: raw transform, augmentation (training only), target transform."""
+        def run(x, y):
+            rt = getattr(self, "raw_transform", None)
+            if rt is not None:
+                x = rt(x)
+            if train:
+                x, y = self._augment(x, y)
+            return x, self._targets(y)
+        return run
+
+    def _batches(self, loader, train: bool):
+        from .input_pipeline import DevicePrefetcher
+        on_gpu = self.device.type == "cuda"
+        return DevicePrefetcher(loader, self.device, self._prepass(train), enabled=on_gpu and getattr(self, "prefetch", True))
+
     def _forward_and_loss(self, x, y):
         pred = self.model(x)
         return pred, self.loss(pred, y)
@@ -345,10 +367,7 @@ class DefaultTrainer:
         """The hot loop (reference :805-831): H2D copy, zero_grad, forward, loss, backward, step."""
         self.model.train()
         n_iter, t0 = 0, time.time()
-        for x, y in self.train_loader:
-            x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
-            x, y = self._augment(x, y)
-            y = self._targets(y)
+        for x, y in self._batches(self.train_loader, train=True):
             self.optimizer.zero_grad()
             with self._precision():
                 pred, loss = self._forward_and_loss(x, y)
@@ -368,9 +387,7 @@ class DefaultTrainer:
         self.model.eval()
         metric_val = loss_val = None
         with torch.no_grad(), self._precision():
-            for x, y in self.val_loader:
-                x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
-                y = self._targets(y)
+            for x, y in self._batches(self.val_loader, train=False):
                 pred, loss = self._forward_and_loss(x, y)
                 metric = self.metric(pred, y)
                 loss_val = loss.detach() if loss_val is None else loss_val + loss.detach()

@@ -92,10 +92,7 @@ class SPOCOTrainer(DefaultTrainer):
         self.model.train()
         self.model2.train()
         n_iter, t0 = 0, time.time()
-        for x, y in self.train_loader:
-            x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
-            x, y = self._augment(x, y)
-            y = self._targets(y)
+        for x, y in self._batches(self.train_loader, train=True):
             prediction, loss = self._step(x, self.loss, y)
             if self.logger is not None:
                 lr = [pm["lr"] for pm in self.optimizer.param_groups][0]
@@ -117,9 +114,7 @@ class SPOCOTrainer(DefaultTrainer):
         self.model2.eval()
         metric = loss = None
         with torch.no_grad(), self._precision():
-            for x, y in self.val_loader:
-                x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
-                y = self._targets(y)
+            for x, y in self._batches(self.val_loader, train=False):
                 prediction, prediction2 = self.model(x), self.model2(x)
                 lv = self.loss((prediction, prediction2), y).detach()
                 mv = self.metric(prediction, y).detach()
