@@ -59,6 +59,10 @@ CONV_CASES = [
     (1, 16, 16, 24, 64, 64, (3, 3, 3)),  # z-sliding wgrad kernel, two Cout tiles
     (2, 33, 8, 8, 32, 96, (3, 3, 3)),    # z-sliding, odd depth, Cout = 3 tiles (last group half empty)
     (1, 16, 132, 136, 32, 32, (3, 3, 3)),  # z-sliding, 289 columns > 256 CUs: workgroups walk two columns each
+    (1, 16, 16, 16, 256, 512, (3, 3, 3)),  # benchmark widths of the deepest levels: split-K forward / dgrad, 16^3 wgrad
+    (2, 8, 8, 8, 512, 512, (3, 3, 3)),     # the 8^3 base level: split-K forward, the single-wave-of-workgroups wgrad plan
+    (2, 20, 24, 40, 64, 32, (3, 3, 3)),    # ping-pong kernel, Cin = 64 -> one Cout tile (decoder level 0), ragged patches
+    (2, 12, 24, 24, 128, 64, (3, 3, 3)),   # ping-pong kernel, Cin = 128 -> two Cout tiles (decoder level 1)
 ]
 
 

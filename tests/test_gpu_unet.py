@@ -127,6 +127,45 @@ def test_unet3d_mfma_sizes_match_oracle(norm):
     _check_against_fp64(model, pred, loss, case)
 
 
+def test_unet3d_benchmark_widths_depth4_match_fp64_oracle():
+    """The benchmark network itself -- UNet3d(1, 2, initial_features=32, depth=4): 32 ... 512 features, every kernel family
+    of cfg 2 incl. the split-K convolutions of the 8^3 / 4^3 levels -- on one 64^3 volume against the float64 oracle."""
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    torch.manual_seed(0)
+    model = UNet3d(1, 2, depth=4, initial_features=32)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 1, 64, 64, 64, generator=g)
+    y = (torch.rand(1, 2, 64, 64, 64, generator=g) > 0.5).float()
+    case = (model, [2, 2, 2, 2], x, y, "InstanceNorm")
+    model.to(DEV)
+    pred = model(x.to(DEV))
+    loss = DiceLoss()(pred, y.to(DEV))
+    loss.backward()
+    _check_against_fp64(model, pred, loss, case)
+
+
+def test_anisotropic_cfg3_factors_match_fp64_oracle():
+    """AnisotropicUNet with the scale factors of cfg 3 ([[1,2,2],[1,2,2],[2,2,2],[2,2,2]], 12 affinity channels, Sigmoid)
+    at initial_features=32 on 1x1x16x64x64: the 1x3x3 (2-D) MFMA kernels, anisotropic pooling / upsampling."""
+    from oracle import loss_ref
+    from torch_em_amd.loss import ApplyAndRemoveMask, DiceLoss, LossWrapper
+    from torch_em_amd.model import AnisotropicUNet
+    torch.manual_seed(0)
+    sf = [[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]]
+    model = AnisotropicUNet(1, 12, sf, initial_features=32, final_activation="Sigmoid", anisotropic_kernel=True)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 1, 16, 64, 64, generator=g)
+    y = torch.cat([(torch.rand(1, 12, 16, 64, 64, generator=g) > 0.5).float(),
+                   (torch.rand(1, 12, 16, 64, 64, generator=g) > 0.3).float()], dim=1)
+    case = (model, sf, x, y, "InstanceNorm", "Sigmoid", loss_ref.masked_dice_loss)
+    model.to(DEV)
+    pred = model(x.to(DEV))
+    loss = LossWrapper(DiceLoss(), ApplyAndRemoveMask("multiply"))(pred, y.to(DEV))
+    loss.backward()
+    _check_against_fp64(model, pred, loss, case)
+
+
 def test_anisotropic_mfma_sizes_match_oracle():
     from oracle import loss_ref
     from torch_em_amd.loss import ApplyAndRemoveMask, DiceLoss, LossWrapper
@@ -179,8 +218,10 @@ def test_benchmark_config_full_size_properties():
         loss = DiceLoss()(model(x), y)
         loss.backward()
         vals.append(float(loss))
-        grads.append(model.out_conv.weight.grad.clone())
-    assert np.isfinite(vals[0]) and vals[0] == vals[1] and torch.equal(grads[0], grads[1])
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    assert np.isfinite(vals[0]) and vals[0] == vals[1]
+    for k in grads[0]:   # no atomics anywhere on the path: EVERY gradient is bitwise reproducible
+        assert torch.equal(grads[0][k], grads[1][k]), k
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     nthreads = torch.get_num_threads()
     torch.set_num_threads(16)  # the oracle's sweet spot on the 2x64-core host (scripts/cpu_threads_probe.py)
