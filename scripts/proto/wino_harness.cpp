@@ -6,7 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "../torch_em_amd/csrc/tem_common.h"
+#include "../../torch_em_amd/csrc/tem_common.h"
 int64_t tem_conv_wino_pack_bytes(int Cin, int Cout);
 void tem_pack_weights_wino(const float* w, void* dst, int Cw_out, int Cw_in, int transpose, int f16, hipStream_t s);
 bool tem_conv_fwd_wino(const float* x, int64_t x_ld, const float* scale, const float* shift, const void* wp,
