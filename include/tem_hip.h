@@ -55,6 +55,7 @@ int tem_device_cus(void);
  *   "wgrad_sums"          1 | 0   norm-backward sums taken from the weight gradient
  *   "wgrad_sums_min_mb"   256     ... for layers whose replaced pass reads at least this many MiB
  *   "fwd_persistent"     -1 | 0 | 1   exact-fp32 forward: persistent variant (-1: 64-column tiles only)
+ *   "conv1x1_stream"      1 | 0   1x1x1 convolutions / data gradients as a streaming GEMM instead of the patch kernel
  * Unknown names return TEM_EINVAL. */
 int tem_set_option(const char* name, int64_t value);
 int tem_get_option(const char* name, int64_t* value);

@@ -524,6 +524,9 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
     if (tem_conv_fwd_pp(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, kd, kh, kw, act, nsplit,
                         stat, s))
         return TEM_OK;
+    if (kd == 1 && kh == 1 && kw == 1 && tem_option(TEM_OPT_CONV1X1_STREAM) &&
+        tem_conv1x1_stream(x, x_ld, scale, wp, bias, y, y_ld, ref, ref_ld, (int64_t)N * D * H * W, Cin, Cout, act, nsplit, stat, s))
+        return TEM_OK;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     const bool flat = (D == 1 && kd == 1);
     const int TZ = flat ? 1 : 4, TY = flat ? 16 : 8, TX = flat ? 16 : 8;

@@ -55,6 +55,10 @@ bool tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const flo
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
                      int W, int Cin, int Cout, int kd, int kh, int kw, int act, int nsplit, float* stat, hipStream_t s);
 int64_t tem_conv_pp_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
+// conv1x1_stream.hip: 1x1x1 convolution / data gradient as a streaming GEMM (false: not taken)
+bool tem_conv1x1_stream(const float* x, int64_t x_ld, const float* scale, const float* wp, const float* bias, float* y,
+                        int64_t y_ld, const float* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act, int nsplit,
+                        const float* stat, hipStream_t s);
 // shared with conv_mfma.hip
 int tem_fwd_ksplit(int64_t nblk, int nchunks);
 void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, const float* bias, int act,
