@@ -63,6 +63,8 @@ CONV_CASES = [
     (2, 8, 8, 8, 512, 512, (3, 3, 3)),     # the 8^3 base level: split-K forward, the single-wave-of-workgroups wgrad plan
     (2, 20, 24, 40, 64, 32, (3, 3, 3)),    # ping-pong kernel, Cin = 64 -> one Cout tile (decoder level 0), ragged patches
     (2, 12, 24, 24, 128, 64, (3, 3, 3)),   # ping-pong kernel, Cin = 128 -> two Cout tiles (decoder level 1)
+    (1, 16, 32, 32, 64, 32, (1, 1, 1)),    # streaming 1x1x1 GEMM (>= 16384 voxels), one Cout tile
+    (1, 17, 33, 31, 32, 96, (1, 1, 1)),    # streaming 1x1x1 GEMM, ragged voxel count, three Cout tiles
 ]
 
 

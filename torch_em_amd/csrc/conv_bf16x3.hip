@@ -905,6 +905,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
 //   * ONE barrier per plane; a column accumulates over up to D planes, so far fewer partial slabs are written.
 // Ring slot of plane z is (z + 4) & 3; planes -1 and D are stored as zeros (padding applies after the pre-norm).
 // ---------------------------------------------------------------------------
+#ifndef TEM_ZS_BALANCE
+#define TEM_ZS_BALANCE 1   // z-sliding wgrad: units 16, 17 cut in halves over waves 0..3 (4.5 units per SIMD instead of 5/5/4/4)
+#endif
 #define ZS_NPL 4
 #define ZS_PLB 320                       // bytes per ci per plane: 10 halo rows x 32 B (16 bf16 slots, 10 used)
 #define ZS_CIS (ZS_NPL * ZS_PLB + 16)    // bytes per ci (padded like the patch kernel: conflict-free b128 reads)
@@ -954,6 +957,17 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
         uok[i] = u < 18;
         urg[i] = (uok[i] ? u : 0) % NRG;
         uv[i] = (uok[i] ? u : 0) / NRG;
+    }
+    // 18 units over 8 waves would put 5 / 5 / 4 / 4 on the four SIMDs (waves w and w+4 share one).  The two units left
+    // after two rounds (16, 17) are therefore cut in halves along their k-slabs: waves 0 and 2 each take half the slabs of
+    // unit 16, waves 1 and 3 of unit 17 -- 4.5 units per SIMD -- and the partial accumulators of waves 2, 3 are added to
+    // those of waves 0, 1 through LDS once, before the slabs are written.
+    const int sh2 = TEM_ZS_BALANCE ? (wv >> 1) & 1 : 0;   // which half of the third unit's slabs
+    if (TEM_ZS_BALANCE) {
+        const int u = 16 + (wv & 1);
+        uok[MAXU - 1] = wv < 4;
+        urg[MAXU - 1] = u % NRG;
+        uv[MAXU - 1] = u / NRG;
     }
 
     // staging items of this thread
@@ -1008,6 +1022,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                 const int xbase = r * ZS_CIS + (tz == 0 ? slot[0] : (tz == 1 ? slot[1] : slot[2])) + ty * 32;
 #pragma unroll
                 for (int sl = 0; sl < SPU; ++sl) {
+                    if (TEM_ZS_BALANCE && i == MAXU - 1 && (sl / (SPU / 2)) != sh2) continue;   // the other wave's slabs
                     const int prow = 2 * (sl0 + sl) + kh;  // this lane half's patch row (0..7)
                     const int goff = (ct * 32 + r) * ZS_GS + prow * 16;
                     const int xoff = xbase + prow * 32;
@@ -1138,6 +1153,26 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             float a = 0.f;
             for (int rr = 0; rr < 32; ++rr) a += red[rr * GC + tid];
             dbpart[(int64_t)sp * Cout + cog * GC + tid] = a;
+        }
+    }
+    // ---- the halves of units 16 / 17: waves 2, 3 hand their partial sums to waves 0, 1 ----
+    if (TEM_ZS_BALANCE) {
+        __syncthreads();
+        float* xch = reinterpret_cast<float*>(ldsb);   // [2][KW][16][64]
+        if (wv == 2 || wv == 3) {
+#pragma unroll
+            for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) xch[(((wv - 2) * KW + tx) * 16 + reg) * 64 + lane] = acc[MAXU - 1][tx][reg];
+        }
+        __syncthreads();
+        if (wv < 2) {
+#pragma unroll
+            for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) acc[MAXU - 1][tx][reg] += xch[((wv * KW + tx) * 16 + reg) * 64 + lane];
+        } else {
+            uok[MAXU - 1] = false;
         }
     }
     // ---- partial slabs: D[row = ci][col = co] ----
