@@ -913,6 +913,18 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
 #define ZS_CIS (ZS_NPL * ZS_PLB + 16)    // bytes per ci (padded like the patch kernel: conflict-free b128 reads)
 #define ZS_GS 144                        // bytes per co row of one g plane: 64 bf16 + 16 pad
 
+typedef __amdgpu_buffer_rsrc_t zs_rsrc_t;
+typedef float zs_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int zs_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ zs_rsrc_t zs_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 zs_load4(zs_rsrc_t r, unsigned voff, unsigned soff) {
+    const zs_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const zs_f4 f = __builtin_bit_cast(zs_f4, v);   // whole-vector cast (element-wise bit casts get the load narrowed, conv_pp.hip)
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
 template <int NCO, bool H16 = false>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restrict__ x, int64_t x_ld,
                                                           const float* __restrict__ scale,
@@ -999,6 +1011,30 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
         sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + xcq * 4);
         sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + xcq * 4);
     }
+    // Everything about a thread's two x voxels and two g voxels except the plane is fixed for the whole column: in-range
+    // flags and BYTE offsets inside a z-plane are computed here once; a load in the plane loop is then
+    // "buffer_load_dwordx4 v, voff, s[rsrc], s_plane" (the 64-bit address products and the bounds tests per load made the
+    // four loads of a plane cost ~1600 cycles of issue, half an MFMA phase; needs H*W*ld*4 < 2^31, checked by the host side)
+    bool okxa = false, okxb = false, okga = false, okgb = false;
+    unsigned offx = 0, offg = 0;
+    {
+        const int gy = y0 + xrow - 1, gx = x0 + 2 * xpr - 1;
+        const bool rowok = xit && gy >= 0 && gy < H;
+        okxa = rowok && gx >= 0 && gx < W;
+        okxb = rowok && gx + 1 >= 0 && gx + 1 < W;
+        offx = (unsigned)(((gy < 0 ? 0 : gy) * W + (gx < 0 ? 0 : gx)) * (int)x_ld + cit * 32 + xcq * 4) * 4u;  // of voxel gx (or 0)
+        const int hy = y0 + gprow, hx = x0 + 2 * gpr;
+        const bool grow = git && hy < H && gcq * 4 < Cout - cog * GC;
+        okga = grow && hx < W;
+        okgb = grow && hx + 1 < W;
+        offg = (unsigned)(((hy < H ? hy : 0) * W + (hx < W ? hx : 0)) * (int)g_ld + cog * GC + gcq * 4) * 4u;
+    }
+    // first voxel of the pair out of range on the left (gx == -1): the second one sits at offset 0 of the row
+    const unsigned offxb = (x0 + 2 * xpr - 1 < 0) ? offx : offx + (unsigned)x_ld * 4u;
+    const unsigned offgb = offg + (unsigned)g_ld * 4u;
+    const float* const xn = x + (int64_t)n * D * H * W * x_ld;   // the resource of a load starts at its z-plane (scalar
+    const float* const gn = g + (int64_t)n * D * H * W * g_ld;   // 64-bit add per plane): offsets stay inside one plane
+    const int64_t xplane = (int64_t)H * W * x_ld, gplane = (int64_t)H * W * g_ld;
     xa = make_float4(0.f, 0.f, 0.f, 0.f);
     xb = xa;
     ga = xa;
@@ -1108,33 +1144,23 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
         // ---- loads for the next pending set: x plane t+3 (planes za-1 .. zb), g plane t+2 (za .. zb-1) ----
         {
             const int zx = t + 3;
+            const bool zxok = zx >= za - 1 && zx <= zb && zx >= 0 && zx < D;   // wave-uniform
+            inA = zxok && okxa;
+            inB = zxok && okxb;
             xa = make_float4(0.f, 0.f, 0.f, 0.f);
             xb = xa;
-            inA = inB = false;
-            if (xit && zx >= za - 1 && zx <= zb && zx >= 0 && zx < D) {
-                const int gy = y0 + xrow - 1, gx = x0 + 2 * xpr - 1;
-                if (gy >= 0 && gy < H) {
-                    const float* rowp = x + (((int64_t)n * D + zx) * H + gy) * W * x_ld + cit * 32 + xcq * 4;
-                    if (gx >= 0 && gx < W) {
-                        xa = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * x_ld);
-                        inA = true;
-                    }
-                    if (gx + 1 >= 0 && gx + 1 < W) {
-                        xb = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * x_ld);
-                        inB = true;
-                    }
-                }
+            if (zxok) {
+                const zs_rsrc_t rsx = zs_rsrc(xn + zx * xplane);
+                if (okxa) xa = zs_load4(rsx, offx, 0);
+                if (okxb) xb = zs_load4(rsx, offxb, 0);
             }
             const int zg = t + 2;
             ga = make_float4(0.f, 0.f, 0.f, 0.f);
             gb = ga;
-            if (git && zg >= za && zg < zb) {
-                const int gy = y0 + gprow, gx = x0 + 2 * gpr;
-                if (gy < H && gcq * 4 < Cout - cog * GC) {
-                    const float* rowp = g + (((int64_t)n * D + zg) * H + gy) * W * g_ld + cog * GC + gcq * 4;
-                    if (gx < W) ga = ZS_GLOAD(rowp + (int64_t)gx * g_ld);
-                    if (gx + 1 < W) gb = ZS_GLOAD(rowp + (int64_t)(gx + 1) * g_ld);
-                }
+            if (zg >= za && zg < zb) {
+                const zs_rsrc_t rsg = zs_rsrc(gn + zg * gplane);
+                if (okga) ga = zs_load4(rsg, offg, 0);
+                if (okgb) gb = zs_load4(rsg, offgb, 0);
             }
         }
         __syncthreads();
@@ -1327,6 +1353,8 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
     }
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
     if (z.use) {
+        TEM_REQUIRE((int64_t)H * W * (x_ld > g_ld ? x_ld : g_ld) * 4 < (1ll << 31),
+                    "tem_conv3d_wgrad(bf16x3): one z-plane of x / g must stay below 2 GiB (32-bit offsets inside a plane)");
         float* zpart = (float*)ws;
         float* zdb = db ? zpart + tem_align_up((int64_t)z.S * z.ks2 * 27 * Cin * Cout, 64) : nullptr;
         TEM_REQUIRE(!norm_sums || (db && w_sd && sd_layout && tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw)),
