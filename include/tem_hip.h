@@ -99,6 +99,10 @@ int tem_conv_pack_weights(const float* w, float* dst, int Cout, int Cin, int kd,
  * (56 bytes each, `begin` = running offset in units of 8 weights, ascending); total = sum of Cout*Cin*taps/8.  Same result as n calls
  * of tem_conv_pack_weights. */
 int tem_conv_pack_weights_batch(const void* descs_dev, int n, int64_t total, tem_stream_t stream);
+/* Same records and result, coalesced reads: one workgroup per [32 out][32 in][taps] tile of a tensor staged in LDS
+ * (taps <= 27, Cout and Cin multiples of 16).  `begin` of a record = its first TILE (tiles per tensor:
+ * ceil(Cout / 32) * ceil(Cin / 32)); total_tiles = their sum = the grid. */
+int tem_conv_pack_weights_tiles(const void* descs_dev, int n, int64_t total_tiles, tem_stream_t stream);
 /* inverse of the GENERIC pack for weight gradients: [tap][ci][co] -> [Cout][Cin][kd][kh][kw] */
 int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Cin, int kd, int kh, int kw,
                           tem_stream_t stream);

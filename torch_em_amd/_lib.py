@@ -30,6 +30,7 @@ SIGNATURES = {
     "tem_conv_packed_size": (c_i64, [c_int] * 5),
     "tem_conv_pack_weights": (c_int, [c_vp, c_vp] + [c_int] * 7 + [c_vp]),
     "tem_conv_pack_weights_batch": (c_int, [c_vp, c_int, c_i64, c_vp]),
+    "tem_conv_pack_weights_tiles": (c_int, [c_vp, c_int, c_i64, c_vp]),
     "tem_conv_unpack_wgrad": (c_int, [c_vp, c_vp] + [c_int] * 5 + [c_vp]),
     "tem_conv3d_fwd_ws": (c_i64, [c_int] * 10),
     "tem_conv3d_fwd": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64]

@@ -179,6 +179,95 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const PackDesc* __re
         }
     }
 }
+// The same re-pack with COALESCED reads: a workgroup stages one [32 out][32 in][taps] tile of a weight tensor (rows of
+// 32 * taps consecutive floats, 16-byte loads) in LDS and emits the fragments of that tile from there.  The gather kernel
+// above reads 8 floats `taps` apart per work item: 454 MB fetched per launch for 85 MB of weights (cfg 2), 0.21 ms.
+// `tbegin` of a record = its first tile in the grid (tiles per tensor: ceil(Cout / 32) * ceil(Cin / 32)).
+struct PackTileDesc {
+    const float* w;
+    unsigned short* dst;
+    int Cout, Cin, KD, KH, KW, transpose, NS, fp16;
+    long long tbegin;
+};
+#define PT_MAXF 28672   // LDS floats of a tile: 32 rows x (32 x 27 + 4) = 27776
+__global__ __launch_bounds__(1024) void k_pack_weights_tiles(const PackTileDesc* __restrict__ descs, int n) {
+    __shared__ float tile[PT_MAXF];
+    __shared__ int sh_desc;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {  // last descriptor with tbegin <= blockIdx.x
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].tbegin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        sh_desc = lo;
+    }
+    __syncthreads();
+    const PackTileDesc d = descs[sh_desc];
+    const int ntaps = d.KD * d.KH * d.KW;
+    const int nci = (d.Cin + 31) >> 5;
+    const int t = (int)((long long)blockIdx.x - d.tbegin);
+    const int cob = t / nci, cib = t % nci;                  // 32-blocks of the weight's own (out, in) channels
+    const int R = min(32, d.Cout - cob * 32), C = min(32, d.Cin - cib * 32);   // 16 or 32
+    const int rowf = C * ntaps, pitch = rowf + 4;
+    // ---- load: R rows of C * taps consecutive floats (row start and length are multiples of 4 floats) ----
+    for (int i = threadIdx.x; i < R * (rowf >> 2); i += 1024) {
+        const int rr = i / (rowf >> 2), q = i % (rowf >> 2);
+        const float4 v = *reinterpret_cast<const float4*>(d.w + ((long long)(cob * 32 + rr) * d.Cin + cib * 32) * ntaps + q * 4);
+        *reinterpret_cast<float4*>(tile + rr * pitch + q * 4) = v;
+    }
+    __syncthreads();
+    // ---- emit: fragments (32 out-channels of the EXECUTED conv x 16 of its in-channels) of every tap ----
+    // forward: out = co (R must be 32), in = ci (C / 16 fragments per tap); data gradient: out = ci (C must be 32), in = co
+    const int nfr = d.transpose ? (R >> 4) : (C >> 4);
+    const int CinL = d.transpose ? d.Cout : d.Cin;
+    const int c16n = CinL >> 4;
+    const int ntL = d.transpose ? cib : cob;
+    for (int it = threadIdx.x; it < ntaps * nfr * 64; it += 1024) {
+        const int lane = it & 63, fr = (it >> 6) % nfr, tap = (it >> 6) / nfr;
+        const int kh = lane >> 5, col = lane & 31;
+        const int tz = tap / (d.KH * d.KW), ty = (tap / d.KW) % d.KH, tx = tap % d.KW;
+        const int ftap = ((d.KD - 1 - tz) * d.KH + (d.KH - 1 - ty)) * d.KW + (d.KW - 1 - tx);
+        float rem[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = fr * 16 + kh * 8 + j;   // in-channel of the executed conv inside the tile
+            rem[j] = d.transpose ? tile[k * pitch + col * ntaps + ftap] : tile[col * pitch + k * ntaps + tap];
+            if (d.fp16 == 3) rem[j] = __builtin_amdgcn_fmed3f(rem[j] * F16_W_PRESCALE, -64000.f, 64000.f);
+        }
+        const int c16 = (d.transpose ? cob * 2 : cib * 2) + fr;
+        uint4* out = reinterpret_cast<uint4*>(d.dst) + ((((long long)ntL * ntaps + tap) * c16n + c16) * d.NS) * 64 + lane;
+        for (int p = 0; p < d.NS; ++p) {
+            unsigned pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (d.fp16) {
+                    const _Float16 a = (_Float16)rem[2 * q], b = (_Float16)rem[2 * q + 1];
+                    pk[q] = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+                    rem[2 * q] -= (float)a;
+                    rem[2 * q + 1] -= (float)b;
+                    if (d.fp16 == 2) {
+                        rem[2 * q] *= F16_LO_SCALE;
+                        rem[2 * q + 1] *= F16_LO_SCALE;
+                    }
+                } else {
+                    const unsigned short a = bf16_bits(rem[2 * q]), b = bf16_bits(rem[2 * q + 1]);
+                    pk[q] = (unsigned)a | ((unsigned)b << 16);
+                    rem[2 * q] -= __builtin_bit_cast(float, (unsigned)a << 16);
+                    rem[2 * q + 1] -= __builtin_bit_cast(float, (unsigned)b << 16);
+                }
+            }
+            out[(long long)p * 64] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
+}
+extern "C" int tem_conv_pack_weights_tiles(const void* descs_dev, int n, int64_t total_tiles, tem_stream_t stream) {
+    TEM_REQUIRE(descs_dev && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "tem_conv_pack_weights_tiles: bad arguments");
+    hipLaunchKernelGGL(k_pack_weights_tiles, dim3((unsigned)total_tiles), dim3(1024), 0, (hipStream_t)stream,
+                       (const PackTileDesc*)descs_dev, n);
+    TEM_CHECK_LAUNCH("tem_conv_pack_weights_tiles");
+    return TEM_OK;
+}
+
 extern "C" int tem_conv_pack_weights_batch(const void* descs_dev, int n, int64_t total, tem_stream_t stream) {
     TEM_REQUIRE(descs_dev && n > 0 && total > 0, "tem_conv_pack_weights_batch: bad arguments");
     hipLaunchKernelGGL(k_pack_weights_batch, dim3(tem_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream,

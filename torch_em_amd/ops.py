@@ -168,22 +168,37 @@ def pack_weights(w: torch.Tensor, transpose: bool, mfma) -> torch.Tensor:
 
 
 def pack_table(jobs):
-    """Device descriptor table for tem_conv_pack_weights_batch.  jobs: (w, dst, cout, cin, k3, transpose, nsplit, fp16)."""
+    """Device descriptor tables for tem_conv_pack_weights_tiles (all tensors whose kernel has <= 27 taps: one workgroup per
+    32 x 32 x taps tile) and tem_conv_pack_weights_batch (the rest).  jobs: (w, dst, cout, cin, k3, transpose, nsplit, fp16)."""
     import struct
-    blob, begin = b"", 0
+    tiled, gather = b"", b""
+    ntile = nitem = n_t = n_g = 0
     for w, dst, cout, cin, k, transpose, nsplit, fp16 in jobs:
-        blob += struct.pack("<qq8iq", w.data_ptr(), dst.data_ptr(), cout, cin, k[0], k[1], k[2], int(transpose), nsplit,
-                            fp16, begin)
-        begin += cout * cin * k[0] * k[1] * k[2] // 8
+        taps = k[0] * k[1] * k[2]
+        if taps <= 27 and cout % 16 == 0 and cin % 16 == 0:
+            tiled += struct.pack("<qq8iq", w.data_ptr(), dst.data_ptr(), cout, cin, k[0], k[1], k[2], int(transpose), nsplit,
+                                 fp16, ntile)
+            ntile += ((cout + 31) // 32) * ((cin + 31) // 32)
+            n_t += 1
+        else:
+            gather += struct.pack("<qq8iq", w.data_ptr(), dst.data_ptr(), cout, cin, k[0], k[1], k[2], int(transpose),
+                                  nsplit, fp16, nitem)
+            nitem += cout * cin * taps // 8
+            n_g += 1
     dev = jobs[0][0].device
-    table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-    return {"table": table, "n": len(jobs), "total": begin, "keep": [(j[0], j[1]) for j in jobs]}
+    mk = lambda blob: torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev) if blob else None  # noqa: E731
+    return {"tiles": mk(tiled), "n_tiles": n_t, "total_tiles": ntile, "table": mk(gather), "n": n_g, "total": nitem,
+            "keep": [(j[0], j[1]) for j in jobs]}
 
 
 def pack_weights_batch(tab):
     lib = _lib.load()
-    _lib.check(lib.tem_conv_pack_weights_batch(_p(tab["table"]), tab["n"], tab["total"], _stream(tab["table"])),
-               "tem_conv_pack_weights_batch")
+    if tab["n_tiles"]:
+        _lib.check(lib.tem_conv_pack_weights_tiles(_p(tab["tiles"]), tab["n_tiles"], tab["total_tiles"],
+                                                   _stream(tab["tiles"])), "tem_conv_pack_weights_tiles")
+    if tab["n"]:
+        _lib.check(lib.tem_conv_pack_weights_batch(_p(tab["table"]), tab["n"], tab["total"], _stream(tab["table"])),
+                   "tem_conv_pack_weights_batch")
 
 
 def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=None, ref=None, mfma=False,
