@@ -124,6 +124,7 @@ MIXED_CASES = [
     (1, 1, 20, 33, 16, 64, (1, 3, 3)),    # 2-D
     (2, 4, 8, 8, 64, 32, (1, 1, 1)),
     (2, 8, 8, 8, 128, 128, (3, 3, 3)),    # split-K
+    (1, 16, 32, 32, 64, 32, (1, 1, 1)),   # >= 16384 voxels: the data gradient runs the streaming 1x1x1 GEMM with one fp16 term
 ]
 
 
