@@ -139,6 +139,35 @@ def gen_trainer(torch_em, tmp):
           "epoch", ckpt["epoch"])
 
 
+def gen_trainer_amp(torch_em, tmp):
+    """G7b: the reference's MIXED-PRECISION loop -- torch.autocast(float16) + torch.GradScaler
+    (trainer/default_trainer.py:134-142, 789-803) -- and its fp32 loop on the same data at MFMA-eligible widths
+    (UNet2d(1, 2, depth=2, initial_features=32)), 8 iterations each on the CPU: loss per iteration, validation metric, the
+    scaler's final scale (autocast's fp16 gradients overflow in step 0 of this run: the step is skipped, 65536 -> 32768)."""
+    from torch_em.model import UNet2d
+    xt, yt = make_batches(11, 8)
+    xv, yv = make_batches(12, 4)
+    train = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xt, yt), batch_size=2, shuffle=False)
+    val = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xv, yv), batch_size=2, shuffle=False)
+    out = dict(xt=xt.numpy(), yt=yt.numpy(), xv=xv.numpy(), yv=yv.numpy(), learning_rate=np.float64(1e-3))
+    for tag, dt in (("fp32", None), ("amp", "float16")):
+        torch.manual_seed(0)
+        model = UNet2d(1, 2, depth=2, initial_features=32)
+        if tag == "fp32":
+            out.update({f"sd0.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()})
+        trainer = torch_em.default_segmentation_trainer(
+            name="g7b" + tag, model=model, train_loader=train, val_loader=val, learning_rate=1e-3, device="cpu",
+            mixed_precision=dt is not None, mixed_precision_dtype=dt, logger=Recorder, save_root=tmp, compile_model=False)
+        trainer.fit(iterations=8)
+        log = Recorder.log
+        out[f"{tag}_train_loss"] = np.array(log["train_loss"])
+        out[f"{tag}_val_metric"] = np.array(log["val_metric"])
+        if dt is not None:
+            out["amp_final_scale"] = np.float64(trainer.scaler.get_scale())
+        print("G7b", tag, [f"{v:.5f}" for v in log["train_loss"]], log["val_metric"])
+    np.savez_compressed(os.path.join(OUT, "g7b_trainer_amp_unet2d.npz"), **out)
+
+
 def gen_affinities():
     spec = importlib.util.spec_from_file_location("ref_test_label_transforms",
                                                   os.path.join(REF_ROOT, "test/transform/test_label_transforms.py"))
@@ -172,3 +201,5 @@ if __name__ == "__main__":
     te = import_reference()
     with tempfile.TemporaryDirectory() as tmp:
         gen_trainer(te, tmp)
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_trainer_amp(te, tmp)
