@@ -125,6 +125,8 @@ MIXED_CASES = [
     (2, 4, 8, 8, 64, 32, (1, 1, 1)),
     (2, 8, 8, 8, 128, 128, (3, 3, 3)),    # split-K
     (1, 16, 32, 32, 64, 32, (1, 1, 1)),   # >= 16384 voxels: the data gradient runs the streaming 1x1x1 GEMM with one fp16 term
+    (2, 16, 64, 64, 32, 32, (3, 3, 3)),   # 512 patches: the ping-pong kernel with one fp16 term, one Cout tile
+    (2, 16, 64, 64, 32, 64, (3, 3, 3)),   # ... two Cout tiles (forward) / one (data gradient)
 ]
 
 

@@ -365,9 +365,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_pp(
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) e[c] = ok ? e[c] : 0.f;
                             }
-                            if (F16) {
+                            if (F16 && NS == 2) {   // fp16x3: range clamp; the one-term mixed mode overflows to inf like autocast
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) e[c] = __builtin_amdgcn_fmed3f(e[c], -60000.f, 60000.f);
+                            }
+                            if (F16 && NS == 1) {
+                                // the mixed mode rounds the fp32 pre-norm result to fp16 (what autocast does to the fp32 output
+                                // of a norm layer): keep hipcc from fusing the two into one v_fma_mix*_f16, which rounds the
+                                // exact product-sum once and differs from the patch kernel by one fp16 ulp in 1 of 2^17 elements
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(e[c]));
                             }
 #pragma unroll
                             for (int p = 0; p < NS; ++p) {
@@ -525,7 +532,7 @@ static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     PpGeom g = {};
     const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
     if (opt == 0) return g;
-    if (!(nsplit == 2 || nsplit == 4)) return g;
+    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5)) return g;   // bf16x3, fp16x3 (scaled lo), one fp16 term (mixed mode)
     if (!(kh == 3 && kw == 3 && (kd == 3 || kd == 1))) return g;
     if (D < 4 || Cin % 16 || Cout % 32) return g;
     if ((int64_t)H * W * 8 * 4 * max_ld >= (1ll << 31)) return g;  // 32-bit byte offsets inside one halo / one patch
@@ -553,15 +560,15 @@ int64_t tem_conv_pp_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, i
     return (int64_t)g.nZ * g.nY * g.nX * g.WM;
 }
 
-template <int KD, int KH, int KW, int TZ, int CT, bool F16>
+template <int KD, int KH, int KW, int TZ, int CT, bool F16, int NS = 2>
 static void pp_launch(const PpGeom& g, const float* x, int64_t x_ld, const float* scale, const float* shift,
                       const float* wp, const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld,
                       int N, int D, int H, int W, int Cin, int Cout, int act, float* stat, hipStream_t s) {
     constexpr int WN = CT;  // 64-column teams: 2 x 2 waves; 32-column teams: 4 x 1
     constexpr int HV = (TZ + KD - 1) * 10 * 10;
-    constexpr size_t ldsb = ((size_t)2 * HV * (2 * 8 + 4) + 8 * 32 * 36) * sizeof(float);  // two halo tiles + 8 wave scratches
+    constexpr size_t ldsb = ((size_t)2 * HV * (NS * 8 + 4) + 8 * 32 * 36) * sizeof(float);  // two halo tiles + 8 wave scratches
     static_assert(ldsb <= 160 * 1024, "LDS budget");
-    auto kern = &k_conv_pp<KD, KH, KW, TZ, 8, 8, CT, WN, 2, F16>;
+    auto kern = &k_conv_pp<KD, KH, KW, TZ, 8, 8, CT, WN, NS, F16>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
@@ -594,7 +601,10 @@ bool tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const flo
     const bool f16 = nsplit == 4;
 #define PPGO(KD, CT)                                                                                                  \
     do {                                                                                                              \
-        if (f16)                                                                                                      \
+        if (nsplit == 5)                                                                                              \
+            pp_launch<KD, 3, 3, 4, CT, true, 1>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, \
+                                                Cout, act, stat, s);                                                  \
+        else if (f16)                                                                                                 \
             pp_launch<KD, 3, 3, 4, CT, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin,  \
                                              Cout, act, stat, s);                                                     \
         else                                                                                                          \
