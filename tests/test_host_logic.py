@@ -253,3 +253,23 @@ def test_mask_transforms_return_tensors_like_the_reference():
         x.grad = None
         LossWrapper(torch.nn.L1Loss(), ApplyMask(method))(x, y, mask=mask).backward()
         assert (x.grad[~mask] == 0).all()
+
+
+def test_bench_self_launches_one_rank_per_gpu():
+    """`python bench.py --gpus 2` without WORLD_SIZE re-executes itself under torch.distributed.run (reference
+    torch_em/multi_gpu_training.py:172-190 spawns its own workers): on this GPU-less box both ranks get as far as
+    cuda.set_device and fail THERE -- not at an argument assert."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    err = p.stderr + p.stdout
+    assert p.returncode != 0
+    assert "No HIP GPUs are available" in err or "set_device" in err, err[-2000:]
+    assert "WORLD_SIZE" not in err.split("Traceback")[0] or "assert" not in err
