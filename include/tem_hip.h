@@ -49,7 +49,8 @@ int tem_device_cus(void);
 /* Dispatch options: process-wide switches between kernel variants that compute the same result (used by
  * profiling scripts and A/B tests; the defaults are the measured-fastest choices).  No reference counterpart
  * (the reference selects nothing: it calls ATen).  Names:
- *   "conv_fwd_variant"   -1 auto | 0 one-patch-per-workgroup kernel | 1 ping-pong team kernel
+ *   "conv_fwd_variant"   -1 auto | 0 one-patch-per-workgroup kernel | 1 ping-pong team kernel (conv_pp.hip) for every shape
+ *                        it can take | 2 z-reuse team kernel (conv_zr.hip, 3x3x3) for every shape it can take
  *   "wgrad_zs"            1 | 0   z-sliding weight-gradient kernel (3x3x3, D >= 16)
  *   "wgrad_zs_persist"    1 | 0   persistent column segments of that kernel
  *   "wgrad_sums"          1 | 0   norm-backward sums taken from the weight gradient
@@ -149,9 +150,10 @@ int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float
  * stat_blocks = tem_conv3d_fwd_stat_blocks(...), which returns 0 for launches that cannot provide them (VALU / exact
  * fp32 kernels, split-K shapes): use tem_norm_stats there.  tem_norm_finalize_partials (below) merges them. */
 int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
-/* Which kernel family a tem_conv3d_fwd launch of this shape selects under the current options: 1 = the ping-pong team
- * kernel (csrc/conv_pp.hip: 3x3x3 / 1x3x3, two-plane layouts, enough patches to fill the chip), 0 = everything else.
- * Profiling aid (kernel tables of bench.py); alignment fall-backs of an individual launch are not reflected. */
+/* Which kernel family a tem_conv3d_fwd launch of this shape selects under the current options: 3 = the z-reuse team
+ * kernel (csrc/conv_zr.hip: 3x3x3, 4x16x8 patches), 1 or 2 = the ping-pong team kernel (csrc/conv_pp.hip: 3x3x3 / 1x3x3,
+ * two-plane layouts, enough patches to fill the chip) with that many 32-column output tiles per team, 0 = everything else.  Profiling / test aid (kernel tables of bench.py, the per-
+ * instantiation parity tests); alignment fall-backs of an individual launch are not reflected. */
 int tem_conv3d_fwd_kernel(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 int tem_conv3d_fwd_stats(const float* x, int64_t x_ld, const float* scale, const float* shift,
                          const float* w_packed, const float* bias, float* y, int64_t y_ld,

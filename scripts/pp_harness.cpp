@@ -7,10 +7,14 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <math.h>
 #include "../torch_em_amd/csrc/tem_common.h"
 #include "../torch_em_amd/csrc/conv_internal.h"
 #ifdef TEM_PP_TRACE
 void tem_pp_trace_read(unsigned long long* dst);
+#endif
+#ifdef TEM_ZR_TRACE
+void tem_zr_trace_read(unsigned long long* dst);
 #endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -56,7 +60,10 @@ int main(int argc, char** argv) {
     auto run = [&]() {
         float* st = use_norm && !use_ref ? stat : nullptr;
         // variants >= 1: straight into THIS executable's copy of conv_pp.hip (calls inside libtem_hip.so bind locally)
-        if (variant >= 1 && tem_conv_fwd_pp(x, Cin, use_norm ? sc : nullptr, use_norm ? sf : nullptr, wp, b, y, Cout, ref, Cout, N, D,
+        if (variant == 2 && tem_conv_fwd_zr(x, Cin, use_norm ? sc : nullptr, use_norm ? sf : nullptr, wp, b, y, Cout, ref, Cout, N, D,
+                                            H, W, Cin, Cout, 3, 3, 3, TEM_ACT_RELU, mode, st, s) > 0)
+            return;
+        if (variant == 1 && tem_conv_fwd_pp(x, Cin, use_norm ? sc : nullptr, use_norm ? sf : nullptr, wp, b, y, Cout, ref, Cout, N, D,
                                             H, W, Cin, Cout, 3, 3, 3, TEM_ACT_RELU, mode, st, s))
             return;
         int rc = tem_conv_fwd_bf16x3(x, Cin, use_norm ? sc : nullptr, use_norm ? sf : nullptr, wp, b, y, Cout, ref, Cout, ws, wsb, N,
@@ -65,6 +72,28 @@ int main(int argc, char** argv) {
     };
     for (int i = 0; i < 3; ++i) run();
     CK(hipDeviceSynchronize());
+    if (getenv("HARNESS_CHECK")) {   // the kernel under test against the library's one-patch-per-workgroup kernel
+        std::vector<float> ya(V * Cout), yb(V * Cout);
+        CK(hipMemcpy(ya.data(), y, ya.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(y, 0xff, V * Cout * 4));
+        tem_set_option("conv_fwd_variant", 0);
+        int rc = tem_conv_fwd_bf16x3(x, Cin, use_norm ? sc : nullptr, use_norm ? sf : nullptr, wp, b, y, Cout, ref, Cout, ws, wsb, N,
+                                     D, H, W, Cin, Cout, 3, 3, 3, TEM_ACT_RELU, mode, nullptr, s);
+        if (rc) { printf("reference launch failed: %s\n", tem_last_error()); exit(1); }
+        CK(hipDeviceSynchronize());
+        tem_set_option("conv_fwd_variant", variant);
+        CK(hipMemcpy(yb.data(), y, yb.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0; size_t bad = 0, nan = 0;
+        for (size_t i = 0; i < ya.size(); ++i) {
+            if (ya[i] != ya[i]) { ++nan; continue; }
+            const double d = fabs((double)ya[i] - yb[i]);
+            if (d > md) md = d;
+            if (fabs(yb[i]) > mx) mx = fabs(yb[i]);
+            if (d > 1e-3) ++bad;
+        }
+        printf("CHECK vs patch kernel: max abs diff %.3e (max |y| %.3e), %zu elements off by > 1e-3, %zu NaN\n", md, mx, bad, nan);
+        run();
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9f, tot = 0.f;
@@ -79,18 +108,30 @@ int main(int argc, char** argv) {
     const double fl = 2.0 * V * Cin * Cout * 27;
     printf("%dx%dx%dx%d %d->%d mode %d variant %d norm %d ref %d: min %.4f ms avg %.4f ms  %.0f TF alg  mfma_frac(2500) %.3f\n", N, D, H, W,
            Cin, Cout, mode, variant, use_norm, use_ref, best, tot / 3, fl / best / 1e9, fl * 3 / best / 1e9 / 2500);
-#ifdef TEM_PP_TRACE
-    std::vector<unsigned long long> tr(2 * 64 * 8);
+#if defined(TEM_PP_TRACE) || defined(TEM_ZR_TRACE)
+#ifdef TEM_ZR_TRACE
+    const int TS = 12;   // stamps per step
+#else
+    const int TS = 8;
+#endif
+    std::vector<unsigned long long> tr(2 * 64 * TS);
+#ifdef TEM_ZR_TRACE
+    tem_zr_trace_read(tr.data());
+#else
     tem_pp_trace_read(tr.data());
+#endif
     for (int team = 0; team < 2; ++team) {
         printf("team %d: step  loads_issue  epilogue  convert  prime  bar1   taps   bar2   (shader cycles; t0 relative to team 0 step 0)\n", team);
         const unsigned long long base = tr[0];
         for (int st = 0; st < 20; ++st) {
-            const unsigned long long* t = &tr[(team * 64 + st) * 8];
+            const unsigned long long* t = &tr[(team * 64 + st) * TS];
             if (!t[0]) break;
             printf("  %2d @%8llu: %6lld %6lld %6lld %6lld %6lld %6lld %6lld\n", st, t[0] - base, (long long)(t[1] - t[0]),
                    (long long)(t[6] - t[1]), (long long)(t[7] ? t[7] - t[6] : 0), (long long)(t[7] ? t[2] - t[7] : t[2] - t[6]),
                    (long long)(t[3] - t[2]), (long long)(t[4] - t[3]), (long long)(t[5] - t[4]));
+            if (TS > 8 && t[8] && t[11] > t[1])   // epilogue split: fold | planes (max, statistics, stores) | reduction | re-init
+                printf("        epilogue: head+fold %lld  planes %lld  stat-reduce %lld  re-init %lld\n", (long long)(t[8] - t[1]),
+                       (long long)(t[9] - t[8]), (long long)(t[10] - t[9]), (long long)(t[11] - t[10]));
         }
     }
 #endif

@@ -1,0 +1,189 @@
+// issue_bench.hip -- how fast does ONE wave issue VALU / LDS instructions on a gfx950 SIMD, alone and beside a wave of
+// the same SIMD that streams v_mfma_f32_32x32x16_f16?  (The question behind the ping-pong convolution kernels: their
+// staging team runs one wave per SIMD beside the multiplying team's wave.)
+// build: hipcc --offload-arch=gfx950 -O3 -o build/issue_bench scripts/proto/issue_bench.hip ; run: build/issue_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+#define REP4(x) x x x x
+#define REP16(x) REP4(REP4(x))
+#define REP64(x) REP4(REP16(x))
+
+// 512 instructions of one kind per measurement (8 independent chains unless noted)
+template <int KIND>
+__device__ __forceinline__ void body(float (&r)[16], unsigned (&u)[8], float c, unsigned char* lds, float* gbuf) {
+    if (KIND == 0) {   // independent v_fma_f32
+        REP64(asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                           "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8"
+                           : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(c));)
+    } else if (KIND == 1) {   // dependent chain
+        REP64(asm volatile("v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n"
+                           "v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1"
+                           : "+v"(r[0]) : "v"(c));)
+    } else if (KIND == 2) {   // v_pk_fma_f32 on 4 independent pairs (x2 per block)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 a = {r[0], r[1]}, b = {r[2], r[3]}, d = {r[4], r[5]}, e = {r[6], r[7]}, cc = {c, c};
+        REP64(asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n"
+                           "v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4"
+                           : "+v"(a), "+v"(b), "+v"(d), "+v"(e) : "v"(cc));)
+        r[0] = a.x + b.x + d.x + e.x;
+    } else if (KIND == 3) {   // v_cvt_pk_f16_f32
+        REP64(asm volatile("v_cvt_pk_f16_f32 %0, %8, %9\n v_cvt_pk_f16_f32 %1, %8, %9\n v_cvt_pk_f16_f32 %2, %8, %9\n v_cvt_pk_f16_f32 %3, %8, %9\n"
+                           "v_cvt_pk_f16_f32 %4, %8, %9\n v_cvt_pk_f16_f32 %5, %8, %9\n v_cvt_pk_f16_f32 %6, %8, %9\n v_cvt_pk_f16_f32 %7, %8, %9"
+                           : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]) : "v"(r[0]), "v"(r[1]));)
+    } else if (KIND == 4) {   // v_fma_mixlo_f16
+        REP64(asm volatile("v_fma_mixlo_f16 %0, %8, %9, %9 op_sel_hi:[1,0,0]\n v_fma_mixlo_f16 %1, %8, %9, %9 op_sel_hi:[1,0,0]\n"
+                           "v_fma_mixlo_f16 %2, %8, %9, %9 op_sel_hi:[1,0,0]\n v_fma_mixlo_f16 %3, %8, %9, %9 op_sel_hi:[1,0,0]\n"
+                           "v_fma_mixlo_f16 %4, %8, %9, %9 op_sel_hi:[1,0,0]\n v_fma_mixlo_f16 %5, %8, %9, %9 op_sel_hi:[1,0,0]\n"
+                           "v_fma_mixlo_f16 %6, %8, %9, %9 op_sel_hi:[1,0,0]\n v_fma_mixlo_f16 %7, %8, %9, %9 op_sel_hi:[1,0,0]"
+                           : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]) : "v"(u[0]), "v"(r[1]));)
+    } else if (KIND == 5) {   // v_cvt_f16_f32 (VOP1, 4 bytes)
+        REP64(asm volatile("v_cvt_f16_f32 %0, %8\n v_cvt_f16_f32 %1, %8\n v_cvt_f16_f32 %2, %8\n v_cvt_f16_f32 %3, %8\n"
+                           "v_cvt_f16_f32 %4, %8\n v_cvt_f16_f32 %5, %8\n v_cvt_f16_f32 %6, %8\n v_cvt_f16_f32 %7, %8"
+                           : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]) : "v"(r[0]));)
+    } else if (KIND == 6) {   // ds_write_b64
+        unsigned a = (unsigned)(size_t)lds;
+        REP64(asm volatile("ds_write_b64 %0, %1\n ds_write_b64 %0, %1 offset:512\n ds_write_b64 %0, %1 offset:1024\n ds_write_b64 %0, %1 offset:1536\n"
+                           "ds_write_b64 %0, %1 offset:2048\n ds_write_b64 %0, %1 offset:2560\n ds_write_b64 %0, %1 offset:3072\n ds_write_b64 %0, %1 offset:3584"
+                           :: "v"(a), "v"(*(double*)&r[0]) : "memory");)
+        asm volatile("s_waitcnt lgkmcnt(0)");
+    } else if (KIND == 7) {   // v_max_f32 (VOP2, 4 bytes)
+        REP64(asm volatile("v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
+                           "v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8"
+                           : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(c));)
+    } else if (KIND == 9) {   // ds_swizzle_b32 (xor 16), independent
+        REP64(asm volatile("ds_swizzle_b32 %0, %0 offset:0x401f\n ds_swizzle_b32 %1, %1 offset:0x401f\n ds_swizzle_b32 %2, %2 offset:0x401f\n ds_swizzle_b32 %3, %3 offset:0x401f\n"
+                           "ds_swizzle_b32 %4, %4 offset:0x401f\n ds_swizzle_b32 %5, %5 offset:0x401f\n ds_swizzle_b32 %6, %6 offset:0x401f\n ds_swizzle_b32 %7, %7 offset:0x401f\n s_waitcnt lgkmcnt(0)"
+                           : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));)
+    } else if (KIND == 10) {   // v_cndmask_b32 with an SGPR-pair mask (VOP3)
+        unsigned long long mk = 0x5555aaaa5555aaaaull;
+        asm volatile("" : "+s"(mk));
+        REP64(asm volatile("v_cndmask_b32 %0, %0, %8, %9\n v_cndmask_b32 %1, %1, %8, %9\n v_cndmask_b32 %2, %2, %8, %9\n v_cndmask_b32 %3, %3, %8, %9\n"
+                           "v_cndmask_b32 %4, %4, %8, %9\n v_cndmask_b32 %5, %5, %8, %9\n v_cndmask_b32 %6, %6, %8, %9\n v_cndmask_b32 %7, %7, %8, %9"
+                           : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(c), "s"(mk));)
+    } else if (KIND == 11) {   // v_mov_b32
+        REP64(asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n"
+                           "v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8"
+                           : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(c));)
+    } else if (KIND == 12) {   // ds_write_b128
+        unsigned a = (unsigned)(size_t)lds;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 d = {r[0], r[1], r[2], r[3]};
+        REP64(asm volatile("ds_write_b128 %0, %1\n ds_write_b128 %0, %1 offset:1024\n ds_write_b128 %0, %1 offset:2048\n ds_write_b128 %0, %1 offset:3072\n"
+                           "ds_write_b128 %0, %1 offset:4096\n ds_write_b128 %0, %1 offset:5120\n ds_write_b128 %0, %1 offset:6144\n ds_write_b128 %0, %1 offset:7168"
+                           :: "v"(a * 2), "v"(d) : "memory");)
+        asm volatile("s_waitcnt lgkmcnt(0)");
+    } else if (KIND == 13) {   // ds_read_b128
+        unsigned a = (unsigned)(size_t)lds;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 d0, d1, d2, d3;
+        REP64(asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:1024\n ds_read_b128 %2, %4 offset:2048\n ds_read_b128 %3, %4 offset:3072\n"
+                           "ds_read_b128 %0, %4 offset:4096\n ds_read_b128 %1, %4 offset:5120\n ds_read_b128 %2, %4 offset:6144\n ds_read_b128 %3, %4 offset:7168\n s_waitcnt lgkmcnt(0)"
+                           : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3) : "v"(a * 2) : "memory");)
+        r[0] = d0.x + d1.x + d2.x + d3.x;
+    } else if (KIND == 14) {   // global_store_dwordx4, 16 B per lane; STRIDE bytes between lanes (16 = contiguous, 128 = one line per lane)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 d = {r[0], r[1], r[2], r[3]};
+        float* gp = gbuf + (size_t)(threadIdx.x >> 6) * 65536 + (threadIdx.x & 63) * 4;
+        REP64(asm volatile("global_store_dwordx4 %0, %1, off\n global_store_dwordx4 %0, %1, off offset:1024\n global_store_dwordx4 %0, %1, off offset:2048\n global_store_dwordx4 %0, %1, off offset:3072\n"
+                           :: "v"(gp), "v"(d) : "memory");
+              asm volatile("global_store_dwordx4 %0, %1, off\n global_store_dwordx4 %0, %1, off offset:1024\n global_store_dwordx4 %0, %1, off offset:2048\n global_store_dwordx4 %0, %1, off offset:3072\n"
+                           :: "v"(gp + 1024), "v"(d) : "memory");)
+        asm volatile("s_waitcnt vmcnt(0)");
+    } else if (KIND == 15) {   // the same stores, 128 B between lanes (a lane's 16 B in its own line: the epilogue's pattern, 32-channel rows)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 d = {r[0], r[1], r[2], r[3]};
+        float* gp = gbuf + (size_t)(threadIdx.x >> 6) * 65536 + (threadIdx.x & 63) * 32;
+        REP64(asm volatile("global_store_dwordx4 %0, %1, off\n global_store_dwordx4 %0, %1, off offset:16\n global_store_dwordx4 %0, %1, off offset:32\n global_store_dwordx4 %0, %1, off offset:48\n"
+                           :: "v"(gp), "v"(d) : "memory");
+              asm volatile("global_store_dwordx4 %0, %1, off offset:64\n global_store_dwordx4 %0, %1, off offset:80\n global_store_dwordx4 %0, %1, off offset:96\n global_store_dwordx4 %0, %1, off offset:112\n"
+                           :: "v"(gp), "v"(d) : "memory");)
+        asm volatile("s_waitcnt vmcnt(0)");
+    } else if (KIND == 8) {   // v_pk_mul_f32
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 a = {r[0], r[1]}, b = {r[2], r[3]}, d = {r[4], r[5]}, e = {r[6], r[7]}, cc = {c, c};
+        REP64(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                           "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4"
+                           : "+v"(a), "+v"(b), "+v"(d), "+v"(e) : "v"(cc));)
+        r[0] = a.x + b.x + d.x + e.x;
+    }
+}
+
+// PARTNER: 0 idle at the barrier, 1 MFMA stream (4 independent accumulators), 2 MFMA stream with s_setprio 1,
+// 3 MFMA stream with s_setprio 1 on the MEASURED wave instead
+template <int KIND, int PARTNER>
+__global__ __launch_bounds__(512, 2) void k(unsigned long long* out, float c, float* gbuf) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[16384];
+    const int wv = threadIdx.x >> 6, team = wv >> 2;
+    float r[16];
+    unsigned u[8];
+    for (int i = 0; i < 16; ++i) r[i] = c + i + threadIdx.x;
+    for (int i = 0; i < 8; ++i) u[i] = threadIdx.x + i;
+    __syncthreads();
+    if (team == 0) {
+        if (PARTNER == 3) __builtin_amdgcn_s_setprio(1);
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        body<KIND>(r, u, c, lds + (threadIdx.x & 63) * 8, gbuf);
+        asm volatile("s_nop 0" ::: "memory");
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) out[0] = t1 - t0;
+    } else if (PARTNER) {
+        if (PARTNER == 2) __builtin_amdgcn_s_setprio(1);
+        floatx16 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+        half8_t x, y;
+        for (int i = 0; i < 8; ++i) { x[i] = (_Float16)(c + i); y[i] = (_Float16)(c - i); }
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+        for (int it = 0; it < 256; ++it) {   // 1024 MFMAs = 32768 cycles of matrix-pipe time
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a3, 0, 0, 0);
+        }
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        r[0] = a0[0] + a1[1] + a2[2] + a3[3];
+        if (threadIdx.x == 256) out[1] = t1 - t0;
+    }
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += r[i];
+    for (int i = 0; i < 8; ++i) s += (float)u[i];
+    if (s == 1.2345f) out[2] = 1;
+}
+
+static void* g_buf;
+template <int KIND, int PARTNER>
+void run(const char* name, unsigned long long* d) {
+    hipMemset(d, 0, 32);
+    hipLaunchKernelGGL((k<KIND, PARTNER>), dim3(1), dim3(512), 0, 0, d, 1.0001f, (float*)g_buf);
+    hipLaunchKernelGGL((k<KIND, PARTNER>), dim3(1), dim3(512), 0, 0, d, 1.0001f, (float*)g_buf);
+    unsigned long long h[4];
+    hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);
+    printf("%-18s partner %d: %6.2f memtime ticks / instr (512 instrs: %llu ticks); partner MFMA loop %llu ticks / 1024\n", name, PARTNER,
+           h[0] / 512.0, h[0], h[1]);
+}
+#define ALLP(K, NAME) run<K, 0>(NAME, d); run<K, 1>(NAME, d); run<K, 2>(NAME, d); run<K, 3>(NAME, d);
+int main() {
+    unsigned long long* d;
+    hipMalloc(&d, 64);
+    hipMalloc(&g_buf, 8 << 20);
+    printf("s_memtime ticks at 100 MHz on gfx9 (constant clock): multiply by shader_clock/100MHz for cycles\n");
+    ALLP(0, "v_fma_f32 indep")
+    ALLP(1, "v_fma_f32 chain")
+    ALLP(2, "v_pk_fma_f32")
+    ALLP(8, "v_pk_mul_f32")
+    ALLP(3, "v_cvt_pk_f16_f32")
+    ALLP(4, "v_fma_mixlo_f16")
+    ALLP(5, "v_cvt_f16_f32")
+    ALLP(7, "v_max_f32")
+    ALLP(6, "ds_write_b64")
+    ALLP(12, "ds_write_b128")
+    ALLP(13, "ds_read_b128")
+    ALLP(14, "store x4 contiguous")
+    ALLP(15, "store x4 128B/lane")
+    ALLP(9, "ds_swizzle_b32")
+    ALLP(10, "v_cndmask_b32 sgpr")
+    ALLP(11, "v_mov_b32")
+    return 0;
+}

@@ -61,8 +61,9 @@ CONV_CASES = [
     (1, 16, 132, 136, 32, 32, (3, 3, 3)),  # z-sliding, 289 columns > 256 CUs: workgroups walk two columns each
     (1, 16, 16, 16, 256, 512, (3, 3, 3)),  # benchmark widths of the deepest levels: split-K forward / dgrad, 16^3 wgrad
     (2, 8, 8, 8, 512, 512, (3, 3, 3)),     # the 8^3 base level: split-K forward, the single-wave-of-workgroups wgrad plan
-    (2, 20, 24, 40, 64, 32, (3, 3, 3)),    # ping-pong kernel, Cin = 64 -> one Cout tile (decoder level 0), ragged patches
-    (2, 12, 24, 24, 128, 64, (3, 3, 3)),   # ping-pong kernel, Cin = 128 -> two Cout tiles (decoder level 1)
+    (2, 20, 24, 40, 64, 32, (3, 3, 3)),    # patch kernel (150 units < 512), Cin = 64 -> one Cout tile (decoder level 0), ragged
+    (2, 12, 24, 24, 128, 64, (3, 3, 3)),   # patch kernel (54 units), Cin = 128 -> two Cout tiles (decoder level 1)
+    # (the ping-pong kernel family has its own test below: test_conv_pingpong_family_parity)
     (1, 16, 32, 32, 64, 32, (1, 1, 1)),    # streaming 1x1x1 GEMM (>= 16384 voxels), one Cout tile
     (1, 17, 33, 31, 32, 96, (1, 1, 1)),    # streaming 1x1x1 GEMM, ragged voxel count, three Cout tiles
 ]
@@ -173,6 +174,79 @@ def test_conv_mixed_precision_mode(case):
         dwe = torch.nn.grad.conv3d_weight(xe, w.shape, r16(gy) if zs else gy, padding=pad)
         assert rel_err(dw.cpu().view(w.shape), dwe) < (2e-5 if zs else 1e-4)
         assert rel_err(db.cpu(), gy.sum((0, 2, 3, 4))) < 5e-5   # bias gradient sums the fp32 values
+
+
+PP_CASES = [
+    # N, D, H, W, Cin, Cout, k, (forward CT, dgrad CT) in auto mode: every case has >= 512 units for both directions
+    ((2, 16, 64, 64, 32, 32, (3, 3, 3)), (1, 1)),    # level-0 encoder conv2 / decoder conv2 shape class
+    ((2, 16, 64, 64, 32, 64, (3, 3, 3)), (2, 1)),    # level-1 encoder conv1: two Cout tiles forward, one tile dgrad
+    ((2, 16, 64, 64, 128, 64, (3, 3, 3)), (2, 2)),   # decoder level 1: two tiles both ways, 8 chunks
+    ((2, 18, 61, 67, 32, 64, (3, 3, 3)), (2, 1)),    # ragged borders in z, y, x (720 units)
+    ((2, 17, 62, 66, 64, 32, (3, 3, 3)), (1, 2)),    # ragged, decoder level-0 conv1 shape class
+    ((2, 16, 64, 64, 32, 32, (1, 3, 3)), (1, 1)),    # anisotropic 1x3x3 kernel, one tile
+    ((2, 16, 64, 64, 64, 64, (1, 3, 3)), (2, 2)),    # anisotropic, two tiles
+]
+
+
+@pytest.fixture
+def conv_variant_option():
+    from torch_em_amd import _lib
+    old = _lib.get_option("conv_fwd_variant")
+    yield lambda v: _lib.set_option("conv_fwd_variant", v)
+    _lib.set_option("conv_fwd_variant", old)
+
+
+@pytest.mark.parametrize("case,cts", PP_CASES)
+@pytest.mark.parametrize("variant", [-1, 0, 1])
+def test_conv_pingpong_family_parity(case, cts, variant, conv_variant_option):
+    """Every instantiation of the ping-pong team kernel k_conv_pp<KD,3,3,..,CT in {1,2},NS,F16> (csrc/conv_pp.hip: the
+    forward / data-gradient convolutions of the 128^3 ... 32^3 levels, reference model/unet.py:417-438) against F.conv3d in
+    fp32, and the SAME shapes on the one-patch-per-workgroup kernel (variant 0): bf16x3 1e-4, fp16x3 2e-5, one-term fp16
+    2e-5 against the convolution of the fp16-rounded operands.  tem_conv3d_fwd_kernel() says which family a launch takes
+    (0 patch kernel, else the number of Cout tiles per team), so a silent fallback cannot pass as coverage."""
+    ops = _ops()
+    from torch_em_amd import _lib
+    lib = _lib.load()
+    conv_variant_option(variant)
+    N, D, H, W, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    scale, shift = torch.rand(N, Cin, generator=g) + 0.5, torch.randn(N, Cin, generator=g)
+    pad = tuple(v // 2 for v in k)
+    xn = (x.double() * scale[:, :, None, None, None].double() + shift[:, :, None, None, None].double()).float()
+    r16 = lambda t: t.half().float()
+    exp = F.relu(F.conv3d(xn, w, b, padding=pad))
+    exp16 = F.relu(F.conv3d(r16(xn), r16(w), b, padding=pad))
+    x5, wd = to5(x), w.to(DEV)
+    for mode in (2, 4, 5):
+        fam = lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, k[0], k[1], k[2], mode)
+        assert fam == (0 if variant == 0 else cts[0]), (mode, fam)
+        y5 = ops.new_act(N, D, H, W, Cout, DEV)
+        ops.conv_fwd(x5, ops.pack_weights(wd, transpose=False, mfma=mode), b.to(DEV), y5, k, Cin, Cout, scale=scale.to(DEV),
+                     shift=shift.to(DEV), act="relu", mfma=mode)
+        err = rel_err(from5(y5), exp16 if mode == 5 else exp)
+        assert err < (1e-4 if mode == 2 else 2e-5), f"fwd mode {mode}: {err}"
+    # data gradient = the same kernel on the transposed weights (Cout -> Cin channels), no norm, no activation; the
+    # fp16x3 data gradient (mode 4) reads a raw gradient: exercised at two magnitudes (the engine prescales by a power of two)
+    gy = torch.randn(exp.shape, generator=g)
+    gxe = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=pad)
+    gxe16 = torch.nn.grad.conv3d_input(x.shape, r16(w), r16(gy), padding=pad)
+    g5 = to5(gy)
+    for mode in (2, 4, 5):
+        fam = lib.tem_conv3d_fwd_kernel(N, D, H, W, Cout, Cin, k[0], k[1], k[2], mode)
+        assert fam == (0 if variant == 0 else cts[1]), (mode, fam)
+        gx5 = ops.new_act(N, D, H, W, Cin, DEV)
+        ops.conv_fwd(g5, ops.pack_weights(wd, transpose=True, mfma=mode), None, gx5, k, Cout, Cin, mfma=mode)
+        err = rel_err(from5(gx5), gxe16 if mode == 5 else gxe)
+        assert err < (1e-4 if mode == 2 else 2e-5), f"dgrad mode {mode}: {err}"
+        # masked data gradient (the ReLU mask of the producing layer applied in the epilogue: `ref`)
+        if mode != 5:
+            refm = torch.randn(N, Cin, D, H, W, generator=torch.Generator().manual_seed(3))
+            ops.conv_fwd(g5, ops.pack_weights(wd, transpose=True, mfma=mode), None, gx5, k, Cout, Cin, mfma=mode, ref=to5(refm))
+            err = rel_err(from5(gx5), gxe * (refm > 0))
+            assert err < (1e-4 if mode == 2 else 2e-5), f"masked dgrad mode {mode}: {err}"
 
 
 @pytest.mark.parametrize("case", [      # >= 384 workgroups each: smaller launches run split-K and cannot fuse

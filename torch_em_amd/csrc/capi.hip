@@ -28,7 +28,7 @@ static const TemOption g_opt_table[TEM_OPT_COUNT] = {
     {"wgrad_sums", 1},          // TEM_OPT_WGRAD_SUMS: norm-backward sums from the weight gradient
     {"wgrad_sums_min_mb", 256}, // TEM_OPT_WGRAD_SUMS_MIN_MB: ... for layers whose replaced pass reads at least this much
     {"fwd_persistent", -1},     // TEM_OPT_FWD_PERSISTENT: exact-fp32 forward, persistent variant (-1 = 64-column tiles only)
-    {"conv_fwd_variant", -1},   // TEM_OPT_CONV_FWD_VARIANT: split-precision forward/dgrad kernel (-1 auto, 0 patch kernel, 1 ping-pong)
+    {"conv_fwd_variant", -1},   // TEM_OPT_CONV_FWD_VARIANT: split-precision forward/dgrad kernel (-1 auto, 0 patch kernel, 1 ping-pong forced, 2 z-reuse forced)
     {"conv1x1_stream", 1},      // TEM_OPT_CONV1X1_STREAM: 1x1x1 convolutions / data gradients as a streaming GEMM (conv1x1_stream.hip)
 };
 static long long g_opt_val[TEM_OPT_COUNT];

@@ -333,9 +333,10 @@ extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Ci
 }
 
 extern "C" int tem_conv3d_fwd_kernel(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma) {
-    if (use_mfma >= 2 && use_mfma <= 6 && Cin % 16 == 0 && Cout % 32 == 0 &&
-        tem_conv_pp_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) >= 0)
-        return 1;
+    if (use_mfma >= 2 && use_mfma <= 6 && Cin % 16 == 0 && Cout % 32 == 0) {
+        if (tem_conv_zr_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) >= 0) return 3;
+        return tem_conv_pp_tiles(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma);
+    }
     return 0;
 }
 

@@ -610,9 +610,14 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
                 "tem_conv3d_fwd(split-bf16): x / packed weights must be 16-byte aligned with ld%%4==0");
     TEM_REQUIRE(!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)),
                 "tem_conv3d_fwd(split-bf16): scale/shift must be 16-byte aligned");
-    if (tem_conv_fwd_pp(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, kd, kh, kw, act, nsplit,
-                        stat, s))
-        return TEM_OK;
+    const int zr = tem_conv_fwd_zr(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, kd, kh, kw, act,
+                                   nsplit, stat, s);
+    if (zr < 0) return TEM_EINVAL;
+    if (zr) return TEM_OK;
+    const int pp = tem_conv_fwd_pp(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, kd, kh, kw, act,
+                                   nsplit, stat, s);
+    if (pp < 0) return TEM_EINVAL;
+    if (pp) return TEM_OK;
     if (kd == 1 && kh == 1 && kw == 1 && tem_option(TEM_OPT_CONV1X1_STREAM) &&
         tem_conv1x1_stream(x, x_ld, scale, wp, bias, y, y_ld, ref, ref_ld, (int64_t)N * D * H * W, Cin, Cout, act, nsplit, stat, s))
         return TEM_OK;
@@ -691,6 +696,8 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
 // produce them (split-K over the input channels, or no MFMA instantiation)
 int64_t tem_conv_fwd_bf16x3_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
     if (Cin % 16 || Cout % 32) return 0;
+    const int64_t zrb = tem_conv_zr_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit);
+    if (zrb >= 0) return zrb;
     const int64_t ppb = tem_conv_pp_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit);
     if (ppb >= 0) return ppb;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);

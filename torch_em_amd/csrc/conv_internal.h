@@ -50,11 +50,17 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
                         int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
                         int nsplit, float* stat, hipStream_t s);
 int64_t tem_conv_fwd_bf16x3_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
-// conv_pp.hip: ping-pong team kernel for the levels with many patches (false / -1: shape not taken)
-bool tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+// conv_pp.hip: ping-pong team kernel for the levels with many patches (1 launched, 0 shape not taken, -1 error set)
+int tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
                      int W, int Cin, int Cout, int kd, int kh, int kw, int act, int nsplit, float* stat, hipStream_t s);
 int64_t tem_conv_pp_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
+int tem_conv_pp_tiles(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
+// conv_zr.hip: z-reuse ping-pong kernel, 3x3x3 only (same return convention as tem_conv_fwd_pp)
+int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp, const float* bias,
+                    float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout,
+                    int kd, int kh, int kw, int act, int nsplit, float* stat, hipStream_t s);
+int64_t tem_conv_zr_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
 // conv1x1_stream.hip: 1x1x1 convolution / data gradient as a streaming GEMM (false: not taken)
 bool tem_conv1x1_stream(const float* x, int64_t x_ld, const float* scale, const float* wp, const float* bias, float* y,
                         int64_t y_ld, const float* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act, int nsplit,

@@ -531,7 +531,7 @@ struct PpGeom {
 static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit, int64_t max_ld) {
     PpGeom g = {};
     const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
-    if (opt == 0) return g;
+    if (opt == 0) return g;   // (2 = z-reuse kernel forced: shapes it does not take still come here)
     if (!(nsplit == 2 || nsplit == 4 || nsplit == 5)) return g;   // bf16x3, fp16x3 (scaled lo), one fp16 term (mixed mode)
     if (!(kh == 3 && kw == 3 && (kd == 3 || kd == 1))) return g;
     if (D < 4 || Cin % 16 || Cout % 32) return g;
@@ -549,7 +549,7 @@ static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     g.nY = (H + 7) / 8;
     g.nX = (W + 7) / 8;
     g.nunits = (int64_t)N * g.nZ * g.nY * g.nX * (Cout / (32 * g.CT));
-    if (g.nunits < (opt > 0 ? 1 : 2ll * ncu)) return g;
+    if (g.nunits < (opt == 1 ? 1 : 2ll * ncu)) return g;
     g.variant = 1;
     return g;
 }
@@ -558,6 +558,12 @@ int64_t tem_conv_pp_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, i
     const PpGeom g = pp_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, 1);
     if (!g.variant) return -1;
     return (int64_t)g.nZ * g.nY * g.nX * g.WM;
+}
+
+// 32-column tiles per team of the instantiation this shape selects (1 or 2), 0 when the shape is not handled here
+int tem_conv_pp_tiles(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
+    const PpGeom g = pp_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, 1);
+    return g.variant ? g.CT : 0;
 }
 
 template <int KD, int KH, int KW, int TZ, int CT, bool F16, int NS = 2>
@@ -586,18 +592,26 @@ static void pp_launch(const PpGeom& g, const float* x, int64_t x_ld, const float
                        g.nY, g.nX, stat, (int)g.nunits);
 }
 
-// -> true when the launch was taken
-bool tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+// -> 1 when the launch was taken, 0 when the shape belongs to another kernel, -1 when the caller sized a statistics
+// buffer for this kernel (tem_conv_pp_stat_blocks) but an alignment condition of the launch fails: falling through to the
+// patch kernel would write a differently shaped partials buffer (tem_last_error is set)
+int tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
                      int W, int Cin, int Cout, int kd, int kh, int kw, int act, int nsplit, float* stat, hipStream_t s) {
     int64_t max_ld = x_ld > y_ld ? x_ld : y_ld;
     if (ref && ref_ld > max_ld) max_ld = ref_ld;
     const PpGeom g = pp_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, max_ld);
-    if (!g.variant) return false;
+    if (!g.variant) return 0;
     // 16-byte epilogue accesses; statistics of a masked output are the patch kernel's business (never asked for together)
     if ((y_ld % 4) || ((uintptr_t)y % 16) || (ref && ((ref_ld % 4) || ((uintptr_t)ref % 16))) || (stat && ref) ||
-        act == TEM_ACT_SIGMOID)
-        return false;
+        act == TEM_ACT_SIGMOID) {
+        if (stat) {
+            tem_set_error("tem_conv3d_fwd_stats: statistics were sized for the ping-pong kernel but this launch cannot take it "
+                          "(y / ref need 16-byte alignment and ld %% 4 == 0, no ref, no sigmoid)");
+            return -1;
+        }
+        return 0;
+    }
     const bool f16 = nsplit == 4;
 #define PPGO(KD, CT)                                                                                                  \
     do {                                                                                                              \
@@ -619,5 +633,5 @@ bool tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const flo
         else PPGO(1, 2);
     }
 #undef PPGO
-    return true;
+    return 1;
 }

@@ -1,0 +1,717 @@
+// conv_zr.hip -- split-precision implicit-GEMM 3x3x3 convolution (forward and data gradient), "z-reuse" ping-pong teams.
+//
+// Replaces aten::convolution / the dgrad half of convolution_backward behind ConvBlock (model/unet.py:417-438) for the
+// 3x3x3 layers of the levels with many patches (128^3 ... 32^3).  Arithmetic and operand layouts are those of
+// k_conv_pp (conv_pp.hip): fp32 NDHWC activations, fused pre-norm while staging, operands split into 16-bit terms,
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_{bf16,f16}, two teams of four waves in opposite phases.
+//
+// What changed, and why.  Round-3 measurements (profiles/r03_issue_bench.txt, scripts/proto/issue_bench.hip):
+// k_conv_pp's tap loop read one activation fragment from LDS and one weight fragment from L1 per MFMA triple, its
+// multiplying team waited for operands (237-304 cycles per tap against 192 of MFMAs), and every other staging phase
+// carried a 5500-cycle epilogue.  Here
+//   * a wave owns a 4 x 8 (y, x) footprint through ALL FOUR z-planes of the team's 4 x 16 x 8 patch.  For a fixed
+//     (ty, tx) the activation fragment of halo plane hz is read ONCE and multiplied with the weights of tz = 0, 1, 2 into
+//     the accumulators of the output planes hz, hz - 1, hz - 2: 6 LDS reads feed 36 MFMAs (was 6 per 18), and the three
+//     weight fragments of a (ty, tx) column stay in registers for 12 products (was 2).  Measured: 34.6 cycles per MFMA in
+//     the tap phase against 34.0 for a bare MFMA stream -- the tap phase is matrix-pipe bound;
+//   * the MFMA operands are swapped (A = weights, B = activations), so a lane ends up with 16 channels of ONE voxel: the
+//     statistics are in-lane sums plus one transposing reduction per unit, the bias is the accumulators' initial value;
+//   * the staging team is bound by INSTRUCTION ISSUE beside the partner's MFMAs (~6 cycles per plain VALU instruction,
+//     ~69 per packed-fp32 one, ~32 per ds_write_b64, ~370 per 16-byte-per-line global store): the split is 14 VALU
+//     instructions per 4 channels (v_cvt_pk_f16_f32, v_fma_mix{lo,hi}_f16; range guard = MODE.FP16_OVFL), this file is
+//     compiled without the SLP vectoriser (no v_pk_*_f32), and outputs go through a small LDS transpose to full lines;
+//   * halo records are 32 B per plane (no padding); bank conflicts are avoided by swapping the two 16-byte halves of a
+//     record where bit 2 of the halo voxel index is set (8 consecutive x-voxels then cover all 8 16-byte bank groups);
+//   * one kernel per epilogue mode (plain / statistics / ReLU mask): with all of them in one function hipcc spilled 100-260
+//     registers, and a spill reload (vmcnt(0)) serialises the halo loads of the staging phase.
+// Phase balance at 32 -> 32 channels, 2 x 128^3 (shader cycles): tap phase 11.2 k; staging 6.5 k without, 14 k with the
+// epilogue of the previous unit (halo 1080 voxels, 18 16-byte loads per thread; epilogue 64 outputs per lane).
+#include "tem_common.h"
+#include "conv_internal.h"
+#include "conv_split.h"
+#include <type_traits>
+
+#ifndef TEM_ZR_PRIO
+#define TEM_ZR_PRIO 1    // s_setprio of the team in its MFMA phase
+#endif
+#ifndef TEM_ZR_R0
+#define TEM_ZR_R0 2      // halo planes (of 6; three 16-byte loads each) requested BEFORE the epilogue of the previous unit
+#endif
+#ifndef TEM_ZR_AD
+#define TEM_ZR_AD 2      // activation-fragment prefetch depth (LDS reads in flight ahead of the MFMAs that use them)
+#endif
+#ifndef TEM_ZR_ST_AUX
+#define TEM_ZR_ST_AUX 0  // cache policy of the epilogue stores (2 = nt)
+#endif
+#ifndef TEM_ZR_ABL
+#define TEM_ZR_ABL 0     // harness-only ablations: 1 no halo loads, 2 no stores, 4 no weight loads, 8 no LDS writes, 16 no MFMAs
+#endif
+
+typedef float floatx4z __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4z __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t zr_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 zr_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4z v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const floatx4z f = __builtin_bit_cast(floatx4z, v);   // whole-vector cast (element casts narrow the load)
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ uint4 zr_load4u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4z v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void zr_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b, float c, float d) {
+    const u32x4z v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
+                      __builtin_bit_cast(unsigned, d)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, TEM_ZR_ST_AUX);
+}
+
+// value of lane ^ M (M < 32): ds_swizzle in bit mode needs no index register (a __shfl_xor keeps four of them live)
+template <int M>
+__device__ __forceinline__ float zr_swz(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (M << 10) | 0x1f));
+}
+
+// value of the lane a DPP control selects (row_ror / row_half_mirror / quad_perm: inside a row of 16 lanes)
+template <int CTRL>
+__device__ __forceinline__ float zr_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// (g0 - 2^12 h.lo, g1 - 2^12 h.hi) rounded to two fp16 in one register: h = two fp16 in one register (the hi terms),
+// g = 2^12 x the fp32 values they were rounded from.  v_fma_mix{lo,hi}_f16 take the fp16 operand by half (op_sel), compute
+// the fma in fp32 (exact here) and round once into the selected half of the destination: 2 instructions where
+// convert / subtract / scale / convert-pack needs 7 (hipcc's vectoriser picks 4 v_cvt + v_pk_fma + v_cvt_pk instead).
+__device__ __forceinline__ unsigned zr_mix_lo(unsigned h, float g0, float g1) {
+    unsigned q;
+    const float c = -F16_LO_SCALE;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(q) : "v"(h), "s"(c), "v"(g0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(q) : "v"(h), "s"(c), "v"(g1));
+    return q;
+}
+
+#ifdef TEM_ZR_TRACE   // developer build (scripts/zr_harness.cpp): shader-clock stamps of the phases of one workgroup
+#ifndef TEM_ZR_TRACE_BLOCK
+#define TEM_ZR_TRACE_BLOCK 0
+#endif
+__device__ unsigned long long tem_zr_trace_buf[2][64][12];
+#define ZR_STAMP(i)                                                                           \
+    do {                                                                                      \
+        if (blockIdx.x == TEM_ZR_TRACE_BLOCK && tw == 0 && lane == 0 && s < 64)               \
+            tem_zr_trace_buf[team][s][i] = __builtin_amdgcn_s_memtime();                      \
+    } while (0)
+void tem_zr_trace_read(unsigned long long* dst) {
+    (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(tem_zr_trace_buf), sizeof(unsigned long long) * 2 * 64 * 12);
+}
+#else
+#define ZR_STAMP(i) asm volatile("; ZRMARK " #i)
+#endif
+
+struct ZrUnit {
+    int cot, n, z0, y0, x0;
+};
+
+// NS planes per operand; F16: fp16 terms with the lo planes stored x 2^12 and their cross products in a second
+// accumulator set (TEM_WL_F16X3), NS == 1 && F16: the one-term mixed mode; else bf16 terms in one accumulator set.
+// MODE (launch-uniform, one epilogue per instantiation): 0 plain, 1 fused statistics (`stat`), 2 ReLU mask (`ref`).
+template <int NS, bool F16, int MODE>
+__global__ __launch_bounds__(512, 2) void k_conv_zr(
+    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
+    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
+    int nY, int nX, float* __restrict__ stat, int nunits) {
+    constexpr int TZ = 4, TY = 16, TX = 8;
+    constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    constexpr int HV = HZ * HY * HX;             // 1080 halo voxels
+    constexpr int PLB = HV * 32;                 // bytes per plane of a team's tile (16 channels x 2 B per voxel)
+    constexpr int NIT = HZ * 3;                  // float4 slots per thread and chunk: three per halo plane
+    constexpr int R0 = TEM_ZR_R0 < HZ ? TEM_ZR_R0 : HZ;   // halo planes loaded before the epilogue
+    constexpr int FR = NS * 64;                  // uint4s per (tap, 16-channel chunk) fragment group
+    constexpr bool SC = F16 && NS == 2;
+    constexpr int ZSTEP = HY * HX * 32;          // bytes between halo z-planes: 5760 = 45 * 128 (bank-neutral)
+    static_assert((HY * HX) % 8 == 4, "the record-half swizzle alternates with hz");
+    extern __shared__ __attribute__((aligned(16))) unsigned char zr_lds[];   // [2 teams][NS planes][HV][32 B], [4 waves][32][144 B]
+
+    // MODE.FP16_OVFL (bit 23): fp16 results that overflow clamp to +-65504 instead of becoming inf -- the range guard of
+    // the two-term split (a normalised activation never gets there; k_conv_pp spends a v_med3 per element on the same guard)
+    if (SC) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wv >> 2, tw = wv & 3, tl = tid & 255;
+    const int kh = lane >> 5, v = lane & 31;
+    const int py = v >> 3, px = v & 7;
+    unsigned char* lds = zr_lds + team * (NS * PLB);
+
+    const int G = 2 * gridDim.x;
+    const int slot = tem_xcd_remap(blockIdx.x, gridDim.x) * 2 + team;
+    const int ncot = Cout >> 5;
+    const int nch = Cin >> 4;
+    const int my_units = slot < nunits ? (nunits - slot + G - 1) / G : 0;
+    const int P = ((nunits + G - 1) / G) * nch;
+
+    auto decode = [&](int ui) {
+        int u = slot + ui * G;
+        ZrUnit t;
+        t.cot = u % ncot; u /= ncot;
+        t.x0 = (u % nX) * TX; u /= nX;
+        t.y0 = (u % nY) * TY; u /= nY;
+        t.z0 = (u % nZ) * TZ; u /= nZ;
+        t.n = u;
+        return t;
+    };
+
+    // ---- per-thread constants ----
+    // staging: a halo z-plane has HY * HX = 180 voxels x 4 four-channel quarters = 720 slots: three per thread (the third
+    // only for tl < 208).  Slot j of plane hz: plane voxel q_j = (tl + 256 j) >> 2, channels c4*4 .. c4*4+3 of the chunk.
+    // Only the three in-plane byte offsets live in VGPRs; the plane offset is the scalar offset of the buffer load.
+    const int c4 = tl & 3;
+    unsigned poff[3];        // byte offset of slot j inside a halo plane (from the halo origin)
+    unsigned lwj[3];         // LDS byte offset of slot j in plane 0 (16-byte half swizzled by bit 2 of the record index)
+    int hyj[3], hxj[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = min((tl + 256 * j) >> 2, HY * HX - 1);
+        hyj[j] = q / HX;
+        hxj[j] = q % HX;
+        poff[j] = ((unsigned)(hyj[j] * W + hxj[j]) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u;
+        lwj[j] = (unsigned)(q * 32) + (unsigned)((((c4 >> 1) ^ ((q >> 2) & 1)) << 4) | ((c4 & 1) << 3));
+    }
+    const bool slot2 = tl < (HY * HX * 4 - 512);   // the third slot exists for 208 threads
+    const unsigned ctr_off = ((unsigned)(W + 1) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u;  // plane voxel (1, 1): always inside
+    const unsigned plane_b = (unsigned)(H * W) * (unsigned)x_ld * 4u;   // bytes between z-planes of x
+    // tap loop: halo voxel of this lane's footprint voxel at (hz, ty, tx) = (0, 0, 0)
+    const int hvb = (4 * tw + py) * HX + px;
+    // epilogue: this lane owns voxel (py, px) of the wave's footprint and channels 8 j + 4 kh + (0..3), j = 0..3
+    // (after the LDS transpose of the epilogue: voxel row 4 tw + m with m per store, x = lane >> 3, 16-byte piece lane & 7)
+    const unsigned yoff_lane = ((unsigned)(4 * tw * W + (lane >> 3)) * (unsigned)y_ld + (unsigned)(4 * (lane & 7))) * 4u;
+    const unsigned roff_lane = ((unsigned)(4 * tw * W + (lane >> 3)) * (unsigned)ref_ld + (unsigned)(4 * (lane & 7))) * 4u;
+    const __amdgpu_buffer_rsrc_t rw = zr_rsrc(wp);
+    const unsigned woff_lane = (unsigned)lane * 16u;
+    const float act_floor = act == TEM_ACT_RELU ? 0.f : -__builtin_inff();
+
+    floatx16 acc[TZ];
+    floatx16 accl[SC ? TZ : 1];
+    const int tapstride = nch * FR;      // uint4s between taps of the packed weights
+
+    int ui = 0, ci = 0;
+    ZrUnit cu = decode(0), eu = cu;
+    bool epi_pending = false;
+    // bias: lane l keeps channel (l & 31) of the unit being computed; the epilogue of the PREVIOUS unit resets the
+    // accumulators to it (the accumulators start from the bias, nothing is added afterwards)
+    float bv = (bias && my_units > 0) ? bias[cu.cot * 32 + v] : 0.f;
+    auto bias16 = [&](float* b16) {   // the 16 channels of this lane's accumulator registers: 8 (i >> 2) + 4 kh + (i & 3)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c0 = 8 * (i >> 2) + (i & 3);
+            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), c0));
+            const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), c0 + 4));
+            b16[i] = kh ? hi : lo;
+        }
+    };
+    {
+        float b16[16];
+        bias16(b16);
+#pragma unroll
+        for (int z = 0; z < TZ; ++z)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[z][i] = b16[i];
+                if (SC) accl[SC ? z : 0][i] = 0.f;
+            }
+    }
+    unsigned wsoff = 0;
+
+    if (team) __syncthreads();
+    for (int s = 0; s <= P; ++s) {
+        const bool do_stage = ui < my_units;
+        uint4 wq[2][3][NS];   // weight fragments of the (ty, tx) column in use and of the next one (declared per step: a
+                              // function-scope array is loop-carried for hipcc and gets spilled across the staging phase)
+        {
+            // ================= staging phase (the partner team runs its tap loop) =================
+            ZR_STAMP(0);
+            // keep hipcc from hoisting the 18 LDS / 18 global addresses of a phase out of the unit loop (it spills them)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(lwj[j]), "+v"(poff[j]));
+            unsigned yoff_l = yoff_lane, roff_l = roff_lane;
+            asm volatile("" : "+v"(yoff_l), "+v"(roff_l));
+            float4 tmp[NIT];
+            unsigned inb = 0xffffffffu;
+            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool interior = true;
+            __amdgpu_buffer_rsrc_t rx = zr_rsrc(x);
+            if (do_stage) {
+                if (scale) {
+                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
+                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
+                }
+                // the halo origin may lie outside the tensor for border patches (only in-range voxels are dereferenced)
+                const float* xb = x + ((((int64_t)cu.n * D + (cu.z0 - 1)) * H + (cu.y0 - 1)) * W + (cu.x0 - 1)) * x_ld + ci * BCK;
+                rx = zr_rsrc(xb);
+                interior = (cu.z0 >= 1) & (cu.z0 + HZ - 1 <= D) & (cu.y0 >= 1) & (cu.y0 + HY - 1 <= H) & (cu.x0 >= 1) &
+                           (cu.x0 + HX - 1 <= W);
+                if (TEM_ZR_ABL & 32) interior = true;   // timing experiment: border code paths compiled out (wrong at the faces)
+            }
+            unsigned yx = 7u;   // in-plane validity of the three slots: border patches only, once per phase, from a laundered
+            if (do_stage && !interior) {   // copy of tl (loop-invariant code motion would keep six more registers live)
+                int tl_ = tl;
+                asm volatile("" : "+v"(tl_));
+                yx = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int q = min((tl_ + 256 * j) >> 2, HY * HX - 1);
+                    const unsigned gy = (unsigned)(cu.y0 - 1 + q / HX), gx = (unsigned)(cu.x0 - 1 + q % HX);
+                    yx |= ((gy < (unsigned)H) & (gx < (unsigned)W)) ? (1u << j) : 0u;
+                }
+            }
+            auto issue_loads = [&](auto interior_tag, auto lo_tag, auto hi_tag) {   // halo planes LO .. HI-1
+                constexpr bool INTERIOR = decltype(interior_tag)::value;
+                constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
+                if (INTERIOR) {
+#pragma unroll
+                    for (int hz = LO; hz < HI; ++hz)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            if (TEM_ZR_ABL & 1) tmp[hz * 3 + j] = make_float4(0.5f + hz, 0.25f, -1.f, 2.f);
+                            else tmp[hz * 3 + j] = zr_load4(rx, poff[j], (unsigned)hz * plane_b);
+                        }
+                } else {
+                    if (LO == 0) inb = 0;
+#pragma unroll
+                    for (int hz = LO; hz < HI; ++hz) {
+                        const bool zok = (unsigned)(cu.z0 - 1 + hz) < (unsigned)D;   // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const bool ok = zok & ((yx >> j) & 1u);
+                            inb |= ok ? (1u << (hz * 3 + j)) : 0u;
+                            tmp[hz * 3 + j] = zr_load4(rx, (ok ? poff[j] : ctr_off) + (ok ? (unsigned)hz * plane_b : plane_b), 0);
+                        }
+                    }
+                }
+            };
+            if (do_stage) {
+                if (interior) issue_loads(std::true_type{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R0>{});
+                else issue_loads(std::false_type{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R0>{});
+            }
+            ZR_STAMP(1);
+            // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
+            if (epi_pending) {
+                const __amdgpu_buffer_rsrc_t ry = zr_rsrc(y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld + eu.cot * 32);
+                constexpr bool has_ref = MODE == 2;
+                const __amdgpu_buffer_rsrc_t rr_ = zr_rsrc(has_ref ? ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld + eu.cot * 32 : y);
+                const bool full = (TEM_ZR_ABL & 32) ? true : ((eu.z0 + TZ <= D) & (eu.y0 + TY <= H) & (eu.x0 + TX <= W));
+                const bool vok = (eu.y0 + 4 * tw + py < H) & (eu.x0 + px < W);   // this lane's footprint voxel (any z)
+                if (SC) {   // fold the scaled cross products first: their 64 registers are free for the rest of the epilogue
+#pragma unroll
+                    for (int z = 0; z < TZ; ++z)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[z][i] = fmaf(accl[SC ? z : 0][i], 1.f / F16_LO_SCALE, acc[z][i]);
+                }
+                ZR_STAMP(8);
+                float ssum[16], ssq[16];   // per-lane statistics partials (scalar fp32: packed fp32 waits for the matrix pipe)
+                if (MODE == 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
+                }
+                // Stores: a lane holds 16 B pieces of ONE voxel, so a direct store touches 32 lines with 32 B each -- measured at
+                // ~370 cycles per instruction beside the partner's MFMAs (scripts/proto/issue_bench.hip), 5900 per unit.  Each
+                // plane therefore goes through a wave-private LDS scratch ([32 voxels][128 B + 16 B pad]): written as it sits
+                // in the accumulators, read back with 8 consecutive lanes on one voxel row, stored (and masked) as full lines.
+                unsigned char* scr = zr_lds + 2 * NS * PLB + tw * (32 * 144);
+                unsigned char* scr_w = scr + v * 144 + kh * 16;                 // + 32 j: piece (2 j + kh) of this lane's voxel
+                const unsigned char* scr_r = scr + (lane >> 3) * 144 + (lane & 7) * 16;   // + 8 m rows: voxel (py = m, px = lane >> 3)
+                const bool tok_yx = (eu.x0 + (lane >> 3) < W);                  // transposed voxel: x in range (y, z per store)
+                auto body = [&](auto full_tag, auto ref_tag, auto stat_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value, HASREF = decltype(ref_tag)::value, STAT = decltype(stat_tag)::value;
+                    float4 q[2][4];
+                    auto load_ref = [&](int z) {
+                        const unsigned zo = (unsigned)z * (unsigned)(H * W);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const bool ok = FULL || (tok_yx & (eu.y0 + 4 * tw + m < H) & (eu.z0 + z < D));
+                            q[z & 1][m] = zr_load4(rr_, ok ? roff_l : 0u, ok ? (zo + (unsigned)(m * W)) * (unsigned)ref_ld * 4u : 0u);
+                        }
+                    };
+                    if (HASREF) load_ref(0);
+#pragma unroll
+                    for (int z = 0; z < TZ; ++z) {
+                        const bool ok = FULL || (vok & (eu.z0 + z < D));
+                        const unsigned zo = (unsigned)z * (unsigned)(H * W);
+                        if (HASREF && z + 1 < TZ) load_ref(z + 1);   // the masks of the next plane fly during this one
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float o[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int i = 4 * j + c;
+                                asm("v_max_f32 %0, %1, %2" : "=v"(o[c]) : "v"(acc[z][i]), "v"(act_floor));   // fmaxf() costs a canonicalising v_max first
+                            }
+                            if (STAT) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const float ov = (FULL || ok) ? o[c] : 0.f;
+                                    ssum[4 * j + c] += ov;
+                                    ssq[4 * j + c] = fmaf(ov, ov, ssq[4 * j + c]);
+                                }
+                            }
+                            *reinterpret_cast<float4*>(scr_w + 32 * j) = make_float4(o[0], o[1], o[2], o[3]);
+                        }
+                        float4 t[4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) t[m] = *reinterpret_cast<const float4*>(scr_r + m * (8 * 144));
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            if (HASREF) {
+                                t[m].x = q[z & 1][m].x > 0.f ? t[m].x : 0.f;
+                                t[m].y = q[z & 1][m].y > 0.f ? t[m].y : 0.f;
+                                t[m].z = q[z & 1][m].z > 0.f ? t[m].z : 0.f;
+                                t[m].w = q[z & 1][m].w > 0.f ? t[m].w : 0.f;
+                            }
+                            const bool sok = FULL || (tok_yx & (eu.y0 + 4 * tw + m < H) & (eu.z0 + z < D));
+                            if (sok && (!(TEM_ZR_ABL & 2) || t[m].x == 12345.678f))
+                                zr_store4(ry, yoff_l, (zo + (unsigned)(m * W)) * (unsigned)y_ld * 4u, t[m].x, t[m].y, t[m].z, t[m].w);
+                        }
+                    }
+                };
+                if (full) body(std::true_type{}, std::integral_constant<bool, MODE == 2>{}, std::integral_constant<bool, MODE == 1>{});
+                else body(std::false_type{}, std::integral_constant<bool, MODE == 2>{}, std::integral_constant<bool, MODE == 1>{});
+                ZR_STAMP(9);
+                if (MODE == 1) {
+                    // transposing reduction over the 32 voxel lanes of each half-wave: after the step with partner lane ^ m
+                    // a lane keeps the half of its values selected by its own bit m -- 16 -> 8 -> 4 -> 2 -> 1 values per lane
+                    // and quantity; the last step (partner lane ^ 1) leaves the total in both lanes.
+                    float a8[8], b8[8];
+                    {
+                        const bool up = (lane & 16) != 0;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float keepa = up ? ssum[i + 8] : ssum[i], senda = up ? ssum[i] : ssum[i + 8];
+                            const float keepb = up ? ssq[i + 8] : ssq[i], sendb = up ? ssq[i] : ssq[i + 8];
+                            a8[i] = keepa + zr_swz<16>(senda);
+                            b8[i] = keepb + zr_swz<16>(sendb);
+                        }
+                    }
+                    // the remaining steps stay inside a row of 16 lanes: DPP operands (no LDS round trip).  Partners: lane ^ 8
+                    // (row_ror:8), lane ^ 7 (row_half_mirror), lane ^ 3 (quad_perm [3,2,1,0]), lane ^ 1 (quad_perm [1,0,3,2]) --
+                    // any pairing works as long as the two lanes differ in the bit that selects what they keep.
+                    float a4[4], b4[4];
+                    {
+                        const bool up = (lane & 8) != 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float keepa = up ? a8[i + 4] : a8[i], senda = up ? a8[i] : a8[i + 4];
+                            const float keepb = up ? b8[i + 4] : b8[i], sendb = up ? b8[i] : b8[i + 4];
+                            a4[i] = keepa + zr_dpp<0x128>(senda);
+                            b4[i] = keepb + zr_dpp<0x128>(sendb);
+                        }
+                    }
+                    float a2[2], b2[2];
+                    {
+                        const bool up = (lane & 4) != 0;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const float keepa = up ? a4[i + 2] : a4[i], senda = up ? a4[i] : a4[i + 2];
+                            const float keepb = up ? b4[i + 2] : b4[i], sendb = up ? b4[i] : b4[i + 2];
+                            a2[i] = keepa + zr_dpp<0x141>(senda);
+                            b2[i] = keepb + zr_dpp<0x141>(sendb);
+                        }
+                    }
+                    float a1, b1;
+                    {
+                        const bool up = (lane & 2) != 0;
+                        const float keepa = up ? a2[1] : a2[0], senda = up ? a2[0] : a2[1];
+                        const float keepb = up ? b2[1] : b2[0], sendb = up ? b2[0] : b2[1];
+                        a1 = keepa + zr_dpp<0x1B>(senda);
+                        b1 = keepb + zr_dpp<0x1B>(sendb);
+                    }
+                    a1 += zr_dpp<0xB1>(a1);
+                    b1 += zr_dpp<0xB1>(b1);
+                    // this lane now holds register index i = bits (4,3,2,1) of its lane id: channel 8 (i >> 2) + 4 kh + (i & 3)
+                    const int i = (lane >> 1) & 15;
+                    const int ch = eu.cot * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
+                    const int64_t patch = ((int64_t)(eu.z0 / TZ) * nY + eu.y0 / TY) * nX + eu.x0 / TX;
+                    const int64_t nblk = (int64_t)nZ * nY * nX * 4;
+                    float* dst = stat + (((int64_t)eu.n * nblk + patch * 4 + tw) * Cout + ch) * 2;
+                    dst[lane & 1] = (lane & 1) ? b1 : a1;
+                }
+                ZR_STAMP(10);
+                // the next unit of this team starts from ITS bias (bv already belongs to it: cu was decoded after the last
+                // tap phase); the accumulator registers were dead from their stores up to here
+                float b16[16];
+                bias16(b16);
+#pragma unroll
+                for (int z = 0; z < TZ; ++z)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        acc[z][i] = b16[i];
+                        if (SC) accl[SC ? z : 0][i] = 0.f;
+                    }
+                epi_pending = false;
+                ZR_STAMP(11);
+            }
+            ZR_STAMP(6);
+            // ---- norm, split, LDS tile, R0 planes behind the loads; then prime the weight fragments of the first column ----
+            if (do_stage) {
+                // Measured (scripts/proto/issue_bench.hip): beside a wave that streams MFMAs a plain VALU instruction of this
+                // wave issues every ~6 cycles, a v_fma_mix*_f16 every ~9-12, a ds_write_b64 every ~32 -- but a PACKED fp32
+                // instruction (v_pk_fma_f32 / v_pk_mul_f32) only every ~69: they queue behind the matrix pipe.  So: scalar
+                // fp32 math, and per 4 channels 4 v_fma (norm), 2 v_cvt_pk_f16 (hi), 4 v_mul (g = 2^12 e)
+                // + 4 v_fma_mix{lo,hi}_f16 (lo' = g - 2^12 hi, exact in fp32, rounded once), 2 ds_write_b64.
+                // Range: MODE.FP16_OVFL clamps instead of producing inf (set at kernel entry for the two-term layout).
+                auto convert = [&](auto interior_tag, auto hz_tag) {
+                    constexpr bool INTERIOR = decltype(interior_tag)::value;
+                    constexpr int hz = decltype(hz_tag)::value;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int it = hz * 3 + j;
+                        if (j < 2 || slot2) {
+                            float m = 1.f;
+                            if (!INTERIOR) m = ((inb >> it) & 1u) ? 1.f : 0.f;   // zero padding comes after the norm (model/unet.py:429-438)
+                            float e[4] = {fmaf(tmp[it].x, sc4.x, sf4.x), fmaf(tmp[it].y, sc4.y, sf4.y),
+                                          fmaf(tmp[it].z, sc4.z, sf4.z), fmaf(tmp[it].w, sc4.w, sf4.w)};
+                            if (!INTERIOR) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) e[c] *= m;
+                            }
+                            // record hz * 180 + q_j: bit 2 of the record index flips with hz (180 = 4 mod 8)
+                            unsigned char* dstp = lds + (lwj[j] ^ ((hz & 1) ? 16u : 0u)) + hz * ZSTEP;
+                            if (SC) {
+                                const half2_t hh0 = {(_Float16)e[0], (_Float16)e[1]}, hh1 = {(_Float16)e[2], (_Float16)e[3]};
+                                unsigned u0 = __builtin_bit_cast(unsigned, hh0), u1 = __builtin_bit_cast(unsigned, hh1);
+                                if (!(TEM_ZR_ABL & 8) || u0 == 0x12345678u) *reinterpret_cast<uint2*>(dstp) = make_uint2(u0, u1);
+                                const float g[4] = {e[0] * F16_LO_SCALE, e[1] * F16_LO_SCALE, e[2] * F16_LO_SCALE, e[3] * F16_LO_SCALE};
+                                const unsigned q0 = zr_mix_lo(u0, g[0], g[1]), q1 = zr_mix_lo(u1, g[2], g[3]);
+                                if (!(TEM_ZR_ABL & 8) || u0 == 0x12345678u) *reinterpret_cast<uint2*>(dstp + PLB) = make_uint2(q0, q1);
+                            } else {
+                                if (F16 && NS == 1) {   // one rounding to fp16 after the fp32 norm, as autocast (see conv_pp.hip)
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(e[c]));
+                                }
+#pragma unroll
+                                for (int p = 0; p < NS; ++p) {
+                                    const unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
+                                    if (!(TEM_ZR_ABL & 8) || h0 == 0x12345678u)
+                                        *reinterpret_cast<uint2*>(dstp + p * PLB) = make_uint2(h0, h1);
+                                    if (p + 1 < NS) {
+                                        e[0] -= lo16<F16>(h0);
+                                        e[1] -= hi16<F16>(h0);
+                                        e[2] -= lo16<F16>(h1);
+                                        e[3] -= hi16<F16>(h1);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                };
+                auto stage_planes = [&](auto interior_tag) {
+#define ZR_PLANE(HZI)                                                                                              \
+    do {                                                                                                           \
+        if ((HZI) + R0 < HZ)                                                                                       \
+            issue_loads(interior_tag, std::integral_constant<int, ((HZI) + R0 < HZ ? (HZI) + R0 : 0)>{},           \
+                        std::integral_constant<int, ((HZI) + R0 < HZ ? (HZI) + R0 + 1 : 0)>{});                    \
+        convert(interior_tag, std::integral_constant<int, (HZI)>{});                                               \
+    } while (0)
+                    ZR_PLANE(0); ZR_PLANE(1); ZR_PLANE(2); ZR_PLANE(3); ZR_PLANE(4); ZR_PLANE(5);
+#undef ZR_PLANE
+                };
+                if (interior) stage_planes(std::true_type{});
+                else stage_planes(std::false_type{});
+                ZR_STAMP(7);
+                wsoff = (unsigned)((cu.cot * 27 * nch + ci) * FR) * 16u;   // (column tile, tap 0, chunk ci) of the packed weights
+#pragma unroll
+                for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+                    for (int p = 0; p < NS; ++p)
+                        wq[0][tz][p] = zr_load4u(rw, woff_lane, wsoff + (unsigned)((tz * 9) * tapstride + p * 64) * 16u);
+            }
+            ZR_STAMP(2);
+        }
+        __syncthreads();
+        {
+            ZR_STAMP(3);
+            // ================= MFMA phase: 27 taps of one 16-channel chunk out of this team's tile =================
+            if (do_stage) {
+                int ts = tapstride;
+                asm volatile("" : "+s"(ts));
+                if (TEM_ZR_PRIO) __builtin_amdgcn_s_setprio(TEM_ZR_PRIO);
+                // activation fragment of step st = g * 6 + hz (g = ty * 3 + tx): halo voxel hvb + (hz * HY + ty) * HX + tx,
+                // 16-byte half kh ^ bit2(voxel); bit 2 alternates with hz (HY * HX = 180 = 4 mod 8), so two addresses per
+                // column serve its six planes through immediate offsets
+                constexpr int NSTEP = 9 * HZ;
+                constexpr int AD = TEM_ZR_AD;
+                uint4 af[AD + 1][NS];
+                unsigned a01[2] = {0u, 0u};
+                int hvb_ = hvb;
+                asm volatile("" : "+v"(hvb_));   // the 18 column addresses are computed in place, not hoisted and spilled
+                auto col_addr = [&](int g) {
+                    const int hvv = hvb_ + (g / 3) * HX + (g % 3);
+                    const unsigned half = (unsigned)(((hvv >> 2) & 1) ^ kh) << 4;
+                    a01[0] = (unsigned)hvv * 32u + half;
+                    a01[1] = (unsigned)hvv * 32u + (half ^ 16u) + (unsigned)ZSTEP;
+                };
+                auto a_read = [&](int st) {   // st compile-time after unrolling
+                    const int hz = st % HZ;
+#pragma unroll
+                    for (int p = 0; p < NS; ++p)
+                        af[st % (AD + 1)][p] = *reinterpret_cast<const uint4*>(lds + a01[hz & 1] + (hz >> 1) * (2 * ZSTEP) + p * PLB);
+                };
+                col_addr(0);
+#pragma unroll
+                for (int st = 0; st < AD; ++st) a_read(st);
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) {
+                    const int g = st / HZ, hz = st % HZ;
+                    // prefetch: activation fragment AD steps ahead (addresses of the next column when it crosses over)
+                    if (st + AD < NSTEP) {
+                        if ((st + AD) % HZ == 0) col_addr((st + AD) / HZ);
+                        a_read(st + AD);
+                    }
+                    // weight fragments of the next column, one tz per step of the first three steps of this column
+                    if (hz < 3 && g + 1 < 9 && !(TEM_ZR_ABL & 4)) {
+                        const int gn = g + 1, tz = hz;
+                        const int tap = tz * 9 + gn;
+#pragma unroll
+                        for (int p = 0; p < NS; ++p)
+                            wq[gn & 1][tz][p] = zr_load4u(rw, woff_lane, wsoff + (unsigned)(tap * ts + p * 64) * 16u);
+                    }
+                    // products of this step: output plane z = hz - tz for tz = 0..2; smallest terms first, interleaved over z
+                    const uint4* a = af[st % (AD + 1)];
+#pragma unroll
+                    for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                        for (int i = 0; i <= sum; ++i)
+#pragma unroll
+                            for (int tz = 0; tz < 3; ++tz) {
+                                const int z = hz - tz;
+                                if (z < 0 || z >= TZ) continue;
+                                // plane pair (weight plane i, activation plane sum - i)
+                                if (TEM_ZR_ABL & 16) {
+                                    asm volatile("" ::"v"(a[sum - i].x), "v"(a[sum - i].w), "v"(wq[g & 1][tz][i].x), "v"(wq[g & 1][tz][i].w));
+                                    continue;
+                                }
+                                if (SC && sum == 1)
+                                    accl[SC ? z : 0] = mfma16<F16>(wq[g & 1][tz][i], a[sum - i], accl[SC ? z : 0]);
+                                else
+                                    acc[z] = mfma16<F16>(wq[g & 1][tz][i], a[sum - i], acc[z]);
+                            }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (TEM_ZR_PRIO) __builtin_amdgcn_s_setprio(0);
+            }
+            ZR_STAMP(4);
+        }
+        if (do_stage) {
+            if (++ci == nch) {
+                ci = 0;
+                eu = cu;
+                epi_pending = true;
+                bv = 0.f;
+                if (++ui < my_units) {
+                    cu = decode(ui);
+                    if (bias) bv = bias[cu.cot * 32 + v];
+                }
+            }
+        }
+        __syncthreads();
+        ZR_STAMP(5);
+    }
+    if (!team) __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct ZrGeom {
+    int ok;
+    int nZ, nY, nX;
+    int64_t nunits;
+};
+
+// 3x3x3 kernels with two-plane (or the one-term mixed) layouts, 16-byte-vector friendly channel counts and at least one
+// unit per team of every CU (smaller launches stay with k_conv_pp / the split-K patch kernel).
+static ZrGeom zr_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit, int64_t max_ld) {
+    ZrGeom g = {};
+    const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
+    if (opt == 0 || opt == 1) return g;
+    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5)) return g;
+    if (!(kd == 3 && kh == 3 && kw == 3)) return g;
+    if (D < 4 || Cin % 16 || Cout % 32) return g;
+    if ((int64_t)H * W * 8 * 4 * max_ld >= (1ll << 31)) return g;   // 32-bit byte offsets inside one halo / one patch
+    static int ncu = 0;
+    if (!ncu) {
+        ncu = tem_device_cus();
+        if (ncu <= 0) ncu = 256;
+    }
+    g.nZ = (D + 3) / 4;
+    g.nY = (H + 15) / 16;
+    g.nX = (W + 7) / 8;
+    g.nunits = (int64_t)N * g.nZ * g.nY * g.nX * (Cout / 32);
+    if (g.nunits >= (1ll << 31)) return g;
+    if (g.nunits < (opt == 2 ? 1 : 2ll * ncu)) return g;
+    g.ok = 1;
+    return g;
+}
+
+int64_t tem_conv_zr_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
+    const ZrGeom g = zr_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, 1);
+    if (!g.ok) return -1;
+    return (int64_t)g.nZ * g.nY * g.nX * 4;
+}
+
+template <int NS, bool F16, int MODE>
+static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H, int W,
+                      int Cin, int Cout, int act, float* stat, hipStream_t s) {
+    constexpr size_t ldsb = (size_t)2 * NS * 1080 * 32 + 4 * 32 * 144;   // two tiles + the epilogue's transpose scratch
+    static_assert(ldsb <= 160 * 1024, "LDS budget");
+    auto kern = &k_conv_zr<NS, F16, MODE>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        attr = true;
+    }
+    static int ncu = 0;
+    if (!ncu) {
+        ncu = tem_device_cus();
+        if (ncu <= 0) ncu = 256;
+    }
+    int64_t grid = (g.nunits + 1) / 2;
+    if (grid > ncu) grid = ncu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp),
+                       bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits);
+}
+
+// -> 1 launched, 0 shape not taken, -1 error (statistics sized for this kernel but the launch cannot take it)
+int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp, const float* bias,
+                    float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout,
+                    int kd, int kh, int kw, int act, int nsplit, float* stat, hipStream_t s) {
+    int64_t max_ld = x_ld > y_ld ? x_ld : y_ld;
+    if (ref && ref_ld > max_ld) max_ld = ref_ld;
+    const ZrGeom g = zr_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, max_ld);
+    if (!g.ok) return 0;
+    if ((y_ld % 4) || ((uintptr_t)y % 16) || (ref && ((ref_ld % 4) || ((uintptr_t)ref % 16))) || (stat && ref) ||
+        (bias && ((uintptr_t)bias % 16)) || act == TEM_ACT_SIGMOID) {
+        if (stat) {
+            tem_set_error("tem_conv3d_fwd_stats: statistics were sized for the z-reuse kernel but this launch cannot take it "
+                          "(y / ref / bias need 16-byte alignment and ld %% 4 == 0, no ref, no sigmoid)");
+            return -1;
+        }
+        return 0;
+    }
+#define ZRGO(NS, F16)                                                                                                         \
+    do {                                                                                                                      \
+        if (stat)                                                                                                             \
+            zr_launch<NS, F16, 1>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, s); \
+        else if (ref)                                                                                                         \
+            zr_launch<NS, F16, 2>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, s); \
+        else                                                                                                                  \
+            zr_launch<NS, F16, 0>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, s); \
+    } while (0)
+    if (nsplit == 5) ZRGO(1, true);
+    else if (nsplit == 4) ZRGO(2, true);
+    else ZRGO(2, false);
+#undef ZRGO
+    return 1;
+}
