@@ -185,6 +185,7 @@ PP_CASES = [
     ((2, 17, 62, 66, 64, 32, (3, 3, 3)), (1, 2)),    # ragged, decoder level-0 conv1 shape class
     ((2, 16, 64, 64, 32, 32, (1, 3, 3)), (1, 1)),    # anisotropic 1x3x3 kernel, one tile
     ((2, 16, 64, 64, 64, 64, (1, 3, 3)), (2, 2)),    # anisotropic, two tiles
+    ((2, 32, 64, 64, 32, 32, (3, 3, 3)), (1, 1)),    # 512 z-reuse units both ways: the shape class of the level-0 layers in auto mode
 ]
 
 
@@ -196,14 +197,31 @@ def conv_variant_option():
     _lib.set_option("conv_fwd_variant", old)
 
 
+def _expected_family(variant, k, pp_tiles, zr_units):
+    """The dispatch rule of tem_conv3d_fwd (csrc/conv_bf16x3.hip): z-reuse for 3x3x3 with >= 512 units (or when forced),
+    else ping-pong (every PP_CASES shape has >= 512 ping-pong units), patch kernel only when asked for."""
+    if variant == 0:
+        return 0
+    if variant == 1:
+        return pp_tiles
+    if k == (3, 3, 3) and (variant == 2 or zr_units >= 512):
+        return 3
+    return pp_tiles
+
+
+def _zr_units(N, D, H, W, cout):
+    return N * ((D + 3) // 4) * ((H + 15) // 16) * ((W + 7) // 8) * (cout // 32)
+
+
 @pytest.mark.parametrize("case,cts", PP_CASES)
-@pytest.mark.parametrize("variant", [-1, 0, 1])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2])
 def test_conv_pingpong_family_parity(case, cts, variant, conv_variant_option):
-    """Every instantiation of the ping-pong team kernel k_conv_pp<KD,3,3,..,CT in {1,2},NS,F16> (csrc/conv_pp.hip: the
-    forward / data-gradient convolutions of the 128^3 ... 32^3 levels, reference model/unet.py:417-438) against F.conv3d in
-    fp32, and the SAME shapes on the one-patch-per-workgroup kernel (variant 0): bf16x3 1e-4, fp16x3 2e-5, one-term fp16
-    2e-5 against the convolution of the fp16-rounded operands.  tem_conv3d_fwd_kernel() says which family a launch takes
-    (0 patch kernel, else the number of Cout tiles per team), so a silent fallback cannot pass as coverage."""
+    """Every instantiation of the two team kernels -- k_conv_zr<NS,F16,MODE> (csrc/conv_zr.hip, 3x3x3, z-reuse) and
+    k_conv_pp<KD,3,3,..,CT in {1,2},NS,F16> (csrc/conv_pp.hip) -- that run the forward / data-gradient convolutions of the
+    128^3 ... 32^3 levels (reference model/unet.py:417-438), against F.conv3d in fp32, and the SAME shapes on the
+    one-patch-per-workgroup kernel (variant 0): bf16x3 1e-4, fp16x3 2e-5, one-term fp16 2e-5 against the convolution of the
+    fp16-rounded operands.  tem_conv3d_fwd_kernel() says which family a launch takes (0 patch kernel, 1 / 2 ping-pong with
+    that many Cout tiles per team, 3 z-reuse), so a silent fallback cannot pass as coverage."""
     ops = _ops()
     from torch_em_amd import _lib
     lib = _lib.load()
@@ -222,7 +240,7 @@ def test_conv_pingpong_family_parity(case, cts, variant, conv_variant_option):
     x5, wd = to5(x), w.to(DEV)
     for mode in (2, 4, 5):
         fam = lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, k[0], k[1], k[2], mode)
-        assert fam == (0 if variant == 0 else cts[0]), (mode, fam)
+        assert fam == _expected_family(variant, k, cts[0], _zr_units(N, D, H, W, Cout)), (mode, fam)
         y5 = ops.new_act(N, D, H, W, Cout, DEV)
         ops.conv_fwd(x5, ops.pack_weights(wd, transpose=False, mfma=mode), b.to(DEV), y5, k, Cin, Cout, scale=scale.to(DEV),
                      shift=shift.to(DEV), act="relu", mfma=mode)
@@ -236,7 +254,7 @@ def test_conv_pingpong_family_parity(case, cts, variant, conv_variant_option):
     g5 = to5(gy)
     for mode in (2, 4, 5):
         fam = lib.tem_conv3d_fwd_kernel(N, D, H, W, Cout, Cin, k[0], k[1], k[2], mode)
-        assert fam == (0 if variant == 0 else cts[1]), (mode, fam)
+        assert fam == _expected_family(variant, k, cts[1], _zr_units(N, D, H, W, Cin)), (mode, fam)
         gx5 = ops.new_act(N, D, H, W, Cin, DEV)
         ops.conv_fwd(g5, ops.pack_weights(wd, transpose=True, mfma=mode), None, gx5, k, Cout, Cin, mfma=mode)
         err = rel_err(from5(gx5), gxe16 if mode == 5 else gxe)
@@ -250,6 +268,8 @@ def test_conv_pingpong_family_parity(case, cts, variant, conv_variant_option):
 
 
 @pytest.mark.parametrize("case", [      # >= 384 workgroups each: smaller launches run split-K and cannot fuse
+    (2, 18, 61, 67, 32, 64, (3, 3, 3), 32),   # z-reuse kernel (720 units), ragged in z, y and x, two column tiles, GroupNorm(32, 64)
+    (2, 32, 64, 64, 32, 32, (3, 3, 3), 32),   # z-reuse kernel, exactly one unit per team
     (2, 17, 50, 66, 32, 32, (3, 3, 3), 32),   # ragged patches, one column tile
     (1, 24, 64, 64, 32, 64, (3, 3, 3), 32),   # 2x2 wave tiling, GroupNorm(32, 64)
     (2, 8, 48, 48, 64, 96, (1, 3, 3), 96),    # three column tiles
