@@ -174,6 +174,27 @@ int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const flo
                      int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                      int use_mfma, int sd_layout, tem_stream_t stream);
 
+/* tem_conv3d_wgrad (w == NULL, norm_sums == NULL) or tem_conv3d_wgrad_sums that ALSO reports the largest |g|: g_amax
+ * (device, one 32-bit word the caller cleared) receives the bit pattern of max |g| by an integer atomicMax -- exact and
+ * order-independent.  dw comes in state_dict order.  Only the z-sliding 3x3x3 kernel stages all of g
+ * (tem_conv3d_wgrad_gmax_ok: 3x3x3, D >= 16, Cin, Cout % 32 == 0, use_mfma == 2).  Consumer: tem_conv3d_fwd_gscaled. */
+int tem_conv3d_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
+int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                          const float* g, int64_t g_ld, const float* w, const float* gamma, const float* beta,
+                          float* dw, float* db, float* norm_sums, unsigned* g_amax, void* ws, int64_t ws_bytes,
+                          int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma,
+                          tem_stream_t stream);
+
+/* Data gradient of nn.Conv3d (the dgrad half of convolution_backward behind model/unet.py:417-438) with fp32-class
+ * products on an UNNORMALISED input: tem_conv3d_fwd with use_mfma = 4 (two fp16 terms per operand, 22 mantissa bits)
+ * on w_packed = tem_conv_pack_weights(transpose = 1, use_mfma = 4), no bias / norm / activation, where the kernel first
+ * multiplies x by the power of two that puts *in_amax (bit pattern of max |x|, e.g. from tem_conv3d_wgrad_gmax) into
+ * [2^14, 2^15) and divides the result by it: exact, and nothing can leave fp16's range.  Only for launches that
+ * tem_conv3d_fwd_kernel(..., 4) reports as 3. */
+int tem_conv3d_fwd_gscaled(const float* x, int64_t x_ld, const float* w_packed, float* y, int64_t y_ld,
+                           const float* ref, int64_t ref_ld, const unsigned* in_amax, void* ws, int64_t ws_bytes,
+                           int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, tem_stream_t stream);
+
 /* tem_conv3d_wgrad of a first layer (Cin <= 4, VALU kernel) whose g is still the RAW data gradient behind the norm that
  * follows this conv's ReLU (the second norm of the first ConvBlock, model/unet.py:429-438): the norm backward
  * g := (y > 0) ? a*g - m1 - (y - mean)*m2r : 0 (gcoef[N][Cout][4] from tem_norm_bwd_coef, y = this conv's output) is

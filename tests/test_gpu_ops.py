@@ -267,6 +267,47 @@ def test_conv_pingpong_family_parity(case, cts, variant, conv_variant_option):
             assert err < (1e-4 if mode == 2 else 2e-5), f"masked dgrad mode {mode}: {err}"
 
 
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 32), (2, 18, 61, 67, 64, 32), (2, 16, 64, 64, 64, 64)])
+@pytest.mark.parametrize("gscale", [1.0, 3e-7, 5e4])
+def test_data_gradient_fp16_two_term_with_device_prescale(case, gscale):
+    """tem_conv3d_wgrad_gmax + tem_conv3d_fwd_gscaled: the weight gradient reports max |g| (bit pattern, integer atomicMax),
+    the data gradient (dgrad half of convolution_backward, reference model/unet.py:417-438) prescales g by the power of
+    two that puts that maximum at 2^14, runs the fp16 two-term layout and unscales: fp32-class (2e-5 against F.conv3d's
+    fp32 data gradient, the bf16x3 kernels have 1e-4) for gradients of any magnitude -- 3e-7 sits far below fp16's
+    normal range, 5e4 next to its overflow."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout = case
+    k = (3, 3, 3)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.2
+    gy = torch.randn(N, Cout, D, H, W, generator=g) * gscale
+    gy[0, 0, 0, 0, :4] = 0.0
+    refm = torch.randn(N, Cin, D, H, W, generator=g)
+    gxe = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=(1, 1, 1))
+    dwe = torch.nn.grad.conv3d_weight(x, w.shape, gy, padding=(1, 1, 1))
+    x5, g5, wd = to5(x), to5(gy), w.to(DEV)
+    assert ops.conv_wgrad_gmax_ok(g5, k, Cin, Cout, 2) and ops.conv_fwd_family(g5, k, Cout, Cin, 4) == 3
+    amax = torch.zeros(1, dtype=torch.int32, device=DEV)
+    dw = torch.empty(w.numel(), device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    ops.conv_wgrad_gmax(x5, g5, k, Cin, Cout, dw, db, amax)
+    assert rel_err(dw.cpu().view(w.shape), dwe) < 1e-4 and rel_err(db.cpu(), gy.sum((0, 2, 3, 4))) < 5e-5
+    assert int(amax.cpu()[0]) == int(gy.abs().max().view(torch.int32))          # exact: the bit pattern of max |g|
+    wp = ops.pack_weights(wd, transpose=True, mfma=4)
+    gx5 = ops.new_act(N, D, H, W, Cin, DEV)
+    ops.conv_fwd_gscaled(g5, wp, gx5, k, Cout, Cin, amax)
+    err = rel_err(from5(gx5), gxe)
+    assert err < 2e-5, err
+    ops.conv_fwd_gscaled(g5, wp, gx5, k, Cout, Cin, amax, ref=to5(refm))          # ReLU mask of the producing layer
+    err = rel_err(from5(gx5), gxe * (refm > 0))
+    assert err < 2e-5, err
+    # the bf16x3 data gradient of the same operands: the 16-bit class this path replaces (guards against a silent fallback)
+    gx2 = ops.new_act(N, D, H, W, Cin, DEV)
+    ops.conv_fwd(g5, ops.pack_weights(wd, transpose=True, mfma=2), None, gx2, k, Cout, Cin, mfma=2)
+    assert not torch.equal(gx2, gx5)
+
+
 @pytest.mark.parametrize("case", [      # >= 384 workgroups each: smaller launches run split-K and cannot fuse
     (2, 18, 61, 67, 32, 64, (3, 3, 3), 32),   # z-reuse kernel (720 units), ragged in z, y and x, two column tiles, GroupNorm(32, 64)
     (2, 32, 64, 64, 32, 32, (3, 3, 3), 32),   # z-reuse kernel, exactly one unit per team

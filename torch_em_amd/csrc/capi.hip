@@ -30,6 +30,7 @@ static const TemOption g_opt_table[TEM_OPT_COUNT] = {
     {"fwd_persistent", -1},     // TEM_OPT_FWD_PERSISTENT: exact-fp32 forward, persistent variant (-1 = 64-column tiles only)
     {"conv_fwd_variant", -1},   // TEM_OPT_CONV_FWD_VARIANT: split-precision forward/dgrad kernel (-1 auto, 0 patch kernel, 1 ping-pong forced, 2 z-reuse forced)
     {"conv1x1_stream", 1},      // TEM_OPT_CONV1X1_STREAM: 1x1x1 convolutions / data gradients as a streaming GEMM (conv1x1_stream.hip)
+    {"fwd_ksplit_chunks", 0},   // TEM_OPT_FWD_KSPLIT_CHUNKS: split-K forward launches: at most this many 16-channel chunks per partial (0: heuristic only)
 };
 static long long g_opt_val[TEM_OPT_COUNT];
 static bool g_opt_set[TEM_OPT_COUNT];

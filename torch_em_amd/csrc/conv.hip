@@ -587,6 +587,49 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
                              use_mfma, sd_layout, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
+extern "C" int tem_conv3d_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                                        int use_mfma) {
+    return use_mfma == 2 && tem_conv_wgrad_gmax_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
+}
+
+extern "C" int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                                     const float* g, int64_t g_ld, const float* w, const float* gamma,
+                                     const float* beta, float* dw, float* db, float* norm_sums, unsigned* g_amax,
+                                     void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd,
+                                     int kh, int kw, int use_mfma, tem_stream_t stream) {
+    TEM_REQUIRE(g_amax, "tem_conv3d_wgrad_gmax: null g_amax");
+    TEM_REQUIRE(tem_conv3d_wgrad_gmax_ok(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma),
+                "tem_conv3d_wgrad_gmax: tem_conv3d_wgrad_gmax_ok() == 0 for this layer");
+    TEM_REQUIRE(!norm_sums || (w && db && tem_conv3d_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma)),
+                "tem_conv3d_wgrad_gmax: norm_sums needs weights, a bias gradient and tem_conv3d_wgrad_sums_ok() != 0");
+    tem_wgrad_gmax_target = g_amax;
+    const int rc = conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh,
+                                     kw, use_mfma, 1, norm_sums ? w : nullptr, gamma, beta, norm_sums, nullptr, 0, nullptr,
+                                     stream);
+    tem_wgrad_gmax_target = nullptr;
+    return rc;
+}
+
+extern "C" int tem_conv3d_fwd_gscaled(const float* x, int64_t x_ld, const float* w_packed, float* y, int64_t y_ld,
+                                      const float* ref, int64_t ref_ld, const unsigned* in_amax, void* ws,
+                                      int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh,
+                                      int kw, tem_stream_t stream) {
+    TEM_REQUIRE(in_amax, "tem_conv3d_fwd_gscaled: null in_amax");
+    TEM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0 && tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, kd, kh, kw, 4) == 3,
+                "tem_conv3d_fwd_gscaled: only launches that tem_conv3d_fwd_kernel() reports as 3 (z-reuse kernel) take a "
+                "device-side prescale");
+    tem_zr_in_amax = in_amax;
+    const int rc = conv3d_fwd_impl(x, x_ld, nullptr, nullptr, w_packed, nullptr, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
+                                   W, Cin, Cout, kd, kh, kw, TEM_ACT_NONE, 4, nullptr, stream);
+    const bool consumed = tem_zr_in_amax == nullptr;
+    tem_zr_in_amax = nullptr;
+    if (rc == TEM_OK && !consumed) {
+        tem_set_error("tem_conv3d_fwd_gscaled: the launch did not take the z-reuse kernel (alignment of y / ref?)");
+        return TEM_EINVAL;
+    }
+    return rc;
+}
+
 extern "C" int tem_conv3d_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                         int use_mfma) {
     if (use_mfma != 2 && use_mfma != 5) return 0;

@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                                                           int64_t g_ld, float* __restrict__ part,
                                                           float* __restrict__ dbpart, int N, int D, int H, int W,
                                                           int Cin, int Cout, int T, int nY, int nX, int zsegs,
-                                                          int S, int ncz) {
+                                                          int S, int ncz, unsigned* __restrict__ gmax) {
     constexpr int NT = 27, NRG = 9, KW = 3;
     constexpr int KS2 = (NCO == 1) ? 2 : 1;
     constexpr int GC = 32 * NCO;
@@ -1088,6 +1088,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_db = (dbpart != nullptr) && (cit == 0);
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float gmx = 0.f;   // largest |g| this thread staged (gmax != nullptr: tem_conv3d_wgrad_gmax)
 
     // The accumulators live across column segments: a workgroup writes ONE partial slab however many columns it
     // walks (a slab is 8 % of a column's own traffic, and the merge kernel reads every slab back).  The pipeline
@@ -1236,6 +1237,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                 }
                 dbacc[c] += a[c] + b[c];
             }
+            if (gmax) {   // grid-uniform; two v_max3 per plane
+                gmx = __builtin_fmaxf(gmx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[0]), __builtin_fabsf(a[1])),
+                                                           __builtin_fmaxf(__builtin_fabsf(a[2]), __builtin_fabsf(a[3]))));
+                gmx = __builtin_fmaxf(gmx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(b[0]), __builtin_fabsf(b[1])),
+                                                           __builtin_fmaxf(__builtin_fabsf(b[2]), __builtin_fabsf(b[3]))));
+            }
         }
         // ---- loads for the next pending set: x plane t+3 (planes za-1 .. zb), g plane t+2 (za .. zb-1) ----
         {
@@ -1263,6 +1270,13 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
     }
     }  // column segments
 
+    // ---- largest |g|: the bit patterns of non-negative floats order like unsigned integers, and an integer max is
+    // exact and order-independent (deterministic); NaN / inf propagate as the largest patterns ----
+    if (gmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmx = __builtin_fmaxf(gmx, __shfl_xor(gmx, o, 64));
+        if (lane == 0) atomicMax(gmax, __builtin_bit_cast(unsigned, gmx));
+    }
     // ---- bias-gradient partial of this workgroup ----
     if (do_db) {
         float* red = reinterpret_cast<float*>(ldsb);  // [32][GC]
@@ -1431,6 +1445,13 @@ static void launch_wb(const float* x, int64_t x_ld, const float* scale, const fl
     launch_wb_t<KD, KH, KW, NCO, KS2, 2>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s);
 }
 
+// tem_conv3d_wgrad_gmax (conv.hip) parks its output pointer here around its call into tem_conv_wgrad_bf16x3: one more
+// positional argument would have to thread through four internal signatures for the one kernel that honours it
+thread_local unsigned* tem_wgrad_gmax_target = nullptr;
+int tem_conv_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    return Cin % 32 == 0 && Cout % 32 == 0 && zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw).use;
+}
+
 int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                           int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
                           int Cin, int Cout, int kd, int kh, int kw, int sd_layout, int h16, const float* w_sd,
@@ -1448,6 +1469,8 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
         return TEM_EWS;
     }
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
+    unsigned* const gmax = tem_wgrad_gmax_target;   // set by tem_conv3d_wgrad_gmax for the duration of this call
+    TEM_REQUIRE(!gmax || (z.use && !h16), "tem_conv3d_wgrad_gmax: tem_conv3d_wgrad_gmax_ok() == 0 for this layer");
     if (z.use) {
         TEM_REQUIRE((int64_t)H * W * (x_ld > g_ld ? x_ld : g_ld) * 4 < (1ll << 31),
                     "tem_conv3d_wgrad(bf16x3): one z-plane of x / g must stay below 2 GiB (32-bit offsets inside a plane)");
@@ -1472,10 +1495,10 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
             }
             if (h16)
                 hipLaunchKernelGGL((k_conv_wgrad_zs<2, true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
-                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz);
+                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
             else
             hipLaunchKernelGGL((k_conv_wgrad_zs<2>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
-                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz);
+                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
         } else {
             constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS;
             static bool a1 = false;
@@ -1492,10 +1515,10 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
             }
             if (h16)
                 hipLaunchKernelGGL((k_conv_wgrad_zs<1, true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
-                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz);
+                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
             else
             hipLaunchKernelGGL((k_conv_wgrad_zs<1>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
-                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz);
+                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
         }
         if (norm_sums) {
             float* extra = zdb + tem_align_up((int64_t)z.S * Cout, 64);

@@ -74,6 +74,11 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
                           int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
                           int Cin, int Cout, int kd, int kh, int kw, int sd_layout, int h16, const float* w_sd,
                           const float* gamma, const float* beta, float* norm_sums, hipStream_t s);
+// largest |g| as a by-product of the z-sliding weight gradient (tem_conv3d_wgrad_gmax)
+extern thread_local unsigned* tem_wgrad_gmax_target;
+int tem_conv_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
+// prescale of the z-reuse kernel's input by a power of two derived from a device-side |max| (tem_conv3d_fwd_gscaled)
+extern thread_local const unsigned* tem_zr_in_amax;
 // wgrad_sums.hip: norm-backward sums from the weight gradient
 int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int64_t tem_wgrad_sums_ws_floats(int N, int D, int H, int Cin, int Cout);

@@ -475,6 +475,13 @@ int tem_fwd_ksplit(int64_t nblk, int nchunks) {
     int ks = 1;
     for (int d = 1; d <= nchunks; ++d)
         if (nchunks % d == 0 && d <= target) ks = d;
+    // "fwd_ksplit_chunks" = c > 0: no partial accumulates more than c chunks (27 c MFMA steps per accumulator).  The matrix
+    // core rounds each step's products into the fp32 accumulator; many steps in ONE accumulator cost accuracy that the
+    // split-K epilogue's fp32 adds do not -- only where split-K runs anyway (few workgroups).
+    const long long mc = tem_option(TEM_OPT_FWD_KSPLIT_CHUNKS);
+    if (mc > 0)
+        for (int d = ks; d <= nchunks; ++d)
+            if (nchunks % d == 0 && nchunks / d <= mc) { ks = d; break; }
     return ks;
 }
 

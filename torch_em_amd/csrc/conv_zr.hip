@@ -15,7 +15,7 @@
 //     weight fragments of a (ty, tx) column stay in registers for 12 products (was 2).  Measured: 34.6 cycles per MFMA in
 //     the tap phase against 34.0 for a bare MFMA stream -- the tap phase is matrix-pipe bound;
 //   * the MFMA operands are swapped (A = weights, B = activations), so a lane ends up with 16 channels of ONE voxel: the
-//     statistics are in-lane sums plus one transposing reduction per unit, the bias is the accumulators' initial value;
+//     statistics are in-lane sums plus one transposing reduction per unit;
 //   * the staging team is bound by INSTRUCTION ISSUE beside the partner's MFMAs (~6 cycles per plain VALU instruction,
 //     ~69 per packed-fp32 one, ~32 per ds_write_b64, ~370 per 16-byte-per-line global store): the split is 14 VALU
 //     instructions per 4 channels (v_cvt_pk_f16_f32, v_fma_mix{lo,hi}_f16; range guard = MODE.FP16_OVFL), this file is
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
-    int nY, int nX, float* __restrict__ stat, int nunits) {
+    int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax) {
     constexpr int TZ = 4, TY = 16, TX = 8;
     constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     constexpr int HV = HZ * HY * HX;             // 1080 halo voxels
@@ -191,6 +191,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const __amdgpu_buffer_rsrc_t rw = zr_rsrc(wp);
     const unsigned woff_lane = (unsigned)lane * 16u;
     const float act_floor = act == TEM_ACT_RELU ? 0.f : -__builtin_inff();
+    // in_amax (tem_conv3d_fwd_gscaled: a data gradient in the fp16 two-term layout): the input is an unnormalised
+    // gradient, so it is multiplied by the power of two that puts its largest magnitude into [2^14, 2^15) -- exact, inside
+    // fp16's range with 29 binades below the maximum before a hi term goes subnormal -- and the output by its inverse.
+    float psc = 1.f, pinv = 1.f;
+    if (in_amax) {
+        const int e = (int)((*in_amax >> 23) & 0xffu);                      // biased exponent of max |x| (0: all zeros)
+        const int k = e == 0 ? 0 : min(max(141 - e, -100), 100);            // amax * 2^k in [2^14, 2^15)
+        psc = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+        pinv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+    }
 
     floatx16 acc[TZ];
     floatx16 accl[SC ? TZ : 1];
@@ -199,29 +209,27 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     int ui = 0, ci = 0;
     ZrUnit cu = decode(0), eu = cu;
     bool epi_pending = false;
-    // bias: lane l keeps channel (l & 31) of the unit being computed; the epilogue of the PREVIOUS unit resets the
-    // accumulators to it (the accumulators start from the bias, nothing is added afterwards)
+    // bias: lane l keeps channel (l & 31) of the unit being computed.  It is added in the epilogue: accumulators that START
+    // from it measure worse -- the matrix core truncates each step's products against the larger accumulator, a one-sided
+    // error that a GroupNorm backward sums over all voxels (1.5e-3 on the first layer's bias gradient).
     float bv = (bias && my_units > 0) ? bias[cu.cot * 32 + v] : 0.f;
-    auto bias16 = [&](float* b16) {   // the 16 channels of this lane's accumulator registers: 8 (i >> 2) + 4 kh + (i & 3)
+    float bve = 0.f;   // ... of the unit whose accumulators wait for their epilogue
+    auto bias16 = [&](float* b16, float bsrc) {   // the 16 channels of this lane's accumulator registers: 8 (i >> 2) + 4 kh + (i & 3)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int c0 = 8 * (i >> 2) + (i & 3);
-            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), c0));
-            const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), c0 + 4));
+            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bsrc), c0));
+            const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bsrc), c0 + 4));
             b16[i] = kh ? hi : lo;
         }
     };
-    {
-        float b16[16];
-        bias16(b16);
 #pragma unroll
-        for (int z = 0; z < TZ; ++z)
+    for (int z = 0; z < TZ; ++z)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc[z][i] = b16[i];
-                if (SC) accl[SC ? z : 0][i] = 0.f;
-            }
-    }
+        for (int i = 0; i < 16; ++i) {
+            acc[z][i] = 0.f;
+            if (SC) accl[SC ? z : 0][i] = 0.f;
+        }
     unsigned wsoff = 0;
 
     if (team) __syncthreads();
@@ -246,6 +254,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                 if (scale) {
                     sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
                     sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
+                } else if (in_amax) {
+                    sc4 = make_float4(psc, psc, psc, psc);
                 }
                 // the halo origin may lie outside the tensor for border patches (only in-range voxels are dereferenced)
                 const float* xb = x + ((((int64_t)cu.n * D + (cu.z0 - 1)) * H + (cu.y0 - 1)) * W + (cu.x0 - 1)) * x_ld + ci * BCK;
@@ -307,7 +317,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
 #pragma unroll
                     for (int z = 0; z < TZ; ++z)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[z][i] = fmaf(accl[SC ? z : 0][i], 1.f / F16_LO_SCALE, acc[z][i]);
+                        for (int i = 0; i < 16; ++i) {
+                            if (in_amax) acc[z][i] = fmaf(accl[SC ? z : 0][i], pinv * (1.f / F16_LO_SCALE), acc[z][i] * pinv);
+                            else acc[z][i] = fmaf(accl[SC ? z : 0][i], 1.f / F16_LO_SCALE, acc[z][i]);
+                        }
+                }
+                if (bias) {   // launch-uniform
+                    float b16[16];
+                    bias16(b16, bve);
+#pragma unroll
+                    for (int z = 0; z < TZ; ++z)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[z][i] += b16[i];
                 }
                 ZR_STAMP(8);
                 float ssum[16], ssq[16];   // per-lane statistics partials (scalar fp32: packed fp32 waits for the matrix pipe)
@@ -437,15 +458,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                     dst[lane & 1] = (lane & 1) ? b1 : a1;
                 }
                 ZR_STAMP(10);
-                // the next unit of this team starts from ITS bias (bv already belongs to it: cu was decoded after the last
-                // tap phase); the accumulator registers were dead from their stores up to here
-                float b16[16];
-                bias16(b16);
+                // the next unit of this team starts from zero (the accumulator registers were dead from their stores up to here)
 #pragma unroll
                 for (int z = 0; z < TZ; ++z)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        acc[z][i] = b16[i];
+                        acc[z][i] = 0.f;
                         if (SC) accl[SC ? z : 0][i] = 0.f;
                     }
                 epi_pending = false;
@@ -607,6 +625,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                 ci = 0;
                 eu = cu;
                 epi_pending = true;
+                bve = bv;
                 bv = 0.f;
                 if (++ui < my_units) {
                     cu = decode(ui);
@@ -663,7 +682,7 @@ int64_t tem_conv_zr_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, i
 template <int NS, bool F16, int MODE>
 static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                       const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H, int W,
-                      int Cin, int Cout, int act, float* stat, hipStream_t s) {
+                      int Cin, int Cout, int act, float* stat, const unsigned* in_amax, hipStream_t s) {
     constexpr size_t ldsb = (size_t)2 * NS * 1080 * 32 + 4 * 32 * 144;   // two tiles + the epilogue's transpose scratch
     static_assert(ldsb <= 160 * 1024, "LDS budget");
     auto kern = &k_conv_zr<NS, F16, MODE>;
@@ -680,8 +699,12 @@ static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float
     int64_t grid = (g.nunits + 1) / 2;
     if (grid > ncu) grid = ncu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp),
-                       bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits);
+                       bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits, in_amax);
 }
+
+// tem_conv3d_fwd_gscaled (conv.hip) parks the device pointer of max |input| here around its call; the launch that honours
+// it clears it (so the caller can tell that the prescale really happened)
+thread_local const unsigned* tem_zr_in_amax = nullptr;
 
 // -> 1 launched, 0 shape not taken, -1 error (statistics sized for this kernel but the launch cannot take it)
 int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp, const float* bias,
@@ -703,12 +726,20 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
 #define ZRGO(NS, F16)                                                                                                         \
     do {                                                                                                                      \
         if (stat)                                                                                                             \
-            zr_launch<NS, F16, 1>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, s); \
+            zr_launch<NS, F16, 1>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
         else if (ref)                                                                                                         \
-            zr_launch<NS, F16, 2>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, s); \
+            zr_launch<NS, F16, 2>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
         else                                                                                                                  \
-            zr_launch<NS, F16, 0>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, s); \
+            zr_launch<NS, F16, 0>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
     } while (0)
+    const unsigned* in_amax = tem_zr_in_amax;
+    if (in_amax) {
+        if (nsplit != 4 || bias || scale || stat) {
+            tem_set_error("tem_conv3d_fwd_gscaled: fp16 two-term layout, no bias / norm / statistics");
+            return -1;
+        }
+        tem_zr_in_amax = nullptr;   // consumed
+    }
     if (nsplit == 5) ZRGO(1, true);
     else if (nsplit == 4) ZRGO(2, true);
     else ZRGO(2, false);

@@ -309,6 +309,62 @@ def _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sum
     return sums
 
 
+def conv_wgrad_gmax_ok(x, k, cin, cout, mfma) -> bool:
+    N, D, H, W, _, _ = _act5(x)
+    return bool(_lib.load().tem_conv3d_wgrad_gmax_ok(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
+
+
+def conv_wgrad_gmax(x, g, k, cin, cout, dw_out, db_out, gmax, scale=None, shift=None, mfma=2, sums_from=None):
+    """conv_wgrad that also leaves the bit pattern of max |g| in `gmax` (int32[1], cleared by the caller) -- the prescale
+    of the fp16 two-term data gradient (conv_fwd_gscaled).  sums_from as in conv_wgrad -> sums[N, cin, 2] or None."""
+    _req_cuda(x, g, dw_out, gmax)
+    N, D, H, W, C, x_ld = _act5(x)
+    g_ld = _act5(g)[5]
+    lib = _lib.load()
+    nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma))
+    ws = _workspace(nws, x.device)
+    w = gamma = beta = sums = None
+    if sums_from is not None:
+        w, gamma, beta = sums_from
+        w = w.detach()
+        sums = torch.empty((N, cin, 2), dtype=torch.float32, device=x.device)
+    kind = _wgrad_tag(mfma, k, cout) if PROFILER is not None else None
+    ev0 = _prof_begin(x, kind)
+    _lib.check(lib.tem_conv3d_wgrad_gmax(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w), _p(gamma), _p(beta),
+                                         _p(dw_out), _p(db_out), _p(sums), _p(gmax), _p(ws), nws, N, D, H, W, cin, cout,
+                                         k[0], k[1], k[2], int(mfma), _stream(x)), "tem_conv3d_wgrad_gmax")
+    if ev0 is not None:
+        _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
+    return sums
+
+
+def conv_fwd_gscaled(x, w_packed, y, k, cin, cout, amax, ref=None):
+    """Data gradient with fp32-class products (tem_conv3d_fwd_gscaled): x an unnormalised gradient, w_packed =
+    pack_weights(w, transpose=True, mfma=4), amax = int32[1] holding the bit pattern of max |x| (conv_wgrad_gmax)."""
+    _req_cuda(x, w_packed, y, amax)
+    N, D, H, W, C, x_ld = _act5(x)
+    Ny, Dy, Hy, Wy, Cy, y_ld = _act5(y)
+    if C != cin or Cy != cout or (N, D, H, W) != (Ny, Dy, Hy, Wy):
+        raise ValueError(f"conv_fwd_gscaled: shape mismatch x{tuple(x.shape)} y{tuple(y.shape)} cin={cin} cout={cout}")
+    ref_ld = _act5(ref)[5] if ref is not None else 0
+    lib = _lib.load()
+    nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 1)
+    ws = _workspace(nws, x.device) if nws else None
+    kind = _fwd_tag(4, k, cout, True) if PROFILER is not None else None
+    ev0 = _prof_begin(x, kind)
+    _lib.check(lib.tem_conv3d_fwd_gscaled(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(amax), _p(ws), nws,
+                                          N, D, H, W, cin, cout, k[0], k[1], k[2], _stream(x)), "tem_conv3d_fwd_gscaled")
+    if ev0 is not None:
+        _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
+    return y
+
+
+def conv_fwd_family(x, k, cin, cout, mfma) -> int:
+    """tem_conv3d_fwd_kernel: 0 patch / other kernels, 1 / 2 ping-pong teams, 3 z-reuse teams"""
+    N, D, H, W, _, _ = _act5(x)
+    return int(_lib.load().tem_conv3d_fwd_kernel(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
+
+
 def _conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, mfma=False):
     """dw_out: flat [ntaps*cin*cout] in the reference's [Cout,Cin,kd,kh,kw] order; db_out: [cout]."""
     _req_cuda(x, g, dw_out)
