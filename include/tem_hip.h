@@ -342,6 +342,23 @@ int tem_dice_grad(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv,
                   float* gp, int64_t g_sn, int64_t g_sc, int64_t g_sv,
                   int N, int C, int64_t V, tem_stream_t stream);
 
+/* The logits / BCE members of the Dice family (reference loss/dice.py:136-253: DiceLossWithLogits, BCEDiceLoss,
+ * BCEDiceLossWithLogits) on the same kernels.  flags: TEM_DICE_LOGITS -- p holds logits, the Dice terms use sigmoid(p);
+ * TEM_DICE_BCE -- sums gets a 4th column per channel with the summed binary cross entropy (F.binary_cross_entropy's log
+ * clamp at -100; with TEM_DICE_LOGITS F.binary_cross_entropy_with_logits).  tem_dice_finalize2 reads sums with ncol
+ * columns; tem_dice_grad2 returns gout * (w_dice * dDice/dp + w_bce * dBCEsum/dp) (w_bce = beta / element count). */
+#define TEM_DICE_LOGITS 1
+#define TEM_DICE_BCE 2
+int tem_dice_sums2(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn, int64_t t_sc,
+                   int64_t t_sv, int N, int C, int64_t V, double* sums, void* ws, int64_t ws_bytes, int flags,
+                   tem_stream_t stream);
+int tem_dice_finalize2(const double* sums, int ncol, int C, double eps, int channelwise, int invert, int reduce,
+                       float* out, float* ca, float* cb, tem_stream_t stream);
+int tem_dice_grad2(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn, int64_t t_sc,
+                   int64_t t_sv, const float* ca, const float* cb, const float* gout, int gout_per_channel, float* gp,
+                   int64_t g_sn, int64_t g_sc, int64_t g_sv, int N, int C, int64_t V, int flags, float w_dice,
+                   float w_bce, tem_stream_t stream);
+
 /* ---- optimizer -------------------------------------------------------------
  * torch.optim.AdamW step as configured by default_segmentation_trainer
  * (segmentation.py:543): decoupled weight decay, bias correction, eps outside

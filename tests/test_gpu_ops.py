@@ -633,6 +633,40 @@ def test_layout_roundtrip_and_standardize():
     assert rel_err(s, exp) < 1e-5
 
 
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_dice_family_against_reference_golden(layout):
+    """DiceLossWithLogits, BCEDiceLoss, BCEDiceLossWithLogits (reference loss/dice.py:136-253) against values and input
+    gradients the REFERENCE produced (tests/golden/gen_golden_losses.py -> g5b_dice_variants.npz), incl. saturated logits
+    (+-40) and the log(0) clamp of binary_cross_entropy."""
+    from torch_em_amd.loss import BCEDiceLoss, BCEDiceLossWithLogits, DiceLossWithLogits
+    gd = np.load(os.path.join(GOLDEN, "g5b_dice_variants.npz"))
+    target = torch.from_numpy(gd["target"]).to(DEV)
+    cases = {
+        "dwl_default": (DiceLossWithLogits(), "logits"),
+        "dwl_mean": (DiceLossWithLogits(reduce_channel="mean"), "logits"),
+        "dwl_flat": (DiceLossWithLogits(channelwise=False), "logits"),
+        "bce_default": (BCEDiceLoss(), "probs"),
+        "bce_weighted": (BCEDiceLoss(alpha=0.7, beta=1.3), "probs"),
+        "bce_flat": (BCEDiceLoss(alpha=0.5, beta=2.0, channelwise=False), "probs"),
+        "bcel_default": (BCEDiceLossWithLogits(), "logits"),
+        "bcel_weighted": (BCEDiceLossWithLogits(alpha=1.5, beta=0.25, channelwise=False), "logits"),
+    }
+    for name, (loss, key) in cases.items():
+        x = torch.from_numpy(gd[key]).to(DEV)
+        if layout == "channels_last":
+            x = x.contiguous(memory_format=torch.channels_last_3d)
+        x.requires_grad_(True)
+        val = loss(x, target)
+        val.backward()
+        ref_loss, ref_grad = float(gd[f"{name}.loss"]), torch.from_numpy(gd[f"{name}.grad"])
+        assert abs(float(val) - ref_loss) < 3e-6 * max(1.0, abs(ref_loss)), (name, float(val), ref_loss)
+        # the saturated entries of `probs` (p = 0 / 1) have a gradient of +-1e12 / count in the reference: relative check
+        assert rel_err(x.grad.cpu(), ref_grad) < 5e-6, (name, rel_err(x.grad.cpu(), ref_grad))
+    assert DiceLossWithLogits(reduce_channel="min").init_kwargs == {"channelwise": True, "eps": 1e-7, "reduce_channel": "min"}
+    with pytest.raises(ValueError, match="Unsupported channel reduction"):
+        DiceLossWithLogits(reduce_channel="median")
+
+
 def test_dice_against_reference_golden():
     from torch_em_amd.loss import ApplyAndRemoveMask, DiceLoss, LossWrapper, dice_score
     gd = dict(np.load(os.path.join(GOLDEN, "g5_dice.npz")))

@@ -504,3 +504,50 @@ def test_mixed_precision_trainer_against_reference_autocast_run(tmp_path):
     assert np.allclose(log["metric"], g["fp32_val_metric"], rtol=3e-2)
     # ... and it is NOT the fp32 path: the operands really are rounded
     assert max(abs(a - b) for a, b in zip(log["loss"], g["fp32_train_loss"])) > 1e-5
+
+
+def test_from_checkpoint_restores_the_device_pre_pass(tmp_path):
+    """The reference keeps raw / label transforms inside its pickled datasets, so they survive
+    DefaultTrainer.from_checkpoint (trainer/default_trainer.py:288-330).  Here they are trainer arguments that run on the
+    device: the checkpoint has to carry them, and a trainer rebuilt from it must train on the same standardised inputs and
+    generated targets -- or refuse when one of them could not be stored."""
+    import functools
+    import torch_em_amd
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.trainer import DefaultTrainer
+    from torch_em_amd.transform.label import BatchTargets, BoundaryTransform
+    from torch_em_amd.transform.raw import standardize
+    g = torch.Generator().manual_seed(3)
+    raws = torch.rand(4, 1, 16, 16, 16, generator=g) * 200.0 + 50.0                    # un-standardised raw data
+    labels = torch.randint(0, 4, (4, 1, 16, 16, 16), generator=g).float()              # instance ids
+    ds = torch.utils.data.TensorDataset(raws, labels)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False)
+    torch.manual_seed(0)
+    model = UNet3d(1, 2, depth=2, initial_features=4)
+    raw_t = functools.partial(standardize, per_sample=True)
+    tgt_t = BatchTargets(BoundaryTransform(add_binary_target=True))
+    trainer = torch_em_amd.default_segmentation_trainer("pre", model, loader, loader, device=DEV, logger=None,
+                                                        save_root=str(tmp_path), raw_transform=raw_t, target_transform=tgt_t)
+    trainer.fit(iterations=2)
+    init = torch.load(os.path.join(trainer.checkpoint_folder, "latest.pt"), weights_only=False)["init"]
+    assert init["unpicklable_transforms"] == [] and init["prefetch"] is True
+    back = DefaultTrainer.from_checkpoint(trainer.checkpoint_folder, name="latest", device=DEV)
+    assert isinstance(back.raw_transform, functools.partial) and back.raw_transform.func is standardize
+    assert back.raw_transform.keywords == {"per_sample": True}
+    assert isinstance(back.target_transform, BatchTargets) and back.augmentation is None and back.prefetch is True
+    # the same two further steps from the same state: identical loss trajectories (the pre-pass really runs)
+    back.fit(iterations=2)
+    trainer.fit(iterations=2)
+    for a, b in zip(back.model.state_dict().values(), trainer.model.state_dict().values()):
+        assert torch.equal(a, b)
+    # a lambda cannot travel: warning at save time, RuntimeError at from_checkpoint unless it is passed again
+    model2 = UNet3d(1, 2, depth=2, initial_features=4)
+    with pytest.warns(UserWarning, match="cannot be pickled"):
+        t2 = torch_em_amd.default_segmentation_trainer("pre2", model2, loader, loader, device=DEV, logger=None,
+                                                       save_root=str(tmp_path), raw_transform=lambda x: x / 255.0,
+                                                       target_transform=tgt_t)
+        t2.fit(iterations=1)
+    with pytest.raises(RuntimeError, match="raw_transform"):
+        DefaultTrainer.from_checkpoint(t2.checkpoint_folder, name="latest", device=DEV)
+    t3 = DefaultTrainer.from_checkpoint(t2.checkpoint_folder, name="latest", device=DEV, raw_transform=raw_t)
+    assert t3.raw_transform is raw_t and isinstance(t3.target_transform, BatchTargets)

@@ -137,27 +137,55 @@ def test_unet3d_mfma_sizes_match_oracle(norm):
 
 def test_unet3d_benchmark_widths_depth4_match_fp64_oracle():
     """The benchmark network itself -- UNet3d(1, 2, initial_features=32, depth=4): 32 ... 512 features, every kernel family
-    of cfg 2 incl. the split-K convolutions of the 8^3 / 4^3 levels -- on one 64^3 volume against the float64 oracle.
-    Measured (TEM_TEST_VERBOSE=1): forward / loss as everywhere; gradients at the 8^3 / 4^3 levels 5.3e-3 ... 7.4e-3 from
-    float64 in relative L2 where the fp32 reference path has 1.5e-3 and this library's exact-fp32 build
-    (TEM_PRECISION=fp32) 2.2e-3: eight levels of bf16x3 data-gradient convolutions (2^-17 per product) in front of instance
-    statistics over 64 voxels.  Running the <= 8^3 levels' backward with fp32-class products does not change it (the error
-    arrives with the incoming gradient), doing so for all levels costs 2.5 ms/step; the bound for this case is therefore
-    6x / 5x the reference path's own error (still <= 1e-2 per tensor), and single entries of the 4^3 level may move by more
-    than 5 % (one flipped ReLU mask entry is 1/64 of a sum) as long as they stay isolated."""
+    of cfg 2 incl. the split-K convolutions of the 8^3 / 4^3 levels -- on 64^3 volumes against the float64 oracle, with
+    the STANDARD bounds of _check_against_fp64 (whole gradient within 2x, every tensor within 4x the fp32 reference
+    path's own error) applied to the MEDIAN over four seeds.
+    Why a median: at these widths the gradient error against float64 is decided by a handful of near-tie decisions (ReLU
+    masks / pooling arg-maxes of the 4^3 and 8^3 levels: one flipped entry is 1/64 of every sum it enters), so it scatters
+    by 3-10x from seed to seed for ANY arithmetic that differs from float64 at the 1e-7 level -- the reference's fp32 CPU
+    path included.  Measured over six seeds (profiles/r03_depth4_error_*.txt, scripts/depth4_error_survey.py), global
+    relative L2 error: fp32 reference path 1.4e-3 ... 3.9e-3 (median 1.8e-3), this library (default arithmetic) 1.3e-3 ...
+    3.0e-3 with one 1.5e-2 outlier (median 1.9e-3), its exact-fp32 build 2.3e-3 ... 6.2e-3.  Round 2 looked at ONE seed
+    (4.5e-3 vs 1.3e-3), widened the bound to 6x / 5x and blamed the 16-bit backward products; fp32-class data gradients
+    (TEM_DGRAD16=1) leave that number unchanged."""
     from torch_em_amd.loss import DiceLoss
     from torch_em_amd.model import UNet3d
-    torch.manual_seed(0)
-    model = UNet3d(1, 2, depth=4, initial_features=32)
-    g = torch.Generator().manual_seed(6)
-    x = torch.randn(1, 1, 64, 64, 64, generator=g)
-    y = (torch.rand(1, 2, 64, 64, 64, generator=g) > 0.5).float()
-    case = (model, [2, 2, 2, 2], x, y, "InstanceNorm")
-    model.to(DEV)
-    pred = model(x.to(DEV))
-    loss = DiceLoss()(pred, y.to(DEV))
-    loss.backward()
-    _check_against_fp64(model, pred, loss, case, l2_factor=6.0, global_factor=5.0)
+    per_seed, per_tensor = [], {}
+    for seed in (0, 1, 2, 3):
+        torch.manual_seed(seed)
+        model = UNet3d(1, 2, depth=4, initial_features=32)
+        g = torch.Generator().manual_seed(100 + seed)
+        x = torch.randn(1, 1, 64, 64, 64, generator=g)
+        y = (torch.rand(1, 2, 64, 64, 64, generator=g) > 0.5).float()
+        case = (model, [2, 2, 2, 2], x, y, "InstanceNorm")
+        pred64, loss64, g64 = _oracle_case(*case, dtype=torch.float64)
+        _, _, g32 = _oracle_case(*case, dtype=torch.float32)
+        model.to(DEV)
+        pred = model(x.to(DEV))
+        loss = DiceLoss()(pred, y.to(DEV))
+        loss.backward()
+        assert rel_err(pred.detach().cpu(), pred64) < TOL and abs(float(loss) - float(loss64)) < TOL
+        gscale = max(float(v.abs().max()) for v in g64.values())
+        keys = [k for k, _ in model.named_parameters() if float(g64[k].abs().max()) >= 1e-4 * gscale]
+        hip = {k: p.grad.double().cpu().numpy() for k, p in model.named_parameters()}
+        cat = lambda d: np.concatenate([np.asarray(d[k], dtype=np.float64).ravel() for k in keys])  # noqa: E731
+        r_all = cat({k: g64[k].numpy() for k in keys})
+        e_h = float(np.linalg.norm(cat(hip) - r_all) / np.linalg.norm(r_all))
+        e_c = float(np.linalg.norm(cat({k: g32[k].numpy() for k in keys}) - r_all) / np.linalg.norm(r_all))
+        per_seed.append((e_h, e_c))
+        for k in keys:
+            r = g64[k].numpy().astype(np.float64)
+            per_tensor.setdefault(k, []).append((float(np.linalg.norm(hip[k] - r) / np.linalg.norm(r)),
+                                                 float(np.linalg.norm(g32[k].numpy() - r) / np.linalg.norm(r))))
+        print(f"seed {seed}: global gradient L2 rel err vs float64: hip {e_h:.2e}, fp32 reference path {e_c:.2e}")
+        assert e_h < 3e-2, (seed, e_h)              # a single seed may lose the near-tie lottery, but not by more than this
+        del model
+    med_h, med_c = float(np.median([a for a, _ in per_seed])), float(np.median([b for _, b in per_seed]))
+    print(f"median over seeds: hip {med_h:.2e}, fp32 reference path {med_c:.2e}")
+    assert med_h <= max(TOL, 2.0 * med_c), ("global L2 (median over seeds)", med_h, med_c)
+    for k, v in per_tensor.items():
+        mh, mc = float(np.median([a for a, _ in v])), float(np.median([b for _, b in v]))
+        assert mh <= min(1e-2, max(TOL, 4.0 * mc)), (k, "L2 (median over seeds)", mh, mc)
 
 
 def test_anisotropic_cfg3_factors_match_fp64_oracle():
@@ -264,7 +292,17 @@ def test_benchmark_config_full_size_properties():
         assert e < 5e-2, (k, e)
         num += float(np.sum((a - r) ** 2))
         den += float(np.sum(r ** 2))
-    assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
+    glob = (num / den) ** 0.5
+    # measured value on record (stdout with -s, and gpurun_out/ -> profiles/r03_fullsize_grad_error.json): the bound below
+    # is loose because both sides are fp32-class implementations of an ill-conditioned gradient (see the depth-4 test)
+    print(f"cfg 2 full size: global gradient L2 rel err vs the fp32 CPU oracle {glob:.3e}, loss {vals[0]:.7f} vs {float(lo):.7f}")
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "fullsize_grad_error.json"), "w") as f:
+            json.dump({"config": "UNet3d(1,2,initial_features=32,depth=4) 2x1x128^3 DiceLoss, default arithmetic",
+                       "global_grad_l2_rel_err_vs_fp32_cpu_oracle": glob, "loss_hip": vals[0], "loss_oracle": float(lo)}, f)
+    assert glob < 1e-2, glob
 
 
 def test_affinity_config_full_size_properties():

@@ -78,6 +78,11 @@ SIGNATURES = {
     "tem_dice_finalize": (c_int, [c_vp, c_int, c_double, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "tem_dice_grad": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int,
                               c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_vp]),
+    "tem_dice_sums2": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_vp, c_vp, c_i64,
+                               c_int, c_vp]),
+    "tem_dice_finalize2": (c_int, [c_vp, c_int, c_int, c_double, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "tem_dice_grad2": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_int,
+                               c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int, c_float, c_float, c_vp]),
     "tem_adamw_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_i64,
                                c_float, c_vp]),
     "tem_ema_update": (c_int, [c_vp, c_vp, c_i64, c_float, c_vp]),

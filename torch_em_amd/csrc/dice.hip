@@ -10,17 +10,24 @@
 extern "C" int64_t tem_dice_ws(int N, int64_t V, int C) {
     (void)N;
     (void)V;
-    return (int64_t)DICE_MAX_BLOCKS * C * 3 * (int64_t)sizeof(float);
+    return (int64_t)DICE_MAX_BLOCKS * C * 4 * (int64_t)sizeof(float);
 }
 
+// flags of the Dice family (reference loss/dice.py:136-253): TEM_DICE_LOGITS -- the prediction holds logits, the Dice
+// terms use sigmoid(x) (DiceLossWithLogits, BCEDiceLossWithLogits); TEM_DICE_BCE -- a fourth per-channel sum carries the
+// binary cross entropy (BCEDiceLoss: F.binary_cross_entropy with its log clamp at -100; with TEM_DICE_LOGITS:
+// F.binary_cross_entropy_with_logits = max(x, 0) - x t + log1p(exp(-|x|)))
+__device__ __forceinline__ float dice_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
 // thread -> (channel c, voxel sub-row r); CFAST: consecutive threads walk channels (NDHWC
-// prediction), else consecutive threads walk voxels (NCDHW prediction).
+// prediction), else consecutive threads walk voxels (NCDHW prediction).  NS sums per channel: 3, or 4 with the BCE term.
 template <bool CFAST>
 __global__ void k_dice_partial(const float* __restrict__ p, int64_t p_sn, int64_t p_sc, int64_t p_sv,
                                const float* __restrict__ t, int64_t t_sn, int64_t t_sc, int64_t t_sv,
                                const float* __restrict__ mask, int N, int C, int64_t V, int rows, int64_t vper,
-                               int nblk_per_n, float* __restrict__ part) {
-    extern __shared__ float sh[];  // [rows][C][3]
+                               int nblk_per_n, float* __restrict__ part, int flags) {
+    extern __shared__ float sh[];  // [rows][C][NS]
+    const int NS = (flags & TEM_DICE_BCE) ? 4 : 3;
     const int n = blockIdx.x / nblk_per_n, b = blockIdx.x % nblk_per_n;
     int c, r;
     if (CFAST) {
@@ -35,9 +42,19 @@ __global__ void k_dice_partial(const float* __restrict__ p, int64_t p_sn, int64_
     const float* pp = p + (int64_t)n * p_sn + (int64_t)c * p_sc;
     const float* tp = t + (int64_t)n * t_sn + (int64_t)c * t_sc;
     const float* mp = mask ? mask + (int64_t)n * t_sn + (int64_t)c * t_sc : nullptr;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int64_t v = v0 + r; v < v1; v += rows) {
         float pv = pp[v * p_sv], tv = tp[v * t_sv];
+        if (flags) {   // launch-uniform
+            const float xv = pv;
+            if (flags & TEM_DICE_LOGITS) pv = dice_sigmoid(xv);
+            if (flags & TEM_DICE_BCE) {
+                if (flags & TEM_DICE_LOGITS)
+                    s3 += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
+                else
+                    s3 -= tv * fmaxf(logf(pv), -100.f) + (1.f - tv) * fmaxf(logf(1.f - pv), -100.f);
+            }
+        }
         if (mp) {
             float m = mp[v * t_sv];
             pv *= m;
@@ -47,50 +64,57 @@ __global__ void k_dice_partial(const float* __restrict__ p, int64_t p_sn, int64_
         s1 = fmaf(pv, pv, s1);
         s2 = fmaf(tv, tv, s2);
     }
-    float* my = sh + ((int64_t)r * C + c) * 3;
+    float* my = sh + ((int64_t)r * C + c) * NS;
     my[0] = s0;
     my[1] = s1;
     my[2] = s2;
+    if (NS == 4) my[3] = s3;
     __syncthreads();
     if (r == 0) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         for (int rr = 0; rr < rows; ++rr) {
-            const float* o = sh + ((int64_t)rr * C + c) * 3;
+            const float* o = sh + ((int64_t)rr * C + c) * NS;
             a0 += o[0];
             a1 += o[1];
             a2 += o[2];
+            if (NS == 4) a3 += o[3];
         }
-        float* o = part + ((int64_t)blockIdx.x * C + c) * 3;
+        float* o = part + ((int64_t)blockIdx.x * C + c) * NS;
         o[0] = a0;
         o[1] = a1;
         o[2] = a2;
+        if (NS == 4) o[3] = a3;
     }
 }
 
 __global__ __launch_bounds__(256) void k_dice_reduce(const float* __restrict__ part, int nblk, int C,
-                                                     double* __restrict__ sums) {
+                                                     double* __restrict__ sums, int NS) {
     const int c = blockIdx.x;
-    double a[3] = {0.0, 0.0, 0.0};
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < nblk; b += 256) {
-        const float* o = part + ((int64_t)b * C + c) * 3;
+        const float* o = part + ((int64_t)b * C + c) * NS;
         a[0] += (double)o[0];
         a[1] += (double)o[1];
         a[2] += (double)o[2];
+        if (NS == 4) a[3] += (double)o[3];
     }
-    __shared__ double sh[3][4];
+    __shared__ double sh[4][4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         a[k] = tem_wave_sum_d(a[k]);
         if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = a[k];
     }
     __syncthreads();
-    if (threadIdx.x < 3) sums[c * 3 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+    if (threadIdx.x < NS) sums[c * NS + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
 
-extern "C" int tem_dice_sums(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
-                             int64_t t_sc, int64_t t_sv, const float* mask, int N, int C, int64_t V, double* sums,
-                             void* ws, int64_t ws_bytes, tem_stream_t stream) {
+static int dice_sums_impl(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
+                          int64_t t_sc, int64_t t_sv, const float* mask, int N, int C, int64_t V, double* sums,
+                          void* ws, int64_t ws_bytes, int flags, tem_stream_t stream) {
     TEM_REQUIRE(p && t && sums && ws, "tem_dice_sums: null pointer");
+    TEM_REQUIRE((flags & ~(TEM_DICE_LOGITS | TEM_DICE_BCE)) == 0 && (!(flags & TEM_DICE_BCE) || !mask),
+                "tem_dice_sums2: unknown flags, or the BCE term together with a mask");
+    const int NS = (flags & TEM_DICE_BCE) ? 4 : 3;
     TEM_REQUIRE(N > 0 && C > 0 && C <= 1024 && V > 0, "tem_dice_sums: bad shape (C=%d)", C);
     if (ws_bytes < tem_dice_ws(N, V, C)) {
         tem_set_error("tem_dice_sums: workspace too small");
@@ -108,18 +132,31 @@ extern "C" int tem_dice_sums(const float* p, int64_t p_sn, int64_t p_sc, int64_t
     if (nb > maxb) nb = maxb;
     int64_t vper = tem_cdiv(V, nb);
     int nblk = (int)nb * N;
-    size_t lds = (size_t)rows * C * 3 * sizeof(float);
+    size_t lds = (size_t)rows * C * NS * sizeof(float);
     float* part = (float*)ws;
     bool cfast = (p_sc == 1);
     if (cfast)
         hipLaunchKernelGGL((k_dice_partial<true>), dim3(nblk), dim3(threads), lds, (hipStream_t)stream, p, p_sn, p_sc,
-                           p_sv, t, t_sn, t_sc, t_sv, mask, N, C, V, rows, vper, (int)nb, part);
+                           p_sv, t, t_sn, t_sc, t_sv, mask, N, C, V, rows, vper, (int)nb, part, flags);
     else
         hipLaunchKernelGGL((k_dice_partial<false>), dim3(nblk), dim3(threads), lds, (hipStream_t)stream, p, p_sn, p_sc,
-                           p_sv, t, t_sn, t_sc, t_sv, mask, N, C, V, rows, vper, (int)nb, part);
-    hipLaunchKernelGGL(k_dice_reduce, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums);
+                           p_sv, t, t_sn, t_sc, t_sv, mask, N, C, V, rows, vper, (int)nb, part, flags);
+    hipLaunchKernelGGL(k_dice_reduce, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums, NS);
     TEM_CHECK_LAUNCH("tem_dice_sums");
     return TEM_OK;
+}
+
+extern "C" int tem_dice_sums(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
+                             int64_t t_sc, int64_t t_sv, const float* mask, int N, int C, int64_t V, double* sums,
+                             void* ws, int64_t ws_bytes, tem_stream_t stream) {
+    return dice_sums_impl(p, p_sn, p_sc, p_sv, t, t_sn, t_sc, t_sv, mask, N, C, V, sums, ws, ws_bytes, 0, stream);
+}
+
+// sums[C][3] as tem_dice_sums, or [C][4] with TEM_DICE_BCE (4th column: the sum of the per-element cross entropy)
+extern "C" int tem_dice_sums2(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
+                              int64_t t_sc, int64_t t_sv, int N, int C, int64_t V, double* sums, void* ws,
+                              int64_t ws_bytes, int flags, tem_stream_t stream) {
+    return dice_sums_impl(p, p_sn, p_sc, p_sv, t, t_sn, t_sc, t_sv, nullptr, N, C, V, sums, ws, ws_bytes, flags, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -129,14 +166,14 @@ extern "C" int tem_dice_sums(const float* p, int64_t p_sn, int64_t p_sc, int64_t
 //   d out_c / d p = ca_c * t + cb_c * p
 // ---------------------------------------------------------------------------
 __global__ void k_dice_finalize(const double* __restrict__ sums, int C, double eps, int channelwise, int invert,
-                                int reduce, float* __restrict__ out, float* __restrict__ ca, float* __restrict__ cb) {
+                                int reduce, float* __restrict__ out, float* __restrict__ ca, float* __restrict__ cb, int NS) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double sgn = invert ? -1.0 : 1.0;
     if (!channelwise) {
         double num = 0.0, den = 0.0;
         for (int c = 0; c < C; ++c) {
-            num += sums[c * 3];
-            den += sums[c * 3 + 1] + sums[c * 3 + 2];
+            num += sums[c * NS];
+            den += sums[c * NS + 1] + sums[c * NS + 2];
         }
         double cd = den < eps ? eps : den;
         double score = 2.0 * num / cd;
@@ -152,7 +189,7 @@ __global__ void k_dice_finalize(const double* __restrict__ sums, int C, double e
     int arg = 0;
     double best = 0.0;
     for (int c = 0; c < C; ++c) {
-        double num = sums[c * 3], den = sums[c * 3 + 1] + sums[c * 3 + 2];
+        double num = sums[c * NS], den = sums[c * NS + 1] + sums[c * NS + 2];
         double cd = den < eps ? eps : den;
         double score = 2.0 * num / cd;
         double val = invert ? 1.0 - score : score;
@@ -183,14 +220,24 @@ __global__ void k_dice_finalize(const double* __restrict__ sums, int C, double e
     }
 }
 
-extern "C" int tem_dice_finalize(const double* sums, int C, double eps, int channelwise, int invert, int reduce,
-                                 float* out, float* ca, float* cb, tem_stream_t stream) {
+static int dice_finalize_impl(const double* sums, int C, double eps, int channelwise, int invert, int reduce, float* out,
+                              float* ca, float* cb, int NS, tem_stream_t stream) {
     TEM_REQUIRE(sums && out && ca && cb && C > 0, "tem_dice_finalize: bad arguments");
     TEM_REQUIRE(reduce >= 0 && reduce <= 4, "tem_dice_finalize: Unsupported channel reduction %d", reduce);
     hipLaunchKernelGGL(k_dice_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, C, eps, channelwise, invert,
-                       reduce, out, ca, cb);
+                       reduce, out, ca, cb, NS);
     TEM_CHECK_LAUNCH("tem_dice_finalize");
     return TEM_OK;
+}
+extern "C" int tem_dice_finalize(const double* sums, int C, double eps, int channelwise, int invert, int reduce,
+                                 float* out, float* ca, float* cb, tem_stream_t stream) {
+    return dice_finalize_impl(sums, C, eps, channelwise, invert, reduce, out, ca, cb, 3, stream);
+}
+// tem_dice_finalize on sums with `ncol` (3 or 4) columns per channel (tem_dice_sums2)
+extern "C" int tem_dice_finalize2(const double* sums, int ncol, int C, double eps, int channelwise, int invert, int reduce,
+                                  float* out, float* ca, float* cb, tem_stream_t stream) {
+    TEM_REQUIRE(ncol == 3 || ncol == 4, "tem_dice_finalize2: ncol must be 3 or 4");
+    return dice_finalize_impl(sums, C, eps, channelwise, invert, reduce, out, ca, cb, ncol, stream);
 }
 
 // gp = gout * (ca*t + cb*p) * mask   (p, t masked first)
@@ -201,7 +248,7 @@ __global__ __launch_bounds__(256) void k_dice_grad(const float* __restrict__ p, 
                                                    const float* __restrict__ ca, const float* __restrict__ cb,
                                                    const float* __restrict__ gout, int gout_per_channel,
                                                    float* __restrict__ gp, int64_t g_sn, int64_t g_sc, int64_t g_sv,
-                                                   int C, int64_t V) {
+                                                   int C, int64_t V, int flags, float w_dice, float w_bce) {
     const int n = blockIdx.y;
     const int64_t items = V * C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
@@ -223,22 +270,49 @@ __global__ __launch_bounds__(256) void k_dice_grad(const float* __restrict__ p, 
             tv *= m;
         }
         float go = gout ? gout[gout_per_channel ? c : 0] : 1.f;
+        if (flags) {   // launch-uniform: the logits / BCE members of the family (no mask there)
+            const float xv = pv;
+            if (flags & TEM_DICE_LOGITS) pv = dice_sigmoid(xv);
+            float d = w_dice * (ca[c] * tv + cb[c] * pv);
+            if (flags & TEM_DICE_LOGITS) d *= pv * (1.f - pv);                       // d sigmoid / d x
+            if (flags & TEM_DICE_BCE)   // aten binary_cross_entropy_backward: (p - t) / max(p (1 - p), 1e-12); with logits: sigmoid(x) - t
+                d += w_bce * ((flags & TEM_DICE_LOGITS) ? (pv - tv) : (pv - tv) / fmaxf(pv * (1.f - pv), 1e-12f));
+            gp[(int64_t)n * g_sn + (int64_t)c * g_sc + v * g_sv] = go * d;
+            continue;
+        }
         gp[(int64_t)n * g_sn + (int64_t)c * g_sc + v * g_sv] = go * (ca[c] * tv + cb[c] * pv) * m;
     }
 }
 
+static int dice_grad_impl(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
+                          int64_t t_sc, int64_t t_sv, const float* mask, const float* ca, const float* cb,
+                          const float* gout, int gout_per_channel, float* gp, int64_t g_sn, int64_t g_sc,
+                          int64_t g_sv, int N, int C, int64_t V, int flags, float w_dice, float w_bce, tem_stream_t stream) {
+    TEM_REQUIRE(p && t && ca && cb && gp && N > 0 && C > 0 && V > 0, "tem_dice_grad: bad arguments");
+    TEM_REQUIRE((flags & ~(TEM_DICE_LOGITS | TEM_DICE_BCE)) == 0 && (!flags || !mask), "tem_dice_grad2: unknown flags, or flags with a mask");
+    dim3 grid(tem_grid_1d(V * C, 256, 2048), N);
+    if (p_sc == 1)
+        hipLaunchKernelGGL((k_dice_grad<true>), grid, dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
+                           t_sc, t_sv, mask, ca, cb, gout, gout_per_channel, gp, g_sn, g_sc, g_sv, C, V, flags, w_dice, w_bce);
+    else
+        hipLaunchKernelGGL((k_dice_grad<false>), grid, dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
+                           t_sc, t_sv, mask, ca, cb, gout, gout_per_channel, gp, g_sn, g_sc, g_sv, C, V, flags, w_dice, w_bce);
+    TEM_CHECK_LAUNCH("tem_dice_grad");
+    return TEM_OK;
+}
 extern "C" int tem_dice_grad(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
                              int64_t t_sc, int64_t t_sv, const float* mask, const float* ca, const float* cb,
                              const float* gout, int gout_per_channel, float* gp, int64_t g_sn, int64_t g_sc,
                              int64_t g_sv, int N, int C, int64_t V, tem_stream_t stream) {
-    TEM_REQUIRE(p && t && ca && cb && gp && N > 0 && C > 0 && V > 0, "tem_dice_grad: bad arguments");
-    dim3 grid(tem_grid_1d(V * C, 256, 2048), N);
-    if (p_sc == 1)
-        hipLaunchKernelGGL((k_dice_grad<true>), grid, dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
-                           t_sc, t_sv, mask, ca, cb, gout, gout_per_channel, gp, g_sn, g_sc, g_sv, C, V);
-    else
-        hipLaunchKernelGGL((k_dice_grad<false>), grid, dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
-                           t_sc, t_sv, mask, ca, cb, gout, gout_per_channel, gp, g_sn, g_sc, g_sv, C, V);
-    TEM_CHECK_LAUNCH("tem_dice_grad");
-    return TEM_OK;
+    return dice_grad_impl(p, p_sn, p_sc, p_sv, t, t_sn, t_sc, t_sv, mask, ca, cb, gout, gout_per_channel, gp, g_sn, g_sc,
+                          g_sv, N, C, V, 0, 1.f, 0.f, stream);
+}
+// gp = gout * (w_dice * dDice/dx + w_bce * dBCE_sum/dx): the gradient of alpha * dice + beta * mean-BCE w.r.t. the
+// prediction (probabilities, or logits with TEM_DICE_LOGITS), w_dice = alpha, w_bce = beta / (N C V)
+extern "C" int tem_dice_grad2(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
+                              int64_t t_sc, int64_t t_sv, const float* ca, const float* cb, const float* gout,
+                              int gout_per_channel, float* gp, int64_t g_sn, int64_t g_sc, int64_t g_sv, int N, int C,
+                              int64_t V, int flags, float w_dice, float w_bce, tem_stream_t stream) {
+    return dice_grad_impl(p, p_sn, p_sc, p_sv, t, t_sn, t_sc, t_sv, nullptr, ca, cb, gout, gout_per_channel, gp, g_sn,
+                          g_sc, g_sv, N, C, V, flags, w_dice, w_bce, stream);
 }

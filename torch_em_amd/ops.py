@@ -622,6 +622,59 @@ def dice_sums(p, t, mask=None) -> torch.Tensor:
 
 
 REDUCE = {None: 0, "sum": 1, "mean": 2, "max": 3, "min": 4}
+DICE_LOGITS, DICE_BCE = 1, 2
+
+
+def dice_sums2(p, t, flags: int):
+    """dice_sums for the logits / BCE members of the family (tem_dice_sums2): double[C, 3] or, with DICE_BCE, [C, 4]
+    (4th column: summed binary cross entropy of the channel)."""
+    _req_cuda(p, t)
+    ps = _ncv_strides(p)
+    if ps is None:
+        p = p.contiguous()
+        ps = _ncv_strides(p)
+    ts = _ncv_strides(t)
+    if ts is None:
+        t = t.contiguous()
+        ts = _ncv_strides(t)
+    N, C, V = ps[3:]
+    ncol = 4 if flags & DICE_BCE else 3
+    sums = torch.empty((C, ncol), dtype=torch.float64, device=p.device)
+    lib = _lib.load()
+    nws = lib.tem_dice_ws(N, V, C)
+    ws = _workspace(nws, p.device)
+    _lib.check(lib.tem_dice_sums2(_p(p), ps[0], ps[1], ps[2], _p(t), ts[0], ts[1], ts[2], N, C, V, _p(sums), _p(ws), nws,
+                                  int(flags), _stream(p)), "tem_dice_sums2")
+    return sums, p, t
+
+
+def dice_finalize2(sums, eps, channelwise, invert, reduce):
+    C, ncol = sums.shape
+    dev = sums.device
+    n_out = C if (channelwise and reduce is None) else 1
+    out = torch.empty((n_out,), dtype=torch.float32, device=dev)
+    ca = torch.empty((C,), dtype=torch.float32, device=dev)
+    cb = torch.empty((C,), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().tem_dice_finalize2(_p(sums), ncol, C, float(eps), int(channelwise), int(invert), REDUCE[reduce],
+                                              _p(out), _p(ca), _p(cb), _stream(sums)), "tem_dice_finalize2")
+    return out, ca, cb
+
+
+def dice_grad2(p, t, ca, cb, gout, gout_per_channel, channels_last: bool, flags: int, w_dice: float, w_bce: float):
+    ps = _ncv_strides(p)
+    ts = _ncv_strides(t)
+    N, C, V = ps[3:]
+    if channels_last:
+        gp_phys = torch.empty((N,) + tuple(p.shape[2:]) + (C,), dtype=torch.float32, device=p.device)
+        gp = gp_phys.permute(0, gp_phys.dim() - 1, *range(1, gp_phys.dim() - 1))
+        gs = (V * C, 1, C)
+    else:
+        gp = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+        gs = (C * V, V, 1)
+    _lib.check(_lib.load().tem_dice_grad2(_p(p), ps[0], ps[1], ps[2], _p(t), ts[0], ts[1], ts[2], _p(ca), _p(cb), _p(gout),
+                                          int(gout_per_channel), _p(gp), gs[0], gs[1], gs[2], N, C, V, int(flags),
+                                          float(w_dice), float(w_bce), _stream(p)), "tem_dice_grad2")
+    return gp
 
 
 def dice_finalize(sums, eps, channelwise, invert, reduce):

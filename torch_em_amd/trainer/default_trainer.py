@@ -60,6 +60,9 @@ def _init_kwargs(obj):
     return {}
 
 
+_FROM_CHECKPOINT = object()   # sentinel: "take it from the checkpoint"
+
+
 class _NullProgress:
     total = 0
 
@@ -149,7 +152,27 @@ class DefaultTrainer:
             "val_dataset": getattr(self.val_loader, "dataset", None),
             "train_loader_kwargs": {"batch_size": getattr(self.train_loader, "batch_size", None)},
             "val_loader_kwargs": {"batch_size": getattr(self.val_loader, "batch_size", None)},
+            # the on-device pre-pass (standardisation, target generation, augmentation) replaces transforms that the
+            # reference keeps inside its pickled datasets -- so it has to survive a resume the same way
+            **self._device_transforms_record(),
         }
+
+    def _device_transforms_record(self):
+        import pickle
+        rec, lost = {"prefetch": self.prefetch}, []
+        for key in ("raw_transform", "target_transform", "augmentation"):
+            obj = getattr(self, key)
+            try:
+                pickle.dumps(obj)
+            except Exception:  # a lambda / local function: cannot travel in the checkpoint
+                obj = None
+                lost.append(key)
+            rec[key] = obj
+        rec["unpicklable_transforms"] = lost
+        if lost:
+            warnings.warn(f"DefaultTrainer: {lost} cannot be pickled into the checkpoint (lambda / local function?); "
+                          "from_checkpoint() will ask for them again")
+        return rec
 
     def _initialize(self, iterations, load_from_checkpoint, epochs=None):
         for attr in ("train_loader", "val_loader", "model", "loss", "optimizer", "metric", "device"):
@@ -228,11 +251,20 @@ class DefaultTrainer:
         return save_dict
 
     @classmethod
-    def from_checkpoint(cls, checkpoint_folder, name="best", device=None, train_loader=None, val_loader=None):
+    def from_checkpoint(cls, checkpoint_folder, name="best", device=None, train_loader=None, val_loader=None,
+                        raw_transform=_FROM_CHECKPOINT, target_transform=_FROM_CHECKPOINT, augmentation=_FROM_CHECKPOINT):
         """Rebuild a trainer from `<checkpoint_folder>/<name>.pt` (reference :288-330).  Loaders are rebuilt
-        from the pickled datasets unless given."""
+        from the pickled datasets unless given.  The on-device `raw_transform` / `target_transform` / `augmentation` of
+        the saved trainer come back from the checkpoint; one that could not be pickled must be passed again (RuntimeError
+        otherwise: training on un-standardised inputs or raw label ids must not happen silently)."""
         save_dict = torch.load(os.path.join(checkpoint_folder, f"{name}.pt"), weights_only=False)
         init = save_dict["init"]
+        given = {"raw_transform": raw_transform, "target_transform": target_transform, "augmentation": augmentation}
+        missing = [k for k in init.get("unpicklable_transforms", []) if given[k] is _FROM_CHECKPOINT]
+        if missing:
+            raise RuntimeError(f"from_checkpoint: the saved trainer used {missing}, which could not be stored in the "
+                               "checkpoint; pass them to from_checkpoint()")
+        transforms = {k: (init.get(k) if v is _FROM_CHECKPOINT else v) for k, v in given.items()}
         model = _import_class(init["model_class"])(**init["model_kwargs"])
         loss = _import_class(init["loss_class"])(**init["loss_kwargs"])
         metric = _import_class(init["metric_class"])(**init["metric_kwargs"])
@@ -250,7 +282,8 @@ class DefaultTrainer:
                       early_stopping=init["early_stopping"], logger=None, id_=init["id_"],
                       save_root=init["save_root"], rank=init.get("rank"),
                       mixed_precision_dtype=init["mixed_precision_dtype"]
-                      if init.get("mixed_precision_explicit", False) else None)
+                      if init.get("mixed_precision_explicit", False) else None,
+                      prefetch=init.get("prefetch", True), **transforms)
         trainer._initialize(0, save_dict)
         trainer._is_initialized = True
         return trainer
