@@ -525,7 +525,7 @@ def test_from_checkpoint_restores_the_device_pre_pass(tmp_path):
     torch.manual_seed(0)
     model = UNet3d(1, 2, depth=2, initial_features=4)
     raw_t = functools.partial(standardize, per_sample=True)
-    tgt_t = BatchTargets(BoundaryTransform(add_binary_target=True))
+    tgt_t = BatchTargets(BoundaryTransform(add_binary_target=True, ndim=3))
     trainer = torch_em_amd.default_segmentation_trainer("pre", model, loader, loader, device=DEV, logger=None,
                                                         save_root=str(tmp_path), raw_transform=raw_t, target_transform=tgt_t)
     trainer.fit(iterations=2)
