@@ -33,6 +33,9 @@ STEP_GB = 25.58                 # conv-centric fp32 traffic of c
 
 # live-event tags -> kernel names as rocprofv3 prints them (dominant template instantiation of each tag)
 RP_NAMES = {
+    "k_conv_zr_f16x3<3,3,3>": "k_conv_zr<2, true, 1>",
+    "k_conv_zr_bf16x3<3,3,3>": "k_conv_zr<2, false, 2>",
+    "k_conv_zr_f16<3,3,3>": "k_conv_zr<1, true, 1>",
     "k_conv_pp_bf16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, false>",
     "k_conv_pp_bf16x3<3,3,3,CT=1>": "k_conv_pp<3, 3, 3, 4, 8, 8, 1, 1, 2, false>",
     "k_conv_pp_f16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, true>",
@@ -50,6 +53,8 @@ RP_NAMES = {
     "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, false>",
     "k_conv_wgrad_bf16x3<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, false>",
 }
+
+SUSTAINED_F16_MFMA_TFLOPS = 1640.0   # measured: profiles/r03_mfma_sustained.txt (pure MFMA stream, random operands, all CUs)
 
 PRECISION_DTYPE = {
     "fp32": "f32",
@@ -92,12 +97,16 @@ def cpu_baseline(max_threads):
     torch.set_num_threads(threads)
     x = torch.randn(2, 1, 128, 128, 128, generator=g)
     y = (torch.rand(2, 2, 128, 128, 128, generator=g) > 0.5).float()
-    t0 = time.perf_counter()
-    unet_ref.unet_loss_and_grads(sd, x, y, [2, 2, 2, 2])
-    dt = time.perf_counter() - t0
+    unet_ref.unet_loss_and_grads(sd, x, y, [2, 2, 2, 2])   # warm-up at the measured size (first-touch pages, oneDNN primitives)
+    dts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        unet_ref.unet_loss_and_grads(sd, x, y, [2, 2, 2, 2])
+        dts.append(time.perf_counter() - t0)
+    dt = min(dts)
     return {"value": 2 * 128 ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
             "sample": "oracle (torch-CPU fp32 restatement) zero_grad+fwd+DiceLoss+bwd of the same UNet3d on the full cfg-2 "
-                      f"batch 2x1x128^3, one step, no warm-up at this size: {dt:.2f} s/step (no optimizer step: AdamW is "
+                      f"batch 2x1x128^3, best of 2 steps after one warm-up step at this size: {dt:.2f} s/step (no optimizer step: AdamW is "
                       "~3 % of the reference's CPU step, BASELINE.md section 2); thread count chosen by a 32^3 probe over "
                       f"8/16/32/64 of {max_threads} hardware threads"}
 
@@ -214,6 +223,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=0, world_size=1)
     model = DDP(net, device_ids=[local_rank]) if (world > 1 or force_ddp) else net
+    if isinstance(model, DDP):
+        model.sync.measure = True   # HIP events around the join of the gradient exchange (ddp.allreduce_exposed_ms)
     opt = FusedAdamW(net.parameters(), lr=1e-3)
     loss_fn = DiceLoss()
     g = torch.Generator().manual_seed(rank)
@@ -265,6 +276,8 @@ def main():
     ev_steps = {(i * args.steps) // n_ev for i in range(n_ev)} if (rank == 0 and dom_tag is not None) else set()
     if ev_steps:
         ops.PROFILER = []
+    if isinstance(model, DDP):
+        model.sync.exposed_ms()   # drop the warm-up steps' events
     t0 = time.perf_counter()
     for i in range(args.steps):
         if ev_steps:
@@ -276,11 +289,23 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dom_prof, ops.PROFILER, ops.PROFILER_FILTER = ops.PROFILER or [], None, None
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank_ms = [float(v.item()) / args.steps * 1e3 for v in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss)
+    ddp_info = None
+    if isinstance(model, DDP):
+        ddp_info = {"bytes": model.sync.stats["bytes"], "n_collectives": model.sync.stats["n_collectives"],
+                    "allreduce_exposed_ms": model.sync.exposed_ms(), "ranks": dist.get_world_size(),
+                    "backend": dist.get_backend(), "per_rank_ms_per_step": per_rank_ms,
+                    "note": "bytes / collectives of one step's gradient exchange (in-place all-reduce of arena ranges on "
+                            "RCCL's stream, overlapped with backward); allreduce_exposed_ms = mean time the compute stream "
+                            "waited at the join before the optimizer (HIP events), over the timed steps"}
 
     if rank == 0:
         voxels = args.batch * S ** 3
@@ -323,9 +348,8 @@ def main():
         achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s (algorithmic: 2*MACs of the convolution)
         split = 6 if "bf16x6" in dom_tag else (3 if ("bf16x3" in dom_tag or "f16x3" in dom_tag) else
                                                1 if "_f16<" in dom_tag else 0)
-        traffic_file = os.path.join(ROOT, "profiles", "r02_traffic_bytes_per_launch.json")
-        if not os.path.exists(traffic_file):
-            traffic_file = os.path.join(ROOT, "profiles", "r01_traffic_bytes_per_launch.json")
+        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_bytes_per_launch.json") for r in (3, 2, 1))
+                             if os.path.exists(f)), "")
         # split-bf16 kernels execute 3 (or 6) bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3 (6)
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
         standard = (args.batch == 2 and S == 128)
@@ -353,11 +377,18 @@ def main():
                          "peak_note": (f"dense bf16 MFMA peak 2500 TFLOP/s / {split} MFMAs per product (split-bf16, fp32 "
                                        "accumulate); executed-MFMA fraction of 2500 = frac" if split else
                                        "exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                         # what this chip SUSTAINS: a register-only stream of v_mfma_f32_32x32x16_f16 on all 256 CUs with
+                         # random operands runs at 1.65 GHz (power-limited; 2.2 GHz / 2150 TF on all-zero operands):
+                         # scripts/proto/memtime_cal.hip, profiles/r03_mfma_sustained.txt
+                         "sustained_peak": (SUSTAINED_F16_MFMA_TFLOPS / split) if split else None,
+                         "frac_of_sustained": (achieved / (SUSTAINED_F16_MFMA_TFLOPS / split)) if split else None,
                          "launches_per_step": dom["launches"] // max(len(ev_steps), 1),
                          "event_steps": sorted(ev_steps),
                          "avg_launch_ms": dom["ms"] / dom["launches"],
                          "flops_per_launch_avg": dom["flops"] / dom["launches"]},
         }
+        if ddp_info is not None:
+            out["ddp"] = ddp_info
         if standard:
             out["step_roofline"] = {
                 "flops_frac_fp32_mfma": STEP_GFLOP / ms / PEAK_FP32_MFMA_TFLOPS,

@@ -49,12 +49,19 @@ class GradSync:
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self.world = dist.get_world_size(process_group)
         self._avg = dist.get_backend(process_group) == "nccl"
+        # observability (bench.py `ddp` keys): bytes and collectives of the last exchange, and -- when `measure` is set --
+        # HIP events around the join in finish(): the time the compute stream had to WAIT for collectives (what is left
+        # exposed after the overlap with backward)
+        self.measure = False
+        self.stats = {"bytes": 0, "n_collectives": 0}
+        self._events = []
         self.reset()
 
     def reset(self):
         self._pending = []   # (lo, hi) element ranges produced but not yet launched
         self._works = []
         self._launched = []
+        self._bytes = self._ncoll = 0
 
     @staticmethod
     def _coalesce(ranges):
@@ -73,6 +80,8 @@ class GradSync:
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             self._works.append((dist.all_reduce(view, op=op, group=self.pg, async_op=True), view))
             self._launched.append((lo, hi))
+            self._bytes += (hi - lo) * 4
+            self._ncoll += 1
 
     def ready(self, flat: torch.Tensor, lo: int, hi: int):
         """Backward has finished writing flat[lo:hi] (enqueued on the current stream)."""
@@ -96,11 +105,28 @@ class GradSync:
             self._pending += rest
         if self._pending:
             self._launch(flat, self._pending)
+        ev = None
+        if self.measure and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for work, view in self._works:
             work.wait()
             if not self._avg:
                 view.div_(self.world)
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
+        self.stats = {"bytes": self._bytes, "n_collectives": self._ncoll}
         self.reset()
+
+    def exposed_ms(self):
+        """Mean time (ms) the compute stream waited in finish() over the measured steps so far (synchronises)."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        t = [a.elapsed_time(b) for a, b in self._events]
+        self._events = []
+        return sum(t) / len(t)
 
 
 class DDP(torch.nn.Module):

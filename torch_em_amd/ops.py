@@ -25,6 +25,8 @@ PROFILER_FILTER = None
 
 
 def _fwd_tag(mfma, k, cout, pp=False):
+    if pp == 3:  # the z-reuse team kernel (csrc/conv_zr.hip)
+        return f"k_conv_zr_{'f16x3' if int(mfma) == 4 else 'f16' if int(mfma) == 5 else 'bf16x3'}<3,3,3>"
     if pp:  # the ping-pong team kernel (csrc/conv_pp.hip)
         return f"k_conv_pp_{'f16x3' if int(mfma) == 4 else 'bf16x3'}<{k[0]},{k[1]},{k[2]},CT={2 if cout % 64 == 0 else 1}>"
     kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3", 5: "k_conv_fwd_f16",
@@ -218,7 +220,7 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     ws = _workspace(nws, x.device) if nws else None
     kind = None
     if PROFILER is not None:
-        pp = bool(mfma) and bool(lib.tem_conv3d_fwd_kernel(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
+        pp = lib.tem_conv3d_fwd_kernel(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if mfma else 0
         kind = _fwd_tag(mfma, k, cout, pp)
     nblk = lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if want_stats else 0
     ev0 = _prof_begin(x, kind)
@@ -350,7 +352,7 @@ def conv_fwd_gscaled(x, w_packed, y, k, cin, cout, amax, ref=None):
     lib = _lib.load()
     nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 1)
     ws = _workspace(nws, x.device) if nws else None
-    kind = _fwd_tag(4, k, cout, True) if PROFILER is not None else None
+    kind = _fwd_tag(4, k, cout, 3) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
     _lib.check(lib.tem_conv3d_fwd_gscaled(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(amax), _p(ws), nws,
                                           N, D, H, W, cin, cout, k[0], k[1], k[2], _stream(x)), "tem_conv3d_fwd_gscaled")
