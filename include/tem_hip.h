@@ -51,7 +51,8 @@ int tem_device_cus(void);
  * (the reference selects nothing: it calls ATen).  Names:
  *   "conv_fwd_variant"   -1 auto | 0 one-patch-per-workgroup kernel | 1 ping-pong team kernel (conv_pp.hip) for every shape
  *                        it can take | 2 z-reuse team kernel (conv_zr.hip, 3x3x3) for every shape it can take
- *   "wgrad_zs"            1 | 0   z-sliding weight-gradient kernel (3x3x3, D >= 16)
+ *   "wgrad_zs"            2 | 1 | 0   z-sliding weight gradient (3x3x3, D >= 16): 2 = with a staging team (k_conv_wgrad_zt),
+ *                        1 = the round-2 kernel (k_conv_wgrad_zs), 0 = patch kernel
  *   "wgrad_zs_persist"    1 | 0   persistent column segments of that kernel
  *   "wgrad_sums"          1 | 0   norm-backward sums taken from the weight gradient
  *   "wgrad_sums_min_mb"   256     ... for layers whose replaced pass reads at least this many MiB

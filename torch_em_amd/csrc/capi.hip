@@ -23,7 +23,7 @@ struct TemOption {
     long long def;
 };
 static const TemOption g_opt_table[TEM_OPT_COUNT] = {
-    {"wgrad_zs", 1},            // TEM_OPT_WGRAD_ZS: z-sliding weight-gradient kernel for 3x3x3, D >= 16
+    {"wgrad_zs", 1},            // TEM_OPT_WGRAD_ZS: z-sliding weight gradient for 3x3x3, D >= 16 (2 staging-team kernel, 1 round-2 kernel, 0 patch kernel)
     {"wgrad_zs_persist", 1},    // TEM_OPT_WGRAD_ZS_PERSIST: persistent column segments (one slab per workgroup)
     {"wgrad_sums", 1},          // TEM_OPT_WGRAD_SUMS: norm-backward sums from the weight gradient
     {"wgrad_sums_min_mb", 256}, // TEM_OPT_WGRAD_SUMS_MIN_MB: ... for layers whose replaced pass reads at least this much
@@ -31,6 +31,7 @@ static const TemOption g_opt_table[TEM_OPT_COUNT] = {
     {"conv_fwd_variant", -1},   // TEM_OPT_CONV_FWD_VARIANT: split-precision forward/dgrad kernel (-1 auto, 0 patch kernel, 1 ping-pong forced, 2 z-reuse forced)
     {"conv1x1_stream", 1},      // TEM_OPT_CONV1X1_STREAM: 1x1x1 convolutions / data gradients as a streaming GEMM (conv1x1_stream.hip)
     {"fwd_ksplit_chunks", 0},   // TEM_OPT_FWD_KSPLIT_CHUNKS: split-K forward launches: at most this many 16-channel chunks per partial (0: heuristic only)
+    {"wgrad_cus", 256},         // TEM_OPT_WGRAD_CUS: workgroups the z-sliding weight gradient asks for (one per CU)
 };
 static long long g_opt_val[TEM_OPT_COUNT];
 static bool g_opt_set[TEM_OPT_COUNT];

@@ -1333,8 +1333,328 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------
+// 3x3x3 weight gradient, z-sliding with a STAGING TEAM (round 3; the default for D >= 16).
+// k_conv_wgrad_zs runs "MFMA phase, staging, barrier" per plane on all eight waves: the matrix pipe idles while the
+// planes of the next step are converted (0.54 busy).  What the forward / data-gradient kernels showed (conv_zr.hip) is
+// that ONE wave per SIMD keeps the pipe full when it does nothing else, and that the wave beside it has ~1500 issue
+// slots per 10 k cycles for everything else.  So here the roles are fixed:
+//   * waves 0..3 (one per SIMD) only multiply: they own the 27 x (32 x 32) accumulators of ONE (Cin tile, Cout tile)
+//     pair -- row groups (tz, ty) w and w + 4 with their three tx taps each, plus tap tx = w of row group 8 for w < 3:
+//     7 / 7 / 7 / 6 taps = 112 accumulator registers, 84 / 84 / 84 / 72 MFMAs per plane; no k-halves, nothing to merge;
+//   * waves 4..7 only stage: the next x plane into the free ring slot, the next g plane into the free buffer (pre-norm,
+//     hi/lo split, transposed LDS stores), the loads after that, the bias-gradient sums and max |g|;
+//   * one barrier per plane, the ring / buffer discipline of k_conv_wgrad_zs unchanged.
+// A layer with two or more Cout tiles becomes that many workgroup columns: each stages x again, which costs HBM/L2 reads
+// but no time (the staging team has the slack).  Same LDS layout as k_conv_wgrad_zs<1>, same partial-slab format
+// with KS2 = 1.
+// ---------------------------------------------------------------------------
+template <bool H16>
+__global__ __launch_bounds__(512, 2) void k_conv_wgrad_zt(const float* __restrict__ x, int64_t x_ld,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ g,
+                                                          int64_t g_ld, float* __restrict__ part,
+                                                          float* __restrict__ dbpart, int N, int D, int H, int W,
+                                                          int Cin, int Cout, int T, int nY, int nX, int zsegs,
+                                                          int S, int ncz, unsigned* __restrict__ gmax) {
+    constexpr int NT = 27, KW = 3, NA = 7;   // accumulators per multiplying wave
+    constexpr int GC = 32;
+    constexpr int XPL = 32 * ZS_CIS;       // bytes per (hi|lo) plane set of Xt
+    constexpr int GPL = GC * ZS_GS;        // bytes per (hi|lo) g plane
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char* Xh = ldsb;
+    unsigned char* Xl = ldsb + XPL;
+    unsigned char* Gb = ldsb + 2 * XPL;    // [buffer 2][hi|lo][GC][ZS_GS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mteam = wv < 4;             // multiplying team / staging team
+    const int kh = lane >> 5, r = lane & 31;
+    const int bid0 = tem_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid0 % T;
+    const int sp = bid0 / T;               // partial-slab index: this workgroup walks column segments sp, sp+S, ...
+    const int ncit = Cin >> 5;
+    const int cit = tile % ncit, cog = tile / ncit;
+
+    // multiplying waves: accumulator j < 6 is tap (row group wv + 4 (j / 3), tx = j % 3); j == 6 is (row group 8, tx = wv)
+    floatx16 acc[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[j][k] = 0.f;
+
+    const int tl = tid & 255;
+    const bool git = !mteam;
+    const int gcq = tl & 7, grp = tl >> 3, gprow = grp >> 2, gpr = grp & 3;
+    const bool do_db = (dbpart != nullptr) && (cit == 0);
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float gmx = 0.f;
+    const int n = sp / S;
+    if (mteam) {
+        // ---------------- multiplying team ----------------
+        for (int cz = sp % S; cz < ncz; cz += S) {
+        const int zseg = cz % zsegs;
+        const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
+        // the staging team primes the ring for four barriers; then one plane per barrier (no `if (t >= za)` inside the
+        // loop: with it hipcc kept two register tuples per accumulator across the back edge)
+        for (int t = za - 4; t < za; ++t) __syncthreads();
+#pragma unroll 1
+        for (int t = za; t < zb; ++t) {
+            int wvl = wv;
+            asm volatile("" : "+s"(wvl));   // keeps the wave-id tests inside ONE copy of the loop body
+        {
+            const unsigned char* Gh = Gb + (t & 1) * 2 * GPL;
+            const unsigned char* Gl = Gh + GPL;
+            const int gbase = r * ZS_GS + kh * 16;   // g fragment of k-slab sl: + 32 sl (re-read per row group: LDS has room,
+                                                     // 32 registers for all four slabs do not)
+            auto rowgroup = [&](int rg, auto ntx_tag, int txs, int j0) {
+                // NTX == 3: all three tx windows of row group rg into acc[j0 .. j0+2]; NTX == 1: window txs into acc[j0]
+                constexpr int NTX = decltype(ntx_tag)::value;
+                const int tz = rg / 3, ty = rg % 3;
+                const int xbase = r * ZS_CIS + ((t + tz - 1 + 4) & 3) * ZS_PLB + ty * 32;   // ring slot of plane t + tz - 1 (scalar)
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    const int xoff = xbase + (2 * sl + kh) * 32;
+                    const uint4 bhs = *reinterpret_cast<const uint4*>(Gh + gbase + 32 * sl);
+                    uint4 bls = bhs;
+                    if (!H16) bls = *reinterpret_cast<const uint4*>(Gl + gbase + 32 * sl);
+                    const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
+                    const unsigned wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
+                    uint4 wl = wh;
+                    unsigned wl4 = wh4;
+                    if (!H16) {
+                        wl = *reinterpret_cast<const uint4*>(Xl + xoff);
+                        wl4 = *reinterpret_cast<const unsigned*>(Xl + xoff + 16);
+                    }
+                    uint4 fh[NTX], fl[NTX];
+                    if (NTX == 3) {
+                        fh[0] = wh;
+                        fl[0] = wl;
+                        fh[NTX > 1 ? 1 : 0] = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
+                                                         __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
+                        fl[NTX > 1 ? 1 : 0] = make_uint4(__builtin_amdgcn_alignbyte(wl.y, wl.x, 2), __builtin_amdgcn_alignbyte(wl.z, wl.y, 2),
+                                                         __builtin_amdgcn_alignbyte(wl.w, wl.z, 2), __builtin_amdgcn_alignbyte(wl4, wl.w, 2));
+                        fh[NTX > 2 ? 2 : 0] = make_uint4(wh.y, wh.z, wh.w, wh4);
+                        fl[NTX > 2 ? 2 : 0] = make_uint4(wl.y, wl.z, wl.w, wl4);
+                    } else {   // one window, txs wave-uniform: v_alignbyte shifts by 0..3 bytes only, window 2 starts one dword up
+                        const unsigned sh = txs == 1 ? 2u : 0u;
+                        const bool up = txs == 2;
+                        const unsigned h0 = up ? wh.y : wh.x, h1 = up ? wh.z : wh.y, h2 = up ? wh.w : wh.z, h3 = up ? wh4 : wh.w;
+                        const unsigned l0 = up ? wl.y : wl.x, l1 = up ? wl.z : wl.y, l2 = up ? wl.w : wl.z, l3 = up ? wl4 : wl.w;
+                        fh[0] = make_uint4(__builtin_amdgcn_alignbyte(h1, h0, sh), __builtin_amdgcn_alignbyte(h2, h1, sh),
+                                           __builtin_amdgcn_alignbyte(h3, h2, sh), __builtin_amdgcn_alignbyte(wh4, h3, sh));
+                        fl[0] = make_uint4(__builtin_amdgcn_alignbyte(l1, l0, sh), __builtin_amdgcn_alignbyte(l2, l1, sh),
+                                           __builtin_amdgcn_alignbyte(l3, l2, sh), __builtin_amdgcn_alignbyte(wl4, l3, sh));
+                    }
+                    if constexpr (H16) {
+#pragma unroll
+                        for (int tx = 0; tx < NTX; ++tx) acc[j0 + tx] = mfma16<true>(fh[tx], bhs, acc[j0 + tx]);
+                    } else {
+                        const bf16x8 gh8 = __builtin_bit_cast(bf16x8, bhs), gl8 = __builtin_bit_cast(bf16x8, bls);
+#pragma unroll
+                        for (int tx = 0; tx < NTX; ++tx)
+                            acc[j0 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl[tx]), gh8, acc[j0 + tx], 0, 0, 0);
+#pragma unroll
+                        for (int tx = 0; tx < NTX; ++tx)
+                            acc[j0 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh[tx]), gl8, acc[j0 + tx], 0, 0, 0);
+#pragma unroll
+                        for (int tx = 0; tx < NTX; ++tx)
+                            acc[j0 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh[tx]), gh8, acc[j0 + tx], 0, 0, 0);
+                    }
+                }
+            };
+            rowgroup(wvl, std::integral_constant<int, 3>{}, 0, 0);
+            rowgroup(wvl + 4, std::integral_constant<int, 3>{}, 0, 3);
+            // wave 3 has no seventh tap: it multiplies window 0 of row group 8 into an accumulator that is never stored (the
+            // other waves need these 12 MFMA slots anyway; an `if` here made hipcc copy accumulators around the loop)
+            rowgroup(8, std::integral_constant<int, 1>{}, wvl < 3 ? wvl : 0, 6);
+        }
+            __syncthreads();
+        }
+        }  // column segments
+        // (written here, inside the multiplying team's branch: behind the join the staging team would have to keep 112
+        // registers of zeros alive for it)
+        // ---- partial slabs: D[row = ci][col = co] ----
+        if (cog * 32 < Cout) {
+    #pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                if (j == 6 && wv >= 3) break;
+                const int tap = (j < 6) ? (wv + 4 * (j / 3)) * KW + (j % 3) : 8 * KW + wv;
+                float* dst = part + (((int64_t)sp * NT + tap) * Cin + cit * 32) * Cout + cog * 32 + r;
+    #pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    dst[(int64_t)row * Cout] = acc[j][reg];
+                }
+            }
+        }
+
+    } else {
+        // ---------------- staging team ----------------
+    // staging items of a staging-team thread: x items tl and tl + 256 (400 of them: halo row 10, x pair 5, channel quad 8),
+    // g item tl (256: patch row 8, x pair 4, channel quad 8)
+    float4 xa[2], xb[2], ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga;
+    bool inA[2] = {false, false}, inB[2] = {false, false};
+    float4 sc4[2], sf4[2];
+    int xcq[2], xrow[2], xpr[2];
+    bool xit[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int it = tl + 256 * q;
+        xit[q] = !mteam && it < 400;
+        xcq[q] = it & 7;
+        const int xrp = (it >> 3) % 50;
+        xrow[q] = xrp / 5;
+        xpr[q] = xrp % 5;
+        xa[q] = xb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sc4[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+        sf4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    for (int cz = sp % S; cz < ncz; cz += S) {
+    const int zseg = cz % zsegs;
+    const int col = cz / zsegs;
+    const int ptx = col % nX;
+    const int pty = col / nX;
+    const int y0 = pty * 8, x0 = ptx * 8;
+    const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
+    bool okxa[2] = {false, false}, okxb[2] = {false, false}, okga = false, okgb = false;
+    unsigned offx[2] = {0u, 0u}, offxb[2] = {0u, 0u}, offg = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (scale && xit[q]) {
+            sc4[q] = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + xcq[q] * 4);
+            sf4[q] = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + xcq[q] * 4);
+        }
+        const int gy = y0 + xrow[q] - 1, gx = x0 + 2 * xpr[q] - 1;
+        const bool rowok = xit[q] && gy >= 0 && gy < H;
+        okxa[q] = rowok && gx >= 0 && gx < W;
+        okxb[q] = rowok && gx + 1 >= 0 && gx + 1 < W;
+        offx[q] = (unsigned)(((gy < 0 ? 0 : gy) * W + (gx < 0 ? 0 : gx)) * (int)x_ld + cit * 32 + xcq[q] * 4) * 4u;
+        offxb[q] = (gx < 0) ? offx[q] : offx[q] + (unsigned)x_ld * 4u;
+        xa[q] = xb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        inA[q] = inB[q] = false;
+    }
+    {
+        const int hy = y0 + gprow, hx = x0 + 2 * gpr;
+        const bool grow = git && hy < H && gcq * 4 < Cout - cog * GC;
+        okga = grow && hx < W;
+        okgb = grow && hx + 1 < W;
+        offg = (unsigned)(((hy < H ? hy : 0) * W + (hx < W ? hx : 0)) * (int)g_ld + cog * GC + gcq * 4) * 4u;
+    }
+    const unsigned offgb = offg + (unsigned)g_ld * 4u;
+    const float* const xn = x + (int64_t)n * D * H * W * x_ld;
+    const float* const gn = g + (int64_t)n * D * H * W * g_ld;
+    const int64_t xplane = (int64_t)H * W * x_ld, gplane = (int64_t)H * W * g_ld;
+    ga = make_float4(0.f, 0.f, 0.f, 0.f);
+    gb = ga;
+    // iteration t: the multiplying team works on plane t (if t >= za); the staging team stores its pending registers
+    // (x plane t+2, g plane t+1) and loads the next pending set (x plane t+3, g plane t+2); barrier.  Two loops with the
+    // same trip count, one per role (one loop with the role test inside made hipcc unswitch and peel it into 30 copies).
+#pragma unroll 1
+        for (int t = za - 4; t < zb; ++t) {
+        // ---- pending registers -> LDS: x plane t+2 into its ring slot, g plane t+1 into buffer (t+1)&1 ----
+        if (t >= za - 3) {
+            const int sl = ((t + 2 + 4) & 3) * ZS_PLB;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (!xit[q]) continue;
+                const float a[4] = {xa[q].x, xa[q].y, xa[q].z, xa[q].w}, b[4] = {xb[q].x, xb[q].y, xb[q].z, xb[q].w};
+                const float s4[4] = {sc4[q].x, sc4[q].y, sc4[q].z, sc4[q].w}, f4[4] = {sf4[q].x, sf4[q].y, sf4[q].z, sf4[q].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float va = inA[q] ? fmaf(a[c], s4[c], f4[c]) : 0.f;
+                    const float vb = inB[q] ? fmaf(b[c], s4[c], f4[c]) : 0.f;
+                    const int off = (xcq[q] * 4 + c) * ZS_CIS + sl + xrow[q] * 32 + xpr[q] * 4;
+                    if constexpr (H16) {
+                        *reinterpret_cast<unsigned*>(Xh + off) = pk16<true>(va, vb);
+                    } else {
+                        unsigned hi, lo;
+                        split2(va, vb, hi, lo);
+                        *reinterpret_cast<unsigned*>(Xh + off) = hi;
+                        *reinterpret_cast<unsigned*>(Xl + off) = lo;
+                    }
+                }
+            }
+        }
+        if (t + 1 >= za && t + 1 < zb) {
+            unsigned char* Gh = Gb + ((t + 1) & 1) * 2 * GPL;
+            unsigned char* Gl = Gh + GPL;
+            const float a[4] = {ga.x, ga.y, ga.z, ga.w}, b[4] = {gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int off = (gcq * 4 + c) * ZS_GS + (gprow * 8 + gpr * 2) * 2;
+                if constexpr (H16) {
+                    *reinterpret_cast<unsigned*>(Gh + off) = pk16<true>(a[c], b[c]);
+                } else {
+                    unsigned hi, lo;
+                    split2(a[c], b[c], hi, lo);
+                    *reinterpret_cast<unsigned*>(Gh + off) = hi;
+                    *reinterpret_cast<unsigned*>(Gl + off) = lo;
+                }
+                dbacc[c] += a[c] + b[c];
+            }
+            if (gmax) {
+                gmx = __builtin_fmaxf(gmx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[0]), __builtin_fabsf(a[1])),
+                                                           __builtin_fmaxf(__builtin_fabsf(a[2]), __builtin_fabsf(a[3]))));
+                gmx = __builtin_fmaxf(gmx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(b[0]), __builtin_fabsf(b[1])),
+                                                           __builtin_fmaxf(__builtin_fabsf(b[2]), __builtin_fabsf(b[3]))));
+            }
+        }
+        // ---- loads for the next pending set: x plane t+3 (planes za-1 .. zb), g plane t+2 (za .. zb-1) ----
+        {
+            const int zx = t + 3;
+            const bool zxok = zx >= za - 1 && zx <= zb && zx >= 0 && zx < D;   // wave-uniform
+            const zs_rsrc_t rsx = zs_rsrc(xn + (zxok ? zx : 0) * xplane);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                inA[q] = zxok && okxa[q];
+                inB[q] = zxok && okxb[q];
+                xa[q] = xb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (zxok) {
+                    if (okxa[q]) xa[q] = zs_load4(rsx, offx[q], 0);
+                    if (okxb[q]) xb[q] = zs_load4(rsx, offxb[q], 0);
+                }
+            }
+            const int zg = t + 2;
+            ga = make_float4(0.f, 0.f, 0.f, 0.f);
+            gb = ga;
+            if (zg >= za && zg < zb) {
+                const zs_rsrc_t rsg = zs_rsrc(gn + zg * gplane);
+                if (okga) ga = zs_load4(rsg, offg, 0);
+                if (okgb) gb = zs_load4(rsg, offgb, 0);
+            }
+        }
+            __syncthreads();
+        }
+    }  // column segments
+    }
+
+
+    if (gmax && !mteam) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmx = __builtin_fmaxf(gmx, __shfl_xor(gmx, o, 64));
+        if (lane == 0) atomicMax(gmax, __builtin_bit_cast(unsigned, gmx));
+    }
+    // ---- bias-gradient partial of this workgroup (staging team: 256 threads = 32 (row, x pair) groups x 8 quads) ----
+    if (do_db) {
+        float* red = reinterpret_cast<float*>(ldsb);  // [32][GC]
+        if (git) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[grp * GC + gcq * 4 + c] = dbacc[c];
+        }
+        __syncthreads();
+        if (tid < GC && cog * GC + tid < Cout) {
+            float a = 0.f;
+            for (int rr = 0; rr < 32; ++rr) a += red[rr * GC + tid];
+            dbpart[(int64_t)sp * Cout + cog * GC + tid] = a;
+        }
+    }
+}
+
 struct ZsPlan {
     bool use;
+    bool teams;   // k_conv_wgrad_zt (staging team) instead of k_conv_wgrad_zs
     int nco, ks2, T, nY, nX, zsegs, S, Ss, ncz;
 };
 static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
@@ -1342,20 +1662,25 @@ static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int
     const int enable = (int)tem_option(TEM_OPT_WGRAD_ZS);
     p.use = enable && kd == 3 && kh == 3 && kw == 3 && D >= 16;
     const int ncot = Cout / 32;
-    p.nco = ncot >= 2 ? 2 : 1;
-    p.ks2 = p.nco == 1 ? 2 : 1;
+    p.teams = enable >= 2;
+    p.nco = (ncot >= 2 && !p.teams) ? 2 : 1;
+    p.ks2 = (p.nco == 1 && !p.teams) ? 2 : 1;
     p.T = (Cin / 32) * ((ncot + p.nco - 1) / p.nco);
     p.nY = (H + 7) / 8;
     p.nX = (W + 7) / 8;
     int64_t cols = (int64_t)N * p.nY * p.nX;
     int zs = 1;
-    while (p.T * cols * zs < 256 && D / (zs * 2) >= 8) zs *= 2;  // one workgroup per CU: fill the chip
+    // "wgrad_cus": workgroups (= CUs, one workgroup per CU) this kernel asks for; fewer than the chip has leaves CUs to
+    // HBM-bound kernels of another stream (TEM_OVERLAP_WGRAD=2)
+    long long ncu = tem_option(TEM_OPT_WGRAD_CUS);
+    if (ncu < 8 || ncu > 256) ncu = 256;
+    while (p.T * cols * zs < ncu && D / (zs * 2) >= 8) zs *= 2;  // one workgroup per CU: fill the chip
     p.zsegs = zs;
     p.ncz = p.nY * p.nX * zs;  // column segments per sample
     // persistent over column segments: q segments per workgroup, T * S workgroups ~ one per CU; a workgroup stays
     // inside one sample (Ss slabs per sample, S = N * Ss)
     const int persist = (int)tem_option(TEM_OPT_WGRAD_ZS_PERSIST);
-    const int64_t q = persist ? ((int64_t)N * p.ncz * p.T + 255) / 256 : 1;
+    const int64_t q = persist ? ((int64_t)N * p.ncz * p.T + ncu - 1) / ncu : 1;
     p.Ss = (int)((p.ncz + q - 1) / q);
     p.S = N * p.Ss;
     return p;
@@ -1479,7 +1804,23 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
         TEM_REQUIRE(!norm_sums || (db && w_sd && sd_layout && tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw)),
                     "tem_conv3d_wgrad_sums: this layer cannot deliver the norm sums (tem_conv3d_wgrad_sums_ok() == 0)");
         const unsigned nblk = (unsigned)((int64_t)z.T * z.S);
-        if (z.nco == 2) {
+        if (z.teams) {
+            constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS;
+            static bool at = false;
+            if (!at) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zt<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zt<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                at = true;
+            }
+            if (h16)
+                hipLaunchKernelGGL((k_conv_wgrad_zt<true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
+                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
+            else
+                hipLaunchKernelGGL((k_conv_wgrad_zt<false>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
+                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
+        } else if (z.nco == 2) {
             constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)64 * ZS_GS;
             static bool a2 = false;
             if (!a2) {

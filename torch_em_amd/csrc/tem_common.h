@@ -17,6 +17,7 @@ enum {
     TEM_OPT_CONV_FWD_VARIANT,
     TEM_OPT_CONV1X1_STREAM,
     TEM_OPT_FWD_KSPLIT_CHUNKS,
+    TEM_OPT_WGRAD_CUS,
     TEM_OPT_COUNT
 };
 long long tem_option(int id);
