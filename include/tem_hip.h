@@ -385,6 +385,11 @@ int tem_amp_unscale(float* grad, int64_t n, float inv_scale, float* found_inf, t
  */
 int tem_boundary_target(const int64_t* labels, float* out, int D, int H, int W,
                         int add_binary_target, tem_stream_t stream);
+/* find_boundaries' other same-shape modes: mode 0 "thick", 1 "inner" (thick & label != 0), 2 "outer" (thick &
+ * (background | two objects touch in the full 3^ndim window)); BoundaryTransform(mode=...) transform/label.py:108,123.
+ * "subpixel" changes the output shape to 2n-1 and cannot be a training target: not provided. */
+int tem_boundary_target_mode(const int64_t* labels, float* out, int D, int H, int W,
+                             int add_binary_target, int mode, tem_stream_t stream);
 /* offsets: HOST array [n_off][3] (z,y,x); 2-D data: D==1 and z offset 0.
  * out channels: [binary?] + n_off affinities (1 = different/invalid) [+ (binary mask?) + n_off mask].
  * has_ignore==0: no ignore label (mask = in-bounds only). */

@@ -101,8 +101,55 @@ def boundaries(labels, add_binary_target=False):
     return out
 
 
-def boundaries_morphology(labels):
+def boundaries_mode(labels, mode="thick", add_binary_target=False):
+    """find_boundaries(labels, mode) for the same-shape modes, from the definitions (neighbour loops, no morphology):
+    thick = some face neighbour differs; inner = thick & foreground; outer = thick & (background | the full 3^ndim
+    window of a foreground voxel holds max(label) != min(label, background -> dtype max)).  scikit-image is absent from
+    this image (reference setup.py:17, unpinned): pinned by the three known-answer arrays of its find_boundaries
+    docstring (tests/test_oracle_golden.py) and by `boundaries_morphology`, the published algorithm on scipy.ndimage."""
+    labels = np.asarray(labels)
+    thick = boundaries(labels)[0].astype(bool)
+    if mode == "thick":
+        b = thick
+    elif mode == "inner":
+        b = thick & (labels != 0)
+    elif mode == "outer":
+        big = np.iinfo(labels.dtype).max
+        inv = np.where(labels == 0, big, labels)
+        pad_l = np.pad(labels, 1, mode="edge")     # edge padding never changes a window's max / min
+        pad_i = np.pad(inv, 1, mode="edge")
+        mx, mn = labels.copy(), inv.copy()
+        import itertools
+        for off in itertools.product((0, 1, 2), repeat=labels.ndim):
+            sl = tuple(slice(o, o + n) for o, n in zip(off, labels.shape))
+            mx = np.maximum(mx, pad_l[sl])
+            mn = np.minimum(mn, pad_i[sl])
+        b = thick & ((labels == 0) | ((mx != mn) & (labels != 0)))
+    else:
+        raise ValueError(mode)
+    out = b[None].astype("float32")
+    if add_binary_target:
+        out = np.concatenate([(labels != 0)[None].astype("float32"), out], axis=0)
+    return out
+
+
+def boundaries_morphology(labels, mode="thick"):
     """The documented find_boundaries(mode='thick') algorithm via scipy.ndimage (cross-check)."""
     from scipy import ndimage as ndi
+    # scipy's separable min / max filters keep their intermediate results in the input dtype after computing in double:
+    # the "outer" stand-in value iinfo(int64).max is not a double and comes back as INT64_MIN (so find_boundaries itself
+    # is off for int64 / uint64 label images there).  The cross-check therefore runs on int32, where the published
+    # algorithm is exact; `boundaries_mode` and the HIP kernel evaluate the definition in integers for every dtype.
+    assert np.abs(labels).max() < 2 ** 31 - 1
+    labels = labels.astype("int32")
     fp = ndi.generate_binary_structure(labels.ndim, 1)
-    return (ndi.grey_dilation(labels, footprint=fp) != ndi.grey_erosion(labels, footprint=fp))[None].astype("float32")
+    b = ndi.grey_dilation(labels, footprint=fp) != ndi.grey_erosion(labels, footprint=fp)
+    if mode == "inner":
+        b &= labels != 0
+    elif mode == "outer":
+        bg = labels == 0
+        fp = ndi.generate_binary_structure(labels.ndim, labels.ndim)
+        inv = np.array(labels, copy=True)
+        inv[bg] = np.iinfo(labels.dtype).max
+        b &= bg | ((ndi.grey_dilation(labels, footprint=fp) != ndi.grey_erosion(inv, footprint=fp)) & ~bg)
+    return b[None].astype("float32")

@@ -98,3 +98,41 @@ def test_affine3d_warp_vs_oracle_and_replay_on_labels():
     # by name, as the reference's get_augmentations does
     pipe = get_augmentations(3, transforms=["RandomRotation3D", "RandomHorizontalFlip3D"])
     assert pipe(x.cuda())[0].shape == x.shape and pipe.halo == [32, 32, 32]
+
+
+def test_affine2d_warp_with_shear_vs_oracle():
+    """2-D RandomAffine / RandomRotation (reference transform/augmentation.py:234,239) on the 3-D warp kernel with one
+    z-plane: rotation + zoom + shift + x / y shear for the image, nearest replay for the labels."""
+    from oracle import augment_ref
+    from torch_em_amd.transform import KorniaAugmentationPipeline, RandomAffine, RandomRotation, get_augmentations
+    torch.manual_seed(5)
+    x = torch.randn(4, 3, 40, 28)
+    lbl = torch.randint(0, 5, (4, 1, 40, 28))
+    aug = RandomAffine(70, translate=(0.1, 0.2), scale=(0.8, 1.2), shear=(-20, 20, -10, 10), p=1.0)
+    xt, lt = KorniaAugmentationPipeline(aug)(x.cuda(), lbl.cuda())
+    assert xt.shape == x.shape and lt.shape == lbl.shape
+    inv = RandomAffine.inverse_matrices(aug._params, x.shape)
+    assert float(inv[:, 2, :].abs().sub(torch.tensor([0, 0, 1.0, 0], dtype=torch.float64)).abs().max()) < 1e-12  # z stays
+    assert float(aug._params["shear"].abs().max()) > 1.0
+    want = augment_ref.affine_warp3d(x[:, :, None], inv)[:, :, 0]
+    assert float((xt.cpu() - want).abs().max()) < 2e-4
+    want_l = augment_ref.affine_warp3d(lbl.float()[:, :, None], inv, nearest=True)[:, :, 0]
+    assert float((lt.cpu() != want_l).float().mean()) < 5e-3
+    # shear only: the centre row / column stays, x moves with y
+    sh = RandomAffine(0, shear=(45, 45), p=1.0)
+    img = torch.zeros(1, 1, 9, 9)
+    img[0, 0, :, 4] = 1.0                              # a vertical line through the centre
+    got = KorniaAugmentationPipeline(sh)(img.cuda())[0].cpu()[0, 0]
+    assert abs(float(got[4, 4]) - 1.0) < 1e-5 and abs(float(got[4].sum()) - 1.0) < 1e-5
+    cols = got.argmax(1)
+    assert (cols[1:] - cols[:-1]).abs().eq(1).all()   # the line leans by one column per row
+    # the plain rotation: 90 degrees on a square image, identity for p = 0, the reference's halo hint
+    sq = torch.randn(2, 1, 11, 11)
+    rot = KorniaAugmentationPipeline(RandomRotation((90, 90), p=1.0))
+    got = rot(sq.cuda())[0].cpu()
+    assert float((got - torch.rot90(sq, 1, (-2, -1))).abs().max()) < 1e-5 or \
+        float((got - torch.rot90(sq, -1, (-2, -1))).abs().max()) < 1e-5
+    assert rot.halo == [32, 32]
+    assert torch.equal(KorniaAugmentationPipeline(RandomRotation(90, p=0.0))(sq.cuda())[0].cpu(), sq)
+    pipe = get_augmentations(2, transforms=["RandomAffine", "RandomVerticalFlip"])
+    assert pipe.halo is None and pipe(x.cuda())[0].shape == x.shape

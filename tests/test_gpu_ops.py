@@ -747,6 +747,12 @@ def test_label_targets_bit_exact():
             exp = label_ref.boundaries(lab, add_bin)
             got = ops.boundary_target(ld, add_bin).cpu().numpy()
             assert np.array_equal(got, exp), (shape, add_bin)
+            lab2 = lab.copy()
+            lab2[lab2 == lab2.max()] = -1            # an ignore label below the background
+            for mode in ("thick", "inner", "outer"):     # BoundaryTransform(mode=...), reference label.py:108,123
+                exp = label_ref.boundaries_mode(lab2, mode, add_bin)
+                got = ops.boundary_target(torch.from_numpy(lab2).to(DEV), add_bin, mode).cpu().numpy()
+                assert np.array_equal(got, exp), (shape, add_bin, mode)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])

@@ -125,6 +125,28 @@ def test_boundaries_kat_and_morphology():
     assert out.shape == (2,) + lab.shape and np.array_equal(out[0], (lab != 0).astype("float32"))
 
 
+def test_boundary_modes_known_answers():
+    """The three same-shape modes on the example of scikit-image's find_boundaries docstring (its published outputs)."""
+    lab = np.zeros((9, 10), "int64")
+    lab[2:7, 5:8] = 5
+    lab[3:6, 2:5] = 1
+    rows = {"thick": ["0000000000", "0000011100", "0011111110", "0111110110", "0110110110", "0111110110", "0011111110",
+                      "0000011100", "0000000000"],
+            "inner": ["0000000000", "0000000000", "0000011100", "0011110100", "0010110100", "0011110100", "0000011100",
+                      "0000000000", "0000000000"],
+            "outer": ["0000000000", "0000011100", "0011110010", "0100110010", "0100110010", "0100110010", "0011110010",
+                      "0000011100", "0000000000"]}
+    for mode, r in rows.items():
+        want = np.array([[int(c) for c in line] for line in r], "float32")
+        assert np.array_equal(label_ref.boundaries_mode(lab, mode)[0], want), mode
+        assert np.array_equal(label_ref.boundaries_morphology(lab, mode)[0], want), mode
+    for shape, seed in (((32, 32), 3), ((8, 12, 10), 4), ((1, 9), 5)):
+        lab = _labels(shape, True, seed)
+        lab[lab == lab.max()] = -1                       # an ignore label below the background
+        for mode in rows:
+            assert np.array_equal(label_ref.boundaries_mode(lab, mode), label_ref.boundaries_morphology(lab, mode))
+
+
 def test_adamw_oracle_matches_torch():
     rng = np.random.RandomState(0)
     p0 = rng.randn(1000).astype("float32")

@@ -5,6 +5,7 @@ The reference has no native code; this is the binding a torch-em maintainer woul
 missing, every op raises.  `build()` compiles it in-tree with hipcc for gfx950.
 """
 import ctypes
+import threading
 import os
 import subprocess
 
@@ -88,6 +89,7 @@ SIGNATURES = {
     "tem_ema_update": (c_int, [c_vp, c_vp, c_i64, c_float, c_vp]),
     "tem_amp_unscale": (c_int, [c_vp, c_i64, c_float, c_vp, c_vp]),
     "tem_boundary_target": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "tem_boundary_target_mode": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tem_affinity_target": (c_int, [c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_i64,
                                     c_int, c_int, c_int, c_vp]),
     "tem_nchw_to_nhwc": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_i64, c_vp]),
@@ -177,8 +179,27 @@ def get_option(name):
     return int(out.value)
 
 
+_tls = threading.local()
+
+
+def launch_on(idx):
+    """Make device `idx` current for the launch being assembled; `check()` -- which wraps every launch -- puts the
+    caller's device back, so an op on a `cuda:1` tensor does not move the process's current device for good."""
+    import torch
+    cur = torch.cuda.current_device()
+    if idx is not None and idx != cur:
+        if getattr(_tls, "restore", None) is None:
+            _tls.restore = cur
+        torch.cuda.set_device(idx)
+
+
 def check(rc, what=""):
     """Map a C-ABI return code to the exception the reference raises for the same mistake."""
+    prev = getattr(_tls, "restore", None)
+    if prev is not None:
+        import torch
+        _tls.restore = None
+        torch.cuda.set_device(prev)
     if rc == 0:
         return
     msg = load().tem_last_error().decode("utf-8", "replace")

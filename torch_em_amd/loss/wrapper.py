@@ -101,8 +101,7 @@ class LossWrapper(nn.Module):
         if mask.shape != target.shape or mask.stride() != target.stride():
             # a broadcast mask (singleton channel) or a differently laid out one: the kernel reads target and mask with one
             # set of strides, so both become dense tensors of the same layout
-            target = target.contiguous()
-            mask = mask.expand_as(target).contiguous()
+            target, mask = (t.contiguous() for t in torch.broadcast_tensors(target, mask))
         return self.loss(prediction, target, mask=mask)
 
     def apply_transform(self, prediction, target, **kwargs):

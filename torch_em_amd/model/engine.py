@@ -637,7 +637,15 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         _conv(sspec, cur, t)                       # 1x1 conv at low resolution ...
         cat = lv["cat"]
         if (d * f[0], h * f[1], w * f[2]) != tuple(cat.shape[1:4]):
-            raise NotImplementedError("skip connections that need cropping are not supported")
+            # reference Decoder._crop (model/unet.py:363-366) centre-crops the skip by (diff // 2) per side, which only
+            # yields matching shapes for EVEN differences (never with factor-2 pooling, where a ragged size differs by 1
+            # and the reference's torch.cat raises); this engine writes the skip straight into the concat buffer and has
+            # no cropped variant
+            raise NotImplementedError(
+                f"input size {tuple(cat.shape[1:4])} at this level is not a multiple of the scale factor {f}: the "
+                "upsampled tensor and the skip connection differ in shape (the reference raises in torch.cat for odd "
+                "differences and centre-crops even ones; cropping is not implemented here) -- pad the input to a "
+                "multiple of the product of the scale factors")
         ops.upsample_fwd(t, cat[..., :lv["c_up"]], f)  # ... interpolated straight into the concat buffer
         out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev)
         # statistics of the concat for the block's first norm without reading it: the skip half's partial sums were

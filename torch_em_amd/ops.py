@@ -60,12 +60,11 @@ def _prof_end(t, ev0, tag, flops):
 
 def _stream(t: torch.Tensor):
     """The stream the launch goes to: torch's current stream of the TENSOR's device.  A HIP launch is issued on the
-    calling thread's current device, so that device is made current first (one process drives one GPU in this design;
-    a process that touches several -- `DefaultTrainer(device="cuda:1")`, `predict_with_halo(gpu_ids=[1])` -- gets the
-    device of the tensors it passes, like a torch op would)."""
-    idx = t.device.index
-    if idx is not None and idx != torch.cuda.current_device():
-        torch.cuda.set_device(idx)
+    calling thread's current device, so that device is made current for the launch and `_lib.check()` -- which wraps
+    every launch -- restores the caller's (one process drives one GPU in this design; a process that touches several --
+    `DefaultTrainer(device="cuda:1")`, `predict_with_halo(gpu_ids=[1])` -- gets the device of the tensors it passes,
+    like a torch op would, and keeps its own current device)."""
+    _lib.launch_on(t.device.index)
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
@@ -751,16 +750,22 @@ def ema_update(theta_k, theta_q, momentum):
 
 
 # ---------------------------------------------------------------- labels ----
-def boundary_target(labels: torch.Tensor, add_binary_target: bool) -> torch.Tensor:
+BOUNDARY_MODES = {"thick": 0, "inner": 1, "outer": 2}
+
+
+def boundary_target(labels: torch.Tensor, add_binary_target: bool, mode: str = "thick") -> torch.Tensor:
     _req_cuda(labels)
+    if mode not in BOUNDARY_MODES:
+        raise NotImplementedError(f"find_boundaries mode '{mode}': the MI355X kernel has {sorted(BOUNDARY_MODES)} "
+                                  "('subpixel' returns a 2n-1 grid, which cannot be a training target)")
     labels = labels.to(torch.int64).contiguous()
     sp = tuple(labels.shape)
     D, H, W = (1,) * (3 - len(sp)) + sp
     nch = 2 if add_binary_target else 1
     out = torch.empty((nch,) + sp, dtype=torch.float32, device=labels.device)
     lib = _lib.load()
-    _lib.check(lib.tem_boundary_target(_p(labels), _p(out), D, H, W, int(add_binary_target), _stream(labels)),
-               "tem_boundary_target")
+    _lib.check(lib.tem_boundary_target_mode(_p(labels), _p(out), D, H, W, int(add_binary_target),
+                                            BOUNDARY_MODES[mode], _stream(labels)), "tem_boundary_target_mode")
     return out
 
 

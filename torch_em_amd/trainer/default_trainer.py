@@ -100,6 +100,13 @@ class DefaultTrainer:
         asked = mixed_precision_dtype == "float16" or (mixed_precision_dtype is None and
                                                         os.environ.get("TEM_MIXED_PRECISION", "0") == "1")
         self._amp = bool(mixed_precision) and asked and self.device.type == "cuda"
+        if mixed_precision and not self._amp and mixed_precision_dtype is None and self.device.type == "cuda":
+            # the reference's default (mixed_precision=True) means autocast(float16) + GradScaler there; here it would
+            # silently train in the slower fp32-class arithmetic -- say so once
+            warnings.warn("DefaultTrainer: mixed_precision=True without mixed_precision_dtype keeps the fp32-class "
+                          "arithmetic of this path (parity-grade, ~1.5x slower than its mixed mode); pass "
+                          "mixed_precision_dtype='float16' for the counterpart of torch.autocast(float16) + GradScaler, "
+                          "or mixed_precision=False to silence this message", stacklevel=2)
         self._mixed_precision_explicit = mixed_precision_dtype is not None
         if self._amp:
             from ..optim import GradScaler
@@ -174,22 +181,28 @@ class DefaultTrainer:
                           "from_checkpoint() will ask for them again")
         return rec
 
-    def _initialize(self, iterations, load_from_checkpoint, epochs=None):
-        for attr in ("train_loader", "val_loader", "model", "loss", "optimizer", "metric", "device"):
-            assert getattr(self, attr) is not None
-        if load_from_checkpoint is not None:
-            self.load_checkpoint(load_from_checkpoint)
-        if sum((iterations is not None, epochs is not None)) != 1:
+    def _plan(self, iterations, epochs):
+        """(iterations, epochs) to run from here: the caller names exactly one of them, the other follows from the
+        number of batches per epoch (same contract and message as the reference's `_initialize`, :512-528)."""
+        named = [v for v in (iterations, epochs) if v is not None]
+        if len(named) != 1:
             raise ValueError(
                 "Exactly one of 'iterations' or 'epochs' has to be specified to initialize the trainer."
                 f"You have passed 'iterations'={iterations} and 'epochs'={epochs}"
             )
-        if epochs is None:
-            epochs = int(np.ceil(float(iterations) / len(self.train_loader)))
-        else:
-            iterations = epochs * len(self.train_loader)
-        self.max_iteration = self._iteration + iterations
-        self.max_epoch = self._epoch + epochs
+        per_epoch = len(self.train_loader)
+        if iterations is not None:
+            return iterations, -(-int(iterations) // per_epoch)      # ceil: a partial last epoch still counts as one
+        return epochs * per_epoch, epochs
+
+    def _initialize(self, iterations, load_from_checkpoint, epochs=None):
+        missing = [a for a in ("train_loader", "val_loader", "model", "loss", "optimizer", "metric", "device")
+                   if getattr(self, a) is None]
+        assert not missing, f"DefaultTrainer: {missing} must be set before fit()"
+        if load_from_checkpoint is not None:
+            self.load_checkpoint(load_from_checkpoint)
+        iterations, epochs = self._plan(iterations, epochs)
+        self.max_iteration, self.max_epoch = self._iteration + iterations, self._epoch + epochs
         if not getattr(self, "_is_initialized", False):
             self.model.to(self.device)
             if isinstance(self.loss, torch.nn.Module):

@@ -13,7 +13,7 @@ Parameter replay: like the reference (:212-220) the first tensor draws the param
 (labels) replays them, with NEAREST interpolation for non-float inputs; everything is returned as `dtype`.
 Besides the reference's default pipelines and its two elastic classes, the 3-D affine / rotation augmentations it lists
 (`RandomAffine3D`, `RandomRotation3D`, :235,240) run as one trilinear / nearest warp pass per tensor (`tem_affine_warp3d`);
-the 2-D `RandomAffine` / `RandomRotation` raise NotImplementedError.
+the 2-D `RandomAffine` / `RandomRotation` (:234,239; incl. shear) use the same kernel with a depth of one.
 """
 from typing import List, Sequence, Tuple, Union
 
@@ -162,6 +162,77 @@ class RandomRotation3D(RandomAffine3D):
         super().__init__(degrees, None, None, None, resample, same_on_batch, align_corners, p, keepdim)
 
 
+class RandomAffine(RandomAffine3D):
+    """kornia's 2-D `RandomAffine(degrees, translate=None, scale=None, shear=None, ...)` (reference AUGMENTATIONS :234:
+    degrees=90, scale=(0.9, 1.1)) on the 3-D warp kernel with a depth of one: rotation about the image centre by an
+    angle in [-d, d] (or (min, max)), isotropic zoom, translation fractions of (W, H), x / y shear angles in degrees
+    (`shear`: one number s -> x shear in [-s, s]; (a, b) -> x shear in [a, b]; (a, b, c, d) -> x in [a, b], y in [c, d]).
+    The forward map is dst = R * Shear * scale * (src - c) + c + t; kornia is not in this image -- composition order and
+    centre ((size - 1) / 2) are this build's definition: parity unpinned."""
+    spatial = 2
+
+    def __init__(self, degrees, translate=None, scale=None, shear=None, resample="bilinear", same_on_batch: bool = False,
+                 align_corners: bool = False, padding_mode="zeros", p: float = 0.5, keepdim: bool = False):
+        if padding_mode not in ("zeros", 0):
+            raise NotImplementedError("RandomAffine: the MI355X warp kernel pads with zeros")
+        torch.nn.Module.__init__(self)
+        self.degrees = (_pair(degrees, "degrees"), (0.0, 0.0), (0.0, 0.0))     # yaw only
+        self.scale = None if scale is None else _pair(scale[:2] if len(scale) > 2 else scale, "scale")
+        self.translate = None if translate is None else (float(translate[0]), float(translate[1]), 0.0)
+        if shear is None:
+            self.shear = None
+        elif isinstance(shear, (int, float)):
+            self.shear = ((-float(shear), float(shear)), (0.0, 0.0))
+        elif len(shear) == 2:
+            self.shear = ((float(shear[0]), float(shear[1])), (0.0, 0.0))
+        elif len(shear) == 4:
+            self.shear = ((float(shear[0]), float(shear[1])), (float(shear[2]), float(shear[3])))
+        else:
+            raise ValueError("shear: a number, (min, max) or (xmin, xmax, ymin, ymax)")
+        self.p, self.same_on_batch, self.keepdim = p, same_on_batch, keepdim
+        self.flags = dict(interpolation=resample, align_corners=align_corners)
+        self._params = None
+
+    def generate_parameters(self, batch_shape):
+        shape3 = tuple(batch_shape[:-2]) + (1,) + tuple(batch_shape[-2:])
+        params = super().generate_parameters(shape3)
+        n = batch_shape[0]
+        m = 1 if self.same_on_batch else n
+        if self.shear is not None:
+            draw = lambda lo, hi: (torch.rand(m, dtype=torch.float64) * (hi - lo) + lo).expand(n).clone()  # noqa: E731
+            params["shear"] = torch.stack([draw(*self.shear[0]), draw(*self.shear[1])], 1)
+        return params
+
+    @classmethod
+    def inverse_matrices(cls, params, shape) -> torch.Tensor:
+        shape3 = tuple(shape[:-2]) + (1,) + tuple(shape[-2:])
+        out = RandomAffine3D.inverse_matrices(params, shape3)
+        out[:, 2] = torch.tensor([0.0, 0.0, 1.0, 0.0], dtype=torch.float64)     # the one z-plane maps onto itself
+        sh = params.get("shear")
+        if sh is None:
+            return out
+        H, W = shape[-2:]
+        c = torch.tensor([(W - 1) / 2.0, (H - 1) / 2.0, 0.0], dtype=torch.float64)
+        for i in range(out.shape[0]):
+            if not bool(params["batch_prob"][i]):
+                continue
+            sx, sy = [np.tan(float(a) * np.pi / 180.0) for a in sh[i]]
+            shear = torch.tensor([[1.0, sx, 0.0], [sy, 1.0, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
+            # out = inverse of (dst = F (src - c) + c + t) with F = R * scale; the sheared map has F' = F * Shear
+            inv = torch.linalg.inv(shear) @ out[i, :, :3]
+            out[i, :, :3] = inv
+            out[i, :, 3] = c - inv @ (c + params["translations"][i])
+        return out
+
+
+class RandomRotation(RandomAffine):
+    """kornia's 2-D `RandomRotation(degrees)` (reference AUGMENTATIONS :239: degrees=90): RandomAffine without zoom / shift."""
+
+    def __init__(self, degrees, resample="bilinear", same_on_batch: bool = False, align_corners: bool = True,
+                 p: float = 0.5, keepdim: bool = False):
+        super().__init__(degrees, None, None, None, resample, same_on_batch, align_corners, "zeros", p, keepdim)
+
+
 def _gauss1d(ksize: int, sigma: float) -> torch.Tensor:
     x = torch.arange(ksize, dtype=torch.float32) - ksize // 2
     g = torch.exp(-x.pow(2.0) / (2 * float(sigma) ** 2))
@@ -244,17 +315,20 @@ class KorniaAugmentationPipeline(torch.nn.Module):
         for aug in kornia_augmentations:
             if not isinstance(aug, (_RandomFlip, _ElasticBase, RandomAffine3D)):
                 raise NotImplementedError(f"{type(aug).__name__} has no MI355X kernel (flips, elastic deformations and "
-                                          "3-D affine / rotation warps do)")
+                                          "2-D / 3-D affine / rotation warps do)")
         self.augmentations = torch.nn.ModuleList(kornia_augmentations)
         self.dtype = dtype
         self.halo = self.compute_halo()
 
     def compute_halo(self):
-        """The fixed 32-pixel hint the reference gives for rotations (:174-183; unused by its datasets)."""
+        """The fixed 32-pixel hint the reference gives for the pure rotations only (:174-183; unused by its datasets)."""
+        halo = None
         for aug in self.augmentations:
-            if isinstance(aug, RandomAffine3D):
-                return [32, 32, 32]
-        return None
+            if isinstance(aug, RandomRotation):
+                halo = [32, 32]
+            if isinstance(aug, RandomRotation3D):
+                halo = [32, 32, 32]
+        return halo
 
     def is_interpolatable(self, tensor):
         if torch.is_tensor(tensor):
@@ -311,8 +385,9 @@ class KorniaAugmentationPipeline(torch.nn.Module):
                     assert t.shape[0] == N and t.shape[2:] == shape[2:], "all tensors must share batch and spatial shape"
                     nearest = not (ip and aug.flags["interpolation"] in ("bilinear", 1))
                     dst = torch.empty_like(t)
-                    _lib.check(lib.tem_affine_warp3d(ops._p(t), ops._p(mats), ops._p(dst), N, t.shape[1], t.shape[2],
-                                                     t.shape[3], t.shape[4], int(nearest), ops._stream(t)),
+                    depth = t.shape[2] if spatial == 3 else 1   # 2-D images: one z-plane
+                    _lib.check(lib.tem_affine_warp3d(ops._p(t), ops._p(mats), ops._p(dst), N, t.shape[1], depth,
+                                                     t.shape[-2], t.shape[-1], int(nearest), ops._stream(t)),
                                "tem_affine_warp3d")
                     out.append(dst)
                 work = out
@@ -340,6 +415,8 @@ class KorniaAugmentationPipeline(torch.nn.Module):
 
 
 AUGMENTATIONS = {
+    "RandomAffine": {"degrees": 90, "scale": (0.9, 1.1)},
+    "RandomRotation": {"degrees": 90},
     "RandomAffine3D": {"degrees": (90, 90, 90), "scale": (0.0, 1.1)},
     "RandomRotation3D": {"degrees": (90, 90, 90)},
     "RandomDepthicalFlip3D": {},

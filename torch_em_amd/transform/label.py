@@ -45,16 +45,17 @@ class BoundaryTransform:
     """Instance labels -> boundary map [1(+1), *spatial] (reference `:100-129`)."""
 
     def __init__(self, mode: str = "thick", add_binary_target: bool = False, ndim: Optional[int] = None):
-        if mode != "thick":
-            raise NotImplementedError(f"BoundaryTransform mode '{mode}': the MI355X path implements 'thick' "
-                                      "(the reference default)")
+        if mode not in ops.BOUNDARY_MODES:
+            raise NotImplementedError(f"BoundaryTransform mode '{mode}': the MI355X kernel has "
+                                      f"{sorted(ops.BOUNDARY_MODES)}; 'subpixel' returns a 2n-1 grid, which cannot "
+                                      "be a training target")
         self.mode, self.add_binary_target, self.ndim = mode, add_binary_target, ndim
 
     def __call__(self, labels):
         t, is_np = _to_device(labels, self.ndim)
         if t.dim() not in (2, 3):
             raise ValueError(f"expected 2-D or 3-D labels, got shape {tuple(t.shape)}")
-        out = ops.boundary_target(t, self.add_binary_target)
+        out = ops.boundary_target(t, self.add_binary_target, self.mode)
         return out.cpu().numpy() if is_np else out
 
 
