@@ -58,6 +58,9 @@ int tem_device_cus(void);
  *   "wgrad_sums_min_mb"   256     ... for layers whose replaced pass reads at least this many MiB
  *   "fwd_persistent"     -1 | 0 | 1   exact-fp32 forward: persistent variant (-1: 64-column tiles only)
  *   "conv1x1_stream"      1 | 0   1x1x1 convolutions / data gradients as a streaming GEMM instead of the patch kernel
+ *   "fwd_ksplit_chunks"   0       split-K forward: at most this many 16-channel chunks per partial (0: heuristic)
+ *   "wgrad_cus"           256     workgroups the z-sliding weight gradient asks for
+ *   "upsample_generic"    0 | 1   1: the any-factor gather kernels also for factors (1|2, 2, 2)
  * Unknown names return TEM_EINVAL. */
 int tem_set_option(const char* name, int64_t value);
 int tem_get_option(const char* name, int64_t* value);
@@ -309,6 +312,12 @@ int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld,
  * (D,H,W) are u's dims; C = 4 * 2^k <= 256.  Merged by tem_norm_finalize_partials2 with V = D*fz*H*fy*W*fx. */
 int tem_upsample_stats(const float* u, int64_t u_ld, int N, int D, int H, int W, int C, int fz, int fy, int fx,
                        float* part, tem_stream_t stream);
+/* tem_upsample_fwd for factors (1|2, 2, 2) that also returns the first stage of y's statistics, part [N][D*H][C][2]
+ * (sum y, sum y^2 per coarse row: the layout of tem_upsample_stats, whose launch it saves -- the outputs are in
+ * registers).  tem_upsample_fwd_stats_ok: 1 when (C, factors) are taken (C = 4 * 2^k <= 256), else 0. */
+int tem_upsample_fwd_stats_ok(int C, int fz, int fy, int fx);
+int tem_upsample_fwd_stats(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C,
+                           int fz, int fy, int fx, float* part, tem_stream_t stream);
 /* ... of the RAW data gradient gy behind a norm whose input was upsample(u) (u: the low-resolution tensor, same shape
  * as gx): gx = a*U^T gy - m1*U^T 1 - m2r*(U^T U u - mean*U^T 1), ncoef as for tem_maxpool3d_bwd_norm */
 int tem_upsample_bwd_norm(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld,

@@ -368,7 +368,8 @@ def test_first_layer_fused_forward_statistics(case):
     y5, y_ref = ops.new_act(N, D, H, W, Cout, DEV), ops.new_act(N, D, H, W, Cout, DEV)
     part, nblk = ops.conv_fwd(x5, wp, b, y5, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=0, want_stats=True)
     ops.conv_fwd(x5, wp, b, y_ref, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=0)
-    assert torch.equal(y5, y_ref) and nblk == ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8)
+    tx = 32 if Cin == 1 else 8     # Cin = 1: 4x8x32 tiles of the row kernel (k_conv_fwd_c1rows), else 4x8x8 patches
+    assert torch.equal(y5, y_ref) and nblk == ((D + 3) // 4) * ((H + 7) // 8) * ((W + tx - 1) // tx)
     want = ops.norm_stats(y5, Cout, None, None, 1e-5)
     have = ops.norm_stats_from_partials(part, N, D * H * W, Cout, Cout, None, None, 1e-5)
     for a, c in zip(have, want):
@@ -515,12 +516,18 @@ def test_concat_statistics_without_reading_the_concat(case):
     cuts = [0, sk.shape[1] // 3, 2 * sk.shape[1] // 3, sk.shape[1]]
     part_b = torch.stack([torch.stack([sk[:, a:b].sum(1), (sk[:, a:b] ** 2).sum(1)], -1) for a, b in zip(cuts, cuts[1:])], 1)
     assert ops.upsample_stats_ok(u)
-    part_a = ops.upsample_stats(u, f)
-    for rows in (N, 1):
-        want = ops.norm_stats(cat if rows == N else cat.reshape(1, N * D, H, W, C), groups, gamma, beta, 1e-5)
-        have = ops.norm_stats_from_partials2(part_a, part_b.contiguous(), rows, D * H * W, groups, gamma, beta, 1e-5)
-        for a, c, name in zip(have, want, ("mean", "rstd", "scale", "shift")):
-            assert a.shape == c.shape and rel_err(a.cpu(), c.cpu()) < 5e-6, (name, rows, rel_err(a.cpu(), c.cpu()))
+    # the upsampled half's partials: from the factor-2 upsampling kernel itself (tem_upsample_fwd_stats, what the engine
+    # uses) and from the low-resolution stencil (tem_upsample_stats, any factor)
+    cat2 = torch.empty_like(cat)
+    part_f = ops.upsample_fwd(u, cat2[..., :cup], f, stats=True)
+    assert part_f is not None and torch.equal(cat2[..., :cup], cat[..., :cup])
+    for part_a in (part_f, ops.upsample_stats(u, f)):
+        assert part_a.shape == (N, d * h, cup, 2)
+        for rows in (N, 1):
+            want = ops.norm_stats(cat if rows == N else cat.reshape(1, N * D, H, W, C), groups, gamma, beta, 1e-5)
+            have = ops.norm_stats_from_partials2(part_a, part_b.contiguous(), rows, D * H * W, groups, gamma, beta, 1e-5)
+            for a, c, name in zip(have, want, ("mean", "rstd", "scale", "shift")):
+                assert a.shape == c.shape and rel_err(a.cpu(), c.cpu()) < 5e-6, (name, rows, rel_err(a.cpu(), c.cpu()))
 
 
 def test_conv_relu_mask_ref_and_channel_slices():
@@ -600,11 +607,24 @@ def test_maxpool(C, f, shape):
     assert rel_err(from5(gx5), (xr.grad + gskip) * (x > 0)) < 1e-6
 
 
+@pytest.mark.parametrize("generic", [0, 1])
 @pytest.mark.parametrize("C,f,shape", [(4, (2, 2, 2), (2, 3, 4, 5)), (32, (1, 2, 2), (1, 3, 4, 4)),
                                         (8, (2, 2, 2), (1, 1, 1, 1)), (64, (1, 2, 2), (1, 1, 8, 8)),
-                                        (4, (1, 3, 3), (1, 2, 3, 4))])
-def test_upsample(C, f, shape):
+                                        (4, (1, 3, 3), (1, 2, 3, 4)), (32, (2, 2, 2), (2, 5, 7, 9)),
+                                        (12, (2, 2, 2), (1, 2, 1, 3)), (32, (1, 2, 2), (2, 3, 9, 6))])
+def test_upsample(C, f, shape, generic):
+    """F.interpolate(trilinear) forward / adjoint (reference Upsampler3d, model/unet.py:455-458): the factor-2 kernels
+    (2x2x2 outputs per thread, separable) and, with option upsample_generic = 1, the any-factor gather kernels."""
     ops = _ops()
+    from torch_em_amd import _lib
+    _lib.set_option("upsample_generic", generic)
+    try:
+        _upsample_case(ops, C, f, shape)
+    finally:
+        _lib.set_option("upsample_generic", 0)
+
+
+def _upsample_case(ops, C, f, shape):
     N, D, H, W = shape
     g = torch.Generator().manual_seed(C + sum(f))
     x = torch.randn(N, C, D, H, W, generator=g)

@@ -72,6 +72,8 @@ SIGNATURES = {
     "tem_norm_finalize_partials2": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_float,
                                             c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tem_upsample_fwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
+    "tem_upsample_fwd_stats_ok": (c_int, [c_int] * 4),
+    "tem_upsample_fwd_stats": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp, c_vp]),
     "tem_upsample_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
     "tem_dice_ws": (c_i64, [c_int, c_i64, c_int]),
     "tem_dice_sums": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_i64,

@@ -32,6 +32,7 @@ static const TemOption g_opt_table[TEM_OPT_COUNT] = {
     {"conv1x1_stream", 1},      // TEM_OPT_CONV1X1_STREAM: 1x1x1 convolutions / data gradients as a streaming GEMM (conv1x1_stream.hip)
     {"fwd_ksplit_chunks", 0},   // TEM_OPT_FWD_KSPLIT_CHUNKS: split-K forward launches: at most this many 16-channel chunks per partial (0: heuristic only)
     {"wgrad_cus", 256},         // TEM_OPT_WGRAD_CUS: workgroups the z-sliding weight gradient asks for (one per CU)
+    {"upsample_generic", 0},    // TEM_OPT_UPSAMPLE_GENERIC: 1 = any-factor gather kernels also for factor (1|2, 2, 2) (A/B, tests)
 };
 static long long g_opt_val[TEM_OPT_COUNT];
 static bool g_opt_set[TEM_OPT_COUNT];

@@ -19,6 +19,11 @@ __device__ __forceinline__ void ST4(float* p, float4 v) {
 #endif
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+#ifndef TEM_C1_ABL
+#define TEM_C1_ABL 0   // profiling ablations of the Cin = 1 forward row path: 1 = no output stores, 2 = 3 taps instead of 27
+#endif
+
 __device__ __forceinline__ float act_apply_s(float v, int act) {
     if (act == TEM_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == TEM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
@@ -42,9 +47,10 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
     constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
     constexpr int TZ = 4, TY = 8, TX = 8;
     constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1, HV = HZ * HY * HX;
-    constexpr int HVP = ((HV + 3) / 4) * 4;
+    constexpr int HXP = ((HX + 3) / 4) * 4;   // x rows start on 16 bytes: the row path reads them with ds_read_b128
+    constexpr int HVP = HZ * HY * HXP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lx = lds;              // [CIN][HVP]
+    float* lx = lds;              // [CIN][HZ][HY][HXP]
     float* lw = lds + CIN * HVP;  // [NT][CIN][Cout]
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
@@ -65,61 +71,24 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
             v = x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld + ci];
             if (scale) v = fmaf(v, scale[n * CIN + ci], shift[n * CIN + ci]);
         }
-        lx[ci * HVP + hv] = v;
+        lx[ci * HVP + (hz * HY + hy) * HXP + hx] = v;
     }
     __syncthreads();
     const int cq = Cout >> 2;
     float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;  // fused statistics (cq divides 64: a thread keeps its quad)
-    if constexpr (CIN == 1) {
-        if ((256 % cq) == 0) {
-            // A thread keeps its channel quad (item % cq == tid % cq): its 27 weight quads live in registers, which
-            // removes the per-tap 16-byte LDS read that bounded this kernel (27 x 8 LDS cycles per item-wave).
-            const int q = tid % cq;
-            float4 wr[NT];
-#pragma unroll
-            for (int tap = 0; tap < NT; ++tap) wr[tap] = *reinterpret_cast<const float4*>(lw + tap * Cout + q * 4);
-            const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int p = tid / cq; p < 256; p += 256 / cq) {
-                const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-                const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
-                if (gz >= D || gy >= H || gx >= W) continue;
-                float4 acc = b4;
-                const float* xb = lx + (pz * HY + py) * HX + px;
-#pragma unroll
-                for (int tap = 0; tap < NT; ++tap) {
-                    const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
-                    const float xv = xb[(tz * HY + ty) * HX + tx];
-                    acc.x = fmaf(xv, wr[tap].x, acc.x);
-                    acc.y = fmaf(xv, wr[tap].y, acc.y);
-                    acc.z = fmaf(xv, wr[tap].z, acc.z);
-                    acc.w = fmaf(xv, wr[tap].w, acc.w);
-                }
-                acc.x = act_apply_s(acc.x, act);
-                acc.y = act_apply_s(acc.y, act);
-                acc.z = act_apply_s(acc.z, act);
-                acc.w = act_apply_s(acc.w, act);
-                const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
-                ST4(y + v * y_ld + q * 4, acc);
-                ssum.x += acc.x; ssum.y += acc.y; ssum.z += acc.z; ssum.w += acc.w;
-                ssq.x = fmaf(acc.x, acc.x, ssq.x); ssq.y = fmaf(acc.y, acc.y, ssq.y);
-                ssq.z = fmaf(acc.z, acc.z, ssq.z); ssq.w = fmaf(acc.w, acc.w, ssq.w);
-            }
-            goto stats;
-        }
-    }
     for (int item = tid; item < 256 * cq; item += 256) {
         const int p = item / cq, q = item % cq;
         const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
         const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
         if (gz >= D || gy >= H || gx >= W) continue;
         float4 acc = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* xb = lx + (pz * HY + py) * HX + px;
+        const float* xb = lx + (pz * HY + py) * HXP + px;
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
             const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) {
-                const float xv = xb[ci * HVP + (tz * HY + ty) * HX + tx];
+                const float xv = xb[ci * HVP + (tz * HY + ty) * HXP + tx];
                 const float4 wv = *reinterpret_cast<const float4*>(lw + (tap * CIN + ci) * Cout + q * 4);
                 acc.x = fmaf(xv, wv.x, acc.x);
                 acc.y = fmaf(xv, wv.y, acc.y);
@@ -137,7 +106,6 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
         ssq.x = fmaf(acc.x, acc.x, ssq.x); ssq.y = fmaf(acc.y, acc.y, ssq.y);
         ssq.z = fmaf(acc.z, acc.z, ssq.z); ssq.w = fmaf(acc.w, acc.w, ssq.w);
     }
-stats:
     if (stat) {  // per (sample, patch, channel) partial sums for the next norm (see tem_conv3d_fwd_stats)
         float vals[8] = {ssum.x, ssum.y, ssum.z, ssum.w, ssq.x, ssq.y, ssq.z, ssq.w};
 #pragma unroll
@@ -165,6 +133,138 @@ stats:
     }
 }
 
+// ---------------------------------------------------------------------------
+// Cin == 1, 3x3 in-plane taps, Cout = 2 * 2^k <= 128: the first layer of every U-Net here.  Workgroup = 4x8x32 output
+// tile (4 x-segments of 8 share one halo staging, one weight load and one statistics reduction: at 4x8x8 those fixed
+// costs were half the kernel).  thread <-> (x-row, channel PAIR): the pair's 27 weight pairs and a segment's 8
+// accumulator pairs live in registers (v_pk_fma_f32: two FMAs per lane and issue slot); per (tz, ty) the 10 input values
+// of the segment come from LDS in three wide reads and feed 3 taps x 8 voxels: 27 packed FMAs and 3.4 LDS reads per
+// voxel-pair where the voxel-per-thread kernel had 54 scalar FMAs and 27 reads.
+// ---------------------------------------------------------------------------
+#define C1R_TXW 32
+template <int KD>
+__global__ __launch_bounds__(256) void k_conv_fwd_c1rows(const float* __restrict__ x, int64_t x_ld,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ w /*[tap][co]*/,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int64_t y_ld, int N, int D, int H, int W, int Cout, int act,
+                                                         int nZ, int nY, int nX, float* __restrict__ stat) {
+    constexpr int NT = KD * 9, PZ = KD / 2;
+    constexpr int TZ = 4, TY = 8, TX = 8, HZ = TZ + KD - 1, HY = TY + 2, HXW = C1R_TXW + 2, HXP = C1R_TXW + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lx = lds;                  // [HZ][HY][HXP]
+    float* lw = lds + HZ * HY * HXP;  // [NT][Cout]
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int ptx = bid % nX;
+    bid /= nX;
+    const int pty = bid % nY;
+    bid /= nY;
+    const int ptz = bid % nZ;
+    const int n = bid / nZ;
+    const int z0 = ptz * TZ, y0 = pty * TY, x0 = ptx * C1R_TXW;
+    for (int i = tid; i < NT * Cout; i += 256) lw[i] = w[i];
+    {
+        float sc = 1.f, sf = 0.f;
+        if (scale) {
+            sc = scale[n];
+            sf = shift[n];
+        }
+        for (int hv = tid; hv < HZ * HY * HXW; hv += 256) {
+            const int hr = hv / HXW, hx = hv % HXW, hz = hr / HY, hy = hr % HY;
+            const int gz = z0 + hz - PZ, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            float v = 0.f;
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = fmaf(x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld], sc, sf);
+            lx[hr * HXP + hx] = v;
+        }
+    }
+    __syncthreads();
+    const int cp = Cout >> 1;
+    const int q = tid % cp;
+    f2 wr[NT];
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) wr[tap] = *reinterpret_cast<const f2*>(lw + tap * Cout + q * 2);
+    const f2 b2 = bias ? *reinterpret_cast<const f2*>(bias + q * 2) : f2{0.f, 0.f};
+    f2 ss = {0.f, 0.f}, sq = ss;
+    // (Storing a segment's outputs one by one behind the next segment's FMA groups instead of back to back at its end was
+    // measured equal -- 182 vs 176 us at 2x128^3: FMA time and store time add up either way, the issuing waves wait on
+    // the write path.)
+#pragma unroll 1
+    for (int row = tid / cp; row < TZ * TY; row += 256 / cp) {
+        const int pz = row / TY, py = row % TY;
+        const int gz = z0 + pz, gy = y0 + py;
+        if (gz >= D || gy >= H) continue;
+#pragma unroll 1
+        for (int xs = 0; xs < C1R_TXW && x0 + xs < W; xs += TX) {
+            f2 acc[TX];
+#pragma unroll
+            for (int px = 0; px < TX; ++px) acc[px] = b2;
+#pragma unroll
+            for (int tz = 0; tz < ((TEM_C1_ABL & 2) ? 1 : KD); ++tz)
+#pragma unroll
+                for (int ty = 0; ty < ((TEM_C1_ABL & 2) ? 1 : 3); ++ty) {
+                    const float* xr = lx + ((pz + tz) * HY + py + ty) * HXP + xs;
+                    const float4 a = *reinterpret_cast<const float4*>(xr);
+                    const float4 b = *reinterpret_cast<const float4*>(xr + 4);
+                    const float2 c = *reinterpret_cast<const float2*>(xr + 8);
+                    const float xv[10] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y};
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                        for (int px = 0; px < TX; ++px)
+                            acc[px] = __builtin_elementwise_fma(wr[(tz * 3 + ty) * 3 + tx], f2{xv[px + tx], xv[px + tx]}, acc[px]);
+                }
+            const int64_t v0 = (((int64_t)n * D + gz) * H + gy) * W + x0 + xs;
+            // pin the accumulators here: otherwise the 27 FMAs of a voxel sink into its store branch below and all
+            // 90 row values stay live across them (183 VGPRs)
+#pragma unroll
+            for (int px = 0; px < TX; ++px) asm volatile("" : "+v"(acc[px]));
+#pragma unroll
+            for (int px = 0; px < TX; ++px) {
+                if (x0 + xs + px >= W) break;
+                const f2 o = {act_apply_s(acc[px].x, act), act_apply_s(acc[px].y, act)};
+#if !(TEM_C1_ABL & 1)
+                *reinterpret_cast<f2*>(y + (v0 + px) * y_ld + q * 2) = o;
+#endif
+                ss += o;
+                sq = __builtin_elementwise_fma(o, o, sq);
+            }
+        }
+    }
+    if (stat) {  // per (sample, tile, channel) partial sums for the next norm (see tem_conv3d_fwd_stats)
+        float vals[4] = {ss.x, ss.y, sq.x, sq.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (int o = cp; o < 64; o <<= 1) vals[j] += __shfl_xor(vals[j], o, 64);  // lanes sharing q sit cp apart
+        __syncthreads();
+        float* red = lds;  // [4 waves][cp][4]
+        const int wv = tid >> 6, lane = tid & 63;
+        if (lane < cp)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(wv * cp + lane) * 4 + j] = vals[j];
+        __syncthreads();
+        if (tid < Cout) {
+            const int pr = tid >> 1, j = tid & 1;
+            float sa = 0.f, sb = 0.f;
+            for (int w4 = 0; w4 < 4; ++w4) {
+                sa += red[(w4 * cp + pr) * 4 + j];
+                sb += red[(w4 * cp + pr) * 4 + 2 + j];
+            }
+            const int64_t patch = ((int64_t)ptz * nY + pty) * nX + ptx;
+            float* dst = stat + ((((int64_t)n * nZ * nY * nX) + patch) * Cout + tid) * 2;
+            dst[0] = sa;
+            dst[1] = sb;
+        }
+    }
+}
+
+static inline bool c1rows_ok(int Cin, int Cout, int kh, int kw) {
+    const int cp = Cout / 2;
+    return Cin == 1 && kh == 3 && kw == 3 && Cout % 2 == 0 && cp >= 1 && cp <= 64 && (cp & (cp - 1)) == 0;
+}
+
 // blocks per sample of the fused statistics, 0 when the cin1 kernel does not take this shape / cannot keep a channel
 // quad per thread
 int64_t tem_conv_fwd_cin1_stat_blocks(int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
@@ -172,7 +272,8 @@ int64_t tem_conv_fwd_cin1_stat_blocks(int D, int H, int W, int Cin, int Cout, in
     if (Cin > 4 || Cout % 4 || Cin * Cout > 128 || cq > 64 || (cq & (cq - 1))) return 0;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     if (key != 7 && key != 3) return 0;
-    return (int64_t)((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
+    const int tx = c1rows_ok(Cin, Cout, kh, kw) ? C1R_TXW : 8;
+    return (int64_t)((D + 3) / 4) * ((H + 7) / 8) * ((W + tx - 1) / tx);
 }
 
 bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w,
@@ -184,11 +285,24 @@ bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const f
         return false;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     if (key != 7 && key != 3) return false;
+    if (c1rows_ok(Cin, Cout, kh, kw) && y_ld % 2 == 0) {
+        const int nZ = (D + 3) / 4, nY = (H + 7) / 8, nX = (W + C1R_TXW - 1) / C1R_TXW;
+        const int64_t nblk = (int64_t)N * nZ * nY * nX;
+        const int kdv = key == 7 ? 3 : 1;
+        const size_t ldsb = (size_t)((kdv + 3) * 10 * (C1R_TXW + 4) + kdv * 9 * Cout) * sizeof(float);
+        if (key == 7)
+            hipLaunchKernelGGL((k_conv_fwd_c1rows<3>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, shift, w,
+                               bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat);
+        else
+            hipLaunchKernelGGL((k_conv_fwd_c1rows<1>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, shift, w,
+                               bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat);
+        return true;
+    }
     const int nZ = (D + 3) / 4, nY = (H + 7) / 8, nX = (W + 7) / 8;
     const int64_t nblk = (int64_t)N * nZ * nY * nX;
 #define C1(KD_, CI)                                                                                                   \
     case CI: {                                                                                                        \
-        size_t ldsb = (size_t)(CI * ((((KD_ + 3) * 10 * 10 + 3) / 4) * 4) + KD_ * 9 * CI * Cout) * sizeof(float);     \
+        size_t ldsb = (size_t)(CI * ((KD_ + 3) * 10 * 12) + KD_ * 9 * CI * Cout) * sizeof(float);                    \
         hipLaunchKernelGGL((k_conv_fwd_cin1<KD_, 3, 3, CI>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, \
                            shift, w, bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat);                         \
     } break;
@@ -288,8 +402,9 @@ bool tem_conv_fwd_cout1(const float* x, int64_t x_ld, const float* scale, const 
 
 // ---------------------------------------------------------------------------
 // Cin == 1 weight gradient: dw[tap][co] = sum_v xhat[v+tap] * g[v][co]  (+ db[co] = sum_v g).
-// Persistent workgroups walk 4x8x8 patches; thread <-> (voxel lane, co quad) keeps NT x 4
-// accumulators in registers, g is read once with 16-byte loads; one reduction at the end.
+// Persistent workgroups walk 4x8x8 patches; thread <-> (x-row of 8 voxels, co PAIR) keeps NT + 1 accumulator pairs in
+// registers (v_pk_fma_f32), reads its 8 g pairs once with 8-byte loads (16 lanes = one 128-byte line per voxel) and the
+// row's 10 input values per (tz, ty) from LDS in three wide reads; one reduction at the end.
 // ---------------------------------------------------------------------------
 template <int KD, int KH, int KW>
 __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict__ x, int64_t x_ld,
@@ -301,18 +416,19 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
                                                          int nX, int sstride /*Cin: scale[n*Cin] of this channel*/,
                                                          const float* __restrict__ gnx, int64_t gnx_ld,
                                                          const float* __restrict__ gcoef) {
+    static_assert(KH == 3 && KW == 3, "row layout: 3x3 in-plane taps");
     constexpr int NT = KD * KH * KW;
-    constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
+    constexpr int PZ = KD / 2, PY = 1, PX = 1;
     constexpr int TZ = 4, TY = 8, TX = 8;
-    constexpr int HZ = TZ + KD - 1, HY = TY + KH - 1, HX = TX + KW - 1, HV = HZ * HY * HX;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(HV, 4*(NT+1)*Cout)
+    constexpr int HZ = TZ + KD - 1, HY = TY + 2, HX = TX + 2, HXP = 12, HV = HZ * HY * HX;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(HZ*HY*HXP, 4*(NT+1)*Cout)
     const int tid = threadIdx.x;
-    const int cq = Cout >> 2;       // power of two, <= 16
-    const int q = tid % cq, vl = tid / cq;
-    const int nvl = 256 / cq;       // voxel lanes per workgroup
-    float4 acc[NT + 1];
+    const int cp = Cout >> 1;       // power of two, <= 32
+    const int q = tid % cp, rl = tid / cp;
+    const int nrl = 256 / cp;       // rows per pass
+    f2 acc[NT + 1];
 #pragma unroll
-    for (int t = 0; t <= NT; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t <= NT; ++t) acc[t] = f2{0.f, 0.f};
     for (int pidx = blockIdx.x; pidx < P; pidx += gridDim.x) {
         int b = pidx;
         const int ptx = b % nX;
@@ -329,10 +445,10 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
         }
         // g may still be the RAW data gradient behind the norm that follows this conv's ReLU (tem_conv3d_wgrad_gnorm):
         // g := (y > 0) ? a*g - m1 - (y - mean)*m2r : 0 with y = this conv's output (gnx), applied while loading
-        float4 kc[4];
+        float4 kc[2];
         if (gcoef) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) kc[j] = *reinterpret_cast<const float4*>(gcoef + ((int64_t)n * Cout + q * 4 + j) * 4);
+            for (int j = 0; j < 2; ++j) kc[j] = *reinterpret_cast<const float4*>(gcoef + ((int64_t)n * Cout + q * 2 + j) * 4);
         }
         __syncthreads();
         for (int hv = tid; hv < HV; hv += 256) {
@@ -341,71 +457,65 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
             float v = 0.f;
             if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
                 v = fmaf(x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld], sc, sf);
-            lds[hv] = v;
+            lds[(hz * HY + hy) * HXP + hx] = v;
         }
         __syncthreads();
-        // software pipeline over the patch voxels of this lane: the loads of voxel p + nvl are issued before the 27-tap
-        // FMA block of voxel p (they used to sit behind it: one exposed HBM round trip per voxel)
-        auto load_g = [&](int p, float4& gv, float4& yv, bool& ok) {
-            const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-            const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
-            ok = p < 256 && gz < D && gy < H && gx < W;
-            gv = make_float4(0.f, 0.f, 0.f, 0.f);
-            yv = gv;
-            if (ok) {
-                const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
-                gv = *reinterpret_cast<const float4*>(g + v * g_ld + q * 4);
-                if (gcoef) yv = *reinterpret_cast<const float4*>(gnx + v * gnx_ld + q * 4);
-            }
-        };
-        float4 gv_n, yv_n;
-        bool ok_n;
-        load_g(vl, gv_n, yv_n, ok_n);
-        for (int p = vl; p < 256; p += nvl) {
-            const int pz = p / (TY * TX), py = (p / TX) % TY, px = p % TX;
-            float4 gv = gv_n;
-            const float4 yv = yv_n;
-            const bool ok = ok_n;
-            load_g(p + nvl, gv_n, yv_n, ok_n);
-            if (!ok) continue;
-            if (gcoef) {
-                gv.x = yv.x > 0.f ? kc[0].x * gv.x - kc[0].y - (yv.x - kc[0].w) * kc[0].z : 0.f;
-                gv.y = yv.y > 0.f ? kc[1].x * gv.y - kc[1].y - (yv.y - kc[1].w) * kc[1].z : 0.f;
-                gv.z = yv.z > 0.f ? kc[2].x * gv.z - kc[2].y - (yv.z - kc[2].w) * kc[2].z : 0.f;
-                gv.w = yv.w > 0.f ? kc[3].x * gv.w - kc[3].y - (yv.w - kc[3].w) * kc[3].z : 0.f;
-            }
-            const float* xb = lds + (pz * HY + py) * HX + px;
+        for (int row = rl; row < TZ * TY; row += nrl) {
+            const int pz = row / TY, py = row % TY;
+            const int gz = z0 + pz, gy = y0 + py;
+            if (gz >= D || gy >= H) continue;
+            const int64_t v0 = (((int64_t)n * D + gz) * H + gy) * W + x0;
+            f2 gv[TX], yv[TX];
 #pragma unroll
-            for (int tap = 0; tap < NT; ++tap) {
-                const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
-                const float xv = xb[(tz * HY + ty) * HX + tx];
-                acc[tap].x = fmaf(xv, gv.x, acc[tap].x);
-                acc[tap].y = fmaf(xv, gv.y, acc[tap].y);
-                acc[tap].z = fmaf(xv, gv.z, acc[tap].z);
-                acc[tap].w = fmaf(xv, gv.w, acc[tap].w);
+            for (int px = 0; px < TX; ++px) {     // branch-free: a voxel beyond W reads the row's first one and is zeroed
+                const int pc = x0 + px < W ? px : 0;
+                gv[px] = *reinterpret_cast<const f2*>(g + (v0 + pc) * g_ld + q * 2);
+                yv[px] = gcoef ? *reinterpret_cast<const f2*>(gnx + (v0 + pc) * gnx_ld + q * 2) : f2{0.f, 0.f};
             }
-            acc[NT].x += gv.x;
-            acc[NT].y += gv.y;
-            acc[NT].z += gv.z;
-            acc[NT].w += gv.w;
+#pragma unroll
+            for (int px = 0; px < TX; ++px)
+                if (x0 + px >= W) gv[px] = f2{0.f, 0.f};
+            if (gcoef) {
+#pragma unroll
+                for (int px = 0; px < TX; ++px) {
+                    gv[px].x = yv[px].x > 0.f ? kc[0].x * gv[px].x - kc[0].y - (yv[px].x - kc[0].w) * kc[0].z : 0.f;
+                    gv[px].y = yv[px].y > 0.f ? kc[1].x * gv[px].y - kc[1].y - (yv[px].y - kc[1].w) * kc[1].z : 0.f;
+                    if (x0 + px >= W) gv[px] = f2{0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int tz = 0; tz < KD; ++tz)
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) {
+                    const float* xr = lds + ((pz + tz) * HY + py + ty) * HXP;
+                    const float4 a = *reinterpret_cast<const float4*>(xr);
+                    const float4 bq = *reinterpret_cast<const float4*>(xr + 4);
+                    const float2 c = *reinterpret_cast<const float2*>(xr + 8);
+                    const float xv[10] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, c.x, c.y};
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                        for (int px = 0; px < TX; ++px)
+                            acc[(tz * 3 + ty) * 3 + tx] = __builtin_elementwise_fma(gv[px], f2{xv[px + tx], xv[px + tx]},
+                                                                                    acc[(tz * 3 + ty) * 3 + tx]);
+                }
+#pragma unroll
+            for (int px = 0; px < TX; ++px) acc[NT] += gv[px];
         }
     }
-    // reduce over the voxel lanes: lanes sharing q inside a wave sit cq apart
+    // reduce over the row lanes: lanes sharing q inside a wave sit cp apart
 #pragma unroll
     for (int t = 0; t <= NT; ++t) {
-        for (int o = cq; o < 64; o <<= 1) {
+        for (int o = cp; o < 64; o <<= 1) {
             acc[t].x += __shfl_xor(acc[t].x, o, 64);
             acc[t].y += __shfl_xor(acc[t].y, o, 64);
-            acc[t].z += __shfl_xor(acc[t].z, o, 64);
-            acc[t].w += __shfl_xor(acc[t].w, o, 64);
         }
     }
     __syncthreads();
     const int wv = tid >> 6, lane = tid & 63;
-    if (lane < cq) {
+    if (lane < cp) {
 #pragma unroll
-        for (int t = 0; t <= NT; ++t)
-            *reinterpret_cast<float4*>(lds + ((wv * (NT + 1) + t) * Cout) + lane * 4) = acc[t];
+        for (int t = 0; t <= NT; ++t) *reinterpret_cast<f2*>(lds + ((wv * (NT + 1) + t) * Cout) + lane * 2) = acc[t];
     }
     __syncthreads();
     for (int i = tid; i < (NT + 1) * Cout; i += 256) {
@@ -705,11 +815,11 @@ bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const
         const float* sc = scale ? scale + ci : nullptr;
         const float* sf = scale ? shift + ci : nullptr;
         if (key == 7) {
-            size_t ldsf = 6 * 10 * 10 > 4 * (NT + 1) * Cout ? 6 * 10 * 10 : 4 * (NT + 1) * Cout;
+            size_t ldsf = 6 * 10 * 12 > 4 * (NT + 1) * Cout ? 6 * 10 * 12 : 4 * (NT + 1) * Cout;
             hipLaunchKernelGGL((k_conv_wgrad_cin1<3, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x + ci, x_ld, sc,
                                sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin, gnx, gnx_ld, gcoef);
         } else {
-            size_t ldsf = 4 * 10 * 10 > 4 * (NT + 1) * Cout ? 4 * 10 * 10 : 4 * (NT + 1) * Cout;
+            size_t ldsf = 4 * 10 * 12 > 4 * (NT + 1) * Cout ? 4 * 10 * 12 : 4 * (NT + 1) * Cout;
             hipLaunchKernelGGL((k_conv_wgrad_cin1<1, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x + ci, x_ld, sc,
                                sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin, gnx, gnx_ld, gcoef);
         }

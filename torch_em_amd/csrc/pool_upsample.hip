@@ -541,6 +541,304 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Factor-2 fast paths (fy = fx = 2, fz = 1 or 2: every sampler of the U-Nets, reference model/unet.py:455-458).
+// The generic kernels above gather per output element: 8 coarse loads per fine voxel forward, 64 fine loads per coarse
+// voxel backward -- both bound by the texture-address path (16 B x 64 lanes per load instruction), 3-4x off the HBM
+// time.  Here a thread owns a 2x2x2 block of outputs and evaluates the interpolation separably (x, then y, then z) in
+// registers: 27 loads per 8 outputs forward, 216 per 8 backward (27 per output).
+//   fine o = 2i reads coarse (i-1, i) with (0.25, 0.75) -- (x[0], x[0]) with (1, 0) at i = 0; o = 2i+1 reads (i, i+1) with
+//   (0.75, 0.25), i+1 clamped: area_pixel_compute_source_index for scale 1/2, as lin_src().
+// ---------------------------------------------------------------------------
+struct F4 {
+    float v[4];
+};
+__device__ __forceinline__ F4 ld4(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    return F4{{t.x, t.y, t.z, t.w}};
+}
+__device__ __forceinline__ void st4(float* p, const F4& a) { *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
+__device__ __forceinline__ F4 lerp2(float l0, const F4& a, float l1, const F4& b) {
+    F4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.v[j] = l0 * a.v[j] + l1 * b.v[j];
+    return r;
+}
+
+// forward; optionally the (sum y, sum y^2) partials of the block's coarse row [N][D*H][C][2] (what tem_upsample_stats
+// derives from u with a 27-point stencil: here the outputs are in registers anyway)
+template <int FZ>
+__global__ __launch_bounds__(256) void k_upsample2_fwd(const float* __restrict__ x, int64_t x_ld, float* __restrict__ y,
+                                                       int64_t y_ld, int D, int H, int W, int C,
+                                                       float* __restrict__ part) {
+    extern __shared__ float lsu[];  // [4 waves][C][2] when part
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int cq = C >> 2;
+    int row = blockIdx.x;  // (n, zi, yi) of the coarse grid
+    const int yi = row % H;
+    row /= H;
+    const int zi = row % D;
+    const int n = row / D;
+    const int ym = max(yi - 1, 0), yp = min(yi + 1, H - 1);
+    const int zm = max(zi - 1, 0), zp = min(zi + 1, D - 1);
+    const float ya0 = yi == 0 ? 1.f : 0.25f, ya1 = yi == 0 ? 0.f : 0.75f;   // fine 2yi: (ym, yi)
+    const float za0 = zi == 0 ? 1.f : 0.25f, za1 = zi == 0 ? 0.f : 0.75f;
+    const int zrow[3] = {zm, zi, zp}, yrow[3] = {ym, yi, yp};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < W * cq; i += 256) {
+        const int xi = i / cq, c0 = (i % cq) * 4;
+        const int xm = max(xi - 1, 0), xp = min(xi + 1, W - 1);
+        const float xa0 = xi == 0 ? 1.f : 0.25f, xa1 = xi == 0 ? 0.f : 0.75f;
+        F4 Y[FZ == 2 ? 3 : 1][2][2];  // [coarse z][fine y parity][fine x parity]
+#pragma unroll
+        for (int kz = 0; kz < (FZ == 2 ? 3 : 1); ++kz) {
+            const int zc = FZ == 2 ? zrow[kz] : zi;
+            F4 X[3][2];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* r = x + ((((int64_t)n * D + zc) * H + yrow[ky]) * W) * x_ld + c0;
+                const F4 a = ld4(r + (int64_t)xm * x_ld), b = ld4(r + (int64_t)xi * x_ld), c = ld4(r + (int64_t)xp * x_ld);
+                X[ky][0] = lerp2(xa0, a, xa1, b);
+                X[ky][1] = lerp2(0.75f, b, 0.25f, c);
+            }
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                Y[kz][0][sx] = lerp2(ya0, X[0][sx], ya1, X[1][sx]);
+                Y[kz][1][sx] = lerp2(0.75f, X[1][sx], 0.25f, X[2][sx]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one plane's 9 loads in flight, not all 27 (184 VGPRs)
+        }
+#pragma unroll
+        for (int sz = 0; sz < FZ; ++sz)
+#pragma unroll
+            for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    F4 o;
+                    if constexpr (FZ == 2)
+                        o = sz == 0 ? lerp2(za0, Y[0][sy][sx], za1, Y[1][sy][sx]) : lerp2(0.75f, Y[1][sy][sx], 0.25f, Y[2][sy][sx]);
+                    else
+                        o = Y[0][sy][sx];
+                    const int64_t vo = (((int64_t)n * (D * FZ) + zi * FZ + sz) * Ho + 2 * yi + sy) * Wo + 2 * xi + sx;
+                    st4(y + vo * y_ld + c0, o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s1[j] += o.v[j];
+                        s2[j] = fmaf(o.v[j], o.v[j], s2[j]);
+                    }
+                }
+    }
+    if (part) {
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            for (int o = cq; o < 64; o <<= 1) {  // lanes sharing a quad sit cq apart (256 % cq == 0)
+                s1[j] += __shfl_xor(s1[j], o, 64);
+                s2[j] += __shfl_xor(s2[j], o, 64);
+            }
+            if (lane < cq) {
+                lsu[(wv * C + lane * 4 + j) * 2 + 0] = s1[j];
+                lsu[(wv * C + lane * 4 + j) * 2 + 1] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * C; t += 256) {
+            float a = 0.f;
+            for (int w4 = 0; w4 < 4; ++w4) a += lsu[w4 * 2 * C + t];
+            part[((int64_t)n * D * H + (int64_t)zi * H + yi) * 2 * C + t] = a;
+        }
+    }
+}
+
+// One axis of the adjoint for a coarse pair (i0, i0 + 1) at factor 2: the 6 fine positions 2*i0 - 1 + k and, per coarse
+// c, the weights of k = 2c .. 2c + 3 (zero outside the volume / for a pair's missing second element).
+struct UpbAxis {
+    int idx[6];
+    float w[2][4];
+};
+__device__ __forceinline__ UpbAxis upb_axis2(int i0, int in) {
+    UpbAxis a;
+    const int out = 2 * in;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.idx[k] = min(max(2 * i0 - 1 + k, 0), out - 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = 2 * i0 - 1 + 2 * c + k;
+            a.w[c][k] = (o >= 0 && o < out && i0 + c < in) ? lin_w(o, 2, in, i0 + c) : 0.f;
+        }
+    return a;
+}
+// weight of fine position o (factor 2) in coarse i's adjoint; 0 outside the volume / for a missing pair element
+__device__ __forceinline__ float upb_w(int o, int in, int i) {
+    return (o >= 0 && o < 2 * in && i < in) ? lin_w(o, 2, in, i) : 0.f;
+}
+// a[d] for d in 0..2, else 0 -- without a dynamically indexed register array
+__device__ __forceinline__ float pick3(const float (&a)[3], int d) {
+    return d == 0 ? a[0] : d == 1 ? a[1] : d == 2 ? a[2] : 0.f;
+}
+// (U^T U)[i][i + d] and (U^T 1)[i] for the pair: positions i0 - 1 + k, k = 0..3; coarse c uses k = c .. c + 2
+struct UtuAxis {
+    int idx[4];
+    float a[2][3];
+    float s[2];
+};
+__device__ __forceinline__ UtuAxis utu_axis2(int i0, int f, int in) {
+    UtuAxis r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.idx[k] = min(max(i0 - 1 + k, 0), in - 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        r.a[c][0] = r.a[c][1] = r.a[c][2] = 0.f;
+        r.s[c] = 0.f;
+        if (i0 + c < in) utu_axis(i0 + c, f, in, r.a[c], r.s[c]);
+    }
+    return r;
+}
+
+template <int FZ>
+__global__ __launch_bounds__(256) void k_upsample2_bwd(const float* __restrict__ gy, int64_t gy_ld,
+                                                       float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
+                                                       const float* __restrict__ u, int64_t u_ld,
+                                                       const float* __restrict__ ncoef, int64_t ncoef_ld) {
+    constexpr int CZ = FZ == 2 ? 2 : 1;      // coarse z per thread
+    constexpr int NZF = FZ == 2 ? 6 : 1;     // fine z planes it reads
+    const int Do = D * FZ, Ho = 2 * H, Wo = 2 * W;
+    const int cq = C >> 2;
+    const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1, Dp = (D + CZ - 1) / CZ;
+    int row = blockIdx.x;  // (n, z pair, y pair) of the coarse grid
+    const int y0 = (row % Hp) * 2;
+    row /= Hp;
+    const int z0 = (row % Dp) * CZ;
+    const int n = row / Dp;
+    for (int i = threadIdx.x; i < Wp * cq; i += 256) {
+        const int x0 = (i / cq) * 2, c0 = (i % cq) * 4;
+        const UpbAxis ax = upb_axis2(x0, W);
+        F4 acc[CZ][2][2];
+#pragma unroll
+        for (int a = 0; a < CZ; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[a][b][c] = F4{{0.f, 0.f, 0.f, 0.f}};
+        // the z and y loops stay rolled (plane / row index and weights recomputed from the loop counter: wave-uniform
+        // scalar work): unrolled, the 216 loads and their addresses were all hoisted (500 VGPRs, occupancy 1)
+#pragma unroll 1
+        for (int kz = 0; kz < NZF; ++kz) {
+            const int oz = FZ == 2 ? 2 * z0 - 1 + kz : z0;
+            const int zf = min(max(oz, 0), Do - 1);
+            float wz[CZ];
+#pragma unroll
+            for (int a = 0; a < CZ; ++a) wz[a] = FZ == 2 ? upb_w(oz, D, z0 + a) : 1.f;
+            F4 pp[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) pp[b][c] = F4{{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+            for (int ky = 0; ky < 6; ++ky) {
+                const int oy = 2 * y0 - 1 + ky;
+                const float wy[2] = {upb_w(oy, H, y0), upb_w(oy, H, y0 + 1)};
+                const float* r = gy + ((((int64_t)n * Do + zf) * Ho + min(max(oy, 0), Ho - 1)) * Wo) * gy_ld + c0;
+                F4 t[6];
+#pragma unroll
+                for (int kx = 0; kx < 6; ++kx) t[kx] = ld4(r + (int64_t)ax.idx[kx] * gy_ld);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xr = ax.w[c][0] * t[2 * c].v[j] + ax.w[c][1] * t[2 * c + 1].v[j] +
+                                         ax.w[c][2] * t[2 * c + 2].v[j] + ax.w[c][3] * t[2 * c + 3].v[j];
+                        pp[0][c].v[j] = fmaf(wy[0], xr, pp[0][c].v[j]);
+                        pp[1][c].v[j] = fmaf(wy[1], xr, pp[1][c].v[j]);
+                    }
+            }
+#pragma unroll
+            for (int a = 0; a < CZ; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[a][b][c].v[j] = fmaf(wz[a], pp[b][c].v[j], acc[a][b][c].v[j]);
+        }
+        if (ncoef) {
+            // U^T(norm backward(g)) = a*U^T g - m1*U^T 1 - m2r*(U^T U u - mean*U^T 1) (see k_upsample_bwd): the 27-point
+            // stencil on u, separably over the pair's 4x4x4 neighbourhood
+            const UtuAxis bx = utu_axis2(x0, 2, W), by = utu_axis2(y0, 2, H), bz = utu_axis2(z0, FZ, D);
+            F4 q[CZ][2][2];
+#pragma unroll
+            for (int a = 0; a < CZ; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) q[a][b][c] = F4{{0.f, 0.f, 0.f, 0.f}};
+            constexpr int NZU = FZ == 2 ? 4 : 1;
+#pragma unroll 1
+            for (int kz = 0; kz < NZU; ++kz) {
+                const int zc = FZ == 2 ? min(max(z0 - 1 + kz, 0), D - 1) : z0;
+                float wz[CZ];
+#pragma unroll
+                for (int a = 0; a < CZ; ++a) wz[a] = FZ == 2 ? pick3(bz.a[a], kz - a) : 1.f;
+                F4 qp[2][2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) qp[b][c] = F4{{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+                for (int ky = 0; ky < 4; ++ky) {
+                    const float wy[2] = {pick3(by.a[0], ky), pick3(by.a[1], ky - 1)};
+                    const float* r = u + ((((int64_t)n * D + zc) * H + min(max(y0 - 1 + ky, 0), H - 1)) * W) * u_ld + c0;
+                    F4 t[4];
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) t[kx] = ld4(r + (int64_t)bx.idx[kx] * u_ld);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xr = bx.a[c][0] * t[c].v[j] + bx.a[c][1] * t[c + 1].v[j] + bx.a[c][2] * t[c + 2].v[j];
+                            qp[0][c].v[j] = fmaf(wy[0], xr, qp[0][c].v[j]);
+                            qp[1][c].v[j] = fmaf(wy[1], xr, qp[1][c].v[j]);
+                        }
+                }
+#pragma unroll
+                for (int a = 0; a < CZ; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) q[a][b][c].v[j] = fmaf(wz[a], qp[b][c].v[j], q[a][b][c].v[j]);
+            }
+            float4 kc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kc[j] = *reinterpret_cast<const float4*>(ncoef + (int64_t)n * ncoef_ld + (c0 + j) * 4);
+#pragma unroll
+            for (int a = 0; a < CZ; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float S = (FZ == 2 ? bz.s[a] : 1.f) * by.s[b] * bx.s[c];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[a][b][c].v[j] = kc[j].x * acc[a][b][c].v[j] - kc[j].y * S - kc[j].z * (q[a][b][c].v[j] - kc[j].w * S);
+                    }
+        }
+#pragma unroll
+        for (int a = 0; a < CZ; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (z0 + a >= D || y0 + b >= H || x0 + c >= W) continue;
+                    const int64_t v = (((int64_t)n * D + z0 + a) * H + y0 + b) * W + x0 + c;
+                    st4(gx + v * gx_ld + c0, acc[a][b][c]);
+                }
+    }
+}
+
 // Statistics of y = upsample(u) WITHOUT reading y: sum_o y[o] = sum_i (U^T 1)[i] u[i] and sum_o y[o]^2 = sum_i u[i] (U^T U u)[i]
 // -- the same low-resolution 27-point stencil as tem_upsample_bwd_norm.  One block per low-resolution row (n, z, y);
 // part: [N][D*H][C][2] partial sums (sum y, sum y^2) in the layout tem_norm_finalize_partials2 merges.
@@ -632,6 +930,38 @@ extern "C" int tem_upsample_stats(const float* u, int64_t u_ld, int N, int D, in
     return TEM_OK;
 }
 
+// the factor-2 kernels: 16-byte channel quads, and (for the row partials) a quad per lane: C = 4 * 2^k <= 256
+static inline bool upsample2_ok(int C, int fz, int fy, int fx) {
+    return fy == 2 && fx == 2 && (fz == 1 || fz == 2) && C % 4 == 0 && !tem_option(TEM_OPT_UPSAMPLE_GENERIC);
+}
+
+// tem_upsample_fwd that also returns the first stage of y's statistics: part [N][D*H][C][2] (sum y, sum y^2 per coarse
+// row -- the layout of tem_upsample_stats, which it replaces when the factor-2 kernel takes the shape).  Returns
+// TEM_EINVAL when it does not (query tem_upsample_fwd_stats_ok first).
+extern "C" int tem_upsample_fwd_stats_ok(int C, int fz, int fy, int fx) {
+    const int cq = C / 4;
+    return upsample2_ok(C, fz, fy, fx) && cq <= 64 && (cq & (cq - 1)) == 0;
+}
+
+extern "C" int tem_upsample_fwd_stats(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W,
+                                      int C, int fz, int fy, int fx, float* part, tem_stream_t stream) {
+    TEM_REQUIRE(x && y && part && N > 0 && C > 0 && x_ld >= C && y_ld >= C && D > 0 && H > 0 && W > 0,
+                "tem_upsample_fwd_stats: bad arguments");
+    TEM_REQUIRE(tem_upsample_fwd_stats_ok(C, fz, fy, fx) && vec4_ok(C, {x, y}, {x_ld, y_ld}),
+                "tem_upsample_fwd_stats: needs factors (1|2, 2, 2), C = 4 * 2^k <= 256 and 16-byte aligned rows");
+    const int64_t crow = (int64_t)N * D * H;
+    TEM_REQUIRE(crow < (1ll << 31), "tem_upsample_fwd_stats: too many rows");
+    const size_t ldsb = (size_t)4 * C * 2 * sizeof(float);
+    if (fz == 2)
+        hipLaunchKernelGGL((k_upsample2_fwd<2>), dim3((unsigned)crow), dim3(256), ldsb, (hipStream_t)stream, x, x_ld, y, y_ld,
+                           D, H, W, C, part);
+    else
+        hipLaunchKernelGGL((k_upsample2_fwd<1>), dim3((unsigned)crow), dim3(256), ldsb, (hipStream_t)stream, x, x_ld, y, y_ld,
+                           D, H, W, C, part);
+    TEM_CHECK_LAUNCH("tem_upsample_fwd_stats");
+    return TEM_OK;
+}
+
 extern "C" int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C,
                                 int fz, int fy, int fx, tem_stream_t stream) {
     TEM_REQUIRE(x && y && N > 0 && C > 0 && x_ld >= C && y_ld >= C && D > 0 && H > 0 && W > 0,
@@ -639,7 +969,15 @@ extern "C" int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t 
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0, "tem_upsample_fwd: bad factors");
     int64_t rows = (int64_t)N * D * fz * H * fy;
     TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_fwd: too many rows");
-    if (vec4_ok(C, {x, y}, {x_ld, y_ld}))
+    if (upsample2_ok(C, fz, fy, fx) && vec4_ok(C, {x, y}, {x_ld, y_ld})) {
+        const int64_t crow = (int64_t)N * D * H;
+        if (fz == 2)
+            hipLaunchKernelGGL((k_upsample2_fwd<2>), dim3((unsigned)crow), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
+                               y_ld, D, H, W, C, (float*)nullptr);
+        else
+            hipLaunchKernelGGL((k_upsample2_fwd<1>), dim3((unsigned)crow), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
+                               y_ld, D, H, W, C, (float*)nullptr);
+    } else if (vec4_ok(C, {x, y}, {x_ld, y_ld}))
         hipLaunchKernelGGL((k_upsample_fwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
                            y_ld, D, H, W, C, fz, fy, fx);
     else
@@ -657,7 +995,19 @@ static int upsample_bwd_impl(const float* gy, int64_t gy_ld, float* gx, int64_t 
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0, "tem_upsample_bwd: bad factors");
     int64_t rows = (int64_t)N * D * H;
     TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_bwd: too many rows");
-    if (vec4_ok(C, {gy, gx}, {gy_ld, gx_ld}))
+    // the 2x2x2-per-thread kernel has 1/8 of the gather kernel's threads: it needs a volume that still fills the chip
+    const int64_t pairs = (int64_t)N * ((D + fz - 1) / fz) * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    if (upsample2_ok(C, fz, fy, fx) && pairs >= 65536 && vec4_ok(C, {gy, gx, u}, {gy_ld, gx_ld, u_ld})) {
+        if (fz == 2) {
+            const int64_t prow = (int64_t)N * ((D + 1) / 2) * ((H + 1) / 2);
+            hipLaunchKernelGGL((k_upsample2_bwd<2>), dim3((unsigned)prow), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
+                               gx_ld, D, H, W, C, u, u_ld, ncoef, ncoef_ld);
+        } else {
+            const int64_t prow = (int64_t)N * D * ((H + 1) / 2);
+            hipLaunchKernelGGL((k_upsample2_bwd<1>), dim3((unsigned)prow), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
+                               gx_ld, D, H, W, C, u, u_ld, ncoef, ncoef_ld);
+        }
+    } else if (vec4_ok(C, {gy, gx}, {gy_ld, gx_ld}))
         hipLaunchKernelGGL((k_upsample_bwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
                            gx_ld, D, H, W, C, fz, fy, fx, u, u_ld, ncoef, ncoef_ld);
     else

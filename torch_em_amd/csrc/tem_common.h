@@ -18,6 +18,7 @@ enum {
     TEM_OPT_CONV1X1_STREAM,
     TEM_OPT_FWD_KSPLIT_CHUNKS,
     TEM_OPT_WGRAD_CUS,
+    TEM_OPT_UPSAMPLE_GENERIC,
     TEM_OPT_COUNT
 };
 long long tem_option(int id);

@@ -646,18 +646,21 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
                 "upsampled tensor and the skip connection differ in shape (the reference raises in torch.cat for odd "
                 "differences and centre-crops even ones; cropping is not implemented here) -- pad the input to a "
                 "multiple of the product of the scale factors")
-        ops.upsample_fwd(t, cat[..., :lv["c_up"]], f)  # ... interpolated straight into the concat buffer
-        out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev)
         # statistics of the concat for the block's first norm without reading it: the skip half's partial sums were
-        # written by the encoder conv that produced it, the upsampled half's follow from the low-resolution t
-        # (sum y = sum (U^T 1) t, sum y^2 = sum t (U^T U t): tem_upsample_stats)
+        # written by the encoder conv that produced it, the upsampled half's come out of the upsampling kernel (factor 2:
+        # tem_upsample_fwd_stats) or follow from the low-resolution t (sum y = sum (U^T 1) t, sum y^2 = sum t (U^T U t):
+        # tem_upsample_stats)
         p2 = None
         skip_part = lv["bs"].get("out_part")
+        want_stats = False
         if skip_part is not None:
             na = blk.conv_specs()[0].norm_args()
             cpg = cat.shape[4] // na[0]
-            if lv["c_up"] % cpg == 0 and ops.upsample_stats_ok(t):
-                p2 = (ops.upsample_stats(t, f), skip_part[0])
+            want_stats = lv["c_up"] % cpg == 0 and ops.upsample_stats_ok(t)
+        up_part = ops.upsample_fwd(t, cat[..., :lv["c_up"]], f, stats=want_stats)  # ... interpolated straight into the concat buffer
+        out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev)
+        if want_stats:
+            p2 = (up_part if up_part is not None else ops.upsample_stats(t, f), skip_part[0])
         bs = _block_fwd(blk, cat, out, in_partials2=p2)
         st["dec"].append({"low": cur, "sspec": sspec, "bs": bs, "f": f, "out": out, "t": t})
         cur = out

@@ -499,11 +499,23 @@ def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None, gy_c
     return gx
 
 
-def upsample_fwd(x, y, f):
+def upsample_fwd(x, y, f, stats: bool = False):
+    """y = interpolate(x, scale_factor=f, trilinear).  stats=True: also return the first stage of y's statistics,
+    part [N, D*H, C, 2] (tem_upsample_fwd_stats), or None when the factor-2 kernel does not take the shape -- then
+    `upsample_stats` derives them from x."""
     _req_cuda(x, y)
     N, D, H, W, C, x_ld = _act5(x)
     y_ld = _act5(y)[5]
     lib = _lib.load()
+    if stats:
+        if not (lib.tem_upsample_fwd_stats_ok(C, f[0], f[1], f[2]) and x_ld % 4 == 0 and y_ld % 4 == 0 and
+                x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
+            upsample_fwd(x, y, f)
+            return None
+        part = torch.empty((N, D * H, C, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.tem_upsample_fwd_stats(_p(x), x_ld, _p(y), y_ld, N, D, H, W, C, f[0], f[1], f[2], _p(part),
+                                              _stream(x)), "tem_upsample_fwd_stats")
+        return part
     _lib.check(lib.tem_upsample_fwd(_p(x), x_ld, _p(y), y_ld, N, D, H, W, C, f[0], f[1], f[2], _stream(x)),
                "tem_upsample_fwd")
     return y
