@@ -378,6 +378,15 @@ int tem_dice_grad2(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, con
 int tem_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                    float grad_scale, tem_stream_t stream);
+/* The same step for HIP-graph capture: a captured launch has its kernel arguments frozen, but the step count (bias
+ * corrections) and the learning rate change every step.  tem_adamw_hyper fills a 12-float HOST buffer
+ * [lr, beta1, beta2, eps, weight_decay, lr/bc1, 1/sqrt(bc2), grad_scale, skip, 0, 0, 0] exactly as tem_adamw_step
+ * derives those values; the caller copies it to the device before each replay and tem_adamw_step_dev reads it there
+ * (skip != 0: no update -- an overflowed mixed-precision step).  Bit-identical to tem_adamw_step. */
+int tem_adamw_hyper(float* hyper_host, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    int64_t step, float grad_scale);
+int tem_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const float* hyper, tem_stream_t stream);
 /* theta_k = m*theta_k + (1-m)*theta_q : SPOCOTrainer._momentum_update (trainer/spoco_trainer.py:45-47) */
 int tem_ema_update(float* theta_k, const float* theta_q, int64_t n, float momentum, tem_stream_t stream);
 /* Mixed-precision training (reference trainer/default_trainer.py:134-142,789-794: torch.amp.GradScaler): the unscale_

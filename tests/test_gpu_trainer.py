@@ -551,3 +551,77 @@ def test_from_checkpoint_restores_the_device_pre_pass(tmp_path):
         DefaultTrainer.from_checkpoint(t2.checkpoint_folder, name="latest", device=DEV)
     t3 = DefaultTrainer.from_checkpoint(t2.checkpoint_folder, name="latest", device=DEV, raw_transform=raw_t)
     assert t3.raw_transform is raw_t and isinstance(t3.target_transform, BatchTargets)
+
+
+def test_graphed_step_equals_eager(tmp_path):
+    """torch_em_amd/graph.py: the training step captured as ONE HIP graph (zero_grad, forward, loss, backward, AdamW with
+    its step count / learning rate in device memory) replays bit-identically to the eager step, leaves the training
+    state untouched while it is built, follows a learning-rate change, and is what DefaultTrainer(hip_graph=True) runs."""
+    import torch_em_amd
+    from torch_em_amd.graph import GraphedTrainStep
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    ref = UNet3d(1, 2, depth=2, initial_features=8).to(DEV)
+    sd0 = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, 1, 32, 32, 32, generator=g).to(DEV) for _ in range(5)]
+    ys = [(torch.rand(2, 2, 32, 32, 32, generator=g) > 0.5).float().to(DEV) for _ in range(5)]
+    loss_fn = DiceLoss()
+
+    def eager(n_lr_change):
+        m = UNet3d(1, 2, depth=2, initial_features=8).to(DEV)
+        m.load_state_dict(sd0)
+        opt = FusedAdamW(m.parameters(), lr=1e-3)
+        losses = []
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            if i == n_lr_change:
+                opt.param_groups[0]["lr"] = 3e-4
+            opt.zero_grad()
+            loss = loss_fn(m(x), y)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        return m, opt, losses
+
+    m0, opt0, l0 = eager(3)
+    m1 = UNet3d(1, 2, depth=2, initial_features=8).to(DEV)
+    m1.load_state_dict(sd0)
+    opt1 = FusedAdamW(m1.parameters(), lr=1e-3)
+    step = GraphedTrainStep(m1, loss_fn, opt1, xs[0], ys[0])
+    for k, v in m1.state_dict().items():          # building the graph (warm-up steps, capture) changed nothing
+        assert torch.equal(v, sd0[k]), k
+    assert all(float(opt1.state[p]["step"]) == 0 for p in m1.parameters())
+    l1 = []
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        if i == 3:
+            opt1.param_groups[0]["lr"] = 3e-4
+        pred, loss = step(x, y)
+        l1.append(loss.detach().clone())
+    assert pred.shape == (2, 2, 32, 32, 32) and step.replays == 5
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b), (float(a), float(b))
+    for (k, a), b in zip(m0.state_dict().items(), m1.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert all(float(opt1.state[p]["step"]) == 5 for p in m1.parameters())
+    # an eager forward after the replays sees the updated weights (packed-weight caches were invalidated)
+    with torch.no_grad():
+        assert torch.equal(m1(xs[0]), m0(xs[0]))
+    with pytest.raises(ValueError):
+        step(xs[0][:1], ys[0][:1])
+    # through the trainer: same trajectory as the eager trainer, the graph is what ran
+    def run(hip_graph):
+        torch.manual_seed(0)
+        m = UNet3d(1, 2, depth=2, initial_features=4)
+        train = torch.utils.data.DataLoader(_batches(4, 0), batch_size=1, shuffle=False)
+        val = torch.utils.data.DataLoader(_batches(2, 1), batch_size=1, shuffle=False)
+        t = torch_em_amd.default_segmentation_trainer("g%d" % hip_graph, m, train, val, device=DEV, logger=None,
+                                                      save_root=str(tmp_path), mixed_precision=False)
+        t.hip_graph = bool(hip_graph)
+        t.fit(iterations=6)
+        return t
+    t0, t1 = run(0), run(1)
+    assert t1._graphed is not None and t1._graphed.replays == 6 and t1._graph_why is None and t0._graphed is None
+    for (k, a), b in zip(t0.model.state_dict().items(), t1.model.state_dict().values()):
+        assert torch.equal(a, b), k

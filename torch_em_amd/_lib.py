@@ -88,6 +88,8 @@ SIGNATURES = {
                                c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int, c_float, c_float, c_vp]),
     "tem_adamw_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_i64,
                                c_float, c_vp]),
+    "tem_adamw_hyper": (c_int, [c_vp, c_float, c_float, c_float, c_float, c_float, c_i64, c_float]),
+    "tem_adamw_step_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "tem_ema_update": (c_int, [c_vp, c_vp, c_i64, c_float, c_vp]),
     "tem_amp_unscale": (c_int, [c_vp, c_i64, c_float, c_vp, c_vp]),
     "tem_boundary_target": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

@@ -64,6 +64,77 @@ extern "C" int tem_adamw_step(float* param, const float* grad, float* exp_avg, f
     return TEM_OK;
 }
 
+// The same update with its scalars read from DEVICE memory: hyper = [lr, beta1, beta2, eps, weight_decay, step_size,
+// inv_sqrt_bc2, grad_scale, skip, ...].  A launch captured in a HIP graph has its kernel arguments frozen; the step
+// count (bias corrections) and the learning rate change every step, so a captured optimizer step takes them from a
+// 12-float buffer the host refreshes before each replay.  skip != 0 leaves everything untouched (an overflowed
+// mixed-precision step).
+__global__ __launch_bounds__(256) void k_adamw_dev(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   const float* __restrict__ hyper) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step_size = hyper[5],
+                inv_sqrt_bc2 = hyper[6], gscale = hyper[7];
+    if (hyper[8] != 0.f) return;
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 p4 = reinterpret_cast<float4*>(p)[i];
+        float4 g4 = reinterpret_cast<const float4*>(g)[i];
+        float4 m4 = reinterpret_cast<float4*>(m)[i];
+        float4 v4 = reinterpret_cast<float4*>(v)[i];
+        float pp[4] = {p4.x, p4.y, p4.z, p4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+        float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gr = gg[j] * gscale;
+            pp[j] *= (1.f - lr * wd);
+            mm[j] = mm[j] + (1.f - b1) * (gr - mm[j]);
+            vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
+            float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
+            pp[j] -= step_size * (mm[j] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float gr = g[i] * gscale;
+        float pp = p[i] * (1.f - lr * wd);
+        float mm = m[i] + (1.f - b1) * (gr - m[i]);
+        float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+        p[i] = pp - step_size * (mm / denom);
+        m[i] = mm;
+        v[i] = vv;
+    }
+}
+
+extern "C" int tem_adamw_hyper(float* hyper_host, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int64_t step, float grad_scale) {
+    TEM_REQUIRE(hyper_host && step >= 1, "tem_adamw_hyper: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hyper_host[0] = lr; hyper_host[1] = beta1; hyper_host[2] = beta2; hyper_host[3] = eps; hyper_host[4] = weight_decay;
+    hyper_host[5] = (float)((double)lr / bc1);
+    hyper_host[6] = (float)(1.0 / sqrt(bc2));
+    hyper_host[7] = grad_scale;
+    hyper_host[8] = 0.f;
+    hyper_host[9] = hyper_host[10] = hyper_host[11] = 0.f;
+    return TEM_OK;
+}
+
+extern "C" int tem_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  const float* hyper, tem_stream_t stream) {
+    TEM_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper && n > 0, "tem_adamw_step_dev: bad arguments");
+    TEM_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) &&
+                    ((uintptr_t)exp_avg_sq % 16 == 0),
+                "tem_adamw_step_dev: arena pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(k_adamw_dev, dim3(tem_grid_1d(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, hyper);
+    TEM_CHECK_LAUNCH("tem_adamw_step_dev");
+    return TEM_OK;
+}
+
 __global__ __launch_bounds__(256) void k_ema(float* __restrict__ k, const float* __restrict__ q, int64_t n, float mom) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)

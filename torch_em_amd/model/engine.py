@@ -178,11 +178,14 @@ _PACK_BATCH = os.environ.get("TEM_PACK_BATCH", "1") != "0"
 _PACK_TABLES = {}
 
 
-def _repack_stale():
+def _repack_stale(prepare_only: bool = False):
     """Re-pack the weights of every registered conv whose parameter changed in place (same storage, new version):
-    all split-layout packs go into ONE tem_conv_pack_weights_batch launch, written into the existing buffers."""
+    all split-layout packs go into ONE tem_conv_pack_weights_batch launch, written into the existing buffers.
+    prepare_only: build (and upload) the job table for the currently stale set without launching or marking anything
+    fresh -- HIP-graph capture cannot upload it, so torch_em_amd/graph.py does that just before capturing."""
     jobs, rest = [], []
-    for conv in list(_PACKED_CONVS):
+    # a WeakSet has no stable order: sort, so that the same stale set always gives the same table
+    for conv in sorted(_PACKED_CONVS, key=lambda c: c.weight.data_ptr()):
         ent = getattr(conv, "_tem_pack", None)
         w = conv.weight
         if ent is None or not w.is_cuda or ent["ptr"] != w.data_ptr() or ent["prec"] != PRECISION \
@@ -191,6 +194,12 @@ def _repack_stale():
         k = _k3(conv.kernel_size)
         for key, transpose in (("fwd", 0), ("dgrad", 1), ("fwd_inf", 0), ("dgrad16", 1)):
             if key not in ent:
+                continue
+            if prepare_only:
+                if ent.get(key + "_mfma") in (2, 3, 4, 5, 6) and not (key == "fwd_inf" and not ent.get("fwd_inf_used", False)):
+                    mode = ent[key + "_mfma"]
+                    jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
+                                 3 if mode == 3 else 1 if mode == 5 else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
                 continue
             if key == "dgrad" and "dgrad16" in ent and ent.pop("dgrad16_used", False) and not ent.pop("dgrad_used", False):
                 # this layer's data gradient runs in the fp16 layout: the bf16 pack is re-made lazily if ever needed again
@@ -206,7 +215,8 @@ def _repack_stale():
                              3 if mode == 3 else 1 if mode == 5 else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
             else:
                 rest.append((ent, key, w, bool(transpose), mode))
-        ent["version"] = w._version
+        if not prepare_only:
+            ent["version"] = w._version
     for ent, key, w, transpose, mode in rest:
         ent[key] = ops.pack_weights(w, transpose=transpose, mfma=mode)
     by_dev = {}
@@ -217,6 +227,8 @@ def _repack_stale():
         ent = _PACK_TABLES.get(dev)
         if ent is None or ent[0] != sig:
             ent = _PACK_TABLES[dev] = (sig, ops.pack_table(dj))
+        if prepare_only:
+            continue
         with torch.cuda.device(dev):
             ops.pack_weights_batch(ent[1])
 

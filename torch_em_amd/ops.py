@@ -746,6 +746,22 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
                                   eps, weight_decay, int(step), grad_scale, _stream(param)), "tem_adamw_step")
 
 
+def adamw_hyper(host_buf, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """Fill the 12-float HOST tensor that `adamw_step_dev` reads (after a copy to the device): tem_adamw_hyper."""
+    assert not host_buf.is_cuda and host_buf.dtype == torch.float32 and host_buf.numel() >= 12
+    lib = _lib.load()
+    _lib.check(lib.tem_adamw_hyper(ctypes.c_void_p(host_buf.data_ptr()), lr, beta1, beta2, eps, weight_decay, int(step),
+                                   grad_scale), "tem_adamw_hyper")
+
+
+def adamw_step_dev(param, grad, exp_avg, exp_avg_sq, hyper):
+    """adamw_step with lr / bias corrections read from the device tensor `hyper` (HIP-graph capture)."""
+    _req_cuda(param, grad, exp_avg, exp_avg_sq, hyper)
+    lib = _lib.load()
+    _lib.check(lib.tem_adamw_step_dev(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(hyper),
+                                      _stream(param)), "tem_adamw_step_dev")
+
+
 def amp_unscale(grad, inv_scale, found_inf):
     """grad *= inv_scale in place; found_inf[0] = 1 if any element is not finite (GradScaler.unscale_)."""
     _req_cuda(grad, found_inf)

@@ -19,6 +19,43 @@ class FusedAdamW(torch.optim.Optimizer):
         self.grad_scale = grad_scale
         self._arena = None   # ParamArena, built lazily on the device the parameters live on
         self._m = self._v = None
+        self._hyper = None   # device tensor [12] when the step is (being) captured in a HIP graph: see capturable()
+        self._hyper_host = None
+
+    # -- HIP-graph capture ----------------------------------------------------------------
+    def capturable(self, on: bool = True):
+        """Switch to the step whose scalars (lr, bias corrections) live in a device buffer, so that a captured launch
+        stays valid from step to step.  `refresh_hyper()` -- called by step() when it runs eagerly, and by
+        `GraphedTrainStep` before every replay -- advances the step count and re-fills that buffer."""
+        self._ensure_arena()
+        if on and self._hyper is None:
+            self._hyper = torch.zeros(12, dtype=torch.float32, device=self._arena.flat.device)
+            # pinned staging slots, reused round-robin behind an event each: a copy from pageable memory would make the
+            # host wait for everything queued before it (the previous replay), a single pinned buffer could be
+            # overwritten before its copy ran
+            self._hyper_host = [(torch.zeros(12, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+            self._hyper_slot = 0
+        if not on:
+            self._hyper = self._hyper_host = None
+        return self
+
+    def refresh_hyper(self):
+        """step += 1 for every parameter; hyper <- (lr, ..., bias corrections of the new step).  Runs OUTSIDE a graph: an
+        ordinary H2D copy on the current stream, ordered before the replay that follows."""
+        ar, group = self._arena, self.param_groups[0]
+        steps = {int(self.state[p]["step"].item()) for p in ar.params}
+        if len(steps) != 1 or len(self.param_groups) != 1:
+            raise RuntimeError("FusedAdamW.capturable: one parameter group with a common step count is required")
+        step = steps.pop() + 1
+        host, ev = self._hyper_host[self._hyper_slot]
+        self._hyper_slot = (self._hyper_slot + 1) % len(self._hyper_host)
+        ev.synchronize()                      # the copy that last read this slot (4 steps ago) is long done
+        ops.adamw_hyper(host, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
+                        group["weight_decay"], step, self.grad_scale)
+        self._hyper.copy_(host, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self._hyper.device))
+        for p in ar.params:
+            self.state[p]["step"] += 1
 
     # -- arena management ---------------------------------------------------------------
     def _ensure_arena(self):
@@ -64,6 +101,14 @@ class FusedAdamW(torch.optim.Optimizer):
             (g["lr"], g["betas"], g["eps"], g["weight_decay"]) ==
             (group["lr"], group["betas"], group["eps"], group["weight_decay"]) for g in self.param_groups)
         gflat = ar.grads_flat() if uniform else None
+        if self._hyper is not None:
+            if gflat is None:
+                raise RuntimeError("FusedAdamW.capturable: the gradients must be the engine's flat arena")
+            if not torch.cuda.is_current_stream_capturing():
+                self.refresh_hyper()     # under capture the owner of the graph refreshes before each replay
+            ops.adamw_step_dev(ar.flat, gflat, self._m, self._v, self._hyper)
+            ops.bump_versions(ar.params)
+            return loss
         steps = {int(self.state[p]["step"].item()) for p in ar.params}
         if gflat is not None and len(steps) == 1:
             step = steps.pop() + 1

@@ -83,7 +83,7 @@ class DefaultTrainer:
                  save_root: Optional[str] = None, compile_model: Optional[Union[bool, str]] = None,
                  rank: Optional[int] = None, mixed_precision_dtype: Optional[str] = None,
                  target_transform: Optional[Callable] = None, augmentation: Optional[Callable] = None,
-                 raw_transform: Optional[Callable] = None, prefetch: bool = True):
+                 raw_transform: Optional[Callable] = None, prefetch: bool = True, hip_graph: Optional[bool] = None):
         if name is None:
             raise TypeError("Name cannot be None if not using the WandbLogger")
         self.name, self.id_ = name, id_ or name
@@ -115,6 +115,12 @@ class DefaultTrainer:
             self.scaler = None  # fp32-class path: no loss scaling
         self.early_stopping = early_stopping
         self.train_time = 0.0
+        # hip_graph: replay the training step (zero_grad .. optimizer step) as one captured HIP graph instead of ~220
+        # launches enqueued from Python (torch_em_amd/graph.py).  Same results bit for bit; pays off where the host is
+        # the bottleneck (small patches).  None: TEM_HIP_GRAPH=1 in the environment.  Needs FusedAdamW, a single GPU and
+        # no loss scaling; otherwise the step silently runs eagerly (self._graph_why says why).
+        self.hip_graph = (os.environ.get("TEM_HIP_GRAPH", "0") == "1") if hip_graph is None else bool(hip_graph)
+        self._graphed, self._graph_why = None, None
         self.logger_class, self.logger_kwargs = logger, logger_kwargs
         self.logger = None
         # not in the reference: computes the training target from the label batch ON DEVICE (e.g.
@@ -409,15 +415,44 @@ class DefaultTrainer:
         loss.backward()
         self.optimizer.step()
 
+    def _graphed_step(self, x, y):
+        """The captured step for this batch shape, or None (with the reason in self._graph_why) when it must run eagerly."""
+        g = self._graphed
+        if g is not None and g.matches(x, y):
+            return g
+        from ..graph import GraphedTrainStep
+        from ..optim import FusedAdamW
+        why = None
+        if not (torch.is_tensor(x) and torch.is_tensor(y) and x.is_cuda):
+            why = "batch is not a pair of device tensors"
+        elif not isinstance(self.optimizer, FusedAdamW):
+            why = "optimizer is not FusedAdamW"
+        elif self.scaler is not None:
+            why = "dynamic loss scaling reads an overflow flag on the host every step"
+        elif torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1:
+            why = "multi-GPU gradient all-reduce"
+        elif g is not None:
+            why = "batch shape changed (the graph is captured for one shape)"
+        self._graph_why = why
+        if why is not None:
+            return None
+        self._graphed = GraphedTrainStep(self.model, self.loss, self.optimizer, x, y)
+        return self._graphed
+
     def _train_epoch(self, progress):
         """The hot loop (reference :805-831): H2D copy, zero_grad, forward, loss, backward, step."""
         self.model.train()
         n_iter, t0 = 0, time.time()
         for x, y in self._batches(self.train_loader, train=True):
-            self.optimizer.zero_grad()
-            with self._precision():
-                pred, loss = self._forward_and_loss(x, y)
-                self._backprop(loss)
+            step = self._graphed_step(x, y) if self.hip_graph else None
+            if step is not None:
+                pred, loss = step(x, y)
+            else:
+                self.optimizer.zero_grad()
+                with self._precision():
+                    pred, loss = self._forward_and_loss(x, y)
+                    self._backprop(loss)
             if self.logger is not None:
                 lr = [pm["lr"] for pm in self.optimizer.param_groups][0]
                 self.logger.log_train(self._iteration, loss, lr, x, y, pred, log_gradients=True)
