@@ -387,6 +387,15 @@ int tem_adamw_hyper(float* hyper_host, float lr, float beta1, float beta2, float
                     int64_t step, float grad_scale);
 int tem_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        const float* hyper, tem_stream_t stream);
+/* ... under dynamic loss scaling (torch.amp.GradScaler; reference trainer/default_trainer.py:789-794) the device may skip
+ * a step (overflow) before the host has enqueued the next one.  The scaler state lives on the device,
+ * sstate = [scale, growth_tracker, found_inf, applied_steps]; tem_amp_unscale_dev / tem_amp_update_dev are
+ * GradScaler.unscale_ / update on it; tem_adamw_step_tab takes its scalars from row (applied_steps + 1 - lo) of
+ * table = [lo, J, -, -] + J x 12 floats (row j = tem_adamw_hyper for step lo + j) and does nothing when found_inf != 0. */
+int tem_adamw_step_tab(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const float* table, const float* sstate, tem_stream_t stream);
+int tem_amp_unscale_dev(float* grad, int64_t n, float* sstate, tem_stream_t stream);
+int tem_amp_update_dev(float* sstate, float growth, float backoff, int interval, tem_stream_t stream);
 /* theta_k = m*theta_k + (1-m)*theta_q : SPOCOTrainer._momentum_update (trainer/spoco_trainer.py:45-47) */
 int tem_ema_update(float* theta_k, const float* theta_q, int64_t n, float momentum, tem_stream_t stream);
 /* Mixed-precision training (reference trainer/default_trainer.py:134-142,789-794: torch.amp.GradScaler): the unscale_

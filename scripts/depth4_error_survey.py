@@ -18,25 +18,46 @@ from torch_em_amd.loss import DiceLoss  # noqa: E402
 from torch_em_amd.model import UNet3d  # noqa: E402
 
 
-def main():
-    seeds = [int(s) for s in (sys.argv[1:] or ["0", "1", "2", "3", "4", "5"])]
-    print(f"# TEM_PRECISION={os.environ.get('TEM_PRECISION', 'split16')}  TEM_DGRAD16={os.environ.get('TEM_DGRAD16', 'default')}")
-    print("# seed  global_L2(hip)  global_L2(fp32 ref)  worst tensor (hip)  its L2 hip / ref   entries > 1e-2 of max (hip / ref)")
-    for seed in seeds:
+def case(seed, cfg3):
+    """(model, scale factors, x, y, oracle kwargs, loss on the device)"""
+    if not cfg3:
         torch.manual_seed(seed)
         model = UNet3d(1, 2, depth=4, initial_features=32)
         g = torch.Generator().manual_seed(100 + seed)
         x = torch.randn(1, 1, 64, 64, 64, generator=g)
         y = (torch.rand(1, 2, 64, 64, 64, generator=g) > 0.5).float()
+        return model, [2, 2, 2, 2], x, y, dict(norm="InstanceNorm"), DiceLoss()
+    # cfg 3 of BASELINE.json (tests/test_gpu_unet.py::test_anisotropic_cfg3_factors_match_fp64_oracle): seed 0 is that test
+    from oracle import loss_ref
+    from torch_em_amd.loss import ApplyAndRemoveMask, LossWrapper
+    from torch_em_amd.model import AnisotropicUNet
+    torch.manual_seed(seed)
+    sf = [[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]]
+    model = AnisotropicUNet(1, 12, sf, initial_features=32, final_activation="Sigmoid", anisotropic_kernel=True)
+    g = torch.Generator().manual_seed(7 + seed)
+    x = torch.randn(1, 1, 16, 64, 64, generator=g)
+    y = torch.cat([(torch.rand(1, 12, 16, 64, 64, generator=g) > 0.5).float(),
+                   (torch.rand(1, 12, 16, 64, 64, generator=g) > 0.3).float()], dim=1)
+    return model, sf, x, y, dict(norm="InstanceNorm", final_activation="Sigmoid", loss_fn=loss_ref.masked_dice_loss), \
+        LossWrapper(DiceLoss(), ApplyAndRemoveMask("multiply"))
+
+
+def main():
+    args = sys.argv[1:]
+    cfg3 = "--cfg3" in args
+    seeds = [int(s) for s in ([a for a in args if a != "--cfg3"] or ["0", "1", "2", "3", "4", "5"])]
+    print(f"# TEM_PRECISION={os.environ.get('TEM_PRECISION', 'split16')}  TEM_DGRAD16={os.environ.get('TEM_DGRAD16', 'default')}")
+    print("# seed  global_L2(hip)  global_L2(fp32 ref)  worst tensor (hip)  its L2 hip / ref   entries > 1e-2 of max (hip / ref)")
+    for seed in seeds:
+        model, sf, x, y, okw, loss_fn = case(seed, cfg3)
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
         res = {}
         for dt in (torch.float64, torch.float32):
-            _, _, gr = unet_ref.unet_loss_and_grads({k: v.to(dt) for k, v in sd.items()}, x.to(dt), y.to(dt), [2, 2, 2, 2],
-                                                    norm="InstanceNorm")
+            _, _, gr = unet_ref.unet_loss_and_grads({k: v.to(dt) for k, v in sd.items()}, x.to(dt), y.to(dt), sf, **okw)
             res[dt] = {k: v.double().numpy() for k, v in gr.items()}
         model.to("cuda")
         pred = model(x.cuda())
-        DiceLoss()(pred, y.cuda()).backward()
+        loss_fn(pred, y.cuda()).backward()
         hip = {k: p.grad.double().cpu().numpy() for k, p in model.named_parameters()}
         g64, g32 = res[torch.float64], res[torch.float32]
         keys = [k for k in hip if np.abs(g64[k]).max() > 1e-4 * max(np.abs(v).max() for v in g64.values())]

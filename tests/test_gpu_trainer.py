@@ -625,3 +625,79 @@ def test_graphed_step_equals_eager(tmp_path):
     assert t1._graphed is not None and t1._graphed.replays == 6 and t1._graph_why is None and t0._graphed is None
     for (k, a), b in zip(t0.model.state_dict().items(), t1.model.state_dict().values()):
         assert torch.equal(a, b), k
+
+
+def test_graphed_mixed_precision_step_with_device_side_loss_scaling():
+    """The mixed-precision step (reference `_backprop_mixed`, trainer/default_trainer.py:789-794) as a HIP graph: the
+    GradScaler's scale / overflow flag / growth tracker and the count of APPLIED optimizer steps live on the device
+    (tem_amp_unscale_dev, tem_adamw_step_tab, tem_amp_update_dev).  Same trajectory as the eager scaler -- which reads the
+    flag on the host -- bit for bit, including skipped steps after overflows and a scale growth."""
+    from torch_em_amd.graph import GraphedTrainStep
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d, engine
+    from torch_em_amd.optim import FusedAdamW, GradScaler
+    torch.manual_seed(1)
+    sd0 = {k: v.detach().clone() for k, v in UNet3d(1, 2, depth=2, initial_features=16).to(DEV).state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    n = 36
+    xs = [torch.randn(1, 1, 32, 32, 32, generator=g).to(DEV) for _ in range(n)]
+    ys = [(torch.rand(1, 2, 32, 32, 32, generator=g) > 0.5).float().to(DEV) for _ in range(n)]
+    loss_fn = DiceLoss()
+    mk_scaler = lambda: GradScaler(init_scale=2.0 ** 36, growth_interval=3)  # noqa: E731  overflows first, grows later
+
+    m0 = UNet3d(1, 2, depth=2, initial_features=16).to(DEV)
+    m0.load_state_dict(sd0)
+    opt0, sc0, l0, scales0 = FusedAdamW(m0.parameters(), lr=1e-3), mk_scaler(), [], []
+    for x, y in zip(xs, ys):
+        opt0.zero_grad()
+        with engine.precision_scope("amp"):
+            loss = loss_fn(m0(x), y)
+            sc0.scale(loss).backward()
+            sc0.step(opt0)
+            sc0.update()
+        l0.append(loss.detach().clone())
+        scales0.append(sc0.get_scale())
+    steps0 = {int(v["step"]) for v in opt0.state_dict()["state"].values()}
+    assert len(steps0) == 1 and 0 < steps0.copy().pop() < n          # some steps were skipped ...
+    assert any(b > a for a, b in zip(scales0, scales0[1:]))          # ... and the scale grew again later
+
+    m1 = UNet3d(1, 2, depth=2, initial_features=16).to(DEV)
+    m1.load_state_dict(sd0)
+    opt1, sc1 = FusedAdamW(m1.parameters(), lr=1e-3), mk_scaler()
+    step = GraphedTrainStep(m1, loss_fn, opt1, xs[0], ys[0], scaler=sc1, precision="amp")
+    for k, v in m1.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+    assert sc1.get_scale() == 2.0 ** 36
+    l1 = []
+    for x, y in zip(xs, ys):                      # no host sync in here: the host runs ahead of the device
+        l1.append(step(x, y)[1].detach().clone())
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b) or (not torch.isfinite(a).all() and not torch.isfinite(b).all()), (float(a), float(b))
+    for (k, a), b in zip(m0.state_dict().items(), m1.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert sc1.get_scale() == scales0[-1]
+    assert {int(v["step"]) for v in opt1.state_dict()["state"].values()} == steps0
+
+    # through the trainer (mixed_precision_dtype="float16" + hip_graph): same weights and checkpointed scaler / step counts
+    import torch_em_amd
+
+    def run(hip_graph, root):
+        torch.manual_seed(0)
+        m = UNet3d(1, 2, depth=2, initial_features=8)
+        train = torch.utils.data.DataLoader(_batches(4, 0), batch_size=1, shuffle=False)
+        val = torch.utils.data.DataLoader(_batches(2, 1), batch_size=1, shuffle=False)
+        t = torch_em_amd.default_segmentation_trainer("a%d" % hip_graph, m, train, val, device=DEV, logger=None,
+                                                      save_root=root, mixed_precision=True,
+                                                      mixed_precision_dtype="float16")
+        t.hip_graph = bool(hip_graph)
+        t.fit(iterations=6)
+        return t, torch.load(os.path.join(t.checkpoint_folder, "latest.pt"), weights_only=False)
+    import tempfile
+    with tempfile.TemporaryDirectory() as root:
+        (t0, c0), (t1, c1) = run(0, root), run(1, root)
+    assert t1._graphed is not None and t1._graphed.replays == 6 and t1._graphed.scaler is t1.scaler
+    for (k, a), b in zip(t0.model.state_dict().items(), t1.model.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert c0["scaler_state"] == c1["scaler_state"]
+    assert [int(v["step"]) for v in c0["optimizer_state"]["state"].values()] == \
+        [int(v["step"]) for v in c1["optimizer_state"]["state"].values()]

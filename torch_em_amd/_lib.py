@@ -90,6 +90,9 @@ SIGNATURES = {
                                c_float, c_vp]),
     "tem_adamw_hyper": (c_int, [c_vp, c_float, c_float, c_float, c_float, c_float, c_i64, c_float]),
     "tem_adamw_step_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "tem_adamw_step_tab": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "tem_amp_unscale_dev": (c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "tem_amp_update_dev": (c_int, [c_vp, c_float, c_float, c_int, c_vp]),
     "tem_ema_update": (c_int, [c_vp, c_vp, c_i64, c_float, c_vp]),
     "tem_amp_unscale": (c_int, [c_vp, c_i64, c_float, c_vp, c_vp]),
     "tem_boundary_target": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

@@ -8,6 +8,12 @@ forward / backward / optimizer), so the whole step becomes one `hipGraphLaunch`:
 What stays outside the graph, per replay: the copy of the batch into the captured input buffers and the refresh of the
 12-float optimizer buffer (step count -> bias corrections, learning rate: `FusedAdamW.refresh_hyper`).
 
+With dynamic loss scaling (`scaler=`, the mixed-precision step) the overflow decision moves to the device as in
+torch.amp.GradScaler: scale / unscale / skip-or-step / update all run inside the graph on a 4-float device state, and
+because the host can no longer know how many steps were really applied when it enqueues the next replay, it uploads
+the optimizer scalars for a WINDOW of step numbers and the kernel picks its row (`FusedAdamW.refresh_table`); the applied
+count comes back through a ring of asynchronous 16-byte reads.
+
 No reference counterpart (torch_em trains eagerly); results are bit-identical to the eager step
 (tests/test_gpu_trainer.py::test_graphed_step_equals_eager)."""
 import torch
@@ -17,7 +23,9 @@ from .optim import FusedAdamW
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn, optimizer, x, y, warmup: int = 2, precision=None):
+    READBACK_SLOTS = 8   # < FusedAdamW.TABLE_ROWS - 1: the host runs at most this many replays ahead of what it knows
+
+    def __init__(self, model, loss_fn, optimizer, x, y, warmup: int = 2, precision=None, scaler=None):
         if not (torch.is_tensor(x) and x.is_cuda):
             raise RuntimeError("GraphedTrainStep: HIP graphs need the batch on an MI355X (got a CPU tensor)")
         if not isinstance(optimizer, FusedAdamW):
@@ -30,13 +38,28 @@ class GraphedTrainStep:
         self.model, self.loss_fn, self.optimizer, self.precision = model, loss_fn, optimizer, precision
         self.params = [p for g in optimizer.param_groups for p in g["params"]]
         self.static_x, self.static_y = x.clone(), y.clone()
-        optimizer.capturable(True)
+        self.scaler = scaler if (scaler is not None and scaler.is_enabled()) else None
+        optimizer._ensure_arena()
+        if self.scaler is not None:
+            step0 = {int(optimizer.state[p]["step"].item()) for p in optimizer._arena.params}
+            if len(step0) != 1:
+                raise RuntimeError("GraphedTrainStep: the parameters must share one optimizer step count")
+            self.sstate = self.scaler.capturable(x.device, applied_steps=step0.pop())
+            optimizer.capturable_scaled(self.sstate)
+            self._ring = [(torch.zeros(4, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in
+                          range(self.READBACK_SLOTS)]
+            self._pending = []          # (slot, replay index) of reads in flight, oldest first
+            self._known = int(self.sstate[3].item())
+            optimizer._pre_state_dict = self.sync_state
+        else:
+            optimizer.capturable(True)
         # Warm-up on a side stream (workspaces, gradient arena, packed-weight buffers and the allocator reach their
         # steady state), as torch's capture recipe asks -- but without consuming training steps: parameters, moments and
         # step counts are restored afterwards, so building the graph leaves the training state untouched.
         ar = optimizer._arena
         saved = (ar.flat.clone(), optimizer._m.clone(), optimizer._v.clone(),
-                 [optimizer.state[p]["step"].clone() for p in ar.params])
+                 [optimizer.state[p]["step"].clone() for p in ar.params],
+                 self.sstate.clone() if self.scaler is not None else None)
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(side):
@@ -45,12 +68,15 @@ class GraphedTrainStep:
             ar.flat.copy_(saved[0])
             optimizer._m.copy_(saved[1])
             optimizer._v.copy_(saved[2])
+            if self.scaler is not None:
+                self.sstate.copy_(saved[4])
         torch.cuda.current_stream(x.device).wait_stream(side)
         for p, st in zip(ar.params, saved[3]):
             optimizer.state[p]["step"].copy_(st)
         ops.bump_versions(self.params)
         from .model import engine
-        engine._repack_stale(prepare_only=True)   # the weight-packing job table: its upload cannot be captured
+        with self._scope():
+            engine._repack_stale(prepare_only=True)   # the weight-packing job table: its upload cannot be captured
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)   # autograd must ASSIGN the captured gradients, not add to old ones
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -68,8 +94,13 @@ class GraphedTrainStep:
         with self._scope():
             pred = self.model(self.static_x)
             loss = self.loss_fn(pred, self.static_y)
-            loss.backward()
-            self.optimizer.step()
+            if self.scaler is not None:     # reference `_backprop_mixed` (trainer/default_trainer.py:789-794)
+                self.scaler.scale(loss).backward()
+                self.scaler.step(self.optimizer)
+                self.scaler.update()
+            else:
+                loss.backward()
+                self.optimizer.step()
         return pred, loss
 
     def _eager_step(self):
@@ -88,8 +119,42 @@ class GraphedTrainStep:
                              f"y{tuple(self.static_y.shape)}; got x{tuple(x.shape)} / y{tuple(y.shape)}")
         self.static_x.copy_(x, non_blocking=True)
         self.static_y.copy_(y, non_blocking=True)
-        self.optimizer.refresh_hyper()
-        self.graph.replay()
+        if self.scaler is None:
+            self.optimizer.refresh_hyper()
+            self.graph.replay()
+        else:
+            self._poll(block_if_full=True)
+            self.optimizer.refresh_table(self._known)
+            self.graph.replay()
+            slot = self.replays % self.READBACK_SLOTS
+            buf, ev = self._ring[slot]
+            buf.copy_(self.sstate, non_blocking=True)
+            ev.record(torch.cuda.current_stream(self.sstate.device))
+            self._pending.append(slot)
         ops.bump_versions(self.params)   # eager code that runs next (validation) must re-pack the weights
         self.replays += 1
         return self.pred, self.loss
+
+    # -- dynamic loss scaling: what the host knows about the device's step count ------------------------------------
+    def _poll(self, block_if_full: bool = False):
+        """Consume finished state reads (oldest first): `_known` = applied optimizer steps as of the newest one.  With every
+        slot in flight, wait for the oldest -- that bounds how stale `_known` can be (READBACK_SLOTS replays), which is
+        what the row window of `refresh_table` covers."""
+        while self._pending:
+            buf, ev = self._ring[self._pending[0]]
+            if not ev.query():
+                if not (block_if_full and len(self._pending) >= self.READBACK_SLOTS):
+                    break
+                ev.synchronize()
+            self._known = int(buf[3])
+            self._pending.pop(0)
+        self.optimizer.set_step_count(self._known)
+
+    def sync_state(self):
+        """Blocking: bring the host-side mirrors (optimizer step counts, scaler scale) up to date, e.g. for a checkpoint."""
+        if self.scaler is None:
+            return
+        self._known = int(self.sstate[3].item())
+        self._pending.clear()
+        self.optimizer.set_step_count(self._known)
+        self.scaler._from_device()

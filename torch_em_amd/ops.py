@@ -762,6 +762,28 @@ def adamw_step_dev(param, grad, exp_avg, exp_avg_sq, hyper):
                                       _stream(param)), "tem_adamw_step_dev")
 
 
+def adamw_step_tab(param, grad, exp_avg, exp_avg_sq, table, sstate):
+    """adamw_step with its scalars from the row of `table` that the device-side step count in `sstate` selects; skipped
+    when sstate's overflow flag is up (tem_adamw_step_tab)."""
+    _req_cuda(param, grad, exp_avg, exp_avg_sq, table, sstate)
+    lib = _lib.load()
+    _lib.check(lib.tem_adamw_step_tab(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(table),
+                                      _p(sstate), _stream(param)), "tem_adamw_step_tab")
+
+
+def amp_unscale_dev(grad, sstate):
+    _req_cuda(grad, sstate)
+    lib = _lib.load()
+    _lib.check(lib.tem_amp_unscale_dev(_p(grad), grad.numel(), _p(sstate), _stream(grad)), "tem_amp_unscale_dev")
+
+
+def amp_update_dev(sstate, growth, backoff, interval):
+    _req_cuda(sstate)
+    lib = _lib.load()
+    _lib.check(lib.tem_amp_update_dev(_p(sstate), float(growth), float(backoff), int(interval), _stream(sstate)),
+               "tem_amp_update_dev")
+
+
 def amp_unscale(grad, inv_scale, found_inf):
     """grad *= inv_scale in place; found_inf[0] = 1 if any element is not finite (GradScaler.unscale_)."""
     _req_cuda(grad, found_inf)

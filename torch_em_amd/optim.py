@@ -21,6 +21,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._m = self._v = None
         self._hyper = None   # device tensor [12] when the step is (being) captured in a HIP graph: see capturable()
         self._hyper_host = None
+        self._table = self._sstate = None   # ... under dynamic loss scaling: see capturable_scaled()
+        self._pre_state_dict = None         # the graph owner's hook: bring the host step counts up to date
+
+    def state_dict(self):
+        if self._pre_state_dict is not None:
+            self._pre_state_dict()
+        return super().state_dict()
 
     # -- HIP-graph capture ----------------------------------------------------------------
     def capturable(self, on: bool = True):
@@ -36,8 +43,44 @@ class FusedAdamW(torch.optim.Optimizer):
             self._hyper_host = [(torch.zeros(12, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
             self._hyper_slot = 0
         if not on:
-            self._hyper = self._hyper_host = None
+            self._hyper = self._hyper_host = self._table = self._sstate = None
         return self
+
+    TABLE_ROWS = 16
+
+    def capturable_scaled(self, sstate: torch.Tensor):
+        """capturable() under dynamic loss scaling: the device may skip a step (overflow) that the host has already
+        counted, so the number of APPLIED steps lives in `sstate[3]` (the GradScaler's device state) and the host uploads
+        the scalars of a window of step numbers (`refresh_table`); the kernel picks its row (tem_adamw_step_tab)."""
+        self._ensure_arena()
+        dev = self._arena.flat.device
+        n = 4 + 12 * self.TABLE_ROWS
+        self._sstate = sstate
+        self._table = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._table_host = [(torch.zeros(n, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+        self._table_slot = 0
+        self._hyper = None
+        return self
+
+    def refresh_table(self, applied: int):
+        """Rows for steps applied + 1 .. applied + TABLE_ROWS (`applied` = a lower bound of the device's count that is at
+        most TABLE_ROWS - 1 replays old)."""
+        group = self.param_groups[0]
+        if len(self.param_groups) != 1:
+            raise RuntimeError("FusedAdamW.capturable: one parameter group is required")
+        host, ev = self._table_host[self._table_slot]
+        self._table_slot = (self._table_slot + 1) % len(self._table_host)
+        ev.synchronize()
+        host[0], host[1] = float(applied + 1), float(self.TABLE_ROWS)
+        for j in range(self.TABLE_ROWS):
+            ops.adamw_hyper(host[4 + 12 * j:4 + 12 * (j + 1)], group["lr"], group["betas"][0], group["betas"][1],
+                            group["eps"], group["weight_decay"], applied + 1 + j, self.grad_scale)
+        self._table.copy_(host, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self._table.device))
+
+    def set_step_count(self, applied: int):
+        for p in self._arena.params:
+            self.state[p]["step"].fill_(float(applied))
 
     def refresh_hyper(self):
         """step += 1 for every parameter; hyper <- (lr, ..., bias corrections of the new step).  Runs OUTSIDE a graph: an
@@ -101,6 +144,15 @@ class FusedAdamW(torch.optim.Optimizer):
             (g["lr"], g["betas"], g["eps"], g["weight_decay"]) ==
             (group["lr"], group["betas"], group["eps"], group["weight_decay"]) for g in self.param_groups)
         gflat = ar.grads_flat() if uniform else None
+        if self._table is not None:
+            if gflat is None:
+                raise RuntimeError("FusedAdamW.capturable: the gradients must be the engine's flat arena")
+            if not torch.cuda.is_current_stream_capturing():   # eager use (warm-up): exact count, one host read
+                applied = int(self._sstate[3].item())
+                self.refresh_table(applied)
+            ops.adamw_step_tab(ar.flat, gflat, self._m, self._v, self._table, self._sstate)
+            ops.bump_versions(ar.params)
+            return loss
         if self._hyper is not None:
             if gflat is None:
                 raise RuntimeError("FusedAdamW.capturable: the gradients must be the engine's flat arena")
@@ -160,13 +212,28 @@ class GradScaler:
         self._found_inf: Dict[torch.device, torch.Tensor] = {}
         self._unscaled = set()       # id(optimizer) already unscaled since the last update()
         self._overflow = False       # any optimizer saw inf/NaN since the last update()
-        self._scale_dev = {}
+        self._sstate = None          # device state [scale, growth_tracker, found_inf, applied_steps]: see capturable()
+
+    # -- HIP-graph capture ------------------------------------------------------------------
+    def capturable(self, device, applied_steps: int = 0):
+        """Move the scaler's state to the device, as torch.amp.GradScaler keeps it: scale(), unscale_(), step() and
+        update() then run without the host reading the overflow flag, so the whole step can be captured in a HIP graph
+        (torch_em_amd/graph.py).  `applied_steps` seeds the optimizer step count that travels with it."""
+        self._sstate = torch.tensor([self._scale, float(self._growth_tracker), 0.0, float(applied_steps)],
+                                    dtype=torch.float32, device=device)
+        return self._sstate
+
+    def _from_device(self):
+        if self._sstate is not None:
+            vals = self._sstate.tolist()     # host sync
+            self._scale, self._growth_tracker = float(vals[0]), int(vals[1])
 
     # -- queries ---------------------------------------------------------------------------
     def is_enabled(self) -> bool:
         return self._enabled
 
     def get_scale(self) -> float:
+        self._from_device()
         return self._scale if self._enabled else 1.0
 
     def get_growth_factor(self):
@@ -184,6 +251,8 @@ class GradScaler:
             return outputs
         if isinstance(outputs, (list, tuple)):
             return type(outputs)(self.scale(o) for o in outputs)
+        if self._sstate is not None:
+            return outputs * self._sstate[0]
         return outputs * self._scale
 
     def _flag(self, device):
@@ -203,6 +272,11 @@ class GradScaler:
         if isinstance(optimizer, FusedAdamW):
             optimizer._ensure_arena()
             flat = optimizer._arena.grads_flat()
+        if self._sstate is not None:
+            if flat is None:
+                raise RuntimeError("GradScaler.capturable: needs FusedAdamW with the engine's flat gradient arena")
+            ops.amp_unscale_dev(flat, self._sstate)
+            return
         if flat is not None:
             ops.amp_unscale(flat, inv, self._flag(flat.device))
             return
@@ -220,6 +294,8 @@ class GradScaler:
             return optimizer.step(*args, **kwargs)
         if id(optimizer) not in self._unscaled:
             self.unscale_(optimizer)
+        if self._sstate is not None:
+            return optimizer.step(*args, **kwargs)      # tem_adamw_step_tab reads the overflow flag itself
         found = any(float(f.item()) != 0.0 for f in self._found_inf.values())   # host sync, like torch's _maybe_opt_step
         if found:
             self._overflow = True
@@ -228,6 +304,12 @@ class GradScaler:
 
     def update(self, new_scale=None):
         if not self._enabled:
+            return
+        if self._sstate is not None:
+            if new_scale is not None:
+                raise NotImplementedError("GradScaler.capturable: update(new_scale)")
+            ops.amp_update_dev(self._sstate, self._growth_factor, self._backoff_factor, self._growth_interval)
+            self._unscaled.clear()
             return
         if new_scale is not None:
             self._scale = float(new_scale)
@@ -248,6 +330,7 @@ class GradScaler:
     def state_dict(self):
         if not self._enabled:
             return {}
+        self._from_device()
         return {"scale": self._scale, "growth_factor": self._growth_factor, "backoff_factor": self._backoff_factor,
                 "growth_interval": self._growth_interval, "_growth_tracker": self._growth_tracker}
 
@@ -259,3 +342,5 @@ class GradScaler:
         self._scale = float(state_dict["scale"])
         self._growth_factor, self._backoff_factor = state_dict["growth_factor"], state_dict["backoff_factor"]
         self._growth_interval, self._growth_tracker = state_dict["growth_interval"], state_dict["_growth_tracker"]
+        if self._sstate is not None:
+            self._sstate[0], self._sstate[1] = self._scale, float(self._growth_tracker)

@@ -117,8 +117,9 @@ class DefaultTrainer:
         self.train_time = 0.0
         # hip_graph: replay the training step (zero_grad .. optimizer step) as one captured HIP graph instead of ~220
         # launches enqueued from Python (torch_em_amd/graph.py).  Same results bit for bit; pays off where the host is
-        # the bottleneck (small patches).  None: TEM_HIP_GRAPH=1 in the environment.  Needs FusedAdamW, a single GPU and
-        # no loss scaling; otherwise the step silently runs eagerly (self._graph_why says why).
+        # the bottleneck (small patches).  None: TEM_HIP_GRAPH=1 in the environment.  Needs FusedAdamW and a single GPU;
+        # otherwise the step runs eagerly (self._graph_why says why).  With mixed precision the GradScaler's state moves
+        # to the device for good (as torch.amp.GradScaler keeps it).
         self.hip_graph = (os.environ.get("TEM_HIP_GRAPH", "0") == "1") if hip_graph is None else bool(hip_graph)
         self._graphed, self._graph_why = None, None
         self.logger_class, self.logger_kwargs = logger, logger_kwargs
@@ -427,8 +428,6 @@ class DefaultTrainer:
             why = "batch is not a pair of device tensors"
         elif not isinstance(self.optimizer, FusedAdamW):
             why = "optimizer is not FusedAdamW"
-        elif self.scaler is not None:
-            why = "dynamic loss scaling reads an overflow flag on the host every step"
         elif torch.distributed.is_available() and torch.distributed.is_initialized() and \
                 torch.distributed.get_world_size() > 1:
             why = "multi-GPU gradient all-reduce"
@@ -437,7 +436,8 @@ class DefaultTrainer:
         self._graph_why = why
         if why is not None:
             return None
-        self._graphed = GraphedTrainStep(self.model, self.loss, self.optimizer, x, y)
+        self._graphed = GraphedTrainStep(self.model, self.loss, self.optimizer, x, y, scaler=self.scaler,
+                                         precision="amp" if getattr(self, "_amp", False) else None)
         return self._graphed
 
     def _train_epoch(self, progress):
