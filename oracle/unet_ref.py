@@ -72,7 +72,12 @@ def unet_forward(sd, x, scale_factors, norm="InstanceNorm", final_activation=Non
         x = F.interpolate(x, scale_factor=f if isinstance(f, int) else tuple(float(v) for v in f), mode=mode,
                           align_corners=False)
         x = _conv(x, sd[f"decoder.samplers.{i}.conv.weight"], sd[f"decoder.samplers.{i}.conv.bias"])
-        x = torch.cat([x, skips[depth - 1 - i]], dim=1)
+        # Decoder._concat / _crop (reference model/unet.py:363-373): the skip tensor is centre-cropped by (difference // 2)
+        # per side in EVERY dimension before the concat (an odd difference leaves it one too large: torch.cat raises)
+        skip = skips[depth - 1 - i]
+        off = [(a - b) // 2 for a, b in zip(skip.shape, x.shape)]
+        skip = skip[tuple(slice(o, a - o) for o, a in zip(off, skip.shape))]
+        x = torch.cat([x, skip], dim=1)
         x = _block(sd, f"decoder.blocks.{i}", x, norm, training)
         dec_out.append(x)
     if "out_conv.0.weight" in sd:

@@ -49,6 +49,21 @@ def test_anisotropic_unet_masked_dice_matches_reference_golden(aniso):
     _run(model, _load(f"g2_aniso_{aniso}.npz"), LossWrapper(DiceLoss(), ApplyAndRemoveMask("multiply")))
 
 
+def test_decoder_crop_matches_reference_golden():
+    """Decoder._crop (reference model/unet.py:363-373): scale factors [[3,3,3],[2,2,2]] on 14^3 -- the level-0 skip tensor
+    (14^3) is centre-cropped to the 12^3 of the upsampled tensor.  Reachable only with `model.check_shape = False`
+    (UNetBase.forward :248), which the golden run set; with the check on, both raise the same ValueError."""
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import AnisotropicUNet
+    model = AnisotropicUNet(1, 2, [[3, 3, 3], [2, 2, 2]], initial_features=4)
+    with pytest.raises(ValueError, match="is not divisible by"):
+        model.to(DEV)(torch.zeros(1, 1, 14, 14, 14, device=DEV))
+    model.check_shape = False
+    _run(model, _load("g2c_crop.npz"), DiceLoss())
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):   # an odd difference cannot be cropped away
+        model(torch.zeros(1, 1, 13, 14, 14, device=DEV))
+
+
 def test_unet2d_matches_reference_golden():
     from torch_em_amd.loss import DiceLoss
     from torch_em_amd.model import UNet2d

@@ -41,6 +41,17 @@ def test_aniso_oracle_matches_reference(aniso):
         assert rel_err(v, g[f"grad.{k}"]) < 1e-4, k
 
 
+def test_crop_oracle_matches_reference():
+    """Decoder._crop (reference model/unet.py:363-373): 12^3 upsampled against a 14^3 skip tensor (check_shape = False)."""
+    g = _load("g2c_crop.npz")
+    pred, loss, grads = unet_ref.unet_loss_and_grads(_sd(g), torch.from_numpy(g["x"]), torch.from_numpy(g["y"]),
+                                                     [[3, 3, 3], [2, 2, 2]])
+    assert tuple(pred.shape) == (2, 2, 12, 12, 12) and rel_err(pred, g["pred"]) < 1e-5
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for k, v in grads.items():
+        assert rel_err(v, g[f"grad.{k}"]) < 1e-4, k
+
+
 def test_unet2d_oracle_matches_reference():
     g = _load("g3_unet2d.npz")
     pred, loss, grads = unet_ref.unet_loss_and_grads(_sd(g), torch.from_numpy(g["x"]), torch.from_numpy(g["y"]),

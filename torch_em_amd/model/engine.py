@@ -620,7 +620,8 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         f = _f3(enc.scale_factors[l], dim)
         c_up = dec.samplers[depth - 1 - l].conv.out_channels
         _, D, H, W, _ = cur.shape
-        if D % f[0] or H % f[1] or W % f[2]:
+        floor = bool(D % f[0] or H % f[1] or W % f[2])
+        if floor and getattr(model, "check_shape", True):
             raise ValueError(f"Invalid shape for U-Net: {(D, H, W)[3 - dim:]} is not divisible by {f[3 - dim:]}")
         cat = ops.new_act(N, D, H, W, c_up + blk.out_channels, dev)
         skip = cat[..., c_up:]
@@ -629,8 +630,16 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         dnorm = dec.blocks[depth - 1 - l].conv_specs()[0].norm
         bs = _block_fwd(blk, cur, skip, out_stats=_FUSE_STATS and _FUSE_CONCAT_STATS and _norm_is_live(dnorm))
         pooled = ops.new_act(N, D // f[0], H // f[1], W // f[2], blk.out_channels, dev)
-        ops.maxpool_fwd(skip, pooled, f)
-        st["levels"].append({"cat": cat, "skip": skip, "bs": bs, "f": f, "c_up": c_up})
+        lvl = {"cat": cat, "skip": skip, "bs": bs, "f": f, "c_up": c_up}
+        if floor:
+            # model.check_shape = False and a size the factor does not divide: nn.MaxPool3d drops the remainder.  The pooling
+            # kernels take whole windows, so they get a dense copy of the covered sub-volume (not the fast path; the
+            # decoder then crops this level's skip tensor, reference Decoder._crop)
+            lvl["floor_sub"] = skip[:, :D // f[0] * f[0], :H // f[1] * f[1], :W // f[2] * f[2]].contiguous()
+            ops.maxpool_fwd(lvl["floor_sub"], pooled, f)
+        else:
+            ops.maxpool_fwd(skip, pooled, f)
+        st["levels"].append(lvl)
         cur = pooled
     _, D, H, W, _ = cur.shape
     base_out = ops.new_act(N, D, H, W, model.base.out_channels, dev)
@@ -648,22 +657,28 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         t = ops.new_act(N, d, h, w, sspec.cout, dev)
         _conv(sspec, cur, t)                       # 1x1 conv at low resolution ...
         cat = lv["cat"]
-        if (d * f[0], h * f[1], w * f[2]) != tuple(cat.shape[1:4]):
-            # reference Decoder._crop (model/unet.py:363-366) centre-crops the skip by (diff // 2) per side, which only
-            # yields matching shapes for EVEN differences (never with factor-2 pooling, where a ragged size differs by 1
-            # and the reference's torch.cat raises); this engine writes the skip straight into the concat buffer and has
-            # no cropped variant
-            raise NotImplementedError(
-                f"input size {tuple(cat.shape[1:4])} at this level is not a multiple of the scale factor {f}: the "
-                "upsampled tensor and the skip connection differ in shape (the reference raises in torch.cat for odd "
-                "differences and centre-crops even ones; cropping is not implemented here) -- pad the input to a "
-                "multiple of the product of the scale factors")
+        up_sp, sk_sp = (d * f[0], h * f[1], w * f[2]), tuple(cat.shape[1:4])
+        cropped = up_sp != sk_sp
+        if cropped:
+            # reference Decoder._crop (model/unet.py:363-373; reachable with model.check_shape = False only): the skip tensor
+            # is centre-cropped by (difference // 2) per side.  Not the fast path: the concat buffer the encoder wrote into
+            # has the skip's shape, so a second one with the upsampled shape receives a copy of the cropped skip half, and
+            # its statistics / the backward of its norm take the plain (unfused) route.
+            diff = [a - b_ for a, b_ in zip(sk_sp, up_sp)]
+            if any(v < 0 or v % 2 for v in diff):
+                raise RuntimeError(f"Sizes of tensors must match except in dimension 1: the upsampled tensor is {up_sp}, the "
+                                   f"skip connection {sk_sp} (Decoder._crop removes (difference // 2) per side, which only "
+                                   "fits even differences; the reference fails in torch.cat the same way)")
+            off = [v // 2 for v in diff]
+            cat = ops.new_act(N, up_sp[0], up_sp[1], up_sp[2], lv["cat"].shape[4], dev)
+            cat[..., lv["c_up"]:] = lv["skip"][:, off[0]:off[0] + up_sp[0], off[1]:off[1] + up_sp[1], off[2]:off[2] + up_sp[2]]
+            lv["cat_c"], lv["crop"] = cat, off
         # statistics of the concat for the block's first norm without reading it: the skip half's partial sums were
         # written by the encoder conv that produced it, the upsampled half's come out of the upsampling kernel (factor 2:
         # tem_upsample_fwd_stats) or follow from the low-resolution t (sum y = sum (U^T 1) t, sum y^2 = sum t (U^T U t):
         # tem_upsample_stats)
         p2 = None
-        skip_part = lv["bs"].get("out_part")
+        skip_part = None if cropped else lv["bs"].get("out_part")
         want_stats = False
         if skip_part is not None:
             na = blk.conv_specs()[0].norm_args()
@@ -774,8 +789,8 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
     for i in reversed(range(depth)):
         d = st["dec"][i]
         lv = st["levels"][depth - 1 - i]
-        g_cat = torch.empty_like(lv["cat"])
-        coef = _block_bwd(d["bs"], g_cur, g_cat, grads, defer_input_norm=True)
+        g_cat = torch.empty_like(lv.get("cat_c", lv["cat"]))
+        coef = _block_bwd(d["bs"], g_cur, g_cat, grads, defer_input_norm="crop" not in lv)
         low, sspec = d["low"], d["sspec"]
         g_t = ops.new_act(low.shape[0], low.shape[1], low.shape[2], low.shape[3], sspec.cout, low.device)
         ops.upsample_bwd(g_cat[..., :lv["c_up"]], g_t, d["f"],
@@ -789,6 +804,11 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
             if extra is not None:
                 g_low.add_(extra)
         lv["g_skip"] = g_cat[..., lv["c_up"]:]
+        if "crop" in lv:   # the adjoint of the centre crop: zeros around the gradient of the cropped window
+            o, sk = lv["crop"], lv["skip"]
+            gs = torch.zeros(sk.shape, dtype=sk.dtype, device=sk.device)
+            gs[:, o[0]:o[0] + g_cat.shape[1], o[1]:o[1] + g_cat.shape[2], o[2]:o[2] + g_cat.shape[3]] = lv["g_skip"]
+            lv["g_skip"] = gs
         g_cur = g_low
         stage_done()
     bb = st["base"]
@@ -803,8 +823,17 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         skip = lv["skip"]
         g_skip_full = ops.new_act(skip.shape[0], skip.shape[1], skip.shape[2], skip.shape[3], skip.shape[4],
                                   skip.device)
-        ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True,
-                        gskip_coef=lv.get("g_skip_coef"), gy_coef=pool_coef)
+        if "floor_sub" in lv:
+            # remainder voxels outside every pooling window only receive the (zero-padded, cropped) decoder gradient
+            sub = lv["floor_sub"]
+            g_sub = torch.empty_like(sub)
+            ops.maxpool_bwd(g_cur, sub, g_sub, lv["f"], gy_coef=pool_coef)
+            g_skip_full.copy_(lv["g_skip"])
+            g_skip_full[:, :sub.shape[1], :sub.shape[2], :sub.shape[3]] += g_sub
+            g_skip_full.mul_(skip > 0)
+        else:
+            ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True,
+                            gskip_coef=lv.get("g_skip_coef"), gy_coef=pool_coef)
         need_in = (l > 0) or need_input_grad
         xin = lv["bs"]["xin"]
         g_in = torch.empty_like(xin) if need_in else None
