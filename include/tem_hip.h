@@ -198,6 +198,14 @@ int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* scale, cons
 int tem_conv3d_fwd_gscaled(const float* x, int64_t x_ld, const float* w_packed, float* y, int64_t y_ld,
                            const float* ref, int64_t ref_ld, const unsigned* in_amax, void* ws, int64_t ws_bytes,
                            int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, tem_stream_t stream);
+/* tem_conv3d_fwd of a data gradient that lands behind a ReLU + norm (the first conv of a block, seen from the second's
+ * backward): y = ref > 0 ? a*conv(x) - m1 - (ref - mean)*m2r : 0 with coef[N][Cout][4] = (a, m1, m2r, mean) from
+ * tem_norm_bwd_coef.  The epilogue of the z-reuse kernel replaces the elementwise pass of tem_norm_bwd_from_sums (the
+ * reference: autograd's native_layer_norm / relu backward kernels).  Only for launches tem_conv3d_fwd_kernel() == 3. */
+int tem_conv3d_fwd_refnorm(const float* x, int64_t x_ld, const float* w_packed, float* y, int64_t y_ld,
+                           const float* ref, int64_t ref_ld, const float* coef, void* ws, int64_t ws_bytes,
+                           int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma,
+                           tem_stream_t stream);
 
 /* tem_conv3d_wgrad of a first layer (Cin <= 4, VALU kernel) whose g is still the RAW data gradient behind the norm that
  * follows this conv's ReLU (the second norm of the first ConvBlock, model/unet.py:429-438): the norm backward

@@ -308,6 +308,37 @@ def test_data_gradient_fp16_two_term_with_device_prescale(case, gscale):
     assert not torch.equal(gx2, gx5)
 
 
+@pytest.mark.parametrize("mode", [2, 5])
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 32), (2, 18, 61, 67, 64, 32), (2, 16, 64, 64, 64, 64)])
+def test_data_gradient_with_norm_backward_epilogue(case, mode):
+    """tem_conv3d_fwd_refnorm: the data gradient of a block's second conv leaves the z-reuse kernel with the backward of the
+    norm in front of that conv and the ReLU mask of the first conv's output already applied (reference: autograd's
+    native_group_norm_backward + threshold_backward after convolution_backward, model/unet.py:417-438) -- equal to the
+    plain data gradient followed by the elementwise pass of tem_norm_bwd_from_sums it replaces."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout = case              # the conv maps Cin -> Cout; its data gradient Cout -> Cin
+    k = (3, 3, 3)
+    g = torch.Generator().manual_seed(23)
+    w = (torch.randn(Cout, Cin, *k, generator=g) * 0.2).to(DEV)
+    g5 = to5(torch.randn(N, Cout, D, H, W, generator=g))
+    a1 = to5(torch.relu(torch.randn(N, Cin, D, H, W, generator=g) + 0.2))     # a ReLU output: ~45 % zeros
+    coef = torch.randn(N, Cin, 4, generator=g).to(DEV)
+    assert ops.conv_fwd_family(g5, k, Cout, Cin, mode) == 3
+    wp = ops.pack_weights(w, transpose=True, mfma=mode)
+    plain = ops.new_act(N, D, H, W, Cin, DEV)
+    ops.conv_fwd(g5, wp, None, plain, k, Cout, Cin, mfma=mode)
+    kc = coef.view(N, 1, 1, 1, Cin, 4)
+    want = torch.where(a1 > 0, kc[..., 0] * plain - kc[..., 1] - (a1 - kc[..., 3]) * kc[..., 2], torch.zeros_like(plain))
+    got = torch.full((N, D, H, W, Cin + 8), 7.0, device=DEV)                  # a channel slice of a wider buffer
+    ops.conv_fwd_refnorm(g5, wp, got[..., :Cin], k, Cout, Cin, a1, coef, mode)
+    assert float((got[..., :Cin] - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float(got[..., Cin:].min()) == 7.0 and float(got[..., Cin:].max()) == 7.0
+    with pytest.raises(ValueError):                                            # a shape the z-reuse kernel does not take
+        small = to5(torch.randn(1, Cout, 4, 8, 8, generator=g))
+        ops.conv_fwd_refnorm(small, wp, ops.new_act(1, 4, 8, 8, Cin, DEV), k, Cout, Cin,
+                             ops.new_act(1, 4, 8, 8, Cin, DEV), coef[:1].contiguous(), mode)
+
+
 @pytest.mark.parametrize("case", [      # >= 384 workgroups each: smaller launches run split-K and cannot fuse
     (2, 18, 61, 67, 32, 64, (3, 3, 3), 32),   # z-reuse kernel (720 units), ragged in z, y and x, two column tiles, GroupNorm(32, 64)
     (2, 32, 64, 64, 32, 32, (3, 3, 3), 32),   # z-reuse kernel, exactly one unit per team

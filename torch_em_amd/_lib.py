@@ -46,6 +46,7 @@ SIGNATURES = {
     "tem_conv3d_wgrad_gmax": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]
                               + [c_int] * 10 + [c_vp]),
     "tem_conv3d_fwd_gscaled": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp]),
+    "tem_conv3d_fwd_refnorm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp]),
     "tem_norm_ws": (c_i64, [c_int, c_i64, c_int]),
     "tem_conv3d_wgrad_gnorm_ok": (c_int, [c_int] * 6),
     "tem_conv3d_wgrad_gnorm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64]

@@ -630,6 +630,29 @@ extern "C" int tem_conv3d_fwd_gscaled(const float* x, int64_t x_ld, const float*
     return rc;
 }
 
+// Data gradient that lands behind a ReLU + norm: y = ref > 0 ? a*(conv) - m1 - (ref - mean)*m2r : 0 with coef[N][Cout][4] =
+// (a, m1, m2r, mean) from tem_norm_bwd_coef -- the epilogue of the z-reuse kernel replaces tem_norm_bwd_from_sums' pass over
+// g and ref.  Only for launches tem_conv3d_fwd_kernel() reports as 3.
+extern "C" int tem_conv3d_fwd_refnorm(const float* x, int64_t x_ld, const float* w_packed, float* y, int64_t y_ld,
+                                      const float* ref, int64_t ref_ld, const float* coef, void* ws, int64_t ws_bytes,
+                                      int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma,
+                                      tem_stream_t stream) {
+    TEM_REQUIRE(ref && coef, "tem_conv3d_fwd_refnorm: null ref / coef");
+    TEM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0 && tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) == 3,
+                "tem_conv3d_fwd_refnorm: only launches that tem_conv3d_fwd_kernel() reports as 3 (z-reuse kernel) apply a "
+                "norm backward in their epilogue");
+    tem_zr_ref_coef = coef;
+    const int rc = conv3d_fwd_impl(x, x_ld, nullptr, nullptr, w_packed, nullptr, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
+                                   W, Cin, Cout, kd, kh, kw, TEM_ACT_NONE, use_mfma, nullptr, stream);
+    const bool consumed = tem_zr_ref_coef == nullptr;
+    tem_zr_ref_coef = nullptr;
+    if (rc == TEM_OK && !consumed) {
+        tem_set_error("tem_conv3d_fwd_refnorm: the launch did not take the z-reuse kernel (alignment of y / ref?)");
+        return TEM_EINVAL;
+    }
+    return rc;
+}
+
 extern "C" int tem_conv3d_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                         int use_mfma) {
     if (use_mfma != 2 && use_mfma != 5) return 0;

@@ -79,6 +79,7 @@ extern thread_local unsigned* tem_wgrad_gmax_target;
 int tem_conv_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 // prescale of the z-reuse kernel's input by a power of two derived from a device-side |max| (tem_conv3d_fwd_gscaled)
 extern thread_local const unsigned* tem_zr_in_amax;
+extern thread_local const float* tem_zr_ref_coef;
 // wgrad_sums.hip: norm-backward sums from the weight gradient
 int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int64_t tem_wgrad_sums_ws_floats(int N, int D, int H, int Cin, int Cout);

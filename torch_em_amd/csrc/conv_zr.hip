@@ -116,7 +116,10 @@ struct ZrUnit {
 
 // NS planes per operand; F16: fp16 terms with the lo planes stored x 2^12 and their cross products in a second
 // accumulator set (TEM_WL_F16X3), NS == 1 && F16: the one-term mixed mode; else bf16 terms in one accumulator set.
-// MODE (launch-uniform, one epilogue per instantiation): 0 plain, 1 fused statistics (`stat`), 2 ReLU mask (`ref`).
+// MODE (launch-uniform, one epilogue per instantiation): 0 plain, 1 fused statistics (`stat`), 2 ReLU mask (`ref`),
+// 3 ReLU mask + backward of the norm behind it: y = ref > 0 ? a*acc - m1 - (ref - mean)*m2r : 0 with (a, m1, m2r, mean) per
+// (sample, output channel) read from `stat` (= coef[N][Cout][4], tem_norm_bwd_coef): a data gradient that lands behind a
+// ReLU + norm leaves this kernel finished -- the elementwise pass over g and ref (k_norm_bwd_apply) disappears.
 template <int NS, bool F16, int MODE>
 __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
             // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
             if (epi_pending) {
                 const __amdgpu_buffer_rsrc_t ry = zr_rsrc(y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld + eu.cot * 32);
-                constexpr bool has_ref = MODE == 2;
+                constexpr bool has_ref = MODE == 2 || MODE == 3;
                 const __amdgpu_buffer_rsrc_t rr_ = zr_rsrc(has_ref ? ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld + eu.cot * 32 : y);
                 const bool full = (TEM_ZR_ABL & 32) ? true : ((eu.z0 + TZ <= D) & (eu.y0 + TY <= H) & (eu.x0 + TX <= W));
                 const bool vok = (eu.y0 + 4 * tw + py < H) & (eu.x0 + px < W);   // this lane's footprint voxel (any z)
@@ -344,6 +347,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                 unsigned char* scr_w = scr + v * 144 + kh * 16;                 // + 32 j: piece (2 j + kh) of this lane's voxel
                 const unsigned char* scr_r = scr + (lane >> 3) * 144 + (lane & 7) * 16;   // + 8 m rows: voxel (py = m, px = lane >> 3)
                 const bool tok_yx = (eu.x0 + (lane >> 3) < W);                  // transposed voxel: x in range (y, z per store)
+                float4 kc[4];   // MODE 3: (a, m1, m2r, mean) of the 4 channels this lane stores
+                if (MODE == 3) {
+                    const float4* cf = reinterpret_cast<const float4*>(stat) + ((int64_t)eu.n * Cout + eu.cot * 32 + (lane & 7) * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) kc[c] = cf[c];
+                }
                 auto body = [&](auto full_tag, auto ref_tag, auto stat_tag) {
                     constexpr bool FULL = decltype(full_tag)::value, HASREF = decltype(ref_tag)::value, STAT = decltype(stat_tag)::value;
                     float4 q[2][4];
@@ -384,7 +393,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                         for (int m = 0; m < 4; ++m) t[m] = *reinterpret_cast<const float4*>(scr_r + m * (8 * 144));
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
-                            if (HASREF) {
+                            if (MODE == 3) {
+                                const float4 r = q[z & 1][m];
+                                t[m].x = r.x > 0.f ? kc[0].x * t[m].x - kc[0].y - (r.x - kc[0].w) * kc[0].z : 0.f;
+                                t[m].y = r.y > 0.f ? kc[1].x * t[m].y - kc[1].y - (r.y - kc[1].w) * kc[1].z : 0.f;
+                                t[m].z = r.z > 0.f ? kc[2].x * t[m].z - kc[2].y - (r.z - kc[2].w) * kc[2].z : 0.f;
+                                t[m].w = r.w > 0.f ? kc[3].x * t[m].w - kc[3].y - (r.w - kc[3].w) * kc[3].z : 0.f;
+                            } else if (HASREF) {
                                 t[m].x = q[z & 1][m].x > 0.f ? t[m].x : 0.f;
                                 t[m].y = q[z & 1][m].y > 0.f ? t[m].y : 0.f;
                                 t[m].z = q[z & 1][m].z > 0.f ? t[m].z : 0.f;
@@ -396,8 +411,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                         }
                     }
                 };
-                if (full) body(std::true_type{}, std::integral_constant<bool, MODE == 2>{}, std::integral_constant<bool, MODE == 1>{});
-                else body(std::false_type{}, std::integral_constant<bool, MODE == 2>{}, std::integral_constant<bool, MODE == 1>{});
+                if (full) body(std::true_type{}, std::integral_constant<bool, has_ref>{}, std::integral_constant<bool, MODE == 1>{});
+                else body(std::false_type{}, std::integral_constant<bool, has_ref>{}, std::integral_constant<bool, MODE == 1>{});
                 ZR_STAMP(9);
                 if (MODE == 1) {
                     // transposing reduction over the 32 voxel lanes of each half-wave: after the step with partner lane ^ m
@@ -705,6 +720,9 @@ static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float
 // tem_conv3d_fwd_gscaled (conv.hip) parks the device pointer of max |input| here around its call; the launch that honours
 // it clears it (so the caller can tell that the prescale really happened)
 thread_local const unsigned* tem_zr_in_amax = nullptr;
+// tem_conv3d_fwd_refnorm parks coef[N][Cout][4] here the same way: the launch applies the ReLU mask of `ref` AND the backward
+// of the norm behind it in its epilogue (MODE 3)
+thread_local const float* tem_zr_ref_coef = nullptr;
 
 // -> 1 launched, 0 shape not taken, -1 error (statistics sized for this kernel but the launch cannot take it)
 int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp, const float* bias,
@@ -727,11 +745,22 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
     do {                                                                                                                      \
         if (stat)                                                                                                             \
             zr_launch<NS, F16, 1>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+        else if (ref && rcoef)                                                                                                \
+            zr_launch<NS, F16, 3>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act,        \
+                                  const_cast<float*>(rcoef), in_amax, s);                                                     \
         else if (ref)                                                                                                         \
             zr_launch<NS, F16, 2>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
         else                                                                                                                  \
             zr_launch<NS, F16, 0>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
     } while (0)
+    const float* rcoef = tem_zr_ref_coef;
+    if (rcoef) {
+        if (!ref || stat || ((uintptr_t)rcoef % 16)) {
+            tem_set_error("tem_conv3d_fwd_refnorm: needs ref, no statistics, 16-byte aligned coefficients");
+            return -1;
+        }
+        tem_zr_ref_coef = nullptr;   // consumed
+    }
     const unsigned* in_amax = tem_zr_in_amax;
     if (in_amax) {
         if (nsplit != 4 || bias || scale || stat) {

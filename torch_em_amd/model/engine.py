@@ -362,11 +362,18 @@ def _join_side(device):
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
-def _dgrad(spec: ConvSpec, g, gx, ref=None, gmax=None):
-    """gmax: int32[1] with max |g| (from _wgrad(..., gmax=) of the same layer) -> fp16 two-term layout, else bf16x3"""
+def _dgrad(spec: ConvSpec, g, gx, ref=None, gmax=None, refnorm=None):
+    """gmax: int32[1] with max |g| (from _wgrad(..., gmax=) of the same layer) -> fp16 two-term layout, else bf16x3.
+    refnorm: coef [N, C, 4] of the norm behind `ref` -- its backward (and ref's ReLU mask) run in the kernel's epilogue."""
     if _OVERLAP_WGRAD == 2:
         _join_side(g.device)  # MFMA kernels never overlap each other: wait for the weight gradient in flight
     ent = spec.packed()
+    if refnorm is not None:
+        if "dgrad" not in ent:
+            ent["dgrad"] = ops.pack_weights(spec.conv.weight, transpose=True, mfma=ent["dgrad_mfma"])
+        ent["dgrad_used"] = True
+        ops.conv_fwd_refnorm(g, ent["dgrad"], gx, spec.k, spec.cout, spec.cin, ref, refnorm, ent["dgrad_mfma"])
+        return
     if gmax is not None:
         if "dgrad16" not in ent:
             ent["dgrad16"], ent["dgrad16_mfma"] = ops.pack_weights(spec.conv.weight, transpose=True, mfma=4), 4
@@ -508,6 +515,9 @@ def _block_fwd(blk, xin, out, in_partials2=None, out_stats=False):
 # backward -- apply gx = a*g - m1 - (x - mean)*m2r on the fly (ops.norm_bwd_coef / tem_upsample_bwd_norm /
 # tem_maxpool3d_bwd_norm).  TEM_DEFER_CONCAT_NORM=0 restores the in-place pass.
 _DEFER_CONCAT_NORM = os.environ.get("TEM_DEFER_CONCAT_NORM", "1") != "0"
+# norm backward + ReLU mask in the epilogue of the data-gradient kernel (tem_conv3d_fwd_refnorm); TEM_FUSE_NORM_BWD_DGRAD=0:
+# the elementwise pass of tem_norm_bwd_from_sums
+_FUSE_NORM_BWD_DGRAD = os.environ.get("TEM_FUSE_NORM_BWD_DGRAD", "1") != "0"
 
 
 def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sums=None, coef_only=False):
@@ -538,7 +548,17 @@ def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
     # per layer: dgrad first (alone), then the weight gradient (side stream, see _OVERLAP_WGRAD) next to the norm backward
     ga1 = torch.empty_like(a1)
     affine1 = bs["s1"] is not None and c1.norm_args()[1] is not None
-    if bs["s2"] is not None:
+    if bs["s2"] is not None and _FUSE_NORM_BWD_DGRAD and bs["s2"][4] == "sample" and not _OVERLAP_WGRAD and \
+            not (gin is None and not affine1) and not _dgrad16_ok(c2, gout) and c2.conv.bias is not None and \
+            ops.conv_wgrad_sums_ok(a1, c2.k, c2.cin, c2.cout, c2.packed()["wgrad_mfma"]) and \
+            ops.conv_fwd_family(gout, c2.k, c2.cout, c2.cin, c2.packed()["dgrad_mfma"]) == 3:
+        # The weight gradient runs FIRST and delivers the sums of norm2's backward (tem_conv3d_wgrad_sums) without the data
+        # gradient existing yet; with the coefficients known, the data-gradient kernel applies norm2's backward and the
+        # ReLU mask of a1 in its epilogue: no elementwise pass over ga1 and a1 (0.28 ms at 2 x 128^3 x 32)
+        sums = _wgrad(c2, a1, gout, grads, bs["s2"], want_sums=True)
+        coef = _norm_bwd_inplace(c2, gout, a1, bs["s2"], True, grads, sums=sums, coef_only=True)
+        _dgrad(c2, gout, ga1, ref=a1, refnorm=coef)
+    elif bs["s2"] is not None:
         if _dgrad16_ok(c2, gout):   # weight gradient first: it delivers max |gout| for the prescale of the data gradient
             gm = grads.amax_slot()
             sums = _wgrad(c2, a1, gout, grads, bs["s2"], want_sums=True, gmax=gm)

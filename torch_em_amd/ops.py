@@ -360,6 +360,29 @@ def conv_fwd_gscaled(x, w_packed, y, k, cin, cout, amax, ref=None):
     return y
 
 
+def conv_fwd_refnorm(x, w_packed, y, k, cin, cout, ref, coef, mfma):
+    """Data gradient that lands behind a ReLU + norm (tem_conv3d_fwd_refnorm): y = ref > 0 ? a*conv(x) - m1 - (ref - mean)*m2r
+    : 0, coef [N, cout, 4] from norm_bwd_coef.  Only where conv_fwd_family(...) == 3."""
+    _req_cuda(x, w_packed, y, ref, coef)
+    N, D, H, W, C, x_ld = _act5(x)
+    Ny, Dy, Hy, Wy, Cy, y_ld = _act5(y)
+    if C != cin or Cy != cout or (N, D, H, W) != (Ny, Dy, Hy, Wy) or tuple(coef.shape) != (N, cout, 4) or \
+            not coef.is_contiguous():
+        raise ValueError(f"conv_fwd_refnorm: shape mismatch x{tuple(x.shape)} y{tuple(y.shape)} coef{tuple(coef.shape)}")
+    ref_ld = _act5(ref)[5]
+    lib = _lib.load()
+    nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 1)
+    ws = _workspace(nws, x.device) if nws else None
+    kind = _fwd_tag(mfma, k, cout, 3) if PROFILER is not None else None
+    ev0 = _prof_begin(x, kind)
+    _lib.check(lib.tem_conv3d_fwd_refnorm(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(coef), _p(ws), nws,
+                                          N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma), _stream(x)),
+               "tem_conv3d_fwd_refnorm")
+    if ev0 is not None:
+        _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
+    return y
+
+
 def conv_fwd_family(x, k, cin, cout, mfma) -> int:
     """tem_conv3d_fwd_kernel: 0 patch / other kernels, 1 / 2 ping-pong teams, 3 z-reuse teams"""
     N, D, H, W, _, _ = _act5(x)
