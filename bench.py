@@ -142,9 +142,17 @@ def extra_measurements(step, args, engine):
         for key, fn in (("cfg1_ms_per_step", wl.cfg1), ("cfg3_ms_per_step", wl.cfg3), ("cfg5_ms_per_step", wl.cfg5)):
             out[key] = fn()["ms_per_step"]
             torch.cuda.empty_cache()
+        spec = importlib.util.spec_from_file_location("host_overhead", os.path.join(ROOT, "scripts", "host_overhead.py"))
+        ho = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ho)
+        # the step as ONE replayed HIP graph (torch_em_amd/graph.py): host enqueue time and step time, at the benchmark size
+        # (GPU-bound either way) and at 32^3 (host-bound when enqueued launch by launch)
+        out["hip_graph"] = {"cfg2": ho.run(args.size, args.batch, 5), "patch32": ho.run(32, args.batch, 10)}
+        torch.cuda.empty_cache()
         out["extras_note"] = ("exact_fp32 / amp: the cfg-2 step of this run under engine.set_precision('fp32' / 'amp'), 3 steps "
                               "after 2 warm-ups; cfg1/cfg3/cfg5: BASELINE configs 1, 3, 5 (per-GPU step incl. on-device "
-                              "targets), scripts/bench_workloads.py; all at the engine's default precision unless named")
+                              "targets), scripts/bench_workloads.py; hip_graph: scripts/host_overhead.py (host_ms = enqueue of one step into an idle "
+                              "queue, gpu_ms = back-to-back steps); all at the engine's default precision unless named")
     except Exception as e:  # the headline must survive a failing extra
         out["extras_error"] = f"{type(e).__name__}: {e}"
     finally:

@@ -55,7 +55,7 @@ int tem_device_cus(void);
  *                        1 = the round-2 kernel (k_conv_wgrad_zs), 0 = patch kernel
  *   "wgrad_zs_persist"    1 | 0   persistent column segments of that kernel
  *   "wgrad_sums"          1 | 0   norm-backward sums taken from the weight gradient
- *   "wgrad_sums_min_mb"   256     ... for layers whose replaced pass reads at least this many MiB
+ *   "wgrad_sums_min_mb"   128     ... for layers whose norm input has at least this many MiB
  *   "fwd_persistent"     -1 | 0 | 1   exact-fp32 forward: persistent variant (-1: 64-column tiles only)
  *   "conv1x1_stream"      1 | 0   1x1x1 convolutions / data gradients as a streaming GEMM instead of the patch kernel
  *   "fwd_ksplit_chunks"   0       split-K forward: at most this many 16-channel chunks per partial (0: heuristic)

@@ -39,6 +39,35 @@ def measure(fn, steps):
     return host / steps * 1e3, e0.elapsed_time(e1) / steps
 
 
+def run(size=128, batch=2, steps=20, precision=None):
+    """-> {"workload", "eager": {host_ms, gpu_ms}, "hip_graph": {host_ms, gpu_ms}} for the cfg-2 network at batch x size^3"""
+    prev = engine.PRECISION
+    if precision:
+        engine.set_precision(precision)
+    try:
+        torch.manual_seed(0)
+        model = UNet3d(1, 2, depth=4, initial_features=32).to("cuda")
+        opt = FusedAdamW(model.parameters(), lr=1e-4)
+        loss_fn = DiceLoss()
+        x = torch.randn(batch, 1, size, size, size, device="cuda")
+        y = (torch.rand(batch, 2, size, size, size, device="cuda") > 0.5).float()
+
+        def eager():
+            opt.zero_grad()
+            loss = loss_fn(model(x), y)
+            loss.backward()
+            opt.step()
+
+        eh, eg = measure(eager, steps)
+        step = GraphedTrainStep(model, loss_fn, opt, x, y)
+        gh, gg = measure(lambda: step(x, y), steps)
+        return {"workload": f"UNet3d(1->2, 32 features, depth 4) {batch}x1x{size}^3, {engine.PRECISION}",
+                "eager": {"host_ms": round(eh, 3), "gpu_ms": round(eg, 3)},
+                "hip_graph": {"host_ms": round(gh, 3), "gpu_ms": round(gg, 3)}}
+    finally:
+        engine.set_precision(prev)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=128)
@@ -46,27 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--precision", default=None)
     a = ap.parse_args()
-    if a.precision:
-        engine.set_precision(a.precision)
-    torch.manual_seed(0)
-    model = UNet3d(1, 2, depth=4, initial_features=32).to("cuda")
-    opt = FusedAdamW(model.parameters(), lr=1e-4)
-    loss_fn = DiceLoss()
-    x = torch.randn(a.batch, 1, a.size, a.size, a.size, device="cuda")
-    y = (torch.rand(a.batch, 2, a.size, a.size, a.size, device="cuda") > 0.5).float()
-
-    def eager():
-        opt.zero_grad()
-        loss = loss_fn(model(x), y)
-        loss.backward()
-        opt.step()
-
-    eh, eg = measure(eager, a.steps)
-    step = GraphedTrainStep(model, loss_fn, opt, x, y)
-    gh, gg = measure(lambda: step(x, y), a.steps)
-    print(json.dumps({"workload": f"UNet3d(1->2, 32 features, depth 4) {a.batch}x1x{a.size}^3, {engine.PRECISION}",
-                      "eager": {"host_ms": round(eh, 3), "gpu_ms": round(eg, 3)},
-                      "hip_graph": {"host_ms": round(gh, 3), "gpu_ms": round(gg, 3)}}))
+    print(json.dumps(run(a.size, a.batch, a.steps, a.precision)))
 
 
 if __name__ == "__main__":

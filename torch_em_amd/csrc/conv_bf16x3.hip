@@ -1724,7 +1724,7 @@ int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd
     if (!enable || Cin % 32 || Cout % 32) return 0;
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
     const int cq = Cout / 4;
-    // four small launches replace one pass over gz and x: only worth it where that pass is long (>= 256 MB tensors)
+    // four small launches replace one pass over gz and x: only worth it where that pass is long (>= 128 MB tensors by default)
     const int64_t min_bytes = (int64_t)tem_option(TEM_OPT_WGRAD_SUMS_MIN_MB) << 20;
     const int64_t bytes = (int64_t)N * D * H * W * Cin * 4;
     return z.use && N <= 4 && Cout <= 128 && Cin <= 256 && (cq & (cq - 1)) == 0 && H >= 3 && W >= 3 && D >= 3 &&

@@ -144,6 +144,9 @@ __global__ __launch_bounds__(256) void k_shell_plane_sums(const float* __restric
 //   with z[u + (t - 1)] and T[tap] sums g[u] over the u with u + (t - 1) inside the volume.
 // Every reduction runs 4 lanes wide (slots) resp. 8 lanes wide (tap x co) with shuffles: no serial 100-step loops.
 // ---------------------------------------------------------------------------
+#ifndef TEM_NS_ABL
+#define TEM_NS_ABL 0   // profiling ablations: 1 no class totals, 2 no bias-gradient total, 4 no weight loop
+#endif
 __global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __restrict__ planepart,
                                                               const float* __restrict__ dbpart, int Ss, int D, int H,
                                                               int Cin, int Cout, const float* __restrict__ w,
@@ -153,40 +156,45 @@ __global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __re
     float* cls = lt;
     float* T = lt + 27 * Cout;
     const int n = blockIdx.y, nslot = D - 2 + 2 * H;
-    const int l4 = threadIdx.x & 3, e4 = threadIdx.x >> 2;  // 256 entries per round, 4 slot lanes each (1024 threads)
-    for (int e0 = 0; e0 < 27 * Cout; e0 += 256) {
-        const int t = e0 + e4;
+    const int l4 = threadIdx.x & 3, e4 = threadIdx.x >> 2;  // bias-gradient total below: 256 entries per round, 4 row lanes each
+    // class totals: one thread per entry (z class, y/x class, co), consecutive lanes on consecutive floats of a slot row, 32
+    // slots in flight.  Measured (TEM_NS_ABL builds, 32 -> 32 at 2 x 128^3): the kernel takes 39 us on its 2-8 workgroups --
+    // 14 for these totals, 4 for the bias-gradient total, 15 for the weight loop at the end, 5 for everything else --
+    // and neither coalescing (this version; the first one spread a wave's lanes over 4 slot rows) nor deeper load batches
+    // change that: each phase is a chain of 2-4 dependent round trips to data another XCD just wrote.
+    for (int t = threadIdx.x; t < ((TEM_NS_ABL & 1) ? 0 : 27 * Cout); t += 1024) {
+        const int cz = t / (9 * Cout), rem = t % (9 * Cout);
+        const int s0 = cz == 1 ? 0 : (cz == 0 ? D - 2 : D - 2 + H), s1 = cz == 1 ? D - 2 : s0 + H;
         float a = 0.f;
-        if (t < 27 * Cout) {
-            const int cz = t / (9 * Cout), rem = t % (9 * Cout);
-            const int s0 = cz == 1 ? 0 : (cz == 0 ? D - 2 : D - 2 + H), s1 = cz == 1 ? D - 2 : s0 + H;
-            int sl = s0 + l4;
-            for (; sl + 28 < s1; sl += 32) {  // eight independent loads in flight: these loops are pure latency
-                float v[8];
+        for (int sl = s0; sl < s1; sl += 32) {
+            float v[32];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = planepart[((int64_t)n * nslot + sl + 4 * k) * 9 * Cout + rem];
-                a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            }
-            for (; sl < s1; sl += 4) a += planepart[((int64_t)n * nslot + sl) * 9 * Cout + rem];
+            for (int k = 0; k < 32; ++k) v[k] = sl + k < s1 ? planepart[((int64_t)n * nslot + sl + k) * 9 * Cout + rem] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; k += 8)
+                a += ((v[k] + v[k + 1]) + (v[k + 2] + v[k + 3])) + ((v[k + 4] + v[k + 5]) + (v[k + 6] + v[k + 7]));
         }
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
-        if (l4 == 0 && t < 27 * Cout) cls[t] = a;
+        cls[t] = a;
     }
+    if (TEM_NS_ABL & 1)
+        for (int t = threadIdx.x; t < 27 * Cout; t += 1024) cls[t] = 0.f;
     __syncthreads();
     // the interior class (1,1,1) = total - everything else; total = per-sample bias gradient (Ss partial rows)
     for (int c0 = 0; c0 < Cout; c0 += 256) {
         const int co = c0 + e4;
         float tot = 0.f;
         if (co < Cout) {
-            int sp = l4;
-            for (; sp + 28 < Ss; sp += 32) {
-                float v[8];
+            for (int sp = l4; sp < ((TEM_NS_ABL & 2) ? 0 : Ss); sp += 128) {
+                float v[32];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = dbpart[((int64_t)n * Ss + sp + 4 * k) * Cout + co];
-                tot += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                for (int k = 0; k < 32; ++k) {
+                    const int si = sp + 4 * k;
+                    v[k] = si < Ss ? dbpart[((int64_t)n * Ss + si) * Cout + co] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 32; k += 8)
+                    tot += ((v[k] + v[k + 1]) + (v[k + 2] + v[k + 3])) + ((v[k + 4] + v[k + 5]) + (v[k + 6] + v[k + 7]));
             }
-            for (; sp < Ss; sp += 4) tot += dbpart[((int64_t)n * Ss + sp) * Cout + co];
         }
         tot += __shfl_xor(tot, 1, 64);
         tot += __shfl_xor(tot, 2, 64);
@@ -221,20 +229,17 @@ __global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __re
     const int ci = blockIdx.x * 32 + (threadIdx.x >> 5), l8 = threadIdx.x & 31;  // 32 lanes per input channel
     double A = 0.0, S2 = 0.0;
     if (ci < Cin) {
-        int j = l8;
-        for (; j + 96 < 27 * Cout; j += 128) {  // j = tap * Cout + co; four weight loads in flight
-            float wv[4];
+        // lane = tap, loop over co: a load instruction reads the 27 consecutive floats of w[co][ci][:] for two input
+        // channels (the (tap, co)-per-lane version gathered 64 separate cache lines per instruction: 15 us)
+        if (l8 < 27) {
+            for (int c0 = 0; c0 < ((TEM_NS_ABL & 4) ? 0 : Cout); c0 += 16) {
+                float wv[16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int jj = j + 32 * k;
-                wv[k] = w[((int64_t)(jj % Cout) * Cin + ci) * 27 + jj / Cout];
+                for (int k = 0; k < 16; ++k) wv[k] = c0 + k < Cout ? w[((int64_t)(c0 + k) * Cin + ci) * 27 + l8] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (c0 + k < Cout) A += (double)wv[k] * (double)T[l8 * Cout + c0 + k];
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) A += (double)wv[k] * (double)T[j + 32 * k];
-        }
-        for (; j < 27 * Cout; j += 32) {
-            const int tap = j / Cout, co = j % Cout;
-            A += (double)w[((int64_t)co * Cin + ci) * 27 + tap] * (double)T[j];
         }
         for (int j = l8; j < 27 * cg; j += 32) {
             const int tap = j / cg, k = j % cg;
