@@ -70,6 +70,8 @@ PRECISION_DTYPE = {
     "amp": "f16 operands (REDUCED PRECISION, not the headline configuration: conv operands rounded to fp16, one fp16 MFMA "
            "per product, fp32 accumulate and storage -- the counterpart of the reference's torch.autocast(float16); no "
            "loss scaling in this synthetic step)",
+    "amp_bf16": "bf16 operands (REDUCED PRECISION, not the headline configuration: conv operands rounded to bf16, one bf16 "
+                "MFMA per product, fp32 accumulate and storage -- the counterpart of torch.autocast(bfloat16))",
 }
 
 
@@ -131,7 +133,8 @@ def extra_measurements(step, args, engine):
         return (time.perf_counter() - t0) / n * 1e3
     try:
         if args.batch == 2 and args.size == 128:
-            for prec, key in (("fp32", "exact_fp32_ms_per_step"), ("amp", "amp_ms_per_step")):
+            for prec, key in (("fp32", "exact_fp32_ms_per_step"), ("amp", "amp_ms_per_step"),
+                              ("amp_bf16", "amp_bf16_ms_per_step")):
                 engine.set_precision(prec)
                 out[key] = timed()
         engine.set_precision(prev)
@@ -199,7 +202,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys (exact-fp32 / mixed-precision step times of cfg 2, cfg 1/3/5 step times)")
-    ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "split", "split16", "bf16x3", "amp"],
+    ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "split", "split16", "bf16x3", "amp", "amp_bf16"],
                     help="MFMA conv arithmetic (default: engine default = split16)")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table to this file")
     args = ap.parse_args()

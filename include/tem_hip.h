@@ -90,6 +90,7 @@ int tem_get_option(const char* name, int64_t* value);
 #define TEM_WL_BF16X6 3
 #define TEM_WL_F16X3 4  /* like BF16X3 with two fp16 terms per weight (22 mantissa bits), lo plane stored x 2^12 */
 #define TEM_WL_F16 5    /* ONE fp16 term per weight (half the bytes): the mixed-precision mode, use_mfma 5 */
+#define TEM_WL_BF16 7   /* ONE bf16 term per weight: mixed precision with mixed_precision_dtype="bfloat16", use_mfma 7 */
 #define TEM_WL_F16X3S 6 /* two fp16 terms of the weight x 2^7 (both terms carry the prescale; activations are staged x 2^5,
                            the kernel's epilogue multiplies by 2^-12): one accumulator for all three products, use_mfma 6 */
 #define TEM_ACT_NONE 0
@@ -134,6 +135,9 @@ int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Ci
  *                the reference's default GPU mode, torch.autocast(float16) around nn.Conv3d
  *                (trainer/default_trainer.py:134-142,789-794); NOT parity-grade (2^-11 per operand), used only
  *                when the trainer is created with mixed_precision=True (TEM_WL_F16 pack);
+ *                7 = the same with operands rounded to bf16 (ONE v_mfma_f32_32x32x16_bf16 per product): the
+ *                arithmetic of torch.autocast(bfloat16), mixed_precision_dtype="bfloat16" (:134-142: no GradScaler
+ *                for this dtype); 2^-8 per operand (TEM_WL_BF16 pack);
  *                0 = VALU kernel (TEM_WL_GENERIC pack).
  *   ws:          optional workspace of tem_conv3d_fwd_ws() bytes.  Spatially small, channel-rich
  *                layers (the 8^3/16^3 levels) cannot fill 256 CUs with (patch x Cout-tile)

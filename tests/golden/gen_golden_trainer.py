@@ -168,6 +168,27 @@ def gen_trainer_amp(torch_em, tmp):
     np.savez_compressed(os.path.join(OUT, "g7b_trainer_amp_unet2d.npz"), **out)
 
 
+def gen_trainer_bf16(torch_em, tmp):
+    """G7c: the reference's loop with mixed_precision_dtype="bfloat16" -- torch.autocast(bfloat16), NO GradScaler
+    (trainer/default_trainer.py:134-142) -- on the data / initial weights of G7b (same seeds), 8 iterations on the CPU."""
+    from torch_em.model import UNet2d
+    xt, yt = make_batches(11, 8)
+    xv, yv = make_batches(12, 4)
+    train = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xt, yt), batch_size=2, shuffle=False)
+    val = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xv, yv), batch_size=2, shuffle=False)
+    torch.manual_seed(0)
+    model = UNet2d(1, 2, depth=2, initial_features=32)
+    trainer = torch_em.default_segmentation_trainer(
+        name="g7c", model=model, train_loader=train, val_loader=val, learning_rate=1e-3, device="cpu",
+        mixed_precision=True, mixed_precision_dtype="bfloat16", logger=Recorder, save_root=tmp, compile_model=False)
+    assert trainer.scaler is not None and not trainer.scaler.is_enabled()   # created disabled for bfloat16 (:138-140)
+    trainer.fit(iterations=8)
+    log = Recorder.log
+    np.savez_compressed(os.path.join(OUT, "g7c_trainer_bf16_unet2d.npz"), bf16_train_loss=np.array(log["train_loss"]),
+                        bf16_val_metric=np.array(log["val_metric"]))
+    print("G7c bf16", [f"{v:.5f}" for v in log["train_loss"]], log["val_metric"])
+
+
 def gen_affinities():
     spec = importlib.util.spec_from_file_location("ref_test_label_transforms",
                                                   os.path.join(REF_ROOT, "test/transform/test_label_transforms.py"))
@@ -194,12 +215,20 @@ def gen_affinities():
 
 
 if __name__ == "__main__":
+    import sys
     import tempfile
     torch.set_num_threads(4)
     torch.use_deterministic_algorithms(True)
+    if "--bf16-only" in sys.argv:   # G7c was added later; the other fixtures are not regenerated
+        te = import_reference()
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_trainer_bf16(te, tmp)
+        sys.exit(0)
     gen_affinities()
     te = import_reference()
     with tempfile.TemporaryDirectory() as tmp:
         gen_trainer(te, tmp)
     with tempfile.TemporaryDirectory() as tmp:
         gen_trainer_amp(te, tmp)
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_trainer_bf16(te, tmp)

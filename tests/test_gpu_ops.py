@@ -128,14 +128,17 @@ MIXED_CASES = [
     (1, 16, 32, 32, 64, 32, (1, 1, 1)),   # >= 16384 voxels: the data gradient runs the streaming 1x1x1 GEMM with one fp16 term
     (2, 16, 64, 64, 32, 32, (3, 3, 3)),   # 512 patches: the ping-pong kernel with one fp16 term, one Cout tile
     (2, 16, 64, 64, 32, 64, (3, 3, 3)),   # ... two Cout tiles (forward) / one (data gradient)
+    (2, 32, 64, 64, 32, 32, (3, 3, 3)),   # 512 units of the z-reuse kernel: its one-term instantiations
 ]
 
 
+@pytest.mark.parametrize("mode", [5, 7])
 @pytest.mark.parametrize("case", MIXED_CASES)
-def test_conv_mixed_precision_mode(case):
-    """use_mfma = 5 (mixed_precision=True): operands rounded to fp16, one MFMA per product, fp32 accumulation -- the
-    arithmetic of torch.autocast(float16) around nn.Conv3d (reference trainer/default_trainer.py:134-142).  Expected
-    values: the fp32 convolution of the fp16-ROUNDED operands, so only the summation order differs (2e-5)."""
+def test_conv_mixed_precision_mode(case, mode):
+    """use_mfma = 5 / 7 (mixed_precision=True with dtype float16 / bfloat16): operands rounded to fp16 / bf16, one MFMA per
+    product, fp32 accumulation -- the arithmetic of torch.autocast(float16 / bfloat16) around nn.Conv3d (reference
+    trainer/default_trainer.py:134-142).  Expected values: the fp32 convolution of the ROUNDED operands, so only the
+    summation order differs (2e-5)."""
     ops = _ops()
     N, D, H, W, Cin, Cout, k = case
     g = torch.Generator().manual_seed(5)
@@ -145,15 +148,15 @@ def test_conv_mixed_precision_mode(case):
     scale = torch.rand(N, Cin, generator=g) + 0.5
     shift = torch.randn(N, Cin, generator=g)
     pad = tuple(v // 2 for v in k)
-    r16 = lambda t: t.half().float()
-    # the kernel applies the pre-norm as ONE fused multiply-add before rounding to fp16: float64 reproduces that
+    r16 = (lambda t: t.half().float()) if mode == 5 else (lambda t: t.bfloat16().float())
+    # the kernel applies the pre-norm as ONE fused multiply-add before rounding to 16 bits: float64 reproduces that
     xn = (x.double() * scale[:, :, None, None, None].double() + shift[:, :, None, None, None].double()).float()
     xh = r16(xn)
     exp = F.relu(F.conv3d(xh, r16(w), b, padding=pad))
     x5, wd = to5(x), w.to(DEV)
     y5 = ops.new_act(N, D, H, W, Cout, DEV)
-    ops.conv_fwd(x5, ops.pack_weights(wd, transpose=False, mfma=5), b.to(DEV), y5, k, Cin, Cout, scale=scale.to(DEV),
-                 shift=shift.to(DEV), act="relu", mfma=5)
+    ops.conv_fwd(x5, ops.pack_weights(wd, transpose=False, mfma=mode), b.to(DEV), y5, k, Cin, Cout, scale=scale.to(DEV),
+                 shift=shift.to(DEV), act="relu", mfma=mode)
     assert rel_err(from5(y5), exp) < 2e-5
     # the same numbers are NOT the fp32 result: the mode really rounds (guards against a silent fp32 fallback)
     exact = F.relu(F.conv3d(xn, w, b, padding=pad))
@@ -163,13 +166,13 @@ def test_conv_mixed_precision_mode(case):
         wr = r16(w).requires_grad_(False)
         gxe = torch.nn.grad.conv3d_input(x.shape, wr, r16(gy), padding=pad)
         gx5 = ops.new_act(N, D, H, W, Cin, DEV)
-        ops.conv_fwd(to5(gy), ops.pack_weights(wd, transpose=True, mfma=5), None, gx5, k, Cout, Cin, mfma=5)
+        ops.conv_fwd(to5(gy), ops.pack_weights(wd, transpose=True, mfma=mode), None, gx5, k, Cout, Cin, mfma=mode)
         assert rel_err(from5(gx5), gxe) < 2e-5
     if ops.mfma_ok(Cin, Cout, k, wgrad=True):
         dw = torch.empty(w.numel(), device=DEV)
         db = torch.empty(Cout, device=DEV)
-        ops.conv_wgrad(x5, to5(gy), k, Cin, Cout, dw, db, scale=scale.to(DEV), shift=shift.to(DEV), mfma=5)
-        zs = k == (3, 3, 3) and D >= 16
+        ops.conv_wgrad(x5, to5(gy), k, Cin, Cout, dw, db, scale=scale.to(DEV), shift=shift.to(DEV), mfma=mode)
+        zs = k == (3, 3, 3) and D >= 16      # the z-sliding kernel has the one-term variants; the patch kernel stays bf16x3
         xe = xh if zs else xn
         dwe = torch.nn.grad.conv3d_weight(xe, w.shape, r16(gy) if zs else gy, padding=pad)
         assert rel_err(dw.cpu().view(w.shape), dwe) < (2e-5 if zs else 1e-4)

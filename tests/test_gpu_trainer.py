@@ -506,6 +506,52 @@ def test_mixed_precision_trainer_against_reference_autocast_run(tmp_path):
     assert max(abs(a - b) for a, b in zip(log["loss"], g["fp32_train_loss"])) > 1e-5
 
 
+def test_bfloat16_trainer_against_reference_autocast_run(tmp_path):
+    """G7c: the reference's loop with mixed_precision_dtype="bfloat16" (torch.autocast(bfloat16), GradScaler created but
+    DISABLED, trainer/default_trainer.py:134-142), run on the CPU by tests/golden/gen_golden_trainer.py on the data and
+    initial weights of G7b, against this trainer with the same arguments: engine.precision_scope("amp_bf16") -- conv
+    operands rounded to bf16, one MFMA per product (tem_conv3d_* use_mfma = 7), fp32 accumulation and storage.
+    Autocast also keeps activations and their gradients in bf16; this path rounds convolution operands only: iteration 0
+    (same weights) agrees to 2e-3, after 8 steps the two trajectories are 1.6 % apart -- this one 0.3 % from the
+    reference's fp32 run, autocast's 1.3 %."""
+    import torch_em_amd
+    from conftest import GOLDEN
+    from torch_em_amd.model import UNet2d
+    g = dict(np.load(os.path.join(GOLDEN, "g7b_trainer_amp_unet2d.npz")))
+    gb = dict(np.load(os.path.join(GOLDEN, "g7c_trainer_bf16_unet2d.npz")))
+    model = UNet2d(1, 2, depth=2, initial_features=32)
+    model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd0.")})
+    xt, yt, xv, yv = (torch.from_numpy(g[k]) for k in ("xt", "yt", "xv", "yv"))
+    train = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xt, yt), batch_size=2, shuffle=False)
+    val = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xv, yv), batch_size=2, shuffle=False)
+    log = {"loss": [], "metric": []}
+
+    class Recorder:
+        def __init__(self, trainer, save_root, **kw):
+            pass
+
+        def log_train(self, step, loss, lr, x, y, pred, log_gradients=False):
+            log["loss"].append(float(loss))
+
+        def log_validation(self, step, metric, loss, x, y, pred):
+            log["metric"].append(float(metric))
+
+    trainer = torch_em_amd.default_segmentation_trainer("g7c", model, train, val, learning_rate=float(g["learning_rate"]),
+                                                        device=DEV, mixed_precision=True, mixed_precision_dtype="bfloat16",
+                                                        logger=Recorder, save_root=str(tmp_path))
+    assert trainer.scaler is not None and not trainer.scaler.is_enabled() and trainer._amp_bf16 and not trainer._amp
+    trainer.fit(iterations=8)
+    print("bf16 loss", [round(v, 5) for v in log["loss"]], "reference autocast(bfloat16)",
+          [round(float(v), 5) for v in gb["bf16_train_loss"]])
+    assert abs(log["loss"][0] - gb["bf16_train_loss"][0]) < 2e-3 * gb["bf16_train_loss"][0]
+    assert np.allclose(log["loss"], gb["bf16_train_loss"], rtol=2e-2), (log["loss"], list(gb["bf16_train_loss"]))
+    assert np.allclose(log["metric"], gb["bf16_val_metric"], rtol=3e-2)
+    assert np.allclose(log["loss"], g["fp32_train_loss"], rtol=1e-2)
+    assert max(abs(a - b) for a, b in zip(log["loss"], g["fp32_train_loss"])) > 1e-5    # not the fp32 path
+    ckpt = torch.load(os.path.join(trainer.checkpoint_folder, "latest.pt"), weights_only=False)
+    assert ckpt["scaler_state"] == {} and ckpt["init"]["mixed_precision_dtype"] == "bfloat16"   # as the reference's
+
+
 def test_from_checkpoint_restores_the_device_pre_pass(tmp_path):
     """The reference keeps raw / label transforms inside its pickled datasets, so they survive
     DefaultTrainer.from_checkpoint (trainer/default_trainer.py:288-330).  Here they are trainer arguments that run on the

@@ -50,9 +50,10 @@ extern "C" int tem_conv_pack_weights(const float* w, float* dst, int Cout, int C
     TEM_REQUIRE(w && dst && Cout > 0 && Cin > 0, "tem_conv_pack_weights: bad arguments");
     TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
                 "tem_conv_pack_weights: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
-    if (layout == TEM_WL_BF16X3 || layout == TEM_WL_BF16X6 || layout == TEM_WL_F16X3 || layout == TEM_WL_F16 || layout == TEM_WL_F16X3S) {
+    if (layout == TEM_WL_BF16X3 || layout == TEM_WL_BF16X6 || layout == TEM_WL_F16X3 || layout == TEM_WL_F16 || layout == TEM_WL_F16X3S ||
+        layout == TEM_WL_BF16) {
         int rc = tem_pack_weights_bf16x3(w, dst, Cout, Cin, kd, kh, kw, transpose,
-                                         layout == TEM_WL_BF16X6 ? 3 : (layout == TEM_WL_F16X3 ? 4 : (layout == TEM_WL_F16 ? 5 : (layout == TEM_WL_F16X3S ? 6 : 2))),
+                                         layout == TEM_WL_BF16X6 ? 3 : (layout == TEM_WL_F16X3 ? 4 : (layout == TEM_WL_F16 ? 5 : (layout == TEM_WL_F16X3S ? 6 : (layout == TEM_WL_BF16 ? 7 : 2)))),
                                          (hipStream_t)stream);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv_pack_weights(bf16x3)");
@@ -254,7 +255,7 @@ static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, con
     TEM_REQUIRE(act >= 0 && act <= 2, "tem_conv3d_fwd: Invalid activation: %d", act);
     TEM_REQUIRE(!ref || ref_ld >= Cout, "tem_conv3d_fwd: bad ref_ld");
     hipStream_t s = (hipStream_t)stream;
-    if (use_mfma >= 2 && use_mfma <= 6) {
+    if (use_mfma >= 2 && use_mfma <= 7) {
         int rc = tem_conv_fwd_bf16x3(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
                                      W, Cin, Cout, kd, kh, kw, act, use_mfma, stat, s);
         if (rc != TEM_OK) return rc;
@@ -328,12 +329,12 @@ extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Ci
                                               int use_mfma) {
     if (use_mfma == 0)  // VALU kernels: only the small-Cin first-layer kernel (conv_small.hip) provides them
         return (ref_free_cin1_ok(Cout)) ? tem_conv_fwd_cin1_stat_blocks(D, H, W, Cin, Cout, kd, kh, kw) : 0;
-    if (use_mfma < 2 || use_mfma > 6) return 0;
+    if (use_mfma < 2 || use_mfma > 7) return 0;
     return tem_conv_fwd_bf16x3_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma);
 }
 
 extern "C" int tem_conv3d_fwd_kernel(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma) {
-    if (use_mfma >= 2 && use_mfma <= 6 && Cin % 16 == 0 && Cout % 32 == 0) {
+    if (use_mfma >= 2 && use_mfma <= 7 && Cin % 16 == 0 && Cout % 32 == 0) {
         if (tem_conv_zr_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) >= 0) return 3;
         return tem_conv_pp_tiles(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma);
     }
@@ -488,7 +489,7 @@ extern "C" int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int 
     int ntaps = kd * kh * kw;
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
     int64_t bytes = tem_align_up(p.db_floats, 64) * 4;
-    if (use_mfma == 2 || use_mfma == 5) {
+    if (use_mfma == 2 || use_mfma == 5 || use_mfma == 7) {
         bytes += tem_conv_wgrad_bf16x3_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
     } else if (use_mfma) {
         bytes += tem_conv_wgrad_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
@@ -534,11 +535,11 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
     float* dbpart = (float*)ws;
     float* rest = dbpart + tem_align_up(p.db_floats, 64);
     TEM_REQUIRE(!gcoef || !use_mfma, "tem_conv3d_wgrad_gnorm: use_mfma must be 0");
-    if (use_mfma == 2 || use_mfma == 5) {
+    if (use_mfma == 2 || use_mfma == 5 || use_mfma == 7) {
         // 5: single fp16 product in the z-sliding kernel (autocast-equivalent); the other shapes keep bf16x3
         int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                        ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
-                                       sd_layout, use_mfma == 5, w_sd, gamma, beta, norm_sums, s);
+                                       sd_layout, use_mfma == 5 ? 1 : (use_mfma == 7 ? 2 : 0), w_sd, gamma, beta, norm_sums, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(bf16x3)");
         return TEM_OK;
@@ -655,7 +656,7 @@ extern "C" int tem_conv3d_fwd_refnorm(const float* x, int64_t x_ld, const float*
 
 extern "C" int tem_conv3d_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                         int use_mfma) {
-    if (use_mfma != 2 && use_mfma != 5) return 0;
+    if (use_mfma != 2 && use_mfma != 5 && use_mfma != 7) return 0;
     return tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
 }
 

@@ -125,7 +125,7 @@ static void stream_launch(const float* x, int64_t x_ld, const float* wp, const f
                            ref, ref_ld, NV, Cin, Cout, act, nmt);
 }
 
-// nsplit as in tem_conv_fwd_bf16x3: 2 = bf16x3, 3 = bf16x6, 5 = one fp16 term.  false: not taken (pre-norm, statistics, the
+// nsplit as in tem_conv_fwd_bf16x3: 2 = bf16x3, 3 = bf16x6, 5 = one fp16 term, 7 = one bf16 term.  false: not taken (pre-norm, statistics, the
 // scaled fp16x3 layouts, sigmoid -- the patch kernel handles those)
 bool tem_conv1x1_stream(const float* x, int64_t x_ld, const float* scale, const float* wp, const float* bias, float* y,
                         int64_t y_ld, const float* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act, int nsplit,
@@ -142,6 +142,8 @@ bool tem_conv1x1_stream(const float* x, int64_t x_ld, const float* scale, const 
         stream_launch<3, false>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
     else if (nsplit == 5)
         stream_launch<1, true>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
+    else if (nsplit == 7)
+        stream_launch<1, false>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
     else
         return false;
     return true;

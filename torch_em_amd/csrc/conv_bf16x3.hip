@@ -8,6 +8,7 @@
 // fused pre-norm while staging, bias/ReLU/mask epilogue, split-K for the small levels); the split into
 // hi/lo happens once per staged element on the way into LDS, and once per weight at pack time.
 #include "tem_common.h"
+#include <set>
 #include "conv_internal.h"
 
 #ifndef TEM_SPLIT_N
@@ -105,8 +106,10 @@ int tem_pack_weights_bf16x3(const float* w, float* dst, int Cout, int Cin, int k
                             int nsplit, hipStream_t s) {
     // nsplit 4 = fp16x3: two fp16 planes, the lo plane scaled by 2^12 (fp16 = 2); 5 = fp16: one plane (fp16 = 1);
     // 6 = fp16x3 with the whole weight prescaled by 2^7 (fp16 = 3, conv_split.h)
+    // 7 = one bf16 term (the counterpart of torch.autocast(bfloat16)): one plane, bf16 bits
     const int fp16 = nsplit == 4 ? 2 : (nsplit == 5 ? 1 : (nsplit == 6 ? 3 : 0));
     if (fp16) nsplit = nsplit == 5 ? 1 : 2;
+    if (nsplit == 7) nsplit = 1;
     int CoutL = transpose ? Cin : Cout, CinL = transpose ? Cout : Cin;
     TEM_REQUIRE(CinL % 16 == 0 && CoutL % 32 == 0, "tem_conv_pack_weights: split-bf16 layout needs Cin%%16==0, Cout%%32==0");
     int64_t total = (int64_t)Cout * Cin * kd * kh * kw;
@@ -666,6 +669,13 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
             else                                                                                                      \
                 launch_b<KD, KH, KW, TZ, TY, TX, 1, 1, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
                                                              W, Cin, Cout, act, ks, part, stat, s);                         \
+        } else if (nsplit == 7) {                                                                                     \
+            if (nr2)                                                                                                  \
+                launch_b<KD, KH, KW, TZ, TY, TX, 2, 1, false>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                              W, Cin, Cout, act, ks, part, stat, s);                        \
+            else                                                                                                      \
+                launch_b<KD, KH, KW, TZ, TY, TX, 1, 1, false>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                              W, Cin, Cout, act, ks, part, stat, s);                        \
         } else                                                                                                        \
             GO2(KD, KH, KW, TZ, TY, TX, 2);                                                                           \
     } while (0)
@@ -1021,7 +1031,7 @@ __device__ __forceinline__ float4 zs_load4(zs_rsrc_t r, unsigned voff, unsigned 
     return make_float4(f.x, f.y, f.z, f.w);
 }
 
-template <int NCO, bool H16 = false>
+template <int NCO, int ONE = 0>   // ONE: 0 bf16x3 (hi + lo planes), 1 one fp16 term, 2 one bf16 term
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restrict__ x, int64_t x_ld,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ g,
@@ -1159,7 +1169,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                     const int prow = 2 * (sl0 + sl) + kh;  // this lane half's patch row (0..7)
                     const int goff = (ct * 32 + r) * ZS_GS + prow * 16;
                     const int xoff = xbase + prow * 32;
-                    if constexpr (H16) {
+                    if constexpr (ONE != 0) {
                         // single fp16 product (the autocast-equivalent mode): hi planes only
                         const uint4 bh = *reinterpret_cast<const uint4*>(Gh + goff);
                         const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
@@ -1167,9 +1177,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                         const uint4 f1 = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
                                                     __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
                         const uint4 f2 = make_uint4(wh.y, wh.z, wh.w, wh4);
-                        acc[i][0] = mfma16<true>(wh, bh, acc[i][0]);
-                        acc[i][1] = mfma16<true>(f1, bh, acc[i][1]);
-                        acc[i][2] = mfma16<true>(f2, bh, acc[i][2]);
+                        acc[i][0] = mfma16<ONE == 1>(wh, bh, acc[i][0]);
+                        acc[i][1] = mfma16<ONE == 1>(f1, bh, acc[i][1]);
+                        acc[i][2] = mfma16<ONE == 1>(f2, bh, acc[i][2]);
                         continue;
                     }
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Gh + goff));
@@ -1210,8 +1220,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                 const float va = inA ? fmaf(a[c], s4[c], f4[c]) : 0.f;
                 const float vb = inB ? fmaf(b[c], s4[c], f4[c]) : 0.f;
                 const int off = (xcq * 4 + c) * ZS_CIS + sl + xrow * 32 + xpr * 4;
-                if constexpr (H16) {
-                    *reinterpret_cast<unsigned*>(Xh + off) = pk16<true>(va, vb);
+                if constexpr (ONE != 0) {
+                    *reinterpret_cast<unsigned*>(Xh + off) = pk16<ONE == 1>(va, vb);
                 } else {
                     unsigned hi, lo;
                     split2(va, vb, hi, lo);
@@ -1227,8 +1237,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int off = (gcq * 4 + c) * ZS_GS + (gprow * 8 + gpr * 2) * 2;
-                if constexpr (H16) {
-                    *reinterpret_cast<unsigned*>(Gh + off) = pk16<true>(a[c], b[c]);
+                if constexpr (ONE != 0) {
+                    *reinterpret_cast<unsigned*>(Gh + off) = pk16<ONE == 1>(a[c], b[c]);
                 } else {
                     unsigned hi, lo;
                     split2(a[c], b[c], hi, lo);
@@ -1349,7 +1359,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
 // but no time (the staging team has the slack).  Same LDS layout as k_conv_wgrad_zs<1>, same partial-slab format
 // with KS2 = 1.
 // ---------------------------------------------------------------------------
-template <bool H16>
+template <int ONE>
 __global__ __launch_bounds__(512, 2) void k_conv_wgrad_zt(const float* __restrict__ x, int64_t x_ld,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ g,
@@ -1417,12 +1427,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_zt(const float* __restric
                     const int xoff = xbase + (2 * sl + kh) * 32;
                     const uint4 bhs = *reinterpret_cast<const uint4*>(Gh + gbase + 32 * sl);
                     uint4 bls = bhs;
-                    if (!H16) bls = *reinterpret_cast<const uint4*>(Gl + gbase + 32 * sl);
+                    if (ONE == 0) bls = *reinterpret_cast<const uint4*>(Gl + gbase + 32 * sl);
                     const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
                     const unsigned wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
                     uint4 wl = wh;
                     unsigned wl4 = wh4;
-                    if (!H16) {
+                    if (ONE == 0) {
                         wl = *reinterpret_cast<const uint4*>(Xl + xoff);
                         wl4 = *reinterpret_cast<const unsigned*>(Xl + xoff + 16);
                     }
@@ -1446,9 +1456,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_zt(const float* __restric
                         fl[0] = make_uint4(__builtin_amdgcn_alignbyte(l1, l0, sh), __builtin_amdgcn_alignbyte(l2, l1, sh),
                                            __builtin_amdgcn_alignbyte(l3, l2, sh), __builtin_amdgcn_alignbyte(wl4, l3, sh));
                     }
-                    if constexpr (H16) {
+                    if constexpr (ONE != 0) {
 #pragma unroll
-                        for (int tx = 0; tx < NTX; ++tx) acc[j0 + tx] = mfma16<true>(fh[tx], bhs, acc[j0 + tx]);
+                        for (int tx = 0; tx < NTX; ++tx) acc[j0 + tx] = mfma16<ONE == 1>(fh[tx], bhs, acc[j0 + tx]);
                     } else {
                         const bf16x8 gh8 = __builtin_bit_cast(bf16x8, bhs), gl8 = __builtin_bit_cast(bf16x8, bls);
 #pragma unroll
@@ -1566,8 +1576,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_zt(const float* __restric
                     const float va = inA[q] ? fmaf(a[c], s4[c], f4[c]) : 0.f;
                     const float vb = inB[q] ? fmaf(b[c], s4[c], f4[c]) : 0.f;
                     const int off = (xcq[q] * 4 + c) * ZS_CIS + sl + xrow[q] * 32 + xpr[q] * 4;
-                    if constexpr (H16) {
-                        *reinterpret_cast<unsigned*>(Xh + off) = pk16<true>(va, vb);
+                    if constexpr (ONE != 0) {
+                        *reinterpret_cast<unsigned*>(Xh + off) = pk16<ONE == 1>(va, vb);
                     } else {
                         unsigned hi, lo;
                         split2(va, vb, hi, lo);
@@ -1584,8 +1594,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_zt(const float* __restric
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int off = (gcq * 4 + c) * ZS_GS + (gprow * 8 + gpr * 2) * 2;
-                if constexpr (H16) {
-                    *reinterpret_cast<unsigned*>(Gh + off) = pk16<true>(a[c], b[c]);
+                if constexpr (ONE != 0) {
+                    *reinterpret_cast<unsigned*>(Gh + off) = pk16<ONE == 1>(a[c], b[c]);
                 } else {
                     unsigned hi, lo;
                     split2(a[c], b[c], hi, lo);
@@ -1804,63 +1814,30 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
         TEM_REQUIRE(!norm_sums || (db && w_sd && sd_layout && tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw)),
                     "tem_conv3d_wgrad_sums: this layer cannot deliver the norm sums (tem_conv3d_wgrad_sums_ok() == 0)");
         const unsigned nblk = (unsigned)((int64_t)z.T * z.S);
-        if (z.teams) {
-            constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS;
-            static bool at = false;
-            if (!at) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zt<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zt<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                at = true;
+        // h16: 0 bf16x3 (hi + lo planes, 3 MFMAs per product), 1 one fp16 term, 2 one bf16 term (the mixed-precision modes)
+        auto launch = [&](auto kern, size_t lb) {
+            static std::set<const void*> sized;   // kernels whose dynamic-LDS limit was raised already
+            const void* key = reinterpret_cast<const void*>(kern);
+            if (!sized.count(key)) {
+                (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                sized.insert(key);
             }
-            if (h16)
-                hipLaunchKernelGGL((k_conv_wgrad_zt<true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
-                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
-            else
-                hipLaunchKernelGGL((k_conv_wgrad_zt<false>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
-                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
-        } else if (z.nco == 2) {
-            constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)64 * ZS_GS;
-            static bool a2 = false;
-            if (!a2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zs<2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                a2 = true;
-            }
-            static bool a2h = false;
-            if (h16 && !a2h) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zs<2, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                a2h = true;
-            }
-            if (h16)
-                hipLaunchKernelGGL((k_conv_wgrad_zs<2, true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
-                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
-            else
-            hipLaunchKernelGGL((k_conv_wgrad_zs<2>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
-                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
-        } else {
-            constexpr size_t lb = 2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS;
-            static bool a1 = false;
-            if (!a1) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zs<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                a1 = true;
-            }
-            static bool a1h = false;
-            if (h16 && !a1h) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_zs<1, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                a1h = true;
-            }
-            if (h16)
-                hipLaunchKernelGGL((k_conv_wgrad_zs<1, true>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld,
-                                   zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
-            else
-            hipLaunchKernelGGL((k_conv_wgrad_zs<1>), dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb,
-                               N, D, H, W, Cin, Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
-        }
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb, N, D, H, W, Cin,
+                               Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
+        };
+        auto go = [&](auto k0, auto k1, auto k2, size_t lb) {
+            if (h16 == 1) launch(k1, lb);
+            else if (h16 == 2) launch(k2, lb);
+            else launch(k0, lb);
+        };
+        if (z.teams)
+            go(&k_conv_wgrad_zt<0>, &k_conv_wgrad_zt<1>, &k_conv_wgrad_zt<2>, 2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS);
+        else if (z.nco == 2)
+            go(&k_conv_wgrad_zs<2, 0>, &k_conv_wgrad_zs<2, 1>, &k_conv_wgrad_zs<2, 2>,
+               2 * (size_t)32 * ZS_CIS + 4 * (size_t)64 * ZS_GS);
+        else
+            go(&k_conv_wgrad_zs<1, 0>, &k_conv_wgrad_zs<1, 1>, &k_conv_wgrad_zs<1, 2>,
+               2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS);
         if (norm_sums) {
             float* extra = zdb + tem_align_up((int64_t)z.S * Cout, 64);
             tem_wgrad_sums_launch(zpart, z.Ss, z.ks2, zdb, g, g_ld, w_sd, gamma, beta, dw, extra, N, D, H, W, Cin, Cout,

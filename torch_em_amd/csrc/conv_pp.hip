@@ -532,7 +532,7 @@ static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     PpGeom g = {};
     const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
     if (opt == 0) return g;   // (2 = z-reuse kernel forced: shapes it does not take still come here)
-    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5)) return g;   // bf16x3, fp16x3 (scaled lo), one fp16 term (mixed mode)
+    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7)) return g;   // bf16x3, fp16x3 (scaled lo), one fp16 / bf16 term (mixed modes)
     if (!(kh == 3 && kw == 3 && (kd == 3 || kd == 1))) return g;
     if (D < 4 || Cin % 16 || Cout % 32) return g;
     if ((int64_t)H * W * 8 * 4 * max_ld >= (1ll << 31)) return g;  // 32-bit byte offsets inside one halo / one patch
@@ -618,6 +618,9 @@ int tem_conv_fwd_pp(const float* x, int64_t x_ld, const float* scale, const floa
         if (nsplit == 5)                                                                                              \
             pp_launch<KD, 3, 3, 4, CT, true, 1>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, \
                                                 Cout, act, stat, s);                                                  \
+        else if (nsplit == 7)                                                                                         \
+            pp_launch<KD, 3, 3, 4, CT, false, 1>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, \
+                                                 Cout, act, stat, s);                                                 \
         else if (f16)                                                                                                 \
             pp_launch<KD, 3, 3, 4, CT, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin,  \
                                              Cout, act, stat, s);                                                     \

@@ -669,7 +669,7 @@ static ZrGeom zr_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     ZrGeom g = {};
     const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
     if (opt == 0 || opt == 1) return g;
-    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5)) return g;
+    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7)) return g;
     if (!(kd == 3 && kh == 3 && kw == 3)) return g;
     if (D < 4 || Cin % 16 || Cout % 32) return g;
     if ((int64_t)H * W * 8 * 4 * max_ld >= (1ll << 31)) return g;   // 32-bit byte offsets inside one halo / one patch
@@ -770,6 +770,7 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
         tem_zr_in_amax = nullptr;   // consumed
     }
     if (nsplit == 5) ZRGO(1, true);
+    else if (nsplit == 7) ZRGO(1, false);
     else if (nsplit == 4) ZRGO(2, true);
     else ZRGO(2, false);
 #undef ZRGO

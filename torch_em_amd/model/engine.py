@@ -52,6 +52,9 @@ _FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
 #            rounded to fp16, ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation, fp32 storage; needs loss
 #            scaling (optim.GradScaler).  2^-11 per operand: NOT parity-grade; the trainers select it only when asked
 #            (mixed_precision=True with an explicit mixed_precision_dtype="float16", or TEM_MIXED_PRECISION=1).
+#   "amp_bf16" the same with operands rounded to bf16 (ONE v_mfma_f32_32x32x16_bf16 per product): the counterpart of
+#            torch.autocast(bfloat16), mixed_precision_dtype="bfloat16"; fp32 exponent range, so no loss scaling (the
+#            reference creates a GradScaler for float16 only, trainer/default_trainer.py:134-142); 2^-8 per operand.
 # Why the forward keeps fp32-class products ("split" is the default; "mixed"/"fp32" use the exact MFMA): the U-Net's gradient is ill-conditioned w.r.t. the FORWARD values -- a
 # 1e-7 relative forward perturbation flips ReLU masks / pooling arg-maxes of near-ties and moves
 # gradient entries by ~1e-4..1e-3 (that is the fp32 reference's own distance from the float64
@@ -64,7 +67,7 @@ _F16X3_MODE = int(os.environ.get("TEM_F16X3_LAYOUT", "4"))
 
 def set_precision(mode: str):
     global PRECISION
-    if mode not in ("fp32", "mixed", "split", "split16", "bf16x3", "amp"):
+    if mode not in ("fp32", "mixed", "split", "split16", "bf16x3", "amp", "amp_bf16"):
         raise ValueError(f"unknown precision mode {mode}")
     PRECISION = mode
 
@@ -120,13 +123,14 @@ class ConvSpec:
 
     # --- packed weights (cached until the parameter changes) -----------------------
     def _modes(self):
-        mode_f = {"bf16x3": 2, "split": 3, "split16": 3, "amp": 5}.get(PRECISION, 1)
+        mode_f = {"bf16x3": 2, "split": 3, "split16": 3, "amp": 5, "amp_bf16": 7}.get(PRECISION, 1)
         if PRECISION == "split16" and self.norm is not None and self.k != (1, 1, 1):
             # fp16x3: the conv reads pre-normalised activations (|x^| of order 1..100 << 65504; clamped at 6e4).
             # TEM_F16X3_LAYOUT=6 selects the single-accumulator variant with prescaled operands (csrc/conv_split.h), which
             # fails the GroupNorm parity test (one-sided accumulation error): experiments only.
             mode_f = _F16X3_MODE
-        mode_d = 5 if PRECISION == "amp" else 2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
+        mode_d = 5 if PRECISION == "amp" else 7 if PRECISION == "amp_bf16" else \
+            2 if PRECISION in ("bf16x3", "mixed", "split", "split16") else 1
         mf = mode_f if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k) else 0
         md = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cout, self.cin, self.k) else 0
         mw = mode_d if (not _FORCE_GENERIC) and ops.mfma_ok(self.cin, self.cout, self.k, wgrad=True) else 0
@@ -196,10 +200,10 @@ def _repack_stale(prepare_only: bool = False):
             if key not in ent:
                 continue
             if prepare_only:
-                if ent.get(key + "_mfma") in (2, 3, 4, 5, 6) and not (key == "fwd_inf" and not ent.get("fwd_inf_used", False)):
+                if ent.get(key + "_mfma") in (2, 3, 4, 5, 6, 7) and not (key == "fwd_inf" and not ent.get("fwd_inf_used", False)):
                     mode = ent[key + "_mfma"]
                     jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
-                                 3 if mode == 3 else 1 if mode == 5 else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
+                                 3 if mode == 3 else 1 if mode in (5, 7) else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
                 continue
             if key == "dgrad" and "dgrad16" in ent and ent.pop("dgrad16_used", False) and not ent.pop("dgrad_used", False):
                 # this layer's data gradient runs in the fp16 layout: the bf16 pack is re-made lazily if ever needed again
@@ -210,9 +214,9 @@ def _repack_stale(prepare_only: bool = False):
                 del ent["fwd_inf"], ent["fwd_inf_mfma"]
                 continue
             mode = ent[key + "_mfma"]
-            if mode in (2, 3, 4, 5, 6):
+            if mode in (2, 3, 4, 5, 6, 7):
                 jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
-                             3 if mode == 3 else 1 if mode == 5 else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
+                             3 if mode == 3 else 1 if mode in (5, 7) else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
             else:
                 rest.append((ent, key, w, bool(transpose), mode))
         if not prepare_only:

@@ -26,11 +26,11 @@ PROFILER_FILTER = None
 
 def _fwd_tag(mfma, k, cout, pp=False):
     if pp == 3:  # the z-reuse team kernel (csrc/conv_zr.hip)
-        return f"k_conv_zr_{'f16x3' if int(mfma) == 4 else 'f16' if int(mfma) == 5 else 'bf16x3'}<3,3,3>"
+        return f"k_conv_zr_{'f16x3' if int(mfma) == 4 else 'f16' if int(mfma) == 5 else 'bf16' if int(mfma) == 7 else 'bf16x3'}<3,3,3>"
     if pp:  # the ping-pong team kernel (csrc/conv_pp.hip)
         return f"k_conv_pp_{'f16x3' if int(mfma) == 4 else 'bf16x3'}<{k[0]},{k[1]},{k[2]},CT={2 if cout % 64 == 0 else 1}>"
     kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3", 5: "k_conv_fwd_f16",
-             6: "k_conv_fwd_f16x3"}.get(int(mfma)) or
+             6: "k_conv_fwd_f16x3", 7: "k_conv_fwd_bf16"}.get(int(mfma)) or
             ("k_conv_fwd_mfma" if mfma else "k_conv_fwd_valu")) + f"<{k[0]},{k[1]},{k[2]}"
     return kind + (f",NR={2 if cout % 64 == 0 else 1}>" if mfma else ">")
 
@@ -38,8 +38,9 @@ def _fwd_tag(mfma, k, cout, pp=False):
 def _wgrad_tag(mfma, k, cout):
     ntaps = k[0] * k[1] * k[2]
     return ("k_conv_wgrad_bf16x3" if int(mfma) == 2 else "k_conv_wgrad_f16" if int(mfma) == 5 else
+            "k_conv_wgrad_bf16" if int(mfma) == 7 else
             "k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + \
-        f"<{k[0]},{k[1]},{k[2]}" + (f",NCO={2 if cout >= 64 else 1}" if int(mfma) in (2, 5) and ntaps > 1 else "") + ">(+reduce)"
+        f"<{k[0]},{k[1]},{k[2]}" + (f",NCO={2 if cout >= 64 else 1}" if int(mfma) in (2, 5, 7) and ntaps > 1 else "") + ">(+reduce)"
 
 
 def _prof_begin(t, tag=None):
@@ -155,7 +156,8 @@ def mfma_ok(cin: int, cout: int, k: Sequence[int], wgrad: bool = False) -> bool:
 def pack_weights(w: torch.Tensor, transpose: bool, mfma) -> torch.Tensor:
     """state_dict layout [Cout, Cin, (kd,) kh, kw] -> kernel layout (see tem_hip.h).
     mfma: False/0 generic, True/1 exact-fp32 MFMA fragments, 2 / 3 split-bf16 fragments (2 / 3 terms), 4 split-fp16
-    (lo plane scaled), 5 one fp16 term (mixed precision), 6 split-fp16 with prescaled operands."""
+    (lo plane scaled), 5 one fp16 term (mixed precision), 6 split-fp16 with prescaled operands, 7 one bf16 term
+    (mixed precision with dtype bfloat16)."""
     _req_cuda(w)
     w = w.detach().contiguous()
     cout, cin = w.shape[:2]

@@ -14,8 +14,9 @@ Differences that follow from the MI355X-first design:
     the environment): the step then runs inside `engine.precision_scope("amp")` (conv operands rounded to fp16, one
     MFMA per product: what `torch.autocast(float16)` does to `nn.Conv3d`, reference :134-142, :800-803) with
     `optim.GradScaler` doing `scale(loss).backward(); step(optimizer); update()` exactly as `_backprop_mixed`
-    (:789-794), `scaler_state` saved / restored like the reference (:595-596, :636-638).  `"bfloat16"` has no
-    counterpart here and keeps the fp32-class path (more precise than requested, no scaler -- as the reference);
+    (:789-794), `scaler_state` saved / restored like the reference (:595-596, :636-638).
+    `mixed_precision_dtype="bfloat16"` runs `precision_scope("amp_bf16")`: operands rounded to bf16, one MFMA per product,
+    and -- as in the reference, which creates a GradScaler for float16 only -- no loss scaling;
   * `compile_model` is accepted and ignored: the model is already one hand-scheduled autograd node,
     there is no tracing compiler in this path;
   * the hot loop never synchronises the host: loss values are kept on device and only read at
@@ -100,6 +101,8 @@ class DefaultTrainer:
         asked = mixed_precision_dtype == "float16" or (mixed_precision_dtype is None and
                                                         os.environ.get("TEM_MIXED_PRECISION", "0") == "1")
         self._amp = bool(mixed_precision) and asked and self.device.type == "cuda"
+        # "bfloat16": one bf16 MFMA per product, fp32 exponent range => no scaler (reference :134-142)
+        self._amp_bf16 = bool(mixed_precision) and mixed_precision_dtype == "bfloat16" and self.device.type == "cuda"
         if mixed_precision and not self._amp and mixed_precision_dtype is None and self.device.type == "cuda":
             # the reference's default (mixed_precision=True) means autocast(float16) + GradScaler there; here it would
             # silently train in the slower fp32-class arithmetic -- say so once
@@ -111,6 +114,9 @@ class DefaultTrainer:
         if self._amp:
             from ..optim import GradScaler
             self.scaler = GradScaler()
+        elif self._amp_bf16:
+            from ..optim import GradScaler
+            self.scaler = GradScaler(enabled=False)   # as the reference: created, but disabled for bfloat16 (:138-140)
         else:
             self.scaler = None  # fp32-class path: no loss scaling
         self.early_stopping = early_stopping
@@ -330,7 +336,12 @@ class DefaultTrainer:
         print("Start fitting for", self.max_iteration - self._iteration, "iterations / ",
               self.max_epoch - self._epoch, "epochs")
         print("with", len(self.train_loader), "iterations per epoch")
-        print("Training with single precision (exact fp32 on the MI355X matrix cores)")
+        if getattr(self, "_amp", False):      # the reference prints one of two such lines (:712-716)
+            print("Training with mixed precision (fp16 operands on the MI355X matrix cores, dynamic loss scaling)")
+        elif getattr(self, "_amp_bf16", False):
+            print("Training with mixed precision (bf16 operands on the MI355X matrix cores)")
+        else:
+            print("Training with single precision (fp32-class products on the MI355X matrix cores)")
         total = epochs * len(self.train_loader) if iterations is None else iterations
         if progress is None:
             progress = tqdm(total=total, desc=f"Epoch {self._epoch}", leave=True) if tqdm else _NullProgress()
@@ -402,9 +413,9 @@ class DefaultTrainer:
 
     def _precision(self):
         """The counterpart of the reference's autocast context (:800-803)."""
-        if getattr(self, "_amp", False):
+        if getattr(self, "_amp", False) or getattr(self, "_amp_bf16", False):
             from ..model.engine import precision_scope
-            return precision_scope("amp")
+            return precision_scope("amp" if getattr(self, "_amp", False) else "amp_bf16")
         return contextlib.nullcontext()
 
     def _backprop(self, loss):
@@ -437,7 +448,8 @@ class DefaultTrainer:
         if why is not None:
             return None
         self._graphed = GraphedTrainStep(self.model, self.loss, self.optimizer, x, y, scaler=self.scaler,
-                                         precision="amp" if getattr(self, "_amp", False) else None)
+                                         precision="amp" if getattr(self, "_amp", False) else
+                                         "amp_bf16" if getattr(self, "_amp_bf16", False) else None)
         return self._graphed
 
     def _train_epoch(self, progress):
