@@ -61,6 +61,7 @@ int tem_device_cus(void);
  *   "fwd_ksplit_chunks"   0       split-K forward: at most this many 16-channel chunks per partial (0: heuristic)
  *   "wgrad_cus"           256     workgroups the z-sliding weight gradient asks for
  *   "upsample_generic"    0 | 1   1: the any-factor gather kernels also for factors (1|2, 2, 2)
+ *   "team_min_units"      0       units a launch needs for the team kernels (0 = two per CU; lower values measured slower)
  * Unknown names return TEM_EINVAL. */
 int tem_set_option(const char* name, int64_t value);
 int tem_get_option(const char* name, int64_t* value);

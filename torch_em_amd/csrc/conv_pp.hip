@@ -549,7 +549,8 @@ static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     g.nY = (H + 7) / 8;
     g.nX = (W + 7) / 8;
     g.nunits = (int64_t)N * g.nZ * g.nY * g.nX * (Cout / (32 * g.CT));
-    if (g.nunits < (opt == 1 ? 1 : 2ll * ncu)) return g;
+    const long long minu = tem_option(TEM_OPT_TEAM_MIN_UNITS);
+    if (g.nunits < (opt == 1 ? 1 : (minu > 0 ? minu : 2ll * ncu))) return g;
     g.variant = 1;
     return g;
 }

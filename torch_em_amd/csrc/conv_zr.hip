@@ -683,7 +683,8 @@ static ZrGeom zr_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     g.nX = (W + 7) / 8;
     g.nunits = (int64_t)N * g.nZ * g.nY * g.nX * (Cout / 32);
     if (g.nunits >= (1ll << 31)) return g;
-    if (g.nunits < (opt == 2 ? 1 : 2ll * ncu)) return g;
+    const long long minu = tem_option(TEM_OPT_TEAM_MIN_UNITS);
+    if (g.nunits < (opt == 2 ? 1 : (minu > 0 ? minu : 2ll * ncu))) return g;
     g.ok = 1;
     return g;
 }
