@@ -81,6 +81,14 @@ class GraphedTrainStep:
         optimizer.zero_grad(set_to_none=True)   # autograd must ASSIGN the captured gradients, not add to old ones
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.pred, self.loss = self._forward_backward_step()
+        # Everything the captured launches point to that was allocated OUTSIDE the capture (and is therefore not owned by
+        # the graph's memory pool) must outlive the graph even if the engine later replaces its own reference -- a new
+        # pack-job table after an eager validation pass, new packed-weight buffers under another precision mode, a
+        # re-homed gradient arena: hold them here.
+        self._keepalive = [dict(engine._PACK_TABLES), [dict(c._tem_pack) for c in list(engine._PACKED_CONVS)
+                                                        if getattr(c, "_tem_pack", None) is not None],
+                           getattr(self.params[0], "_tem_grad_flat", None), ar.flat, optimizer._m, optimizer._v,
+                           optimizer._hyper, optimizer._table]
         self.replays = 0
 
     def _scope(self):
