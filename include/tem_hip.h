@@ -62,6 +62,7 @@ int tem_device_cus(void);
  *   "wgrad_cus"           256     workgroups the z-sliding weight gradient asks for
  *   "upsample_generic"    0 | 1   1: the any-factor gather kernels also for factors (1|2, 2, 2)
  *   "team_min_units"      0       units a launch needs for the team kernels (0 = two per CU; lower values measured slower)
+ *   "zr_splitk"           1 | 0   z-reuse kernel with split input channels for launches with too few tiles (16^3 / 32^3 levels)
  * Unknown names return TEM_EINVAL. */
 int tem_set_option(const char* name, int64_t value);
 int tem_get_option(const char* name, int64_t* value);
@@ -160,7 +161,9 @@ int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float
  * fp32 kernels, split-K shapes): use tem_norm_stats there.  tem_norm_finalize_partials (below) merges them. */
 int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 /* Which kernel family a tem_conv3d_fwd launch of this shape selects under the current options: 3 = the z-reuse team
- * kernel (csrc/conv_zr.hip: 3x3x3, 4x16x8 patches), 1 or 2 = the ping-pong team kernel (csrc/conv_pp.hip: 3x3x3 / 1x3x3,
+ * kernel (csrc/conv_zr.hip: 3x3x3, 4x16x8 patches), 4 = the same kernel with the input channels split over several units
+ * and a summing epilogue (16^3 / 32^3 levels: too few tiles otherwise; needs the tem_conv3d_fwd_ws() workspace, no fused
+ * statistics), 1 or 2 = the ping-pong team kernel (csrc/conv_pp.hip: 3x3x3 / 1x3x3,
  * two-plane layouts, enough patches to fill the chip) with that many 32-column output tiles per team, 0 = everything else.  Profiling / test aid (kernel tables of bench.py, the per-
  * instantiation parity tests); alignment fall-backs of an individual launch are not reflected. */
 int tem_conv3d_fwd_kernel(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);

@@ -270,6 +270,55 @@ def test_conv_pingpong_family_parity(case, cts, variant, conv_variant_option):
             assert err < (1e-4 if mode == 2 else 2e-5), f"masked dgrad mode {mode}: {err}"
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 16, 256, 256), (2, 16, 16, 16, 128, 256), (2, 15, 16, 15, 128, 256),
+                                  (1, 32, 32, 32, 128, 64)])
+def test_conv_zreuse_split_k(case):
+    """Family 4 of tem_conv3d_fwd_kernel: the z-reuse kernel with the input channels split over several units (the 16^3 /
+    32^3 levels of the U-Net, reference model/unet.py:417-438: too few 4x16x8 tiles to give every team of every CU one)
+    plus the summing epilogue that applies bias / ReLU / the ReLU mask -- forward with the fused pre-norm, data gradient,
+    masked data gradient, against F.conv3d; option zr_splitk = 0 sends the same shapes to the split-K patch kernel."""
+    ops = _ops()
+    from torch_em_amd import _lib
+    lib = _lib.load()
+    N, D, H, W, Cin, Cout = case
+    k, pad = (3, 3, 3), (1, 1, 1)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    scale, shift = torch.rand(N, Cin, generator=g) + 0.5, torch.randn(N, Cin, generator=g)
+    xn = (x.double() * scale[:, :, None, None, None].double() + shift[:, :, None, None, None].double()).float()
+    r16 = lambda t: t.half().float()  # noqa: E731
+    exp = F.relu(F.conv3d(xn, w, b, padding=pad))
+    exp16 = F.relu(F.conv3d(r16(xn), r16(w), b, padding=pad))
+    gy = torch.randn(exp.shape, generator=g)
+    refm = torch.randn(N, Cin, D, H, W, generator=g)
+    gxe = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=pad)
+    x5, g5, wd = to5(x), to5(gy), w.to(DEV)
+    for splitk in (1, 0):
+        _lib.set_option("zr_splitk", splitk)
+        try:
+            for mode in (2, 4, 5):
+                fam = lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, 3, 3, 3, mode)
+                assert fam == (4 if splitk else 0), (mode, fam)
+                assert lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, Cin, Cout, 3, 3, 3, mode) == 0     # split-K: no fused statistics
+                y5 = torch.full((N, D, H, W, Cout + 4), 3.0, device=DEV)                                # a channel slice of a wider buffer
+                ops.conv_fwd(x5, ops.pack_weights(wd, transpose=False, mfma=mode), b.to(DEV), y5[..., :Cout], k, Cin, Cout,
+                             scale=scale.to(DEV), shift=shift.to(DEV), act="relu", mfma=mode)
+                err = rel_err(from5(y5[..., :Cout]), exp16 if mode == 5 else exp)
+                assert err < (1e-4 if mode == 2 else 2e-5), f"fwd mode {mode} splitk {splitk}: {err}"
+                assert float(y5[..., Cout:].min()) == 3.0 and float(y5[..., Cout:].max()) == 3.0
+            for mode in (2, 5):
+                assert lib.tem_conv3d_fwd_kernel(N, D, H, W, Cout, Cin, 3, 3, 3, mode) in ((4, 3) if splitk else (0,))
+                gx5 = ops.new_act(N, D, H, W, Cin, DEV)
+                ops.conv_fwd(g5, ops.pack_weights(wd, transpose=True, mfma=mode), None, gx5, k, Cout, Cin, mfma=mode, ref=to5(refm))
+                want = (torch.nn.grad.conv3d_input(x.shape, r16(w), r16(gy), padding=pad) if mode == 5 else gxe) * (refm > 0)
+                err = rel_err(from5(gx5), want)
+                assert err < (1e-4 if mode == 2 else 2e-5), f"masked dgrad mode {mode} splitk {splitk}: {err}"
+        finally:
+            _lib.set_option("zr_splitk", 1)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 32), (2, 18, 61, 67, 64, 32), (2, 16, 64, 64, 64, 64)])
 @pytest.mark.parametrize("gscale", [1.0, 3e-7, 5e4])
 def test_data_gradient_fp16_two_term_with_device_prescale(case, gscale):

@@ -34,6 +34,7 @@ static const TemOption g_opt_table[TEM_OPT_COUNT] = {
     {"wgrad_cus", 256},         // TEM_OPT_WGRAD_CUS: workgroups the z-sliding weight gradient asks for (one per CU)
     {"upsample_generic", 0},    // TEM_OPT_UPSAMPLE_GENERIC: 1 = any-factor gather kernels also for factor (1|2, 2, 2) (A/B, tests)
     {"team_min_units", 0},      // TEM_OPT_TEAM_MIN_UNITS: units a launch needs for the team kernels (0 = 2 per CU; experiments)
+    {"zr_splitk", 1},           // TEM_OPT_ZR_SPLITK: z-reuse kernel with split input channels for the 16^3 / 32^3 levels
 };
 static long long g_opt_val[TEM_OPT_COUNT];
 static bool g_opt_set[TEM_OPT_COUNT];

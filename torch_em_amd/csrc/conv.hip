@@ -239,7 +239,12 @@ static void launch_fwd_generic(const float* x, int64_t x_ld, const float* scale,
 extern "C" int64_t tem_conv3d_fwd_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                      int use_mfma) {
     if (!use_mfma || Cin % 16 || Cout % 32) return 0;
-    return tem_conv_fwd_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
+    int64_t ws = tem_conv_fwd_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
+    if (use_mfma >= 2 && use_mfma <= 7) {   // the z-reuse kernel's split-K launch may want more slices than the patch kernel's
+        const int64_t zk = (int64_t)tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) * N * D * H * W * Cout * 4;
+        if (zk > ws) ws = zk;
+    }
+    return ws;
 }
 
 static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, const float* shift,
@@ -336,6 +341,7 @@ extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Ci
 extern "C" int tem_conv3d_fwd_kernel(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma) {
     if (use_mfma >= 2 && use_mfma <= 7 && Cin % 16 == 0 && Cout % 32 == 0) {
         if (tem_conv_zr_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) >= 0) return 3;
+        if (tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma)) return 4;   // z-reuse kernel, split input channels
         return tem_conv_pp_tiles(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma);
     }
     return 0;

@@ -621,6 +621,9 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
                                    nsplit, stat, s);
     if (pp < 0) return TEM_EINVAL;
     if (pp) return TEM_OK;
+    if (!stat && tem_conv_fwd_zr_splitk(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin, Cout,
+                                        kd, kh, kw, act, nsplit, s))
+        return TEM_OK;
     if (kd == 1 && kh == 1 && kw == 1 && tem_option(TEM_OPT_CONV1X1_STREAM) &&
         tem_conv1x1_stream(x, x_ld, scale, wp, bias, y, y_ld, ref, ref_ld, (int64_t)N * D * H * W, Cin, Cout, act, nsplit, stat, s))
         return TEM_OK;

@@ -60,6 +60,11 @@ int tem_conv_pp_tiles(int N, int D, int H, int W, int Cin, int Cout, int kd, int
 int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp, const float* bias,
                     float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout,
                     int kd, int kh, int kw, int act, int nsplit, float* stat, hipStream_t s);
+int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                           const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
+                           int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
+                           int nsplit, hipStream_t s);
+int tem_conv_zr_splitk_ks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
 int64_t tem_conv_zr_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
 // conv1x1_stream.hip: 1x1x1 convolution / data gradient as a streaming GEMM (false: not taken)
 bool tem_conv1x1_stream(const float* x, int64_t x_ld, const float* scale, const float* wp, const float* bias, float* y,

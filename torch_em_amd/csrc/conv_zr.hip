@@ -111,7 +111,7 @@ void tem_zr_trace_read(unsigned long long* dst) {
 #endif
 
 struct ZrUnit {
-    int cot, n, z0, y0, x0;
+    int cot, n, z0, y0, x0, ksl;
 };
 
 // NS planes per operand; F16: fp16 terms with the lo planes stored x 2^12 and their cross products in a second
@@ -120,12 +120,16 @@ struct ZrUnit {
 // 3 ReLU mask + backward of the norm behind it: y = ref > 0 ? a*acc - m1 - (ref - mean)*m2r : 0 with (a, m1, m2r, mean) per
 // (sample, output channel) read from `stat` (= coef[N][Cout][4], tem_norm_bwd_coef): a data gradient that lands behind a
 // ReLU + norm leaves this kernel finished -- the elementwise pass over g and ref (k_norm_bwd_apply) disappears.
-template <int NS, bool F16, int MODE>
+// KSPLIT (MODE 0 only): the input channels are cut into `ks` slices, a unit = (tile, column tile, slice) writes its raw
+// partial sums into slice `ksl` of a [ks][N*D*H*W][Cout] workspace (y, y_ld = Cout) and tem_splitk_epilogue adds them up --
+// the 16^3 / 32^3 levels, whose (tile, column tile) count alone cannot give every team of every CU a unit.
+template <int NS, bool F16, int MODE, bool KSPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
-    int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax) {
+    int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax, int ks) {
+    static_assert(!KSPLIT || MODE == 0, "split-K units write raw partial sums");
     constexpr int TZ = 4, TY = 16, TX = 8;
     constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     constexpr int HV = HZ * HY * HX;             // 1080 halo voxels
@@ -151,13 +155,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const int G = 2 * gridDim.x;
     const int slot = tem_xcd_remap(blockIdx.x, gridDim.x) * 2 + team;
     const int ncot = Cout >> 5;
-    const int nch = Cin >> 4;
+    const int nch_all = Cin >> 4;                          // 16-channel chunks of the input
+    const int nch = KSPLIT ? nch_all / ks : nch_all;       // ... of one unit
     const int my_units = slot < nunits ? (nunits - slot + G - 1) / G : 0;
     const int P = ((nunits + G - 1) / G) * nch;
 
     auto decode = [&](int ui) {
         int u = slot + ui * G;
         ZrUnit t;
+        t.ksl = 0;
+        if (KSPLIT) { t.ksl = u % ks; u /= ks; }   // the slices of a tile are neighbours: they share its halo in L2
         t.cot = u % ncot; u /= ncot;
         t.x0 = (u % nX) * TX; u /= nX;
         t.y0 = (u % nY) * TY; u /= nY;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
 
     floatx16 acc[TZ];
     floatx16 accl[SC ? TZ : 1];
-    const int tapstride = nch * FR;      // uint4s between taps of the packed weights
+    const int tapstride = nch_all * FR;  // uint4s between taps of the packed weights
 
     int ui = 0, ci = 0;
     ZrUnit cu = decode(0), eu = cu;
@@ -255,13 +262,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
             __amdgpu_buffer_rsrc_t rx = zr_rsrc(x);
             if (do_stage) {
                 if (scale) {
-                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
-                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + ci * BCK + c4 * 4);
+                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * BCK + c4 * 4);
+                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * BCK + c4 * 4);
                 } else if (in_amax) {
                     sc4 = make_float4(psc, psc, psc, psc);
                 }
                 // the halo origin may lie outside the tensor for border patches (only in-range voxels are dereferenced)
-                const float* xb = x + ((((int64_t)cu.n * D + (cu.z0 - 1)) * H + (cu.y0 - 1)) * W + (cu.x0 - 1)) * x_ld + ci * BCK;
+                const float* xb = x + ((((int64_t)cu.n * D + (cu.z0 - 1)) * H + (cu.y0 - 1)) * W + (cu.x0 - 1)) * x_ld +
+                                  (cu.ksl * nch + ci) * BCK;
                 rx = zr_rsrc(xb);
                 interior = (cu.z0 >= 1) & (cu.z0 + HZ - 1 <= D) & (cu.y0 >= 1) & (cu.y0 + HY - 1 <= H) & (cu.x0 >= 1) &
                            (cu.x0 + HX - 1 <= W);
@@ -311,7 +319,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
             ZR_STAMP(1);
             // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
             if (epi_pending) {
-                const __amdgpu_buffer_rsrc_t ry = zr_rsrc(y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld + eu.cot * 32);
+                const __amdgpu_buffer_rsrc_t ry = zr_rsrc(y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld + eu.cot * 32 +
+                                                          (KSPLIT ? (int64_t)eu.ksl * ((int64_t)N * D * H * W * y_ld) : 0));
                 constexpr bool has_ref = MODE == 2 || MODE == 3;
                 const __amdgpu_buffer_rsrc_t rr_ = zr_rsrc(has_ref ? ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld + eu.cot * 32 : y);
                 const bool full = (TEM_ZR_ABL & 32) ? true : ((eu.z0 + TZ <= D) & (eu.y0 + TY <= H) & (eu.x0 + TX <= W));
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                 if (interior) stage_planes(std::true_type{});
                 else stage_planes(std::false_type{});
                 ZR_STAMP(7);
-                wsoff = (unsigned)((cu.cot * 27 * nch + ci) * FR) * 16u;   // (column tile, tap 0, chunk ci) of the packed weights
+                wsoff = (unsigned)((cu.cot * 27 * nch_all + cu.ksl * nch + ci) * FR) * 16u;   // (column tile, tap 0, chunk) of the packed weights
 #pragma unroll
                 for (int tz = 0; tz < 3; ++tz)
 #pragma unroll
@@ -695,13 +704,13 @@ int64_t tem_conv_zr_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, i
     return (int64_t)g.nZ * g.nY * g.nX * 4;
 }
 
-template <int NS, bool F16, int MODE>
+template <int NS, bool F16, int MODE, bool KSPLIT = false>
 static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                       const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H, int W,
-                      int Cin, int Cout, int act, float* stat, const unsigned* in_amax, hipStream_t s) {
+                      int Cin, int Cout, int act, float* stat, const unsigned* in_amax, hipStream_t s, int ks = 1) {
     constexpr size_t ldsb = (size_t)2 * NS * 1080 * 32 + 4 * 32 * 144;   // two tiles + the epilogue's transpose scratch
     static_assert(ldsb <= 160 * 1024, "LDS budget");
-    auto kern = &k_conv_zr<NS, F16, MODE>;
+    auto kern = &k_conv_zr<NS, F16, MODE, KSPLIT>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
@@ -715,7 +724,64 @@ static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float
     int64_t grid = (g.nunits + 1) / 2;
     if (grid > ncu) grid = ncu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp),
-                       bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits, in_amax);
+                       bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits, in_amax, ks);
+}
+
+// Split-K launch for shapes zr_geometry() declines only because they have too few (tile, column tile) units: the input
+// channels are cut into ks slices so that ks x units >= two per CU, the partial sums go to the workspace and the common
+// split-K epilogue (conv_mfma.hip) applies bias / activation / ReLU mask.  -> 1 launched, 0 not taken.
+// ks of the split-K launch for this shape (0: not taken): only shapes that zr_geometry() / pp_geometry() decline for
+// their unit count, tiles that are not mostly padding, at least two 16-channel chunks per slice
+int tem_conv_zr_splitk_ks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
+    const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
+    if (opt == 0 || opt == 1 || !tem_option(TEM_OPT_ZR_SPLITK)) return 0;
+    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7)) return 0;
+    if (!(kd == 3 && kh == 3 && kw == 3) || D < 4 || Cin % 16 || Cout % 32) return 0;
+    if (zr_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, 1).ok) return 0;
+    if (tem_conv_pp_tiles(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit)) return 0;
+    static int ncu = 0;
+    if (!ncu) {
+        ncu = tem_device_cus();
+        if (ncu <= 0) ncu = 256;
+    }
+    const int nZ = (D + 3) / 4, nY = (H + 15) / 16, nX = (W + 7) / 8;
+    // tiles of 4 x 16 x 8 voxels: an 8^3 level would compute half a tile of padding
+    if ((int64_t)D * H * W * 10 < (int64_t)nZ * 4 * nY * 16 * nX * 8 * 8) return 0;
+    const int64_t units = (int64_t)N * nZ * nY * nX * (Cout / 32);
+    const int nch = Cin / 16;
+    for (int d = 2; d <= nch / 2; ++d)
+        if (nch % d == 0 && units * d >= 2ll * ncu) return d;
+    return 0;
+}
+
+int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                           const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
+                           int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
+                           int nsplit, hipStream_t s) {
+    const int ks = ws ? tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit) : 0;
+    if (!ks) return 0;
+    if ((int64_t)H * W * 8 * 4 * (x_ld > Cout ? x_ld : Cout) >= (1ll << 31)) return 0;
+    if ((y_ld % 4) || ((uintptr_t)y % 16) || (ref && ((ref_ld % 4) || ((uintptr_t)ref % 16))) || (bias && ((uintptr_t)bias % 16)))
+        return 0;
+    const int64_t NV = (int64_t)N * D * H * W;
+    if (ws_bytes < (int64_t)ks * NV * Cout * 4) return 0;
+    ZrGeom g = {};
+    g.nZ = (D + 3) / 4;
+    g.nY = (H + 15) / 16;
+    g.nX = (W + 7) / 8;
+    g.nunits = (int64_t)N * g.nZ * g.nY * g.nX * (Cout / 32) * ks;
+    g.ok = 1;
+    float* part = (float*)ws;
+#define ZRKS(NS, F16)                                                                                                  \
+    zr_launch<NS, F16, 0, true>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,  \
+                                TEM_ACT_NONE, nullptr, nullptr, s, ks)
+    if (nsplit == 5) ZRKS(1, true);
+    else if (nsplit == 7) ZRKS(1, false);
+    else if (nsplit == 4) ZRKS(2, true);
+    else ZRKS(2, false);
+#undef ZRKS
+    tem_splitk_epilogue(part, ks, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
+    return 1;
 }
 
 // tem_conv3d_fwd_gscaled (conv.hip) parks the device pointer of max |input| here around its call; the launch that honours

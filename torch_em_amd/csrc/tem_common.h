@@ -20,6 +20,7 @@ enum {
     TEM_OPT_WGRAD_CUS,
     TEM_OPT_UPSAMPLE_GENERIC,
     TEM_OPT_TEAM_MIN_UNITS,
+    TEM_OPT_ZR_SPLITK,
     TEM_OPT_COUNT
 };
 long long tem_option(int id);

@@ -25,7 +25,7 @@ PROFILER_FILTER = None
 
 
 def _fwd_tag(mfma, k, cout, pp=False):
-    if pp == 3:  # the z-reuse team kernel (csrc/conv_zr.hip)
+    if pp in (3, 4):  # the z-reuse team kernel (csrc/conv_zr.hip); 4 = its split-K launch (16^3 / 32^3 levels)
         return f"k_conv_zr_{'f16x3' if int(mfma) == 4 else 'f16' if int(mfma) == 5 else 'bf16' if int(mfma) == 7 else 'bf16x3'}<3,3,3>"
     if pp:  # the ping-pong team kernel (csrc/conv_pp.hip)
         return f"k_conv_pp_{'f16x3' if int(mfma) == 4 else 'bf16x3'}<{k[0]},{k[1]},{k[2]},CT={2 if cout % 64 == 0 else 1}>"
@@ -386,7 +386,7 @@ def conv_fwd_refnorm(x, w_packed, y, k, cin, cout, ref, coef, mfma):
 
 
 def conv_fwd_family(x, k, cin, cout, mfma) -> int:
-    """tem_conv3d_fwd_kernel: 0 patch / other kernels, 1 / 2 ping-pong teams, 3 z-reuse teams"""
+    """tem_conv3d_fwd_kernel: 0 patch / other kernels, 1 / 2 ping-pong teams, 3 z-reuse teams, 4 z-reuse teams with split-K"""
     N, D, H, W, _, _ = _act5(x)
     return int(_lib.load().tem_conv3d_fwd_kernel(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
 
