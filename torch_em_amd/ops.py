@@ -217,7 +217,7 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     if ref is not None:
         ref_ld = _act5(ref)[5]
     lib = _lib.load()
-    nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 1) if mfma else 0
+    nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if mfma else 0
     ws = _workspace(nws, x.device) if nws else None
     kind = None
     if PROFILER is not None:
