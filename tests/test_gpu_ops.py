@@ -44,6 +44,9 @@ CONV_CASES = [
     (1, 4, 8, 8, 256, 64, (1, 1, 1)),    # split-K, 1x1x1
     (2, 9, 17, 10, 1, 32, (3, 3, 3)),    # Cin == 1 first-layer kernels
     (1, 1, 19, 21, 1, 16, (1, 3, 3)),    # Cin == 1, 2-D
+    (1, 6, 11, 67, 1, 32, (3, 3, 3)),    # Cin == 1: three 32-wide tiles of the row kernel, the last one with 3 voxels
+    (1, 5, 7, 33, 1, 64, (3, 3, 3)),     # Cin == 1, 64 output channels (two row passes), W = 32 + 1
+    (1, 3, 9, 40, 1, 8, (1, 3, 3)),      # Cin == 1, 8 output channels (4 pair lanes per row), 2-D kernel on a volume
     (2, 9, 17, 10, 3, 32, (3, 3, 3)),    # Cin == 3 (RGB) through the small-Cin first-layer kernels
     (1, 1, 19, 21, 2, 16, (1, 3, 3)),    # Cin == 2, 2-D
     (1, 5, 9, 9, 4, 32, (3, 3, 3)),      # Cin == 4
