@@ -143,7 +143,10 @@ def extra_measurements(step, args, engine):
         spec.loader.exec_module(wl)
         torch.cuda.empty_cache()
         for key, fn in (("cfg1_ms_per_step", wl.cfg1), ("cfg3_ms_per_step", wl.cfg3), ("cfg5_ms_per_step", wl.cfg5)):
-            out[key] = fn()["ms_per_step"]
+            res = fn()
+            out[key] = res["ms_per_step"]
+            if "hip_graph_ms_per_step" in res:
+                out[key.replace("_ms_per_step", "_hip_graph_ms_per_step")] = res["hip_graph_ms_per_step"]
             torch.cuda.empty_cache()
         spec = importlib.util.spec_from_file_location("host_overhead", os.path.join(ROOT, "scripts", "host_overhead.py"))
         ho = importlib.util.module_from_spec(spec)

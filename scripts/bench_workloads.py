@@ -12,11 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def _time(step, steps, warmup):
     for _ in range(warmup):
-        v = step()
+        v = step().detach()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        v = step()
+        v = step().detach()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3, v
 
@@ -40,7 +40,15 @@ def cfg1(steps=5, warmup=3, dev="cuda"):
         opt.step()
         return val
     ms, v = _time(step, steps, warmup)
-    return {"ms_per_step": ms, "voxels_per_s": x.numel() / ms * 1e3, "loss": float(v)}
+    out = {"ms_per_step": ms, "voxels_per_s": x.numel() / ms * 1e3, "loss": float(v)}
+    # the same step replayed as one HIP graph (torch_em_amd/graph.py): this small 2-D workload is host-bound when its ~150
+    # launches are enqueued one by one; the label targets stay outside the graph (they are the input pre-pass)
+    from torch_em_amd.graph import GraphedTrainStep
+    y0 = target(lbl)
+    gstep = GraphedTrainStep(model, loss, opt, x, y0)
+    gms, _ = _time(lambda: gstep(x, target(lbl))[1], steps, warmup)
+    out["hip_graph_ms_per_step"] = gms
+    return out
 
 
 def cfg3(steps=3, warmup=2, dev="cuda"):

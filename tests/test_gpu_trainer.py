@@ -635,7 +635,11 @@ def test_graphed_step_equals_eager(tmp_path):
     m1 = UNet3d(1, 2, depth=2, initial_features=8).to(DEV)
     m1.load_state_dict(sd0)
     opt1 = FusedAdamW(m1.parameters(), lr=1e-3)
+    # an autograd graph of an earlier eager forward that the caller still holds: its AccumulateGrad nodes belong to the
+    # default stream (with loss.backward() inside the capture this crashed hipStreamEndCapture)
+    kept_alive = loss_fn(m1(xs[0]), ys[0])
     step = GraphedTrainStep(m1, loss_fn, opt1, xs[0], ys[0])
+    assert kept_alive.grad_fn is not None
     for k, v in m1.state_dict().items():          # building the graph (warm-up steps, capture) changed nothing
         assert torch.equal(v, sd0[k]), k
     assert all(float(opt1.state[p]["step"]) == 0 for p in m1.parameters())

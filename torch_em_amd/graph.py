@@ -99,15 +99,27 @@ class GraphedTrainStep:
         return precision_scope(self.precision)
 
     def _forward_backward_step(self):
+        from .model import engine
         with self._scope():
-            pred = self.model(self.static_x)
-            loss = self.loss_fn(pred, self.static_y)
-            if self.scaler is not None:     # reference `_backprop_mixed` (trainer/default_trainer.py:789-794)
-                self.scaler.scale(loss).backward()
+            # Gradients via fresh leaves + torch.autograd.grad + assignment instead of loss.backward(): see
+            # engine.fresh_leaves (a parameter's AccumulateGrad node may belong to another stream; reaching it from the
+            # capturing stream crashed hipStreamEndCapture when the caller still held a loss of an earlier eager step).
+            with engine.fresh_leaves() as pairs:
+                pred = self.model(self.static_x)
+                loss = self.loss_fn(pred, self.static_y)
+            if pairs:
+                ps = [p for prm, lv in pairs for p, leaf in zip(prm, lv) if leaf.requires_grad]
+                leaves = [leaf for prm, lv in pairs for leaf in lv if leaf.requires_grad]
+            else:                      # not an engine model: plain parameters
+                ps = leaves = [p for p in self.params if p.requires_grad]
+            out = self.scaler.scale(loss) if self.scaler is not None else loss   # reference `_backprop_mixed` (:789-794)
+            grads = torch.autograd.grad(out, leaves, allow_unused=True)
+            for p, g in zip(ps, grads):
+                p.grad = g
+            if self.scaler is not None:
                 self.scaler.step(self.optimizer)
                 self.scaler.update()
             else:
-                loss.backward()
                 self.optimizer.step()
         return pred, loss
 

@@ -883,7 +883,10 @@ class UNetFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[1:])
         y5, st = _forward_impl(model, x, keep=need_grad)
         ctx.model, ctx.st, ctx.nparams = model, st, len(params)
-        ctx.params = list(params)
+        # `params` are the autograd inputs -- the module's parameters, or fresh leaves that alias them (fresh_leaves());
+        # the engine itself always works on the module's own parameter objects (gradient arena keyed by their identity)
+        ctx.params = list(model.parameters())
+        assert len(ctx.params) == len(params)
         if isinstance(y5, list):
             return tuple(_to_logical(y, _dim_of(model)) for y in y5)
         return _to_logical(y5, _dim_of(model))
@@ -907,6 +910,30 @@ class UNetFunction(torch.autograd.Function):
         return tuple(out)
 
 
+_LEAF_SINK = None
+
+
+class fresh_leaves:
+    """`with fresh_leaves() as pairs:` -- every U-Net forward inside takes its parameters through NEW leaf tensors that
+    alias them (`p.detach().requires_grad_()`), and appends (parameters, leaves) to `pairs`; the caller obtains the
+    gradients with `torch.autograd.grad(loss, leaves)` and assigns them.  For HIP-graph capture (torch_em_amd/graph.py):
+    a parameter's own AccumulateGrad node lives on the stream it was created on for as long as ANY autograd graph that
+    used the parameter is alive (a loss tensor the caller kept from an eager step is enough); delivering a gradient to it
+    from the capturing stream is an unjoined cross-stream dependency, and hipStreamEndCapture crashes the process.  New
+    leaves get new nodes on the capturing stream."""
+
+    def __enter__(self):
+        global _LEAF_SINK
+        self.prev, self.pairs = _LEAF_SINK, []
+        _LEAF_SINK = self.pairs
+        return self.pairs
+
+    def __exit__(self, *exc):
+        global _LEAF_SINK
+        _LEAF_SINK = self.prev
+        return False
+
+
 def unet_forward(model, x: torch.Tensor) -> torch.Tensor:
     if not x.is_cuda:
         raise RuntimeError(
@@ -915,7 +942,11 @@ def unet_forward(model, x: torch.Tensor) -> torch.Tensor:
         )
     params = [p for p in model.parameters()]
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-        out = UNetFunction.apply(model, x, *params)
+        inputs = params
+        if _LEAF_SINK is not None:
+            inputs = [p.detach().requires_grad_(True) if p.requires_grad else p for p in params]
+            _LEAF_SINK.append((params, inputs))
+        out = UNetFunction.apply(model, x, *inputs)
         return list(out) if isinstance(out, tuple) else out
     y5, _ = _forward_impl(model, x, keep=False)
     if isinstance(y5, list):
