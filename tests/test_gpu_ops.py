@@ -274,7 +274,7 @@ def test_conv_pingpong_family_parity(case, cts, variant, conv_variant_option):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 16, 256, 256), (2, 16, 16, 16, 128, 256), (2, 15, 16, 15, 128, 256),
-                                  (1, 32, 32, 32, 128, 64)])
+                                  (1, 32, 32, 32, 128, 64), (2, 8, 8, 8, 512, 512)])
 def test_conv_zreuse_split_k(case):
     """Family 4 of tem_conv3d_fwd_kernel: the z-reuse kernel with the input channels split over several units (the 16^3 /
     32^3 levels of the U-Net, reference model/unet.py:417-438: too few 4x16x8 tiles to give every team of every CU one)
