@@ -45,3 +45,29 @@ def test_version_and_error_string():
     assert rc == -1 and b"null pointer" in lib.tem_last_error()
     with pytest.raises(ValueError):
         _lib.check(rc, "tem_conv3d_fwd")
+
+
+def test_cfg2_layers_select_the_team_kernels():
+    """Dispatch guard (no GPU needed: tem_conv3d_fwd_kernel is host logic, 256 CUs assumed without a device): every 3x3x3
+    forward / data-gradient convolution of the benchmark network (UNet3d(1->2, 32 features, depth 4) on 2x1x128^3,
+    BASELINE.json cfg 2) runs on the z-reuse team kernel -- family 3 with fused statistics at the 128^3 ... 32^3 levels,
+    family 4 (split input channels, no fused statistics) where there are too few tiles: a change that silently sends one of
+    them back to the one-patch-per-workgroup kernel costs 0.1-1 ms per step."""
+    from torch_em_amd import _lib
+    lib = _lib.load()
+    # (size, features) per level; each block has cin->f and f->f convs, the decoder's first conv reads 2f channels
+    levels = [(128, 32), (64, 64), (32, 128), (16, 256)]
+    layers = []
+    for i, (s, f) in enumerate(levels):
+        layers += [(s, f, f), (s, 2 * f, f)]                       # conv2 of both blocks / decoder conv1
+        if i:
+            layers.append((s, f // 2, f))                          # encoder conv1 (level 0 has Cin = 1: the row kernel)
+    layers += [(8, 256, 512), (8, 512, 512)]                       # base block
+    for s, cin, cout in layers:
+        for a, b in ((cin, cout), (cout, cin)):                    # forward and its data gradient (transposed channels)
+            for mode in (2, 4, 5, 7):
+                fam = lib.tem_conv3d_fwd_kernel(2, s, s, s, a, b, 3, 3, 3, mode)
+                units = 2 * (s // 4) * max(s // 16, 1) * (s // 8) * (b // 32)
+                assert fam == (3 if units >= 512 else 4), (s, a, b, mode, fam)
+                blocks = lib.tem_conv3d_fwd_stat_blocks(2, s, s, s, a, b, 3, 3, 3, mode)
+                assert (blocks > 0) == (fam == 3), (s, a, b, mode, blocks)
