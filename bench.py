@@ -33,9 +33,10 @@ STEP_GB = 25.58                 # conv-centric fp32 traffic of c
 
 # live-event tags -> kernel names as rocprofv3 prints them (dominant template instantiation of each tag)
 RP_NAMES = {
-    "k_conv_zr_f16x3<3,3,3>": "k_conv_zr<2, true, 1>",
-    "k_conv_zr_bf16x3<3,3,3>": "k_conv_zr<2, false, 2>",
-    "k_conv_zr_f16<3,3,3>": "k_conv_zr<1, true, 1>",
+    "k_conv_zr_f16x3<3,3,3>": "k_conv_zr<2, true, 1, false>",      # <NS, F16, MODE (1 = fused statistics), KSPLIT>
+    "k_conv_zr_bf16x3<3,3,3>": "k_conv_zr<2, false, 0, false>",
+    "k_conv_zr_f16<3,3,3>": "k_conv_zr<1, true, 1, false>",
+    "k_conv_zr_bf16<3,3,3>": "k_conv_zr<1, false, 1, false>",
     "k_conv_pp_bf16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, false>",
     "k_conv_pp_bf16x3<3,3,3,CT=1>": "k_conv_pp<3, 3, 3, 4, 8, 8, 1, 1, 2, false>",
     "k_conv_pp_f16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, true>",
