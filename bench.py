@@ -33,10 +33,10 @@ STEP_GB = 25.58                 # conv-centric fp32 traffic of c
 
 # live-event tags -> kernel names as rocprofv3 prints them (dominant template instantiation of each tag)
 RP_NAMES = {
-    "k_conv_zr_f16x3<3,3,3>": "k_conv_zr<2, true, 1, false>",      # <NS, F16, MODE (1 = fused statistics), KSPLIT>
-    "k_conv_zr_bf16x3<3,3,3>": "k_conv_zr<2, false, 0, false>",
-    "k_conv_zr_f16<3,3,3>": "k_conv_zr<1, true, 1, false>",
-    "k_conv_zr_bf16<3,3,3>": "k_conv_zr<1, false, 1, false>",
+    "k_conv_zr_f16x3<3,3,3>": "k_conv_zr<2, true, 1, false, false>",      # <NS, F16, MODE (1 = fused statistics), KSPLIT, WIDE>
+    "k_conv_zr_bf16x3<3,3,3>": "k_conv_zr<2, false, 0, false, false>",
+    "k_conv_zr_f16<3,3,3>": "k_conv_zr<2, true, 1, false, true>",         # one-term modes: 32 channels per phase
+    "k_conv_zr_bf16<3,3,3>": "k_conv_zr<2, false, 1, false, true>",
     "k_conv_pp_bf16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, false>",
     "k_conv_pp_bf16x3<3,3,3,CT=1>": "k_conv_pp<3, 3, 3, 4, 8, 8, 1, 1, 2, false>",
     "k_conv_pp_f16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, true>",
@@ -49,10 +49,10 @@ RP_NAMES = {
     "k_conv_fwd_f16x3<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 2, true>",
     "k_conv_fwd_f16<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 1, true>",
     "k_conv_fwd_f16<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 1, true>",
-    "k_conv_wgrad_f16<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, true>",
-    "k_conv_wgrad_f16<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, true>",
-    "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, false>",
-    "k_conv_wgrad_bf16x3<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, false>",
+    "k_conv_wgrad_f16<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, 1>",
+    "k_conv_wgrad_f16<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, 1>",
+    "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, 0>",
+    "k_conv_wgrad_bf16x3<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, 0>",
 }
 
 SUSTAINED_F16_MFMA_TFLOPS = 1640.0   # measured: profiles/r03_mfma_sustained.txt (pure MFMA stream, random operands, all CUs)

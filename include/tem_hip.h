@@ -63,6 +63,8 @@ int tem_device_cus(void);
  *   "upsample_generic"    0 | 1   1: the any-factor gather kernels also for factors (1|2, 2, 2)
  *   "team_min_units"      0       units a launch needs for the team kernels (0 = two per CU; lower values measured slower)
  *   "zr_splitk"           1 | 0   z-reuse kernel with split input channels for launches with too few tiles (16^3 / 32^3 levels)
+ *   "zr_wide"             1 | 0   one-term modes (5, 7) of the z-reuse kernel stage 32 channels = whole 128-byte lines per phase
+ *   "zr_tile_blocks"      1 | 0   z-reuse kernel walks its tiles in 4 x 4 x 4 blocks (one compact block per XCD at a time)
  * Unknown names return TEM_EINVAL. */
 int tem_set_option(const char* name, int64_t value);
 int tem_get_option(const char* name, int64_t* value);

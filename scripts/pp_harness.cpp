@@ -29,6 +29,8 @@ int main(int argc, char** argv) {
     const int mode = atoi(argv[7]), variant = atoi(argv[8]);
     const int iters = argc > 9 ? atoi(argv[9]) : 10, use_norm = argc > 10 ? atoi(argv[10]) : 1, use_ref = argc > 11 ? atoi(argv[11]) : 0;
     tem_set_option("conv_fwd_variant", variant);
+    if (getenv("ZR_TILE_BLOCKS")) tem_set_option("zr_tile_blocks", atoi(getenv("ZR_TILE_BLOCKS")));   // A/B of the tile order
+    if (getenv("ZR_WIDE")) tem_set_option("zr_wide", atoi(getenv("ZR_WIDE")));
     const size_t V = (size_t)N * D * H * W;
     uint64_t seed = 1234;
     std::vector<float> hx(V * Cin), hw((size_t)Cout * Cin * 27), hb(Cout), hs((size_t)N * Cin), hf((size_t)N * Cin);

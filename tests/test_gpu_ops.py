@@ -322,6 +322,54 @@ def test_conv_zreuse_split_k(case):
             _lib.set_option("zr_splitk", 1)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 32), (2, 37, 61, 70, 64, 32), (2, 16, 64, 64, 96, 64), (2, 32, 64, 64, 48, 32)])
+def test_conv_zreuse_wide_chunks_and_tile_order(case):
+    """Two dispatch choices of the z-reuse kernel (csrc/conv_zr.hip; forward / data-gradient convolutions of ConvBlock,
+    reference model/unet.py:417-438): "zr_wide" (the one-term modes 5 / 7 stage 32 input channels = whole 128-byte lines
+    per phase when Cin % 32 == 0; 48 channels fall back to 16 per phase) and "zr_tile_blocks" (tiles walked in 4 x 4 x 4
+    blocks, any extent that is not a multiple of 4 / 2 tiles shrinks the block).  The tile order must not change a single
+    bit (a unit's arithmetic is the same, the fused statistics are indexed by position); the wide kernel sums the same
+    products in another order: fp32-rounding close to the narrow one, and both against F.conv3d of the rounded operands."""
+    ops = _ops()
+    from torch_em_amd import _lib
+    lib = _lib.load()
+    N, D, H, W, Cin, Cout = case
+    k, pad = (3, 3, 3), (1, 1, 1)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    scale, shift = torch.rand(N, Cin, generator=g) + 0.5, torch.randn(N, Cin, generator=g)
+    xn = (x.double() * scale[:, :, None, None, None].double() + shift[:, :, None, None, None].double()).float()
+    x5, wd = to5(x), w.to(DEV)
+    out = {}
+    try:
+        for mode in (4, 5, 7):
+            rnd = (lambda t: t) if mode == 4 else (lambda t: t.half().float()) if mode == 5 else (lambda t: t.bfloat16().float())
+            exp = F.relu(F.conv3d(rnd(xn), rnd(w), b, padding=pad))
+            assert lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, 3, 3, 3, mode) == 3
+            for wide in (1, 0):
+                for blocks in (1, 0):
+                    _lib.set_option("zr_wide", wide)
+                    _lib.set_option("zr_tile_blocks", blocks)
+                    y5 = ops.new_act(N, D, H, W, Cout, DEV)
+                    stat, _nb = ops.conv_fwd(x5, ops.pack_weights(wd, transpose=False, mfma=mode), b.to(DEV), y5, k, Cin, Cout,
+                                             scale=scale.to(DEV), shift=shift.to(DEV), act="relu", mfma=mode, want_stats=True)
+                    out[(mode, wide, blocks)] = (y5.clone(), stat.clone())
+                    err = rel_err(from5(y5), exp)
+                    assert err < 2e-5, f"mode {mode} wide {wide} blocks {blocks}: {err}"
+                    assert rel_err(stat[..., 0].sum(1).cpu(), exp.sum((2, 3, 4))) < 1e-4
+                assert torch.equal(out[(mode, wide, 1)][0], out[(mode, wide, 0)][0]), f"mode {mode}: tile order changed the output"
+                assert torch.equal(out[(mode, wide, 1)][1], out[(mode, wide, 0)][1]), f"mode {mode}: tile order changed the statistics"
+            d = rel_err(out[(mode, 1, 1)][0].cpu(), out[(mode, 0, 1)][0].cpu())
+            assert d < 2e-6, f"mode {mode}: wide vs narrow {d}"
+            if mode == 4:   # no wide variant of the two-term kernels
+                assert torch.equal(out[(mode, 1, 1)][0], out[(mode, 0, 1)][0])
+    finally:
+        _lib.set_option("zr_wide", 1)
+        _lib.set_option("zr_tile_blocks", 1)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 32), (2, 18, 61, 67, 64, 32), (2, 16, 64, 64, 64, 64)])
 @pytest.mark.parametrize("gscale", [1.0, 3e-7, 5e4])
 def test_data_gradient_fp16_two_term_with_device_prescale(case, gscale):
@@ -392,6 +440,40 @@ def test_data_gradient_with_norm_backward_epilogue(case, mode):
         small = to5(torch.randn(1, Cout, 4, 8, 8, generator=g))
         ops.conv_fwd_refnorm(small, wp, ops.new_act(1, 4, 8, 8, Cin, DEV), k, Cout, Cin,
                              ops.new_act(1, 4, 8, 8, Cin, DEV), coef[:1].contiguous(), mode)
+
+
+@pytest.mark.parametrize("mode", [2, 5, 7])
+def test_norm_backward_epilogue_is_deterministic_over_repeated_launches(mode):
+    """Regression test of a store-data hazard (zr_store4, csrc/conv_zr.hip): with an SGPR soffset on the 16-byte buffer
+    store the compiler let the next row's v_cndmask overwrite the first data register, and the MODE 3 epilogue (data gradient
+    + ReLU mask + norm backward, what autograd does after convolution_backward behind model/unet.py:417-438) stored the x
+    component of row m + 1 into row m in a few lanes -- in 1 % to 99 % of the launches depending on register allocation.
+    120 launches of the shape that showed it must agree bit for bit, and with the unfused two-pass result."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout = 2, 18, 61, 67, 64, 32
+    k = (3, 3, 3)
+    g = torch.Generator().manual_seed(23)
+    w = (torch.randn(Cout, Cin, *k, generator=g) * 0.2).to(DEV)
+    g5 = to5(torch.randn(N, Cout, D, H, W, generator=g))
+    a1 = to5(torch.relu(torch.randn(N, Cin, D, H, W, generator=g) + 0.2))
+    coef = torch.randn(N, Cin, 4, generator=g).to(DEV)
+    wp = ops.pack_weights(w, transpose=True, mfma=mode)
+    plain = ops.new_act(N, D, H, W, Cin, DEV)
+    ops.conv_fwd(g5, wp, None, plain, k, Cout, Cin, mfma=mode)
+    kc = coef.view(N, 1, 1, 1, Cin, 4)
+    want = torch.where(a1 > 0, kc[..., 0] * plain - kc[..., 1] - (a1 - kc[..., 3]) * kc[..., 2], torch.zeros_like(plain))
+    first = None
+    junk = torch.empty(16 << 20, device=DEV)
+    for i in range(120):
+        got = torch.full((N, D, H, W, Cin), float("nan"), device=DEV)
+        ops.conv_fwd_refnorm(g5, wp, got, k, Cout, Cin, a1, coef, mode)
+        if i % 3 == 0:
+            junk.normal_()   # other traffic between the launches
+        if first is None:
+            first = got.clone()
+            assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        else:
+            assert torch.equal(got, first), f"launch {i} differs from launch 0 in {int((got != first).sum())} elements"
 
 
 @pytest.mark.parametrize("case", [      # >= 384 workgroups each: smaller launches run split-K and cannot fuse

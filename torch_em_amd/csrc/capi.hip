@@ -35,6 +35,8 @@ static const TemOption g_opt_table[TEM_OPT_COUNT] = {
     {"upsample_generic", 0},    // TEM_OPT_UPSAMPLE_GENERIC: 1 = any-factor gather kernels also for factor (1|2, 2, 2) (A/B, tests)
     {"team_min_units", 0},      // TEM_OPT_TEAM_MIN_UNITS: units a launch needs for the team kernels (0 = 2 per CU; experiments)
     {"zr_splitk", 1},           // TEM_OPT_ZR_SPLITK: z-reuse kernel with split input channels for the 16^3 / 32^3 levels
+    {"zr_wide", 1},             // TEM_OPT_ZR_WIDE: one-term z-reuse kernel stages 32 channels (whole 128-byte lines) per phase (0: 16, A/B)
+    {"zr_tile_blocks", 1},      // TEM_OPT_ZR_TILE_BLOCKS: z-reuse kernel walks its tiles in 4 x 4 x 4 blocks (one block per XCD at a time; 0: x, y, z order, A/B)
 };
 static long long g_opt_val[TEM_OPT_COUNT];
 static bool g_opt_set[TEM_OPT_COUNT];

@@ -67,7 +67,9 @@ __device__ __forceinline__ uint4 pp_load4u(__amdgpu_buffer_rsrc_t r, unsigned vo
 __device__ __forceinline__ void pp_store4_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
     const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
                      __builtin_bit_cast(unsigned, v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, TEM_PP_ST_AUX);
+    // soffset stays an immediate: with an SGPR there LLVM skips the wait state a VALU write of the data registers needs
+    // after a 16-byte store on gfx950 (see zr_store4 in conv_zr.hip)
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff + soff, 0, TEM_PP_ST_AUX);
 }
 
 #ifdef TEM_PP_TRACE   // developer build (scripts/pp_harness.cpp): shader-clock stamps of the phases of one workgroup

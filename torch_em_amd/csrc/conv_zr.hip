@@ -66,7 +66,13 @@ __device__ __forceinline__ uint4 zr_load4u(__amdgpu_buffer_rsrc_t r, unsigned vo
 __device__ __forceinline__ void zr_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b, float c, float d) {
     const u32x4z v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
                       __builtin_bit_cast(unsigned, d)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, TEM_ZR_ST_AUX);
+    // The scalar offset goes into the VGPR offset, the soffset field stays an immediate: gfx950 reads the data registers of a
+    // 16-byte store after the instruction has issued, and LLVM (ROCm 7.2, GCNHazardRecognizer::createsVALUHazard) only
+    // inserts the wait state before a VALU write of those registers when soffset is NOT a register.  With an SGPR soffset
+    // the next row's v_cndmask overwrote the first data register in lanes 12..15 of every row of 16: the MODE 3 epilogue
+    // stored the x component of row m + 1 into row m, in 1-99 % of the launches depending on register allocation
+    // (scripts/race_zr_store.py; 0 of 1000 with the offset in the VGPR).
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, TEM_ZR_ST_AUX);
 }
 
 // value of lane ^ M (M < 32): ds_swizzle in bit mode needs no index register (a __shfl_xor keeps four of them live)
@@ -123,21 +129,34 @@ struct ZrUnit {
 // KSPLIT (MODE 0 only): the input channels are cut into `ks` slices, a unit = (tile, column tile, slice) writes its raw
 // partial sums into slice `ksl` of a [ks][N*D*H*W][Cout] workspace (y, y_ld = Cout) and tem_splitk_epilogue adds them up --
 // the 16^3 / 32^3 levels, whose (tile, column tile) count alone cannot give every team of every CU a unit.
-template <int NS, bool F16, int MODE, bool KSPLIT = false>
+// WIDE (the one-term mixed modes with Cin % 32 == 0; NS == 2 then counts LDS planes, not terms): a phase stages and
+// multiplies 32 input channels -- plane p of the tile holds channels 16 p .. 16 p + 15 of the chunk.  A 16-channel chunk is
+// half of a 128-byte line of a 32-channel voxel record and the L2 fetches whole lines: with one chunk per phase the other
+// half came back two phases (~9 MB of L2 turnover per XCD) later, from HBM again -- FETCH_SIZE showed 1.83 GB per launch
+// for a 268 MB input (32 -> 32 at 2 x 128^3), and the one-term kernel ran at the HBM ceiling (5.6 TB/s, 374 us; 274 us
+// with every load an L2 hit, TEM_ZR_ABL 64).  Here eight lanes request the whole line in one load instruction (two
+// requests for the halves, even back to back, still fetched 0.99 GB; half a phase apart 1.38 GB).
+template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
-    int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax, int ks) {
+    int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax, int ks, int blk) {
     static_assert(!KSPLIT || MODE == 0, "split-K units write raw partial sums");
+    static_assert(!WIDE || NS == 2, "the wide one-term kernel uses the two LDS planes of the two-term layout");
+    constexpr int CK = WIDE ? 2 * BCK : BCK;     // input channels per phase
     constexpr int TZ = 4, TY = 16, TX = 8;
     constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     constexpr int HV = HZ * HY * HX;             // 1080 halo voxels
     constexpr int PLB = HV * 32;                 // bytes per plane of a team's tile (16 channels x 2 B per voxel)
-    constexpr int NIT = HZ * 3;                  // float4 slots per thread and chunk: three per halo plane
-    constexpr int R0 = TEM_ZR_R0 < HZ ? TEM_ZR_R0 : HZ;   // halo planes loaded before the epilogue
+    constexpr int NIT = HZ * 3;                  // float4 slots per thread: a ring of RP halo planes
+    constexpr int LPV = WIDE ? 8 : 4;            // lanes per halo voxel: one 16-byte load each (WIDE: a whole 128-byte line)
+    constexpr int SPP = WIDE ? 6 : 3;            // load slots per thread and halo plane (the last one only for part of the team)
+    constexpr int RP = NIT / SPP;                // planes the register ring holds
+    constexpr int R0 = WIDE ? ((MODE == 1 || MODE == 3) ? 1 : 2)   // (a ring of three planes: at most two ahead; the statistics / norm-backward epilogues have no room for 12 loads)
+                            : (TEM_ZR_R0 < HZ ? TEM_ZR_R0 : HZ);   // halo planes loaded before the epilogue
     constexpr int FR = NS * 64;                  // uint4s per (tap, 16-channel chunk) fragment group
-    constexpr bool SC = F16 && NS == 2;
+    constexpr bool SC = F16 && NS == 2 && !WIDE;
     constexpr int ZSTEP = HY * HX * 32;          // bytes between halo z-planes: 5760 = 45 * 128 (bank-neutral)
     static_assert(HY % 2 == 0, "the record-half swizzle (row parity) is the same in every halo plane");
     extern __shared__ __attribute__((aligned(16))) unsigned char zr_lds[];   // [2 teams][NS planes][HV][32 B], [4 waves][32][144 B]
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const int G = 2 * gridDim.x;
     const int slot = tem_xcd_remap(blockIdx.x, gridDim.x) * 2 + team;
     const int ncot = Cout >> 5;
-    const int nch_all = Cin >> 4;                          // 16-channel chunks of the input
+    const int nch_all = Cin / CK;                          // chunks of the input (16 channels; WIDE: 32)
     const int nch = KSPLIT ? nch_all / ks : nch_all;       // ... of one unit
     const int my_units = slot < nunits ? (nunits - slot + G - 1) / G : 0;
     const int P = ((nunits + G - 1) / G) * nch;
@@ -172,9 +191,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
         t.ksl = 0;
         if (KSPLIT) { t.ksl = u % ks; u /= ks; }   // the slices of a tile are neighbours: they share its halo in L2
         t.cot = u % ncot; u /= ncot;
-        t.x0 = (u % nX) * TX; u /= nX;
-        t.y0 = (u % nY) * TY; u /= nY;
-        t.z0 = (u % nZ) * TZ; u /= nZ;
+        // Tiles in blocks of 2^lx x 2^ly x 2^lz (x fastest inside a block, blocks x fastest): the 64 units that the teams of
+        // one XCD work on at a time (tem_xcd_remap) then form a compact 3-D block whose halos overlap inside that XCD's L2
+        // -- in plain x, y, z order they are a 4-voxel-thin slab whose z halo (a third of all halo lines) belongs to
+        // tiles on other XCDs or in other iterations.  blk = lx | ly << 4 | lz << 8 (0: plain order).
+        const int lx = blk & 15, ly = (blk >> 4) & 15, lz = blk >> 8;
+        const int b = u & ((1 << (lx + ly + lz)) - 1);
+        u >>= lx + ly + lz;
+        const int bx = b & ((1 << lx) - 1), by = (b >> lx) & ((1 << ly) - 1), bz = b >> (lx + ly);
+        const int mX = nX >> lx, mY = nY >> ly, mZ = nZ >> lz;
+        t.x0 = (((u % mX) << lx) + bx) * TX; u /= mX;
+        t.y0 = (((u % mY) << ly) + by) * TY; u /= mY;
+        t.z0 = (((u % mZ) << lz) + bz) * TZ; u /= mZ;
         t.n = u;
         return t;
     };
@@ -183,19 +211,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     // staging: a halo z-plane has HY * HX = 180 voxels x 4 four-channel quarters = 720 slots: three per thread (the third
     // only for tl < 208).  Slot j of plane hz: plane voxel q_j = (tl + 256 j) >> 2, channels c4*4 .. c4*4+3 of the chunk.
     // Only the three in-plane byte offsets live in VGPRs; the plane offset is the scalar offset of the buffer load.
-    const int c4 = tl & 3;
-    unsigned poff[3];        // byte offset of slot j inside a halo plane (from the halo origin)
-    unsigned lwj[3];         // LDS byte offset of slot j in any plane (16-byte half swizzled by the parity of the halo row)
-    int hyj[3], hxj[3];
+    // WIDE: 8 lanes per voxel (a load instruction requests whole 128-byte lines: 32 channels), six slots per thread, the sixth for
+    // tl < 160; quads 4 .. 7 go to plane 1 of the tile.
+    const int c4 = tl & (LPV - 1);
+    unsigned poff[SPP];      // byte offset of slot j inside a halo plane (from the halo origin)
+    unsigned lwj[SPP];       // LDS byte offset of slot j in any plane (16-byte half swizzled by the parity of the halo row)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int q = min((tl + 256 * j) >> 2, HY * HX - 1);
-        hyj[j] = q / HX;
-        hxj[j] = q % HX;
-        poff[j] = ((unsigned)(hyj[j] * W + hxj[j]) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u;
-        lwj[j] = (unsigned)(q * 32) + (unsigned)((((c4 >> 1) ^ (hyj[j] & 1)) << 4) | ((c4 & 1) << 3));
+    for (int j = 0; j < SPP; ++j) {
+        const int q = min((tl + 256 * j) / LPV, HY * HX - 1);
+        const int hy = q / HX, hx = q % HX;
+        poff[j] = ((unsigned)(hy * W + hx) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u;
+        lwj[j] = (unsigned)(q * 32) + (unsigned)(((((c4 >> 1) & 1) ^ (hy & 1)) << 4) | ((c4 & 1) << 3)) + (unsigned)((c4 >> 2) * PLB);
     }
-    const bool slot2 = tl < (HY * HX * 4 - 512);   // the third slot exists for 208 threads
+    const bool slot2 = tl < (HY * HX * LPV - 256 * (SPP - 1));   // the last slot exists for 208 (WIDE: 160) threads
     const unsigned ctr_off = ((unsigned)(W + 1) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u;  // plane voxel (1, 1): always inside
     const unsigned plane_b = (unsigned)(H * W) * (unsigned)x_ld * 4u;   // bytes between z-planes of x
     // tap loop: halo voxel of this lane's footprint voxel at (hz, ty, tx) = (0, 0, 0)
@@ -258,41 +286,42 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
             ZR_STAMP(0);
             // keep hipcc from hoisting the 18 LDS / 18 global addresses of a phase out of the unit loop (it spills them)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(lwj[j]), "+v"(poff[j]));
+            for (int j = 0; j < SPP; ++j) asm volatile("" : "+v"(lwj[j]), "+v"(poff[j]));
             unsigned yoff_l = yoff_lane, roff_l = roff_lane;
             asm volatile("" : "+v"(yoff_l), "+v"(roff_l));
             float4 tmp[NIT];
-            unsigned inb = 0xffffffffu;
+            unsigned inb[2] = {0xffffffffu, 0xffffffffu};   // validity of the slots of halo planes 0..2 / 3..5 (border patches)
             float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
             bool interior = true;
             __amdgpu_buffer_rsrc_t rx = zr_rsrc(x);
             if (do_stage) {
                 if (scale) {
-                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * BCK + c4 * 4);
-                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * BCK + c4 * 4);
+                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * 4);
+                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * 4);
                 } else if (in_amax) {
                     sc4 = make_float4(psc, psc, psc, psc);
                 }
                 // the halo origin may lie outside the tensor for border patches (only in-range voxels are dereferenced)
                 const float* xb = x + ((((int64_t)cu.n * D + (cu.z0 - 1)) * H + (cu.y0 - 1)) * W + (cu.x0 - 1)) * x_ld +
-                                  (cu.ksl * nch + ci) * BCK;
-                rx = zr_rsrc(xb);
+                                  (cu.ksl * nch + ci) * CK;
+                rx = zr_rsrc((TEM_ZR_ABL & 64) ? x + (cu.ksl * nch + ci) * CK : xb);   // timing experiment: every unit reads the halo at the origin (L2 hits)
                 interior = (cu.z0 >= 1) & (cu.z0 + HZ - 1 <= D) & (cu.y0 >= 1) & (cu.y0 + HY - 1 <= H) & (cu.x0 >= 1) &
                            (cu.x0 + HX - 1 <= W);
                 if (TEM_ZR_ABL & 32) interior = true;   // timing experiment: border code paths compiled out (wrong at the faces)
             }
-            unsigned yx = 7u;   // in-plane validity of the three slots: border patches only, once per phase, from a laundered
+            unsigned yx = (1u << SPP) - 1u;   // in-plane validity of the slots: border patches only, once per phase, from a laundered
             if (do_stage && !interior) {   // copy of tl (loop-invariant code motion would keep six more registers live)
                 int tl_ = tl;
                 asm volatile("" : "+v"(tl_));
                 yx = 0;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int q = min((tl_ + 256 * j) >> 2, HY * HX - 1);
+                for (int j = 0; j < SPP; ++j) {
+                    const int q = min((tl_ + 256 * j) / LPV, HY * HX - 1);
                     const unsigned gy = (unsigned)(cu.y0 - 1 + q / HX), gx = (unsigned)(cu.x0 - 1 + q % HX);
                     yx |= ((gy < (unsigned)H) & (gx < (unsigned)W)) ? (1u << j) : 0u;
                 }
             }
+            // the SPP loads of halo plane hz live in slot hz % RP of the register ring
             auto issue_loads = [&](auto interior_tag, auto lo_tag, auto hi_tag) {   // halo planes LO .. HI-1
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
                 constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
@@ -300,20 +329,20 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
 #pragma unroll
                     for (int hz = LO; hz < HI; ++hz)
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            if (TEM_ZR_ABL & 1) tmp[hz * 3 + j] = make_float4(0.5f + hz, 0.25f, -1.f, 2.f);
-                            else tmp[hz * 3 + j] = zr_load4(rx, poff[j], (unsigned)hz * plane_b);
+                        for (int j = 0; j < SPP; ++j) {
+                            if (TEM_ZR_ABL & 1) tmp[(hz % RP) * SPP + j] = make_float4(0.5f + hz, 0.25f, -1.f, 2.f);
+                            else tmp[(hz % RP) * SPP + j] = zr_load4(rx, poff[j], (unsigned)hz * plane_b);
                         }
                 } else {
-                    if (LO == 0) inb = 0;
+                    if (LO == 0) inb[0] = inb[1] = 0;
 #pragma unroll
                     for (int hz = LO; hz < HI; ++hz) {
                         const bool zok = (unsigned)(cu.z0 - 1 + hz) < (unsigned)D;   // wave-uniform
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
+                        for (int j = 0; j < SPP; ++j) {
                             const bool ok = zok & ((yx >> j) & 1u);
-                            inb |= ok ? (1u << (hz * 3 + j)) : 0u;
-                            tmp[hz * 3 + j] = zr_load4(rx, (ok ? poff[j] : ctr_off) + (ok ? (unsigned)hz * plane_b : plane_b), 0);
+                            inb[hz / 3] |= ok ? (1u << ((hz % 3) * SPP + j)) : 0u;
+                            tmp[(hz % RP) * SPP + j] = zr_load4(rx, (ok ? poff[j] : ctr_off) + (ok ? (unsigned)hz * plane_b : plane_b), 0);
                         }
                     }
                 }
@@ -516,11 +545,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                     constexpr bool INTERIOR = decltype(interior_tag)::value;
                     constexpr int hz = decltype(hz_tag)::value;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int it = hz * 3 + j;
-                        if (j < 2 || slot2) {
+                    for (int j = 0; j < SPP; ++j) {
+                        const int it = (hz % RP) * SPP + j;
+                        if (j < SPP - 1 || slot2) {
                             float m = 1.f;
-                            if (!INTERIOR) m = ((inb >> it) & 1u) ? 1.f : 0.f;   // zero padding comes after the norm (model/unet.py:429-438)
+                            if (!INTERIOR) m = ((inb[hz / 3] >> ((hz % 3) * SPP + j)) & 1u) ? 1.f : 0.f;   // zero padding comes after the norm (model/unet.py:429-438)
                             float e[4] = {fmaf(tmp[it].x, sc4.x, sf4.x), fmaf(tmp[it].y, sc4.y, sf4.y),
                                           fmaf(tmp[it].z, sc4.z, sf4.z), fmaf(tmp[it].w, sc4.w, sf4.w)};
                             if (!INTERIOR) {
@@ -535,6 +564,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                                 const float g[4] = {e[0] * F16_LO_SCALE, e[1] * F16_LO_SCALE, e[2] * F16_LO_SCALE, e[3] * F16_LO_SCALE};
                                 const unsigned q0 = zr_mix_lo(u0, g[0], g[1]), q1 = zr_mix_lo(u1, g[2], g[3]);
                                 if (!(TEM_ZR_ABL & 8) || u0 == 0x12345678u) *reinterpret_cast<uint2*>(dstp + PLB) = make_uint2(q0, q1);
+                            } else if (WIDE) {   // one term; lwj carries the plane of this thread's channel quad
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(e[c]));   // one rounding after the fp32 norm, as autocast
+                                const unsigned h0 = pk16<F16>(e[0], e[1]), h1 = pk16<F16>(e[2], e[3]);
+                                if (!(TEM_ZR_ABL & 8) || h0 == 0x12345678u) *reinterpret_cast<uint2*>(dstp) = make_uint2(h0, h1);
                             } else {
                                 if (F16 && NS == 1) {   // one rounding to fp16 after the fp32 norm, as autocast (see conv_pp.hip)
 #pragma unroll
@@ -628,6 +662,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                     }
                     // products of this step: output plane z = hz - tz for tz = 0..2; smallest terms first, interleaved over z
                     const uint4* a = af[st % (AD + 1)];
+                    if (WIDE) {   // plane p of both operands = channels 16 p .. 16 p + 15 of the chunk
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int tz = 0; tz < 3; ++tz) {
+                                const int z = hz - tz;
+                                if (z < 0 || z >= TZ) continue;
+                                acc[z] = mfma16<F16>(wq[g & 1][tz][p], a[p], acc[z]);
+                            }
+                    } else
 #pragma unroll
                     for (int sum = NS - 1; sum >= 0; --sum)
 #pragma unroll
@@ -712,13 +756,20 @@ int64_t tem_conv_zr_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, i
     return (int64_t)g.nZ * g.nY * g.nX * 4;
 }
 
-template <int NS, bool F16, int MODE, bool KSPLIT = false>
+// tile-order blocks (see decode() in the kernel): up to 4 x 4 x 4 tiles, each extent a divisor of the tile count
+static int zr_tile_blocks(const ZrGeom& g) {
+    if (!tem_option(TEM_OPT_ZR_TILE_BLOCKS)) return 0;
+    auto lg = [](int n) { return n % 4 == 0 ? 2 : (n % 2 == 0 ? 1 : 0); };
+    return lg(g.nX) | (lg(g.nY) << 4) | (lg(g.nZ) << 8);
+}
+
+template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false>
 static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                       const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H, int W,
                       int Cin, int Cout, int act, float* stat, const unsigned* in_amax, hipStream_t s, int ks = 1) {
     constexpr size_t ldsb = (size_t)2 * NS * 1080 * 32 + 4 * 32 * 144;   // two tiles + the epilogue's transpose scratch
     static_assert(ldsb <= 160 * 1024, "LDS budget");
-    auto kern = &k_conv_zr<NS, F16, MODE, KSPLIT>;
+    auto kern = &k_conv_zr<NS, F16, MODE, KSPLIT, WIDE>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
@@ -732,7 +783,8 @@ static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float
     int64_t grid = (g.nunits + 1) / 2;
     if (grid > ncu) grid = ncu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp),
-                       bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits, in_amax, ks);
+                       bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits, in_amax, ks,
+                       zr_tile_blocks(g));
 }
 
 // Split-K launch for shapes zr_geometry() declines only because they have too few (tile, column tile) units: the input
@@ -783,13 +835,16 @@ int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, con
     g.nunits = (int64_t)N * g.nZ * g.nY * g.nX * (Cout / 32) * ks;
     g.ok = 1;
     float* part = (float*)ws;
-#define ZRKS(NS, F16)                                                                                                  \
-    zr_launch<NS, F16, 0, true>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,  \
-                                TEM_ACT_NONE, nullptr, nullptr, s, ks)
-    if (nsplit == 5) ZRKS(1, true);
-    else if (nsplit == 7) ZRKS(1, false);
-    else if (nsplit == 4) ZRKS(2, true);
-    else ZRKS(2, false);
+#define ZRKS(NS, F16, WIDE)                                                                                            \
+    zr_launch<NS, F16, 0, true, WIDE>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,  \
+                                      TEM_ACT_NONE, nullptr, nullptr, s, ks)
+    const bool wide = (nsplit == 5 || nsplit == 7) && (Cin / 16 / ks) % 2 == 0 && tem_option(TEM_OPT_ZR_WIDE);   // slices of whole 32-channel chunks
+    if (nsplit == 5 && wide) ZRKS(2, true, true);
+    else if (nsplit == 7 && wide) ZRKS(2, false, true);
+    else if (nsplit == 5) ZRKS(1, true, false);
+    else if (nsplit == 7) ZRKS(1, false, false);
+    else if (nsplit == 4) ZRKS(2, true, false);
+    else ZRKS(2, false, false);
 #undef ZRKS
     tem_splitk_epilogue(part, ks, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
     return 1;
@@ -819,17 +874,17 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
         }
         return 0;
     }
-#define ZRGO(NS, F16)                                                                                                         \
+#define ZRGO(NS, F16, WIDE)                                                                                                   \
     do {                                                                                                                      \
         if (stat)                                                                                                             \
-            zr_launch<NS, F16, 1>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+            zr_launch<NS, F16, 1, false, WIDE>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
         else if (ref && rcoef)                                                                                                \
-            zr_launch<NS, F16, 3>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act,        \
+            zr_launch<NS, F16, 3, false, WIDE>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act,        \
                                   const_cast<float*>(rcoef), in_amax, s);                                                     \
         else if (ref)                                                                                                         \
-            zr_launch<NS, F16, 2>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+            zr_launch<NS, F16, 2, false, WIDE>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
         else                                                                                                                  \
-            zr_launch<NS, F16, 0>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+            zr_launch<NS, F16, 0, false, WIDE>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
     } while (0)
     const float* rcoef = tem_zr_ref_coef;
     if (rcoef) {
@@ -847,10 +902,14 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
         }
         tem_zr_in_amax = nullptr;   // consumed
     }
-    if (nsplit == 5) ZRGO(1, true);
-    else if (nsplit == 7) ZRGO(1, false);
-    else if (nsplit == 4) ZRGO(2, true);
-    else ZRGO(2, false);
+    // one-term modes: 32 channels per phase whenever the channel count allows it (whole 128-byte lines per staging phase)
+    const bool wide = (nsplit == 5 || nsplit == 7) && Cin % 32 == 0 && tem_option(TEM_OPT_ZR_WIDE);
+    if (nsplit == 5 && wide) ZRGO(2, true, true);
+    else if (nsplit == 7 && wide) ZRGO(2, false, true);
+    else if (nsplit == 5) ZRGO(1, true, false);
+    else if (nsplit == 7) ZRGO(1, false, false);
+    else if (nsplit == 4) ZRGO(2, true, false);
+    else ZRGO(2, false, false);
 #undef ZRGO
     return 1;
 }

@@ -21,6 +21,8 @@ enum {
     TEM_OPT_UPSAMPLE_GENERIC,
     TEM_OPT_TEAM_MIN_UNITS,
     TEM_OPT_ZR_SPLITK,
+    TEM_OPT_ZR_WIDE,
+    TEM_OPT_ZR_TILE_BLOCKS,
     TEM_OPT_COUNT
 };
 long long tem_option(int id);
