@@ -151,9 +151,10 @@ def test_bench_kernel_names_match_committed_profiles():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    traffic = json.load(open(os.path.join(root, "profiles", "r01_traffic_bytes_per_launch.json")))
-    for tag in ("k_conv_fwd_f16x3<3,3,3,NR=1>", "k_conv_fwd_f16x3<3,3,3,NR=2>", "k_conv_fwd_bf16x3<3,3,3,NR=1>",
-                "k_conv_fwd_bf16x3<3,3,3,NR=2>", "k_conv_wgrad_bf16x3<3,3,3,NCO=1>", "k_conv_wgrad_bf16x3<3,3,3,NCO=2>"):
+    traffic = json.load(open(os.path.join(root, "profiles", "r03_traffic_bytes_per_launch.json")))
+    # the kernels that lead the default (fp32-class) step of this round
+    for tag in ("k_conv_zr_f16x3<3,3,3>", "k_conv_zr_bf16x3<3,3,3>", "k_conv_wgrad_bf16x3<3,3,3,NCO=1>",
+                "k_conv_wgrad_bf16x3<3,3,3,NCO=2>"):
         assert mod.RP_NAMES[tag] in traffic, (tag, mod.RP_NAMES[tag])
 
 
