@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--precision", default=None, choices=["fp32", "mixed", "split", "split16", "bf16x3", "amp", "amp_bf16"],
                     help="MFMA conv arithmetic (default: engine default = split16)")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table to this file")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="developer A/B: a dispatch option of the library (include/tem_hip.h, tem_set_option), e.g. zr_wide=0")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -220,6 +222,10 @@ def main():
 
     if args.precision:
         engine.set_precision(args.precision)
+    for kv in args.option:
+        from torch_em_amd import _lib
+        name, _, val = kv.partition("=")
+        _lib.set_option(name, int(val))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     void* ws; CK(hipMalloc(&ws, wsb));
     hipStream_t s = 0;
     auto run = [&]() {
-        int rc = tem_conv_wgrad_bf16x3(x, Cin, sc, sf, g, Cout, dw, db, ws, wsb, N, D, H, W, Cin, Cout, 3, 3, 3, 1, 0, nullptr, nullptr,
+        int rc = tem_conv_wgrad_bf16x3(x, Cin, sc, sf, g, Cout, dw, db, ws, wsb, N, D, H, W, Cin, Cout, 3, 3, 3, 1, getenv("WG_ONE") ? atoi(getenv("WG_ONE")) : 0, nullptr, nullptr,
                                        nullptr, nullptr, s);
         if (rc) { printf("launch failed: %s\n", tem_last_error()); exit(1); }
     };

@@ -1018,6 +1018,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
 #define TEM_ZS_BALANCE 1   // z-sliding wgrad: units 16, 17 cut in halves over waves 0..3 (4.5 units per SIMD instead of 5/5/4/4)
 #endif
 #define ZS_NPL 4
+#ifndef TEM_ZS_L2HIT
+#define TEM_ZS_L2HIT 0   // harness only: loads of all planes hit the first four (L2-resident) planes; wrong results
+#endif
 #define ZS_PLB 320                       // bytes per ci per plane: 10 halo rows x 32 B (16 bf16 slots, 10 used)
 #define ZS_CIS (ZS_NPL * ZS_PLB + 16)    // bytes per ci (padded like the patch kernel: conflict-free b128 reads)
 #define ZS_GS 144                        // bytes per co row of one g plane: 64 bf16 + 16 pad
@@ -1266,7 +1269,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             xa = make_float4(0.f, 0.f, 0.f, 0.f);
             xb = xa;
             if (zxok) {
-                const zs_rsrc_t rsx = zs_rsrc(xn + zx * xplane);
+                const zs_rsrc_t rsx = zs_rsrc(xn + (TEM_ZS_L2HIT ? (zx & 3) : zx) * xplane);   // (harness experiment: every column reads the first planes)
                 if (okxa) xa = zs_load4(rsx, offx, 0);
                 if (okxb) xb = zs_load4(rsx, offxb, 0);
             }
@@ -1274,7 +1277,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
             ga = make_float4(0.f, 0.f, 0.f, 0.f);
             gb = ga;
             if (zg >= za && zg < zb) {
-                const zs_rsrc_t rsg = zs_rsrc(gn + zg * gplane);
+                const zs_rsrc_t rsg = zs_rsrc(gn + (TEM_ZS_L2HIT ? (zg & 3) : zg) * gplane);
                 if (okga) ga = zs_load4(rsg, offg, 0);
                 if (okgb) gb = zs_load4(rsg, offgb, 0);
             }
