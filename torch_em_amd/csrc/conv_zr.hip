@@ -791,7 +791,7 @@ static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float
 // channels are cut into ks slices so that ks x units >= two per CU, the partial sums go to the workspace and the common
 // split-K epilogue (conv_mfma.hip) applies bias / activation / ReLU mask.  -> 1 launched, 0 not taken.
 #ifndef TEM_ZR_KS_FILL
-#define TEM_ZR_KS_FILL 5   // tenths of the tiled volume that must be real voxels for a split-K launch (measured: 8 -> 5: cfg 5 -0.2 ms, cfg 2 -0.04 ms; the 8^3 level is half padding)
+#define TEM_ZR_KS_FILL 4   // tenths of the tiled volume that must be real voxels for a split-K launch (measured: 8 -> 5: cfg 5 -0.2 ms, cfg 2 -0.04 ms, the 8^3 level is half padding; 5 -> 4: cfg 5 25.37 -> 25.04 ms, its 6 x 12 x 12 level is 42 % real; 3: 25.16)
 #endif
 // ks of the split-K launch for this shape (0: not taken): only shapes that zr_geometry() / pp_geometry() decline for
 // their unit count, tiles that are not mostly padding, at least two 16-channel chunks per slice
@@ -808,7 +808,7 @@ int tem_conv_zr_splitk_ks(int N, int D, int H, int W, int Cin, int Cout, int kd,
         if (ncu <= 0) ncu = 256;
     }
     const int nZ = (D + 3) / 4, nY = (H + 15) / 16, nX = (W + 7) / 8;
-    // tiles of 4 x 16 x 8 voxels: at most half of the tiled volume may be padding (an 8^3 level)
+    // tiles of 4 x 16 x 8 voxels: at most 60 % of the tiled volume may be padding (an 8^3 level has 50 %, 6 x 12 x 12 has 58 %)
     if ((int64_t)D * H * W * 10 < (int64_t)nZ * 4 * nY * 16 * nX * 8 * TEM_ZR_KS_FILL) return 0;
     const int64_t units = (int64_t)N * nZ * nY * nX * (Cout / 32);
     const int nch = Cin / 16;
