@@ -41,7 +41,11 @@
 #define TEM_ZR_AD 2      // activation-fragment prefetch depth (LDS reads in flight ahead of the MFMAs that use them)
 #endif
 #ifndef TEM_ZR_ST_AUX
-#define TEM_ZR_ST_AUX 0  // cache policy of the epilogue stores (2 = nt)
+#define TEM_ZR_ST_AUX 2  // cache policy of the epilogue stores: 2 = nt (streaming: the outputs do not push the halo lines that neighbouring
+                         // tiles share out of the XCD's L2; measured 17.02 -> 16.82 ms fp32-class, 9.995 -> 9.89 ms amp; sc1 = 16: 16.84 / 9.94)
+#endif
+#ifndef TEM_ZR_ST_AUX_KS
+#define TEM_ZR_ST_AUX_KS 2  // ... of split-K partial sums (read back at once by tem_splitk_epilogue)
 #endif
 #ifndef TEM_ZR_ABL
 #define TEM_ZR_ABL 0     // harness-only ablations: 1 no halo loads, 2 no stores, 4 no weight loads, 8 no LDS writes, 16 no MFMAs
@@ -63,6 +67,7 @@ __device__ __forceinline__ uint4 zr_load4u(__amdgpu_buffer_rsrc_t r, unsigned vo
     const u32x4z v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+template <int AUX>
 __device__ __forceinline__ void zr_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b, float c, float d) {
     const u32x4z v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
                       __builtin_bit_cast(unsigned, d)};
@@ -72,7 +77,7 @@ __device__ __forceinline__ void zr_store4(__amdgpu_buffer_rsrc_t r, unsigned vof
     // the next row's v_cndmask overwrote the first data register in lanes 12..15 of every row of 16: the MODE 3 epilogue
     // stored the x component of row m + 1 into row m, in 1-99 % of the launches depending on register allocation
     // (scripts/race_zr_store.py; 0 of 1000 with the offset in the VGPR).
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, TEM_ZR_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, AUX);
 }
 
 // value of lane ^ M (M < 32): ds_swizzle in bit mode needs no index register (a __shfl_xor keeps four of them live)
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                             }
                             const bool sok = FULL || (tok_yx & (eu.y0 + 4 * tw + m < H) & (eu.z0 + z < D));
                             if (sok && (!(TEM_ZR_ABL & 2) || t[m].x == 12345.678f))
-                                zr_store4(ry, yoff_l, (zo + (unsigned)(m * W)) * (unsigned)y_ld * 4u, t[m].x, t[m].y, t[m].z, t[m].w);
+                                zr_store4<KSPLIT ? TEM_ZR_ST_AUX_KS : TEM_ZR_ST_AUX>(ry, yoff_l, (zo + (unsigned)(m * W)) * (unsigned)y_ld * 4u, t[m].x, t[m].y, t[m].z, t[m].w);
                         }
                     }
                 };
