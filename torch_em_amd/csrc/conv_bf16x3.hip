@@ -1018,6 +1018,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
 #define TEM_ZS_BALANCE 1   // z-sliding wgrad: units 16, 17 cut in halves over waves 0..3 (4.5 units per SIMD instead of 5/5/4/4)
 #endif
 #define ZS_NPL 4
+#ifndef TEM_ZS_LD_AUX
+#define TEM_ZS_LD_AUX 0   // cache policy of the x / g plane loads (2 = nt: measured +0.03 ms / step, not used)
+#endif
 #ifndef TEM_ZS_L2HIT
 #define TEM_ZS_L2HIT 0   // harness only: loads of all planes hit the first four (L2-resident) planes; wrong results
 #endif
@@ -1032,7 +1035,7 @@ __device__ __forceinline__ zs_rsrc_t zs_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
 __device__ __forceinline__ float4 zs_load4(zs_rsrc_t r, unsigned voff, unsigned soff) {
-    const zs_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const zs_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, TEM_ZS_LD_AUX);
     const zs_f4 f = __builtin_bit_cast(zs_f4, v);   // whole-vector cast (element-wise bit casts get the load narrowed, conv_pp.hip)
     return make_float4(f.x, f.y, f.z, f.w);
 }
