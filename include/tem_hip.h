@@ -180,7 +180,8 @@ int tem_conv3d_fwd_stats(const float* x, int64_t x_ld, const float* scale, const
  * sd_layout != 0: dw is written in the reference's state_dict order [Cout][Cin][kd][kh][kw]
  * (what param.grad needs); 0: tap-major [tap][ci][co] (tem_conv_unpack_wgrad converts).
  * use_mfma: 0 VALU, 1 exact-fp32 MFMA, 2 split-bf16 MFMA (tem_conv3d_fwd), 5 mixed precision (x and g rounded to
- * fp16, one MFMA per product, in the z-sliding 3x3x3 kernel; other shapes run mode 2). */
+ * fp16, one MFMA per product, in the z-sliding 3x3x3 kernel; other shapes run mode 2); 8 (workspace query only) the
+ * fp16 2x1 arithmetic of tem_conv3d_wgrad_gscaled. */
 int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const float* shift,
                      const float* g, int64_t g_ld, float* dw_tap_ci_co, float* db,
@@ -198,6 +199,24 @@ int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* scale, cons
                           float* dw, float* db, float* norm_sums, unsigned* g_amax, void* ws, int64_t ws_bytes,
                           int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma,
                           tem_stream_t stream);
+
+/* Weight gradient (the wgrad half of convolution_backward behind nn.Conv3d, /root/reference/torch_em/model/unet.py:
+ * 429-438) in the "fp16 2x1" arithmetic: xhat = hi + lo in two fp16 terms (16-bit class: xhat is a normalised activation),
+ * g rounded to ONE fp16 term after the power-of-two prescale that puts *g_amax (device word: bit pattern of max |g|, from
+ * tem_absmax or a producer of g) into [2^14, 2^15) -- TWO v_mfma_f32_32x32x16_f16 per product instead of the three of
+ * the split-bf16 mode, fp32 accumulation, the result multiplied by the inverse power (exact).  Every dw entry carries
+ * the random rounding of an 11-bit g: ~2e-4 relative (scripts/backward_arith_sim.py), unbiased.  dw in state_dict
+ * order; w / gamma / beta / norm_sums as in tem_conv3d_wgrad_sums (NULL: plain weight gradient).  Only the z-sliding
+ * 3x3x3 kernel (tem_conv3d_wgrad_gscaled_ok: 3x3x3, D >= 16, Cin, Cout % 32 == 0); workspace tem_conv3d_wgrad_ws(.., 8). */
+int tem_conv3d_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
+int tem_conv3d_wgrad_gscaled(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                             const float* g, int64_t g_ld, const float* w, const float* gamma, const float* beta,
+                             float* dw, float* db, float* norm_sums, const unsigned* g_amax, void* ws, int64_t ws_bytes,
+                             int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, tem_stream_t stream);
+/* *amax = max(*amax, bit pattern of max |x|) over nvox rows of C floats (row stride ld): integer atomicMax, exact and
+ * order-independent; the caller clears the word.  The prescale source of tem_conv3d_wgrad_gscaled / tem_conv3d_fwd_gscaled
+ * when no producer of the tensor delivered it (no reference counterpart: torch.autocast has no per-tensor scale). */
+int tem_absmax(const float* x, int64_t ld, int C, int64_t nvox, unsigned* amax, tem_stream_t stream);
 
 /* Data gradient of nn.Conv3d (the dgrad half of convolution_backward behind model/unet.py:417-438) with fp32-class
  * products on an UNNORMALISED input: tem_conv3d_fwd with use_mfma = 4 (two fp16 terms per operand, 22 mantissa bits)
@@ -409,9 +428,11 @@ int tem_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  * a step (overflow) before the host has enqueued the next one.  The scaler state lives on the device,
  * sstate = [scale, growth_tracker, found_inf, applied_steps]; tem_amp_unscale_dev / tem_amp_update_dev are
  * GradScaler.unscale_ / update on it; tem_adamw_step_tab takes its scalars from row (applied_steps + 1 - lo) of
- * table = [lo, J, -, -] + J x 12 floats (row j = tem_adamw_hyper for step lo + j) and does nothing when found_inf != 0. */
+ * table = [lo, J, -, -] + J x 12 floats (row j = tem_adamw_hyper for step lo + j) and does nothing when found_inf != 0.
+ * A row outside the window (the caller's step count lagged by more than J - 1) is NOT clamped: nothing is updated and
+ * found_inf is set, so the step counts as skipped instead of running with another step's bias corrections. */
 int tem_adamw_step_tab(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                       const float* table, const float* sstate, tem_stream_t stream);
+                       const float* table, float* sstate, tem_stream_t stream);
 int tem_amp_unscale_dev(float* grad, int64_t n, float* sstate, tem_stream_t stream);
 int tem_amp_update_dev(float* sstate, float growth, float backoff, int interval, tem_stream_t stream);
 /* theta_k = m*theta_k + (1-m)*theta_q : SPOCOTrainer._momentum_update (trainer/spoco_trainer.py:45-47) */

@@ -36,11 +36,29 @@ int main(int argc, char** argv) {
     if (wsb2 > wsb) wsb = wsb2;
     void* ws; CK(hipMalloc(&ws, wsb));
     hipStream_t s = 0;
+    int h16 = getenv("WG_ONE") ? atoi(getenv("WG_ONE")) : 0;   // 0 bf16x3, 1 fp16, 2 bf16, 3 fp16 2x1 (prescaled g)
+    unsigned* amax; CK(hipMalloc(&amax, 4)); CK(hipMemset(amax, 0, 4));
+    if (tem_absmax(g, Cout, Cout, (int64_t)V, amax, s)) { printf("absmax failed: %s\n", tem_last_error()); return 1; }
     auto run = [&]() {
-        int rc = tem_conv_wgrad_bf16x3(x, Cin, sc, sf, g, Cout, dw, db, ws, wsb, N, D, H, W, Cin, Cout, 3, 3, 3, 1, getenv("WG_ONE") ? atoi(getenv("WG_ONE")) : 0, nullptr, nullptr,
+        tem_wgrad_gscale_source = h16 == 3 ? amax : nullptr;
+        int rc = tem_conv_wgrad_bf16x3(x, Cin, sc, sf, g, Cout, dw, db, ws, wsb, N, D, H, W, Cin, Cout, 3, 3, 3, 1, h16, nullptr, nullptr,
                                        nullptr, nullptr, s);
+        tem_wgrad_gscale_source = nullptr;
         if (rc) { printf("launch failed: %s\n", tem_last_error()); exit(1); }
     };
+    if (getenv("HARNESS_CHECK_ARITH")) {   // the arithmetic variant WG_ONE against bf16x3 (expected: the rounding of the variant)
+        std::vector<float> a((size_t)Cin * Cout * 27), b(a.size());
+        const int want = h16;
+        tem_set_option("wgrad_zs", 1);
+        h16 = 0; run(); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(a.data(), dw, a.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(dw, 0xff, a.size() * 4));
+        h16 = want; run(); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(b.data(), dw, b.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0, l2d = 0, l2 = 0;
+        for (size_t i = 0; i < a.size(); ++i) { md = fmax(md, fabs((double)a[i] - b[i])); mx = fmax(mx, fabs((double)a[i])); l2d += ((double)a[i] - b[i]) * ((double)a[i] - b[i]); l2 += (double)a[i] * a[i]; }
+        printf("CHECK h16=%d vs bf16x3: max |dw diff| %.3e (max |dw| %.3e), relative L2 %.3e\n", want, md, mx, sqrt(l2d / l2));
+    }
     const int zsopt = argc > 8 ? atoi(argv[8]) : 2;
     if (getenv("HARNESS_CHECK")) {   // the staging-team kernel (wgrad_zs = 2) against the round-2 kernel (1)
         std::vector<float> a((size_t)Cin * Cout * 27), b(a.size()), da(Cout), dbv(Cout);

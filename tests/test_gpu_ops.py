@@ -602,6 +602,82 @@ def test_wgrad_delivers_norm_backward_sums(case):
             float((outs[1][2] - outs[0][2]).abs().max()) < 1e-4 * sa
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 24, 32, 32), (1, 20, 24, 17, 32, 32), (2, 16, 16, 16, 64, 64), (2, 33, 8, 8, 32, 96),
+                                  (1, 16, 132, 136, 32, 32)])
+@pytest.mark.parametrize("gscale", [1.0, 3e-7, 5e4])
+def test_wgrad_fp16_two_by_one_with_device_prescale(case, gscale):
+    """tem_conv3d_wgrad_gscaled (the default weight-gradient arithmetic of the pre-normalised 3x3x3 layers since round 4):
+    x^ in two fp16 terms, g in ONE fp16 term after the power-of-two prescale from max |g| (tem_absmax), two MFMAs per
+    product.  Expected values: the float64 weight gradient of exactly those rounded operands -- only the fp32 summation
+    order differs (2e-5 of max |dw|); against the unrounded float64 gradient the published bound of this arithmetic is
+    1e-3 of max |dw| (measured 1e-4 .. 3e-4: an 11-bit g), and it must NOT be the 1e-5 of three products (that would be a
+    silent fallback to bf16x3)."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout = case
+    k = (3, 3, 3)
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, D, H, W, generator=gen)
+    gy = torch.randn(N, Cout, D, H, W, generator=gen) * gscale
+    scale = torch.rand(N, Cin, generator=gen) + 0.5
+    shift = torch.randn(N, Cin, generator=gen)
+    xn = (x.double() * scale[:, :, None, None, None].double() + shift[:, :, None, None, None].double()).float()
+    hi = xn.half().float()
+    lo = (xn - hi).half().float()
+    e = int(np.floor(np.log2(float(gy.abs().max()))))
+    sc = 2.0 ** (14 - e)
+    gr = (gy * sc).half().double() / sc
+    exp = torch.nn.grad.conv3d_weight(hi.double() + lo.double(), (Cout, Cin, *k), gr, padding=1)
+    exact = torch.nn.grad.conv3d_weight(xn.double(), (Cout, Cin, *k), gy.double(), padding=1)
+    x5, g5 = to5(x), to5(gy)
+    assert ops.conv_wgrad_gscaled_ok(x5, k, Cin, Cout)
+    amax = ops.absmax(g5)
+    assert int(amax.item()) == int(gy.abs().max().view(torch.int32).item())   # bit pattern of max |g|, exact
+    dw = torch.empty(exp.numel(), device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    ops.conv_wgrad_gscaled(x5, g5, k, Cin, Cout, dw, db, amax, scale=scale.to(DEV), shift=shift.to(DEV))
+    got = dw.cpu().view(exp.shape).double()
+    assert rel_err(got, exp) < 2e-5
+    assert 3e-5 < rel_err(got, exact) < 1e-3
+    assert rel_err(db.cpu(), gy.sum((0, 2, 3, 4))) < 5e-5   # the bias gradient sums the unrounded fp32 values
+    # repeated launches are bit-identical (no floating-point atomics)
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad_gscaled(x5, g5, k, Cin, Cout, dw2, db, amax, scale=scale.to(DEV), shift=shift.to(DEV))
+    assert torch.equal(dw, dw2)
+
+
+def test_wgrad_fp16_two_by_one_zero_gradient_and_norm_sums():
+    """all-zero g (max |g| = 0: no prescale) gives zeros; with sums_from the norm-backward sums come out as for bf16x3"""
+    ops = _ops()
+    N, D, H, W, Cin, Cout = 2, 16, 16, 24, 32, 32
+    k = (3, 3, 3)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(N, Cin, D, H, W, generator=gen).double() * 1.5 + 0.3
+    w = (torch.randn(Cout, Cin, *k, generator=gen) * 0.1).double()
+    gout = torch.randn(N, Cout, D, H, W, generator=gen).double() * 1e-5
+    mean = x.mean((2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var((2, 3, 4), unbiased=False) + 1e-5)
+    xn = (x - mean[:, :, None, None, None]) * rstd[:, :, None, None, None]
+    gz = torch.nn.grad.conv3d_input(x.shape, w, gout, padding=1)
+    A_ref, B_ref = gz.sum((2, 3, 4)), (gz * xn).sum((2, 3, 4))
+    scale, shift = rstd.float().to(DEV), (-mean * rstd).float().to(DEV)
+    x5, g5 = to5(x.float()), to5(gout.float())
+    dw = torch.empty(w.numel(), device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    z5 = torch.zeros_like(g5)
+    ops.conv_wgrad_gscaled(x5, z5, k, Cin, Cout, dw, db, ops.absmax(z5), scale=scale, shift=shift)
+    assert float(dw.abs().max()) == 0.0 and float(db.abs().max()) == 0.0
+    if not ops.conv_wgrad_sums_ok(x5, k, Cin, Cout, 2):
+        pytest.skip("the wgrad_sums options exclude this size")
+    sums = ops.conv_wgrad_gscaled(x5, g5, k, Cin, Cout, dw, db, ops.absmax(g5), scale=scale, shift=shift,
+                                  sums_from=(w.float().to(DEV), None, None))
+    A, B = sums[..., 0].cpu().double(), sums[..., 1].cpu().double()
+    sa = float(gz.pow(2).sum((2, 3, 4)).sqrt().max())
+    sb = float((gz * xn).pow(2).sum((2, 3, 4)).sqrt().max())
+    # sum gz comes from the bias gradient (fp32 values); sum gz*xn from dw: the 11-bit g shows here (bound 2e-3 of the term size)
+    assert float((A - A_ref).abs().max()) < 1e-4 * sa, float((A - A_ref).abs().max()) / sa
+    assert float((B - B_ref).abs().max()) < 2e-3 * sb, float((B - B_ref).abs().max()) / sb
+
+
 @pytest.mark.parametrize("case", [((2, 2, 2), (2, 6, 5, 7), 32, 32, 32), ((1, 2, 2), (1, 5, 6, 4), 64, 64, 32),
                                   ((1, 2, 2), (2, 1, 9, 8), 32, 32, 1), ((2, 2, 2), (1, 3, 4, 4), 8, 24, 8)])
 def test_deferred_concat_norm_backward(case):

@@ -677,6 +677,46 @@ def test_graphed_step_equals_eager(tmp_path):
         assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize("mixed", [False, True])
+def test_graph_is_dropped_when_a_checkpoint_is_loaded(tmp_path, mixed):
+    """FusedAdamW.load_state_dict re-homes parameters / moments, GradScaler.load_state_dict rewinds scale and
+    step count -- a HIP graph captured before has the old buffers baked in.  fit -> load_checkpoint -> fit with
+    hip_graph=True must capture a NEW graph and give the trajectory of the eager trainer doing the same."""
+    import torch_em_amd
+    from torch_em_amd.model import UNet3d
+
+    def run(hip_graph):
+        torch.manual_seed(0)
+        m = UNet3d(1, 2, depth=2, initial_features=4)
+        train = torch.utils.data.DataLoader(_batches(4, 0), batch_size=1, shuffle=False)
+        val = torch.utils.data.DataLoader(_batches(2, 1), batch_size=1, shuffle=False)
+        kw = dict(mixed_precision=True, mixed_precision_dtype="float16") if mixed else dict(mixed_precision=False)
+        t = torch_em_amd.default_segmentation_trainer("r%d%d" % (hip_graph, mixed), m, train, val, device=DEV, logger=None,
+                                                      save_root=str(tmp_path), **kw)
+        t.hip_graph = bool(hip_graph)
+        t.fit(iterations=4)
+        first = t._graphed
+        t.save_checkpoint("mid", t.current_metric, t.best_metric)
+        t.fit(iterations=2)                       # moves on to iteration 6 ...
+        t.load_checkpoint("mid")                  # ... and back to the state of iteration 4
+        assert t._iteration == 4 and t._graphed is None
+        t.fit(iterations=4)
+        return t, first
+
+    (t0, _), (t1, g_first) = run(0), run(1)
+    assert g_first is not None and g_first.stale and t1._graphed is not None and t1._graphed is not g_first
+    assert not t1._graphed.stale and t1._graphed.replays == 4
+    with pytest.raises(RuntimeError):
+        g_first(g_first.static_x, g_first.static_y)
+    assert t0._iteration == t1._iteration
+    for (k, a), b in zip(t0.model.state_dict().items(), t1.model.state_dict().values()):
+        assert torch.equal(a, b), k
+    s0, s1 = t0.optimizer.state_dict()["state"], t1.optimizer.state_dict()["state"]
+    assert [int(v["step"]) for v in s0.values()] == [int(v["step"]) for v in s1.values()]
+    if mixed:
+        assert t0.scaler.state_dict() == t1.scaler.state_dict()
+
+
 def test_graphed_mixed_precision_step_with_device_side_loss_scaling():
     """The mixed-precision step (reference `_backprop_mixed`, trainer/default_trainer.py:789-794) as a HIP graph: the
     GradScaler's scale / overflow flag / growth tracker and the count of APPLIED optimizer steps live on the device

@@ -495,7 +495,7 @@ extern "C" int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int 
     int ntaps = kd * kh * kw;
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
     int64_t bytes = tem_align_up(p.db_floats, 64) * 4;
-    if (use_mfma == 2 || use_mfma == 5 || use_mfma == 7) {
+    if (use_mfma == 2 || use_mfma == 5 || use_mfma == 7 || use_mfma == 8) {
         bytes += tem_conv_wgrad_bf16x3_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
     } else if (use_mfma) {
         bytes += tem_conv_wgrad_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
@@ -541,11 +541,13 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
     float* dbpart = (float*)ws;
     float* rest = dbpart + tem_align_up(p.db_floats, 64);
     TEM_REQUIRE(!gcoef || !use_mfma, "tem_conv3d_wgrad_gnorm: use_mfma must be 0");
-    if (use_mfma == 2 || use_mfma == 5 || use_mfma == 7) {
+    if (use_mfma == 2 || use_mfma == 5 || use_mfma == 7 || use_mfma == 8) {
         // 5: single fp16 product in the z-sliding kernel (autocast-equivalent); the other shapes keep bf16x3
+        // 8: fp16 2x1 (tem_conv3d_wgrad_gscaled; z-sliding kernel only)
         int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                        ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
-                                       sd_layout, use_mfma == 5 ? 1 : (use_mfma == 7 ? 2 : 0), w_sd, gamma, beta, norm_sums, s);
+                                       sd_layout, use_mfma == 5 ? 1 : (use_mfma == 7 ? 2 : (use_mfma == 8 ? 3 : 0)), w_sd, gamma,
+                                       beta, norm_sums, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(bf16x3)");
         return TEM_OK;
@@ -617,6 +619,61 @@ extern "C" int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* 
     return rc;
 }
 
+// ---- weight gradient with 16-bit-class x^ and an 11-bit g (two MFMAs per product instead of three) -----------------------
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, int64_t ld, int cq, int64_t nq, unsigned* __restrict__ amax) {
+    // nq = voxels * cq float4 items; max |x| as an integer max of the bit patterns (exact, order-independent; NaN / inf win)
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256) {
+        const int64_t v = i / cq;
+        const int q = (int)(i - v * cq);
+        typedef float f4n __attribute__((ext_vector_type(4)));
+        const f4n t = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(x + v * ld + q * 4));
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t.x), __builtin_fabsf(t.y)),
+                                               __builtin_fmaxf(__builtin_fabsf(t.z), __builtin_fabsf(t.w))));
+    }
+    unsigned u = __builtin_bit_cast(unsigned, m);   // fmaxf drops NaNs: compare as integers from here on
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o, 64));
+    __shared__ unsigned red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = u;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
+extern "C" int tem_absmax(const float* x, int64_t ld, int C, int64_t nvox, unsigned* amax, tem_stream_t stream) {
+    TEM_REQUIRE(x && amax && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && nvox >= 0,
+                "tem_absmax: needs 16-byte aligned rows of C %% 4 == 0 floats");
+    if (nvox == 0) return TEM_OK;
+    const int64_t nq = nvox * (C / 4);
+    int64_t nb = tem_cdiv(nq, 256 * 8);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ld, C / 4, nq, amax);
+    TEM_CHECK_LAUNCH("tem_absmax");
+    return TEM_OK;
+}
+
+extern "C" int tem_conv3d_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    return tem_conv_wgrad_gscaled_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
+}
+
+extern "C" int tem_conv3d_wgrad_gscaled(const float* x, int64_t x_ld, const float* scale, const float* shift,
+                                        const float* g, int64_t g_ld, const float* w, const float* gamma,
+                                        const float* beta, float* dw, float* db, float* norm_sums,
+                                        const unsigned* g_amax, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
+                                        int Cin, int Cout, int kd, int kh, int kw, tem_stream_t stream) {
+    TEM_REQUIRE(g_amax, "tem_conv3d_wgrad_gscaled: null g_amax");
+    TEM_REQUIRE(tem_conv3d_wgrad_gscaled_ok(N, D, H, W, Cin, Cout, kd, kh, kw),
+                "tem_conv3d_wgrad_gscaled: tem_conv3d_wgrad_gscaled_ok() == 0 for this layer");
+    TEM_REQUIRE(!norm_sums || (w && db && tem_conv3d_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw, 8)),
+                "tem_conv3d_wgrad_gscaled: norm_sums needs weights, a bias gradient and tem_conv3d_wgrad_sums_ok() != 0");
+    tem_wgrad_gscale_source = g_amax;
+    const int rc = conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh,
+                                     kw, 8, 1, norm_sums ? w : nullptr, gamma, beta, norm_sums, nullptr, 0, nullptr,
+                                     stream);
+    tem_wgrad_gscale_source = nullptr;
+    return rc;
+}
+
 extern "C" int tem_conv3d_fwd_gscaled(const float* x, int64_t x_ld, const float* w_packed, float* y, int64_t y_ld,
                                       const float* ref, int64_t ref_ld, const unsigned* in_amax, void* ws,
                                       int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh,
@@ -662,7 +719,7 @@ extern "C" int tem_conv3d_fwd_refnorm(const float* x, int64_t x_ld, const float*
 
 extern "C" int tem_conv3d_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                         int use_mfma) {
-    if (use_mfma != 2 && use_mfma != 5 && use_mfma != 7) return 0;
+    if (use_mfma != 2 && use_mfma != 5 && use_mfma != 7 && use_mfma != 8) return 0;
     return tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
 }
 

@@ -1040,17 +1040,32 @@ __device__ __forceinline__ float4 zs_load4(zs_rsrc_t r, unsigned voff, unsigned 
     return make_float4(f.x, f.y, f.z, f.w);
 }
 
-template <int NCO, int ONE = 0>   // ONE: 0 bf16x3 (hi + lo planes), 1 one fp16 term, 2 one bf16 term
+// ONE: 0 bf16x3 (hi + lo planes of both operands, 3 MFMAs per product), 1 one fp16 term, 2 one bf16 term (the mixed
+// precision modes), 3 "fp16 2x1": x^ = hi + lo in two fp16 terms (x^ is a normalised activation: |lo| <= 2^-12 |x^| stays
+// accurate to 2^-25 absolute without a scaled lo plane), g ONE fp16 term after the power-of-two prescale that puts
+// *g_amax into [2^14, 2^15) -- two MFMAs per product (hi * g, lo * g), the result multiplied by the inverse power.
+template <int NCO, int ONE = 0>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restrict__ x, int64_t x_ld,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ g,
                                                           int64_t g_ld, float* __restrict__ part,
                                                           float* __restrict__ dbpart, int N, int D, int H, int W,
                                                           int Cin, int Cout, int T, int nY, int nX, int zsegs,
-                                                          int S, int ncz, unsigned* __restrict__ gmax) {
+                                                          int S, int ncz, unsigned* __restrict__ gmax,
+                                                          const unsigned* __restrict__ g_amax) {
     constexpr int NT = 27, NRG = 9, KW = 3;
     constexpr int KS2 = (NCO == 1) ? 2 : 1;
     constexpr int GC = 32 * NCO;
+    constexpr bool H21 = ONE == 3;        // fp16 2x1
+    float psc = 1.f, pinv = 1.f;
+    if (H21) {
+        // MODE.FP16_OVFL: conversions clamp at +-65504 instead of producing inf (|x^| of a norm output is far below that)
+        __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+        const int e = (int)((*g_amax >> 23) & 0xffu);                       // biased exponent of max |g| (0: all zeros)
+        const int k = e == 0 ? 0 : min(max(141 - e, -100), 100);            // max |g| * 2^k in [2^14, 2^15)
+        psc = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+        pinv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+    }
     constexpr int XPL = 32 * ZS_CIS;       // bytes per (hi|lo) plane set of Xt
     constexpr int GPL = GC * ZS_GS;        // bytes per (hi|lo) g plane
     constexpr int MAXU = 3;                // 18 units over 8 waves
@@ -1178,7 +1193,28 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                     const int prow = 2 * (sl0 + sl) + kh;  // this lane half's patch row (0..7)
                     const int goff = (ct * 32 + r) * ZS_GS + prow * 16;
                     const int xoff = xbase + prow * 32;
-                    if constexpr (ONE != 0) {
+                    if constexpr (H21) {
+                        // x^ two fp16 terms, g one: lo * g first (small products enter the accumulator before the large ones)
+                        const uint4 bh = *reinterpret_cast<const uint4*>(Gh + goff);
+                        const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
+                        const uint4 wl = *reinterpret_cast<const uint4*>(Xl + xoff);
+                        const unsigned wh4 = *reinterpret_cast<const unsigned*>(Xh + xoff + 16);
+                        const unsigned wl4 = *reinterpret_cast<const unsigned*>(Xl + xoff + 16);
+                        uint4 fh[KW], fl[KW];
+                        fh[0] = wh;
+                        fl[0] = wl;
+                        fh[1] = make_uint4(__builtin_amdgcn_alignbyte(wh.y, wh.x, 2), __builtin_amdgcn_alignbyte(wh.z, wh.y, 2),
+                                           __builtin_amdgcn_alignbyte(wh.w, wh.z, 2), __builtin_amdgcn_alignbyte(wh4, wh.w, 2));
+                        fl[1] = make_uint4(__builtin_amdgcn_alignbyte(wl.y, wl.x, 2), __builtin_amdgcn_alignbyte(wl.z, wl.y, 2),
+                                           __builtin_amdgcn_alignbyte(wl.w, wl.z, 2), __builtin_amdgcn_alignbyte(wl4, wl.w, 2));
+                        fh[2] = make_uint4(wh.y, wh.z, wh.w, wh4);
+                        fl[2] = make_uint4(wl.y, wl.z, wl.w, wl4);
+#pragma unroll
+                        for (int tx = 0; tx < KW; ++tx) acc[i][tx] = mfma16<true>(fl[tx], bh, acc[i][tx]);
+#pragma unroll
+                        for (int tx = 0; tx < KW; ++tx) acc[i][tx] = mfma16<true>(fh[tx], bh, acc[i][tx]);
+                        continue;
+                    } else if constexpr (ONE != 0) {
                         // single fp16 product (the autocast-equivalent mode): hi planes only
                         const uint4 bh = *reinterpret_cast<const uint4*>(Gh + goff);
                         const uint4 wh = *reinterpret_cast<const uint4*>(Xh + xoff);
@@ -1229,7 +1265,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
                 const float va = inA ? fmaf(a[c], s4[c], f4[c]) : 0.f;
                 const float vb = inB ? fmaf(b[c], s4[c], f4[c]) : 0.f;
                 const int off = (xcq * 4 + c) * ZS_CIS + sl + xrow * 32 + xpr * 4;
-                if constexpr (ONE != 0) {
+                if constexpr (H21) {
+                    const unsigned hi = pk16<true>(va, vb);
+                    *reinterpret_cast<unsigned*>(Xh + off) = hi;
+                    *reinterpret_cast<unsigned*>(Xl + off) = pk16<true>(va - lo16<true>(hi), vb - hi16<true>(hi));
+                } else if constexpr (ONE != 0) {
                     *reinterpret_cast<unsigned*>(Xh + off) = pk16<ONE == 1>(va, vb);
                 } else {
                     unsigned hi, lo;
@@ -1246,7 +1286,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int off = (gcq * 4 + c) * ZS_GS + (gprow * 8 + gpr * 2) * 2;
-                if constexpr (ONE != 0) {
+                if constexpr (H21) {
+                    *reinterpret_cast<unsigned*>(Gh + off) = pk16<true>(a[c] * psc, b[c] * psc);
+                } else if constexpr (ONE != 0) {
                     *reinterpret_cast<unsigned*>(Gh + off) = pk16<ONE == 1>(a[c], b[c]);
                 } else {
                     unsigned hi, lo;
@@ -1344,7 +1386,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_zs(const float* __restric
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                        dst[(int64_t)row * Cout] = acc[i][tx][reg];
+                        dst[(int64_t)row * Cout] = H21 ? acc[i][tx][reg] * pinv : acc[i][tx][reg];
                     }
                 }
             }
@@ -1375,7 +1417,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_zt(const float* __restric
                                                           int64_t g_ld, float* __restrict__ part,
                                                           float* __restrict__ dbpart, int N, int D, int H, int W,
                                                           int Cin, int Cout, int T, int nY, int nX, int zsegs,
-                                                          int S, int ncz, unsigned* __restrict__ gmax) {
+                                                          int S, int ncz, unsigned* __restrict__ gmax,
+                                                          const unsigned* __restrict__ /* g_amax: k_conv_wgrad_zs<., 3> only */) {
     constexpr int NT = 27, KW = 3, NA = 7;   // accumulators per multiplying wave
     constexpr int GC = 32;
     constexpr int XPL = 32 * ZS_CIS;       // bytes per (hi|lo) plane set of Xt
@@ -1792,6 +1835,12 @@ static void launch_wb(const float* x, int64_t x_ld, const float* scale, const fl
 // tem_conv3d_wgrad_gmax (conv.hip) parks its output pointer here around its call into tem_conv_wgrad_bf16x3: one more
 // positional argument would have to thread through four internal signatures for the one kernel that honours it
 thread_local unsigned* tem_wgrad_gmax_target = nullptr;
+// tem_conv3d_wgrad_gscaled (conv.hip) parks the device word with max |g| here the same way (h16 == 3 reads it)
+thread_local const unsigned* tem_wgrad_gscale_source = nullptr;
+int tem_conv_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
+    return Cin % 32 == 0 && Cout % 32 == 0 && z.use && !z.teams;
+}
 int tem_conv_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     return Cin % 32 == 0 && Cout % 32 == 0 && zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw).use;
 }
@@ -1815,6 +1864,9 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
     unsigned* const gmax = tem_wgrad_gmax_target;   // set by tem_conv3d_wgrad_gmax for the duration of this call
     TEM_REQUIRE(!gmax || (z.use && !h16), "tem_conv3d_wgrad_gmax: tem_conv3d_wgrad_gmax_ok() == 0 for this layer");
+    const unsigned* const g_amax = tem_wgrad_gscale_source;   // set by tem_conv3d_wgrad_gscaled for the duration of this call
+    TEM_REQUIRE(h16 != 3 || (g_amax && z.use && !z.teams),
+                "tem_conv3d_wgrad_gscaled: tem_conv3d_wgrad_gscaled_ok() == 0 for this layer (or no g_amax)");
     if (z.use) {
         TEM_REQUIRE((int64_t)H * W * (x_ld > g_ld ? x_ld : g_ld) * 4 < (1ll << 31),
                     "tem_conv3d_wgrad(bf16x3): one z-plane of x / g must stay below 2 GiB (32-bit offsets inside a plane)");
@@ -1832,20 +1884,22 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
                 sized.insert(key);
             }
             hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb, N, D, H, W, Cin,
-                               Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax);
+                               Cout, z.T, z.nY, z.nX, z.zsegs, z.Ss, z.ncz, gmax, g_amax);
         };
-        auto go = [&](auto k0, auto k1, auto k2, size_t lb) {
+        auto go = [&](auto k0, auto k1, auto k2, auto k3, size_t lb) {
             if (h16 == 1) launch(k1, lb);
             else if (h16 == 2) launch(k2, lb);
+            else if (h16 == 3) launch(k3, lb);
             else launch(k0, lb);
         };
         if (z.teams)
-            go(&k_conv_wgrad_zt<0>, &k_conv_wgrad_zt<1>, &k_conv_wgrad_zt<2>, 2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS);
+            go(&k_conv_wgrad_zt<0>, &k_conv_wgrad_zt<1>, &k_conv_wgrad_zt<2>, &k_conv_wgrad_zt<0>,
+               2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS);
         else if (z.nco == 2)
-            go(&k_conv_wgrad_zs<2, 0>, &k_conv_wgrad_zs<2, 1>, &k_conv_wgrad_zs<2, 2>,
+            go(&k_conv_wgrad_zs<2, 0>, &k_conv_wgrad_zs<2, 1>, &k_conv_wgrad_zs<2, 2>, &k_conv_wgrad_zs<2, 3>,
                2 * (size_t)32 * ZS_CIS + 4 * (size_t)64 * ZS_GS);
         else
-            go(&k_conv_wgrad_zs<1, 0>, &k_conv_wgrad_zs<1, 1>, &k_conv_wgrad_zs<1, 2>,
+            go(&k_conv_wgrad_zs<1, 0>, &k_conv_wgrad_zs<1, 1>, &k_conv_wgrad_zs<1, 2>, &k_conv_wgrad_zs<1, 3>,
                2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS);
         if (norm_sums) {
             float* extra = zdb + tem_align_up((int64_t)z.S * Cout, 64);

@@ -115,11 +115,18 @@ __global__ __launch_bounds__(256) void k_adamw_dev(float* __restrict__ p, const 
 // as tem_adamw_hyper fills it), and the kernel takes row applied_steps + 1 - lo.  found_inf != 0: no update.
 __global__ __launch_bounds__(256) void k_adamw_tab(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   const float* __restrict__ table, const float* __restrict__ sstate) {
+                                                   const float* __restrict__ table, float* __restrict__ sstate) {
     if (sstate[2] != 0.f) return;
     const int lo = (int)table[0], J = (int)table[1];
-    int row = (int)sstate[3] + 1 - lo;
-    row = row < 0 ? 0 : row >= J ? J - 1 : row;
+    const int row = (int)sstate[3] + 1 - lo;
+    if (row < 0 || row >= J) {
+        // The host's lower bound of the applied-step count is older than the window it uploaded (it must never be: the
+        // owner of the graph bounds its lead, torch_em_amd/graph.py READBACK_SLOTS < TABLE_ROWS - 1).  Applying the bias
+        // corrections of another step number would be silently wrong, so NO workgroup updates anything (all of them take
+        // this branch: same inputs) and the step is reported like an overflow: skipped, visible in the scaler's state.
+        if (blockIdx.x == 0 && threadIdx.x == 0) sstate[2] = 1.f;
+        return;
+    }
     const float* hyper = table + 4 + 12 * row;
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step_size = hyper[5],
                 inv_sqrt_bc2 = hyper[6], gscale = hyper[7];
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void k_adamw_tab(float* __restrict__ p, const 
 }
 
 extern "C" int tem_adamw_step_tab(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                  const float* table, const float* sstate, tem_stream_t stream) {
+                                  const float* table, float* sstate, tem_stream_t stream) {
     TEM_REQUIRE(param && grad && exp_avg && exp_avg_sq && table && sstate && n > 0, "tem_adamw_step_tab: bad arguments");
     TEM_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) &&
                     ((uintptr_t)exp_avg_sq % 16 == 0),

@@ -22,6 +22,18 @@ from . import ops
 from .optim import FusedAdamW
 
 
+def cumulative_average_norm(model):
+    """A norm layer with running statistics and momentum=None averages them over `num_batches_tracked`, which the engine
+    reads on the HOST (engine._update_running): inside a capture that value would be frozen into the graph.  Returns
+    the reason string for such a model, else None."""
+    for name, mod in model.named_modules():
+        if getattr(mod, "track_running_stats", False) and getattr(mod, "running_mean", None) is not None and \
+                getattr(mod, "momentum", 0.1) is None:
+            return (f"{name or type(mod).__name__}: running statistics with momentum=None (cumulative average) need the "
+                    "batch counter on the host each step")
+    return None
+
+
 class GraphedTrainStep:
     READBACK_SLOTS = 8   # < FusedAdamW.TABLE_ROWS - 1: the host runs at most this many replays ahead of what it knows
 
@@ -35,12 +47,19 @@ class GraphedTrainStep:
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
                 torch.distributed.get_world_size() > 1:
             raise NotImplementedError("GraphedTrainStep: the gradient all-reduce of multi-GPU training is not captured")
+        why = cumulative_average_norm(model)
+        if why is not None:
+            raise NotImplementedError("GraphedTrainStep: " + why)
         self.model, self.loss_fn, self.optimizer, self.precision = model, loss_fn, optimizer, precision
         self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.stale = False   # set when optimizer / scaler state is loaded: the captured pointers and counts are then wrong
         self.static_x, self.static_y = x.clone(), y.clone()
         self.scaler = scaler if (scaler is not None and scaler.is_enabled()) else None
         optimizer._ensure_arena()
         if self.scaler is not None:
+            # the host may enqueue READBACK_SLOTS replays beyond the newest step count it has read back; the window of
+            # optimizer rows it uploads must cover that lead (tem_adamw_step_tab refuses rows outside the window)
+            assert self.READBACK_SLOTS < FusedAdamW.TABLE_ROWS - 1
             step0 = {int(optimizer.state[p]["step"].item()) for p in optimizer._arena.params}
             if len(step0) != 1:
                 raise RuntimeError("GraphedTrainStep: the parameters must share one optimizer step count")
@@ -55,11 +74,15 @@ class GraphedTrainStep:
             optimizer.capturable(True)
         # Warm-up on a side stream (workspaces, gradient arena, packed-weight buffers and the allocator reach their
         # steady state), as torch's capture recipe asks -- but without consuming training steps: parameters, moments and
-        # step counts are restored afterwards, so building the graph leaves the training state untouched.
+        # step counts are restored afterwards, so building the graph leaves the training state untouched
         ar = optimizer._arena
         saved = (ar.flat.clone(), optimizer._m.clone(), optimizer._v.clone(),
                  [optimizer.state[p]["step"].clone() for p in ar.params],
                  self.sstate.clone() if self.scaler is not None else None)
+        # ... nor anything else a step advances: module buffers (BatchNorm / InstanceNormTrackStats running statistics and
+        # their batch counters) and the device's random-number state
+        buffers = [(b, b.detach().clone()) for b in model.buffers()]
+        rng_state = torch.cuda.get_rng_state(x.device)
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(side):
@@ -73,6 +96,10 @@ class GraphedTrainStep:
         torch.cuda.current_stream(x.device).wait_stream(side)
         for p, st in zip(ar.params, saved[3]):
             optimizer.state[p]["step"].copy_(st)
+        with torch.no_grad():
+            for b, old in buffers:
+                b.copy_(old)
+        torch.cuda.set_rng_state(rng_state, x.device)
         ops.bump_versions(self.params)
         from .model import engine
         with self._scope():
@@ -90,6 +117,19 @@ class GraphedTrainStep:
                            getattr(self.params[0], "_tem_grad_flat", None), ar.flat, optimizer._m, optimizer._v,
                            optimizer._hyper, optimizer._table]
         self.replays = 0
+        # optimizer.load_state_dict / scaler.load_state_dict re-home the buffers this graph has baked in
+        import weakref
+        ref = weakref.ref(self)
+
+        def _invalidate():
+            me = ref()
+            if me is not None:
+                me.stale = True
+        for owner in (optimizer, self.scaler):
+            if owner is not None:
+                if not hasattr(owner, "_invalidate_hooks"):
+                    owner._invalidate_hooks = []
+                owner._invalidate_hooks.append(_invalidate)
 
     def _scope(self):
         if self.precision is None:
@@ -134,6 +174,9 @@ class GraphedTrainStep:
     def __call__(self, x, y):
         """One optimisation step on (x, y).  Returns (prediction, loss): the graph's own output buffers, overwritten by
         the next call."""
+        if self.stale:
+            raise RuntimeError("GraphedTrainStep: optimizer or GradScaler state was loaded after the capture; the graph "
+                               "still points at the old parameter / moment buffers -- capture a new one")
         if not self.matches(x, y):
             raise ValueError(f"GraphedTrainStep was captured for x{tuple(self.static_x.shape)} / "
                              f"y{tuple(self.static_y.shape)}; got x{tuple(x.shape)} / y{tuple(y.shape)}")

@@ -26,6 +26,12 @@ def check_consecutive(labels: torch.Tensor) -> bool:
 class _ContrastiveFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb, target, delta_var, delta_dist, alpha, beta, gamma):
+        # one stream handle serves every launch below: the embeddings' device stays current throughout
+        with torch.cuda.device(emb.device if emb.is_cuda else None):
+            return _ContrastiveFunction._forward(ctx, emb, target, delta_var, delta_dist, alpha, beta, gamma)
+
+    @staticmethod
+    def _forward(ctx, emb, target, delta_var, delta_dist, alpha, beta, gamma):
         e_all = _sp._prep(emb.detach())
         N, E = e_all.shape[0], e_all.shape[1]
         spatial = tuple(e_all.shape[2:])

@@ -86,12 +86,13 @@ def compute_cluster_means(embeddings: torch.Tensor, target: torch.Tensor, n_inst
     e = _prep(embeddings.detach())
     lbl = target.to(torch.int64).contiguous()
     E, V = e.shape[0], lbl.numel()
-    ctx = _Ctx(e, n_instances, E, V, 1, 0, 0)
-    rng = _label_stats(lbl, ctx.lib, ctx.stream, ctx.ws).tolist()
-    assert rng[0] == 0, "The target min value has to be zero, otherwise this will lead to errors in scatter."
-    if rng[1] >= n_instances:
-        raise ValueError(f"target contains label {rng[1]} but n_instances is {n_instances}")
-    return _cluster_means(ctx, e, V, lbl, V, E, n_instances)[0]
+    with torch.cuda.device(e.device):   # the stream handle of _Ctx is used for two launches
+        ctx = _Ctx(e, n_instances, E, V, 1, 0, 0)
+        rng = _label_stats(lbl, ctx.lib, ctx.stream, ctx.ws).tolist()
+        assert rng[0] == 0, "The target min value has to be zero, otherwise this will lead to errors in scatter."
+        if rng[1] >= n_instances:
+            raise ValueError(f"target contains label {rng[1]} but n_instances is {n_instances}")
+        return _cluster_means(ctx, e, V, lbl, V, E, n_instances)[0]
 
 
 class GaussianKernel(nn.Module):
@@ -134,7 +135,10 @@ class _SpocoFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb_q, emb_k, target, cfg):
         need_grad = emb_q.requires_grad
-        value, grad = _evaluate(emb_q.detach(), None if emb_k is None else emb_k.detach(), target, cfg, need_grad)
+        # one stream handle serves all launches of the evaluation: the embeddings' device stays current for its whole
+        # duration (ops._stream() alone holds it only until the first _lib.check())
+        with torch.cuda.device(emb_q.device):
+            value, grad = _evaluate(emb_q.detach(), None if emb_k is None else emb_k.detach(), target, cfg, need_grad)
         ctx.grad = grad
         return value
 
@@ -386,19 +390,20 @@ class _ConsistencyFunction(torch.autograd.Function):
         N, E = q.shape[0], q.shape[1]
         nz, D, H, W = _geom(tuple(q.shape[2:]))
         V = D * H * W
-        c = _Ctx(q, 1, E, V, nz, max_anchors, 0)
         need = emb_q.requires_grad
         grad = torch.zeros_like(q) if need else None
         vals = torch.zeros(N, dtype=torch.float32, device=q.device)
-        p, n = c.wsp()
-        for b in range(N):
-            # the reference's mask is all ones (:598), so the rank IS the flat voxel index
-            idx = torch.tensor([int(np.random.randint(V)) for _ in range(max_anchors)], dtype=torch.int64,
-                               device=q.device)
-            _lib.check(c.lib.tem_spoco_consistency(
-                ops._p(q[b]), ops._p(k[b]), V, V, nz, E, ops._p(idx), max_anchors, float(two_sigma), 1e-7,
-                ctypes.c_void_p(vals.data_ptr() + 4 * b), 1.0, ops._p(grad[b]) if need else None, V, p, n, c.stream),
-                "tem_spoco_consistency")
+        with torch.cuda.device(q.device):   # c.stream serves N launches: keep q's device current for all of them
+            c = _Ctx(q, 1, E, V, nz, max_anchors, 0)
+            p, n = c.wsp()
+            for b in range(N):
+                # the reference's mask is all ones (:598), so the rank IS the flat voxel index
+                idx = torch.tensor([int(np.random.randint(V)) for _ in range(max_anchors)], dtype=torch.int64,
+                                   device=q.device)
+                _lib.check(c.lib.tem_spoco_consistency(
+                    ops._p(q[b]), ops._p(k[b]), V, V, nz, E, ops._p(idx), max_anchors, float(two_sigma), 1e-7,
+                    ctypes.c_void_p(vals.data_ptr() + 4 * b), 1.0, ops._p(grad[b]) if need else None, V, p, n, c.stream),
+                    "tem_spoco_consistency")
         ctx.grad = grad
         return vals.sum()
 

@@ -38,9 +38,9 @@ def _fwd_tag(mfma, k, cout, pp=False):
 def _wgrad_tag(mfma, k, cout):
     ntaps = k[0] * k[1] * k[2]
     return ("k_conv_wgrad_bf16x3" if int(mfma) == 2 else "k_conv_wgrad_f16" if int(mfma) == 5 else
-            "k_conv_wgrad_bf16" if int(mfma) == 7 else
+            "k_conv_wgrad_bf16" if int(mfma) == 7 else "k_conv_wgrad_f16x2" if int(mfma) == 8 else
             "k_conv_wgrad_mfma" if mfma else "k_conv_wgrad_valu") + \
-        f"<{k[0]},{k[1]},{k[2]}" + (f",NCO={2 if cout >= 64 else 1}" if int(mfma) in (2, 5, 7) and ntaps > 1 else "") + ">(+reduce)"
+        f"<{k[0]},{k[1]},{k[2]}" + (f",NCO={2 if cout >= 64 else 1}" if int(mfma) in (2, 5, 7, 8) and ntaps > 1 else "") + ">(+reduce)"
 
 
 def _prof_begin(t, tag=None):
@@ -336,6 +336,46 @@ def conv_wgrad_gmax(x, g, k, cin, cout, dw_out, db_out, gmax, scale=None, shift=
     _lib.check(lib.tem_conv3d_wgrad_gmax(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w), _p(gamma), _p(beta),
                                          _p(dw_out), _p(db_out), _p(sums), _p(gmax), _p(ws), nws, N, D, H, W, cin, cout,
                                          k[0], k[1], k[2], int(mfma), _stream(x)), "tem_conv3d_wgrad_gmax")
+    if ev0 is not None:
+        _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
+    return sums
+
+
+def conv_wgrad_gscaled_ok(x, k, cin, cout) -> bool:
+    N, D, H, W, _, _ = _act5(x)
+    return bool(_lib.load().tem_conv3d_wgrad_gscaled_ok(N, D, H, W, cin, cout, k[0], k[1], k[2]))
+
+
+def absmax(x, amax=None):
+    """bit pattern of max |x| of an activation tensor [N, D, H, W, C(ld)] -> int32[1] on the device (tem_absmax);
+    `amax` (cleared by the caller) accumulates when given."""
+    _req_cuda(x)
+    N, D, H, W, C, ld = _act5(x)
+    if amax is None:
+        amax = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.load().tem_absmax(_p(x), ld, C, N * D * H * W, _p(amax), _stream(x)), "tem_absmax")
+    return amax
+
+
+def conv_wgrad_gscaled(x, g, k, cin, cout, dw_out, db_out, amax, scale=None, shift=None, sums_from=None):
+    """Weight gradient in the fp16 2x1 arithmetic (tem_conv3d_wgrad_gscaled): x^ two fp16 terms, g one fp16 term prescaled
+    from amax = int32[1] with the bit pattern of max |g| (absmax or a producer of g).  sums_from as in conv_wgrad."""
+    _req_cuda(x, g, dw_out, amax)
+    N, D, H, W, C, x_ld = _act5(x)
+    g_ld = _act5(g)[5]
+    lib = _lib.load()
+    nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 8)
+    ws = _workspace(nws, x.device)
+    w = gamma = beta = sums = None
+    if sums_from is not None:
+        w, gamma, beta = sums_from
+        w = w.detach()
+        sums = torch.empty((N, cin, 2), dtype=torch.float32, device=x.device)
+    kind = _wgrad_tag(8, k, cout) if PROFILER is not None else None
+    ev0 = _prof_begin(x, kind)
+    _lib.check(lib.tem_conv3d_wgrad_gscaled(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w), _p(gamma), _p(beta),
+                                            _p(dw_out), _p(db_out), _p(sums), _p(amax), _p(ws), nws, N, D, H, W, cin, cout,
+                                            k[0], k[1], k[2], _stream(x)), "tem_conv3d_wgrad_gscaled")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return sums

@@ -128,8 +128,16 @@ class FusedAdamW(torch.optim.Optimizer):
             self.state[p] = {"step": step.clone().float().cpu(), "exp_avg": m, "exp_avg_sq": v}
 
     def load_state_dict(self, state_dict):
+        """A captured step (torch_em_amd/graph.py) has the OLD arena / moment / scalar buffers baked in: loading a state
+        re-homes them, so the capture-mode buffers are dropped here and every registered owner of a graph is told
+        (GraphedTrainStep marks itself stale and the trainer captures a new one on the next step)."""
         super().load_state_dict(state_dict)
         self._arena = None  # re-home the loaded moments into arenas on the next step
+        self._hyper = self._hyper_host = self._table = self._sstate = None
+        self._pre_state_dict = None
+        hooks, self._invalidate_hooks = getattr(self, "_invalidate_hooks", []), []
+        for h in hooks:
+            h()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -342,5 +350,9 @@ class GradScaler:
         self._scale = float(state_dict["scale"])
         self._growth_factor, self._backoff_factor = state_dict["growth_factor"], state_dict["backoff_factor"]
         self._growth_interval, self._growth_tracker = state_dict["growth_interval"], state_dict["_growth_tracker"]
-        if self._sstate is not None:
-            self._sstate[0], self._sstate[1] = self._scale, float(self._growth_tracker)
+        # a device-side copy of the state belongs to a captured step whose optimizer step count no longer matches what a
+        # checkpoint restores: drop it and tell the owner of the graph (it re-captures with the loaded values)
+        self._sstate = None
+        hooks, self._invalidate_hooks = getattr(self, "_invalidate_hooks", []), []
+        for h in hooks:
+            h()

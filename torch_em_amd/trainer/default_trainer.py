@@ -268,6 +268,7 @@ class DefaultTrainer:
                             for k, v in save_dict["model_state"].items())
         self.model.load_state_dict(state)
         self.model.to(self.device)
+        self._graphed = None   # a captured step points at the buffers the next line re-homes (it also marks itself stale)
         self.optimizer.load_state_dict(save_dict["optimizer_state"])
         if self.lr_scheduler is not None and "scheduler_state" in save_dict:
             self.lr_scheduler.load_state_dict(save_dict["scheduler_state"])
@@ -430,6 +431,8 @@ class DefaultTrainer:
     def _graphed_step(self, x, y):
         """The captured step for this batch shape, or None (with the reason in self._graph_why) when it must run eagerly."""
         g = self._graphed
+        if g is not None and g.stale:   # load_checkpoint / load_state_dict since the capture: capture again
+            g = self._graphed = None
         if g is not None and g.matches(x, y):
             return g
         from ..graph import GraphedTrainStep
@@ -444,6 +447,9 @@ class DefaultTrainer:
             why = "multi-GPU gradient all-reduce"
         elif g is not None:
             why = "batch shape changed (the graph is captured for one shape)"
+        else:
+            from ..graph import cumulative_average_norm
+            why = cumulative_average_norm(self.model)
         self._graph_why = why
         if why is not None:
             return None
