@@ -602,10 +602,61 @@ def test_wgrad_delivers_norm_backward_sums(case):
             float((outs[1][2] - outs[0][2]).abs().max()) < 1e-4 * sa
 
 
+@pytest.fixture
+def wgrad_kernel_option():
+    """option "wgrad_zs": 1 k_conv_wgrad_zs, 2 k_conv_wgrad_zt, 3 k_conv_wgrad_tr (transposing LDS reads)"""
+    from torch_em_amd import _lib
+    old = _lib.get_option("wgrad_zs")
+    yield lambda v: _lib.set_option("wgrad_zs", v)
+    _lib.set_option("wgrad_zs", old)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("mode", [2, 5, 7])
+@pytest.mark.parametrize("case", [(2, 16, 16, 24, 32, 32), (1, 20, 24, 17, 32, 32), (2, 16, 16, 16, 64, 64), (2, 33, 8, 8, 32, 96),
+                                  (1, 16, 132, 136, 32, 32), (3, 17, 9, 10, 64, 32)])
+def test_wgrad_z_sliding_kernels_agree_with_float64(case, mode, kernel, wgrad_kernel_option):
+    """Every z-sliding weight-gradient kernel (round 2: k_conv_wgrad_zs, round 3: _zt with a staging team, round 4: _tr with
+    voxel-major LDS records and ds_read_b64_tr_b16 fragment reads) in the bf16x3 / one-term fp16 / one-term bf16 modes against
+    the float64 weight gradient of the operands rounded as the mode rounds them (only the summation order differs)."""
+    ops = _ops()
+    wgrad_kernel_option(kernel)
+    N, D, H, W, Cin, Cout = case
+    k = (3, 3, 3)
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(N, Cin, D, H, W, generator=gen)
+    gy = torch.randn(N, Cout, D, H, W, generator=gen)
+    scale = torch.rand(N, Cin, generator=gen) + 0.5
+    shift = torch.randn(N, Cin, generator=gen)
+    xn = (x.double() * scale[:, :, None, None, None].double() + shift[:, :, None, None, None].double()).float()
+    if mode == 2:
+        def r2(t):
+            hi = t.bfloat16().float()
+            return hi.double() + (t - hi).bfloat16().double()
+        xh, gh = r2(xn), r2(gy)
+        exp = torch.nn.grad.conv3d_weight(xh, (Cout, Cin, *k), gh, padding=1) - \
+            torch.nn.grad.conv3d_weight(xh - xn.bfloat16().double(), (Cout, Cin, *k), gh - gy.bfloat16().double(), padding=1)  # no lo*lo
+        tol = 2e-5
+    else:
+        r16 = (lambda t: t.half().double()) if mode == 5 else (lambda t: t.bfloat16().double())
+        exp = torch.nn.grad.conv3d_weight(r16(xn), (Cout, Cin, *k), r16(gy), padding=1)
+        tol = 2e-5
+    x5, g5 = to5(x), to5(gy)
+    dw = torch.empty(exp.numel(), device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale.to(DEV), shift=shift.to(DEV), mfma=mode)
+    assert rel_err(dw.cpu().view(exp.shape), exp) < tol
+    assert rel_err(db.cpu(), gy.sum((0, 2, 3, 4))) < 5e-5
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(x5, g5, k, Cin, Cout, dw2, db, scale=scale.to(DEV), shift=shift.to(DEV), mfma=mode)
+    assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("kernel", [1, 3])
 @pytest.mark.parametrize("case", [(2, 16, 16, 24, 32, 32), (1, 20, 24, 17, 32, 32), (2, 16, 16, 16, 64, 64), (2, 33, 8, 8, 32, 96),
                                   (1, 16, 132, 136, 32, 32)])
 @pytest.mark.parametrize("gscale", [1.0, 3e-7, 5e4])
-def test_wgrad_fp16_two_by_one_with_device_prescale(case, gscale):
+def test_wgrad_fp16_two_by_one_with_device_prescale(case, gscale, kernel, wgrad_kernel_option):
     """tem_conv3d_wgrad_gscaled (the default weight-gradient arithmetic of the pre-normalised 3x3x3 layers since round 4):
     x^ in two fp16 terms, g in ONE fp16 term after the power-of-two prescale from max |g| (tem_absmax), two MFMAs per
     product.  Expected values: the float64 weight gradient of exactly those rounded operands -- only the fp32 summation
@@ -613,6 +664,7 @@ def test_wgrad_fp16_two_by_one_with_device_prescale(case, gscale):
     1e-3 of max |dw| (measured 1e-4 .. 3e-4: an 11-bit g), and it must NOT be the 1e-5 of three products (that would be a
     silent fallback to bf16x3)."""
     ops = _ops()
+    wgrad_kernel_option(kernel)
     N, D, H, W, Cin, Cout = case
     k = (3, 3, 3)
     gen = torch.Generator().manual_seed(11)

@@ -1717,6 +1717,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_zt(const float* __restric
 struct ZsPlan {
     bool use;
     bool teams;   // k_conv_wgrad_zt (staging team) instead of k_conv_wgrad_zs
+    bool tr;      // k_conv_wgrad_tr (conv_wgrad_tr.hip: staging team + transposing LDS reads); same plan as `teams`
     int nco, ks2, T, nY, nX, zsegs, S, Ss, ncz;
 };
 static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
@@ -1725,6 +1726,7 @@ static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int
     p.use = enable && kd == 3 && kh == 3 && kw == 3 && D >= 16;
     const int ncot = Cout / 32;
     p.teams = enable >= 2;
+    p.tr = enable >= 3;
     p.nco = (ncot >= 2 && !p.teams) ? 2 : 1;
     p.ks2 = (p.nco == 1 && !p.teams) ? 2 : 1;
     p.T = (Cin / 32) * ((ncot + p.nco - 1) / p.nco);
@@ -1839,7 +1841,7 @@ thread_local unsigned* tem_wgrad_gmax_target = nullptr;
 thread_local const unsigned* tem_wgrad_gscale_source = nullptr;
 int tem_conv_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
-    return Cin % 32 == 0 && Cout % 32 == 0 && z.use && !z.teams;
+    return Cin % 32 == 0 && Cout % 32 == 0 && z.use && (!z.teams || z.tr);
 }
 int tem_conv_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     return Cin % 32 == 0 && Cout % 32 == 0 && zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw).use;
@@ -1865,7 +1867,7 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
     unsigned* const gmax = tem_wgrad_gmax_target;   // set by tem_conv3d_wgrad_gmax for the duration of this call
     TEM_REQUIRE(!gmax || (z.use && !h16), "tem_conv3d_wgrad_gmax: tem_conv3d_wgrad_gmax_ok() == 0 for this layer");
     const unsigned* const g_amax = tem_wgrad_gscale_source;   // set by tem_conv3d_wgrad_gscaled for the duration of this call
-    TEM_REQUIRE(h16 != 3 || (g_amax && z.use && !z.teams),
+    TEM_REQUIRE(h16 != 3 || (g_amax && z.use && (!z.teams || z.tr)),
                 "tem_conv3d_wgrad_gscaled: tem_conv3d_wgrad_gscaled_ok() == 0 for this layer (or no g_amax)");
     if (z.use) {
         TEM_REQUIRE((int64_t)H * W * (x_ld > g_ld ? x_ld : g_ld) * 4 < (1ll << 31),
@@ -1892,7 +1894,10 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
             else if (h16 == 3) launch(k3, lb);
             else launch(k0, lb);
         };
-        if (z.teams)
+        if (z.tr)
+            tem_conv_wgrad_tr_launch(h16, nblk, x, x_ld, scale, shift, g, g_ld, zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX,
+                                     z.zsegs, z.Ss, z.ncz, gmax, g_amax, s);
+        else if (z.teams)
             go(&k_conv_wgrad_zt<0>, &k_conv_wgrad_zt<1>, &k_conv_wgrad_zt<2>, &k_conv_wgrad_zt<0>,
                2 * (size_t)32 * ZS_CIS + 4 * (size_t)32 * ZS_GS);
         else if (z.nco == 2)

@@ -88,6 +88,11 @@ int tem_conv_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, int Cout, int
 // prescale of the z-reuse kernel's input by a power of two derived from a device-side |max| (tem_conv3d_fwd_gscaled)
 extern thread_local const unsigned* tem_zr_in_amax;
 extern thread_local const float* tem_zr_ref_coef;
+// conv_wgrad_tr.hip: z-sliding weight gradient with a staging team and transposing LDS reads (option wgrad_zs = 3)
+void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_ld, const float* scale, const float* shift,
+                              const float* g, int64_t g_ld, float* zpart, float* zdb, int N, int D, int H, int W, int Cin,
+                              int Cout, int T, int nY, int nX, int zsegs, int Ss, int ncz, unsigned* gmax,
+                              const unsigned* g_amax, hipStream_t s);
 // wgrad_sums.hip: norm-backward sums from the weight gradient
 int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int64_t tem_wgrad_sums_ws_floats(int N, int D, int H, int Cin, int Cout);

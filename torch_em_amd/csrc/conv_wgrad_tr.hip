@@ -1,0 +1,382 @@
+// conv_wgrad_tr.hip -- 3x3x3 weight gradient (the wgrad half of aten::convolution_backward behind nn.Conv3d,
+// /root/reference/torch_em/model/unet.py:429-438): z-sliding column, staging team, HARDWARE-TRANSPOSED operand reads.
+//
+// dW[tap][ci][co] = sum_v x^[v + tap][ci] * g[v][co] is a GEMM whose K dimension is the VOXEL index, so both MFMA
+// operands want 8 consecutive voxels of ONE channel per lane -- the transpose of the channels-last tensors in HBM.  The
+// round-2 / round-3 kernels (k_conv_wgrad_zs / _zt, conv_bf16x3.hip) paid for that transpose on the vector ALU: channel-major
+// 16-bit planes in LDS written with one ds_write_b32 per (voxel pair, channel), x-shifted windows by v_alignbyte in the
+// multiplying waves -- 5.5 VALU instructions per MFMA (profiles/r03_pmc_stalls.txt), and the power samples of round 4
+// (profiles/r04_power_*.txt) show the kernel at the 1.4 kW socket limit while its matrix pipe is 0.53 busy: the watts go
+// into that staging work.  gfx950 has the transpose in the LDS read path: ds_read_b64_tr_b16 hands lane i of a 16-lane
+// group element (i & 3) of the 8-byte items of lanes 4 j + (i >> 2), j = 0..3 -- a 4 x 16 transpose of 16-bit values.  So:
+//   * LDS holds VOXEL-major records, 32 channels x 16 bit = 64 B per voxel and term, exactly as the staging thread has
+//     them after its 16-byte global load: 4 channels of a voxel -> norm -> convert -> ONE ds_write_b64 per term;
+//   * a k-slab of the MFMA = two x-rows of 8 voxels (lanes 0..31: row 2 s, lanes 32..63: row 2 s + 1); a fragment read is two
+//     ds_read_b64_tr_b16 (voxels x .. x+3 and x+4 .. x+7 of the row); the 32 lanes of a half address 4 consecutive
+//     records = 256 contiguous bytes: conflict free for every tap shift (a tap is an address offset: no v_alignbyte, no
+//     17th element);
+//   * roles as in k_conv_wgrad_zt: waves 0..3 (one per SIMD) only multiply -- wave w owns taps w, w + 4, .., (7 / 7 / 7 / 6
+//     accumulator tiles of one (Cin tile, Cout tile) pair) -- waves 4..7 only stage (next x plane into the free slot of
+//     the 4-plane ring, next g plane into the free buffer); one barrier per plane; persistent over column segments, one
+//     partial slab per workgroup (format of k_conv_wgrad_zt: KS2 = 1).
+// ARITH: 0 bf16x3 (x^ and g two bf16 terms, 3 MFMAs per product), 1 one fp16 term each (mixed precision), 2 one bf16 term
+// each, 3 fp16 2x1 (x^ two fp16 terms, g one fp16 term prescaled from *g_amax: the default of the fp32-class mode).
+#include "tem_common.h"
+#include "conv_internal.h"
+#include "conv_split.h"
+#include <set>
+#include <type_traits>
+
+#define TR_REC 64                  // bytes per voxel record: 32 channels x 16 bit
+#define TR_XROW (10 * TR_REC)      // a halo row: 10 voxels
+#define TR_XPL (10 * TR_XROW)      // a halo plane: 10 rows
+#define TR_XT (4 * TR_XPL)         // one term of x^: ring of 4 halo planes
+#define TR_GPL (64 * TR_REC)       // a g plane: 8 x 8 voxels
+#define TR_GT (2 * TR_GPL)         // one term of g: two buffers
+
+typedef short tr_s4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tr_s4* tr_lds_p;
+typedef __amdgpu_buffer_rsrc_t tr_rsrc_t;
+typedef float tr_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int tr_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
+    const tr_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_p)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ uint4 tr_frag(const unsigned char* p) {   // 8 voxels of this lane's channel: two transposing reads
+    const uint2 a = tr_read(p), b = tr_read(p + 4 * TR_REC);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ tr_rsrc_t tr_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 tr_load4(tr_rsrc_t r, unsigned voff) {
+    const tr_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    const tr_f4 f = __builtin_bit_cast(tr_f4, v);   // whole-vector cast (element-wise casts get the load narrowed, conv_pp.hip)
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+// (e0 - h.lo, e1 - h.hi) rounded to two fp16 in one register: the lo term of the fp16 two-term split (h = the hi terms).
+// v_fma_mix{lo,hi}_f16 read the fp16 operand by half, compute in fp32 (exact here) and round once (conv_zr.hip: zr_mix_lo)
+__device__ __forceinline__ unsigned tr_mix_lo(unsigned h, float e0, float e1) {
+    unsigned q;
+    const float c = -1.f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(q) : "v"(h), "s"(c), "v"(e0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(q) : "v"(h), "s"(c), "v"(e1));
+    return q;
+}
+
+template <int ARITH>
+__global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restrict__ x, int64_t x_ld,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ g,
+                                                          int64_t g_ld, float* __restrict__ part,
+                                                          float* __restrict__ dbpart, int N, int D, int H, int W,
+                                                          int Cin, int Cout, int T, int nY, int nX, int zsegs,
+                                                          int S, int ncz, unsigned* __restrict__ gmax,
+                                                          const unsigned* __restrict__ g_amax) {
+    constexpr int NT = 27, NA = 7;
+    constexpr int NX = (ARITH == 0 || ARITH == 3) ? 2 : 1;   // terms of x^
+    constexpr int NG = (ARITH == 0) ? 2 : 1;                 // terms of g
+    constexpr bool F16 = ARITH == 1 || ARITH == 3;
+    constexpr bool H21 = ARITH == 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char* const X0 = ldsb;                  // [term NX][slot 4][row 10][x 10][32 ch]
+    unsigned char* const G0 = ldsb + NX * TR_XT;     // [term NG][buffer 2][row 8][x 8][32 ch]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mteam = wv < 4;
+    const int bid0 = tem_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid0 % T;
+    const int sp = bid0 / T;               // partial-slab index: this workgroup walks column segments sp % S, + S, ...
+    const int ncit = Cin >> 5;
+    const int cit = tile % ncit, cog = tile / ncit;
+    const int n = sp / S;
+
+    float psc = 1.f, pinv = 1.f;
+    if (F16) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // MODE.FP16_OVFL: conversions clamp instead of inf
+    if (H21) {
+        const int e = (int)((*g_amax >> 23) & 0xffu);                       // biased exponent of max |g| (0: all zeros)
+        const int k = e == 0 ? 0 : min(max(141 - e, -100), 100);            // max |g| * 2^k in [2^14, 2^15)
+        psc = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+        pinv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+    }
+
+    if (mteam) {
+        // ---------------- multiplying team ----------------
+        floatx16 acc[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[j][k] = 0.f;
+        // lane part of a fragment address: half-wave = x-row of the slab, 16-lane group = channel half, lanes 4 j .. 4 j + 3 of
+        // a group address voxel j of the run, 8 bytes (4 channels) each
+        const int p16 = lane & 15;
+        const int lane_rec = (p16 >> 2) * TR_REC + ((lane >> 4) & 1) * 32 + (p16 & 3) * 8;
+        const int lane_x = (lane >> 5) * TR_XROW + lane_rec;
+        const int lane_g = (lane >> 5) * (8 * TR_REC) + lane_rec;
+        // tap j of this wave: wv + 4 j (wave 3 has six: its seventh accumulator repeats tap 26 and is never stored)
+        int tapoff[NA], taptz[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int tau = min(wv + 4 * j, NT - 1);
+            taptz[j] = tau / 9;
+            tapoff[j] = ((tau / 3) % 3) * TR_XROW + (tau % 3) * TR_REC;
+        }
+        for (int cz = sp % S; cz < ncz; cz += S) {
+            const int zseg = cz % zsegs;
+            const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
+            for (int t = za - 4; t < za; ++t) __syncthreads();   // the staging team primes the ring
+#pragma unroll 1
+            for (int t = za; t < zb; ++t) {
+                const unsigned char* xb[NA];
+#pragma unroll
+                for (int j = 0; j < NA; ++j)
+                    xb[j] = X0 + lane_x + ((t + taptz[j] - 1 + 4) & 3) * TR_XPL + tapoff[j];
+                const unsigned char* gb = G0 + lane_g + (t & 1) * TR_GPL;
+                // Software pipeline over the 4 k-slabs x (term) phases of a plane: the fragment reads of the NEXT phase are
+                // issued between the MFMAs of the current one (sched_group_barrier: 1 MFMA, then up to 3 LDS reads -- a wave
+                // hides ~5 other instructions per 32-cycle MFMA), so a phase never starts by waiting for LDS.
+                // Phases of slab sl: [x lo * g hi] (NX == 2), [x hi * g lo] (NG == 2), [x hi * g hi]; products small first.
+                uint4 gh, gl, xh[NA], xl[NA];
+                auto load_g = [&](int sl) {
+                    gh = tr_frag(gb + sl * 16 * TR_REC);
+                    if (NG == 2) gl = tr_frag(gb + TR_GT + sl * 16 * TR_REC);
+                };
+                auto load_xh = [&](int sl) {
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) xh[j] = tr_frag(xb[j] + sl * 2 * TR_XROW);
+                };
+                auto load_xl = [&](int sl) {
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) xl[j] = tr_frag(xb[j] + TR_XT + sl * 2 * TR_XROW);
+                };
+                auto interleave = [&]() {   // the 7 MFMAs of the phase just written, each followed by a share of the reads
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                load_g(0);
+                if (NX == 2) load_xl(0);
+                else load_xh(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    if (NX == 2) {
+                        load_xh(sl);   // for the next phase of this slab
+#pragma unroll
+                        for (int j = 0; j < NA; ++j) acc[j] = mfma16<F16>(xl[j], gh, acc[j]);
+                        interleave();
+                    }
+                    if (NG == 2) {
+#pragma unroll
+                        for (int j = 0; j < NA; ++j) acc[j] = mfma16<F16>(xh[j], gl, acc[j]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // last phase of the slab: the g fragment(s) and the first x operand of the next slab are read meanwhile
+                    // (into a second g register set: this phase still multiplies with the current one)
+                    const uint4 ghc = gh;
+                    if (sl < 3) {
+                        load_g(sl + 1);
+                        if (NX == 2) load_xl(sl + 1);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) acc[j] = mfma16<F16>(xh[j], ghc, acc[j]);
+                    if (NX == 1 && sl < 3) {   // one-term x: its next fragments can only follow the MFMAs that read the current ones
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_xh(sl + 1);
+                    }
+                    interleave();
+                }
+                __syncthreads();
+            }
+        }
+        // ---- partial slabs: D[row = ci][col = co] ----
+        if (cog * 32 < Cout) {
+            const int kh = lane >> 5, r = lane & 31;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int tap = wv + 4 * j;
+                if (tap >= NT) break;
+                float* dst = part + (((int64_t)sp * NT + tap) * Cin + cit * 32) * Cout + cog * 32 + r;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    dst[(int64_t)row * Cout] = H21 ? acc[j][reg] * pinv : acc[j][reg];
+                }
+            }
+        }
+    }
+
+    // ---------------- staging team ----------------
+    // item = (voxel, channel quad): 8 lanes cover the 128-byte line of a voxel; x plane: 100 halo voxels = 800 items over 256
+    // threads (four rounds, the last one 32 threads), g plane: 64 voxels = 512 items (two rounds).  The quad of a thread is
+    // the same in every round (256 % 8 == 0), so norm parameters and the bias-gradient sums are per thread.
+    const int tl = tid & 255;
+    const int quad = tl & 7;
+    const bool do_db = (dbpart != nullptr) && (cit == 0);
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float gmx = 0.f;
+    if (!mteam) {
+        float4 xa[4], ga[2];
+        unsigned inx = 0, ing = 0;       // bit q: the pending registers of round q hold an in-range voxel
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) {
+            sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + quad * 4);
+            sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + quad * 4);
+        }
+        const float* const xn = x + (int64_t)n * D * H * W * x_ld;   // a load's resource starts at its z-plane: offsets stay
+        const float* const gn = g + (int64_t)n * D * H * W * g_ld;   // inside one plane (< 2 GiB, checked by the host side)
+        const int64_t xplane = (int64_t)H * W * x_ld, gplane = (int64_t)H * W * g_ld;
+        for (int cz = sp % S; cz < ncz; cz += S) {
+            const int zseg = cz % zsegs;
+            const int col = cz / zsegs;
+            const int y0 = (col / nX) * 8, x0 = (col % nX) * 8;
+            const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
+            unsigned okx = 0, okg = 0, offx[4], offg[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int hv = (tl + 256 * q) >> 3;                 // halo voxel 0..99 (round 3: threads 0..31 only)
+                const int gy = y0 + hv / 10 - 1, gx = x0 + hv % 10 - 1;
+                const bool ok = hv < 100 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                okx |= ok ? (1u << q) : 0u;
+                offx[q] = ok ? (unsigned)((gy * W + gx) * (int)x_ld + cit * 32 + quad * 4) * 4u : 0u;
+                xa[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int gv = (tl + 256 * q) >> 3;                 // patch voxel 0..63
+                const int hy = y0 + (gv >> 3), hx = x0 + (gv & 7);
+                const bool ok = hy < H && hx < W && cog * 32 + quad * 4 < Cout;
+                okg |= ok ? (1u << q) : 0u;
+                offg[q] = ok ? (unsigned)((hy * W + hx) * (int)g_ld + cog * 32 + quad * 4) * 4u : 0u;
+                ga[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            inx = ing = 0;
+            // iteration t: the multiplying team works on plane t (if t >= za); this team stores its pending registers (x plane
+            // t + 2 into ring slot (t + 2) & 3, g plane t + 1 into buffer (t + 1) & 1), issues the loads of x plane t + 3 and
+            // g plane t + 2, and joins the barrier.  Planes -1 and D (and out-of-range voxels) are stored as zeros: zero
+            // padding applies after the pre-norm (model/unet.py:429-438).
+#pragma unroll 1
+            for (int t = za - 4; t < zb; ++t) {
+                if (t >= za - 3) {
+                    unsigned char* const xs = X0 + ((t + 2 + 4) & 3) * TR_XPL + quad * 8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int hv = (tl + 256 * q) >> 3;
+                        if (q == 3 && hv >= 100) break;
+                        const bool in = (inx >> q) & 1u;
+                        const float e0 = in ? fmaf(xa[q].x, sc4.x, sf4.x) : 0.f, e1 = in ? fmaf(xa[q].y, sc4.y, sf4.y) : 0.f;
+                        const float e2 = in ? fmaf(xa[q].z, sc4.z, sf4.z) : 0.f, e3 = in ? fmaf(xa[q].w, sc4.w, sf4.w) : 0.f;
+                        uint2 hi, lo;
+                        if (H21) {
+                            hi = make_uint2(pk16<true>(e0, e1), pk16<true>(e2, e3));
+                            lo = make_uint2(tr_mix_lo(hi.x, e0, e1), tr_mix_lo(hi.y, e2, e3));
+                        } else if (ARITH == 0) {
+                            split2(e0, e1, hi.x, lo.x);
+                            split2(e2, e3, hi.y, lo.y);
+                        } else {
+                            hi = lo = make_uint2(pk16<F16>(e0, e1), pk16<F16>(e2, e3));
+                        }
+                        *reinterpret_cast<uint2*>(xs + hv * TR_REC) = hi;
+                        if (NX == 2) *reinterpret_cast<uint2*>(xs + TR_XT + hv * TR_REC) = lo;
+                    }
+                }
+                if (t + 1 >= za && t + 1 < zb) {
+                    unsigned char* const gs = G0 + ((t + 1) & 1) * TR_GPL + quad * 8;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int gv = (tl + 256 * q) >> 3;
+                        const float4 v = ga[q];   // zeros where out of range
+                        uint2 hi, lo;
+                        if (H21) {
+                            hi = lo = make_uint2(pk16<true>(v.x * psc, v.y * psc), pk16<true>(v.z * psc, v.w * psc));
+                        } else if (ARITH == 0) {
+                            split2(v.x, v.y, hi.x, lo.x);
+                            split2(v.z, v.w, hi.y, lo.y);
+                        } else {
+                            hi = lo = make_uint2(pk16<F16>(v.x, v.y), pk16<F16>(v.z, v.w));
+                        }
+                        *reinterpret_cast<uint2*>(gs + gv * TR_REC) = hi;
+                        if (NG == 2) *reinterpret_cast<uint2*>(gs + TR_GT + gv * TR_REC) = lo;
+                        dbacc[0] += v.x;
+                        dbacc[1] += v.y;
+                        dbacc[2] += v.z;
+                        dbacc[3] += v.w;
+                        if (gmax)   // grid-uniform
+                            gmx = __builtin_fmaxf(gmx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)),
+                                                                       __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+                    }
+                }
+                {
+                    const int zx = t + 3;
+                    const bool zxok = zx >= za - 1 && zx <= zb && zx >= 0 && zx < D;   // wave-uniform
+                    inx = zxok ? okx : 0u;
+                    const tr_rsrc_t rsx = tr_rsrc(xn + (zxok ? zx : 0) * xplane);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        xa[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if ((inx >> q) & 1u) xa[q] = tr_load4(rsx, offx[q]);
+                    }
+                    const int zg = t + 2;
+                    const bool zgok = zg >= za && zg < zb;
+                    ing = zgok ? okg : 0u;
+                    const tr_rsrc_t rsg = tr_rsrc(gn + (zgok ? zg : 0) * gplane);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        ga[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if ((ing >> q) & 1u) ga[q] = tr_load4(rsg, offg[q]);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- largest |g| (tem_conv3d_wgrad_gmax): integer max of the bit patterns, exact and order-independent ----
+    if (gmax && !mteam) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmx = __builtin_fmaxf(gmx, __shfl_xor(gmx, o, 64));
+        if (lane == 0) atomicMax(gmax, __builtin_bit_cast(unsigned, gmx));
+    }
+    // ---- bias-gradient partial of this workgroup: 32 threads per channel quad ----
+    if (do_db) {
+        float* red = reinterpret_cast<float*>(ldsb);  // [32][32]
+        if (!mteam) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[(tl >> 3) * 32 + quad * 4 + c] = dbacc[c];
+        }
+        __syncthreads();
+        if (tid < 32 && cog * 32 + tid < Cout) {
+            float a = 0.f;
+            for (int rr = 0; rr < 32; ++rr) a += red[rr * 32 + tid];
+            dbpart[(int64_t)sp * Cout + cog * 32 + tid] = a;
+        }
+    }
+}
+
+// h16: 0 bf16x3, 1 one fp16 term, 2 one bf16 term, 3 fp16 2x1 (g_amax required).  Same arguments, partial-slab format and
+// plan (teams: one (Cin tile, Cout tile) pair per workgroup, KS2 = 1) as k_conv_wgrad_zt.
+void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_ld, const float* scale, const float* shift,
+                              const float* g, int64_t g_ld, float* zpart, float* zdb, int N, int D, int H, int W, int Cin,
+                              int Cout, int T, int nY, int nX, int zsegs, int Ss, int ncz, unsigned* gmax,
+                              const unsigned* g_amax, hipStream_t s) {
+    auto launch = [&](auto kern, size_t lb) {
+        static std::set<const void*> sized;   // kernels whose dynamic-LDS limit was raised already
+        const void* key = reinterpret_cast<const void*>(kern);
+        if (!sized.count(key)) {
+            (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            sized.insert(key);
+        }
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb, N, D, H, W, Cin, Cout,
+                           T, nY, nX, zsegs, Ss, ncz, gmax, g_amax);
+    };
+    if (h16 == 1) launch(&k_conv_wgrad_tr<1>, (size_t)TR_XT + TR_GT);
+    else if (h16 == 2) launch(&k_conv_wgrad_tr<2>, (size_t)TR_XT + TR_GT);
+    else if (h16 == 3) launch(&k_conv_wgrad_tr<3>, (size_t)2 * TR_XT + TR_GT);
+    else launch(&k_conv_wgrad_tr<0>, (size_t)2 * TR_XT + 2 * TR_GT);
+}
