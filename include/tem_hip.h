@@ -51,8 +51,9 @@ int tem_device_cus(void);
  * (the reference selects nothing: it calls ATen).  Names:
  *   "conv_fwd_variant"   -1 auto | 0 one-patch-per-workgroup kernel | 1 ping-pong team kernel (conv_pp.hip) for every shape
  *                        it can take | 2 z-reuse team kernel (conv_zr.hip, 3x3x3) for every shape it can take
- *   "wgrad_zs"            2 | 1 | 0   z-sliding weight gradient (3x3x3, D >= 16): 2 = with a staging team (k_conv_wgrad_zt),
- *                        1 = the round-2 kernel (k_conv_wgrad_zs), 0 = patch kernel
+ *   "wgrad_zs"            3 | 2 | 1 | 0   z-sliding weight gradient (3x3x3, D >= 16): 3 (default) = staging team + voxel-major
+ *                        LDS records read with ds_read_b64_tr_b16 (k_conv_wgrad_tr), 2 = staging team with channel-major
+ *                        planes (k_conv_wgrad_zt), 1 = the round-2 kernel (k_conv_wgrad_zs), 0 = patch kernel
  *   "wgrad_zs_persist"    1 | 0   persistent column segments of that kernel
  *   "wgrad_sums"          1 | 0   norm-backward sums taken from the weight gradient
  *   "wgrad_sums_min_mb"   128     ... for layers whose norm input has at least this many MiB

@@ -10,6 +10,9 @@
 #ifdef TEM_ZS_TRACE
 void tem_zs_trace_read(unsigned long long* dst);
 #endif
+#ifdef TEM_TR_TRACE
+void tem_tr_trace_read(unsigned long long* dst);
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 static float frand(uint64_t& s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (float)((s >> 40) & 0xffffff) / 8388608.f - 1.f; }
 
@@ -89,6 +92,23 @@ int main(int argc, char** argv) {
     const double fl = 2.0 * V * Cin * Cout * 27;
     printf("wgrad[zs=%d] %dx%dx%dx%d %d->%d: min %.4f ms (kernel + slab merge)  %.0f TF alg  mfma_frac(2500) %.3f\n", zsopt, N, D, H, W, Cin, Cout, best,
            fl / best / 1e9, fl * 3 / best / 1e9 / 2500);
+#ifdef TEM_TR_TRACE
+    {
+        std::vector<unsigned long long> tt(8 * 64 * 4);
+        tem_tr_trace_read(tt.data());
+        for (int wv : {0, 3, 4, 7}) {
+            printf("wave %d (%s): plane  start->%s  ->%s  barrier   plane-to-plane   (s_memtime ticks)\n", wv, wv < 4 ? "multiply" : "stage",
+                   wv < 4 ? "prologue" : "stored", wv < 4 ? "mfma done" : "loads issued");
+            for (int it = 4; it < 40; ++it) {
+                const unsigned long long* t = &tt[(wv * 64 + it) * 4];
+                const unsigned long long* tp = &tt[(wv * 64 + it - 1) * 4];
+                if (!t[0] || !t[3]) break;
+                printf("  %2d: %6lld %6lld %6lld   %6lld\n", it, (long long)(t[1] - t[0]), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]),
+                       (long long)(t[0] - tp[0]));
+            }
+        }
+    }
+#endif
 #ifdef TEM_ZS_TRACE
     std::vector<unsigned long long> tr(8 * 64 * 8);
     tem_zs_trace_read(tr.data());

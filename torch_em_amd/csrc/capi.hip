@@ -23,7 +23,7 @@ struct TemOption {
     long long def;
 };
 static const TemOption g_opt_table[TEM_OPT_COUNT] = {
-    {"wgrad_zs", 1},            // TEM_OPT_WGRAD_ZS: z-sliding weight gradient for 3x3x3, D >= 16 (2 staging-team kernel, 1 round-2 kernel, 0 patch kernel)
+    {"wgrad_zs", 3},            // TEM_OPT_WGRAD_ZS: z-sliding weight gradient for 3x3x3, D >= 16 (3 k_conv_wgrad_tr: staging team + transposing LDS reads, 2 k_conv_wgrad_zt, 1 k_conv_wgrad_zs, 0 patch kernel)
     {"wgrad_zs_persist", 1},    // TEM_OPT_WGRAD_ZS_PERSIST: persistent column segments (one slab per workgroup)
     {"wgrad_sums", 1},          // TEM_OPT_WGRAD_SUMS: norm-backward sums from the weight gradient
     {"wgrad_sums_min_mb", 128}, // TEM_OPT_WGRAD_SUMS_MIN_MB: ... for layers whose norm input has at least this many MiB (measured: 256 -> 128 -0.07 ms, 64 +0.09 ms)

@@ -15,8 +15,11 @@
 //     ds_read_b64_tr_b16 (voxels x .. x+3 and x+4 .. x+7 of the row); the 32 lanes of a half address 4 consecutive
 //     records = 256 contiguous bytes: conflict free for every tap shift (a tap is an address offset: no v_alignbyte, no
 //     17th element);
-//   * roles as in k_conv_wgrad_zt: waves 0..3 (one per SIMD) only multiply -- wave w owns taps w, w + 4, .., (7 / 7 / 7 / 6
-//     accumulator tiles of one (Cin tile, Cout tile) pair) -- waves 4..7 only stage (next x plane into the free slot of
+//   * roles as in k_conv_wgrad_zt: waves 0..3 (one per SIMD) only multiply -- wave w owns row groups (tz, ty) w and w + 4 with
+//     their three tx taps and one tap of row group 8 (7 / 7 / 7 / 6 accumulator tiles of one (Cin tile, Cout tile) pair); the
+//     three tx fragments of a row group come out of ONE 12-voxel window (three transposing reads + 4 v_alignbyte for
+//     tx = 1: the first version read every tap's fragment separately and ran at 1.6 GHz with the matrix pipe 0.62 busy --
+//     LDS reads cost power too) -- waves 4..7 only stage (next x plane into the free slot of
 //     the 4-plane ring, next g plane into the free buffer); one barrier per plane; persistent over column segments, one
 //     partial slab per workgroup (format of k_conv_wgrad_zt: KS2 = 1).
 // ARITH: 0 bf16x3 (x^ and g two bf16 terms, 3 MFMAs per product), 1 one fp16 term each (mixed precision), 2 one bf16 term
@@ -65,6 +68,34 @@ __device__ __forceinline__ unsigned tr_mix_lo(unsigned h, float e0, float e1) {
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(q) : "v"(h), "s"(c), "v"(e1));
     return q;
 }
+
+// (g0 * s, g1 * s) rounded to two fp16 in one register: the prescaled gradient term (all sources fp32)
+__device__ __forceinline__ unsigned tr_mix_scale(float g0, float g1, float sc) {
+    unsigned q;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(q) : "v"(g0), "s"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(q) : "v"(g1), "s"(sc));
+    return q;
+}
+
+#ifndef TEM_TR_ABL
+#define TEM_TR_ABL 0   // harness-only ablations (wrong results): 1 staging team idle, 2 multiplying team idle, 4 fragments read once
+#endif                 // per plane (no LDS reads in the MFMA stream), 8 staging without global loads
+#ifdef TEM_TR_TRACE   // developer build (scripts/wg_harness.sh ... -DTEM_TR_TRACE): shader-clock stamps of one workgroup's plane loop
+#ifndef TEM_TR_TRACE_BLOCK
+#define TEM_TR_TRACE_BLOCK 100
+#endif
+__device__ unsigned long long tem_tr_trace_buf[8][64][4];
+#define TR_STAMP(it, i)                                                                               \
+    do {                                                                                              \
+        if (blockIdx.x == TEM_TR_TRACE_BLOCK && lane == 0 && (it) >= 0 && (it) < 64)                  \
+            tem_tr_trace_buf[wv][it][i] = __builtin_amdgcn_s_memtime();                               \
+    } while (0)
+void tem_tr_trace_read(unsigned long long* dst) {
+    (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(tem_tr_trace_buf), sizeof(unsigned long long) * 8 * 64 * 4);
+}
+#else
+#define TR_STAMP(it, i)
+#endif
 
 template <int ARITH>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restrict__ x, int64_t x_ld,
@@ -116,24 +147,26 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
         const int lane_rec = (p16 >> 2) * TR_REC + ((lane >> 4) & 1) * 32 + (p16 & 3) * 8;
         const int lane_x = (lane >> 5) * TR_XROW + lane_rec;
         const int lane_g = (lane >> 5) * (8 * TR_REC) + lane_rec;
-        // tap j of this wave: wv + 4 j (wave 3 has six: its seventh accumulator repeats tap 26 and is never stored)
-        int tapoff[NA], taptz[NA];
+        // taps of this wave (as k_conv_wgrad_zt): accumulators 0..2 = row group (tz, ty) = wv with tx = 0, 1, 2; 3..5 = row group
+        // wv + 4; accumulator 6 = (row group 8, tx = wv) -- wave 3 has no seventh tap: it repeats tx = 0 there and never stores it.
+        // A row group reads ONE 12-voxel window of its x row (three transposing reads: elements k0 .. k11 of the lane's
+        // channel); the tx = 0 fragment is registers 0..3 of it, tx = 2 registers 1..4, tx = 1 four v_alignbyte.
+        int rgtz[3], rgoff[3];
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int tau = min(wv + 4 * j, NT - 1);
-            taptz[j] = tau / 9;
-            tapoff[j] = ((tau / 3) % 3) * TR_XROW + (tau % 3) * TR_REC;
+        for (int a = 0; a < 3; ++a) {
+            const int rg = a < 2 ? wv + 4 * a : 8;
+            rgtz[a] = rg / 3;
+            rgoff[a] = (rg % 3) * TR_XROW + (a == 2 ? (wv < 3 ? wv : 0) * TR_REC : 0);
         }
         for (int cz = sp % S; cz < ncz; cz += S) {
             const int zseg = cz % zsegs;
             const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
-            for (int t = za - 4; t < za; ++t) __syncthreads();   // the staging team primes the ring
+            for (int t = za - 5; t < za; ++t) __syncthreads();   // the staging team primes the ring (five iterations)
 #pragma unroll 1
             for (int t = za; t < zb; ++t) {
-                const unsigned char* xb[NA];
+                const unsigned char* xb[3];
 #pragma unroll
-                for (int j = 0; j < NA; ++j)
-                    xb[j] = X0 + lane_x + ((t + taptz[j] - 1 + 4) & 3) * TR_XPL + tapoff[j];
+                for (int a = 0; a < 3; ++a) xb[a] = X0 + lane_x + ((t + rgtz[a] - 1 + 4) & 3) * TR_XPL + rgoff[a];
                 const unsigned char* gb = G0 + lane_g + (t & 1) * TR_GPL;
                 // Software pipeline over the 4 k-slabs x (term) phases of a plane: the fragment reads of the NEXT phase are
                 // issued between the MFMAs of the current one (sched_group_barrier: 1 MFMA, then up to 3 LDS reads -- a wave
@@ -141,29 +174,56 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                 // Phases of slab sl: [x lo * g hi] (NX == 2), [x hi * g lo] (NG == 2), [x hi * g hi]; products small first.
                 uint4 gh, gl, xh[NA], xl[NA];
                 auto load_g = [&](int sl) {
+                    if ((TEM_TR_ABL & 4) && sl > 0) return;
                     gh = tr_frag(gb + sl * 16 * TR_REC);
                     if (NG == 2) gl = tr_frag(gb + TR_GT + sl * 16 * TR_REC);
                 };
-                auto load_xh = [&](int sl) {
+                auto load_x = [&](uint4* f, int term, int sl) {
+                    if ((TEM_TR_ABL & 4) && sl > 0) return;
 #pragma unroll
-                    for (int j = 0; j < NA; ++j) xh[j] = tr_frag(xb[j] + sl * 2 * TR_XROW);
-                };
-                auto load_xl = [&](int sl) {
-#pragma unroll
-                    for (int j = 0; j < NA; ++j) xl[j] = tr_frag(xb[j] + TR_XT + sl * 2 * TR_XROW);
-                };
-                auto interleave = [&]() {   // the 7 MFMAs of the phase just written, each followed by a share of the reads
-#pragma unroll
-                    for (int j = 0; j < NA; ++j) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    for (int a = 0; a < 2; ++a) {
+                        const unsigned char* p = xb[a] + term * TR_XT + sl * 2 * TR_XROW;
+                        const uint2 w0 = tr_read(p), w1 = tr_read(p + 4 * TR_REC), w2 = tr_read(p + 8 * TR_REC);
+                        f[3 * a + 0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
+                        f[3 * a + 1] = make_uint4(__builtin_amdgcn_alignbyte(w0.y, w0.x, 2), __builtin_amdgcn_alignbyte(w1.x, w0.y, 2),
+                                                  __builtin_amdgcn_alignbyte(w1.y, w1.x, 2), __builtin_amdgcn_alignbyte(w2.x, w1.y, 2));
+                        f[3 * a + 2] = make_uint4(w0.y, w1.x, w1.y, w2.x);
                     }
+                    f[6] = tr_frag(xb[2] + term * TR_XT + sl * 2 * TR_XROW);
+                };
+                auto load_xh = [&](int sl) { load_x(xh, 0, sl); };
+                auto load_xl = [&](int sl) { load_x(xl, 1, sl); };
+                auto interleave = [&]() {   // the 7 MFMAs of the phase just written and the reads / shifts for the next one:
+                    // reads behind the first three MFMAs, the v_alignbyte of the tx = 1 fragments behind the last three (their
+                    // reads have returned by then: an LDS wait inside the MFMA stream would stall the matrix pipe)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 };
+                TR_STAMP(t - za, 0);
+                if (TEM_TR_ABL & 2) {
+                    __syncthreads();
+                    continue;
+                }
                 load_g(0);
                 if (NX == 2) load_xl(0);
                 else load_xh(0);
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef TEM_TR_TRACE
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                TR_STAMP(t - za, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) {
                     if (NX == 2) {
@@ -192,7 +252,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                     }
                     interleave();
                 }
+                TR_STAMP(t - za, 2);
                 __syncthreads();
+                TR_STAMP(t - za, 3);
             }
         }
         // ---- partial slabs: D[row = ci][col = co] ----
@@ -200,8 +262,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
             const int kh = lane >> 5, r = lane & 31;
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
-                const int tap = wv + 4 * j;
-                if (tap >= NT) break;
+                if (j == 6 && wv >= 3) break;
+                const int tap = (j < 6) ? (wv + 4 * (j / 3)) * 3 + (j % 3) : 8 * 3 + wv;
                 float* dst = part + (((int64_t)sp * NT + tap) * Cin + cit * 32) * Cout + cog * 32 + r;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
@@ -222,8 +284,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
     float gmx = 0.f;
     if (!mteam) {
-        float4 xa[4], ga[2];
-        unsigned inx = 0, ing = 0;       // bit q: the pending registers of round q hold an in-range voxel
+        // The staging waves share their SIMDs with the multiplying waves and get an issue slot every ~8 cycles (trace of the
+        // first version: 250 instructions = 2000 - 2700 cycles per plane, the multiplying team waited for them).  So this
+        // loop is written for instruction COUNT: no per-element masks (out-of-range voxels use scale = shift = 0 chosen once
+        // per column and a load offset beyond the buffer, which returns zeros), no branches around loads, and
+        // TWO sets of pending registers: the loads of an iteration are converted two iterations later.
+        float4 xa[2][4], ga[2][2];
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (scale) {
             sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + quad * 4);
@@ -232,58 +298,70 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
         const float* const xn = x + (int64_t)n * D * H * W * x_ld;   // a load's resource starts at its z-plane: offsets stay
         const float* const gn = g + (int64_t)n * D * H * W * g_ld;   // inside one plane (< 2 GiB, checked by the host side)
         const int64_t xplane = (int64_t)H * W * x_ld, gplane = (int64_t)H * W * g_ld;
+        constexpr unsigned OOB = 0x80000000u;   // >= num_records of tr_rsrc: the load returns zeros
         for (int cz = sp % S; cz < ncz; cz += S) {
             const int zseg = cz % zsegs;
             const int col = cz / zsegs;
             const int y0 = (col / nX) * 8, x0 = (col % nX) * 8;
             const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
-            unsigned okx = 0, okg = 0, offx[4], offg[2];
+            unsigned offx[4], offg[2];
+            float4 scm[4], sfm[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int hv = (tl + 256 * q) >> 3;                 // halo voxel 0..99 (round 3: threads 0..31 only)
                 const int gy = y0 + hv / 10 - 1, gx = x0 + hv % 10 - 1;
                 const bool ok = hv < 100 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                okx |= ok ? (1u << q) : 0u;
-                offx[q] = ok ? (unsigned)((gy * W + gx) * (int)x_ld + cit * 32 + quad * 4) * 4u : 0u;
-                xa[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                offx[q] = ok ? (unsigned)((gy * W + gx) * (int)x_ld + cit * 32 + quad * 4) * 4u : OOB;
+                scm[q] = ok ? sc4 : make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies after the pre-norm
+                sfm[q] = ok ? sf4 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int gv = (tl + 256 * q) >> 3;                 // patch voxel 0..63
                 const int hy = y0 + (gv >> 3), hx = x0 + (gv & 7);
                 const bool ok = hy < H && hx < W && cog * 32 + quad * 4 < Cout;
-                okg |= ok ? (1u << q) : 0u;
-                offg[q] = ok ? (unsigned)((hy * W + hx) * (int)g_ld + cog * 32 + quad * 4) * 4u : 0u;
-                ga[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                offg[q] = ok ? (unsigned)((hy * W + hx) * (int)g_ld + cog * 32 + quad * 4) * 4u : OOB;
             }
-            inx = ing = 0;
-            // iteration t: the multiplying team works on plane t (if t >= za); this team stores its pending registers (x plane
-            // t + 2 into ring slot (t + 2) & 3, g plane t + 1 into buffer (t + 1) & 1), issues the loads of x plane t + 3 and
-            // g plane t + 2, and joins the barrier.  Planes -1 and D (and out-of-range voxels) are stored as zeros: zero
-            // padding applies after the pre-norm (model/unet.py:429-438).
-#pragma unroll 1
-            for (int t = za - 4; t < zb; ++t) {
+            bool zin[2] = {false, false};   // the set's x plane lies inside the volume (wave-uniform)
+            // iteration t: the multiplying team works on plane t (if t >= za); this team converts and stores the register set
+            // loaded two iterations ago (x plane t + 2 into ring slot (t + 2) & 3, g plane t + 1 into buffer (t + 1) & 1), loads
+            // x plane t + 4 and g plane t + 3 into the same set, and joins the barrier.  Planes -1 and D are stored as zeros.
+            auto iteration = [&](int t, float4(&xs_)[4], float4(&gs_)[2], bool& zin_) {
+                TR_STAMP(t - za, 0);
+                if (TEM_TR_ABL & 1) {
+                    __syncthreads();
+                    return;
+                }
                 if (t >= za - 3) {
                     unsigned char* const xs = X0 + ((t + 2 + 4) & 3) * TR_XPL + quad * 8;
+                    if (zin_) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int hv = (tl + 256 * q) >> 3;
-                        if (q == 3 && hv >= 100) break;
-                        const bool in = (inx >> q) & 1u;
-                        const float e0 = in ? fmaf(xa[q].x, sc4.x, sf4.x) : 0.f, e1 = in ? fmaf(xa[q].y, sc4.y, sf4.y) : 0.f;
-                        const float e2 = in ? fmaf(xa[q].z, sc4.z, sf4.z) : 0.f, e3 = in ? fmaf(xa[q].w, sc4.w, sf4.w) : 0.f;
-                        uint2 hi, lo;
-                        if (H21) {
-                            hi = make_uint2(pk16<true>(e0, e1), pk16<true>(e2, e3));
-                            lo = make_uint2(tr_mix_lo(hi.x, e0, e1), tr_mix_lo(hi.y, e2, e3));
-                        } else if (ARITH == 0) {
-                            split2(e0, e1, hi.x, lo.x);
-                            split2(e2, e3, hi.y, lo.y);
-                        } else {
-                            hi = lo = make_uint2(pk16<F16>(e0, e1), pk16<F16>(e2, e3));
+                        for (int q = 0; q < 4; ++q) {
+                            const int hv = (tl + 256 * q) >> 3;
+                            if (q == 3 && hv >= 100) break;
+                            const float e0 = fmaf(xs_[q].x, scm[q].x, sfm[q].x), e1 = fmaf(xs_[q].y, scm[q].y, sfm[q].y);
+                            const float e2 = fmaf(xs_[q].z, scm[q].z, sfm[q].z), e3 = fmaf(xs_[q].w, scm[q].w, sfm[q].w);
+                            uint2 hi, lo;
+                            if (H21) {
+                                hi = make_uint2(pk16<true>(e0, e1), pk16<true>(e2, e3));
+                                lo = make_uint2(tr_mix_lo(hi.x, e0, e1), tr_mix_lo(hi.y, e2, e3));
+                            } else if (ARITH == 0) {
+                                split2(e0, e1, hi.x, lo.x);
+                                split2(e2, e3, hi.y, lo.y);
+                            } else {
+                                hi = lo = make_uint2(pk16<F16>(e0, e1), pk16<F16>(e2, e3));
+                            }
+                            *reinterpret_cast<uint2*>(xs + hv * TR_REC) = hi;
+                            if (NX == 2) *reinterpret_cast<uint2*>(xs + TR_XT + hv * TR_REC) = lo;
                         }
-                        *reinterpret_cast<uint2*>(xs + hv * TR_REC) = hi;
-                        if (NX == 2) *reinterpret_cast<uint2*>(xs + TR_XT + hv * TR_REC) = lo;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int hv = (tl + 256 * q) >> 3;
+                            if (q == 3 && hv >= 100) break;
+                            *reinterpret_cast<uint2*>(xs + hv * TR_REC) = make_uint2(0u, 0u);
+                            if (NX == 2) *reinterpret_cast<uint2*>(xs + TR_XT + hv * TR_REC) = make_uint2(0u, 0u);
+                        }
                     }
                 }
                 if (t + 1 >= za && t + 1 < zb) {
@@ -291,10 +369,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int gv = (tl + 256 * q) >> 3;
-                        const float4 v = ga[q];   // zeros where out of range
+                        const float4 v = gs_[q];   // zeros where out of range (load offset beyond the buffer)
                         uint2 hi, lo;
                         if (H21) {
-                            hi = lo = make_uint2(pk16<true>(v.x * psc, v.y * psc), pk16<true>(v.z * psc, v.w * psc));
+                            hi = lo = make_uint2(tr_mix_scale(v.x, v.y, psc), tr_mix_scale(v.z, v.w, psc));
                         } else if (ARITH == 0) {
                             split2(v.x, v.y, hi.x, lo.x);
                             split2(v.z, v.w, hi.y, lo.y);
@@ -312,27 +390,30 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                                                                        __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
                     }
                 }
+                TR_STAMP(t - za, 1);
                 {
-                    const int zx = t + 3;
-                    const bool zxok = zx >= za - 1 && zx <= zb && zx >= 0 && zx < D;   // wave-uniform
-                    inx = zxok ? okx : 0u;
-                    const tr_rsrc_t rsx = tr_rsrc(xn + (zxok ? zx : 0) * xplane);
+                    const int zx = t + 4;
+                    zin_ = zx >= za - 1 && zx <= zb && zx >= 0 && zx < D;   // wave-uniform
+                    if (zin_ && !(TEM_TR_ABL & 8)) {
+                        const tr_rsrc_t rsx = tr_rsrc(xn + zx * xplane);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        xa[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if ((inx >> q) & 1u) xa[q] = tr_load4(rsx, offx[q]);
+                        for (int q = 0; q < 4; ++q) xs_[q] = tr_load4(rsx, offx[q]);
                     }
-                    const int zg = t + 2;
-                    const bool zgok = zg >= za && zg < zb;
-                    ing = zgok ? okg : 0u;
-                    const tr_rsrc_t rsg = tr_rsrc(gn + (zgok ? zg : 0) * gplane);
+                    const int zg = t + 3;
+                    if (zg >= za && zg < zb && !(TEM_TR_ABL & 8)) {
+                        const tr_rsrc_t rsg = tr_rsrc(gn + zg * gplane);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        ga[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if ((ing >> q) & 1u) ga[q] = tr_load4(rsg, offg[q]);
+                        for (int q = 0; q < 2; ++q) gs_[q] = tr_load4(rsg, offg[q]);
                     }
                 }
+                TR_STAMP(t - za, 2);
                 __syncthreads();
+                TR_STAMP(t - za, 3);
+            };
+#pragma unroll 1
+            for (int t = za - 5; t < zb; t += 2) {
+                iteration(t, xa[0], ga[0], zin[0]);
+                if (t + 1 < zb) iteration(t + 1, xa[1], ga[1], zin[1]);
             }
         }
     }
