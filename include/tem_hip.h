@@ -214,6 +214,15 @@ int tem_conv3d_wgrad_gscaled(const float* x, int64_t x_ld, const float* scale, c
                              const float* g, int64_t g_ld, const float* w, const float* gamma, const float* beta,
                              float* dw, float* db, float* norm_sums, const unsigned* g_amax, void* ws, int64_t ws_bytes,
                              int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, tem_stream_t stream);
+/* max |y| of a tensor as a BY-PRODUCT of the launch that writes it (saves tem_absmax's pass over the tensor):
+ * tem_arm_output_amax(p) attaches the device word p (cleared by the caller) to the calling thread's NEXT launch.  If that
+ * entry point is one of the producers of data gradients that support it -- tem_maxpool3d_bwd / _bwd_norm, tem_conv3d_fwd on
+ * the 1x1x1 streaming / expanding kernels and on the z-reuse kernel with a ReLU mask, tem_conv3d_fwd_refnorm -- the
+ * launch also leaves the bit pattern of max |y| in *p (integer atomicMax) and consumes the
+ * request.  tem_disarm_output_amax() clears it and returns 1 when it was NOT consumed (the caller then runs tem_absmax).
+ * Never affects the values written. */
+int tem_arm_output_amax(unsigned* amax);
+int tem_disarm_output_amax(void);
 /* *amax = max(*amax, bit pattern of max |x|) over nvox rows of C floats (row stride ld): integer atomicMax, exact and
  * order-independent; the caller clears the word.  The prescale source of tem_conv3d_wgrad_gscaled / tem_conv3d_fwd_gscaled
  * when no producer of the tensor delivered it (no reference counterpart: torch.autocast has no per-tensor scale). */

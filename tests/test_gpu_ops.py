@@ -697,6 +697,63 @@ def test_wgrad_fp16_two_by_one_with_device_prescale(case, gscale, kernel, wgrad_
     assert torch.equal(dw, dw2)
 
 
+def test_output_amax_is_a_by_product_of_the_gradient_producers():
+    """tem_arm_output_amax: the kernels that write the data gradients of the big levels (max-pool backward, the 1x1x1
+    expanding / streaming data gradients, the z-reuse data gradient with a ReLU mask or a fused norm backward) deliver the
+    exact bit pattern of max |output|; a launch that does not support it leaves the request armed."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(21)
+
+    def armed(fn):
+        am = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.arm_output_amax(am)
+        out = fn()
+        left = ops.disarm_output_amax()
+        return out, am, left
+
+    def bits(t):
+        return int(t.abs().max().view(torch.int32).item())
+
+    # max-pool backward merging a skip gradient, ReLU mask
+    N, D, H, W, C = 2, 8, 16, 16, 32
+    x = to5(torch.randn(N, C, D, H, W, generator=gen))
+    gy = to5(torch.randn(N, C, D // 2, H // 2, W // 2, generator=gen) * 3e-6)
+    gs = to5(torch.randn(N, C, D, H, W, generator=gen) * 1e-6)
+    gx = torch.empty_like(x)
+    out, am, left = armed(lambda: ops.maxpool_bwd(gy, x, gx, (2, 2, 2), gskip=gs, relu_mask=True))
+    assert not left and int(am.item()) == bits(out)
+    # out_conv data gradient (2 -> 32 channels, masked): expanding kernel
+    ref = to5(torch.randn(N, 32, D, H, W, generator=gen))
+    w = torch.randn(2, 32, 1, 1, 1, generator=gen).to(DEV)
+    g2 = to5(torch.randn(N, 2, D, H, W, generator=gen) * 1e-5)
+    y = torch.empty_like(ref)
+    out, am, left = armed(lambda: ops.conv_fwd(g2, ops.pack_weights(w, transpose=True, mfma=0), None, y, (1, 1, 1), 2, 32, ref=ref, mfma=0))
+    assert not left and int(am.item()) == bits(out)
+    # sampler data gradient (1x1x1, >= 16384 voxels): streaming kernel
+    N, D, H, W = 1, 16, 32, 32
+    w = (torch.randn(32, 64, 1, 1, 1, generator=gen) * 0.1).to(DEV)
+    g3 = to5(torch.randn(N, 32, D, H, W, generator=gen) * 1e-4)
+    ref = to5(torch.randn(N, 64, D, H, W, generator=gen))
+    y = torch.empty_like(ref)
+    out, am, left = armed(lambda: ops.conv_fwd(g3, ops.pack_weights(w, transpose=True, mfma=2), None, y, (1, 1, 1), 32, 64, ref=ref, mfma=2))
+    assert not left and int(am.item()) == bits(out)
+    # 3x3x3 data gradient on the z-reuse kernel: with a ReLU mask it delivers, without one it leaves the request armed
+    N, D, H, W = 2, 32, 64, 64
+    w = (torch.randn(32, 32, 3, 3, 3, generator=gen) * 0.1).to(DEV)
+    g4 = to5(torch.randn(N, 32, D, H, W, generator=gen) * 1e-3)
+    ref = to5(torch.randn(N, 32, D, H, W, generator=gen))
+    y = torch.empty_like(ref)
+    wp = ops.pack_weights(w, transpose=True, mfma=2)
+    assert ops.conv_fwd_family(g4, (3, 3, 3), 32, 32, 2) == 3
+    out, am, left = armed(lambda: ops.conv_fwd(g4, wp, None, y, (3, 3, 3), 32, 32, ref=ref, mfma=2))
+    assert not left and int(am.item()) == bits(out)
+    coef = torch.rand(N, 32, 4, generator=gen).to(DEV)
+    out, am, left = armed(lambda: ops.conv_fwd_refnorm(g4, wp, y, (3, 3, 3), 32, 32, ref, coef, 2))
+    assert not left and int(am.item()) == bits(out)
+    out, am, left = armed(lambda: ops.conv_fwd(g4, wp, None, y, (3, 3, 3), 32, 32, mfma=2))
+    assert left and int(am.item()) == 0
+
+
 def test_wgrad_fp16_two_by_one_zero_gradient_and_norm_sums():
     """all-zero g (max |g| = 0: no prescale) gives zeros; with sums_from the norm-backward sums come out as for bf16x3"""
     ops = _ops()

@@ -696,7 +696,7 @@ def test_graph_is_dropped_when_a_checkpoint_is_loaded(tmp_path, mixed):
         t.hip_graph = bool(hip_graph)
         t.fit(iterations=4)
         first = t._graphed
-        t.save_checkpoint("mid", t.current_metric, t.best_metric)
+        t.save_checkpoint("mid", 0.5, 0.5)
         t.fit(iterations=2)                       # moves on to iteration 6 ...
         t.load_checkpoint("mid")                  # ... and back to the state of iteration 4
         assert t._iteration == 4 and t._graphed is None

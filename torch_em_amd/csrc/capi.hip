@@ -67,6 +67,23 @@ extern "C" int tem_get_option(const char* name, int64_t* value) {
 }
 extern "C" int tem_version(void) { return 100; }
 
+// ---- output amax: one-shot request attached to the calling thread's NEXT launch -------------------------------------
+static thread_local unsigned* g_output_amax = nullptr;
+unsigned* tem_take_output_amax() {
+    unsigned* p = g_output_amax;
+    g_output_amax = nullptr;
+    return p;
+}
+extern "C" int tem_arm_output_amax(unsigned* amax) {
+    g_output_amax = amax;
+    return TEM_OK;
+}
+extern "C" int tem_disarm_output_amax(void) {
+    const int pending = g_output_amax != nullptr;
+    g_output_amax = nullptr;
+    return pending;
+}
+
 extern "C" int tem_device_cus(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return TEM_ELAUNCH;

@@ -15,8 +15,10 @@ __global__ __launch_bounds__(256) void k_conv1x1_stream(const float* __restrict_
                                                         const unsigned short* __restrict__ wp,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         int64_t y_ld, const float* __restrict__ ref, int64_t ref_ld,
-                                                        int64_t NV, int Cin, int Cout, int act, int64_t nmt) {
+                                                        int64_t NV, int Cin, int Cout, int act, int64_t nmt,
+                                                        unsigned* __restrict__ amax) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float amx = 0.f;
     const int r = lane & 31, kh = lane >> 5;
     const int ctg = blockIdx.y;                 // group of CT Cout tiles
     const int nks = Cin >> 4;
@@ -100,11 +102,13 @@ __global__ __launch_bounds__(256) void k_conv1x1_stream(const float* __restrict_
                             o.w = rv.w > 0.f ? o.w : 0.f;
                         }
                         *reinterpret_cast<float4*>(y + v * y_ld + co) = o;
+                        amx = tem_amax4(amx, o.x, o.y, o.z, o.w);
                     }
                 }
             }
         }
     }
+    if (amax) tem_amax_commit(amax, amx);
 }
 
 template <int NS, bool F16>
@@ -117,12 +121,13 @@ static void stream_launch(const float* x, int64_t x_ld, const float* wp, const f
     int64_t gx = (nmt + 3) / 4;
     if (gx > 8192) gx = 8192;   // grid-stride: 8 workgroups per CU keep the loads in flight
     const dim3 grid((unsigned)gx, (unsigned)ngroups);
+    unsigned* const amax = tem_take_output_amax();
     if (CT == 2)
         hipLaunchKernelGGL((k_conv1x1_stream<NS, F16, 2>), grid, dim3(256), 0, s, x, x_ld, (const unsigned short*)wp, bias, y, y_ld,
-                           ref, ref_ld, NV, Cin, Cout, act, nmt);
+                           ref, ref_ld, NV, Cin, Cout, act, nmt, amax);
     else
         hipLaunchKernelGGL((k_conv1x1_stream<NS, F16, 1>), grid, dim3(256), 0, s, x, x_ld, (const unsigned short*)wp, bias, y, y_ld,
-                           ref, ref_ld, NV, Cin, Cout, act, nmt);
+                           ref, ref_ld, NV, Cin, Cout, act, nmt, amax);
 }
 
 // nsplit as in tem_conv_fwd_bf16x3: 2 = bf16x3, 3 = bf16x6, 5 = one fp16 term, 7 = one bf16 term.  false: not taken (pre-norm, statistics, the

@@ -1106,9 +1106,11 @@ __global__ __launch_bounds__(256) void k_conv1x1_expand(const float* __restrict_
                                                         const float* __restrict__ w /*[ci][co]*/,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         int64_t y_ld, const float* __restrict__ ref, int64_t ref_ld,
-                                                        int64_t NV, int Cin, int Cout, int act) {
+                                                        int64_t NV, int Cin, int Cout, int act,
+                                                        unsigned* __restrict__ amax) {
     const int cq = Cout >> 2;
     const int64_t items = NV * cq, stride = (int64_t)gridDim.x * 256;
+    float amx = 0.f;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t v = i / cq;
     int q = (int)(i % cq);
@@ -1140,7 +1142,9 @@ __global__ __launch_bounds__(256) void k_conv1x1_expand(const float* __restrict_
             if (!(rr.w > 0.f)) a.w = 0.f;
         }
         ST4(y + v * y_ld + q * 4, a);
+        amx = tem_amax4(amx, a.x, a.y, a.z, a.w);
     }
+    if (amax) tem_amax_commit(amax, amx);
 }
 
 bool tem_conv1x1_expand(const float* x, int64_t x_ld, const float* scale, const float* w, const float* bias, float* y,
@@ -1150,6 +1154,6 @@ bool tem_conv1x1_expand(const float* x, int64_t x_ld, const float* scale, const 
         (bias && (uintptr_t)bias % 16) || (ref && (ref_ld % 4 || (uintptr_t)ref % 16)))
         return false;
     hipLaunchKernelGGL(k_conv1x1_expand, dim3(tem_grid_1d(NV * (Cout / 4), 256, 256 * 16)), dim3(256), 0, s, x, x_ld, w,
-                       bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act);
+                       bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, tem_take_output_amax());
     return true;
 }

@@ -146,8 +146,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
-    int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax, int ks, int blk) {
+    int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax, int ks, int blk,
+    unsigned* __restrict__ out_amax) {
     static_assert(!KSPLIT || MODE == 0, "split-K units write raw partial sums");
+    constexpr bool AMAX = MODE == 2 || MODE == 3;   // data gradients: max |y| as a by-product (tem_arm_output_amax)
+    float amx = 0.f;
     static_assert(!WIDE || NS == 2, "the wide one-term kernel uses the two LDS planes of the two-term layout");
     constexpr int CK = WIDE ? 2 * BCK : BCK;     // input channels per phase
     constexpr int TZ = 4, TY = 16, TX = 8;
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                                 t[m].w = q[z & 1][m].w > 0.f ? t[m].w : 0.f;
                             }
                             const bool sok = FULL || (tok_yx & (eu.y0 + 4 * tw + m < H) & (eu.z0 + z < D));
+                            if (AMAX && sok) amx = tem_amax4(amx, t[m].x, t[m].y, t[m].z, t[m].w);
                             if (sok && (!(TEM_ZR_ABL & 2) || t[m].x == 12345.678f))
                                 zr_store4<KSPLIT ? TEM_ZR_ST_AUX_KS : TEM_ZR_ST_AUX>(ry, yoff_l, (zo + (unsigned)(m * W)) * (unsigned)y_ld * 4u, t[m].x, t[m].y, t[m].z, t[m].w);
                         }
@@ -718,6 +722,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
         ZR_STAMP(5);
     }
     if (!team) __syncthreads();
+    if (AMAX && out_amax) tem_amax_commit(out_amax, amx);
 }
 
 // ---------------------------------------------------------------------------
@@ -787,9 +792,10 @@ static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float
     }
     int64_t grid = (g.nunits + 1) / 2;
     if (grid > ncu) grid = ncu;
+    unsigned* const out_amax = (MODE == 2 || MODE == 3) ? tem_take_output_amax() : nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp),
                        bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits, in_amax, ks,
-                       zr_tile_blocks(g));
+                       zr_tile_blocks(g), out_amax);
 }
 
 // Split-K launch for shapes zr_geometry() declines only because they have too few (tile, column tile) units: the input

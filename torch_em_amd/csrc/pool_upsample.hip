@@ -114,9 +114,11 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
                                                      const float* __restrict__ gskip, int64_t gskip_ld, int relu_mask,
                                                      float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
                                                      int fz, int fy, int fx, const float* __restrict__ gcoef,
-                                                     int64_t gcoef_ld, const float* __restrict__ ycoef) {
+                                                     int64_t gcoef_ld, const float* __restrict__ ycoef,
+                                                     unsigned* __restrict__ amax) {
     const int Do = D / fz, Ho = H / fy, Wo = W / fx;
     const int cq = C / VEC;
+    float amx = 0.f;
     int row = blockIdx.x;
     const int yo = row % Ho;
     row /= Ho;
@@ -182,10 +184,12 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
                         if (am[j] == k) v += g[j];
                         if (relu_mask && !(t[k][j] > 0.f)) v = 0.f;
                         o[k][j] = v;
+                        amx = __builtin_fmaxf(amx, __builtin_fabsf(v));
                     }
                     st_vec<VEC>(gx + vk[k] * gx_ld + c0, o[k]);
                 }
         }
+        if (amax) tem_amax_commit(amax, amx);
         return;
     }
     for (int i = threadIdx.x; i < Wo * cq; i += 256) {
@@ -250,10 +254,12 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
                     for (int j = 0; j < VEC; ++j) {
                         if (am[j] == k) o[j] += g[j];
                         if (relu_mask && !(t[j] > 0.f)) o[j] = 0.f;
+                        amx = __builtin_fmaxf(amx, __builtin_fabsf(o[j]));
                     }
                     st_vec<VEC>(gx + v * gx_ld + c0, o);
                 }
     }
+    if (amax) tem_amax_commit(amax, amx);
 }
 
 extern "C" int tem_maxpool3d_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W,
@@ -283,12 +289,13 @@ static int maxpool3d_bwd_impl(const float* gy, int64_t gy_ld, const float* x, in
                 "tem_maxpool3d_bwd: shape (%d,%d,%d) not divisible by factors (%d,%d,%d)", D, H, W, fz, fy, fx);
     int64_t rows = (int64_t)N * (D / fz) * (H / fy);
     TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_bwd: too many rows");
+    unsigned* const amax = tem_take_output_amax();
     if (vec4_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}))
         hipLaunchKernelGGL((k_maxpool_bwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
-                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef);
+                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef, amax);
     else
         hipLaunchKernelGGL((k_maxpool_bwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
-                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef);
+                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef, amax);
     TEM_CHECK_LAUNCH("tem_maxpool3d_bwd");
     return TEM_OK;
 }

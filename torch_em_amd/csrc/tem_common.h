@@ -57,6 +57,22 @@ static inline int tem_grid_1d(int64_t work_items, int block, int max_blocks = 25
 
 #define TEM_WAVE 64
 
+// "output amax": max |y| of the tensor a launch writes, as a by-product (tem_arm_output_amax, capi.hip).  A launch site
+// that supports it takes the armed device word with tem_take_output_amax(); its kernel keeps a per-thread maximum
+// (tem_amax4) and ends with tem_amax_commit() -- wave reduction, then an integer atomicMax of the bit pattern (exact,
+// order-independent) that most waves skip after one plain read of the word.
+unsigned* tem_take_output_amax();
+__device__ __forceinline__ float tem_amax4(float m, float a, float b, float c, float d) {
+    return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))),
+                           __builtin_fmaxf(__builtin_fabsf(c), __builtin_fabsf(d)));
+}
+__device__ __forceinline__ void tem_amax_commit(unsigned* amax, float m) {   // all lanes of a wave; amax wave-uniform, non-null
+    unsigned u = __builtin_bit_cast(unsigned, m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o, 64));
+    if ((threadIdx.x & 63) == 0 && u > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, u);
+}
+
 __device__ __forceinline__ float tem_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

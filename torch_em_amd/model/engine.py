@@ -190,6 +190,30 @@ def _dgrad16_ok(spec, g) -> bool:
 _WGRAD_F16X2 = os.environ.get("TEM_WGRAD_ARITH", "f16x2") == "f16x2"
 
 
+_FUSE_AMAX = os.environ.get("TEM_FUSE_AMAX", "1") != "0"   # 0: every fp16 2x1 weight gradient runs its own absmax pass
+
+
+class _output_amax:
+    """`with _output_amax(grads, out):` -- the launch inside that writes the data gradient `out` also delivers max |out|
+    (tem_arm_output_amax) for the fp16 2x1 weight gradient that reads `out` next; when no kernel of the launch supports it
+    the consumer falls back to one absmax pass.  `out` must not be modified afterwards (callers that do drop the entry)."""
+
+    def __init__(self, grads, out):
+        self.on = grads is not None and _FUSE_AMAX and _WGRAD_F16X2 and PRECISION == "split16" and not _FORCE_GENERIC
+        self.grads, self.out = grads, out
+
+    def __enter__(self):
+        if self.on:
+            self.slot = self.grads.amax_slot()
+            ops.arm_output_amax(self.slot)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on and not ops.disarm_output_amax() and exc[0] is None:
+            self.out._tem_amax = self.slot   # on the tensor OBJECT: dies with it (an address could be reused by another tensor)
+        return False
+
+
 def _wgrad_f16x2_ok(spec, x, stats) -> bool:
     return _WGRAD_F16X2 and PRECISION == "split16" and stats is not None and not _FORCE_GENERIC and not _OVERLAP_WGRAD and \
         spec.k == (3, 3, 3) and spec.cin % 32 == 0 and spec.cout % 32 == 0 and \
@@ -385,9 +409,15 @@ def _join_side(device):
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
-def _dgrad(spec: ConvSpec, g, gx, ref=None, gmax=None, refnorm=None):
+def _dgrad(spec: ConvSpec, g, gx, ref=None, gmax=None, refnorm=None, grads=None):
     """gmax: int32[1] with max |g| (from _wgrad(..., gmax=) of the same layer) -> fp16 two-term layout, else bf16x3.
-    refnorm: coef [N, C, 4] of the norm behind `ref` -- its backward (and ref's ReLU mask) run in the kernel's epilogue."""
+    refnorm: coef [N, C, 4] of the norm behind `ref` -- its backward (and ref's ReLU mask) run in the kernel's epilogue.
+    grads: gx is FINAL after this call (nothing rewrites it): ask the kernel for max |gx| as a by-product."""
+    with _output_amax(grads, gx):
+        _dgrad_launch(spec, g, gx, ref, gmax, refnorm)
+
+
+def _dgrad_launch(spec: ConvSpec, g, gx, ref, gmax, refnorm):
     if _OVERLAP_WGRAD == 2:
         _join_side(g.device)  # MFMA kernels never overlap each other: wait for the weight gradient in flight
     ent = spec.packed()
@@ -434,6 +464,8 @@ def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None, want_sums=False, gma
                 ops.conv_wgrad_sums_ok(x, spec.k, spec.cin, spec.cout, ent["wgrad_mfma"]):
             _, gamma, beta, _ = spec.norm_args()
             sums_from = (spec.conv.weight, gamma, beta)
+        if amax is None:
+            amax = getattr(g, "_tem_amax", None)
         if amax is None:   # no producer of g delivered max |g|: one pass over g
             amax = ops.absmax(g, grads.amax_slot())
         return ops.conv_wgrad_gscaled(x, g, spec.k, spec.cin, spec.cout, dw, db, amax, scale=scale, shift=shift,
@@ -591,7 +623,7 @@ def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
         # ReLU mask of a1 in its epilogue: no elementwise pass over ga1 and a1 (0.28 ms at 2 x 128^3 x 32)
         sums = _wgrad(c2, a1, gout, grads, bs["s2"], want_sums=True)
         coef = _norm_bwd_inplace(c2, gout, a1, bs["s2"], True, grads, sums=sums, coef_only=True)
-        _dgrad(c2, gout, ga1, ref=a1, refnorm=coef)
+        _dgrad(c2, gout, ga1, ref=a1, refnorm=coef, grads=grads)
     elif bs["s2"] is not None:
         if _dgrad16_ok(c2, gout):   # weight gradient first: it delivers max |gout| for the prescale of the data gradient
             gm = grads.amax_slot()
@@ -835,7 +867,7 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
     last = st["last"]
     if "ospec" in st:
         g_cur = torch.empty_like(last)
-        _dgrad(st["ospec"], g, g_cur, ref=last)
+        _dgrad(st["ospec"], g, g_cur, ref=last, grads=grads)
         _wgrad(st["ospec"], last, g, grads)
     else:
         g_cur = torch.empty_like(last)
@@ -851,12 +883,13 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
                          norm=None if coef is None else (d["t"], coef[:, :lv["c_up"]]))
         lv["g_skip_coef"] = None if coef is None else coef[:, lv["c_up"]:]
         g_low = torch.empty_like(low)
-        _dgrad(sspec, g_t, g_low, ref=low)  # `low` is the ReLU output of the previous block
+        _dgrad(sspec, g_t, g_low, ref=low, grads=grads)  # `low` is the ReLU output of the previous block
         _wgrad(sspec, low, g_t, grads)
         if side is not None and i > 0:
             extra = side_grad(i - 1, low)  # `low` is decoder level i-1's output
             if extra is not None:
                 g_low.add_(extra)
+                g_low._tem_amax = None   # rewritten: the producer's max |g_low| no longer holds
         lv["g_skip"] = g_cat[..., lv["c_up"]:]
         if "crop" in lv:   # the adjoint of the centre crop: zeros around the gradient of the cropped window
             o, sk = lv["crop"], lv["skip"]
@@ -886,8 +919,9 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
             g_skip_full[:, :sub.shape[1], :sub.shape[2], :sub.shape[3]] += g_sub
             g_skip_full.mul_(skip > 0)
         else:
-            ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True,
-                            gskip_coef=lv.get("g_skip_coef"), gy_coef=pool_coef)
+            with _output_amax(grads, g_skip_full):
+                ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True,
+                                gskip_coef=lv.get("g_skip_coef"), gy_coef=pool_coef)
         need_in = (l > 0) or need_input_grad
         xin = lv["bs"]["xin"]
         g_in = torch.empty_like(xin) if need_in else None

@@ -357,6 +357,17 @@ def absmax(x, amax=None):
     return amax
 
 
+def arm_output_amax(amax):
+    """The NEXT library launch of this thread, if it is a producer of data gradients that supports it, also leaves the bit
+    pattern of max |output| in `amax` (int32[1], cleared by the caller): tem_arm_output_amax."""
+    _lib.check(_lib.load().tem_arm_output_amax(_p(amax)), "tem_arm_output_amax")
+
+
+def disarm_output_amax() -> bool:
+    """-> True when the armed request was NOT consumed (the caller then needs absmax())"""
+    return bool(_lib.load().tem_disarm_output_amax())
+
+
 def conv_wgrad_gscaled(x, g, k, cin, cout, dw_out, db_out, amax, scale=None, shift=None, sums_from=None):
     """Weight gradient in the fp16 2x1 arithmetic (tem_conv3d_wgrad_gscaled): x^ two fp16 terms, g one fp16 term prescaled
     from amax = int32[1] with the bit pattern of max |g| (absmax or a producer of g).  sums_from as in conv_wgrad."""
