@@ -49,10 +49,12 @@ RP_NAMES = {
     "k_conv_fwd_f16x3<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 2, true>",
     "k_conv_fwd_f16<3,3,3,NR=2>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 2, 1, true>",
     "k_conv_fwd_f16<3,3,3,NR=1>": "k_conv_fwd_bfsplit<3, 3, 3, 4, 8, 8, 1, 1, true>",
-    "k_conv_wgrad_f16<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, 1>",
-    "k_conv_wgrad_f16<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, 1>",
-    "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_zs<2, 0>",
-    "k_conv_wgrad_bf16x3<3,3,3,NCO=1>": "k_conv_wgrad_zs<1, 0>",
+    "k_conv_wgrad_f16<3,3,3,NCO=2>": "k_conv_wgrad_tr<1>",       # round 4: one instantiation per arithmetic (no NCO variants)
+    "k_conv_wgrad_f16<3,3,3,NCO=1>": "k_conv_wgrad_tr<1>",
+    "k_conv_wgrad_bf16x3<3,3,3,NCO=2>": "k_conv_wgrad_tr<0>",
+    "k_conv_wgrad_bf16x3<3,3,3,NCO=1>": "k_conv_wgrad_tr<0>",
+    "k_conv_wgrad_f16x2<3,3,3,NCO=2>": "k_conv_wgrad_tr<3>",
+    "k_conv_wgrad_f16x2<3,3,3,NCO=1>": "k_conv_wgrad_tr<3>",
 }
 
 SUSTAINED_F16_MFMA_TFLOPS = 1640.0   # measured: profiles/r03_mfma_sustained.txt (pure MFMA stream, random operands, all CUs)
@@ -65,8 +67,11 @@ PRECISION_DTYPE = {
              "backward convs: 2 terms / 3 MFMAs; fp32 accumulate)",
     "split16": "f32-class (forward convs on normalised activations: fp32 operands split into 2 fp16 terms = 22 mantissa "
                "bits, lo plane scaled by 2^12 with its own fp32 accumulator, 3 fp16 MFMAs per product; other forward "
-               "convs 3 bf16 terms / 6 MFMAs; backward convs 2 bf16 terms / 3 MFMAs; fp32 accumulate; gradient error vs "
-               "float64 = that of the fp32 reference path, tests/test_gpu_unet.py)",
+               "convs 3 bf16 terms / 6 MFMAs; data-gradient convs 2 bf16 terms / 3 MFMAs (16-bit products); WEIGHT-gradient "
+               "convs of the pre-normalised 3x3x3 layers: xhat 2 fp16 terms x g ONE fp16 term after a power-of-two prescale from "
+               "max|g| = 2 MFMAs per product, ~2e-4 unbiased relative noise on those dw tensors (profiles/"
+               "r04_backward_arith_sim.txt; TEM_WGRAD_ARITH=bf16x3 restores 3 MFMAs: key wgrad_bf16x3_ms_per_step); fp32 "
+               "accumulate and storage; gradient error vs float64 = that of the fp32 reference path, tests/test_gpu_unet.py)",
     "bf16x3": "bf16x3 (all MFMA convs split-bf16, fp32 accumulate)",
     "amp": "f16 operands (REDUCED PRECISION, not the headline configuration: conv operands rounded to fp16, one fp16 MFMA "
            "per product, fp32 accumulate and storage -- the counterpart of the reference's torch.autocast(float16); no "
@@ -138,6 +143,13 @@ def extra_measurements(step, args, engine):
                               ("amp_bf16", "amp_bf16_ms_per_step")):
                 engine.set_precision(prec)
                 out[key] = timed()
+            # the default arithmetic with the three-product (bf16x3) weight gradients of rounds 1-3
+            engine.set_precision(prev)
+            f16x2, engine._WGRAD_F16X2 = engine._WGRAD_F16X2, False
+            try:
+                out["wgrad_bf16x3_ms_per_step"] = timed(n=5)
+            finally:
+                engine._WGRAD_F16X2 = f16x2
         engine.set_precision(prev)
         spec = importlib.util.spec_from_file_location("bench_workloads", os.path.join(ROOT, "scripts", "bench_workloads.py"))
         wl = importlib.util.module_from_spec(spec)
@@ -368,8 +380,8 @@ def main():
             dom["flops"] += flops
         achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s (algorithmic: 2*MACs of the convolution)
         split = 6 if "bf16x6" in dom_tag else (3 if ("bf16x3" in dom_tag or "f16x3" in dom_tag) else
-                                               1 if "_f16<" in dom_tag else 0)
-        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_bytes_per_launch.json") for r in (3, 2, 1))
+                                               2 if "f16x2" in dom_tag else 1 if "_f16<" in dom_tag else 0)
+        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_bytes_per_launch.json") for r in (4, 3, 2, 1))
                              if os.path.exists(f)), "")
         # split-bf16 kernels execute 3 (or 6) bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3 (6)
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
@@ -394,7 +406,10 @@ def main():
                                    + ("" if standard else " (NON-STANDARD SIZE)"),
                        "parallelism": f"dp{world}", "global_batch": world * args.batch, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "kernel": dom_tag,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "traffic_source": (os.path.relpath(traffic_file, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                            "an earlier run of this command, not measured in this run)") if traffic is not None else None,
+                         "kernel": dom_tag,
                          "peak_note": (f"dense bf16 MFMA peak 2500 TFLOP/s / {split} MFMAs per product (split-bf16, fp32 "
                                        "accumulate); executed-MFMA fraction of 2500 = frac" if split else
                                        "exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),

@@ -19,8 +19,8 @@
 //     their three tx taps and one tap of row group 8 (7 / 7 / 7 / 6 accumulator tiles of one (Cin tile, Cout tile) pair); the
 //     three tx fragments of a row group come out of ONE 12-voxel window (three transposing reads + 4 v_alignbyte for
 //     tx = 1: the first version read every tap's fragment separately and ran at 1.6 GHz with the matrix pipe 0.62 busy --
-//     LDS reads cost power too) -- waves 4..7 only stage (next x plane into the free slot of
-//     the 4-plane ring, next g plane into the free buffer); one barrier per plane; persistent over column segments, one
+//     LDS reads cost power too) -- waves 4..7 only stage (x planes into a 5-slot ring, g planes
+//     into 3 buffers, two planes ahead of the multiplication; global loads four planes ahead); one barrier per plane; persistent over column segments, one
 //     partial slab per workgroup (format of k_conv_wgrad_zt: KS2 = 1).
 // ARITH: 0 bf16x3 (x^ and g two bf16 terms, 3 MFMAs per product), 1 one fp16 term each (mixed precision), 2 one bf16 term
 // each, 3 fp16 2x1 (x^ two fp16 terms, g one fp16 term prescaled from *g_amax: the default of the fp32-class mode).
@@ -33,9 +33,13 @@
 #define TR_REC 64                  // bytes per voxel record: 32 channels x 16 bit
 #define TR_XROW (10 * TR_REC)      // a halo row: 10 voxels
 #define TR_XPL (10 * TR_XROW)      // a halo plane: 10 rows
-#define TR_XT (4 * TR_XPL)         // one term of x^: ring of 4 halo planes
+#define TR_NXS 5                   // ring slots of x^ halo planes: 3 being multiplied + 1 prefetched by the multiplying team + 1 being written
+#define TR_NGS 3                   // g planes: multiplied, prefetched, being written
+#define TR_XT (TR_NXS * TR_XPL)    // one term of x^
 #define TR_GPL (64 * TR_REC)       // a g plane: 8 x 8 voxels
-#define TR_GT (2 * TR_GPL)         // one term of g: two buffers
+#define TR_GT (TR_NGS * TR_GPL)    // one term of g
+#define TR_XSLOT(p) ((((p) + 2 * TR_NXS) % TR_NXS) * TR_XPL)   // byte offset of the ring slot of halo plane p (p >= -2 TR_NXS)
+#define TR_GSLOT(p) ((((p) + 3 * TR_NGS) % TR_NGS) * TR_GPL)
 
 typedef short tr_s4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) tr_s4* tr_lds_p;
@@ -163,73 +167,76 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
         for (int cz = sp % S; cz < ncz; cz += S) {
             const int zseg = cz % zsegs;
             const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
-            for (int t = za - 5; t < za; ++t) __syncthreads();   // the staging team primes the ring (five iterations)
+            for (int t = za - 6; t < za; ++t) __syncthreads();   // the staging team primes the ring (six iterations)
+            // Software pipeline over the 4 k-slabs x (term) phases of a plane: the fragment reads of the NEXT phase are issued
+            // between the MFMAs of the current one (sched_group_barrier), so a phase never starts by waiting for LDS -- and
+            // the last phase of a plane reads the first fragments of the NEXT plane: the staging team is one plane further
+            // ahead than the ring of k_conv_wgrad_zs (5 x^ slots, 3 g buffers), so that data is complete before this plane
+            // starts and the barrier at its end only hands slots back (first version: 340 cycles of LDS latency per plane).
+            // Phases of slab sl: [x lo * g hi] (NX == 2), [x hi * g lo] (NG == 2), [x hi * g hi]; products small first.
+            uint4 gh, gl, xh[NA], xl[NA];
+            auto load_g = [&](const unsigned char* gb, int sl) {
+                if ((TEM_TR_ABL & 4) && sl > 0) return;
+                gh = tr_frag(gb + sl * 16 * TR_REC);
+                if (NG == 2) gl = tr_frag(gb + TR_GT + sl * 16 * TR_REC);
+            };
+            auto load_x = [&](uint4* f, const unsigned char* const* xb, int term, int sl) {
+                if ((TEM_TR_ABL & 4) && sl > 0) return;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const unsigned char* p = xb[a] + term * TR_XT + sl * 2 * TR_XROW;
+                    const uint2 w0 = tr_read(p), w1 = tr_read(p + 4 * TR_REC), w2 = tr_read(p + 8 * TR_REC);
+                    f[3 * a + 0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
+                    f[3 * a + 1] = make_uint4(__builtin_amdgcn_alignbyte(w0.y, w0.x, 2), __builtin_amdgcn_alignbyte(w1.x, w0.y, 2),
+                                              __builtin_amdgcn_alignbyte(w1.y, w1.x, 2), __builtin_amdgcn_alignbyte(w2.x, w1.y, 2));
+                    f[3 * a + 2] = make_uint4(w0.y, w1.x, w1.y, w2.x);
+                }
+                f[6] = tr_frag(xb[2] + term * TR_XT + sl * 2 * TR_XROW);
+            };
+            auto interleave = [&]() {   // the 7 MFMAs of the phase just written and the reads / shifts for the next one:
+                // reads behind the first three MFMAs, the v_alignbyte of the tx = 1 fragments behind the last three (their
+                // reads have returned by then: an LDS wait inside the MFMA stream would stall the matrix pipe)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto bases = [&](int t, const unsigned char** xb) -> const unsigned char* {   // fragment bases of plane t
+#pragma unroll
+                for (int a = 0; a < 3; ++a) xb[a] = X0 + lane_x + TR_XSLOT(t + rgtz[a] - 1) + rgoff[a];
+                return G0 + lane_g + TR_GSLOT(t);
+            };
+            {   // first fragments of the segment's first plane
+                const unsigned char* xb0[3];
+                const unsigned char* gb0 = bases(za, xb0);
+                load_g(gb0, 0);
+                load_x(NX == 2 ? xl : xh, xb0, NX == 2 ? 1 : 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll 1
             for (int t = za; t < zb; ++t) {
-                const unsigned char* xb[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) xb[a] = X0 + lane_x + ((t + rgtz[a] - 1 + 4) & 3) * TR_XPL + rgoff[a];
-                const unsigned char* gb = G0 + lane_g + (t & 1) * TR_GPL;
-                // Software pipeline over the 4 k-slabs x (term) phases of a plane: the fragment reads of the NEXT phase are
-                // issued between the MFMAs of the current one (sched_group_barrier: 1 MFMA, then up to 3 LDS reads -- a wave
-                // hides ~5 other instructions per 32-cycle MFMA), so a phase never starts by waiting for LDS.
-                // Phases of slab sl: [x lo * g hi] (NX == 2), [x hi * g lo] (NG == 2), [x hi * g hi]; products small first.
-                uint4 gh, gl, xh[NA], xl[NA];
-                auto load_g = [&](int sl) {
-                    if ((TEM_TR_ABL & 4) && sl > 0) return;
-                    gh = tr_frag(gb + sl * 16 * TR_REC);
-                    if (NG == 2) gl = tr_frag(gb + TR_GT + sl * 16 * TR_REC);
-                };
-                auto load_x = [&](uint4* f, int term, int sl) {
-                    if ((TEM_TR_ABL & 4) && sl > 0) return;
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const unsigned char* p = xb[a] + term * TR_XT + sl * 2 * TR_XROW;
-                        const uint2 w0 = tr_read(p), w1 = tr_read(p + 4 * TR_REC), w2 = tr_read(p + 8 * TR_REC);
-                        f[3 * a + 0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
-                        f[3 * a + 1] = make_uint4(__builtin_amdgcn_alignbyte(w0.y, w0.x, 2), __builtin_amdgcn_alignbyte(w1.x, w0.y, 2),
-                                                  __builtin_amdgcn_alignbyte(w1.y, w1.x, 2), __builtin_amdgcn_alignbyte(w2.x, w1.y, 2));
-                        f[3 * a + 2] = make_uint4(w0.y, w1.x, w1.y, w2.x);
-                    }
-                    f[6] = tr_frag(xb[2] + term * TR_XT + sl * 2 * TR_XROW);
-                };
-                auto load_xh = [&](int sl) { load_x(xh, 0, sl); };
-                auto load_xl = [&](int sl) { load_x(xl, 1, sl); };
-                auto interleave = [&]() {   // the 7 MFMAs of the phase just written and the reads / shifts for the next one:
-                    // reads behind the first three MFMAs, the v_alignbyte of the tx = 1 fragments behind the last three (their
-                    // reads have returned by then: an LDS wait inside the MFMA stream would stall the matrix pipe)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                };
+                const unsigned char *xb[3], *xbn[3];
+                const unsigned char* gb = bases(t, xb);
+                const unsigned char* gbn = bases(t + 1, xbn);
                 TR_STAMP(t - za, 0);
                 if (TEM_TR_ABL & 2) {
                     __syncthreads();
                     continue;
                 }
-                load_g(0);
-                if (NX == 2) load_xl(0);
-                else load_xh(0);
-                __builtin_amdgcn_sched_barrier(0);
-#ifdef TEM_TR_TRACE
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 TR_STAMP(t - za, 1);
-                __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) {
                     if (NX == 2) {
-                        load_xh(sl);   // for the next phase of this slab
+                        load_x(xh, xb, 0, sl);   // for the next phase of this slab
 #pragma unroll
                         for (int j = 0; j < NA; ++j) acc[j] = mfma16<F16>(xl[j], gh, acc[j]);
                         interleave();
@@ -239,18 +246,17 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                         for (int j = 0; j < NA; ++j) acc[j] = mfma16<F16>(xh[j], gl, acc[j]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    // last phase of the slab: the g fragment(s) and the first x operand of the next slab are read meanwhile
-                    // (into a second g register set: this phase still multiplies with the current one)
+                    // last phase of the slab: the g fragment(s) and the first x operand of the next slab -- after slab 3: of
+                    // the next PLANE -- are read meanwhile (into a second g register set: this phase still multiplies with
+                    // the current one)
                     const uint4 ghc = gh;
-                    if (sl < 3) {
-                        load_g(sl + 1);
-                        if (NX == 2) load_xl(sl + 1);
-                    }
+                    load_g(sl < 3 ? gb : gbn, (sl + 1) & 3);
+                    if (NX == 2) load_x(xl, sl < 3 ? xb : xbn, 1, (sl + 1) & 3);
 #pragma unroll
                     for (int j = 0; j < NA; ++j) acc[j] = mfma16<F16>(xh[j], ghc, acc[j]);
-                    if (NX == 1 && sl < 3) {   // one-term x: its next fragments can only follow the MFMAs that read the current ones
+                    if (NX == 1) {   // one-term x: its next fragments can only follow the MFMAs that read the current ones
                         __builtin_amdgcn_sched_barrier(0);
-                        load_xh(sl + 1);
+                        load_x(xh, sl < 3 ? xb : xbn, 0, (sl + 1) & 3);
                     }
                     interleave();
                 }
@@ -325,17 +331,18 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                 offg[q] = ok ? (unsigned)((hy * W + hx) * (int)g_ld + cog * 32 + quad * 4) * 4u : OOB;
             }
             bool zin[2] = {false, false};   // the set's x plane lies inside the volume (wave-uniform)
-            // iteration t: the multiplying team works on plane t (if t >= za); this team converts and stores the register set
-            // loaded two iterations ago (x plane t + 2 into ring slot (t + 2) & 3, g plane t + 1 into buffer (t + 1) & 1), loads
-            // x plane t + 4 and g plane t + 3 into the same set, and joins the barrier.  Planes -1 and D are stored as zeros.
+            // iteration t: the multiplying team works on plane t (if t >= za) and prefetches the first fragments of plane t + 1;
+            // this team converts and stores the register set loaded two iterations ago (x plane t + 3 into its ring slot,
+            // g plane t + 2 into its buffer), loads x plane t + 5 and g plane t + 4 into the same set, and joins the barrier.
+            // Planes -1 and D are stored as zeros.
             auto iteration = [&](int t, float4(&xs_)[4], float4(&gs_)[2], bool& zin_) {
                 TR_STAMP(t - za, 0);
                 if (TEM_TR_ABL & 1) {
                     __syncthreads();
                     return;
                 }
-                if (t >= za - 3) {
-                    unsigned char* const xs = X0 + ((t + 2 + 4) & 3) * TR_XPL + quad * 8;
+                if (t >= za - 4) {
+                    unsigned char* const xs = X0 + TR_XSLOT(t + 3) + quad * 8;
                     if (zin_) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -366,8 +373,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                         }
                     }
                 }
-                if (t + 1 >= za && t + 1 < zb) {
-                    unsigned char* const gs = G0 + ((t + 1) & 1) * TR_GPL + quad * 8;
+                if (t + 2 >= za && t + 2 < zb) {
+                    unsigned char* const gs = G0 + TR_GSLOT(t + 2) + quad * 8;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int gv = (tl + 256 * q) >> 3;
@@ -394,14 +401,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                 }
                 TR_STAMP(t - za, 1);
                 {
-                    const int zx = t + 4;
+                    const int zx = t + 5;
                     zin_ = zx >= za - 1 && zx <= zb && zx >= 0 && zx < D;   // wave-uniform
                     if (zin_ && !(TEM_TR_ABL & 8)) {
                         const tr_rsrc_t rsx = tr_rsrc(xn + zx * xplane);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) xs_[q] = tr_load4(rsx, offx[q]);
                     }
-                    const int zg = t + 3;
+                    const int zg = t + 4;
                     if (zg >= za && zg < zb && !(TEM_TR_ABL & 8)) {
                         const tr_rsrc_t rsg = tr_rsrc(gn + zg * gplane);
 #pragma unroll
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                 TR_STAMP(t - za, 3);
             };
 #pragma unroll 1
-            for (int t = za - 5; t < zb; t += 2) {
+            for (int t = za - 6; t < zb; t += 2) {
                 iteration(t, xa[0], ga[0], zin[0]);
                 if (t + 1 < zb) iteration(t + 1, xa[1], ga[1], zin[1]);
             }
