@@ -311,17 +311,41 @@ def main():
         ops.PROFILER = []
     if isinstance(model, DDP):
         model.sync.exposed_ms()   # drop the warm-up steps' events
+    # TEM_HIP_GRAPH=1: the timed steps are replays of ONE captured HIP graph (torch_em_amd/graph.py; with DDP the RCCL
+    # all-reduces are nodes of it).  Per-launch events cannot be taken inside a replay, so the dominant kernel's events and
+    # the exposed all-reduce time come from `ev_eager` eager steps right before the timed region.
+    graphed = None
+    ddp_exposed_eager = None
+    if os.environ.get("TEM_HIP_GRAPH", "0") == "1":
+        from torch_em_amd.graph import GraphedTrainStep
+        for i in range(n_ev):   # on EVERY rank: the eager steps carry collectives
+            ops.PROFILER_FILTER = {dom_tag} if ev_steps else set()
+            step()
+        torch.cuda.synchronize()
+        if isinstance(model, DDP):
+            ddp_exposed_eager = model.sync.exposed_ms()
+        eager_dom_prof, ops.PROFILER, ops.PROFILER_FILTER = ops.PROFILER or [], None, None
+        graphed = GraphedTrainStep(model, loss_fn, opt, x, y)
+        for _ in range(2):
+            graphed(x, y)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ev_steps = set()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if ev_steps:
             ops.PROFILER_FILTER = {dom_tag} if i in ev_steps else set()
-        loss = step()
+        loss = graphed(x, y)[1] if graphed is not None else step()
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # until the last launch was enqueued (the GPU may lag)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dom_prof, ops.PROFILER, ops.PROFILER_FILTER = ops.PROFILER or [], None, None
+    if graphed is not None:
+        dom_prof, ev_steps = eager_dom_prof, (set(range(n_ev)) if (rank == 0 and dom_tag is not None) else set())
     per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -334,7 +358,8 @@ def main():
     ddp_info = None
     if isinstance(model, DDP):
         ddp_info = {"bytes": model.sync.stats["bytes"], "n_collectives": model.sync.stats["n_collectives"],
-                    "allreduce_exposed_ms": model.sync.exposed_ms(), "ranks": dist.get_world_size(),
+                    "allreduce_exposed_ms": ddp_exposed_eager if graphed is not None else model.sync.exposed_ms(),
+                    "ranks": dist.get_world_size(),
                     "backend": dist.get_backend(), "per_rank_ms_per_step": per_rank_ms,
                     "note": "bytes / collectives of one step's gradient exchange (in-place all-reduce of arena ranges on "
                             "RCCL's stream, overlapped with backward); allreduce_exposed_ms = mean time the compute stream "
@@ -400,6 +425,9 @@ def main():
             "metric": "voxels/sec fwd+bwd, UNet3d 1x128^3 bs=2",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "host_enqueue_ms_per_step": host_enqueue_ms,
+            "step_mode": ("one HIP graph replay per step (TEM_HIP_GRAPH=1; roofline events from eager steps before the timed "
+                          "region)" if graphed is not None else "eager launches"),
             "dtype": PRECISION_DTYPE[engine.PRECISION], "data": "synthetic",
             "config": {"workload": f"UNet3d(1->2, initial_features=32, depth=4, norm={args.norm}) + DiceLoss, "
                                    f"zero_grad+fwd+loss+bwd+AdamW, per-GPU batch {args.batch}x1x{S}^3"

@@ -65,7 +65,7 @@ with open(dst + "_pmc_summary.txt", "w") as f:
         traffic[k] = byts
         # GRBM_GUI_ACTIVE also counts the dispatch ramp around a launch: the derived clock is meaningless (> 2.4 GHz) for
         # launches shorter than ~40 us, so it is only printed for longer ones
-        ghz = f"{cyc / d:5.2f}" if d >= 40e3 else "    -"
+        ghz = f"{cyc / d:5.2f}" if (d >= 200e3 and cyc / d <= 2.45) else "    -"   # launches < 200 us still showed > 2.4 GHz
         f.write(f"{k:80s} {len(dur[k]):8d} {d / 1e3:9.1f} {2 * fe / 1024:11.1f} {wr / 1024:9.1f} "
                 f"{byts / d:8.0f} {busy:9.3f} {ghz}\n")
 json.dump(traffic, open(dst + "_traffic_bytes_per_launch.json", "w"), indent=1)

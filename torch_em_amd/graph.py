@@ -34,6 +34,26 @@ def cumulative_average_norm(model):
     return None
 
 
+def multi_gpu_capture_blocker(model):
+    """Data-parallel training (multi_gpu_training.DDP): the in-place all-reduces of the gradient arena are RCCL launches on
+    ProcessGroupNCCL's stream, forked from and joined to the capturing stream by events -- they become nodes of the graph,
+    so every rank replays forward, backward, the exchange and the optimizer with ONE launch (round 4; before, N ranks each
+    enqueued ~220 launches per step from Python on one host).  What cannot be captured: a process group that is not
+    RCCL (gloo: host-side collectives) and the per-forward buffer broadcast of nets with BatchNorm-style buffers.
+    Returns the reason string, or None when the step can be captured."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    sync = getattr(getattr(model, "module", model), "_tem_grad_sync", None)
+    if sync is None:
+        return None if dist.get_world_size() == 1 else "multi-GPU training without torch_em_amd.multi_gpu_training.DDP"
+    if dist.get_backend(sync.pg) != "nccl":
+        return f"the gradient all-reduce runs on the '{dist.get_backend(sync.pg)}' backend (only RCCL launches are capturable)"
+    if getattr(model, "broadcast_buffers", False) and next(getattr(model, "module", model).buffers(), None) is not None:
+        return "module buffers (running statistics) are broadcast from rank 0 before every forward pass"
+    return None
+
+
 class GraphedTrainStep:
     READBACK_SLOTS = 8   # < FusedAdamW.TABLE_ROWS - 1: the host runs at most this many replays ahead of what it knows
 
@@ -44,9 +64,9 @@ class GraphedTrainStep:
             raise TypeError("GraphedTrainStep: the optimizer must be torch_em_amd.optim.FusedAdamW (its step reads the "
                             "learning rate and bias corrections from device memory; a captured torch optimizer would "
                             "replay the scalars of the captured step)")
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1:
-            raise NotImplementedError("GraphedTrainStep: the gradient all-reduce of multi-GPU training is not captured")
+        why = multi_gpu_capture_blocker(model)
+        if why is not None:
+            raise NotImplementedError("GraphedTrainStep: " + why)
         why = cumulative_average_norm(model)
         if why is not None:
             raise NotImplementedError("GraphedTrainStep: " + why)
@@ -105,6 +125,9 @@ class GraphedTrainStep:
         with self._scope():
             engine._repack_stale(prepare_only=True)   # the weight-packing job table: its upload cannot be captured
         self.graph = torch.cuda.CUDAGraph()
+        sync = getattr(getattr(model, "module", model), "_tem_grad_sync", None)
+        if sync is not None:
+            sync.measure = False   # its HIP events would become graph nodes: exposed time is an eager-step measurement
         optimizer.zero_grad(set_to_none=True)   # autograd must ASSIGN the captured gradients, not add to old ones
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.pred, self.loss = self._forward_backward_step()

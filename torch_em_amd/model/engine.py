@@ -21,6 +21,7 @@ sequenced MI355X-first:
   autograd), so the optimizer step and the data-parallel all-reduce are single launches.
 """
 import os
+import threading
 import weakref
 from typing import List, Optional
 
@@ -296,7 +297,11 @@ def fused_activation(act: nn.Module) -> Optional[str]:
 # ill-conditioning argument for 24-bit forward products (top of this file) does not apply: they run the bf16x3 kernels
 # (outputs ~1e-5 from fp32, inside the 1e-3 tolerance; 1.6x faster convolutions).  TEM_INFER_BF16X3=0 keeps bf16x6.
 _INFER_BF16X3 = os.environ.get("TEM_INFER_BF16X3", "1") != "0"
-_NO_GRAD_FORWARD = False
+class _ThreadFlags(threading.local):
+    no_grad_forward = False   # per thread: predict_with_halo drives one thread per device
+
+
+_TLS = _ThreadFlags()
 
 
 # Forward statistics of a conv output that feeds the next norm directly (conv1 -> norm2 of every ConvBlock) come out of
@@ -317,14 +322,14 @@ def _conv(spec: ConvSpec, x, y, stats=None, act=None, want_stats=False):
     ent = spec.packed()
     scale, shift = (stats[2], stats[3]) if stats is not None else (None, None)
     wpk, mode = ent["fwd"], ent["fwd_mfma"]
-    if _EXACT_FWD_MAX_VOXELS and not _NO_GRAD_FORWARD and mode in (2, 3, 4) and \
+    if _EXACT_FWD_MAX_VOXELS and not _TLS.no_grad_forward and mode in (2, 3, 4) and \
             x.shape[1] * x.shape[2] * x.shape[3] <= _EXACT_FWD_MAX_VOXELS:
         if ent.get("fwd_exact_version") != spec.conv.weight._version:
             ent["fwd_exact"] = ops.pack_weights(spec.conv.weight, transpose=False, mfma=1)
             ent["fwd_exact_version"] = spec.conv.weight._version
         ops.conv_fwd(x, ent["fwd_exact"], spec.conv.bias, y, spec.k, spec.cin, spec.cout, scale=scale, shift=shift, act=act, mfma=1)
         return None if want_stats else y   # the exact kernel writes no statistics: the caller runs norm_stats
-    if _NO_GRAD_FORWARD and _INFER_BF16X3 and mode == 3:
+    if _TLS.no_grad_forward and _INFER_BF16X3 and mode == 3:
         if "fwd_inf" not in ent:  # packed on first use, refreshed with the others by _repack_stale
             ent["fwd_inf"], ent["fwd_inf_mfma"] = ops.pack_weights(spec.conv.weight, transpose=False, mfma=2), 2
         ent["fwd_inf_used"] = True
@@ -680,12 +685,11 @@ def _dim_of(model) -> int:
 
 
 def _forward_impl(model, x: torch.Tensor, keep: bool):
-    global _NO_GRAD_FORWARD
-    prev, _NO_GRAD_FORWARD = _NO_GRAD_FORWARD, not keep
+    prev, _TLS.no_grad_forward = _TLS.no_grad_forward, not keep
     try:
         return _forward_impl_body(model, x, keep)
     finally:
-        _NO_GRAD_FORWARD = prev
+        _TLS.no_grad_forward = prev
 
 
 def _forward_impl_body(model, x: torch.Tensor, keep: bool):

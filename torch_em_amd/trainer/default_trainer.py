@@ -442,14 +442,11 @@ class DefaultTrainer:
             why = "batch is not a pair of device tensors"
         elif not isinstance(self.optimizer, FusedAdamW):
             why = "optimizer is not FusedAdamW"
-        elif torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1:
-            why = "multi-GPU gradient all-reduce"
         elif g is not None:
             why = "batch shape changed (the graph is captured for one shape)"
         else:
-            from ..graph import cumulative_average_norm
-            why = cumulative_average_norm(self.model)
+            from ..graph import cumulative_average_norm, multi_gpu_capture_blocker
+            why = cumulative_average_norm(self.model) or multi_gpu_capture_blocker(self.model)
         self._graph_why = why
         if why is not None:
             return None

@@ -10,8 +10,9 @@ block is gathered (with the reflection) by one HIP kernel, normalised by the sta
 U-Net forward kernels, and scattered into a device output volume by one HIP kernel (csrc/predict.hip); the result
 comes back over PCIe once.  The reference pads, normalises and crops every block with numpy on the host and copies it
 H2D and D2H.  Callables: `preprocess` may be this package's `standardize` (runs on device), None, or a function of
-a CUDA tensor; `postprocess`, `skip_block` and `prediction_function` receive CUDA tensors.  One device per call
-(`gpu_ids` of length 1): blocks of one volume are independent, so several GPUs are several calls on `iter_list` shards.
+a CUDA tensor; `postprocess`, `skip_block` and `prediction_function` receive CUDA tensors.  Several `gpu_ids`: one worker
+thread per entry (as the reference, :188-193, 313), each with its own copy of the model and of the input volume on its
+device and the blocks dealt round-robin; the per-device output volumes are merged box by box on the host.
 """
 import ctypes
 from typing import Any, Callable, List, Optional, Tuple, Union
@@ -108,15 +109,11 @@ def predict_with_halo(input_, model: torch.nn.Module, gpu_ids: List[Union[str, i
                       roi: Optional[Tuple[slice]] = None, iter_list: Optional[List[int]] = None,
                       grid_shift: Optional[Tuple[float, ...]] = None):
     """Block-wise network prediction with a halo; see the module docstring (reference :145-330)."""
-    if len(gpu_ids) != 1:
-        raise NotImplementedError("torch_em_amd.predict_with_halo drives one MI355X per call; shard `iter_list` across "
-                                  "processes for several GPUs")
-    device = torch.device(gpu_ids[0] if not isinstance(gpu_ids[0], int) else f"cuda:{gpu_ids[0]}")
-    if device.type != "cuda":
+    if len(gpu_ids) < 1:
+        raise ValueError("predict_with_halo: gpu_ids is empty")
+    devices = [torch.device(g if not isinstance(g, int) else f"cuda:{g}") for g in gpu_ids]
+    if any(d.type != "cuda" for d in devices):
         raise RuntimeError("torch_em_amd.predict_with_halo runs on MI355X only; there is no CPU fallback")
-    if next(model.parameters()).device != device:
-        from copy import deepcopy
-        model = deepcopy(model).to(device)
     shape_spatial0 = tuple(input_.shape[1:] if with_channels else input_.shape)
     ndim = len(shape_spatial0)
     assert len(block_shape) == len(halo) == ndim
@@ -152,60 +149,91 @@ def predict_with_halo(input_, model: torch.nn.Module, gpu_ids: List[Union[str, i
             "Or pad the input manually beforehand."
         )
 
-    vol = _to_volume(input_eff, with_channels, ndim, device)          # the whole input, once
-    mask_dev = None
-    if mask_eff is not None:
-        mask_dev = torch.as_tensor(np.asarray(mask_eff) != 0).to(device=device, dtype=torch.uint8).contiguous()
-    lib = _lib.load()
-    out_dev = None
-    block_ids = range(blocking.number_of_blocks) if iter_list is None else [int(b) for b in iter_list]
-    written = []
+    block_ids = list(range(blocking.number_of_blocks)) if iter_list is None else [int(b) for b in iter_list]
     try:
         from tqdm import tqdm
     except ImportError:  # pragma: no cover
         def tqdm(it, **kw):
             return it
-    with torch.no_grad():
-        for block_id in tqdm(block_ids, total=len(block_ids), disable=disable_tqdm, desc=tqdm_desc):
-            begin, end = blocking.get_block(block_id)
-            size = [e - b for b, e in zip(begin, end)]
-            if mask_dev is not None:
-                sl = tuple(slice(b, e) for b, e in zip(begin, end))
-                if not bool(mask_dev[sl].any()):
+    progress = tqdm(total=len(block_ids), disable=disable_tqdm, desc=tqdm_desc)
+    lib = _lib.load()
+
+    def run_on(device, my_blocks, my_model):
+        """The blocks `my_blocks` on ONE device: the whole input is uploaded once, every block is a gather kernel, the
+        forward pass and a masked scatter into the device's output volume -> (output volume or None, boxes written)."""
+        if next(my_model.parameters()).device != device:
+            from copy import deepcopy
+            my_model = deepcopy(my_model).to(device)
+        vol = _to_volume(input_eff, with_channels, ndim, device)
+        mask_dev = None
+        if mask_eff is not None:
+            mask_dev = torch.as_tensor(np.asarray(mask_eff) != 0).to(device=device, dtype=torch.uint8).contiguous()
+        out_dev, written = None, []
+        with torch.no_grad(), torch.cuda.device(device):
+            for block_id in my_blocks:
+                progress.update(1)
+                begin, end = blocking.get_block(block_id)
+                size = [e - b for b, e in zip(begin, end)]
+                if mask_dev is not None:
+                    sl = tuple(slice(b, e) for b, e in zip(begin, end))
+                    if not bool(mask_dev[sl].any()):
+                        continue
+                inp = _load_block_device(vol, begin, block_shape, halo, ndim)
+                if not with_channels:
+                    inp = inp[0]
+                if skip_block is not None and skip_block(inp):
                     continue
-            inp = _load_block_device(vol, begin, block_shape, halo, ndim)
-            if not with_channels:
-                inp = inp[0]
-            if skip_block is not None and skip_block(inp):
-                continue
-            if preprocess is standardize:
-                inp = ops.standardize(inp.reshape(1, -1), 1e-7).reshape(inp.shape)  # whole-block statistics
-            elif preprocess is not None:
-                inp = preprocess(inp)
-            model_in = inp[None] if with_channels else inp[None, None]
-            pred = model(model_in) if prediction_function is None else prediction_function(model, model_in)
-            if not torch.is_tensor(pred):
-                pred = pred[0]
-            pred = pred.squeeze(0)
-            if postprocess is not None:
-                pred = postprocess(pred)
-            if pred.dim() == ndim:
-                pred = pred[None]
-            pred = pred.float().contiguous()
-            n_out = pred.shape[0]
-            if out_dev is None:
-                out_dev = torch.zeros([n_out] + _pad3(shape_spatial, 1), dtype=torch.float32, device=device)
-            _lib.check(lib.tem_block_store_inner(
-                ops._p(pred), _i3(_pad3(pred.shape[1:], 1)), ops._p(out_dev), n_out, out_dev.shape[1], out_dev.shape[2],
-                out_dev.shape[3], ops._p(mask_dev), _i3(_pad3(halo, 0)), _i3(_pad3(begin, 0)), _i3(_pad3(size, 1)),
-                ops._stream(pred)), "tem_block_store_inner")
-            written.append(tuple(slice(b, e) for b, e in zip(begin, end)))
+                if preprocess is standardize:
+                    inp = ops.standardize(inp.reshape(1, -1), 1e-7).reshape(inp.shape)  # whole-block statistics
+                elif preprocess is not None:
+                    inp = preprocess(inp)
+                model_in = inp[None] if with_channels else inp[None, None]
+                pred = my_model(model_in) if prediction_function is None else prediction_function(my_model, model_in)
+                if not torch.is_tensor(pred):
+                    pred = pred[0]
+                pred = pred.squeeze(0)
+                if postprocess is not None:
+                    pred = postprocess(pred)
+                if pred.dim() == ndim:
+                    pred = pred[None]
+                pred = pred.float().contiguous()
+                n_out = pred.shape[0]
+                if out_dev is None:
+                    out_dev = torch.zeros([n_out] + _pad3(shape_spatial, 1), dtype=torch.float32, device=device)
+                _lib.check(lib.tem_block_store_inner(
+                    ops._p(pred), _i3(_pad3(pred.shape[1:], 1)), ops._p(out_dev), n_out, out_dev.shape[1], out_dev.shape[2],
+                    out_dev.shape[3], ops._p(mask_dev), _i3(_pad3(halo, 0)), _i3(_pad3(begin, 0)), _i3(_pad3(size, 1)),
+                    ops._stream(pred)), "tem_block_store_inner")
+                written.append(tuple(slice(b, e) for b, e in zip(begin, end)))
+        return out_dev, written
+
+    if len(devices) == 1:
+        parts = [run_on(devices[0], block_ids, model)]
+    else:
+        # one worker thread per entry of gpu_ids, block list dealt round-robin (the reference: a thread pool with one
+        # worker per device pulling blocks, util/prediction.py:188-193, 313); the inner boxes of the blocks are disjoint,
+        # so the per-device output volumes merge by copying each device's boxes
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(len(devices)) as pool:
+            futs = [pool.submit(run_on, d, block_ids[i::len(devices)], model) for i, d in enumerate(devices)]
+            parts = [f.result() for f in futs]
+    progress.close()
+    written = [bb for _, w in parts for bb in w]
+    out_dev = None
+    result = None
+    for od, w in parts:
+        if od is None:
+            continue
+        host = od.reshape([od.shape[0]] + list(shape_spatial)).cpu().numpy()
+        if result is None:
+            result, out_dev = host, od
+        else:
+            for bb in w:
+                result[(slice(None),) + bb] = host[(slice(None),) + bb]
 
     if out_dev is None:  # nothing was predicted (everything masked / skipped)
         n_out = getattr(model, "out_channels", 1)
         result = np.zeros((n_out,) + shape_spatial, dtype="float32")
-    else:
-        result = out_dev.reshape([out_dev.shape[0]] + list(shape_spatial)).cpu().numpy()
     if user_output is None:
         output = result
     else:  # copy only the boxes that were predicted into the caller's array(s), like the reference's in-place writes
