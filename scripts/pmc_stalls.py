@@ -9,7 +9,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collection
 for f in glob.glob(sys.argv[1] + "/*/b_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("void ", "").split("(")[0]
-        if k.startswith("k_conv_zr<2") or k.startswith("k_conv_wgrad_zs"):
+        if k.startswith("k_conv_zr<2") or k.startswith("k_conv_wgrad_zs") or k.startswith("k_conv_wgrad_tr"):
             agg[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])   # sum over XCCs / instances of a dispatch
 names = sorted({c for v in agg.values() for c in v})
 for k, v in sorted(agg.items()):

@@ -498,7 +498,12 @@ extern "C" int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int 
     if (use_mfma == 2 || use_mfma == 5 || use_mfma == 7 || use_mfma == 8) {
         bytes += tem_conv_wgrad_bf16x3_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
     } else if (use_mfma) {
-        bytes += tem_conv_wgrad_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
+        int64_t b = tem_conv_wgrad_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
+        if (tem_conv_wgrad_tr_fp32_ok(N, D, H, W, Cin, Cout, kd, kh, kw)) {
+            const int64_t b2 = tem_conv_wgrad_bf16x3_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
+            if (b2 > b) b = b2;
+        }
+        bytes += b;
     } else {
         int64_t b = p.part_floats * 4;
         int64_t c1 = tem_conv_wgrad_cin1_ws(Cout, ntaps), pj = tem_conv1x1_proj_wgrad_ws(Cin, Cout);
@@ -553,6 +558,16 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
         return TEM_OK;
     }
     TEM_REQUIRE(!norm_sums, "tem_conv3d_wgrad_sums: only the split-bf16 z-sliding kernel delivers the norm sums");
+    if (use_mfma && tem_conv_wgrad_tr_fp32_ok(N, D, H, W, Cin, Cout, kd, kh, kw) && x_ld % 4 == 0 && g_ld % 4 == 0 &&
+        ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0)) {
+        // exact fp32 on the z-sliding staging-team kernel (round 4): fp32 records in LDS, v_mfma_f32_32x32x2_f32
+        int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
+                                       ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
+                                       sd_layout, 4, nullptr, nullptr, nullptr, nullptr, s);
+        if (rc != TEM_OK) return rc;
+        TEM_CHECK_LAUNCH("tem_conv3d_wgrad(fp32, z-sliding)");
+        return TEM_OK;
+    }
     if (use_mfma) {
         int rc = tem_conv_wgrad_mfma(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                      ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,

@@ -1843,6 +1843,11 @@ int tem_conv_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, int Cout, int
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
     return Cin % 32 == 0 && Cout % 32 == 0 && z.use && (!z.teams || z.tr);
 }
+// exact-fp32 weight gradient on k_conv_wgrad_tr<4> (TEM_PRECISION=fp32): the layers the z-sliding plan takes, option wgrad_zs >= 3
+int tem_conv_wgrad_tr_fp32_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
+    const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
+    return Cin % 32 == 0 && Cout % 32 == 0 && z.use && z.tr;
+}
 int tem_conv_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     return Cin % 32 == 0 && Cout % 32 == 0 && zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw).use;
 }
@@ -1867,6 +1872,7 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
     unsigned* const gmax = tem_wgrad_gmax_target;   // set by tem_conv3d_wgrad_gmax for the duration of this call
     TEM_REQUIRE(!gmax || (z.use && !h16), "tem_conv3d_wgrad_gmax: tem_conv3d_wgrad_gmax_ok() == 0 for this layer");
     const unsigned* const g_amax = tem_wgrad_gscale_source;   // set by tem_conv3d_wgrad_gscaled for the duration of this call
+    TEM_REQUIRE(h16 != 4 || (z.use && z.tr), "tem_conv3d_wgrad(fp32 on k_conv_wgrad_tr): tem_conv_wgrad_tr_fp32_ok() == 0 for this layer");
     TEM_REQUIRE(h16 != 3 || (g_amax && z.use && (!z.teams || z.tr)),
                 "tem_conv3d_wgrad_gscaled: tem_conv3d_wgrad_gscaled_ok() == 0 for this layer (or no g_amax)");
     if (z.use) {

@@ -23,23 +23,20 @@
 //     into 3 buffers, two planes ahead of the multiplication; global loads four planes ahead); one barrier per plane; persistent over column segments, one
 //     partial slab per workgroup (format of k_conv_wgrad_zt: KS2 = 1).
 // ARITH: 0 bf16x3 (x^ and g two bf16 terms, 3 MFMAs per product), 1 one fp16 term each (mixed precision), 2 one bf16 term
-// each, 3 fp16 2x1 (x^ two fp16 terms, g one fp16 term prescaled from *g_amax: the default of the fp32-class mode).
+// each, 3 fp16 2x1 (x^ two fp16 terms, g one fp16 term prescaled from *g_amax: the default of the fp32-class mode),
+// 4 exact fp32 on v_mfma_f32_32x32x2_f32 (TEM_PRECISION=fp32): K = 2 voxels = the two lane halves, a lane holds ONE
+// channel value per operand, so fp32 voxel-major records (128 B) ARE the operand layout -- plain ds_read_b32, no transpose.
 #include "tem_common.h"
 #include "conv_internal.h"
 #include "conv_split.h"
 #include <set>
 #include <type_traits>
 
-#define TR_REC 64                  // bytes per voxel record: 32 channels x 16 bit
-#define TR_XROW (10 * TR_REC)      // a halo row: 10 voxels
-#define TR_XPL (10 * TR_XROW)      // a halo plane: 10 rows
+#define TR_REC16 64                // bytes per voxel record: 32 channels x 16 bit (ARITH 4, exact fp32: 128)
 #define TR_NXS 5                   // ring slots of x^ halo planes: 3 being multiplied + 1 prefetched by the multiplying team + 1 being written
 #define TR_NGS 3                   // g planes: multiplied, prefetched, being written
-#define TR_XT (TR_NXS * TR_XPL)    // one term of x^
-#define TR_GPL (64 * TR_REC)       // a g plane: 8 x 8 voxels
-#define TR_GT (TR_NGS * TR_GPL)    // one term of g
-#define TR_XSLOT(p) ((((p) + 2 * TR_NXS) % TR_NXS) * TR_XPL)   // byte offset of the ring slot of halo plane p (p >= -2 TR_NXS)
-#define TR_GSLOT(p) ((((p) + 3 * TR_NGS) % TR_NGS) * TR_GPL)
+#define TR_XT_OF(rec) (TR_NXS * 100 * (rec))   // one term of x^: ring of 10 x 10 halo planes
+#define TR_GT_OF(rec) (TR_NGS * 64 * (rec))    // one term of g: 8 x 8 planes
 
 typedef short tr_s4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) tr_s4* tr_lds_p;
@@ -52,7 +49,7 @@ __device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
     return __builtin_bit_cast(uint2, v);
 }
 __device__ __forceinline__ uint4 tr_frag(const unsigned char* p) {   // 8 voxels of this lane's channel: two transposing reads
-    const uint2 a = tr_read(p), b = tr_read(p + 4 * TR_REC);
+    const uint2 a = tr_read(p), b = tr_read(p + 4 * TR_REC16);
     return make_uint4(a.x, a.y, b.x, b.y);
 }
 __device__ __forceinline__ tr_rsrc_t tr_rsrc(const void* base) {
@@ -115,6 +112,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
     constexpr int NG = (ARITH == 0) ? 2 : 1;                 // terms of g
     constexpr bool F16 = ARITH == 1 || ARITH == 3;
     constexpr bool H21 = ARITH == 3;
+    constexpr bool FP32 = ARITH == 4;   // exact fp32: v_mfma_f32_32x32x2_f32 on fp32 records (no transpose needed: K = 2 voxels = the two lane halves)
+    constexpr int TR_REC = FP32 ? 128 : 64, TR_QB = TR_REC / 8;   // bytes per voxel record / per channel quad
+    constexpr int TR_XROW = 10 * TR_REC, TR_XPL = 10 * TR_XROW, TR_XT = TR_XT_OF(TR_REC);
+    constexpr int TR_GPL = 64 * TR_REC, TR_GT = TR_GT_OF(TR_REC);
+    auto TR_XSLOT = [](int pl) { return ((pl + 2 * TR_NXS) % TR_NXS) * TR_XPL; };   // ring slot of halo plane pl (>= -2 TR_NXS)
+    auto TR_GSLOT = [](int pl) { return ((pl + 3 * TR_NGS) % TR_NGS) * TR_GPL; };
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const X0 = ldsb;                  // [term NX][slot 4][row 10][x 10][32 ch]
     unsigned char* const G0 = ldsb + NX * TR_XT;     // [term NG][buffer 2][row 8][x 8][32 ch]
@@ -151,8 +154,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
         // a group address voxel j of the run, 8 bytes (4 channels) each
         const int p16 = lane & 15;
         const int lane_rec = (p16 >> 2) * TR_REC + ((lane >> 4) & 1) * 32 + (p16 & 3) * 8;
-        const int lane_x = (lane >> 5) * TR_XROW + lane_rec;
-        const int lane_g = (lane >> 5) * (8 * TR_REC) + lane_rec;
+        const int lane_x = (lane >> 5) * TR_XROW + (FP32 ? (lane & 31) * 4 : lane_rec);   // fp32: lane = channel, lane half = row
+        const int lane_g = (lane >> 5) * (8 * TR_REC) + (FP32 ? (lane & 31) * 4 : lane_rec);
         // taps of this wave (as k_conv_wgrad_zt): accumulators 0..2 = row group (tz, ty) = wv with tx = 0, 1, 2; 3..5 = row group
         // wv + 4; accumulator 6 = (row group 8, tx = wv) -- wave 3 has no seventh tap: it repeats tx = 0 there and never stores it.
         // A row group reads ONE 12-voxel window of its x row (three transposing reads: elements k0 .. k11 of the lane's
@@ -215,12 +218,45 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                 for (int a = 0; a < 3; ++a) xb[a] = X0 + lane_x + TR_XSLOT(t + rgtz[a] - 1) + rgoff[a];
                 return G0 + lane_g + TR_GSLOT(t);
             };
-            {   // first fragments of the segment's first plane
+            if constexpr (!FP32) {   // first fragments of the segment's first plane
                 const unsigned char* xb0[3];
                 const unsigned char* gb0 = bases(za, xb0);
                 load_g(gb0, 0);
                 load_x(NX == 2 ? xl : xh, xb0, NX == 2 ? 1 : 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (FP32) {
+                // exact fp32: a k-step = one x position of the slab's two rows (lanes 0..31 row 2 s, 32..63 row 2 s + 1); one
+                // ds_read_b32 per operand, the g value serves the 7 taps; reads of k-step i + 1 fly during the MFMAs of i
+#pragma unroll 1
+                for (int t = za; t < zb; ++t) {
+                    const unsigned char* xb[3];
+                    const unsigned char* gb = bases(t, xb);
+                    if (TEM_TR_ABL & 2) {
+                        __syncthreads();
+                        continue;
+                    }
+                    auto rd = [&](int ks, float* xv) -> float {   // ks = 8 sl + x
+                        const int off = (ks >> 3) * 2 * TR_XROW + (ks & 7) * TR_REC;
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) xv[j] = *reinterpret_cast<const float*>(xb[j / 3] + off + (j % 3) * TR_REC);
+                        xv[6] = *reinterpret_cast<const float*>(xb[2] + off);
+                        return *reinterpret_cast<const float*>(gb + (ks >> 3) * 16 * TR_REC + (ks & 7) * TR_REC);
+                    };
+                    float xc[NA], xn[NA];
+                    float gc = rd(0, xc), gn = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 32; ++ks) {
+                        if (ks + 1 < 32) gn = rd(ks + 1, xn);
+#pragma unroll
+                        for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc[j], gc, acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < NA; ++j) xc[j] = xn[j];
+                        gc = gn;
+                    }
+                    __syncthreads();
+                }
+                continue;
             }
 #pragma unroll 1
             for (int t = za; t < zb; ++t) {
@@ -342,7 +378,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                     return;
                 }
                 if (t >= za - 4) {
-                    unsigned char* const xs = X0 + TR_XSLOT(t + 3) + quad * 8;
+                    unsigned char* const xs = X0 + TR_XSLOT(t + 3) + quad * TR_QB;
                     if (zin_) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -350,6 +386,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                             if (q == 3 && hv >= 100) break;
                             const float e0 = fmaf(xs_[q].x, scm[q].x, sfm[q].x), e1 = fmaf(xs_[q].y, scm[q].y, sfm[q].y);
                             const float e2 = fmaf(xs_[q].z, scm[q].z, sfm[q].z), e3 = fmaf(xs_[q].w, scm[q].w, sfm[q].w);
+                            if constexpr (FP32) {
+                                *reinterpret_cast<float4*>(xs + hv * TR_REC) = make_float4(e0, e1, e2, e3);
+                                continue;
+                            }
                             uint2 hi, lo;
                             if (H21) {
                                 hi = make_uint2(pk16<true>(e0, e1), pk16<true>(e2, e3));
@@ -368,19 +408,26 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                         for (int q = 0; q < 4; ++q) {
                             const int hv = (tl + 256 * q) >> 3;
                             if (q == 3 && hv >= 100) break;
+                            if constexpr (FP32) {
+                                *reinterpret_cast<float4*>(xs + hv * TR_REC) = make_float4(0.f, 0.f, 0.f, 0.f);
+                                continue;
+                            }
                             *reinterpret_cast<uint2*>(xs + hv * TR_REC) = make_uint2(0u, 0u);
                             if (NX == 2) *reinterpret_cast<uint2*>(xs + TR_XT + hv * TR_REC) = make_uint2(0u, 0u);
                         }
                     }
                 }
                 if (t + 2 >= za && t + 2 < zb) {
-                    unsigned char* const gs = G0 + TR_GSLOT(t + 2) + quad * 8;
+                    unsigned char* const gs = G0 + TR_GSLOT(t + 2) + quad * TR_QB;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int gv = (tl + 256 * q) >> 3;
                         const float4 v = gs_[q];   // zeros where out of range (load offset beyond the buffer)
                         uint2 hi, lo;
-                        if (H21) {
+                        if (FP32) {
+                            *reinterpret_cast<float4*>(gs + gv * TR_REC) = v;
+                            hi = lo = make_uint2(0u, 0u);
+                        } else if (H21) {
                             hi = lo = make_uint2(tr_mix_scale(v.x, v.y, psc), tr_mix_scale(v.z, v.w, psc));
                         } else if (ARITH == 0) {
                             split2(v.x, v.y, hi.x, lo.x);
@@ -388,7 +435,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                         } else {
                             hi = lo = make_uint2(pk16<F16>(v.x, v.y), pk16<F16>(v.z, v.w));
                         }
-                        *reinterpret_cast<uint2*>(gs + gv * TR_REC) = hi;
+                        if (!FP32) *reinterpret_cast<uint2*>(gs + gv * TR_REC) = hi;
                         if (NG == 2) *reinterpret_cast<uint2*>(gs + TR_GT + gv * TR_REC) = lo;
                         dbacc[0] += v.x;
                         dbacc[1] += v.y;
@@ -449,7 +496,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
     }
 }
 
-// h16: 0 bf16x3, 1 one fp16 term, 2 one bf16 term, 3 fp16 2x1 (g_amax required).  Same arguments, partial-slab format and
+// h16: 0 bf16x3, 1 one fp16 term, 2 one bf16 term, 3 fp16 2x1 (g_amax required), 4 exact fp32.  Same arguments, partial-slab format and
 // plan (teams: one (Cin tile, Cout tile) pair per workgroup, KS2 = 1) as k_conv_wgrad_zt.
 void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_ld, const float* scale, const float* shift,
                               const float* g, int64_t g_ld, float* zpart, float* zdb, int N, int D, int H, int W, int Cin,
@@ -465,8 +512,10 @@ void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb, N, D, H, W, Cin, Cout,
                            T, nY, nX, zsegs, Ss, ncz, gmax, g_amax);
     };
-    if (h16 == 1) launch(&k_conv_wgrad_tr<1>, (size_t)TR_XT + TR_GT);
-    else if (h16 == 2) launch(&k_conv_wgrad_tr<2>, (size_t)TR_XT + TR_GT);
-    else if (h16 == 3) launch(&k_conv_wgrad_tr<3>, (size_t)2 * TR_XT + TR_GT);
-    else launch(&k_conv_wgrad_tr<0>, (size_t)2 * TR_XT + 2 * TR_GT);
+    constexpr size_t XT = TR_XT_OF(TR_REC16), GT = TR_GT_OF(TR_REC16);
+    if (h16 == 1) launch(&k_conv_wgrad_tr<1>, XT + GT);
+    else if (h16 == 2) launch(&k_conv_wgrad_tr<2>, XT + GT);
+    else if (h16 == 3) launch(&k_conv_wgrad_tr<3>, 2 * XT + GT);
+    else if (h16 == 4) launch(&k_conv_wgrad_tr<4>, (size_t)TR_XT_OF(128) + TR_GT_OF(128));
+    else launch(&k_conv_wgrad_tr<0>, 2 * XT + 2 * GT);
 }

@@ -160,6 +160,7 @@ class DefaultTrainer:
             "mixed_precision": self.mixed_precision, "mixed_precision_dtype": self.mixed_precision_dtype,
             "mixed_precision_explicit": self._mixed_precision_explicit,
             "early_stopping": self.early_stopping, "log_image_interval": self.log_image_interval,
+            "hip_graph": self.hip_graph,
             "logger_class": None if self.logger_class is None else _class_path(self.logger_class),
             "logger_kwargs": self.logger_kwargs,
             "model_class": _class_path(inner), "model_kwargs": _init_kwargs(inner),
@@ -310,7 +311,7 @@ class DefaultTrainer:
                       save_root=init["save_root"], rank=init.get("rank"),
                       mixed_precision_dtype=init["mixed_precision_dtype"]
                       if init.get("mixed_precision_explicit", False) else None,
-                      prefetch=init.get("prefetch", True), **transforms)
+                      prefetch=init.get("prefetch", True), hip_graph=init.get("hip_graph"), **transforms)
         trainer._initialize(0, save_dict)
         trainer._is_initialized = True
         return trainer
