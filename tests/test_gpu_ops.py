@@ -612,13 +612,13 @@ def wgrad_kernel_option():
 
 
 @pytest.mark.parametrize("kernel", [1, 2, 3])
-@pytest.mark.parametrize("mode", [2, 5, 7])
+@pytest.mark.parametrize("mode", [1, 2, 5, 7])
 @pytest.mark.parametrize("case", [(2, 16, 16, 24, 32, 32), (1, 20, 24, 17, 32, 32), (2, 16, 16, 16, 64, 64), (2, 33, 8, 8, 32, 96),
                                   (1, 16, 132, 136, 32, 32), (3, 17, 9, 10, 64, 32)])
 def test_wgrad_z_sliding_kernels_agree_with_float64(case, mode, kernel, wgrad_kernel_option):
     """Every z-sliding weight-gradient kernel (round 2: k_conv_wgrad_zs, round 3: _zt with a staging team, round 4: _tr with
-    voxel-major LDS records and ds_read_b64_tr_b16 fragment reads) in the bf16x3 / one-term fp16 / one-term bf16 modes against
-    the float64 weight gradient of the operands rounded as the mode rounds them (only the summation order differs)."""
+    voxel-major LDS records and ds_read_b64_tr_b16 fragment reads) in the exact-fp32 / bf16x3 / one-term fp16 / one-term bf16
+    modes against the float64 weight gradient of the operands rounded as the mode rounds them (only the summation order differs)."""
     ops = _ops()
     wgrad_kernel_option(kernel)
     N, D, H, W, Cin, Cout = case
@@ -629,7 +629,10 @@ def test_wgrad_z_sliding_kernels_agree_with_float64(case, mode, kernel, wgrad_ke
     scale = torch.rand(N, Cin, generator=gen) + 0.5
     shift = torch.randn(N, Cin, generator=gen)
     xn = (x.double() * scale[:, :, None, None, None].double() + shift[:, :, None, None, None].double()).float()
-    if mode == 2:
+    if mode == 1:   # exact fp32 (kernel 3: k_conv_wgrad_tr<4> on fp32 records; 1 / 2: the patch kernel of conv_mfma.hip)
+        exp = torch.nn.grad.conv3d_weight(xn.double(), (Cout, Cin, *k), gy.double(), padding=1)
+        tol = 2e-5
+    elif mode == 2:
         def r2(t):
             hi = t.bfloat16().float()
             return hi.double() + (t - hi).bfloat16().double()
