@@ -8,7 +8,7 @@ tag=$1; src=$2; shift 2
 mkdir -p build/var
 base=$(basename "$src" .hip)
 extra=""
-case "$base" in conv_pp|conv_zr|conv_bf16x3) extra="-fno-slp-vectorize";; esac
+case "$base" in conv_pp|conv_zr|conv_bf16x3|conv_wgrad_tr) extra="-fno-slp-vectorize";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra "$@" -c "torch_em_amd/csrc/$base.hip" -o "build/var/${base}_$tag.o"
 objs=$(ls build/csrc/*.o | grep -v "/$base.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "build/var/libtem_hip_$tag.so" $objs "build/var/${base}_$tag.o"

@@ -25,6 +25,10 @@ int main(int argc, char** argv) {
     std::vector<float> hx(V * Cin), hg(V * Cout), hs((size_t)N * Cin), hf((size_t)N * Cin);
     for (auto& v : hx) v = 2.f * frand(seed);
     for (auto& v : hg) v = frand(seed);
+    if (getenv("WG_GZERO")) {   // a fraction of exact zeros in g (ReLU masks): the step's gradients are sparser / cooler than noise
+        const float frac = (float)atof(getenv("WG_GZERO"));
+        for (auto& v : hg) if (0.5f * (frand(seed) + 1.f) < frac) v = 0.f;
+    }
     for (auto& v : hs) v = 1.f + 0.5f * frand(seed);
     for (auto& v : hf) v = frand(seed);
     float *x, *g, *sc, *sf, *dw, *db;

@@ -17,9 +17,10 @@
 //     17th element);
 //   * roles as in k_conv_wgrad_zt: waves 0..3 (one per SIMD) only multiply -- wave w owns row groups (tz, ty) w and w + 4 with
 //     their three tx taps and one tap of row group 8 (7 / 7 / 7 / 6 accumulator tiles of one (Cin tile, Cout tile) pair); the
-//     three tx fragments of a row group come out of ONE 12-voxel window (three transposing reads + 4 v_alignbyte for
-//     tx = 1: the first version read every tap's fragment separately and ran at 1.6 GHz with the matrix pipe 0.62 busy --
-//     LDS reads cost power too) -- waves 4..7 only stage (x planes into a 5-slot ring, g planes
+//     tx = 0 and tx = 2 fragments of a row group come out of ONE 12-voxel window (three transposing reads), tx = 1 from two
+//     more (the first version read every tap's fragment separately: 14 reads per 7 MFMAs, 1.6 GHz -- LDS reads cost power;
+//     shifting tx = 1 out of the window with 4 v_alignbyte instead costs issue slots: a SIMD fits ~5 non-MFMA
+//     instructions of BOTH its waves per MFMA) -- waves 4..7 only stage (x planes into a 5-slot ring, g planes
 //     into 3 buffers, two planes ahead of the multiplication; global loads four planes ahead); one barrier per plane; persistent over column segments, one
 //     partial slab per workgroup (format of k_conv_wgrad_zt: KS2 = 1).
 // ARITH: 0 bf16x3 (x^ and g two bf16 terms, 3 MFMAs per product), 1 one fp16 term each (mixed precision), 2 one bf16 term
@@ -78,6 +79,9 @@ __device__ __forceinline__ unsigned tr_mix_scale(float g0, float g1, float sc) {
     return q;
 }
 
+#ifndef TEM_TR_TX1_DIRECT
+#define TEM_TR_TX1_DIRECT 1   // the tx = 1 fragment of a row group by two more transposing reads (0: four v_alignbyte on the window; measured +2 % kernel time: the SIMD is issue-bound at ~5 non-MFMA instructions per MFMA over both waves)
+#endif
 #ifndef TEM_TR_ABL
 #define TEM_TR_ABL 0   // harness-only ablations (wrong results): 1 staging team idle, 2 multiplying team idle, 4 fragments read once
 #endif                 // per plane (no LDS reads in the MFMA stream), 8 staging without global loads
@@ -190,8 +194,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
                     const unsigned char* p = xb[a] + term * TR_XT + sl * 2 * TR_XROW;
                     const uint2 w0 = tr_read(p), w1 = tr_read(p + 4 * TR_REC), w2 = tr_read(p + 8 * TR_REC);
                     f[3 * a + 0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
-                    f[3 * a + 1] = make_uint4(__builtin_amdgcn_alignbyte(w0.y, w0.x, 2), __builtin_amdgcn_alignbyte(w1.x, w0.y, 2),
-                                              __builtin_amdgcn_alignbyte(w1.y, w1.x, 2), __builtin_amdgcn_alignbyte(w2.x, w1.y, 2));
+                    if (TEM_TR_TX1_DIRECT)
+                        f[3 * a + 1] = tr_frag(p + TR_REC16);
+                    else
+                        f[3 * a + 1] = make_uint4(__builtin_amdgcn_alignbyte(w0.y, w0.x, 2), __builtin_amdgcn_alignbyte(w1.x, w0.y, 2),
+                                                  __builtin_amdgcn_alignbyte(w1.y, w1.x, 2), __builtin_amdgcn_alignbyte(w2.x, w1.y, 2));
                     f[3 * a + 2] = make_uint4(w0.y, w1.x, w1.y, w2.x);
                 }
                 f[6] = tr_frag(xb[2] + term * TR_XT + sl * 2 * TR_XROW);
@@ -199,6 +206,16 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
             auto interleave = [&]() {   // the 7 MFMAs of the phase just written and the reads / shifts for the next one:
                 // reads behind the first three MFMAs, the v_alignbyte of the tx = 1 fragments behind the last three (their
                 // reads have returned by then: an LDS wait inside the MFMA stream would stall the matrix pipe)
+                if (TEM_TR_TX1_DIRECT) {   // 12 (+ 2) reads, no shifts: three reads behind each of the first five MFMAs
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    return;
+                }
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
