@@ -446,6 +446,63 @@ def test_affinity_config_full_size_properties():
     assert rel_err(p0[0].cpu(), p1[0].cpu()) < 1e-5                                # per-sample statistics only
 
 
+def test_affinity_config_full_size_sample_matches_oracle():
+    """BASELINE cfg 3 against the fp32 CPU oracle at the FULL per-sample size (1x1x64x256x256; the batch of 2 is two independent
+    samples under InstanceNorm, which test_affinity_config_full_size_properties checks bit for bit): prediction, masked Dice loss
+    and every parameter gradient -- the same robust bounds as the cfg-2 full-size test (both sides are fp32-class
+    implementations of an ill-conditioned gradient).  The oracle step is ~11 TFLOP: about a minute on 16 host threads."""
+    from oracle import label_ref, loss_ref, unet_ref
+    from torch_em_amd.loss import ApplyAndRemoveMask, DiceLoss, LossWrapper
+    from torch_em_amd.model import AnisotropicUNet
+    torch.manual_seed(0)
+    sf = [[1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2]]
+    model = AnisotropicUNet(1, 12, scale_factors=sf, initial_features=32, final_activation="Sigmoid").to(DEV)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 1, 64, 256, 256, generator=g)
+    lbl = torch.randint(0, 50, (1, 1, 8, 16, 16), generator=g).repeat_interleave(8, 2).repeat_interleave(16, 3) \
+        .repeat_interleave(16, 4)
+    offsets = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0], [0, 0, -3], [-3, 0, 0], [0, -9, 0], [0, 0, -9],
+               [-4, 0, 0], [0, -27, 0], [0, 0, -27]]
+    y = torch.from_numpy(label_ref.affinities(lbl[0, 0].numpy(), offsets, add_mask=True))[None].float()
+    pred = model(x.to(DEV))
+    loss = LossWrapper(DiceLoss(), ApplyAndRemoveMask(masking_method="multiply"))(pred, y.to(DEV))
+    loss.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        pr = unet_ref.unet_forward(sd, x, sf, final_activation="Sigmoid")
+        lo = loss_ref.masked_dice_loss(pr, y)
+        lo.backward()
+    finally:
+        torch.set_num_threads(nthreads)
+    assert rel_err(pred.detach().cpu(), pr.detach()) < TOL
+    assert abs(float(loss) - float(lo)) < 1e-4 * max(1.0, abs(float(lo)))
+    named = dict(model.named_parameters())
+    num = den = 0.0
+    gmax_all = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for k, v in sd.items():
+        a = named[k].grad.double().cpu().numpy().ravel()
+        r = v.grad.double().cpu().numpy().ravel()
+        if float(np.abs(r).max()) < 1e-4 * gmax_all:   # mathematically-zero gradients (a bias in front of an InstanceNorm)
+            assert float(np.abs(a).max()) < 1e-3 * gmax_all, k
+            continue
+        e = float(np.linalg.norm(a - r) / np.linalg.norm(r))
+        assert e < 5e-2, (k, e)
+        num += float(np.sum((a - r) ** 2))
+        den += float(np.sum(r ** 2))
+    glob = (num / den) ** 0.5
+    print(f"cfg 3 full-size sample: global gradient L2 rel err vs the fp32 CPU oracle {glob:.3e}, loss {float(loss):.7f} vs {float(lo):.7f}")
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "fullsize_grad_error_cfg3.json"), "w") as f:
+            json.dump({"config": "AnisotropicUNet(1,12,sf=[[1,2,2],[1,2,2],[2,2,2],[2,2,2]],32,Sigmoid) 1x1x64x256x256 masked Dice, default "
+                                 "arithmetic", "global_grad_l2_rel_err_vs_fp32_cpu_oracle": glob, "loss_hip": float(loss),
+                       "loss_oracle": float(lo)}, f)
+    assert glob < 1e-2, glob
+
+
 def test_side_outputs_golden_and_mfma_size():
     """return_side_outputs=True: the reference's golden case (narrow net), then an MFMA-width net against the float64
     oracle (outputs TOL; gradients: every tensor within 1e-2 and the whole gradient within 2e-3 in relative L2 -- the
