@@ -190,6 +190,16 @@ int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const flo
                      int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                      int use_mfma, int sd_layout, tem_stream_t stream);
 
+/* Backward of the output projection out_conv = nn.Conv3d(features, out_channels, 1) (/root/reference/torch_em/model/unet.py:638:
+ * the wgrad + dgrad halves of its convolution_backward, and the threshold_backward of the ReLU in front of it) in ONE pass over
+ * x [NV][Cin] (the ReLU output the projection read): dw [Cout][Cin] (state_dict order), db [Cout] (optional) from
+ * g [NV][Cout], and gx[v][ci] = x[v][ci] > 0 ? sum_co g[v][co] w[co][ci] : 0.  w in state_dict layout.  Shapes:
+ * tem_conv1x1_out_bwd_ok (Cin 32 or 64, Cout <= 4); workspace tem_conv1x1_out_bwd_ws() bytes.  Honours tem_arm_output_amax. */
+int tem_conv1x1_out_bwd_ok(int Cin, int Cout);
+int64_t tem_conv1x1_out_bwd_ws(int Cin, int Cout);
+int tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g_ld, const float* w, float* gx, int64_t gx_ld,
+                        float* dw, float* db, void* ws, int64_t ws_bytes, int64_t NV, int Cin, int Cout, tem_stream_t stream);
+
 /* tem_conv3d_wgrad (w == NULL, norm_sums == NULL) or tem_conv3d_wgrad_sums that ALSO reports the largest |g|: g_amax
  * (device, one 32-bit word the caller cleared) receives the bit pattern of max |g| by an integer atomicMax -- exact and
  * order-independent.  dw comes in state_dict order.  Only the z-sliding 3x3x3 kernel stages all of g

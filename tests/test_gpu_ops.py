@@ -700,6 +700,41 @@ def test_wgrad_fp16_two_by_one_with_device_prescale(case, gscale, kernel, wgrad_
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("case", [(2, 5, 9, 8, 32, 2), (1, 3, 8, 8, 64, 2), (1, 4, 9, 7, 32, 4), (1, 1, 17, 16, 32, 1)])
+def test_out_conv_backward_in_one_pass(case):
+    """tem_conv1x1_out_bwd: weight / bias gradient of the output projection and its ReLU-masked data gradient from ONE pass
+    over the projection's input -- bit-identical to the two kernels it replaces (tem_conv3d_wgrad + tem_conv3d_fwd on the
+    transposed pack with ref), and equal to torch's convolution_backward / threshold_backward in fp32."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout = case
+    gen = torch.Generator().manual_seed(31)
+    x = torch.relu(torch.randn(N, Cin, D, H, W, generator=gen))
+    w = torch.randn(Cout, Cin, 1, 1, 1, generator=gen) * 0.3
+    gy = torch.randn(N, Cout, D, H, W, generator=gen) * 1e-4
+    assert ops.conv1x1_out_bwd_ok(Cin, Cout)
+    x5, g5, wd = to5(x), to5(gy), w.to(DEV)
+    gx = torch.empty_like(x5)
+    dw = torch.empty(w.numel(), device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    am = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.arm_output_amax(am)
+    ops.conv1x1_out_bwd(x5, g5, wd, gx, dw, db)
+    assert not ops.disarm_output_amax() and int(am.item()) == int(gx.abs().max().view(torch.int32).item())
+    # the two separate kernels
+    gx2 = torch.empty_like(x5)
+    ops.conv_fwd(g5, ops.pack_weights(wd, transpose=True, mfma=0), None, gx2, (1, 1, 1), Cout, Cin, ref=x5, mfma=0)
+    dw2 = torch.empty_like(dw)
+    db2 = torch.empty_like(db)
+    ops.conv_wgrad(x5, g5, (1, 1, 1), Cin, Cout, dw2, db2, mfma=0)
+    assert torch.equal(gx, gx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    # torch
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(xr, wr).backward(gy)
+    assert rel_err(from5(gx), xr.grad * (x > 0)) < 2e-5
+    assert rel_err(dw.cpu().view(w.shape), wr.grad) < 5e-5 and rel_err(db.cpu(), gy.sum((0, 2, 3, 4))) < 5e-5
+
+
 def test_output_amax_is_a_by_product_of_the_gradient_producers():
     """tem_arm_output_amax: the kernels that write the data gradients of the big levels (max-pool backward, the 1x1x1
     expanding / streaming data gradients, the z-reuse data gradient with a ReLU mask or a fused norm backward) deliver the

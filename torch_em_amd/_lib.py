@@ -42,6 +42,9 @@ SIGNATURES = {
                              + [c_int] * 11 + [c_vp, c_i64, c_vp]),
     "tem_conv3d_wgrad_ws": (c_i64, [c_int] * 10),
     "tem_conv3d_wgrad": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 11 + [c_vp]),
+    "tem_conv1x1_out_bwd_ok": (c_int, [c_int] * 2),
+    "tem_conv1x1_out_bwd_ws": (c_i64, [c_int] * 2),
+    "tem_conv1x1_out_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
     "tem_conv3d_wgrad_gmax_ok": (c_int, [c_int] * 10),
     "tem_conv3d_wgrad_gmax": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]
                               + [c_int] * 10 + [c_vp]),

@@ -611,6 +611,28 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
                              use_mfma, sd_layout, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
+// Backward of the network's output projection (out_conv: nn.Conv3d(features, out_channels, 1), reference model/unet.py:638)
+// in ONE pass over its input x (a ReLU output): dw, db as tem_conv3d_wgrad AND the masked data gradient
+// gx = (x > 0) * (g . w) as tem_conv3d_fwd(transposed pack, ref = x) -- two kernels that each read the 512 MB tensor before.
+extern "C" int tem_conv1x1_out_bwd_ok(int Cin, int Cout) {
+    return Cin % 32 == 0 && Cin <= 64 && Cout >= 1 && Cout <= 4 && (Cin / 32) * Cout <= 8;
+}
+extern "C" int tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g_ld, const float* w, float* gx,
+                                   int64_t gx_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int64_t NV, int Cin,
+                                   int Cout, tem_stream_t stream) {
+    TEM_REQUIRE(x && g && w && gx && dw && ws && NV > 0 && x_ld >= Cin && gx_ld >= Cin && g_ld >= Cout,
+                "tem_conv1x1_out_bwd: bad arguments");
+    TEM_REQUIRE(tem_conv1x1_out_bwd_ok(Cin, Cout), "tem_conv1x1_out_bwd: tem_conv1x1_out_bwd_ok() == 0 for %d -> %d", Cin, Cout);
+    TEM_REQUIRE(ws_bytes >= tem_conv1x1_proj_wgrad_ws(Cin, Cout), "tem_conv1x1_out_bwd: workspace too small");
+    if (!tem_conv1x1_out_bwd(x, x_ld, g, g_ld, w, gx, gx_ld, dw, db, ws, NV, Cin, Cout, 1, (hipStream_t)stream)) {
+        tem_set_error("tem_conv1x1_out_bwd: x / gx / w need 16-byte alignment and ld %% 4 == 0");
+        return TEM_EINVAL;
+    }
+    TEM_CHECK_LAUNCH("tem_conv1x1_out_bwd");
+    return TEM_OK;
+}
+extern "C" int64_t tem_conv1x1_out_bwd_ws(int Cin, int Cout) { return tem_conv1x1_proj_wgrad_ws(Cin, Cout); }
+
 extern "C" int tem_conv3d_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                         int use_mfma) {
     return use_mfma == 2 && tem_conv_wgrad_gmax_ok(N, D, H, W, Cin, Cout, kd, kh, kw);

@@ -33,6 +33,8 @@ bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const fl
 int64_t tem_conv1x1_proj_wgrad_ws(int Cin, int Cout);
 bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, const float* g, int64_t g_ld, float* dw,
                             float* db, void* ws, int64_t NV, int Cin, int Cout, int sd_layout, hipStream_t s);
+bool tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g_ld, const float* w, float* gx, int64_t gx_ld,
+                         float* dw, float* db, void* ws, int64_t NV, int Cin, int Cout, int sd_layout, hipStream_t s);
 bool tem_conv1x1_expand(const float* x, int64_t x_ld, const float* scale, const float* w, const float* bias, float* y,
                         int64_t y_ld, const float* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act,
                         hipStream_t s);

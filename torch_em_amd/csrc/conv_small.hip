@@ -976,11 +976,17 @@ bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const fl
 }
 
 // weight gradient of the projection: dw[ci][co] = sum_v x[v][ci] * g[v][co], db[co] = sum_v g[v][co]
-template <int COUT, int NJ>
+// EXP (tem_conv1x1_out_bwd, round 4): the same pass also writes the DATA gradient of the projection,
+//   gx[v][ci] = x[v][ci] > 0 ? sum_co g[v][co] * w[co][ci] : 0   (x is the ReLU output the projection read),
+// which used to be k_conv1x1_expand's own pass over x (a 512 MB tensor at the out_conv of a 128^3 net): the thread that
+// holds 4 channels of x for the weight gradient holds what the mask and the 16-byte store need.
+template <int COUT, int NJ, bool EXP = false>
 __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restrict__ x, int64_t x_ld,
                                                             const float* __restrict__ g, int64_t g_ld,
                                                             float* __restrict__ part /*[grid][Cin+1][COUT]*/,
-                                                            int64_t NV, int Cin) {
+                                                            int64_t NV, int Cin, const float* __restrict__ w = nullptr,
+                                                            float* __restrict__ gx = nullptr, int64_t gx_ld = 0,
+                                                            unsigned* __restrict__ amax = nullptr) {
     extern __shared__ float lds[];  // [4][Cin+1][COUT]
     const int l8 = threadIdx.x & 7;
     const int64_t vstride = (int64_t)gridDim.x * 32;
@@ -995,6 +1001,20 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restr
             for (int co = 0; co < COUT; ++co) acc[a][j][co] = 0.f;
 #pragma unroll
     for (int co = 0; co < COUT; ++co) gacc[co] = 0.f;
+    float wq[EXP ? NJ : 1][EXP ? COUT : 1][4];   // EXP: w[co][a * 32 + l8 * 4 .. + 3]
+    float amx = 0.f;
+    if (EXP) {
+#pragma unroll
+        for (int a = 0; a < NJ; ++a)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float4 t = *reinterpret_cast<const float4*>(w + (int64_t)co * Cin + a * 32 + l8 * 4);
+                wq[a][co][0] = t.x;
+                wq[a][co][1] = t.y;
+                wq[a][co][2] = t.z;
+                wq[a][co][3] = t.w;
+            }
+    }
     for (int64_t v = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); v < NV; v += vstride) {
         float gv[COUT];
 #pragma unroll
@@ -1012,9 +1032,22 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restr
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int co = 0; co < COUT; ++co) acc[a][j][co] = fmaf(xv[j], gv[co], acc[a][j][co]);
+                if (EXP) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t2 = 0.f;
+#pragma unroll
+                        for (int co = 0; co < COUT; ++co) t2 = fmaf(gv[co], wq[a][co][j], t2);   // same order as k_conv1x1_expand
+                        o[j] = xv[j] > 0.f ? t2 : 0.f;
+                    }
+                    ST4(gx + v * gx_ld + a * 32 + l8 * 4, make_float4(o[0], o[1], o[2], o[3]));
+                    amx = tem_amax4(amx, o[0], o[1], o[2], o[3]);
+                }
             }
         }
     }
+    if (EXP && amax) tem_amax_commit(amax, amx);
     // lanes with equal l8 inside a wave: xor 8, 16, 32
 #pragma unroll
     for (int a = 0; a < NJ; ++a)
@@ -1093,6 +1126,38 @@ bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, co
 #undef PWJ
     const int64_t slab = (int64_t)(Cin + 1) * Cout;
     tem_reduce_slabs_w(part, grid, 1, Cin, Cout, slab, dw, sd_layout, s);  // [tap=0][ci][co]
+    if (db) tem_reduce_slabs(part + (int64_t)Cin * Cout, grid, Cout, slab, db, s);
+    return true;
+}
+
+// out_conv backward in ONE pass over x: weight / bias gradient of the projection AND its masked data gradient
+// (w: state_dict layout [Cout][Cin]).  false: shape not covered (the caller runs the two separate kernels).
+bool tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g_ld, const float* w, float* gx, int64_t gx_ld,
+                         float* dw, float* db, void* ws, int64_t NV, int Cin, int Cout, int sd_layout, hipStream_t s) {
+    if (Cin % 32 || Cin > 64 || x_ld % 4 || ((uintptr_t)x % 16) || gx_ld % 4 || ((uintptr_t)gx % 16) || ((uintptr_t)w % 16)) return false;
+    const int njr = Cin / 32;
+    if (Cout > 4 || njr * Cout > 8) return false;   // wq registers: NJ * COUT * 4 per lane beside the accumulators
+    int64_t nb = tem_cdiv(NV, 32);
+    const int grid = (int)(nb < PROJ_GRID ? nb : PROJ_GRID);
+    float* part = (float*)ws;
+    size_t ldsb = (size_t)4 * (Cin + 1) * Cout * sizeof(float);
+    unsigned* const amax = tem_take_output_amax();
+#define OBJ(CO, J)                                                                                                     \
+    hipLaunchKernelGGL((k_conv1x1_proj_wgrad<CO, J, true>), dim3(grid), dim3(256), ldsb, s, x, x_ld, g, g_ld, part, NV, Cin, w, gx, \
+                       gx_ld, amax)
+#define OB(CO)                \
+    case CO:                  \
+        if (njr == 1) OBJ(CO, 1); \
+        else OBJ(CO, 2);      \
+        break;
+    switch (Cout) {
+        OB(1) OB(2) OB(3) OB(4)
+        default: return false;
+    }
+#undef OB
+#undef OBJ
+    const int64_t slab = (int64_t)(Cin + 1) * Cout;
+    tem_reduce_slabs_w(part, grid, 1, Cin, Cout, slab, dw, sd_layout, s);
     if (db) tem_reduce_slabs(part + (int64_t)Cin * Cout, grid, Cout, slab, db, s);
     return true;
 }

@@ -191,6 +191,7 @@ def _dgrad16_ok(spec, g) -> bool:
 _WGRAD_F16X2 = os.environ.get("TEM_WGRAD_ARITH", "f16x2") == "f16x2"
 
 
+_FUSE_OUT_BWD = os.environ.get("TEM_FUSE_OUT_BWD", "1") != "0"   # out_conv: weight gradient + masked data gradient in one kernel
 _FUSE_AMAX = os.environ.get("TEM_FUSE_AMAX", "1") != "0"   # 0: every fp16 2x1 weight gradient runs its own absmax pass
 
 
@@ -871,8 +872,16 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
     last = st["last"]
     if "ospec" in st:
         g_cur = torch.empty_like(last)
-        _dgrad(st["ospec"], g, g_cur, ref=last, grads=grads)
-        _wgrad(st["ospec"], last, g, grads)
+        osp = st["ospec"]
+        if _FUSE_OUT_BWD and not _FORCE_GENERIC and not _OVERLAP_WGRAD and osp.k == (1, 1, 1) and osp.conv.weight.is_contiguous() and \
+                ops.conv1x1_out_bwd_ok(osp.cin, osp.cout):
+            # weight / bias gradient of out_conv and its masked data gradient in one pass over `last`
+            with _output_amax(grads, g_cur):
+                ops.conv1x1_out_bwd(last, g, osp.conv.weight, g_cur, grads.view(osp.conv.weight),
+                                    grads.view(osp.conv.bias) if osp.conv.bias is not None else None)
+        else:
+            _dgrad(osp, g, g_cur, ref=last, grads=grads)
+            _wgrad(osp, last, g, grads)
     else:
         g_cur = torch.empty_like(last)
         ops.maxpool_bwd(g, last, g_cur, (1, 1, 1), relu_mask=True)

@@ -341,6 +341,25 @@ def conv_wgrad_gmax(x, g, k, cin, cout, dw_out, db_out, gmax, scale=None, shift=
     return sums
 
 
+def conv1x1_out_bwd_ok(cin, cout) -> bool:
+    return bool(_lib.load().tem_conv1x1_out_bwd_ok(int(cin), int(cout)))
+
+
+def conv1x1_out_bwd(x, g, w, gx, dw_out, db_out=None):
+    """Backward of the output projection in one pass over its input x (tem_conv1x1_out_bwd): dw [cout, cin, 1, 1, 1]-ordered, db,
+    and gx = (x > 0) * (g . w).  x, gx: [N, D, H, W, cin(ld)]; g: [N, D, H, W, cout(ld)]; w: the conv's weight (state_dict)."""
+    _req_cuda(x, g, w, gx, dw_out)
+    N, D, H, W, cin, x_ld = _act5(x)
+    cout, g_ld = _act5(g)[4], _act5(g)[5]
+    gx_ld = _act5(gx)[5]
+    lib = _lib.load()
+    nws = lib.tem_conv1x1_out_bwd_ws(cin, cout)
+    ws = _workspace(nws, x.device)
+    _lib.check(lib.tem_conv1x1_out_bwd(_p(x), x_ld, _p(g), g_ld, _p(w.detach()), _p(gx), gx_ld, _p(dw_out), _p(db_out), _p(ws), nws,
+                                       N * D * H * W, cin, cout, _stream(x)), "tem_conv1x1_out_bwd")
+    return gx
+
+
 def conv_wgrad_gscaled_ok(x, k, cin, cout) -> bool:
     N, D, H, W, _, _ = _act5(x)
     return bool(_lib.load().tem_conv3d_wgrad_gscaled_ok(N, D, H, W, cin, cout, k[0], k[1], k[2]))
