@@ -138,8 +138,10 @@ def test_prediction_blocking_matches_oracle_and_has_no_cpu_path():
     model = UNet3d(1, 1, depth=1, initial_features=4)
     with pytest.raises(RuntimeError):
         predict_with_halo(np.zeros((8, 8, 8), "float32"), model, ["cpu"], (8, 8, 8), (0, 0, 0))
-    with pytest.raises(NotImplementedError):
-        predict_with_halo(np.zeros((8, 8, 8), "float32"), model, [0, 1], (8, 8, 8), (0, 0, 0))
+    with pytest.raises(RuntimeError):   # any CPU entry among several devices: refused before anything runs
+        predict_with_halo(np.zeros((8, 8, 8), "float32"), model, ["cuda:0", "cpu"], (8, 8, 8), (0, 0, 0))
+    with pytest.raises(ValueError):
+        predict_with_halo(np.zeros((8, 8, 8), "float32"), model, [], (8, 8, 8), (0, 0, 0))
 
 
 def test_bench_kernel_names_match_committed_profiles():
@@ -151,10 +153,10 @@ def test_bench_kernel_names_match_committed_profiles():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    traffic = json.load(open(os.path.join(root, "profiles", "r03_traffic_bytes_per_launch.json")))
+    traffic = json.load(open(os.path.join(root, "profiles", "r04_traffic_bytes_per_launch.json")))
     # the kernels that lead the default (fp32-class) step of this round
-    for tag in ("k_conv_zr_f16x3<3,3,3>", "k_conv_zr_bf16x3<3,3,3>", "k_conv_wgrad_bf16x3<3,3,3,NCO=1>",
-                "k_conv_wgrad_bf16x3<3,3,3,NCO=2>"):
+    for tag in ("k_conv_zr_f16x3<3,3,3>", "k_conv_zr_bf16x3<3,3,3>", "k_conv_wgrad_f16x2<3,3,3,NCO=1>",
+                "k_conv_wgrad_f16x2<3,3,3,NCO=2>"):
         assert mod.RP_NAMES[tag] in traffic, (tag, mod.RP_NAMES[tag])
 
 
