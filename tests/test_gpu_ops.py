@@ -792,6 +792,37 @@ def test_output_amax_is_a_by_product_of_the_gradient_producers():
     assert left and int(am.item()) == 0
 
 
+def test_absmax_strided_rows_accumulation_and_non_finite_values():
+    """tem_absmax: rows with a leading dimension (a channel slice of a wider buffer), accumulation into a non-zero word
+    (integer max), and non-finite values: inf wins (the largest finite-ordered pattern); a NaN is skipped by the float maximum
+    -- harmless, because the consumer (the prescaled weight gradient) multiplies the NaN itself through."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(41)
+    wide = torch.randn(2, 5, 6, 7, 48, generator=gen).to(DEV)
+    sl = wide[..., 8:40]                                   # ld = 48, C = 32, 16-byte aligned start
+    am = ops.absmax(sl)
+    assert int(am.item()) == int(sl.abs().max().view(torch.int32).item())
+    assert int(am.item()) <= int(wide.abs().max().view(torch.int32).item())
+    big = torch.full((1, 1, 1, 1, 4), 3.0e4, device=DEV)
+    am2 = ops.absmax(big, am.clone())
+    assert int(am2.item()) == int(torch.tensor(3.0e4).view(torch.int32).item())
+    am3 = ops.absmax(sl, am2)                              # smaller values do not lower the word
+    assert int(am3.item()) == int(torch.tensor(3.0e4).view(torch.int32).item())
+    bad = sl.clone().contiguous()
+    bad[1, 2, 3, 4, 5] = float("inf")
+    assert int(ops.absmax(bad).item()) == 0x7f800000
+    bad2 = sl.clone().contiguous()
+    bad2[0, 0, 0, 0, 0] = float("nan")
+    assert int(ops.absmax(bad2).item()) == int(sl.abs().max().view(torch.int32).item())
+    # ... and the NaN reaches the weight gradient it would be the prescale of
+    x5 = torch.randn(1, 16, 8, 8, 32, generator=gen).to(DEV)
+    g5 = torch.randn(1, 16, 8, 8, 32, generator=gen).to(DEV)
+    g5[0, 3, 3, 3, 7] = float("nan")
+    dw = torch.empty(32 * 32 * 27, device=DEV)
+    ops.conv_wgrad_gscaled(x5, g5, (3, 3, 3), 32, 32, dw, None, ops.absmax(g5))
+    assert bool(torch.isnan(dw.view(32, 32, 27)[7]).any())
+
+
 def test_wgrad_fp16_two_by_one_zero_gradient_and_norm_sums():
     """all-zero g (max |g| = 0: no prescale) gives zeros; with sums_from the norm-backward sums come out as for bf16x3"""
     ops = _ops()

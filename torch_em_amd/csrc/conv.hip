@@ -658,7 +658,8 @@ extern "C" int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* 
 
 // ---- weight gradient with 16-bit-class x^ and an 11-bit g (two MFMAs per product instead of three) -----------------------
 __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, int64_t ld, int cq, int64_t nq, unsigned* __restrict__ amax) {
-    // nq = voxels * cq float4 items; max |x| as an integer max of the bit patterns (exact, order-independent; NaN / inf win)
+    // nq = voxels * cq float4 items; max |x| as an integer max of the bit patterns (exact, order-independent; inf wins, NaNs are
+    // skipped by v_max_f32 -- the consumers multiply the NaN itself through, so nothing is hidden)
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256) {
         const int64_t v = i / cq;
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, int
         m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t.x), __builtin_fabsf(t.y)),
                                                __builtin_fmaxf(__builtin_fabsf(t.z), __builtin_fabsf(t.w))));
     }
-    unsigned u = __builtin_bit_cast(unsigned, m);   // fmaxf drops NaNs: compare as integers from here on
+    unsigned u = __builtin_bit_cast(unsigned, m);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o, 64));
     __shared__ unsigned red[4];
