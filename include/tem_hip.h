@@ -233,6 +233,14 @@ int tem_conv3d_wgrad_gscaled(const float* x, int64_t x_ld, const float* scale, c
  * Never affects the values written. */
 int tem_arm_output_amax(unsigned* amax);
 int tem_disarm_output_amax(void);
+/* The second stage of the norm backward as a BY-PRODUCT of the weight gradient that delivers its first stage
+ * (tem_conv3d_wgrad_sums / _gscaled / _gmax with norm_sums): tem_arm_wgrad_norm_coef attaches the request to the calling
+ * thread's NEXT such call; when C / G is a power of two <= 32 that call also writes coef [N][C][4] -- bit for bit what
+ * tem_norm_bwd_coef(sums = norm_sums, dgamma = dbeta = NULL) would -- and consumes the request (one launch less per layer).
+ * tem_disarm_wgrad_norm_coef() clears it and returns 1 when it was NOT consumed (the caller then runs tem_norm_bwd_coef).
+ * The affine gradients (dgamma, dbeta) are not part of it: a norm with affine parameters still needs tem_norm_bwd_coef. */
+int tem_arm_wgrad_norm_coef(int G, const float* mean, const float* rstd, float* coef);
+int tem_disarm_wgrad_norm_coef(void);
 /* *amax = max(*amax, bit pattern of max |x|) over nvox rows of C floats (row stride ld): integer atomicMax, exact and
  * order-independent; the caller clears the word.  The prescale source of tem_conv3d_wgrad_gscaled / tem_conv3d_fwd_gscaled
  * when no producer of the tensor delivered it (no reference counterpart: torch.autocast has no per-tensor scale). */

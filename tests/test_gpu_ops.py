@@ -304,7 +304,11 @@ def test_conv_zreuse_split_k(case):
             for mode in (2, 4, 5):
                 fam = lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, 3, 3, 3, mode)
                 assert fam == (4 if splitk else 0), (mode, fam)
-                assert lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, Cin, Cout, 3, 3, 3, mode) == 0     # split-K: no fused statistics
+                # the split-K epilogue writes the statistics partials (round 4): 4 rows of 256 / (Cout / 4) voxels per block;
+                # the patch kernel's split-K (option off) cannot
+                vb = 4 * (256 // (Cout // 4))
+                assert lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, Cin, Cout, 3, 3, 3, mode) == \
+                    ((D * H * W + vb - 1) // vb if splitk else 0)
                 y5 = torch.full((N, D, H, W, Cout + 4), 3.0, device=DEV)                                # a channel slice of a wider buffer
                 ops.conv_fwd(x5, ops.pack_weights(wd, transpose=False, mfma=mode), b.to(DEV), y5[..., :Cout], k, Cin, Cout,
                              scale=scale.to(DEV), shift=shift.to(DEV), act="relu", mfma=mode)
@@ -476,7 +480,7 @@ def test_norm_backward_epilogue_is_deterministic_over_repeated_launches(mode):
             assert torch.equal(got, first), f"launch {i} differs from launch 0 in {int((got != first).sum())} elements"
 
 
-@pytest.mark.parametrize("case", [      # >= 384 workgroups each: smaller launches run split-K and cannot fuse
+@pytest.mark.parametrize("case", [
     (2, 18, 61, 67, 32, 64, (3, 3, 3), 32),   # z-reuse kernel (720 units), ragged in z, y and x, two column tiles, GroupNorm(32, 64)
     (2, 32, 64, 64, 32, 32, (3, 3, 3), 32),   # z-reuse kernel, exactly one unit per team
     (2, 17, 50, 66, 32, 32, (3, 3, 3), 32),   # ragged patches, one column tile
@@ -484,6 +488,9 @@ def test_norm_backward_epilogue_is_deterministic_over_repeated_launches(mode):
     (2, 8, 48, 48, 64, 96, (1, 3, 3), 96),    # three column tiles
     (1, 1, 330, 400, 16, 64, (1, 3, 3), 64),  # 2-D patches
     (2, 16, 64, 64, 64, 32, (1, 1, 1), 1),    # 1x1x1, a single group
+    (2, 8, 8, 8, 256, 512, (3, 3, 3), 512),   # z-reuse kernel with split input channels: the split-K epilogue writes them
+    (2, 16, 16, 16, 128, 256, (3, 3, 3), 32), # the same at 16^3, GroupNorm(32, 256)
+    (4, 6, 12, 12, 128, 128, (3, 3, 3), 128), # ragged split-K tiles (the 6 x 12 x 12 level of cfg 5)
 ])
 @pytest.mark.parametrize("mode", [2, 3, 4])
 def test_conv_fused_forward_statistics(case, mode):
@@ -501,7 +508,11 @@ def test_conv_fused_forward_statistics(case, mode):
     y5 = ops.new_act(N, D, H, W, Cout, DEV)
     wp = ops.pack_weights(w, transpose=False, mfma=mode)
     got = ops.conv_fwd(x5, wp, b, y5, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=mode, want_stats=True)
-    assert got is not None
+    if got is None:
+        # the only launches that may decline: split-K of the PATCH kernel (family 0: e.g. mode 3 has no z-reuse split-K launch)
+        from torch_em_amd import _lib
+        assert _lib.load().tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, *k, mode) == 0 and D * H * W <= 16 ** 3
+        return
     part, nblk = got
     y_ref = ops.new_act(N, D, H, W, Cout, DEV)
     ops.conv_fwd(x5, wp, b, y_ref, k, Cin, Cout, scale=scale, shift=shift, act="relu", mfma=mode)
@@ -600,6 +611,45 @@ def test_wgrad_delivers_norm_backward_sums(case):
     if affine:
         assert float((outs[1][1] - outs[0][1]).abs().max()) < 1e-4 * sb and \
             float((outs[1][2] - outs[0][2]).abs().max()) < 1e-4 * sa
+
+
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, 24, 32, 32, 32),    # InstanceNorm: one channel per group
+    (2, 16, 16, 16, 64, 64, 16),    # GroupNorm without affine, 4 channels per group, two blocks of 32 channels
+    (1, 20, 24, 17, 32, 32, 1),     # one group of 32 channels
+    (3, 17, 9, 10, 64, 32, 1),      # one group of 64 channels: wider than a block -> the request stays armed
+    (2, 16, 16, 16, 96, 32, 32),    # 3 channels per group: not a power of two -> stays armed
+])
+def test_wgrad_sums_also_deliver_the_norm_backward_coefficients(case):
+    """tem_arm_wgrad_norm_coef: the kernel that finishes the norm sums also writes coef [N, C, 4] -- bit for bit what
+    tem_norm_bwd_coef(sums=...) derives from them -- and leaves the request armed when the group layout does not fit."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout, G = case
+    k = (3, 3, 3)
+    gen = torch.Generator().manual_seed(11)
+    x5 = to5(torch.randn(N, Cin, D, H, W, generator=gen) * 1.5 + 0.3)
+    g5 = to5(torch.randn(N, Cout, D, H, W, generator=gen))
+    w = (torch.randn(Cout, Cin, *k, generator=gen) * 0.1).to(DEV)
+    if not ops.conv_wgrad_sums_ok(x5, k, Cin, Cout, 2):
+        pytest.skip("the wgrad_sums options exclude this size (tests/conftest.py sets the threshold to 0)")
+    mean, rstd, scale, shift = ops.norm_stats(x5, G, None, None, 1e-5)[:4]
+    dw, db = torch.empty(w.numel(), device=DEV), torch.empty(Cout, device=DEV)
+    coef = torch.full((N, Cin, 4), float("nan"), device=DEV)
+    ops.arm_wgrad_norm_coef(G, mean, rstd, coef)
+    sums = ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=2, sums_from=(w, None, None))
+    left = ops.disarm_wgrad_norm_coef()
+    cg = Cin // G
+    assert left == (not (cg <= 32 and cg & (cg - 1) == 0))
+    assert not ops.disarm_wgrad_norm_coef()          # one-shot: nothing stays behind
+    want = ops.norm_bwd_coef(x5, x5, G, None, mean, rstd, sums=sums)   # with sums the tensors are not read
+    if left:
+        assert bool(torch.isnan(coef).all())          # untouched
+    else:
+        assert torch.equal(coef, want)
+    # a plain weight gradient in between does not consume the request; the next sums launch does
+    ops.arm_wgrad_norm_coef(G, mean, rstd, coef)
+    ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=2)
+    assert ops.disarm_wgrad_norm_coef()
 
 
 @pytest.fixture

@@ -1,5 +1,6 @@
 // capi.hip -- library-level entry points of libtem_hip.so and the layout utilities.
 #include "tem_common.h"
+#include "conv_internal.h"
 #include <stdarg.h>
 #include <string.h>
 
@@ -81,6 +82,19 @@ extern "C" int tem_arm_output_amax(unsigned* amax) {
 extern "C" int tem_disarm_output_amax(void) {
     const int pending = g_output_amax != nullptr;
     g_output_amax = nullptr;
+    return pending;
+}
+
+// ---- norm-backward coefficients as a by-product of the weight gradient that delivers the norm sums (same one-shot shape) --
+thread_local TemWgradCoefReq tem_wgrad_coef_req = {0, nullptr, nullptr, nullptr};
+extern "C" int tem_arm_wgrad_norm_coef(int G, const float* mean, const float* rstd, float* coef) {
+    TEM_REQUIRE(G > 0 && mean && rstd && coef, "tem_arm_wgrad_norm_coef: bad arguments");
+    tem_wgrad_coef_req = {G, mean, rstd, coef};
+    return TEM_OK;
+}
+extern "C" int tem_disarm_wgrad_norm_coef(void) {
+    const int pending = tem_wgrad_coef_req.coef != nullptr;
+    tem_wgrad_coef_req = {0, nullptr, nullptr, nullptr};
     return pending;
 }
 

@@ -621,9 +621,12 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
                                    nsplit, stat, s);
     if (pp < 0) return TEM_EINVAL;
     if (pp) return TEM_OK;
-    if (!stat && tem_conv_fwd_zr_splitk(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin, Cout,
-                                        kd, kh, kw, act, nsplit, s))
+    if (tem_conv_fwd_zr_splitk(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh,
+                               kw, act, nsplit, stat, s))
         return TEM_OK;
+    TEM_REQUIRE(!stat || tem_conv_zr_splitk_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit) < 0,
+                "tem_conv3d_fwd_stats: the split-K launch that writes the statistics needs its workspace "
+                "(tem_conv3d_fwd_ws) and 16-byte aligned y / ref / bias");
     if (kd == 1 && kh == 1 && kw == 1 && tem_option(TEM_OPT_CONV1X1_STREAM) &&
         tem_conv1x1_stream(x, x_ld, scale, wp, bias, y, y_ld, ref, ref_ld, (int64_t)N * D * H * W, Cin, Cout, act, nsplit, stat, s))
         return TEM_OK;
@@ -713,6 +716,10 @@ int64_t tem_conv_fwd_bf16x3_stat_blocks(int N, int D, int H, int W, int Cin, int
     if (zrb >= 0) return zrb;
     const int64_t ppb = tem_conv_pp_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit);
     if (ppb >= 0) return ppb;
+    if (tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit)) {   // z-reuse kernel with split input channels: its epilogue
+        const int64_t skb = tem_conv_zr_splitk_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit);
+        return skb > 0 ? skb : 0;
+    }
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     if (key != 7 && key != 3 && key != 0) return 0;
     const bool flat = (D == 1 && kd == 1);
@@ -1914,8 +1921,7 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
         if (norm_sums) {
             float* extra = zdb + tem_align_up((int64_t)z.S * Cout, 64);
             tem_wgrad_sums_launch(zpart, z.Ss, z.ks2, zdb, g, g_ld, w_sd, gamma, beta, dw, extra, N, D, H, W, Cin, Cout,
-                                  norm_sums, s);
-            if (db) tem_reduce_slabs(zdb, z.S, Cout, Cout, db, s);
+                                  norm_sums, z.S, db, s);
         } else {
             tem_reduce_slabs_w_db(zpart, z.S * z.ks2, 27, Cin, Cout, (int64_t)27 * Cin * Cout, dw, sd_layout, zdb, z.S, db, s);
         }

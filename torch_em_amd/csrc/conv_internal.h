@@ -65,7 +65,7 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
 int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                            const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
                            int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
-                           int nsplit, hipStream_t s);
+                           int nsplit, float* stat, hipStream_t s);
 int tem_conv_zr_splitk_ks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
 int64_t tem_conv_zr_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
 // conv1x1_stream.hip: 1x1x1 convolution / data gradient as a streaming GEMM (false: not taken)
@@ -76,6 +76,10 @@ bool tem_conv1x1_stream(const float* x, int64_t x_ld, const float* scale, const 
 int tem_fwd_ksplit(int64_t nblk, int nchunks);
 void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, const float* bias, int act,
                          const float* ref, int64_t ref_ld, float* y, int64_t y_ld, hipStream_t s);
+int64_t tem_splitk_stat_blocks(int64_t V, int Cout);
+int64_t tem_conv_zr_splitk_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
+void tem_splitk_epilogue_stats(const float* part, int ksplit, int N, int64_t V, int Cout, const float* bias, int act,
+                               const float* ref, int64_t ref_ld, float* y, int64_t y_ld, float* stat, hipStream_t s);
 int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
                           int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
@@ -96,9 +100,17 @@ void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_
                               const float* g, int64_t g_ld, float* zpart, float* zdb, int N, int D, int H, int W, int Cin,
                               int Cout, int T, int nY, int nX, int zsegs, int Ss, int ncz, unsigned* gmax,
                               const unsigned* g_amax, hipStream_t s);
+// capi.hip: tem_arm_wgrad_norm_coef -- taken (cleared) by tem_wgrad_sums_launch when the layer's group layout allows it
+struct TemWgradCoefReq {
+    int G;
+    const float* mean;
+    const float* rstd;
+    float* coef;
+};
+extern thread_local TemWgradCoefReq tem_wgrad_coef_req;
 // wgrad_sums.hip: norm-backward sums from the weight gradient
 int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int64_t tem_wgrad_sums_ws_floats(int N, int D, int H, int Cin, int Cout);
 void tem_wgrad_sums_launch(const float* zpart, int Ss, int ks2, const float* zdb, const float* g, int64_t g_ld,
                            const float* w, const float* gamma, const float* beta, float* dw, float* extra, int N, int D,
-                           int H, int W, int Cin, int Cout, float* sums, hipStream_t s);
+                           int H, int W, int Cin, int Cout, float* sums, int db_chunks, float* db, hipStream_t s);

@@ -445,19 +445,31 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
         const int64_t v = i / cq;
         const int c0 = (int)(i % cq) * 4;
         float4 a = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < ksplit; ++k) {
-            const float4 p = *reinterpret_cast<const float4*>(part + ((int64_t)k * NV + v) * Cout + c0);
-            a.x += p.x;
-            a.y += p.y;
-            a.z += p.z;
-            a.w += p.w;
+        float4 r = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (ref) r = *reinterpret_cast<const float4*>(ref + v * ref_ld + c0);   // issued with the slices, used at the end
+        // four slices per trip, loads unconditional (slices beyond ksplit re-read the last one and are dropped): the
+        // one-load-per-trip loop was ksplit dependent round trips; the sum keeps its order k = 0, 1, 2, ...
+        for (int k0 = 0; k0 < ksplit; k0 += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u < ksplit ? k0 + u : ksplit - 1;
+                p[u] = *reinterpret_cast<const float4*>(part + ((int64_t)k * NV + v) * Cout + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = k0 + u < ksplit;
+                a.x += in ? p[u].x : 0.f;
+                a.y += in ? p[u].y : 0.f;
+                a.z += in ? p[u].z : 0.f;
+                a.w += in ? p[u].w : 0.f;
+            }
         }
         a.x = act_apply(a.x, act);
         a.y = act_apply(a.y, act);
         a.z = act_apply(a.z, act);
         a.w = act_apply(a.w, act);
         if (ref) {
-            const float4 r = *reinterpret_cast<const float4*>(ref + v * ref_ld + c0);
             if (!(r.x > 0.f)) a.x = 0.f;
             if (!(r.y > 0.f)) a.y = 0.f;
             if (!(r.z > 0.f)) a.z = 0.f;
@@ -465,6 +477,90 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
         }
         *reinterpret_cast<float4*>(y + v * y_ld + c0) = a;
     }
+}
+
+// k_splitk_epilogue that also writes the first stage of the statistics of y (sum, sum of squares per channel) for the norm
+// that reads y next -- the partial rows k_norm_partial<.,0> would produce in a pass of its own (one launch and one read
+// of y less per layer of the 8^3 / 16^3 levels).  Block (b, n): voxels [b VB, (b+1) VB) of sample n, thread = (channel
+// quad q, row r of 256 / cq rows); stat: [N][gridDim.x][Cout][2].
+__global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __restrict__ part, int ksplit, int64_t V,
+                                                               int Cout, const float* __restrict__ bias, int act,
+                                                               const float* __restrict__ ref, int64_t ref_ld,
+                                                               float* __restrict__ y, int64_t y_ld, int VB,
+                                                               float* __restrict__ stat) {
+    __shared__ float sh[2048];   // [rows][Cout][2], rows * Cout = 1024
+    const int cq = Cout >> 2, rows = 256 / cq;
+    const int q = threadIdx.x % cq, r = threadIdx.x / cq, c0 = q * 4;
+    const int n = blockIdx.y, b = blockIdx.x;
+    const int64_t NV = V * gridDim.y;
+    const int64_t v0 = (int64_t)b * VB, v1 = v0 + VB < V ? v0 + VB : V;
+    const float4 bz = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t vl = v0 + r; vl < v1; vl += rows) {
+        const int64_t v = (int64_t)n * V + vl;
+        float4 a = bz;
+        float4 rr = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (ref) rr = *reinterpret_cast<const float4*>(ref + v * ref_ld + c0);
+        for (int k0 = 0; k0 < ksplit; k0 += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u < ksplit ? k0 + u : ksplit - 1;
+                p[u] = *reinterpret_cast<const float4*>(part + ((int64_t)k * NV + v) * Cout + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = k0 + u < ksplit;
+                a.x += in ? p[u].x : 0.f;
+                a.y += in ? p[u].y : 0.f;
+                a.z += in ? p[u].z : 0.f;
+                a.w += in ? p[u].w : 0.f;
+            }
+        }
+        a.x = act_apply(a.x, act);
+        a.y = act_apply(a.y, act);
+        a.z = act_apply(a.z, act);
+        a.w = act_apply(a.w, act);
+        if (ref) {
+            if (!(rr.x > 0.f)) a.x = 0.f;
+            if (!(rr.y > 0.f)) a.y = 0.f;
+            if (!(rr.z > 0.f)) a.z = 0.f;
+            if (!(rr.w > 0.f)) a.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(y + v * y_ld + c0) = a;
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] += av[j];
+            s1[j] = fmaf(av[j], av[j], s1[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sh[(r * Cout + c0 + j) * 2 + 0] = s0[j];
+        sh[(r * Cout + c0 + j) * 2 + 1] = s1[j];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < Cout * 2; t += 256) {
+        float a = 0.f;
+        for (int k = 0; k < rows; ++k) a += sh[k * Cout * 2 + t];
+        stat[((int64_t)n * gridDim.x + b) * Cout * 2 + t] = a;
+    }
+}
+
+// partial rows per sample of tem_splitk_epilogue_stats (0: this Cout has no such epilogue)
+int64_t tem_splitk_stat_blocks(int64_t V, int Cout) {
+    const int cq = Cout >> 2;
+    if (Cout % 4 || cq < 8 || cq > 256 || (cq & (cq - 1))) return 0;
+    const int VB = 4 * (256 / cq);
+    return (V + VB - 1) / VB;
+}
+
+void tem_splitk_epilogue_stats(const float* part, int ksplit, int N, int64_t V, int Cout, const float* bias, int act,
+                               const float* ref, int64_t ref_ld, float* y, int64_t y_ld, float* stat, hipStream_t s) {
+    const int VB = 4 * (256 / (Cout >> 2));
+    hipLaunchKernelGGL(k_splitk_epilogue_stats, dim3((unsigned)tem_splitk_stat_blocks(V, Cout), (unsigned)N), dim3(256), 0, s, part,
+                       ksplit, V, Cout, bias, act, ref, ref_ld, y, y_ld, VB, stat);
 }
 
 // Split the input channels over `ks` workgroups when the (patches x Cout tiles) grid cannot fill

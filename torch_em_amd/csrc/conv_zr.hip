@@ -831,9 +831,11 @@ int tem_conv_zr_splitk_ks(int N, int D, int H, int W, int Cin, int Cout, int kd,
 int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                            const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
                            int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
-                           int nsplit, hipStream_t s) {
+                           int nsplit, float* stat, hipStream_t s) {
+    // stat: [N][tem_conv_zr_splitk_stat_blocks()][Cout][2] -- the epilogue also writes the statistics partials of y
     const int ks = ws ? tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit) : 0;
     if (!ks) return 0;
+    if (stat && !tem_splitk_stat_blocks((int64_t)D * H * W, Cout)) return 0;
     if ((int64_t)H * W * 8 * 4 * (x_ld > Cout ? x_ld : Cout) >= (1ll << 31)) return 0;
     if ((y_ld % 4) || ((uintptr_t)y % 16) || (ref && ((ref_ld % 4) || ((uintptr_t)ref % 16))) || (bias && ((uintptr_t)bias % 16)))
         return 0;
@@ -857,8 +859,18 @@ int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, con
     else if (nsplit == 4) ZRKS(2, true, false);
     else ZRKS(2, false, false);
 #undef ZRKS
-    tem_splitk_epilogue(part, ks, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
+    if (stat)
+        tem_splitk_epilogue_stats(part, ks, N, (int64_t)D * H * W, Cout, bias, act, ref, ref_ld, y, y_ld, stat, s);
+    else
+        tem_splitk_epilogue(part, ks, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
     return 1;
+}
+
+// statistics partial rows per sample when tem_conv_fwd_zr_splitk takes the launch with stat != NULL (-1: it does not)
+int64_t tem_conv_zr_splitk_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
+    if (!tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit)) return -1;
+    const int64_t nb = tem_splitk_stat_blocks((int64_t)D * H * W, Cout);
+    return nb > 0 ? nb : -1;
 }
 
 // tem_conv3d_fwd_gscaled (conv.hip) parks the device pointer of max |input| here around its call; the launch that honours

@@ -176,8 +176,8 @@ __global__ __launch_bounds__(VEC == 4 ? 256 : 1024) void k_norm_partial(const fl
     }
 }
 
-__device__ __forceinline__ void block_sum2_d(double& a, double& b) {
-    __shared__ double sh2[2][4];
+__device__ __forceinline__ void block_sum2_d(double& a, double& b) {   // blocks of 4 .. 16 waves
+    __shared__ double sh2[2][16];
     a = tem_wave_sum_d(a);
     b = tem_wave_sum_d(b);
     int w = threadIdx.x >> 6;
@@ -188,23 +188,46 @@ __device__ __forceinline__ void block_sum2_d(double& a, double& b) {
     __syncthreads();
     a = sh2[0][0] + sh2[0][1] + sh2[0][2] + sh2[0][3];
     b = sh2[1][0] + sh2[1][1] + sh2[1][2] + sh2[1][3];
+    for (int k = 4; k < (int)(blockDim.x >> 6); ++k) {
+        a += sh2[0][k];
+        b += sh2[1][k];
+    }
     __syncthreads();
 }
 
+// the (sum, sum of squares) pairs of channels [c0, c0 + cg) over the nblk partial rows of one sample ([nblk][C][2]), this
+// thread's share.  Eight independent 8-byte loads per trip: the level-0 convs leave 16 384 rows, and a loop of one
+// load + two dependent double adds per trip walked them in 64 round trips to L2 (42-46 us per call, r04 trace; 26 us
+// with 8 per trip, the rest of the way with 1024 threads for such layers: norm_finalize_threads).
+__device__ __forceinline__ void norm_sum_partials(const float* __restrict__ part, int nblk, int C, int cg, int c0,
+                                                  double& s, double& ss) {
+    const int total = nblk * cg, nt = (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < total; i0 += nt * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {   // never `cond ? load : 0` per lane: that is a branch + s_waitcnt vmcnt(0) per load
+            const int i = i0 + k * nt < total ? i0 + k * nt : total - 1;
+            const int b = i / cg, c = c0 + i % cg;
+            v[k] = *reinterpret_cast<const float2*>(part + ((int64_t)b * C + c) * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool in = i0 + k * nt < total;
+            s += in ? (double)v[k].x : 0.0;
+            ss += in ? (double)v[k].y : 0.0;
+        }
+    }
+}
+
 // stage 2 (forward): one block per (n, group)
-__global__ __launch_bounds__(256) void k_norm_finalize(const float* __restrict__ part, int nblk, int64_t V, int C, int G,
+__global__ __launch_bounds__(1024) void k_norm_finalize(const float* __restrict__ part, int nblk, int64_t V, int C, int G,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float* __restrict__ mean, float* __restrict__ rstd,
                                                        float* __restrict__ scale, float* __restrict__ shift) {
     const int n = blockIdx.x / G, grp = blockIdx.x % G;
     const int cg = C / G;
     double s = 0.0, ss = 0.0;
-    for (int i = threadIdx.x; i < nblk * cg; i += 256) {
-        int b = i / cg, c = grp * cg + i % cg;
-        int64_t o = (((int64_t)n * nblk + b) * C + c) * 2;
-        s += (double)part[o];
-        ss += (double)part[o + 1];
-    }
+    norm_sum_partials(part + (int64_t)n * nblk * C * 2, nblk, C, cg, grp * cg, s, ss);
     block_sum2_d(s, ss);
     double cnt = (double)V * (double)cg;
     double m = s / cnt;
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(256) void k_norm_finalize(const float* __restrict__
         mean[n * G + grp] = (float)m;
         rstd[n * G + grp] = (float)r;
     }
-    for (int i = threadIdx.x; i < cg; i += 256) {
+    for (int i = threadIdx.x; i < cg; i += (int)blockDim.x) {
         int c = grp * cg + i;
         double ga = gamma ? (double)gamma[c] : 1.0;
         double be = beta ? (double)beta[c] : 0.0;
@@ -224,9 +247,13 @@ __global__ __launch_bounds__(256) void k_norm_finalize(const float* __restrict__
     }
 }
 
+// threads of a finalize block: its nblk * cg partials are one trip of 8 loads per thread up to 2048 of them; the conv
+// epilogues of the 128^3 level leave 16 384 rows -- 1024 threads walk those in 2 trips instead of 8
+static int norm_finalize_threads(int64_t nblk, int cg) { return nblk * cg > 2048 ? 1024 : 256; }
+
 // stage 2 (forward) for a tensor whose channel halves have different producers (decoder concat): channels [0, CA) from
 // partA [n][nblkA][CA][2], channels [CA, C) from partB [n][nblkB][C-CA][2]; a group lies inside one half
-__global__ __launch_bounds__(256) void k_norm_finalize2(const float* __restrict__ partA, int nblkA, int CA,
+__global__ __launch_bounds__(1024) void k_norm_finalize2(const float* __restrict__ partA, int nblkA, int CA,
                                                         const float* __restrict__ partB, int nblkB, int64_t V, int C,
                                                         int G, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, float* __restrict__ mean,
@@ -238,12 +265,7 @@ __global__ __launch_bounds__(256) void k_norm_finalize2(const float* __restrict_
     const float* part = inA ? partA : partB;
     const int nblk = inA ? nblkA : nblkB, Cs = inA ? CA : C - CA, cbase = inA ? grp * cg : grp * cg - CA;
     double s = 0.0, ss = 0.0;
-    for (int i = threadIdx.x; i < nblk * cg; i += 256) {
-        int b = i / cg, c = cbase + i % cg;
-        int64_t o = (((int64_t)n * nblk + b) * Cs + c) * 2;
-        s += (double)part[o];
-        ss += (double)part[o + 1];
-    }
+    norm_sum_partials(part + (int64_t)n * nblk * Cs * 2, nblk, Cs, cg, cbase, s, ss);
     block_sum2_d(s, ss);
     double cnt = (double)V * (double)cg;
     double m = s / cnt;
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(256) void k_norm_finalize2(const float* __restrict_
         mean[n * G + grp] = (float)m;
         rstd[n * G + grp] = (float)r;
     }
-    for (int i = threadIdx.x; i < cg; i += 256) {
+    for (int i = threadIdx.x; i < cg; i += (int)blockDim.x) {
         int c = grp * cg + i;
         double ga = gamma ? (double)gamma[c] : 1.0;
         double be = beta ? (double)beta[c] : 0.0;
@@ -408,8 +430,8 @@ extern "C" int tem_norm_stats(const float* x, int64_t x_ld, int N, int64_t V, in
     else
         hipLaunchKernelGGL((k_norm_partial<1, 0>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, nullptr,
                            (int64_t)0, V, C, G, nullptr, nullptr, g.cq, g.rows, g.vper, part);
-    hipLaunchKernelGGL(k_norm_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, g.nblk, V, C, G, gamma,
-                       beta, eps, mean, rstd, scale, shift);
+    hipLaunchKernelGGL(k_norm_finalize, dim3(N * G), dim3(norm_finalize_threads(g.nblk, C / G)), 0, (hipStream_t)stream, part,
+                       g.nblk, V, C, G, gamma, beta, eps, mean, rstd, scale, shift);
     TEM_CHECK_LAUNCH("tem_norm_stats");
     return TEM_OK;
 }
@@ -422,8 +444,8 @@ extern "C" int tem_norm_finalize_partials(const float* part, int64_t nblk, int N
     TEM_REQUIRE(part && mean && rstd && scale && shift, "tem_norm_finalize_partials: null pointer");
     TEM_REQUIRE(N > 0 && V > 0 && C > 0 && nblk > 0 && nblk < (1ll << 31) / 2, "tem_norm_finalize_partials: bad shape");
     TEM_REQUIRE(G > 0 && C % G == 0, "tem_norm_finalize_partials: C=%d not divisible by G=%d", C, G);
-    hipLaunchKernelGGL(k_norm_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, V, C, G, gamma,
-                       beta, eps, mean, rstd, scale, shift);
+    hipLaunchKernelGGL(k_norm_finalize, dim3(N * G), dim3(norm_finalize_threads(nblk, C / G)), 0, (hipStream_t)stream, part,
+                       (int)nblk, V, C, G, gamma, beta, eps, mean, rstd, scale, shift);
     TEM_CHECK_LAUNCH("tem_norm_finalize_partials");
     return TEM_OK;
 }
@@ -440,8 +462,9 @@ extern "C" int tem_norm_finalize_partials2(const float* partA, int64_t nblkA, in
                 "tem_norm_finalize_partials2: bad shape");
     TEM_REQUIRE(G > 0 && C % G == 0 && CA % (C / G) == 0,
                 "tem_norm_finalize_partials2: groups of %d channels must not straddle the split at %d", C / (G > 0 ? G : 1), CA);
-    hipLaunchKernelGGL(k_norm_finalize2, dim3(N * G), dim3(256), 0, (hipStream_t)stream, partA, (int)nblkA, CA, partB,
-                       (int)nblkB, V, C, G, gamma, beta, eps, mean, rstd, scale, shift);
+    hipLaunchKernelGGL(k_norm_finalize2, dim3(N * G), dim3(norm_finalize_threads(nblkA > nblkB ? nblkA : nblkB, C / G)), 0,
+                       (hipStream_t)stream, partA, (int)nblkA, CA, partB, (int)nblkB, V, C, G, gamma, beta, eps, mean, rstd, scale,
+                       shift);
     TEM_CHECK_LAUNCH("tem_norm_finalize_partials2");
     return TEM_OK;
 }
@@ -487,6 +510,8 @@ static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t
               (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0;
     int64_t items = V * (v4 ? C / 4 : C);
     dim3 agrid(tem_grid_1d(items, 256, 2048), N);
+    // (max |gx| as a by-product was tried here, round 4: every wave of this SHORT kernel ends at the same moment, reads the
+    // still-empty word and issues its atomicMax -- 8192 atomics on one address, +80 us per call; tem_absmax stays)
     if (v4)
         hipLaunchKernelGGL((k_norm_bwd_apply<4>), agrid, dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x, x_ld, gx,
                            gx_ld, V, C, coef, relu_mask);

@@ -448,7 +448,9 @@ __global__ __launch_bounds__(256) void k_instance_sums(const float* __restrict__
     for (int64_t v = v0 + threadIdx.x; v < v1; v += blockDim.x) {
         float ev[EM];
 #pragma unroll
-        for (int e = 0; e < EM; ++e) ev[e] = e < E ? emb[(int64_t)e * cs + v] : 0.f;
+        for (int e = 0; e < EM; ++e) ev[e] = emb[(int64_t)(e < E ? e : 0) * cs + v];   // unconditional loads (a predicated
+#pragma unroll                                                                          // one is a branch + vmcnt(0) each)
+        for (int e = 0; e < EM; ++e) ev[e] = e < E ? ev[e] : 0.f;
         const int l = (int)lbl[v];
 #pragma unroll
         for (int t = 0; t < SP_IT; ++t) {
@@ -549,9 +551,12 @@ __global__ __launch_bounds__(256) void k_push(const float* __restrict__ emb, int
         const bool bg = v < V && lbl[v] == 0;
         if (!__any(bg)) continue;
         float ev[EM], ge[EM];
+        const int64_t vc = v < V ? v : V - 1;
+#pragma unroll
+        for (int e = 0; e < EM; ++e) ev[e] = emb[(int64_t)(e < E ? e : 0) * cs + vc];   // unconditional, dropped below
 #pragma unroll
         for (int e = 0; e < EM; ++e) {
-            ev[e] = (bg && e < E) ? emb[(int64_t)e * cs + v] : 0.f;
+            ev[e] = (bg && e < E) ? ev[e] : 0.f;
             ge[e] = 0.f;
         }
         for (int i = 1; i < C; ++i) {
@@ -830,10 +835,16 @@ __global__ __launch_bounds__(256) void k_consistency(const float* __restrict__ e
     for (int64_t v = v0 + threadIdx.x; v < vend; v += blockDim.x) {
         const bool valid = v < v1;
         float q[EM], k[EM], ge[EM];
+        const int64_t vc = valid ? v : v1 - 1;
+#pragma unroll
+        for (int e = 0; e < EM; ++e) {   // unconditional loads, dropped below
+            q[e] = eq[(int64_t)(e < E ? e : 0) * cs + vc];
+            k[e] = ek[(int64_t)(e < E ? e : 0) * cs + vc];
+        }
 #pragma unroll
         for (int e = 0; e < EM; ++e) {
-            q[e] = (valid && e < E) ? eq[(int64_t)e * cs + v] : 0.f;
-            k[e] = (valid && e < E) ? ek[(int64_t)e * cs + v] : 0.f;
+            q[e] = (valid && e < E) ? q[e] : 0.f;
+            k[e] = (valid && e < E) ? k[e] : 0.f;
             ge[e] = 0.f;
         }
         for (int a = 0; a < A; ++a) {
@@ -1060,8 +1071,10 @@ __global__ __launch_bounds__(256) void k_aff_grad(const float* __restrict__ emb,
         const int x = (int)(u % W), y = (int)((u / W) % H), z = (int)(u / ((int64_t)W * H));
         float eu[EM], g[EM];
 #pragma unroll
+        for (int e = 0; e < EM; ++e) eu[e] = emb[(int64_t)(e < E ? e : 0) * cs + u];   // unconditional loads
+#pragma unroll
         for (int e = 0; e < EM; ++e) {
-            eu[e] = e < E ? emb[(int64_t)e * cs + u] : 0.f;
+            eu[e] = e < E ? eu[e] : 0.f;
             g[e] = 0.f;
         }
         const int64_t lu = lbl[u];

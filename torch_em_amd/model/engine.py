@@ -193,6 +193,38 @@ _WGRAD_F16X2 = os.environ.get("TEM_WGRAD_ARITH", "f16x2") == "f16x2"
 
 _FUSE_OUT_BWD = os.environ.get("TEM_FUSE_OUT_BWD", "1") != "0"   # out_conv: weight gradient + masked data gradient in one kernel
 _FUSE_AMAX = os.environ.get("TEM_FUSE_AMAX", "1") != "0"   # 0: every fp16 2x1 weight gradient runs its own absmax pass
+# the weight gradient that delivers the norm sums also finishes them into the norm-backward coefficients; 0: tem_norm_bwd_coef
+_FUSE_COEF = os.environ.get("TEM_FUSE_NORM_COEF", "1") != "0"
+
+
+class _sums_coef:
+    """`with _sums_coef(spec, stats, x) as rq: sums = <weight gradient with sums_from>; rq.attach(sums)` -- the launch inside
+    also writes the coefficients of the norm backward (tem_arm_wgrad_norm_coef) when the layer allows it; they travel on the
+    sums tensor (`_tem_coef`) to _norm_bwd_inplace(coef_only=True).  Norms with affine parameters keep the separate stage:
+    their dgamma / dbeta come from it."""
+
+    def __init__(self, spec, stats, x, on=True):
+        groups, gamma, beta, _ = spec.norm_args()
+        self.coef = None
+        if on and _FUSE_COEF and gamma is None and beta is None and stats is not None and stats[4] == "sample":
+            self.coef = torch.empty((x.shape[0], spec.cin, 4), dtype=torch.float32, device=x.device)
+            self.args = (groups, stats[0], stats[1])
+
+    def __enter__(self):
+        if self.coef is not None:
+            ops.arm_wgrad_norm_coef(*self.args, self.coef)
+        return self
+
+    def attach(self, sums):
+        if self.coef is not None and not ops.disarm_wgrad_norm_coef() and sums is not None:
+            sums._tem_coef = self.coef
+        self.coef = None
+        return sums
+
+    def __exit__(self, *exc):
+        if self.coef is not None:   # the launch raised before attach()
+            ops.disarm_wgrad_norm_coef()
+        return False
 
 
 class _output_amax:
@@ -462,8 +494,9 @@ def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None, want_sums=False, gma
                 ops.conv_wgrad_sums_ok(x, spec.k, spec.cin, spec.cout, ent["wgrad_mfma"]):
             _, gamma, beta, _ = spec.norm_args()
             sums_from = (spec.conv.weight, gamma, beta)
-        return ops.conv_wgrad_gmax(x, g, spec.k, spec.cin, spec.cout, dw, db, gmax, scale=scale, shift=shift,
-                                   mfma=ent["wgrad_mfma"], sums_from=sums_from)
+        with _sums_coef(spec, stats, x, on=sums_from is not None) as rq:
+            return rq.attach(ops.conv_wgrad_gmax(x, g, spec.k, spec.cin, spec.cout, dw, db, gmax, scale=scale, shift=shift,
+                                                 mfma=ent["wgrad_mfma"], sums_from=sums_from))
     if ent["wgrad_mfma"] == 2 and _wgrad_f16x2_ok(spec, x, stats):
         sums_from = None
         if want_sums and stats[4] == "sample" and db is not None and \
@@ -474,13 +507,15 @@ def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None, want_sums=False, gma
             amax = getattr(g, "_tem_amax", None)
         if amax is None:   # no producer of g delivered max |g|: one pass over g
             amax = ops.absmax(g, grads.amax_slot())
-        return ops.conv_wgrad_gscaled(x, g, spec.k, spec.cin, spec.cout, dw, db, amax, scale=scale, shift=shift,
-                                      sums_from=sums_from)
+        with _sums_coef(spec, stats, x, on=sums_from is not None) as rq:
+            return rq.attach(ops.conv_wgrad_gscaled(x, g, spec.k, spec.cin, spec.cout, dw, db, amax, scale=scale, shift=shift,
+                                                    sums_from=sums_from))
     if want_sums and stats is not None and stats[4] == "sample" and db is not None and not _OVERLAP_WGRAD and \
             ops.conv_wgrad_sums_ok(x, spec.k, spec.cin, spec.cout, ent["wgrad_mfma"]):
         _, gamma, beta, _ = spec.norm_args()
-        return ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"],
-                              sums_from=(spec.conv.weight, gamma, beta))
+        with _sums_coef(spec, stats, x) as rq:
+            return rq.attach(ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift,
+                                            mfma=ent["wgrad_mfma"], sums_from=(spec.conv.weight, gamma, beta)))
     if not _OVERLAP_WGRAD or (_OVERLAP_WGRAD == 1 and vox > _OVERLAP_MAX_VOXELS):
         ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
         return
@@ -600,6 +635,9 @@ def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sum
     mode = stats[4]
     if coef_only:
         assert mode == "sample"
+        ready = getattr(sums, "_tem_coef", None)   # the weight gradient behind `sums` finished them already (_sums_coef)
+        if ready is not None:
+            return ready
         return ops.norm_bwd_coef(g, x, groups, gamma, stats[0], stats[1], dgamma, dbeta, sums=sums)
     if mode == "frozen":
         raise NotImplementedError("backward through a norm with frozen running statistics (model.eval()) is not "

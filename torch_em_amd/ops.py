@@ -387,6 +387,18 @@ def disarm_output_amax() -> bool:
     return bool(_lib.load().tem_disarm_output_amax())
 
 
+def arm_wgrad_norm_coef(groups, mean, rstd, coef):
+    """The NEXT weight gradient of this thread that delivers the norm sums (sums_from=...) also writes coef [N, C, 4] -- what
+    norm_bwd_coef(sums=...) would return for a norm without affine parameters -- when the group layout allows it:
+    tem_arm_wgrad_norm_coef."""
+    _lib.check(_lib.load().tem_arm_wgrad_norm_coef(int(groups), _p(mean), _p(rstd), _p(coef)), "tem_arm_wgrad_norm_coef")
+
+
+def disarm_wgrad_norm_coef() -> bool:
+    """-> True when the armed request was NOT consumed (the caller then needs norm_bwd_coef())"""
+    return bool(_lib.load().tem_disarm_wgrad_norm_coef())
+
+
 def conv_wgrad_gscaled(x, g, k, cin, cout, dw_out, db_out, amax, scale=None, shift=None, sums_from=None):
     """Weight gradient in the fp16 2x1 arithmetic (tem_conv3d_wgrad_gscaled): x^ two fp16 terms, g one fp16 term prescaled
     from amax = int32[1] with the bit pattern of max |g| (absmax or a producer of g).  sums_from as in conv_wgrad."""
