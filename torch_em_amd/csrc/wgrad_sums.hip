@@ -39,11 +39,12 @@ __device__ __forceinline__ void shell_plane_sums_body(const float* __restrict__ 
     const float* gp = g + ((int64_t)n * D + z) * H * W * g_ld + q * 4;
     // four voxels per trip, loads unconditional (a clamped index, the value masked out below): the one-load-per-trip loop
     // was 16 dependent round trips for a ring slot
-    for (int idx0 = lanev; act && idx0 < count; idx0 += 4 * nlv) {
-        float4 v[4];
-        int cls[4];
+    constexpr int SU = 4;
+    for (int idx0 = lanev; act && idx0 < count; idx0 += SU * nlv) {
+        float4 v[SU];
+        int cls[SU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SU; ++u) {
             const int idx = idx0 + u * nlv < count ? idx0 + u * nlv : count - 1;
             int y, x;
             if (!ringmode) {
@@ -64,7 +65,7 @@ __device__ __forceinline__ void shell_plane_sums_body(const float* __restrict__ 
             v[u] = *reinterpret_cast<const float4*>(gp + ((int64_t)y * W + x) * g_ld);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < SU; ++u)
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const float m = (k == cls[u]) ? 1.f : 0.f;
@@ -114,21 +115,23 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_wsum(const float* __restri
     __shared__ double sh[WS_MAXN][8][64];
     const int64_t n_out = (int64_t)ntaps * Cin * Cout;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= nb_w + nb_db) {
+    // block roles: the shell blocks FIRST (the longest: they must not queue behind the merge blocks), then merge, then bias
+    const int nb_sh = (int)gridDim.x - nb_w - nb_db, bid = (int)blockIdx.x - nb_sh;
+    if (bid < 0) {
         // the boundary-shell sums of g need nothing from the weight gradient: their blocks run NEXT TO the slab merge
         // instead of in a launch of their own behind it (20 us per layer)
         // (two slots per block, one per half: all blocks of the launch are resident at once -- with one slot per block
         // the shell blocks queued behind the merge blocks and the launch took the SUM of the two, 30 us)
         const int nslot = sa.D - 2 + 2 * sa.H, half = threadIdx.x >> 8;
-        const int sb = ((int)blockIdx.x - nb_w - nb_db) * 2 + half;
+        const int sb = (int)blockIdx.x * 2 + half;
         const bool act = sb < nslot * N;
         extern __shared__ float lsh[];   // [2 halves][4 waves][9][Cout]
         shell_plane_sums_body(sa.g, sa.g_ld, sa.D, sa.H, sa.W, Cout, sa.planepart, act ? sb % nslot : 0, act ? sb / nslot : 0,
                               lsh + half * 4 * 9 * Cout, threadIdx.x & 255, act);
         return;
     }
-    if ((int)blockIdx.x >= nb_w) {  // the bias gradient rides along (arithmetic of k_reduce_slabs): one launch less per layer
-        const int co = ((int)blockIdx.x - nb_w) * 64 + tx;
+    if (bid >= nb_w) {  // the bias gradient rides along (arithmetic of k_reduce_slabs): one launch less per layer
+        const int co = (bid - nb_w) * 64 + tx;
         double s = 0.0;
         if (co < Cout) {
             double s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -152,24 +155,31 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_wsum(const float* __restri
         }
         return;
     }
-    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n_out; i0 += (int64_t)nb_w * 64) {
+    for (int64_t i0 = (int64_t)bid * 64; i0 < n_out; i0 += (int64_t)nb_w * 64) {
         const int64_t i = i0 + tx;
+        // this thread's chunks ty, ty + 8, ... of every sample: four chunks of all samples per trip, loads unconditional
+        // (clamped sample / chunk / output index, the value dropped afterwards) -- the loop per sample with two loads in
+        // flight was cps / 16 dependent round trips PER SAMPLE
+        const int64_t ic = i < n_out ? i : n_out - 1;
+        double sacc[WS_MAXN];
 #pragma unroll
-        for (int n = 0; n < WS_MAXN; ++n) {
-            double s = 0.0;
-            if (n < N && i < n_out) {
-                double s1 = 0.0;
-                int c = n * cps + ty;
-                const int ce = (n + 1) * cps;
-                for (; c + 8 < ce; c += 16) {
-                    s += (double)part[(int64_t)c * chunk_stride + i];
-                    s1 += (double)part[(int64_t)(c + 8) * chunk_stride + i];
+        for (int n = 0; n < WS_MAXN; ++n) sacc[n] = 0.0;
+        for (int c0 = ty; c0 < cps; c0 += 32) {
+            float v[WS_MAXN][4];
+#pragma unroll
+            for (int n = 0; n < WS_MAXN; ++n)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = c0 + 8 * u < cps ? c0 + 8 * u : cps - 1, nc = n < N ? n : N - 1;
+                    v[n][u] = part[(int64_t)(nc * cps + cc) * chunk_stride + ic];
                 }
-                if (c < ce) s += (double)part[(int64_t)c * chunk_stride + i];
-                s += s1;
-            }
-            sh[n][ty][tx] = s;
+#pragma unroll
+            for (int n = 0; n < WS_MAXN; ++n)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sacc[n] += (n < N && c0 + 8 * u < cps) ? (double)v[n][u] : 0.0;
         }
+#pragma unroll
+        for (int n = 0; n < WS_MAXN; ++n) sh[n][ty][tx] = i < n_out ? sacc[n] : 0.0;
         __syncthreads();
         if (ty == 0) {  // wave 0: one lane per output
             double tot = 0.0;
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __re
                                                               const float* __restrict__ P, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ sums,
                                                               NormCoef nc) {
-    extern __shared__ float lt[];        // cls[27][Cout] then T[27][Cout]
+    extern __shared__ float lt[];        // cls[27][Cout] then T[Cout][32] (tap fastest: the last phase reads it lane = tap)
     __shared__ float ab[32][2];
     float* cls = lt;
     float* T = lt + 27 * Cout;
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __re
     const bool wlane = ci < Cin && l8 < 27 && !(TEM_NS_ABL & 4);
     const unsigned wbase = wlane ? (unsigned)ci * 27u + (unsigned)l8 : 0u;
 #pragma unroll
-    for (int k = 0; k < NS_WPRE; ++k) wpre[k] = w[(unsigned)(k < Cout ? k : Cout - 1) * (unsigned)Cin * 27u + wbase];
+    for (int k = 0; k < NS_WPRE; ++k) wpre[k] = w[(unsigned)k * (unsigned)Cin * 27u + wbase];   // Cout >= 32 = NS_WPRE
     const unsigned pbase = (unsigned)n * (unsigned)(n_out >> 5), cic = (unsigned)(ci < Cin ? ci : Cin - 1);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -321,24 +331,22 @@ __global__ __launch_bounds__(1024) void k_norm_sums_from_wgrad(const float* __re
             }
             a += ok ? cls[k * Cout + co] : 0.f;
         }
-        T[t] = a;
+        T[co * 32 + tap] = a;
     }
     __syncthreads();
     double A = 0.0, S2 = 0.0;
     if (ci < Cin) {
         // lane = tap, loop over co: a load instruction reads the 27 consecutive floats of w[co][ci][:] for two input
         // channels (the (tap, co)-per-lane version gathered 64 separate cache lines per instruction: 15 us)
-        if (wlane) {
+        if (wlane) {   // Cout % 32 == 0: no bounds inside the unrolled loops (a test per k was a branch + wait per term)
 #pragma unroll
-            for (int k = 0; k < NS_WPRE; ++k)
-                if (k < Cout) A += (double)wpre[k] * (double)T[l8 * Cout + k];
+            for (int k = 0; k < NS_WPRE; ++k) A += (double)wpre[k] * (double)T[k * 32 + l8];
             for (int c0 = NS_WPRE; c0 < Cout; c0 += 16) {
                 float wv[16];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) wv[k] = w[(unsigned)(c0 + k < Cout ? c0 + k : Cout - 1) * (unsigned)Cin * 27u + wbase];
+                for (int k = 0; k < 16; ++k) wv[k] = w[(unsigned)(c0 + k) * (unsigned)Cin * 27u + wbase];
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (c0 + k < Cout) A += (double)wv[k] * (double)T[l8 * Cout + c0 + k];
+                for (int k = 0; k < 16; ++k) A += (double)wv[k] * (double)T[(c0 + k) * 32 + l8];
             }
         }
         S2 = l8 < 27 * cg ? (double)ppre[0] : 0.0;
@@ -418,6 +426,6 @@ void tem_wgrad_sums_launch(const float* zpart, int Ss, int ks2, const float* zdb
         nc.rstd = rq.rstd;
         nc.coef = rq.coef;
     }
-    hipLaunchKernelGGL(k_norm_sums_from_wgrad, dim3((Cin + 31) / 32, N), dim3(1024), (size_t)2 * 27 * Cout * sizeof(float),
+    hipLaunchKernelGGL(k_norm_sums_from_wgrad, dim3((Cin + 31) / 32, N), dim3(1024), (size_t)(27 + 32) * Cout * sizeof(float),
                        s, planepart, zdb, Ss, D, H, Cin, Cout, w, P, gamma, beta, sums, nc);
 }
