@@ -333,11 +333,17 @@ __global__ __launch_bounds__(256) void k_norm_bwd_affine(const float* __restrict
     }
 }
 
+// amax (optional, tem_arm_output_amax): max |gx| as a by-product.  This kernel is SHORT: all its waves end at the same moment,
+// so the per-wave "read the word, atomicMax if larger" of the long kernels degenerates into one atomic per wave on one
+// address (~10 ns each: 8192 waves cost +80 us, measured).  With amax the launcher uses 1024-thread blocks and at most 256
+// of them; a block reduces in LDS and issues ONE atomic.
 template <int VEC>
-__global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict__ gy, int64_t gy_ld,
-                                                        const float* __restrict__ x, int64_t x_ld,
-                                                        float* __restrict__ gx, int64_t gx_ld, int64_t V, int C,
-                                                        const float* __restrict__ coef, int relu_mask) {
+__global__ __launch_bounds__(1024) void k_norm_bwd_apply(const float* __restrict__ gy, int64_t gy_ld,
+                                                         const float* __restrict__ x, int64_t x_ld,
+                                                         float* __restrict__ gx, int64_t gx_ld, int64_t V, int C,
+                                                         const float* __restrict__ coef, int relu_mask,
+                                                         unsigned* __restrict__ amax) {
+    __shared__ unsigned smax[16];
     const int n = blockIdx.y;
     const int cq = C / VEC;
     const int64_t items = V * cq;
@@ -345,14 +351,17 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
     const float* xb = x + (int64_t)n * V * x_ld;
     float* ob = gx + (int64_t)n * V * gx_ld;
     const float* cf = coef + (int64_t)n * C * 4;
-    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t dv = stride / cq;
     const int dq = (int)(stride % cq);
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t v = i / cq;
     int q = (int)(i % cq);
-    if constexpr (VEC == 4) {
-        if (dq == 0) {
+    float amx = 0.f;
+    bool fast = false;
+    if constexpr (VEC == 4) fast = dq == 0;
+    if (fast) {
+        if constexpr (VEC == 4) {
             // the grid stride is a multiple of the channel-quad count (every power-of-two width): a thread keeps its
             // four channels, so the 16 coefficients are loaded once instead of per voxel; two voxels per trip
             const int c0 = q * 4;
@@ -378,34 +387,52 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
                     oa[j] = (relu_mask && !(xa[j] > 0.f)) ? 0.f : ra;
                     ob2[j] = (relu_mask && !(xb2[j] > 0.f)) ? 0.f : rb;
                 }
+                amx = tem_amax4(amx, oa[0], oa[1], oa[2], oa[3]);
                 NT_STORE4(ob + v * gx_ld + c0, make_float4(oa[0], oa[1], oa[2], oa[3]));
-                if (two) NT_STORE4(ob + (v + dv) * gx_ld + c0, make_float4(ob2[0], ob2[1], ob2[2], ob2[3]));
+                if (two) {
+                    amx = tem_amax4(amx, ob2[0], ob2[1], ob2[2], ob2[3]);
+                    NT_STORE4(ob + (v + dv) * gx_ld + c0, make_float4(ob2[0], ob2[1], ob2[2], ob2[3]));
+                }
             }
-            return;
+        }
+    } else {
+        for (; i < items; i += stride, v += dv, q += dq) {
+            if (q >= cq) {
+                q -= cq;
+                ++v;
+            }
+            const int c0 = q * VEC;
+            if constexpr (VEC == 4) {
+                float4 g4 = *reinterpret_cast<const float4*>(gb + v * gy_ld + c0);
+                float4 x4 = *reinterpret_cast<const float4*>(xb + v * x_ld + c0);
+                float gv[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w}, ov[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 k = *reinterpret_cast<const float4*>(cf + (int64_t)(c0 + j) * 4);
+                    float r = k.x * gv[j] - k.y - (xv[j] - k.w) * k.z;
+                    ov[j] = (relu_mask && !(xv[j] > 0.f)) ? 0.f : r;
+                }
+                amx = tem_amax4(amx, ov[0], ov[1], ov[2], ov[3]);
+                *reinterpret_cast<float4*>(ob + v * gx_ld + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            } else {
+                float gv = gb[v * gy_ld + c0], xv = xb[v * x_ld + c0];
+                float4 k = *reinterpret_cast<const float4*>(cf + (int64_t)c0 * 4);
+                float r = k.x * gv - k.y - (xv - k.w) * k.z;
+                r = (relu_mask && !(xv > 0.f)) ? 0.f : r;
+                amx = __builtin_fmaxf(amx, __builtin_fabsf(r));
+                ob[v * gx_ld + c0] = r;
+            }
         }
     }
-    for (; i < items; i += stride, v += dv, q += dq) {
-        if (q >= cq) {
-            q -= cq;
-            ++v;
-        }
-        const int c0 = q * VEC;
-        if constexpr (VEC == 4) {
-            float4 g4 = *reinterpret_cast<const float4*>(gb + v * gy_ld + c0);
-            float4 x4 = *reinterpret_cast<const float4*>(xb + v * x_ld + c0);
-            float gv[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w}, ov[4];
+    if (amax) {   // launch-uniform: one atomic per block
+        unsigned u = __builtin_bit_cast(unsigned, amx);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float4 k = *reinterpret_cast<const float4*>(cf + (int64_t)(c0 + j) * 4);
-                float r = k.x * gv[j] - k.y - (xv[j] - k.w) * k.z;
-                ov[j] = (relu_mask && !(xv[j] > 0.f)) ? 0.f : r;
-            }
-            *reinterpret_cast<float4*>(ob + v * gx_ld + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-        } else {
-            float gv = gb[v * gy_ld + c0], xv = xb[v * x_ld + c0];
-            float4 k = *reinterpret_cast<const float4*>(cf + (int64_t)c0 * 4);
-            float r = k.x * gv - k.y - (xv - k.w) * k.z;
-            ob[v * gx_ld + c0] = (relu_mask && !(xv > 0.f)) ? 0.f : r;
+        for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o, 64));
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) u = max(u, smax[w]);
+            if (u > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, u);
         }
     }
 }
@@ -510,14 +537,16 @@ static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t
               (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0;
     int64_t items = V * (v4 ? C / 4 : C);
     dim3 agrid(tem_grid_1d(items, 256, 2048), N);
-    // (max |gx| as a by-product was tried here, round 4: every wave of this SHORT kernel ends at the same moment, reads the
-    // still-empty word and issues its atomicMax -- 8192 atomics on one address, +80 us per call; tem_absmax stays)
+    // gx is what a weight gradient reads next: max |gx| as a by-product when armed (one atomic per 1024-thread block, see the kernel)
+    unsigned* const amax = tem_take_output_amax();
+    const int threads = amax ? 1024 : 256;
+    if (amax) agrid = dim3(tem_grid_1d(items, 1024, N > 0 ? (256 + N - 1) / N : 256), N);
     if (v4)
-        hipLaunchKernelGGL((k_norm_bwd_apply<4>), agrid, dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x, x_ld, gx,
-                           gx_ld, V, C, coef, relu_mask);
+        hipLaunchKernelGGL((k_norm_bwd_apply<4>), agrid, dim3(threads), 0, (hipStream_t)stream, gy, gy_ld, x, x_ld, gx,
+                           gx_ld, V, C, coef, relu_mask, amax);
     else
-        hipLaunchKernelGGL((k_norm_bwd_apply<1>), agrid, dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x, x_ld, gx,
-                           gx_ld, V, C, coef, relu_mask);
+        hipLaunchKernelGGL((k_norm_bwd_apply<1>), agrid, dim3(threads), 0, (hipStream_t)stream, gy, gy_ld, x, x_ld, gx,
+                           gx_ld, V, C, coef, relu_mask, amax);
     TEM_CHECK_LAUNCH("tem_norm_bwd");
     return TEM_OK;
 }

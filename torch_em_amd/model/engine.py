@@ -627,8 +627,9 @@ _DEFER_CONCAT_NORM = os.environ.get("TEM_DEFER_CONCAT_NORM", "1") != "0"
 _FUSE_NORM_BWD_DGRAD = os.environ.get("TEM_FUSE_NORM_BWD_DGRAD", "1") != "0"
 
 
-def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sums=None, coef_only=False):
-    """coef_only: return the [N, C, 4] coefficients instead of applying them (g stays the raw data gradient)"""
+def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sums=None, coef_only=False, amax=False):
+    """coef_only: return the [N, C, 4] coefficients instead of applying them (g stays the raw data gradient)
+    amax: a weight gradient reads the rewritten g next -- the elementwise pass delivers max |g| (see _output_amax)"""
     groups, gamma, beta, _ = spec.norm_args()
     dgamma = grads.view(gamma) if gamma is not None else None
     dbeta = grads.view(beta) if beta is not None else None
@@ -646,7 +647,8 @@ def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sum
         gb = _flat_batch(g)
         ops.norm_bwd(gb, _flat_batch(x), groups, gamma, stats[0], stats[1], relu_mask, gb, dgamma, dbeta)
         return
-    ops.norm_bwd(g, x, groups, gamma, stats[0], stats[1], relu_mask, g, dgamma, dbeta, sums=sums)
+    with _output_amax(grads if amax else None, g):
+        ops.norm_bwd(g, x, groups, gamma, stats[0], stats[1], relu_mask, g, dgamma, dbeta, sums=sums)
 
 
 def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
@@ -686,7 +688,7 @@ def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
                                  grads.view(c1.conv.bias), scale=None if s1 is None else s1[2],
                                  shift=None if s1 is None else s1[3])
             return None
-        _norm_bwd_inplace(c2, ga1, a1, bs["s2"], True, grads, sums=sums)  # a1 is a ReLU output: mask fused
+        _norm_bwd_inplace(c2, ga1, a1, bs["s2"], True, grads, sums=sums, amax=True)  # a1 is a ReLU output: mask fused
     elif _dgrad16_ok(c2, gout):
         gm = grads.amax_slot()
         _wgrad(c2, a1, gout, grads, bs["s2"], gmax=gm)
