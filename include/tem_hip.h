@@ -241,6 +241,19 @@ int tem_disarm_output_amax(void);
  * The affine gradients (dgamma, dbeta) are not part of it: a norm with affine parameters still needs tem_norm_bwd_coef. */
 int tem_arm_wgrad_norm_coef(int G, const float* mean, const float* rstd, float* coef);
 int tem_disarm_wgrad_norm_coef(void);
+/* The FIRST stage of a norm backward (tem_norm_bwd: per-block rows of (sum gy, sum gy * xn)) as a BY-PRODUCT of the data
+ * gradient that writes gy: tem_arm_dgrad_norm_sums attaches the request -- x = the norm's input [N*V][x_ld], its mean / rstd
+ * [N][G], part [N][nblk][C][2] with nblk = tem_conv3d_fwd_stat_blocks() of that launch -- to the calling thread's NEXT
+ * tem_conv3d_fwd.  Launches on the z-reuse kernel with split input channels (tem_conv3d_fwd_kernel() == 4: the 16^3 / 8^3
+ * levels) honour it in their split-K epilogue and consume the request; tem_disarm_dgrad_norm_sums() clears it and returns
+ * 1 when it was NOT consumed.  Feed the rows to tem_norm_bwd_from_partials (coef != NULL: coefficients only, as
+ * tem_norm_bwd_coef; else the elementwise pass as tem_norm_bwd_from_sums). */
+int tem_arm_dgrad_norm_sums(const float* x, int64_t x_ld, const float* mean, const float* rstd, int G, float* part, int64_t nblk);
+int tem_disarm_dgrad_norm_sums(void);
+int tem_norm_bwd_from_partials(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C, int G,
+                               const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx, int64_t gx_ld,
+                               float* dgamma, float* dbeta, const float* part, int64_t nblk, float* coef, void* ws,
+                               int64_t ws_bytes, tem_stream_t stream);
 /* *amax = max(*amax, bit pattern of max |x|) over nvox rows of C floats (row stride ld): integer atomicMax, exact and
  * order-independent; the caller clears the word.  The prescale source of tem_conv3d_wgrad_gscaled / tem_conv3d_fwd_gscaled
  * when no producer of the tensor delivered it (no reference counterpart: torch.autocast has no per-tensor scale). */

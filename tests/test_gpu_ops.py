@@ -652,6 +652,56 @@ def test_wgrad_sums_also_deliver_the_norm_backward_coefficients(case):
     assert ops.disarm_wgrad_norm_coef()
 
 
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, 16, 256, 128, 128, True),   # InstanceNorm-style groups, in-place apply with the ReLU mask
+    (2, 8, 8, 8, 512, 256, 32, False),      # GroupNorm(32, 256), coefficients only
+    (4, 6, 12, 12, 128, 128, 128, True),    # ragged split-K tiles
+])
+def test_split_k_data_gradient_delivers_the_norm_backward_rows(case):
+    """tem_arm_dgrad_norm_sums: the split-K epilogue of a data gradient writes per-block (sum g, sum g * xn) of the norm in
+    front of the conv; tem_norm_bwd_from_partials on those rows == tem_norm_bwd on the tensors (its own reduction pass)."""
+    ops = _ops()
+    N, D, H, W, Cout, Cin, G, apply = case          # the conv is Cin -> Cout; its data gradient Cout -> Cin
+    k = (3, 3, 3)
+    gen = torch.Generator().manual_seed(5)
+    x5 = to5(torch.randn(N, Cin, D, H, W, generator=gen) * 1.3 + 0.2)     # input of the norm in front of the conv
+    g5 = to5(torch.randn(N, Cout, D, H, W, generator=gen))
+    w = (torch.randn(Cout, Cin, *k, generator=gen) * 0.05).to(DEV)
+    mode = 2
+    if ops.conv_fwd_family(g5, k, Cout, Cin, mode) != 4:
+        pytest.skip("not a split-K launch of the z-reuse kernel on this device")
+    wp = ops.pack_weights(w, transpose=True, mfma=mode)
+    mean, rstd = ops.norm_stats(x5, G, None, None, 1e-5)[:2]
+    nblk = ops.conv_fwd_stat_blocks(g5, k, Cout, Cin, mode)
+    assert nblk > 0
+    part = torch.full((N, nblk, Cin, 2), float("nan"), device=DEV)
+    gx, gx_ref = ops.new_act(N, D, H, W, Cin, DEV), ops.new_act(N, D, H, W, Cin, DEV)
+    ops.arm_dgrad_norm_sums(x5, G, mean, rstd, part)
+    ops.conv_fwd(g5, wp, None, gx, k, Cout, Cin, mfma=mode)
+    assert not ops.disarm_dgrad_norm_sums()                       # consumed
+    ops.conv_fwd(g5, wp, None, gx_ref, k, Cout, Cin, mfma=mode)
+    assert torch.equal(gx, gx_ref)                                # the gradient itself is unchanged
+    sums = part.sum(1).cpu().double()
+    xn = (from5(x5).double() - mean.cpu().double().repeat_interleave(Cin // G, 1)[:, :, None, None, None]) * \
+        rstd.cpu().double().repeat_interleave(Cin // G, 1)[:, :, None, None, None]
+    gz = from5(gx).double()
+    A, B = gz.sum((2, 3, 4)), (gz * xn).sum((2, 3, 4))
+    assert float((sums[..., 0] - A).abs().max()) < 2e-5 * float(gz.abs().sum((2, 3, 4)).max())
+    assert float((sums[..., 1] - B).abs().max()) < 2e-5 * float((gz * xn).abs().sum((2, 3, 4)).max())
+    if apply:
+        a, b = gx.clone(), gx.clone()
+        ops.norm_bwd(a, x5, G, None, mean, rstd, True, a)
+        ops.norm_bwd(b, x5, G, None, mean, rstd, True, b, sums=part)
+        assert rel_err(b.cpu(), a.cpu()) < 2e-5
+    else:
+        assert rel_err(ops.norm_bwd_coef(gx, x5, G, None, mean, rstd, sums=part).cpu(),
+                       ops.norm_bwd_coef(gx, x5, G, None, mean, rstd).cpu()) < 2e-5
+    # a launch that cannot deliver the rows leaves the request armed
+    ops.arm_dgrad_norm_sums(x5, G, mean, rstd, part)
+    ops.conv_fwd(g5, ops.pack_weights(w, transpose=True, mfma=0), None, gx_ref, k, Cout, Cin, mfma=0)
+    assert ops.disarm_dgrad_norm_sums()
+
+
 @pytest.fixture
 def wgrad_kernel_option():
     """option "wgrad_zs": 1 k_conv_wgrad_zs, 2 k_conv_wgrad_zt, 3 k_conv_wgrad_tr (transposing LDS reads)"""

@@ -54,6 +54,10 @@ SIGNATURES = {
     "tem_absmax": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_vp]),
     "tem_arm_output_amax": (c_int, [c_vp]),
     "tem_disarm_output_amax": (c_int, []),
+    "tem_arm_dgrad_norm_sums": (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_i64]),
+    "tem_disarm_dgrad_norm_sums": (c_int, []),
+    "tem_norm_bwd_from_partials": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64,
+                                           c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "tem_arm_wgrad_norm_coef": (c_int, [c_int, c_vp, c_vp, c_vp]),
     "tem_disarm_wgrad_norm_coef": (c_int, []),
     "tem_conv3d_fwd_gscaled": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp]),

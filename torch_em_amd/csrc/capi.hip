@@ -98,6 +98,20 @@ extern "C" int tem_disarm_wgrad_norm_coef(void) {
     return pending;
 }
 
+// ---- first stage of a norm backward as a by-product of the data gradient that produces its input gradient -------------
+thread_local TemDgradSumsReq tem_dgrad_sums_req = {nullptr, 0, nullptr, nullptr, 0, nullptr, 0};
+extern "C" int tem_arm_dgrad_norm_sums(const float* x, int64_t x_ld, const float* mean, const float* rstd, int G, float* part,
+                                       int64_t nblk) {
+    TEM_REQUIRE(x && mean && rstd && part && G > 0 && nblk > 0, "tem_arm_dgrad_norm_sums: bad arguments");
+    tem_dgrad_sums_req = {x, x_ld, mean, rstd, G, part, nblk};
+    return TEM_OK;
+}
+extern "C" int tem_disarm_dgrad_norm_sums(void) {
+    const int pending = tem_dgrad_sums_req.part != nullptr;
+    tem_dgrad_sums_req = {nullptr, 0, nullptr, nullptr, 0, nullptr, 0};
+    return pending;
+}
+
 extern "C" int tem_device_cus(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return TEM_ELAUNCH;

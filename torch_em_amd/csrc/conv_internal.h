@@ -76,6 +76,20 @@ bool tem_conv1x1_stream(const float* x, int64_t x_ld, const float* scale, const 
 int tem_fwd_ksplit(int64_t nblk, int nchunks);
 void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, const float* bias, int act,
                          const float* ref, int64_t ref_ld, float* y, int64_t y_ld, hipStream_t s);
+// capi.hip: tem_arm_dgrad_norm_sums -- taken (cleared) by the split-K data gradient whose epilogue can deliver the rows
+struct TemDgradSumsReq {
+    const float* x;      // input of the norm the gradient lands behind: [N*V][x_ld]
+    int64_t x_ld;
+    const float* mean;
+    const float* rstd;
+    int G;
+    float* part;         // [N][nblk][C][2]
+    int64_t nblk;
+};
+extern thread_local TemDgradSumsReq tem_dgrad_sums_req;
+void tem_splitk_epilogue_bwd_sums(const float* part, int ksplit, int N, int64_t V, int Cout, const float* bias, int act,
+                                  const float* ref, int64_t ref_ld, float* y, int64_t y_ld, const TemDgradSumsReq& rq,
+                                  hipStream_t s);
 int64_t tem_splitk_stat_blocks(int64_t V, int Cout);
 int64_t tem_conv_zr_splitk_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit);
 void tem_splitk_epilogue_stats(const float* part, int ksplit, int N, int64_t V, int Cout, const float* bias, int act,

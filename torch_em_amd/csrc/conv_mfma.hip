@@ -483,11 +483,22 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
 // that reads y next -- the partial rows k_norm_partial<.,0> would produce in a pass of its own (one launch and one read
 // of y less per layer of the 8^3 / 16^3 levels).  Block (b, n): voxels [b VB, (b+1) VB) of sample n, thread = (channel
 // quad q, row r of 256 / cq rows); stat: [N][gridDim.x][Cout][2].
+// BWD: the launch is a data gradient whose output lands behind a norm (the one in front of the conv): the rows are
+// (sum g, sum g * xn) with xn = (xin - mean) * rstd of that norm's input xin -- the first stage of its backward
+// (k_norm_partial<.,1>), tem_arm_dgrad_norm_sums.
+struct SplitkNormIn {
+    const float* xin;
+    int64_t xin_ld;
+    const float* mean;
+    const float* rstd;
+    int G;
+};
+template <bool BWD>
 __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __restrict__ part, int ksplit, int64_t V,
                                                                int Cout, const float* __restrict__ bias, int act,
                                                                const float* __restrict__ ref, int64_t ref_ld,
                                                                float* __restrict__ y, int64_t y_ld, int VB,
-                                                               float* __restrict__ stat) {
+                                                               float* __restrict__ stat, SplitkNormIn ni) {
     __shared__ float sh[2048];   // [rows][Cout][2], rows * Cout = 1024
     const int cq = Cout >> 2, rows = 256 / cq;
     const int q = threadIdx.x % cq, r = threadIdx.x / cq, c0 = q * 4;
@@ -496,11 +507,21 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __re
     const int64_t v0 = (int64_t)b * VB, v1 = v0 + VB < V ? v0 + VB : V;
     const float4 bz = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (BWD) {
+        const int cg = Cout / ni.G;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mu[j] = ni.mean[n * ni.G + (c0 + j) / cg];
+            rs[j] = ni.rstd[n * ni.G + (c0 + j) / cg];
+        }
+    }
     for (int64_t vl = v0 + r; vl < v1; vl += rows) {
         const int64_t v = (int64_t)n * V + vl;
         float4 a = bz;
-        float4 rr = make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 rr = make_float4(1.f, 1.f, 1.f, 1.f), xi = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ref) rr = *reinterpret_cast<const float4*>(ref + v * ref_ld + c0);
+        if constexpr (BWD) xi = *reinterpret_cast<const float4*>(ni.xin + v * ni.xin_ld + c0);
         for (int k0 = 0; k0 < ksplit; k0 += 4) {
             float4 p[4];
 #pragma unroll
@@ -528,11 +549,11 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __re
             if (!(rr.w > 0.f)) a.w = 0.f;
         }
         *reinterpret_cast<float4*>(y + v * y_ld + c0) = a;
-        const float av[4] = {a.x, a.y, a.z, a.w};
+        const float av[4] = {a.x, a.y, a.z, a.w}, xv[4] = {xi.x, xi.y, xi.z, xi.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s0[j] += av[j];
-            s1[j] = fmaf(av[j], av[j], s1[j]);
+            s1[j] = fmaf(av[j], BWD ? (xv[j] - mu[j]) * rs[j] : av[j], s1[j]);
         }
     }
 #pragma unroll
@@ -559,8 +580,18 @@ int64_t tem_splitk_stat_blocks(int64_t V, int Cout) {
 void tem_splitk_epilogue_stats(const float* part, int ksplit, int N, int64_t V, int Cout, const float* bias, int act,
                                const float* ref, int64_t ref_ld, float* y, int64_t y_ld, float* stat, hipStream_t s) {
     const int VB = 4 * (256 / (Cout >> 2));
-    hipLaunchKernelGGL(k_splitk_epilogue_stats, dim3((unsigned)tem_splitk_stat_blocks(V, Cout), (unsigned)N), dim3(256), 0, s, part,
-                       ksplit, V, Cout, bias, act, ref, ref_ld, y, y_ld, VB, stat);
+    hipLaunchKernelGGL(k_splitk_epilogue_stats<false>, dim3((unsigned)tem_splitk_stat_blocks(V, Cout), (unsigned)N), dim3(256), 0, s,
+                       part, ksplit, V, Cout, bias, act, ref, ref_ld, y, y_ld, VB, stat, SplitkNormIn{nullptr, 0, nullptr, nullptr, 1});
+}
+
+// the epilogue of a DATA GRADIENT that also writes the first stage of the backward of the norm its output lands behind
+void tem_splitk_epilogue_bwd_sums(const float* part, int ksplit, int N, int64_t V, int Cout, const float* bias, int act,
+                                  const float* ref, int64_t ref_ld, float* y, int64_t y_ld, const TemDgradSumsReq& rq,
+                                  hipStream_t s) {
+    const int VB = 4 * (256 / (Cout >> 2));
+    hipLaunchKernelGGL(k_splitk_epilogue_stats<true>, dim3((unsigned)tem_splitk_stat_blocks(V, Cout), (unsigned)N), dim3(256), 0, s,
+                       part, ksplit, V, Cout, bias, act, ref, ref_ld, y, y_ld, VB, rq.part,
+                       SplitkNormIn{rq.x, rq.x_ld, rq.mean, rq.rstd, rq.G});
 }
 
 // Split the input channels over `ks` workgroups when the (patches x Cout tiles) grid cannot fill

@@ -859,9 +859,14 @@ int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, con
     else if (nsplit == 4) ZRKS(2, true, false);
     else ZRKS(2, false, false);
 #undef ZRKS
+    const TemDgradSumsReq rq = tem_dgrad_sums_req;
     if (stat)
         tem_splitk_epilogue_stats(part, ks, N, (int64_t)D * H * W, Cout, bias, act, ref, ref_ld, y, y_ld, stat, s);
-    else
+    else if (rq.part && rq.nblk == tem_splitk_stat_blocks((int64_t)D * H * W, Cout) && rq.G > 0 && Cout % rq.G == 0 &&
+             rq.x_ld % 4 == 0 && ((uintptr_t)rq.x % 16 == 0)) {
+        tem_dgrad_sums_req = TemDgradSumsReq{nullptr, 0, nullptr, nullptr, 0, nullptr, 0};   // consumed
+        tem_splitk_epilogue_bwd_sums(part, ks, N, (int64_t)D * H * W, Cout, bias, act, ref, ref_ld, y, y_ld, rq, s);
+    } else
         tem_splitk_epilogue(part, ks, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
     return 1;
 }

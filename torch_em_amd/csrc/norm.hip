@@ -499,8 +499,9 @@ extern "C" int tem_norm_finalize_partials2(const float* partA, int64_t nblkA, in
 static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C,
                          int G, const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx,
                          int64_t gx_ld, float* dgamma, float* dbeta, const float* sums, float* coef_out, void* ws,
-                         int64_t ws_bytes, tem_stream_t stream) {
+                         int64_t ws_bytes, tem_stream_t stream, int64_t sums_nblk = 1) {
     TEM_REQUIRE(gy && x && mean && rstd && (gx || coef_out) && ws, "tem_norm_bwd: null pointer");
+    TEM_REQUIRE(sums_nblk >= 1 && sums_nblk < (1ll << 24), "tem_norm_bwd: bad number of partial rows");
     if (coef_out) gx_ld = C;
     TEM_REQUIRE(N > 0 && V > 0 && C > 0 && C <= NORM_MAX_C && x_ld >= C && gy_ld >= C && gx_ld >= C,
                 "tem_norm_bwd: bad shape (C=%d)", C);
@@ -517,7 +518,7 @@ static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t
     int nblk = g.nblk;
     if (sums) {  // first stage delivered by the weight gradient (tem_conv3d_wgrad_sums): [N][1][C][2]
         part = const_cast<float*>(sums);
-        nblk = 1;
+        nblk = (int)sums_nblk;   // [N][sums_nblk][C][2]; 1 for the weight gradient's sums
     } else if (g.vec == 4)
         hipLaunchKernelGGL((k_norm_partial<4, 1>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, gy, gy_ld,
                            V, C, G, mean, rstd, g.cq, g.rows, g.vper, part);
@@ -567,6 +568,17 @@ extern "C" int tem_norm_bwd_from_sums(const float* gy, int64_t gy_ld, const floa
     TEM_REQUIRE(sums, "tem_norm_bwd_from_sums: null sums");
     return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, sums,
                          nullptr, ws, ws_bytes, stream);
+}
+
+// ... was delivered as partial rows part[N][nblk][C][2] by the data gradient that wrote gy (tem_arm_dgrad_norm_sums)
+extern "C" int tem_norm_bwd_from_partials(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V,
+                                          int C, int G, const float* gamma, const float* mean, const float* rstd,
+                                          int relu_mask, float* gx, int64_t gx_ld, float* dgamma, float* dbeta,
+                                          const float* part, int64_t nblk, float* coef, void* ws, int64_t ws_bytes,
+                                          tem_stream_t stream) {
+    TEM_REQUIRE(part && (gx || coef), "tem_norm_bwd_from_partials: null pointer");
+    return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, coef ? nullptr : gx, gx_ld, dgamma, dbeta,
+                         part, coef, ws, ws_bytes, stream, nblk);
 }
 
 // Reduction stage only: coef[n][c] = {a, m1, m2r, mean} with gx = a*gy - m1 - (x - mean)*m2r (and dgamma / dbeta).  The

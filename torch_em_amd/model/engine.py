@@ -447,12 +447,33 @@ def _join_side(device):
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
-def _dgrad(spec: ConvSpec, g, gx, ref=None, gmax=None, refnorm=None, grads=None):
+# the split-K epilogue of a data gradient also writes the first stage of the backward of the norm in front of the conv
+# (tem_arm_dgrad_norm_sums: k_norm_partial<.,1> disappears for the 16^3 / 8^3 levels); 0: the pass over gx and x
+_FUSE_DGRAD_SUMS = os.environ.get("TEM_FUSE_DGRAD_SUMS", "1") != "0"
+
+
+def _dgrad(spec: ConvSpec, g, gx, ref=None, gmax=None, refnorm=None, grads=None, sums_for=None):
     """gmax: int32[1] with max |g| (from _wgrad(..., gmax=) of the same layer) -> fp16 two-term layout, else bf16x3.
     refnorm: coef [N, C, 4] of the norm behind `ref` -- its backward (and ref's ReLU mask) run in the kernel's epilogue.
-    grads: gx is FINAL after this call (nothing rewrites it): ask the kernel for max |gx| as a by-product."""
-    with _output_amax(grads, gx):
-        _dgrad_launch(spec, g, gx, ref, gmax, refnorm)
+    grads: gx is FINAL after this call (nothing rewrites it): ask the kernel for max |gx| as a by-product.
+    sums_for = (x, stats): gx lands behind the norm whose input is x -> partial rows [N, nblk, C, 2] of its backward's first
+    stage when this launch can deliver them (plain launch on the split-K z-reuse kernel), else None."""
+    part = None
+    if sums_for is not None and _FUSE_DGRAD_SUMS and ref is None and gmax is None and refnorm is None and not _FORCE_GENERIC:
+        x, stats = sums_for
+        mode = spec.packed()["dgrad_mfma"]
+        if stats is not None and stats[4] == "sample" and ops.conv_fwd_family(g, spec.k, spec.cout, spec.cin, mode) == 4:
+            nblk = ops.conv_fwd_stat_blocks(g, spec.k, spec.cout, spec.cin, mode)
+            if nblk > 0:
+                part = torch.empty((x.shape[0], nblk, spec.cin, 2), dtype=torch.float32, device=x.device)
+                ops.arm_dgrad_norm_sums(x, spec.norm_args()[0], stats[0], stats[1], part)
+    try:
+        with _output_amax(grads, gx):
+            _dgrad_launch(spec, g, gx, ref, gmax, refnorm)
+    finally:
+        if part is not None and ops.disarm_dgrad_norm_sums():
+            part = None   # not delivered
+    return part
 
 
 def _dgrad_launch(spec: ConvSpec, g, gx, ref, gmax, refnorm):
@@ -676,8 +697,10 @@ def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
             sums = _wgrad(c2, a1, gout, grads, bs["s2"], want_sums=True, gmax=gm)
             _dgrad(c2, gout, ga1, gmax=gm)
         else:
-            _dgrad(c2, gout, ga1)
+            dsums = _dgrad(c2, gout, ga1, sums_for=(a1, bs["s2"]))
             sums = _wgrad(c2, a1, gout, grads, bs["s2"], want_sums=True)
+            if sums is None:
+                sums = dsums
         if gin is None and not affine1 and _DEFER_CONCAT_NORM and bs["s2"][4] == "sample" and not _OVERLAP_WGRAD and \
                 c1.conv.bias is not None and ops.conv_wgrad_gnorm_ok(c1.k, c1.cin, c1.cout, c1.packed()["wgrad_mfma"]):
             # first block of the net: nothing but conv1's weight gradient reads the gradient behind norm2, and that
@@ -707,8 +730,10 @@ def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
         sums = _wgrad(c1, xin, ga1, grads, bs["s1"], want_sums=bs["s1"] is not None, gmax=gm)
         _dgrad(c1, ga1, gin, gmax=gm)
     else:
-        _dgrad(c1, ga1, gin)
+        dsums = _dgrad(c1, ga1, gin, sums_for=(xin, bs["s1"]) if bs["s1"] is not None else None)
         sums = _wgrad(c1, xin, ga1, grads, bs["s1"], want_sums=bs["s1"] is not None)
+        if sums is None:
+            sums = dsums
     if bs["s1"] is not None:
         if defer_input_norm and _DEFER_CONCAT_NORM and bs["s1"][4] == "sample":
             return _norm_bwd_inplace(c1, gin, xin, bs["s1"], False, grads, sums=sums, coef_only=True)

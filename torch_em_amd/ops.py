@@ -387,6 +387,18 @@ def disarm_output_amax() -> bool:
     return bool(_lib.load().tem_disarm_output_amax())
 
 
+def arm_dgrad_norm_sums(x, groups, mean, rstd, part):
+    """The NEXT conv_fwd of this thread, if it is a data gradient on the split-K z-reuse kernel, also writes part[N, nblk, C, 2]
+    = per-block (sum g, sum g * xn) of the norm whose input is x (tem_arm_dgrad_norm_sums): the first stage of norm_bwd."""
+    _lib.check(_lib.load().tem_arm_dgrad_norm_sums(_p(x), _act5(x)[5], _p(mean), _p(rstd), int(groups), _p(part),
+                                                   part.shape[1]), "tem_arm_dgrad_norm_sums")
+
+
+def disarm_dgrad_norm_sums() -> bool:
+    """-> True when the armed request was NOT consumed"""
+    return bool(_lib.load().tem_disarm_dgrad_norm_sums())
+
+
 def arm_wgrad_norm_coef(groups, mean, rstd, coef):
     """The NEXT weight gradient of this thread that delivers the norm sums (sums_from=...) also writes coef [N, C, 4] -- what
     norm_bwd_coef(sums=...) would return for a norm without affine parameters -- when the group layout allows it:
@@ -467,6 +479,12 @@ def conv_fwd_refnorm(x, w_packed, y, k, cin, cout, ref, coef, mfma):
     return y
 
 
+def conv_fwd_stat_blocks(x, k, cin, cout, mfma) -> int:
+    """tem_conv3d_fwd_stat_blocks: statistics partial rows per sample this launch writes (0: it cannot)"""
+    N, D, H, W, _, _ = _act5(x)
+    return int(_lib.load().tem_conv3d_fwd_stat_blocks(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
+
+
 def conv_fwd_family(x, k, cin, cout, mfma) -> int:
     """tem_conv3d_fwd_kernel: 0 patch / other kernels, 1 / 2 ping-pong teams, 3 z-reuse teams, 4 z-reuse teams with split-K"""
     N, D, H, W, _, _ = _act5(x)
@@ -545,6 +563,11 @@ def norm_bwd_coef(gy, x, groups, gamma, mean, rstd, dgamma=None, dbeta=None, sum
     nws = lib.tem_norm_ws(N, V, C)
     ws = _workspace(nws, x.device)
     coef = torch.empty((N, C, 4), dtype=torch.float32, device=x.device)
+    if sums is not None and sums.dim() == 4:   # partial rows [N, nblk, C, 2] from a data gradient (arm_dgrad_norm_sums)
+        _lib.check(lib.tem_norm_bwd_from_partials(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd), 0,
+                                                  None, C, _p(dgamma), _p(dbeta), _p(sums), sums.shape[1], _p(coef), _p(ws), nws,
+                                                  _stream(x)), "tem_norm_bwd_from_partials")
+        return coef
     _lib.check(lib.tem_norm_bwd_coef(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd),
                                      _p(dgamma), _p(dbeta), _p(sums), _p(coef), _p(ws), nws, _stream(x)),
                "tem_norm_bwd_coef")
@@ -561,6 +584,11 @@ def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None,
     V = D * H * W
     nws = lib.tem_norm_ws(N, V, C)
     ws = _workspace(nws, x.device)
+    if sums is not None and sums.dim() == 4:   # partial rows [N, nblk, C, 2] from a data gradient (arm_dgrad_norm_sums)
+        _lib.check(lib.tem_norm_bwd_from_partials(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd),
+                                                  int(relu_mask), _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(sums), sums.shape[1],
+                                                  None, _p(ws), nws, _stream(x)), "tem_norm_bwd_from_partials")
+        return gx
     if sums is not None:
         _lib.check(lib.tem_norm_bwd_from_sums(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd),
                                               int(relu_mask), _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(sums), _p(ws), nws,
