@@ -17,5 +17,5 @@ for w in base new; do
 done
 find $O -name "*.csv" -delete; find $O -name "*.db" -delete
 timeout 1500 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "norm or sums or absmax or amax or wgrad_fp16 or stat or split_k" 2>&1 | tail -3 > $O/pytest_ops.txt
-timeout 1500 python -m pytest tests/test_gpu_unet.py tests/test_gpu_spoco.py -q -m gpu -x 2>&1 | tail -3 > $O/pytest_unet.txt
+timeout 1500 python -m pytest tests/test_gpu_unet.py tests/test_gpu_spoco.py tests/test_gpu_trainer.py -q -m gpu -x 2>&1 | tail -3 > $O/pytest_unet.txt
 tail -2 $O/pytest_ops.txt $O/pytest_unet.txt

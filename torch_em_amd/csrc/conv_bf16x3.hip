@@ -138,6 +138,22 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const PackDesc* __re
         const PackDesc d = descs[lo];
         long long i = gi - d.begin;
         const int ntaps = d.KD * d.KH * d.KW;
+        if (d.NS == 0) {
+            // TEM_WL_GENERIC fp32 layout [tap][ci][co] (k_pack_weights): the first conv (Cin = 1) and out_conv ride along in
+            // the batched launch instead of one launch per tensor and direction; one work item = 8 consecutive outputs
+            const int CoutL = d.transpose ? d.Cin : d.Cout, CinG = d.transpose ? d.Cout : d.Cin;
+            float* dstf = reinterpret_cast<float*>(d.dst);
+            for (int j = 0; j < 8; ++j) {
+                const long long e = i * 8 + j;
+                const int co = (int)(e % CoutL);
+                const long long r = e / CoutL;
+                const int ci = (int)(r % CinG), tap = (int)(r / CinG);
+                const int tz = tap / (d.KH * d.KW), ty = (tap / d.KW) % d.KH, tx = tap % d.KW;
+                const int ftap = ((d.KD - 1 - tz) * d.KH + (d.KH - 1 - ty)) * d.KW + (d.KW - 1 - tx);
+                dstf[e] = d.transpose ? d.w[((long long)ci * d.Cin + co) * ntaps + ftap] : d.w[((long long)co * d.Cin + ci) * ntaps + tap];
+            }
+            continue;
+        }
         const int CinL = d.transpose ? d.Cout : d.Cin;
         const int c16n = CinL >> 4;
         const int lane = (int)(i & 63);

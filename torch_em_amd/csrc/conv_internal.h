@@ -41,7 +41,7 @@ bool tem_conv1x1_expand(const float* x, int64_t x_ld, const float* scale, const 
 void tem_reduce_slabs_w(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
                         int sd_layout, hipStream_t s);
 void tem_reduce_slabs_w_db(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
-                           int sd_layout, const float* dbpart, int db_chunks, float* db, hipStream_t s);
+                           int sd_layout, const float* dbpart, int db_chunks, float* db, hipStream_t s, int64_t db_stride = 0);
 void tem_reduce_slabs(const float* part, int nchunks, int64_t n, int64_t chunk_stride, float* out, hipStream_t s);
 
 // conv_bf16x3.hip: split-bf16 ("bf16x3") MFMA path

@@ -568,7 +568,7 @@ void tem_reduce_slabs(const float* part, int nchunks, int64_t n, int64_t chunk_s
 __global__ __launch_bounds__(512) void k_reduce_slabs_sd(const float* __restrict__ part, int nchunks, int ntaps, int Cin,
                                                          int Cout, int64_t chunk_stride, float* __restrict__ out,
                                                          int nb_w, const float* __restrict__ dbpart, int db_chunks,
-                                                         float* __restrict__ db) {
+                                                         float* __restrict__ db, int64_t db_stride) {
     __shared__ double sh[8][64];
     const int64_t n = (int64_t)ntaps * Cin * Cout;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_sd(const float* __restrict
         const int co = ((int)blockIdx.x - nb_w) * 64 + tx;
         double s = 0.0;
         if (co < Cout)
-            for (int c = ty; c < db_chunks; c += 8) s += (double)dbpart[(int64_t)c * Cout + co];
+            for (int c = ty; c < db_chunks; c += 8) s += (double)dbpart[(int64_t)c * db_stride + co];
         sh[ty][tx] = s;
         __syncthreads();
         if (ty == 0 && co < Cout) {
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_ci(const float* __restrict
 __global__ __launch_bounds__(512) void k_reduce_slabs_sd4(const float* __restrict__ part, int nchunks, int ntaps, int Cin,
                                                           int Cout, int64_t chunk_stride, float* __restrict__ out,
                                                           int nb_w, const float* __restrict__ dbpart, int db_chunks,
-                                                          float* __restrict__ db) {
+                                                          float* __restrict__ db, int64_t db_stride) {
     __shared__ double sh[8][64][4];
     const int64_t n = (int64_t)ntaps * Cin * Cout;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_sd4(const float* __restric
         const int co = ((int)blockIdx.x - nb_w) * 64 + tx;
         double s = 0.0;
         if (co < Cout)
-            for (int c = ty; c < db_chunks; c += 8) s += (double)dbpart[(int64_t)c * Cout + co];
+            for (int c = ty; c < db_chunks; c += 8) s += (double)dbpart[(int64_t)c * db_stride + co];
         sh[ty][tx][0] = s;
         __syncthreads();
         if (ty == 0 && co < Cout) {
@@ -730,14 +730,20 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_sd4(const float* __restric
 __global__ __launch_bounds__(256) void k_reduce_slabs_sd_t(const float* __restrict__ part, int nchunks, int Cin, int Cout,
                                                            int64_t chunk_stride, float* __restrict__ out, int nb_w,
                                                            const float* __restrict__ dbpart, int db_chunks,
-                                                           float* __restrict__ db) {
+                                                           float* __restrict__ db, int64_t db_stride) {
     __shared__ float tile[27][33];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nb_w) {  // bias gradient (see k_reduce_slabs_sd)
         const int co = ((int)blockIdx.x - nb_w) * 256 + tid;
         if (co < Cout) {
             double a = 0.0;
-            for (int c = 0; c < db_chunks; ++c) a += (double)dbpart[(int64_t)c * Cout + co];
+            for (int c0 = 0; c0 < db_chunks; c0 += 8) {   // eight rows per trip, unconditional loads (clamped row, dropped below)
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = dbpart[(int64_t)(c0 + k < db_chunks ? c0 + k : db_chunks - 1) * db_stride + co];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a += c0 + k < db_chunks ? (double)v[k] : 0.0;
+            }
             db[co] = (float)a;
         }
         return;
@@ -759,11 +765,14 @@ __global__ __launch_bounds__(256) void k_reduce_slabs_sd_t(const float* __restri
 }
 
 void tem_reduce_slabs_w_db(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
-                           int sd_layout, const float* dbpart, int db_chunks, float* db, hipStream_t s) {
+                           int sd_layout, const float* dbpart, int db_chunks, float* db, hipStream_t s, int64_t db_stride) {
+    // db_stride: floats between the bias-gradient rows (0: dense rows of Cout; kernels that keep db inside their slabs pass
+    // the slab size)
+    if (!db_stride) db_stride = Cout;
     const int64_t n = (int64_t)ntaps * Cin * Cout;
     if (!sd_layout) {
         tem_reduce_slabs(part, nchunks, n, chunk_stride, dw, s);
-        if (db) tem_reduce_slabs(dbpart, db_chunks, Cout, Cout, db, s);
+        if (db) tem_reduce_slabs(dbpart, db_chunks, Cout, db_stride, db, s);
         return;
     }
     int64_t nb = tem_cdiv(n, 64);
@@ -772,23 +781,23 @@ void tem_reduce_slabs_w_db(const float* part, int nchunks, int ntaps, int Cin, i
     if (ntaps == 27 && Cout % 32 == 0 && n >= (1 << 20) && nchunks <= 64) {
         const int64_t nbt = (int64_t)Cin * (Cout / 32), nbdt = db ? tem_cdiv((int64_t)Cout, 256) : 0;
         hipLaunchKernelGGL(k_reduce_slabs_sd_t, dim3((unsigned)(nbt + nbdt)), dim3(256), 0, s, part, nchunks, Cin, Cout,
-                           chunk_stride, dw, (int)nbt, dbpart, db_chunks, db);
+                           chunk_stride, dw, (int)nbt, dbpart, db_chunks, db, db_stride);
         return;
     }
     if (n % 4 == 0 && chunk_stride % 4 == 0 && ((uintptr_t)part % 16 == 0)) {
         int64_t nb4 = tem_cdiv(n, 256);
         if (nb4 > 4096) nb4 = 4096;
         hipLaunchKernelGGL(k_reduce_slabs_sd4, dim3((unsigned)(nb4 + nbd)), dim3(512), 0, s, part, nchunks, ntaps, Cin, Cout,
-                           chunk_stride, dw, (int)nb4, dbpart, db_chunks, db);
+                           chunk_stride, dw, (int)nb4, dbpart, db_chunks, db, db_stride);
         return;
     }
     hipLaunchKernelGGL(k_reduce_slabs_sd, dim3((unsigned)(nb + nbd)), dim3(512), 0, s, part, nchunks, ntaps, Cin, Cout,
-                       chunk_stride, dw, (int)nb, dbpart, db_chunks, db);
+                       chunk_stride, dw, (int)nb, dbpart, db_chunks, db, db_stride);
 }
 
 void tem_reduce_slabs_w(const float* part, int nchunks, int ntaps, int Cin, int Cout, int64_t chunk_stride, float* dw,
                         int sd_layout, hipStream_t s) {
-    tem_reduce_slabs_w_db(part, nchunks, ntaps, Cin, Cout, chunk_stride, dw, sd_layout, nullptr, 0, nullptr, s);
+    tem_reduce_slabs_w_db(part, nchunks, ntaps, Cin, Cout, chunk_stride, dw, sd_layout, nullptr, 0, nullptr, s, 0);
 }
 
 #define CIN1_GRID 1024
@@ -824,14 +833,15 @@ bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const
                                sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin, gnx, gnx_ld, gcoef);
         }
         // the first NT*Cout entries of a slab are dw[tap][ci][co]; the last Cout are db
-        if (Cin == 1) {
-            tem_reduce_slabs_w(part, grid, NT, 1, Cout, (int64_t)(NT + 1) * Cout, dw, sd_layout, s);
+        if (Cin == 1) {   // the usual first layer: weight and bias gradient in one merge launch
+            tem_reduce_slabs_w_db(part, grid, NT, 1, Cout, (int64_t)(NT + 1) * Cout, dw, sd_layout, part + (int64_t)NT * Cout, grid, db, s,
+                                  (int64_t)(NT + 1) * Cout);
         } else {
             int64_t nb = tem_cdiv((int64_t)NT * Cout, 64);
             hipLaunchKernelGGL(k_reduce_slabs_ci, dim3((unsigned)nb), dim3(512), 0, s, part, grid, NT, Cin, ci, Cout,
                                (int64_t)(NT + 1) * Cout, dw, sd_layout);
         }
-        if (db && ci == 0) tem_reduce_slabs(part + (int64_t)NT * Cout, grid, Cout, (int64_t)(NT + 1) * Cout, db, s);
+        if (db && ci == 0 && Cin != 1) tem_reduce_slabs(part + (int64_t)NT * Cout, grid, Cout, (int64_t)(NT + 1) * Cout, db, s);
     }
     return true;
 }
@@ -1125,8 +1135,7 @@ bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, co
 #undef PW1
 #undef PWJ
     const int64_t slab = (int64_t)(Cin + 1) * Cout;
-    tem_reduce_slabs_w(part, grid, 1, Cin, Cout, slab, dw, sd_layout, s);  // [tap=0][ci][co]
-    if (db) tem_reduce_slabs(part + (int64_t)Cin * Cout, grid, Cout, slab, db, s);
+    tem_reduce_slabs_w_db(part, grid, 1, Cin, Cout, slab, dw, sd_layout, part + (int64_t)Cin * Cout, grid, db, s, slab);  // [tap=0][ci][co], db behind it
     return true;
 }
 
@@ -1157,8 +1166,7 @@ bool tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g
 #undef OB
 #undef OBJ
     const int64_t slab = (int64_t)(Cin + 1) * Cout;
-    tem_reduce_slabs_w(part, grid, 1, Cin, Cout, slab, dw, sd_layout, s);
-    if (db) tem_reduce_slabs(part + (int64_t)Cin * Cout, grid, Cout, slab, db, s);
+    tem_reduce_slabs_w_db(part, grid, 1, Cin, Cout, slab, dw, sd_layout, part + (int64_t)Cin * Cout, grid, db, s, slab);
     return true;
 }
 

@@ -259,6 +259,11 @@ _PACK_BATCH = os.environ.get("TEM_PACK_BATCH", "1") != "0"
 _PACK_TABLES = {}
 
 
+def _generic_batchable(conv, k) -> bool:
+    """k_pack_weights_batch writes the generic layout in items of 8 elements"""
+    return _PACK_BATCH and (conv.out_channels * conv.in_channels * k[0] * k[1] * k[2]) % 8 == 0 and conv.weight.is_contiguous()
+
+
 def _repack_stale(prepare_only: bool = False):
     """Re-pack the weights of every registered conv whose parameter changed in place (same storage, new version):
     all split-layout packs go into ONE tem_conv_pack_weights_batch launch, written into the existing buffers.
@@ -281,6 +286,8 @@ def _repack_stale(prepare_only: bool = False):
                     mode = ent[key + "_mfma"]
                     jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
                                  3 if mode == 3 else 1 if mode in (5, 7) else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
+                elif ent.get(key + "_mfma") == 0 and _generic_batchable(conv, k):
+                    jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose, 0, 0))
                 continue
             if key == "dgrad" and "dgrad16" in ent and ent.pop("dgrad16_used", False) and not ent.pop("dgrad_used", False):
                 # this layer's data gradient runs in the fp16 layout: the bf16 pack is re-made lazily if ever needed again
@@ -294,6 +301,9 @@ def _repack_stale(prepare_only: bool = False):
             if mode in (2, 3, 4, 5, 6, 7):
                 jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
                              3 if mode == 3 else 1 if mode in (5, 7) else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
+            elif mode == 0 and _generic_batchable(conv, k):
+                # the generic fp32 layout (first conv, out_conv) rides along in the batched launch: nsplit 0
+                jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose, 0, 0))
             else:
                 rest.append((ent, key, w, bool(transpose), mode))
         if not prepare_only:

@@ -178,7 +178,7 @@ def pack_table(jobs):
     ntile = nitem = n_t = n_g = 0
     for w, dst, cout, cin, k, transpose, nsplit, fp16 in jobs:
         taps = k[0] * k[1] * k[2]
-        if taps <= 27 and cout % 16 == 0 and cin % 16 == 0:
+        if nsplit != 0 and taps <= 27 and cout % 16 == 0 and cin % 16 == 0:   # nsplit 0 = generic fp32 layout: gather kernel only
             tiled += struct.pack("<qq8iq", w.data_ptr(), dst.data_ptr(), cout, cin, k[0], k[1], k[2], int(transpose), nsplit,
                                  fp16, ntile)
             ntile += ((cout + 31) // 32) * ((cin + 31) // 32)
