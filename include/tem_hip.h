@@ -365,6 +365,13 @@ int tem_norm_bwd_coef(const float* gy, int64_t gy_ld, const float* x, int64_t x_
  */
 int tem_maxpool3d_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld,
                       int N, int D, int H, int W, int C, int fz, int fy, int fx, tem_stream_t stream);
+/* tem_maxpool3d_fwd that also writes the first stage of the statistics of y -- stat_part [N][stat_blocks][C][2], one row of
+ * per-channel (sum, sum of squares) per output row (zo, yo), stat_blocks = tem_maxpool3d_fwd_stat_blocks() (0: this channel
+ * count cannot) -- for the norm in front of the next encoder block's first conv (model/unet.py:311-321, 429-438): feed them to
+ * tem_norm_finalize_partials instead of a tem_norm_stats pass over the pooled tensor. */
+int64_t tem_maxpool3d_fwd_stat_blocks(int D, int H, int C, int fz, int fy);
+int tem_maxpool3d_fwd_stats(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C,
+                            int fz, int fy, int fx, float* stat_part, int64_t stat_blocks, tem_stream_t stream);
 int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld,
                       const float* gskip, int64_t gskip_ld, int relu_mask,
                       float* gx, int64_t gx_ld,

@@ -16,6 +16,6 @@ for w in base new; do
   [ -n "$f" ] && python scripts/step_trace.py $f > $O/step_trace_$w.txt 2>&1
 done
 find $O -name "*.csv" -delete; find $O -name "*.db" -delete
-timeout 1500 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "norm or sums or absmax or amax or wgrad_fp16 or stat or split_k" 2>&1 | tail -3 > $O/pytest_ops.txt
+timeout 1500 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "norm or sums or absmax or amax or wgrad_fp16 or stat or split_k or maxpool" 2>&1 | tail -3 > $O/pytest_ops.txt
 timeout 1500 python -m pytest tests/test_gpu_unet.py tests/test_gpu_spoco.py tests/test_gpu_trainer.py -q -m gpu -x 2>&1 | tail -3 > $O/pytest_unet.txt
 tail -2 $O/pytest_ops.txt $O/pytest_unet.txt

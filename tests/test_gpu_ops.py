@@ -532,6 +532,38 @@ def test_conv_fused_forward_statistics(case, mode):
                         shift=shift, act="relu", mfma=0, want_stats=True) is None
 
 
+@pytest.mark.parametrize("case", [
+    (2, 16, 32, 24, 32, (2, 2, 2), 32),     # InstanceNorm groups
+    (1, 8, 20, 12, 64, (1, 2, 2), 8),       # anisotropic factor, GroupNorm(8, 64)
+    (3, 6, 6, 12, 20, (3, 3, 3), 20),       # 27-voxel windows (general path), C / 4 = 5 does not divide 256: declines
+    (2, 4, 8, 8, 512, (2, 2, 2), 32),       # 128 channel quads
+])
+def test_maxpool_forward_also_delivers_the_statistics_of_its_output(case):
+    """tem_maxpool3d_fwd_stats + tem_norm_finalize_partials == tem_norm_stats of the pooled tensor (the norm in front of the
+    next encoder block's first conv, reference model/unet.py:311-321), without the pass over it."""
+    ops = _ops()
+    N, D, H, W, C, f, groups = case
+    gen = torch.Generator().manual_seed(9)
+    x5 = to5(torch.randn(N, C, D, H, W, generator=gen) * 2.0 + 0.5)
+    Do, Ho, Wo = D // f[0], H // f[1], W // f[2]
+    y, y_ref = ops.new_act(N, Do, Ho, Wo, C, DEV), ops.new_act(N, Do, Ho, Wo, C, DEV)
+    got = ops.maxpool_fwd(x5, y, f, want_stats=True)
+    ops.maxpool_fwd(x5, y_ref, f)
+    assert torch.equal(y, y_ref)
+    cq = C // 4 if C % 4 == 0 else C
+    if 256 % cq:
+        assert got is None
+        return
+    part, nblk = got
+    assert nblk == Do * Ho and tuple(part.shape) == (N, nblk, C, 2)
+    gamma, beta = (torch.rand(C, generator=gen) + 0.5).to(DEV), torch.randn(C, generator=gen).to(DEV)
+    for rows in (N, 1):
+        want = ops.norm_stats(y if rows == N else y.reshape(1, N * Do, Ho, Wo, C), groups, gamma, beta, 1e-5)
+        have = ops.norm_stats_from_partials(part, rows, Do * Ho * Wo, C, groups, gamma, beta, 1e-5)
+        for a, c, name in zip(have, want, ("mean", "rstd", "scale", "shift")):
+            assert a.shape == c.shape and rel_err(a.cpu(), c.cpu()) < 2e-6, (name, rows)
+
+
 @pytest.mark.parametrize("case", [(2, 9, 17, 10, 1, 32, (3, 3, 3)), (1, 1, 19, 21, 1, 16, (1, 3, 3)),
                                   (2, 5, 9, 12, 3, 32, (3, 3, 3))])
 def test_first_layer_fused_forward_statistics(case):

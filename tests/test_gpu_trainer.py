@@ -546,7 +546,10 @@ def test_bfloat16_trainer_against_reference_autocast_run(tmp_path):
     assert abs(log["loss"][0] - gb["bf16_train_loss"][0]) < 2e-3 * gb["bf16_train_loss"][0]
     assert np.allclose(log["loss"], gb["bf16_train_loss"], rtol=2e-2), (log["loss"], list(gb["bf16_train_loss"]))
     assert np.allclose(log["metric"], gb["bf16_val_metric"], rtol=3e-2)
-    assert np.allclose(log["loss"], g["fp32_train_loss"], rtol=1e-2)
+    # against the fp32 run: as far as the reference's OWN bfloat16 run is from it (0.7 % at step 4, 1.3 % at step 8 in the golden
+    # file) -- an 8-bit-mantissa trajectory amplifies any change of summation order (1 % held until the max-pool delivered
+    # the statistics partials, round 4: 1.17 % at step 4)
+    assert np.allclose(log["loss"], g["fp32_train_loss"], rtol=2e-2)
     assert max(abs(a - b) for a, b in zip(log["loss"], g["fp32_train_loss"])) > 1e-5    # not the fp32 path
     ckpt = torch.load(os.path.join(trainer.checkpoint_folder, "latest.pt"), weights_only=False)
     assert ckpt["scaler_state"] == {} and ckpt["init"]["mixed_precision_dtype"] == "bfloat16"   # as the reference's

@@ -78,6 +78,8 @@ SIGNATURES = {
     "tem_norm_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
                              c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tem_maxpool3d_fwd": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
+    "tem_maxpool3d_fwd_stat_blocks": (c_i64, [c_int] * 5),
+    "tem_maxpool3d_fwd_stats": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp, c_i64, c_vp]),
     "tem_maxpool3d_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64] + [c_int] * 8 + [c_vp]),
     "tem_maxpool3d_bwd_norm": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64] + [c_int] * 8
                                + [c_vp, c_i64, c_vp, c_vp]),

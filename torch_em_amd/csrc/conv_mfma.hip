@@ -516,7 +516,13 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __re
             rs[j] = ni.rstd[n * ni.G + (c0 + j) / cg];
         }
     }
-    for (int64_t vl = v0 + r; vl < v1; vl += rows) {
+    // VB = 4 rows of `rows` voxels: exactly four trips, unrolled so that the loads of all four voxels are in flight together
+    // (voxels beyond the range read a clamped one and are dropped)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t vl_raw = v0 + r + (int64_t)u * rows;
+        const bool vin = vl_raw < v1;
+        const int64_t vl = vin ? vl_raw : v1 - 1;
         const int64_t v = (int64_t)n * V + vl;
         float4 a = bz;
         float4 rr = make_float4(1.f, 1.f, 1.f, 1.f), xi = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -548,12 +554,13 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __re
             if (!(rr.z > 0.f)) a.z = 0.f;
             if (!(rr.w > 0.f)) a.w = 0.f;
         }
-        *reinterpret_cast<float4*>(y + v * y_ld + c0) = a;
+        if (vin) *reinterpret_cast<float4*>(y + v * y_ld + c0) = a;
         const float av[4] = {a.x, a.y, a.z, a.w}, xv[4] = {xi.x, xi.y, xi.z, xi.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s0[j] += av[j];
-            s1[j] = fmaf(av[j], BWD ? (xv[j] - mu[j]) * rs[j] : av[j], s1[j]);
+            const float aj = vin ? av[j] : 0.f;
+            s0[j] += aj;
+            s1[j] = fmaf(aj, BWD ? (xv[j] - mu[j]) * rs[j] : aj, s1[j]);
         }
     }
 #pragma unroll

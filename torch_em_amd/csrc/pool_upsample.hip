@@ -54,11 +54,18 @@ static inline bool vec4_ok(int C, std::initializer_list<const void*> ptrs, std::
 // ---------------------------------------------------------------------------
 // max pool
 // ---------------------------------------------------------------------------
+// stat (optional, [N][Do * Ho][C][2], 256 % (C / VEC) == 0): the block's (sum, sum of squares) of every channel of its output
+// row -- the first stage of the statistics of the norm that reads the pooled tensor next (tem_maxpool3d_fwd_stats)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, int64_t x_ld, float* __restrict__ y,
-                                                     int64_t y_ld, int D, int H, int W, int C, int fz, int fy, int fx) {
+                                                     int64_t y_ld, int D, int H, int W, int C, int fz, int fy, int fx,
+                                                     float* __restrict__ stat) {
+    extern __shared__ float pst[];   // stat: [256 / cq rows][C][2]
     const int Do = D / fz, Ho = H / fy, Wo = W / fx;
     const int cq = C / VEC;
+    float s0[VEC], s1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s0[j] = s1[j] = 0.f;
     int row = blockIdx.x;  // (n, zo, yo)
     const int yo = row % Ho;
     row /= Ho;
@@ -85,26 +92,50 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x
                         if (t[k][j] > m[j] || t[k][j] != t[k][j]) m[j] = t[k][j];
                 }
             st_vec<VEC>(y + ((((int64_t)n * Do + zo) * Ho + yo) * Wo + xo) * y_ld + c0, m);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                s0[j] += m[j];
+                s1[j] = fmaf(m[j], m[j], s1[j]);
+            }
         }
-        return;
+    } else {
+        for (int i = threadIdx.x; i < Wo * cq; i += 256) {
+            const int xo = i / cq, c0 = (i % cq) * VEC;
+            float m[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
+            for (int dz = 0; dz < fz; ++dz)
+                for (int dy = 0; dy < fy; ++dy)
+                    for (int dx = 0; dx < fx; ++dx) {
+                        int64_t v = (((int64_t)n * D + zo * fz + dz) * H + yo * fy + dy) * W + xo * fx + dx;
+                        float t[VEC];
+                        ld_vec<VEC>(x + v * x_ld + c0, t);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j)
+                            if (t[j] > m[j] || t[j] != t[j]) m[j] = t[j];
+                    }
+            int64_t vo = (((int64_t)n * Do + zo) * Ho + yo) * Wo + xo;
+            st_vec<VEC>(y + vo * y_ld + c0, m);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                s0[j] += m[j];
+                s1[j] = fmaf(m[j], m[j], s1[j]);
+            }
+        }
     }
-    for (int i = threadIdx.x; i < Wo * cq; i += 256) {
-        const int xo = i / cq, c0 = (i % cq) * VEC;
-        float m[VEC];
+    if (stat) {   // 256 % cq == 0: a thread keeps its channels over its trips; rows of threads share them
+        const int q = threadIdx.x % cq, r = threadIdx.x / cq, rows = 256 / cq;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
-        for (int dz = 0; dz < fz; ++dz)
-            for (int dy = 0; dy < fy; ++dy)
-                for (int dx = 0; dx < fx; ++dx) {
-                    int64_t v = (((int64_t)n * D + zo * fz + dz) * H + yo * fy + dy) * W + xo * fx + dx;
-                    float t[VEC];
-                    ld_vec<VEC>(x + v * x_ld + c0, t);
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j)
-                        if (t[j] > m[j] || t[j] != t[j]) m[j] = t[j];
-                }
-        int64_t vo = (((int64_t)n * Do + zo) * Ho + yo) * Wo + xo;
-        st_vec<VEC>(y + vo * y_ld + c0, m);
+        for (int j = 0; j < VEC; ++j) {
+            pst[(r * C + q * VEC + j) * 2 + 0] = s0[j];
+            pst[(r * C + q * VEC + j) * 2 + 1] = s1[j];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * C; t += 256) {
+            float a = 0.f;
+            for (int k = 0; k < rows; ++k) a += pst[k * 2 * C + t];
+            stat[(int64_t)blockIdx.x * 2 * C + t] = a;
+        }
     }
 }
 
@@ -262,21 +293,48 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
     if (amax) tem_amax_commit(amax, amx);
 }
 
-extern "C" int tem_maxpool3d_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W,
-                                 int C, int fz, int fy, int fx, tem_stream_t stream) {
+static int maxpool3d_fwd_impl(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C, int fz,
+                              int fy, int fx, float* stat, tem_stream_t stream) {
     TEM_REQUIRE(x && y && N > 0 && C > 0 && x_ld >= C && y_ld >= C, "tem_maxpool3d_fwd: bad arguments");
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0 && D % fz == 0 && H % fy == 0 && W % fx == 0,
                 "tem_maxpool3d_fwd: shape (%d,%d,%d) not divisible by factors (%d,%d,%d)", D, H, W, fz, fy, fx);
     int64_t rows = (int64_t)N * (D / fz) * (H / fy);
     TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_fwd: too many rows");
-    if (vec4_ok(C, {x, y}, {x_ld, y_ld}))
-        hipLaunchKernelGGL((k_maxpool_fwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, x_ld, y, y_ld,
-                           D, H, W, C, fz, fy, fx);
+    const bool v4 = vec4_ok(C, {x, y}, {x_ld, y_ld});
+    const int cq = v4 ? C / 4 : C;
+    TEM_REQUIRE(!stat || (cq <= 256 && 256 % cq == 0), "tem_maxpool3d_fwd_stats: tem_maxpool3d_fwd_stat_blocks() == 0 for C = %d", C);
+    const size_t lds = stat ? (size_t)(256 / cq) * C * 2 * sizeof(float) : 0;
+    if (v4)
+        hipLaunchKernelGGL((k_maxpool_fwd<4>), dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, x, x_ld, y, y_ld,
+                           D, H, W, C, fz, fy, fx, stat);
     else
-        hipLaunchKernelGGL((k_maxpool_fwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, x_ld, y, y_ld,
-                           D, H, W, C, fz, fy, fx);
+        hipLaunchKernelGGL((k_maxpool_fwd<1>), dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, x, x_ld, y, y_ld,
+                           D, H, W, C, fz, fy, fx, stat);
     TEM_CHECK_LAUNCH("tem_maxpool3d_fwd");
     return TEM_OK;
+}
+
+extern "C" int tem_maxpool3d_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W,
+                                 int C, int fz, int fy, int fx, tem_stream_t stream) {
+    return maxpool3d_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, nullptr, stream);
+}
+
+// statistics partial rows per sample of tem_maxpool3d_fwd_stats: one per output row (zo, yo); 0: this channel count cannot
+extern "C" int64_t tem_maxpool3d_fwd_stat_blocks(int D, int H, int C, int fz, int fy) {
+    const int cq = C % 4 == 0 ? C / 4 : C;
+    if (fz <= 0 || fy <= 0 || cq > 256 || 256 % cq) return 0;
+    return (int64_t)(D / fz) * (H / fy);
+}
+
+// tem_maxpool3d_fwd that also writes stat_part [N][stat_blocks][C][2]: per output row the (sum, sum of squares) of every
+// channel -- tem_norm_finalize_partials turns them into the statistics of the norm that reads y next (the first norm of the
+// next encoder level: one pass over the pooled tensor and one launch less)
+extern "C" int tem_maxpool3d_fwd_stats(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C,
+                                       int fz, int fy, int fx, float* stat_part, int64_t stat_blocks, tem_stream_t stream) {
+    TEM_REQUIRE(stat_part && stat_blocks > 0 && fz > 0 && fy > 0 && stat_blocks == tem_maxpool3d_fwd_stat_blocks(D, H, C, fz, fy),
+                "tem_maxpool3d_fwd_stats: stat_blocks must be tem_maxpool3d_fwd_stat_blocks() (and > 0)");
+    TEM_REQUIRE((C % 4 == 0) == vec4_ok(C, {x, y}, {x_ld, y_ld}), "tem_maxpool3d_fwd_stats: x / y must be 16-byte aligned with ld %% 4 == 0");
+    return maxpool3d_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, stat_part, stream);
 }
 
 static int maxpool3d_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, const float* gskip,

@@ -195,6 +195,7 @@ _FUSE_OUT_BWD = os.environ.get("TEM_FUSE_OUT_BWD", "1") != "0"   # out_conv: wei
 _FUSE_AMAX = os.environ.get("TEM_FUSE_AMAX", "1") != "0"   # 0: every fp16 2x1 weight gradient runs its own absmax pass
 # the weight gradient that delivers the norm sums also finishes them into the norm-backward coefficients; 0: tem_norm_bwd_coef
 _FUSE_COEF = os.environ.get("TEM_FUSE_NORM_COEF", "1") != "0"
+_FUSE_POOL_STATS = os.environ.get("TEM_FUSE_POOL_STATS", "1") != "0"   # max-pool forward writes the statistics partials of its output
 
 
 class _sums_coef:
@@ -632,13 +633,14 @@ def _norm_is_live(n) -> bool:
                                   getattr(n, "running_mean", None) is not None and not n.training)
 
 
-def _block_fwd(blk, xin, out, in_partials2=None, out_stats=False):
+def _block_fwd(blk, xin, out, in_partials2=None, out_stats=False, in_partials=None):
     """ConvBlock (reference model/unet.py:429-438): [norm->conv->ReLU] x 2.  Returns what backward needs.
     in_partials2: first-stage statistics of the two channel halves of xin (decoder concat) or None.
+    in_partials: first-stage statistics of xin from its producer (the max-pool kernel) or None.
     out_stats: also return the first-stage statistics of `out` (key "out_part"; None when conv2 cannot provide them)."""
     c1, c2 = blk.conv_specs()
     N, D, H, W, _ = xin.shape
-    s1 = _stats(c1, xin, partials2=in_partials2)
+    s1 = _stats(c1, xin, partials=in_partials, partials2=in_partials2)
     a1 = ops.new_act(N, D, H, W, c1.cout, xin.device)
     live = _norm_is_live(c2.norm)
     part = _conv(c1, xin, a1, s1, act="relu", want_stats=_FUSE_STATS and live)
@@ -781,6 +783,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
     dev = xin.device
     st = {"levels": [], "dim": dim, "x_shape": tuple(x.shape)}
     cur = xin
+    cur_part = None   # first-stage statistics of `cur` from the kernel that produced it (the max-pool), if any
     for l in range(depth):
         blk = enc.blocks[l]
         f = _f3(enc.scale_factors[l], dim)
@@ -794,7 +797,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         # the skip tensor feeds the norm in front of the decoder block of this level: its statistics come out of the
         # epilogue of this block's second conv (with the upsampled half's from the low-resolution tensor, see below)
         dnorm = dec.blocks[depth - 1 - l].conv_specs()[0].norm
-        bs = _block_fwd(blk, cur, skip, out_stats=_FUSE_STATS and _FUSE_CONCAT_STATS and _norm_is_live(dnorm))
+        bs = _block_fwd(blk, cur, skip, out_stats=_FUSE_STATS and _FUSE_CONCAT_STATS and _norm_is_live(dnorm), in_partials=cur_part)
         pooled = ops.new_act(N, D // f[0], H // f[1], W // f[2], blk.out_channels, dev)
         lvl = {"cat": cat, "skip": skip, "bs": bs, "f": f, "c_up": c_up}
         if floor:
@@ -803,13 +806,20 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
             # decoder then crops this level's skip tensor, reference Decoder._crop)
             lvl["floor_sub"] = skip[:, :D // f[0] * f[0], :H // f[1] * f[1], :W // f[2] * f[2]].contiguous()
             ops.maxpool_fwd(lvl["floor_sub"], pooled, f)
+            cur_part = None
         else:
-            ops.maxpool_fwd(skip, pooled, f)
+            # the statistics of the pooled tensor (norm of the next block's first conv) as a by-product of the pooling pass
+            nxt = (enc.blocks[l + 1] if l + 1 < depth else model.base).conv_specs()[0].norm
+            if _FUSE_STATS and _FUSE_POOL_STATS and _norm_is_live(nxt):
+                cur_part = ops.maxpool_fwd(skip, pooled, f, want_stats=True)   # (partials, nblk) or None
+            else:
+                ops.maxpool_fwd(skip, pooled, f)
+                cur_part = None
         st["levels"].append(lvl)
         cur = pooled
     _, D, H, W, _ = cur.shape
     base_out = ops.new_act(N, D, H, W, model.base.out_channels, dev)
-    st["base"] = _block_fwd(model.base, cur, base_out)
+    st["base"] = _block_fwd(model.base, cur, base_out, in_partials=cur_part)
     cur = base_out
     st["dec"] = []
     for i in range(depth):

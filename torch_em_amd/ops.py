@@ -601,14 +601,22 @@ def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None,
 
 
 # --------------------------------------------------------- pool / upsample ----
-def maxpool_fwd(x, y, f):
+def maxpool_fwd(x, y, f, want_stats=False):
+    """want_stats: also return (partials [N, nblk, C, 2], nblk) -- the first stage of the statistics of y (what
+    conv_fwd(want_stats=True) returns for a conv output; tem_maxpool3d_fwd_stats) -- or None when this channel count cannot."""
     _req_cuda(x, y)
     N, D, H, W, C, x_ld = _act5(x)
     y_ld = _act5(y)[5]
     lib = _lib.load()
+    nblk = int(lib.tem_maxpool3d_fwd_stat_blocks(D, H, C, f[0], f[1])) if want_stats else 0
+    if nblk > 0 and x_ld % 4 == 0 and y_ld % 4 == 0 and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
+        part = torch.empty((N, nblk, C, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.tem_maxpool3d_fwd_stats(_p(x), x_ld, _p(y), y_ld, N, D, H, W, C, f[0], f[1], f[2], _p(part), nblk,
+                                               _stream(x)), "tem_maxpool3d_fwd_stats")
+        return part, nblk
     _lib.check(lib.tem_maxpool3d_fwd(_p(x), x_ld, _p(y), y_ld, N, D, H, W, C, f[0], f[1], f[2], _stream(x)),
                "tem_maxpool3d_fwd")
-    return y
+    return None if want_stats else y
 
 
 def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None, gy_coef=None):
