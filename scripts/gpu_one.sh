@@ -1,3 +1,4 @@
+# scratch script for one-off gpurun calls: `gpurun -- 'bash scripts/gpu_one.sh'`; default = the GPU suite
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/one; rm -f gpurun_out/one/*
