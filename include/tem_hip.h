@@ -51,7 +51,7 @@ int tem_device_cus(void);
  * (the reference selects nothing: it calls ATen).  Names:
  *   "conv_fwd_variant"   -1 auto | 0 one-patch-per-workgroup kernel | 1 ping-pong team kernel (conv_pp.hip) for every shape
  *                        it can take | 2 z-reuse team kernel (conv_zr.hip, 3x3x3) for every shape it can take
- *   "wgrad_zs"            3 | 2 | 1 | 0   z-sliding weight gradient (3x3x3, D >= 16): 3 (default) = staging team + voxel-major
+ *   "wgrad_zs"            3 | 2 | 1 | 0   z-sliding weight gradient (3x3x3, D >= 8): 3 (default) = staging team + voxel-major
  *                        LDS records read with ds_read_b64_tr_b16 (k_conv_wgrad_tr), 2 = staging team with channel-major
  *                        planes (k_conv_wgrad_zt), 1 = the round-2 kernel (k_conv_wgrad_zs), 0 = patch kernel
  *   "wgrad_zs_persist"    1 | 0   persistent column segments of that kernel
@@ -203,7 +203,7 @@ int tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g_
 /* tem_conv3d_wgrad (w == NULL, norm_sums == NULL) or tem_conv3d_wgrad_sums that ALSO reports the largest |g|: g_amax
  * (device, one 32-bit word the caller cleared) receives the bit pattern of max |g| by an integer atomicMax -- exact and
  * order-independent.  dw comes in state_dict order.  Only the z-sliding 3x3x3 kernel stages all of g
- * (tem_conv3d_wgrad_gmax_ok: 3x3x3, D >= 16, Cin, Cout % 32 == 0, use_mfma == 2).  Consumer: tem_conv3d_fwd_gscaled. */
+ * (tem_conv3d_wgrad_gmax_ok: 3x3x3, D >= 8, Cin, Cout % 32 == 0, use_mfma == 2).  Consumer: tem_conv3d_fwd_gscaled. */
 int tem_conv3d_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* scale, const float* shift,
                           const float* g, int64_t g_ld, const float* w, const float* gamma, const float* beta,
@@ -218,7 +218,7 @@ int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* scale, cons
  * the split-bf16 mode, fp32 accumulation, the result multiplied by the inverse power (exact).  Every dw entry carries
  * the random rounding of an 11-bit g: ~2e-4 relative (scripts/backward_arith_sim.py), unbiased.  dw in state_dict
  * order; w / gamma / beta / norm_sums as in tem_conv3d_wgrad_sums (NULL: plain weight gradient).  Only the z-sliding
- * 3x3x3 kernel (tem_conv3d_wgrad_gscaled_ok: 3x3x3, D >= 16, Cin, Cout % 32 == 0); workspace tem_conv3d_wgrad_ws(.., 8). */
+ * 3x3x3 kernel (tem_conv3d_wgrad_gscaled_ok: 3x3x3, D >= 8, Cin, Cout % 32 == 0); workspace tem_conv3d_wgrad_ws(.., 8). */
 int tem_conv3d_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int tem_conv3d_wgrad_gscaled(const float* x, int64_t x_ld, const float* scale, const float* shift,
                              const float* g, int64_t g_ld, const float* w, const float* gamma, const float* beta,

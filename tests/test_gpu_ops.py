@@ -746,7 +746,8 @@ def wgrad_kernel_option():
 @pytest.mark.parametrize("kernel", [1, 2, 3])
 @pytest.mark.parametrize("mode", [1, 2, 5, 7])
 @pytest.mark.parametrize("case", [(2, 16, 16, 24, 32, 32), (1, 20, 24, 17, 32, 32), (2, 16, 16, 16, 64, 64), (2, 33, 8, 8, 32, 96),
-                                  (1, 16, 132, 136, 32, 32), (3, 17, 9, 10, 64, 32)])
+                                  (1, 16, 132, 136, 32, 32), (3, 17, 9, 10, 64, 32),
+                                  (2, 8, 8, 8, 64, 96), (1, 9, 12, 12, 64, 64), (1, 12, 24, 24, 32, 64)])   # short columns (8 <= D < 16)
 def test_wgrad_z_sliding_kernels_agree_with_float64(case, mode, kernel, wgrad_kernel_option):
     """Every z-sliding weight-gradient kernel (round 2: k_conv_wgrad_zs, round 3: _zt with a staging team, round 4: _tr with
     voxel-major LDS records and ds_read_b64_tr_b16 fragment reads) in the exact-fp32 / bf16x3 / one-term fp16 / one-term bf16

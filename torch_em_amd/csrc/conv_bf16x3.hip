@@ -1736,6 +1736,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_zt(const float* __restric
     }
 }
 
+#ifndef TEM_ZS_MIN_D
+#define TEM_ZS_MIN_D 8   // shortest z column of the z-sliding kernels (16 until round 4: a column of 8 .. 15 planes pays six priming
+#endif                   // iterations for its planes and still beats the patch kernel; k_conv_wgrad_zs is wrong below 8)
 struct ZsPlan {
     bool use;
     bool teams;   // k_conv_wgrad_zt (staging team) instead of k_conv_wgrad_zs
@@ -1745,7 +1748,7 @@ struct ZsPlan {
 static ZsPlan zs_plan(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     ZsPlan p;
     const int enable = (int)tem_option(TEM_OPT_WGRAD_ZS);
-    p.use = enable && kd == 3 && kh == 3 && kw == 3 && D >= 16;
+    p.use = enable && kd == 3 && kh == 3 && kw == 3 && D >= TEM_ZS_MIN_D;
     const int ncot = Cout / 32;
     p.teams = enable >= 2;
     p.tr = enable >= 3;
