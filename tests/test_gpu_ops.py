@@ -122,7 +122,7 @@ def test_conv_fwd_dgrad_wgrad(case, fused):
 
 
 MIXED_CASES = [
-    (1, 8, 16, 16, 32, 64, (3, 3, 3)),    # patch wgrad kernel (D < 16): stays bf16x3
+    (1, 8, 16, 16, 32, 64, (3, 3, 3)),    # shortest z-sliding column (D = 8; below it the patch wgrad kernel stays bf16x3)
     (1, 20, 24, 17, 32, 32, (3, 3, 3)),   # z-sliding wgrad, k-halves
     (1, 16, 16, 24, 64, 64, (3, 3, 3)),   # z-sliding wgrad, two Cout tiles
     (1, 1, 20, 33, 16, 64, (1, 3, 3)),    # 2-D
@@ -175,10 +175,12 @@ def test_conv_mixed_precision_mode(case, mode):
         dw = torch.empty(w.numel(), device=DEV)
         db = torch.empty(Cout, device=DEV)
         ops.conv_wgrad(x5, to5(gy), k, Cin, Cout, dw, db, scale=scale.to(DEV), shift=shift.to(DEV), mfma=mode)
-        zs = k == (3, 3, 3) and D >= 16      # the z-sliding kernel has the one-term variants; the patch kernel stays bf16x3
+        zs = k == (3, 3, 3) and D >= 8       # the z-sliding kernel has the one-term variants; the patch kernel stays bf16x3
         xe = xh if zs else xn
         dwe = torch.nn.grad.conv3d_weight(xe, w.shape, r16(gy) if zs else gy, padding=pad)
-        assert rel_err(dw.cpu().view(w.shape), dwe) < (2e-5 if zs else 1e-4)
+        # (3e-5, not 2e-5: `dwe` is itself an fp32 sum over N*D*H*W terms in ATen's order; against float64 the kernels are
+        # checked in test_wgrad_z_sliding_kernels_agree_with_float64 -- 2 x 8^3 x 128 -> 128 measures 2.5e-5 here)
+        assert rel_err(dw.cpu().view(w.shape), dwe) < (3e-5 if zs else 1e-4)
         assert rel_err(db.cpu(), gy.sum((0, 2, 3, 4))) < 5e-5   # bias gradient sums the fp32 values
 
 
