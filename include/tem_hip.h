@@ -59,6 +59,7 @@ int tem_device_cus(void);
  *   "wgrad_sums_min_mb"   128     ... for layers whose norm input has at least this many MiB
  *   "fwd_persistent"     -1 | 0 | 1   exact-fp32 forward: persistent variant (-1: 64-column tiles only)
  *   "conv1x1_stream"      1 | 0   1x1x1 convolutions / data gradients as a streaming GEMM instead of the patch kernel
+ *   "dice_vox"            1 | 0   Dice sums / gradient kernels with one voxel per thread (C <= 16; 0: the (channel, voxel) kernels)
  *   "fwd_ksplit_chunks"   0       split-K forward: at most this many 16-channel chunks per partial (0: heuristic)
  *   "wgrad_cus"           256     workgroups the z-sliding weight gradient asks for
  *   "upsample_generic"    0 | 1   1: the any-factor gather kernels also for factors (1|2, 2, 2)

@@ -38,6 +38,7 @@ static const TemOption g_opt_table[TEM_OPT_COUNT] = {
     {"zr_splitk", 1},           // TEM_OPT_ZR_SPLITK: z-reuse kernel with split input channels for the 16^3 / 32^3 levels
     {"zr_wide", 1},             // TEM_OPT_ZR_WIDE: one-term z-reuse kernel stages 32 channels (whole 128-byte lines) per phase (0: 16, A/B)
     {"zr_tile_blocks", 1},      // TEM_OPT_ZR_TILE_BLOCKS: z-reuse kernel walks its tiles in 4 x 4 x 4 blocks (one block per XCD at a time; 0: x, y, z order, A/B)
+    {"dice_vox", 1},            // TEM_OPT_DICE_VOX: Dice sums / gradient with one voxel per thread for C <= 16 (0: one (channel, voxel) per thread, A/B)
 };
 static long long g_opt_val[TEM_OPT_COUNT];
 static bool g_opt_set[TEM_OPT_COUNT];

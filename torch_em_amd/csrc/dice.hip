@@ -5,7 +5,7 @@
 // Reduction: fp32 per-thread partials -> fp32 per-block partials -> fp64 per-channel sums.
 #include "tem_common.h"
 
-#define DICE_MAX_BLOCKS 1024
+#define DICE_MAX_BLOCKS 2048
 
 extern "C" int64_t tem_dice_ws(int N, int64_t V, int C) {
     (void)N;
@@ -87,6 +87,97 @@ __global__ void k_dice_partial(const float* __restrict__ p, int64_t p_sn, int64_
     }
 }
 
+// The same sums with one VOXEL per thread and a loop over the channels (C <= DICE_VOX_C), round 4.  The kernel above gives a
+// channel to a lane: with a channels-last prediction and a channel-first target (what UNetFunction and the loaders
+// produce) one of the two tensors is read with lanes a volume apart -- 13 cache lines per load instruction for the 12
+// affinity channels of cfg 3, 1.5 TB/s.  Here both are coalesced: a lane reads its voxel's C contiguous prediction values
+// (16-byte loads when C % 4 == 0) and, per channel, the wave reads 64 consecutive target values.
+#define DICE_VOX_C 16
+template <int VECP>   // prediction loads: 4 = float4 (p_sc == 1, C % 4 == 0, aligned), 2 = float2 (C == 2), 1 = scalar / any strides
+__global__ __launch_bounds__(256) void k_dice_partial_vox(const float* __restrict__ p, int64_t p_sn, int64_t p_sc, int64_t p_sv,
+                                                          const float* __restrict__ t, int64_t t_sn, int64_t t_sc, int64_t t_sv,
+                                                          const float* __restrict__ mask, int N, int C, int64_t V, int64_t vper,
+                                                          int nblk_per_n, float* __restrict__ part, int flags) {
+    __shared__ float shv[4][DICE_VOX_C][4];
+    const int NS = (flags & TEM_DICE_BCE) ? 4 : 3;
+    const int n = blockIdx.x / nblk_per_n, b = blockIdx.x % nblk_per_n;
+    (void)vper;
+    const float* pn = p + (int64_t)n * p_sn;
+    const float* tn = t + (int64_t)n * t_sn;
+    const float* mn = mask ? mask + (int64_t)n * t_sn : nullptr;
+    float s0[DICE_VOX_C], s1[DICE_VOX_C], s2[DICE_VOX_C], s3[DICE_VOX_C];
+#pragma unroll
+    for (int c = 0; c < DICE_VOX_C; ++c) s0[c] = s1[c] = s2[c] = s3[c] = 0.f;
+    // tiles of 256 voxels dealt round-robin to the workgroups of a sample: with one contiguous range per workgroup (ranges
+    // a power of two apart, the C target planes a power of two apart) all workgroups walked the same few HBM channels in
+    // lockstep -- 461 us on cfg 3 where the gradient kernel (grid-stride, same loads plus a store) takes 358
+    for (int64_t vb = (int64_t)b * 256 + threadIdx.x; vb < V; vb += (int64_t)nblk_per_n * 256) {
+        float pq[DICE_VOX_C], tq[DICE_VOX_C], mq[DICE_VOX_C];
+        const float* pv_ = pn + vb * p_sv;
+        if constexpr (VECP == 4) {
+#pragma unroll
+            for (int c = 0; c < DICE_VOX_C; c += 4)
+                if (c < C) {
+                    const float4 q = *reinterpret_cast<const float4*>(pv_ + c);
+                    pq[c] = q.x; pq[c + 1] = q.y; pq[c + 2] = q.z; pq[c + 3] = q.w;
+                }
+        } else if constexpr (VECP == 2) {
+            const float2 q = *reinterpret_cast<const float2*>(pv_);
+            pq[0] = q.x; pq[1] = q.y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < DICE_VOX_C; ++c)
+                if (c < C) pq[c] = pv_[c * p_sc];
+        }
+#pragma unroll
+        for (int c = 0; c < DICE_VOX_C; ++c)
+            if (c < C) {
+                tq[c] = tn[c * t_sc + vb * t_sv];
+                mq[c] = mn ? mn[c * t_sc + vb * t_sv] : 1.f;
+            }
+#pragma unroll
+        for (int c = 0; c < DICE_VOX_C; ++c)
+            if (c < C) {
+                float pv = pq[c], tv = tq[c];
+                if (flags) {   // launch-uniform
+                    const float xv = pv;
+                    if (flags & TEM_DICE_LOGITS) pv = dice_sigmoid(xv);
+                    if (flags & TEM_DICE_BCE) {
+                        if (flags & TEM_DICE_LOGITS)
+                            s3[c] += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
+                        else
+                            s3[c] -= tv * fmaxf(logf(pv), -100.f) + (1.f - tv) * fmaxf(logf(1.f - pv), -100.f);
+                    }
+                }
+                if (mn) {
+                    pv *= mq[c];
+                    tv *= mq[c];
+                }
+                s0[c] = fmaf(pv, tv, s0[c]);
+                s1[c] = fmaf(pv, pv, s1[c]);
+                s2[c] = fmaf(tv, tv, s2[c]);
+            }
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < DICE_VOX_C; ++c)
+        if (c < C) {
+            const float a0 = tem_wave_sum(s0[c]), a1 = tem_wave_sum(s1[c]), a2 = tem_wave_sum(s2[c]);
+            const float a3 = NS == 4 ? tem_wave_sum(s3[c]) : 0.f;
+            if (lane == 0) {
+                shv[wv][c][0] = a0;
+                shv[wv][c][1] = a1;
+                shv[wv][c][2] = a2;
+                shv[wv][c][3] = a3;
+            }
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * NS; i += 256) {
+        const int c = i / NS, k = i % NS;
+        part[((int64_t)blockIdx.x * C + c) * NS + k] = shv[0][c][k] + shv[1][c][k] + shv[2][c][k] + shv[3][c][k];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_dice_reduce(const float* __restrict__ part, int nblk, int C,
                                                      double* __restrict__ sums, int NS) {
     const int c = blockIdx.x;
@@ -122,7 +213,8 @@ static int dice_sums_impl(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_
     }
     int rows = 256 / C;
     if (rows < 1) rows = 1;
-    int threads = rows * C;
+    if (C <= DICE_VOX_C && tem_option(TEM_OPT_DICE_VOX)) rows = 256;   // one voxel per thread (k_dice_partial_vox)
+    int threads = C <= DICE_VOX_C && tem_option(TEM_OPT_DICE_VOX) ? 256 : rows * C;
     int64_t nb = tem_cdiv(V, (int64_t)rows * 8);
     int64_t maxb = DICE_MAX_BLOCKS / N;
     if (maxb < 1) {
@@ -135,7 +227,18 @@ static int dice_sums_impl(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_
     size_t lds = (size_t)rows * C * NS * sizeof(float);
     float* part = (float*)ws;
     bool cfast = (p_sc == 1);
-    if (cfast)
+    if (C <= DICE_VOX_C && tem_option(TEM_OPT_DICE_VOX)) {
+        const bool al = cfast && p_sn % 4 == 0 && p_sv % 4 == 0 && ((uintptr_t)p % 16 == 0);
+        if (al && C % 4 == 0)
+            hipLaunchKernelGGL((k_dice_partial_vox<4>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
+                               t_sc, t_sv, mask, N, C, V, vper, (int)nb, part, flags);
+        else if (cfast && C == 2 && p_sn % 2 == 0 && p_sv == 2 && ((uintptr_t)p % 8 == 0))
+            hipLaunchKernelGGL((k_dice_partial_vox<2>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
+                               t_sc, t_sv, mask, N, C, V, vper, (int)nb, part, flags);
+        else
+            hipLaunchKernelGGL((k_dice_partial_vox<1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
+                               t_sc, t_sv, mask, N, C, V, vper, (int)nb, part, flags);
+    } else if (cfast)
         hipLaunchKernelGGL((k_dice_partial<true>), dim3(nblk), dim3(threads), lds, (hipStream_t)stream, p, p_sn, p_sc,
                            p_sv, t, t_sn, t_sc, t_sv, mask, N, C, V, rows, vper, (int)nb, part, flags);
     else
@@ -284,6 +387,81 @@ __global__ __launch_bounds__(256) void k_dice_grad(const float* __restrict__ p, 
     }
 }
 
+// One voxel per thread (C <= DICE_VOX_C): see k_dice_partial_vox.  The gradient has the prediction's layout, so with a
+// channels-last prediction both its load and the store are C contiguous floats per lane.
+template <int VECP>
+__global__ __launch_bounds__(256) void k_dice_grad_vox(const float* __restrict__ p, int64_t p_sn, int64_t p_sc, int64_t p_sv,
+                                                       const float* __restrict__ t, int64_t t_sn, int64_t t_sc, int64_t t_sv,
+                                                       const float* __restrict__ mask, const float* __restrict__ ca,
+                                                       const float* __restrict__ cb, const float* __restrict__ gout,
+                                                       int gout_per_channel, float* __restrict__ gp, int64_t g_sn, int64_t g_sc,
+                                                       int64_t g_sv, int C, int64_t V, int flags, float w_dice, float w_bce) {
+    const int n = blockIdx.y;
+    const float* pn = p + (int64_t)n * p_sn;
+    const float* tn = t + (int64_t)n * t_sn;
+    const float* mn = mask ? mask + (int64_t)n * t_sn : nullptr;
+    float* gn = gp + (int64_t)n * g_sn;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
+        float pq[DICE_VOX_C], tq[DICE_VOX_C], mq[DICE_VOX_C], gq[DICE_VOX_C];
+        const float* pv_ = pn + v * p_sv;
+        if constexpr (VECP == 4) {
+#pragma unroll
+            for (int c = 0; c < DICE_VOX_C; c += 4)
+                if (c < C) {
+                    const float4 q = *reinterpret_cast<const float4*>(pv_ + c);
+                    pq[c] = q.x; pq[c + 1] = q.y; pq[c + 2] = q.z; pq[c + 3] = q.w;
+                }
+        } else if constexpr (VECP == 2) {
+            const float2 q = *reinterpret_cast<const float2*>(pv_);
+            pq[0] = q.x; pq[1] = q.y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < DICE_VOX_C; ++c)
+                if (c < C) pq[c] = pv_[c * p_sc];
+        }
+#pragma unroll
+        for (int c = 0; c < DICE_VOX_C; ++c)
+            if (c < C) {
+                tq[c] = tn[c * t_sc + v * t_sv];
+                mq[c] = mn ? mn[c * t_sc + v * t_sv] : 1.f;
+            }
+#pragma unroll
+        for (int c = 0; c < DICE_VOX_C; ++c)
+            if (c < C) {
+                float pv = pq[c], tv = tq[c];
+                const float m = mq[c];
+                if (mn) {
+                    pv *= m;
+                    tv *= m;
+                }
+                const float go = gout ? gout[gout_per_channel ? c : 0] : 1.f;   // wave-uniform addresses: scalar loads
+                if (flags) {   // launch-uniform: the logits / BCE members of the family (no mask there)
+                    const float xv = pv;
+                    if (flags & TEM_DICE_LOGITS) pv = dice_sigmoid(xv);
+                    float d = w_dice * (ca[c] * tv + cb[c] * pv);
+                    if (flags & TEM_DICE_LOGITS) d *= pv * (1.f - pv);
+                    if (flags & TEM_DICE_BCE)
+                        d += w_bce * ((flags & TEM_DICE_LOGITS) ? (pv - tv) : (pv - tv) / fmaxf(pv * (1.f - pv), 1e-12f));
+                    gq[c] = go * d;
+                } else {
+                    gq[c] = go * (ca[c] * tv + cb[c] * pv) * m;
+                }
+            }
+        float* gv_ = gn + v * g_sv;
+        if constexpr (VECP == 4) {
+#pragma unroll
+            for (int c = 0; c < DICE_VOX_C; c += 4)
+                if (c < C) *reinterpret_cast<float4*>(gv_ + c) = make_float4(gq[c], gq[c + 1], gq[c + 2], gq[c + 3]);
+        } else if constexpr (VECP == 2) {
+            *reinterpret_cast<float2*>(gv_) = make_float2(gq[0], gq[1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < DICE_VOX_C; ++c)
+                if (c < C) gv_[c * g_sc] = gq[c];
+        }
+    }
+}
+
 static int dice_grad_impl(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_sv, const float* t, int64_t t_sn,
                           int64_t t_sc, int64_t t_sv, const float* mask, const float* ca, const float* cb,
                           const float* gout, int gout_per_channel, float* gp, int64_t g_sn, int64_t g_sc,
@@ -291,7 +469,22 @@ static int dice_grad_impl(const float* p, int64_t p_sn, int64_t p_sc, int64_t p_
     TEM_REQUIRE(p && t && ca && cb && gp && N > 0 && C > 0 && V > 0, "tem_dice_grad: bad arguments");
     TEM_REQUIRE((flags & ~(TEM_DICE_LOGITS | TEM_DICE_BCE)) == 0 && (!flags || !mask), "tem_dice_grad2: unknown flags, or flags with a mask");
     dim3 grid(tem_grid_1d(V * C, 256, 2048), N);
-    if (p_sc == 1)
+    if (C <= DICE_VOX_C && tem_option(TEM_OPT_DICE_VOX)) {
+        const dim3 vgrid(tem_grid_1d(V, 256, 4096), N);
+        // vector accesses: prediction AND gradient channels-last with the same aligned pitch
+        const bool cl = p_sc == 1 && g_sc == 1;
+        const bool al4 = cl && C % 4 == 0 && p_sn % 4 == 0 && p_sv % 4 == 0 && g_sn % 4 == 0 && g_sv % 4 == 0 &&
+                         ((uintptr_t)p % 16 == 0) && ((uintptr_t)gp % 16 == 0);
+        const bool al2 = cl && C == 2 && p_sv == 2 && g_sv == 2 && p_sn % 2 == 0 && g_sn % 2 == 0 && ((uintptr_t)p % 8 == 0) &&
+                         ((uintptr_t)gp % 8 == 0);
+#define TEM_DGV(VP)                                                                                                            \
+    hipLaunchKernelGGL((k_dice_grad_vox<VP>), vgrid, dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn, t_sc, t_sv, \
+                       mask, ca, cb, gout, gout_per_channel, gp, g_sn, g_sc, g_sv, C, V, flags, w_dice, w_bce)
+        if (al4) TEM_DGV(4);
+        else if (al2) TEM_DGV(2);
+        else TEM_DGV(1);
+#undef TEM_DGV
+    } else if (p_sc == 1)
         hipLaunchKernelGGL((k_dice_grad<true>), grid, dim3(256), 0, (hipStream_t)stream, p, p_sn, p_sc, p_sv, t, t_sn,
                            t_sc, t_sv, mask, ca, cb, gout, gout_per_channel, gp, g_sn, g_sc, g_sv, C, V, flags, w_dice, w_bce);
     else

@@ -23,6 +23,7 @@ enum {
     TEM_OPT_ZR_SPLITK,
     TEM_OPT_ZR_WIDE,
     TEM_OPT_ZR_TILE_BLOCKS,
+    TEM_OPT_DICE_VOX,
     TEM_OPT_COUNT
 };
 long long tem_option(int id);
