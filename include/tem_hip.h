@@ -41,6 +41,26 @@ extern "C" {
 
 typedef void* tem_stream_t; /* hipStream_t */
 
+/* ---- activation storage types (round 5) --------------------------------------
+ * The reference trains under torch.autocast(float16 | bfloat16) whenever mixed_precision=True on a GPU
+ * (trainer/default_trainer.py:134-142, 781-794): every activation between two ops is a 16-bit tensor.  The `_st` / `_ex`
+ * entry points take the element type of their activation tensors explicitly; the plain entry points are the TEM_ST_F32
+ * case.  With a 16-bit type the tensor pointers are `const void*`, leading dimensions stay in ELEMENTS, a vector of 4
+ * elements is 8 bytes (alignment requirements scale accordingly), all arithmetic stays fp32 and a value is rounded once
+ * (to nearest even) when it is stored.  Statistics, coefficients, parameters, gradients of parameters, split-K
+ * workspaces and the network output are always fp32. */
+#define TEM_ST_F32 0
+#define TEM_ST_F16 1
+#define TEM_ST_BF16 2
+/* The convolution entry points (and their query functions) carry the storage types in the high bits of `use_mfma`:
+ *   use_mfma | TEM_MFMA_STX(st of x) | TEM_MFMA_STY(st of y and ref; weight gradients: of g)
+ * Supported pairs: both fp32; one side fp32 and the other 16-bit (first layer: fp32 network input -> 16-bit activations;
+ * out_conv: 16-bit activations -> fp32 prediction; VALU kernels, use_mfma 0); both the SAME 16-bit type (MFMA kernels: fp16
+ * storage with use_mfma 5, bf16 storage with use_mfma 7 -- the stored values ARE the MFMA operands; the exact-fp32 and the
+ * split-precision modes take fp32 tensors only).  Workspaces, statistics partials and split-K partial sums stay fp32. */
+#define TEM_MFMA_STX(st) ((st) << 8)
+#define TEM_MFMA_STY(st) ((st) << 12)
+
 /* ---- library ---------------------------------------------------------- */
 const char* tem_last_error(void);
 int tem_version(void);
@@ -200,6 +220,11 @@ int tem_conv1x1_out_bwd_ok(int Cin, int Cout);
 int64_t tem_conv1x1_out_bwd_ws(int Cin, int Cout);
 int tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g_ld, const float* w, float* gx, int64_t gx_ld,
                         float* dw, float* db, void* ws, int64_t ws_bytes, int64_t NV, int Cin, int Cout, tem_stream_t stream);
+/* ... for x / gx of storage type st_x and g of storage type st_g; out_amax (optional): device word that receives max |gx|
+ * as an integer atomicMax of the bit patterns */
+int tem_conv1x1_out_bwd_st(const void* x, int64_t x_ld, const void* g, int64_t g_ld, const float* w, void* gx, int64_t gx_ld,
+                           float* dw, float* db, void* ws, int64_t ws_bytes, int64_t NV, int Cin, int Cout,
+                           unsigned* out_amax, int st_x, int st_g, tem_stream_t stream);
 
 /* tem_conv3d_wgrad (w == NULL, norm_sums == NULL) or tem_conv3d_wgrad_sums that ALSO reports the largest |g|: g_amax
  * (device, one 32-bit word the caller cleared) receives the bit pattern of max |g| by an integer atomicMax -- exact and
@@ -288,6 +313,11 @@ int tem_conv3d_wgrad_gnorm(const float* x, int64_t x_ld, const float* scale, con
                            float* dw, float* db, void* ws, int64_t ws_bytes,
                            int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                            int sd_layout, tem_stream_t stream);
+/* ... for x of storage type st_x and g / y of storage type st_g (TEM_ST_*) */
+int tem_conv3d_wgrad_gnorm_st(const void* x, int64_t x_ld, const float* scale, const float* shift, const void* g, int64_t g_ld,
+                              const void* y, int64_t y_ld, const float* gcoef, float* dw, float* db, void* ws, int64_t ws_bytes,
+                              int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int sd_layout, int st_x,
+                              int st_g, tem_stream_t stream);
 
 /* tem_conv3d_wgrad that ALSO delivers the first stage of the backward of the norm in front of this conv -- per (sample,
  * input channel) sums[n][ci] = (sum_v gz, sum_v gz * xn), gz = the data gradient of this conv (tem_conv3d_fwd with the
@@ -357,6 +387,21 @@ int tem_norm_bwd_coef(const float* gy, int64_t gy_ld, const float* x, int64_t x_
                       int N, int64_t V, int C, int G, const float* gamma,
                       const float* mean, const float* rstd, float* dgamma, float* dbeta,
                       const float* sums, float* coef, void* ws, int64_t ws_bytes, tem_stream_t stream);
+/* tem_norm_stats for a tensor of storage type st (TEM_ST_*) */
+int tem_norm_stats_st(const void* x, int64_t x_ld, int N, int64_t V, int C, int G, const float* gamma, const float* beta,
+                      float eps, float* mean, float* rstd, float* scale, float* shift, void* ws, int64_t ws_bytes, int st,
+                      tem_stream_t stream);
+/* tem_norm_bwd / _from_sums / _from_partials / _coef in one entry point, for tensors of storage type st:
+ *   part, part_nblk : first stage rows [N][part_nblk][C][2] (sum gy, sum gy * xn) delivered by a producer -- the weight
+ *                     gradient (tem_conv3d_wgrad_ex, 1 row) or the data gradient (tem_conv3d_fwd_ex, its nblk rows);
+ *                     NULL = the reduction pass over gy and x runs here
+ *   coef_out        : non-NULL = reduction stage only, writes coef[N][C][4] = {a, m1, m2r, mean} (gx may be NULL)
+ *   out_amax        : optional device word that receives max |gx| (see tem_maxpool3d_bwd_st) */
+int tem_norm_bwd_st(const void* gy, int64_t gy_ld, const void* x, int64_t x_ld, int N, int64_t V, int C, int G,
+                    const float* gamma, const float* mean, const float* rstd, int relu_mask, void* gx, int64_t gx_ld,
+                    float* dgamma, float* dbeta, const float* part, int64_t part_nblk, float* coef_out,
+                    unsigned* out_amax, void* ws, int64_t ws_bytes, int st, tem_stream_t stream);
+
 
 /* ---- pooling / upsampling ------------------------------------------------
  * nn.MaxPool3d(factor) (model/unet.py:300-302,645): kernel == stride == factor.
@@ -409,6 +454,29 @@ int tem_upsample_fwd_stats(const float* x, int64_t x_ld, float* y, int64_t y_ld,
 int tem_upsample_bwd_norm(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld,
                           int N, int D, int H, int W, int C, int fz, int fy, int fx,
                           const float* u, int64_t u_ld, const float* ncoef, int64_t ncoef_ld, tem_stream_t stream);
+
+/* The same operations for tensors of storage type st (TEM_ST_*): one entry point per operation, the optional by-products as
+ * explicit arguments (NULL = not wanted).
+ *   tem_maxpool3d_fwd_st   = tem_maxpool3d_fwd / _fwd_stats (stat_part != NULL)
+ *   tem_maxpool3d_bwd_st   = tem_maxpool3d_bwd / _bwd_norm (gcoef / ycoef != NULL); out_amax (optional): device word that
+ *                            receives max |gx| as an integer atomicMax of the bit patterns (exact, order-independent) -- the
+ *                            weight gradient that reads gx next takes its fp16 prescale from it (tem_conv3d_wgrad_ex)
+ *   tem_upsample_fwd_st    = tem_upsample_fwd / _fwd_stats (part != NULL)
+ *   tem_upsample_bwd_st    = tem_upsample_bwd / _bwd_norm (u, ncoef != NULL)
+ *   tem_upsample_stats_st  = tem_upsample_stats */
+int tem_maxpool3d_fwd_st(const void* x, int64_t x_ld, void* y, int64_t y_ld, int N, int D, int H, int W, int C,
+                         int fz, int fy, int fx, float* stat_part, int64_t stat_blocks, int st, tem_stream_t stream);
+int tem_maxpool3d_bwd_st(const void* gy, int64_t gy_ld, const void* x, int64_t x_ld, const void* gskip, int64_t gskip_ld,
+                         int relu_mask, void* gx, int64_t gx_ld, int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                         const float* gcoef, int64_t gcoef_ld, const float* ycoef, unsigned* out_amax, int st,
+                         tem_stream_t stream);
+int tem_upsample_fwd_st(const void* x, int64_t x_ld, void* y, int64_t y_ld, int N, int D, int H, int W, int C,
+                        int fz, int fy, int fx, float* part, int st, tem_stream_t stream);
+int tem_upsample_bwd_st(const void* gy, int64_t gy_ld, void* gx, int64_t gx_ld, int N, int D, int H, int W, int C,
+                        int fz, int fy, int fx, const void* u, int64_t u_ld, const float* ncoef, int64_t ncoef_ld, int st,
+                        tem_stream_t stream);
+int tem_upsample_stats_st(const void* u, int64_t u_ld, int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                          float* part, int st, tem_stream_t stream);
 
 /* ---- Dice ------------------------------------------------------------------
  * dice_score / DiceLoss (loss/dice.py:34-133) and the masked variant

@@ -146,6 +146,21 @@ SIGNATURES = {
                               + [ctypes.POINTER(c_int)] * 3 + [c_vp]),
     "tem_accumulate_channels": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_i64] + [c_int] * 5 + [c_vp]),
     "tem_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
+    # round 5: activation storage types (TEM_ST_*) as explicit arguments
+    "tem_maxpool3d_fwd_st": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp, c_i64, c_int, c_vp]),
+    "tem_maxpool3d_bwd_st": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64] + [c_int] * 8
+                             + [c_vp, c_i64, c_vp, c_vp, c_int, c_vp]),
+    "tem_upsample_fwd_st": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp, c_int, c_vp]),
+    "tem_upsample_bwd_st": (c_int, [c_vp, c_i64, c_vp, c_i64] + [c_int] * 8 + [c_vp, c_i64, c_vp, c_i64, c_int, c_vp]),
+    "tem_upsample_stats_st": (c_int, [c_vp, c_i64] + [c_int] * 8 + [c_vp, c_int, c_vp]),
+    "tem_norm_stats_st": (c_int, [c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_float,
+                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
+    "tem_norm_bwd_st": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64,
+                                c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
+    "tem_conv3d_wgrad_gnorm_st": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64]
+                                  + [c_int] * 12 + [c_vp]),
+    "tem_conv1x1_out_bwd_st": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int,
+                                       c_vp, c_int, c_int, c_vp]),
 }
 
 _lib = None
@@ -181,7 +196,11 @@ def load():
     import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so both share one HIP runtime)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if os.environ.get("TEM_LIB"):   # an older A/B build of the C-ABI (developer override): the symbol stays unavailable
+                continue
+            raise RuntimeError(f"{LIB_PATH} does not export {name}: rebuild it (make -C torch_em_amd/csrc)")
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib

@@ -1,10 +1,14 @@
 // capi.hip -- library-level entry points of libtem_hip.so and the layout utilities.
 #include "tem_common.h"
 #include "conv_internal.h"
+#include "tem_act.h"
 #include <stdarg.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
+
+// storage types of the call in flight on this thread (tem_act.h): set and restored by the entry point itself
+thread_local TemCallSt tem_call_st = {0, 0};
 
 void tem_set_error(const char* fmt, ...) {
     va_list ap;

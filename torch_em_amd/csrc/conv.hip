@@ -5,6 +5,15 @@
 // (HBM-bound, 0.9 flop/B) and the small test networks.
 #include "tem_common.h"
 #include "conv_internal.h"
+#include "tem_act.h"
+
+// `use_mfma` of the conv entry points carries the storage types of the call in its high bits (tem_hip.h: TEM_MFMA_STX / _STY);
+// every entry point strips them first and keeps them in tem_call_st for the duration of the call
+// (a call that arrives WITHOUT storage bits from inside another entry point inherits that call's types)
+#define TEM_MODE_SCOPE(use_mfma)                                                                        \
+    TemStScope st_scope__(((use_mfma) >> 8) ? (((use_mfma) >> 8) & 15) : tem_call_st.x,                 \
+                          ((use_mfma) >> 8) ? (((use_mfma) >> 12) & 15) : tem_call_st.y);               \
+    use_mfma &= 0xff
 
 // ---------------------------------------------------------------------------
 // weight packing
@@ -105,12 +114,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-template <int KD, int KH, int KW>
-__global__ __launch_bounds__(256) void k_conv_fwd_generic(const float* __restrict__ x, int64_t x_ld,
+template <int KD, int KH, int KW, typename TX, typename TY>
+__global__ __launch_bounds__(256) void k_conv_fwd_generic(const TX* __restrict__ x, int64_t x_ld,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ y,
-                                                          int64_t y_ld, const float* __restrict__ ref, int64_t ref_ld,
+                                                          const float* __restrict__ bias, TY* __restrict__ y,
+                                                          int64_t y_ld, const TY* __restrict__ ref, int64_t ref_ld,
                                                           int N, int D, int H, int W, int Cin, int Cout, int act) {
     constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
     const int64_t NV = (int64_t)N * D * H * W;
@@ -129,15 +138,15 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float* __restric
         float acc = bias ? bias[co] : 0.f;
         if constexpr (KD * KH * KW == 1) {
             const int n1 = scale ? (int)(v / ((int64_t)D * H * W)) : 0;
-            const float* xp = x + v * x_ld;
+            const TX* xp = x + v * x_ld;
             for (int ci = 0; ci < Cin; ++ci) {
-                float xv = xp[ci];
+                float xv = act_ld1(xp + ci);
                 if (scale) xv = fmaf(xv, scale[(int64_t)n1 * Cin + ci], shift[(int64_t)n1 * Cin + ci]);
                 acc = fmaf(xv, w[(int64_t)ci * Cout + co], acc);
             }
             acc = apply_act(acc, act);
-            if (ref && !(ref[v * ref_ld + co] > 0.f)) acc = 0.f;
-            y[v * y_ld + co] = acc;
+            if (ref && !(act_ld1(ref + v * ref_ld + co) > 0.f)) acc = 0.f;
+            act_st1(y + v * y_ld + co, acc);
             continue;
         }
         int xx = (int)(v % W);
@@ -161,10 +170,10 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float* __restric
                     int x2 = xx + tx - PX;
                     if (x2 < 0 || x2 >= W) continue;
                     const int tap = (tz * KH + ty) * KW + tx;
-                    const float* xp = x + ((((int64_t)n * D + z2) * H + y2) * W + x2) * x_ld;
+                    const TX* xp = x + ((((int64_t)n * D + z2) * H + y2) * W + x2) * x_ld;
                     const float* wp = w + (int64_t)tap * Cin * Cout + co;
                     for (int ci = 0; ci < Cin; ++ci) {
-                        float xv = xp[ci];
+                        float xv = act_ld1(xp + ci);
                         if (sc) xv = fmaf(xv, sc[ci], sf[ci]);
                         acc = fmaf(xv, wp[(int64_t)ci * Cout], acc);
                     }
@@ -172,29 +181,29 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float* __restric
             }
         }
         acc = apply_act(acc, act);
-        if (ref && !(ref[v * ref_ld + co] > 0.f)) acc = 0.f;
-        y[v * y_ld + co] = acc;
+        if (ref && !(act_ld1(ref + v * ref_ld + co) > 0.f)) acc = 0.f;
+        act_st1(y + v * y_ld + co, acc);
     }
 }
 
 // 1x1x1 projection to a few channels (out_conv 32->2/12): thread <-> voxel, reads its
 // whole channel row with 16-byte loads, keeps Cout accumulators; weights via L1.
-template <int COUT>
-__global__ __launch_bounds__(256) void k_conv1x1_smallcout(const float* __restrict__ x, int64_t x_ld,
+template <int COUT, typename TX, typename TY>
+__global__ __launch_bounds__(256) void k_conv1x1_smallcout(const TX* __restrict__ x, int64_t x_ld,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ w /*[ci][co]*/,
-                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                           int64_t y_ld, const float* __restrict__ ref, int64_t ref_ld,
+                                                           const float* __restrict__ bias, TY* __restrict__ y,
+                                                           int64_t y_ld, const TY* __restrict__ ref, int64_t ref_ld,
                                                            int64_t V, int64_t NV, int Cin, int act) {
     for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < NV; v += (int64_t)gridDim.x * 256) {
         const int n = (int)(v / V);
         float acc[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
-        const float* xp = x + v * x_ld;
+        const TX* xp = x + v * x_ld;
         for (int ci = 0; ci < Cin; ci += 4) {
-            float4 t = *reinterpret_cast<const float4*>(xp + ci);
+            float4 t = act_ld4(xp + ci);
             float xv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -206,8 +215,8 @@ __global__ __launch_bounds__(256) void k_conv1x1_smallcout(const float* __restri
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
             float a = apply_act(acc[co], act);
-            if (ref && !(ref[v * ref_ld + co] > 0.f)) a = 0.f;
-            y[v * y_ld + co] = a;
+            if (ref && !(act_ld1(ref + v * ref_ld + co) > 0.f)) a = 0.f;
+            act_st1(y + v * y_ld + co, a);
         }
     }
 }
@@ -217,8 +226,10 @@ static void launch_fwd_generic(const float* x, int64_t x_ld, const float* scale,
                                const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D,
                                int H, int W, int Cin, int Cout, int act, hipStream_t s) {
     int64_t items = (int64_t)N * D * H * W * Cout;
-    hipLaunchKernelGGL((k_conv_fwd_generic<KD, KH, KW>), dim3(tem_grid_1d(items, 256, 256 * 16)), dim3(256), 0, s, x,
-                       x_ld, scale, shift, w, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act);
+    TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TY, (void)0,
+                   hipLaunchKernelGGL((k_conv_fwd_generic<KD, KH, KW, TX, TY>), dim3(tem_grid_1d(items, 256, 256 * 16)), dim3(256), 0, s,
+                                      (const TX*)x, x_ld, scale, shift, w, bias, (TY*)y, y_ld, (const TY*)ref, ref_ld, N, D, H, W, Cin,
+                                      Cout, act));
 }
 
 #define DISPATCH_K(KD, KH, KW, CALL)                                  \
@@ -238,6 +249,7 @@ static void launch_fwd_generic(const float* x, int64_t x_ld, const float* scale,
 
 extern "C" int64_t tem_conv3d_fwd_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                      int use_mfma) {
+    TEM_MODE_SCOPE(use_mfma);
     if (!use_mfma || Cin % 16 || Cout % 32) return 0;
     int64_t ws = tem_conv_fwd_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
     if (use_mfma >= 2 && use_mfma <= 7) {   // the z-reuse kernel's split-K launch may want more slices than the patch kernel's
@@ -259,6 +271,10 @@ static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, con
     TEM_REQUIRE((scale == nullptr) == (shift == nullptr), "tem_conv3d_fwd: scale and shift must both be given");
     TEM_REQUIRE(act >= 0 && act <= 2, "tem_conv3d_fwd: Invalid activation: %d", act);
     TEM_REQUIRE(!ref || ref_ld >= Cout, "tem_conv3d_fwd: bad ref_ld");
+    const int stx = tem_call_st.x, sty = tem_call_st.y;
+    TEM_REQUIRE(stx >= 0 && stx <= 2 && sty >= 0 && sty <= 2 && (stx == 0 || sty == 0 || stx == sty),
+                "tem_conv3d_fwd: unsupported storage types (x %d, y %d)", stx, sty);
+    TEM_REQUIRE(!(stx || sty) || use_mfma != 1, "tem_conv3d_fwd: the exact-fp32 MFMA kernels take fp32 tensors only");
     hipStream_t s = (hipStream_t)stream;
     if (use_mfma >= 2 && use_mfma <= 7) {
         int rc = tem_conv_fwd_bf16x3(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
@@ -302,8 +318,9 @@ static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, con
         dim3 grid(tem_grid_1d(NV, 256, 256 * 16));
 #define SC(CO)                                                                                                   \
     case CO:                                                                                                     \
-        hipLaunchKernelGGL((k_conv1x1_smallcout<CO>), grid, dim3(256), 0, s, x, x_ld, scale, shift, w_packed, bias, y, \
-                           y_ld, ref, ref_ld, (int64_t)D * H * W, NV, Cin, act);                                 \
+        TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TY, (void)0,                                            \
+                       hipLaunchKernelGGL((k_conv1x1_smallcout<CO, TX, TY>), grid, dim3(256), 0, s, (const TX*)x, x_ld, scale, shift, \
+                                          w_packed, bias, (TY*)y, y_ld, (const TY*)ref, ref_ld, (int64_t)D * H * W, NV, Cin, act)); \
         break;
         switch (Cout) {
             SC(1) SC(2) SC(3) SC(4) SC(8) SC(12) SC(16)
@@ -324,6 +341,7 @@ extern "C" int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, 
                               const float* w_packed, const float* bias, float* y, int64_t y_ld, const float* ref,
                               int64_t ref_ld, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout,
                               int kd, int kh, int kw, int act, int use_mfma, tem_stream_t stream) {
+    TEM_MODE_SCOPE(use_mfma);
     return conv3d_fwd_impl(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin,
                            Cout, kd, kh, kw, act, use_mfma, nullptr, stream);
 }
@@ -332,6 +350,7 @@ static inline bool ref_free_cin1_ok(int Cout) { return Cout % 4 == 0; }
 
 extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                               int use_mfma) {
+    TEM_MODE_SCOPE(use_mfma);
     if (use_mfma == 0)  // VALU kernels: only the small-Cin first-layer kernel (conv_small.hip) provides them
         return (ref_free_cin1_ok(Cout)) ? tem_conv_fwd_cin1_stat_blocks(D, H, W, Cin, Cout, kd, kh, kw) : 0;
     if (use_mfma < 2 || use_mfma > 7) return 0;
@@ -339,6 +358,7 @@ extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Ci
 }
 
 extern "C" int tem_conv3d_fwd_kernel(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma) {
+    TEM_MODE_SCOPE(use_mfma);
     if (use_mfma >= 2 && use_mfma <= 7 && Cin % 16 == 0 && Cout % 32 == 0) {
         if (tem_conv_zr_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) >= 0) return 3;
         if (tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma)) return 4;   // z-reuse kernel, split input channels
@@ -352,6 +372,7 @@ extern "C" int tem_conv3d_fwd_stats(const float* x, int64_t x_ld, const float* s
                                     int64_t ref_ld, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin,
                                     int Cout, int kd, int kh, int kw, int act, int use_mfma, float* stat_part,
                                     int64_t stat_blocks, tem_stream_t stream) {
+    TEM_MODE_SCOPE(use_mfma);
     TEM_REQUIRE(stat_part, "tem_conv3d_fwd_stats: null statistics buffer");
     TEM_REQUIRE(stat_blocks > 0 && stat_blocks == tem_conv3d_fwd_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma),
                 "tem_conv3d_fwd_stats: stat_blocks must be tem_conv3d_fwd_stat_blocks() of this launch (and > 0)");
@@ -364,11 +385,11 @@ extern "C" int tem_conv3d_fwd_stats(const float* x, int64_t x_ld, const float* s
 // all taps accumulate in registers so g is read once.  Two-stage deterministic:
 // partial[chunk][tap][ci][co] -> fp64 merge.
 // ---------------------------------------------------------------------------
-template <int KD, int KH, int KW>
-__global__ __launch_bounds__(256) void k_conv_wgrad_generic(const float* __restrict__ x, int64_t x_ld,
+template <int KD, int KH, int KW, typename TX, typename TG>
+__global__ __launch_bounds__(256) void k_conv_wgrad_generic(const TX* __restrict__ x, int64_t x_ld,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
-                                                            const float* __restrict__ g, int64_t g_ld, int N, int D,
+                                                            const TG* __restrict__ g, int64_t g_ld, int N, int D,
                                                             int H, int W, int Cin, int Cout, int npairs_blk, int rows,
                                                             int64_t vper, float* __restrict__ part) {
     constexpr int NT = KD * KH * KW;
@@ -393,7 +414,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_generic(const float* __restr
             q /= H;
             int zz = (int)(q % D);
             int n = (int)(q / D);
-            const float gv = g[v * g_ld + co];
+            const float gv = act_ld1(g + v * g_ld + co);
             float sc = 1.f, sf = 0.f;
             if (scale) {
                 sc = scale[(int64_t)n * Cin + ci];
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_generic(const float* __restr
                     for (int tx = 0; tx < KW; ++tx) {
                         int x2 = xx + tx - PX;
                         if (z2 < 0 || z2 >= D || y2 < 0 || y2 >= H || x2 < 0 || x2 >= W) continue;
-                        float xv = x[((((int64_t)n * D + z2) * H + y2) * W + x2) * x_ld + ci];
+                        float xv = act_ld1(x + ((((int64_t)n * D + z2) * H + y2) * W + x2) * x_ld + ci);
                         xv = fmaf(xv, sc, sf);
                         acc[(tz * KH + ty) * KW + tx] = fmaf(xv, gv, acc[(tz * KH + ty) * KW + tx]);
                     }
@@ -434,7 +455,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_generic(const float* __restr
 }
 
 // column sums: db[co] = sum_v g[v][co]
-__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ g, int64_t g_ld, int64_t NV, int C,
+template <typename TG>
+__global__ __launch_bounds__(256) void k_colsum_partial(const TG* __restrict__ g, int64_t g_ld, int64_t NV, int C,
                                                         int rows, int64_t vper, float* __restrict__ part) {
     extern __shared__ float sh[];  // [rows][Cb]
     const int Cb = C < 256 ? C : 256;
@@ -445,7 +467,7 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
         int c = c0 + cl;
         float s = 0.f;
         if (c < C && r < rows)
-            for (int64_t v = v0 + r; v < v1; v += rows) s += g[v * g_ld + c];
+            for (int64_t v = v0 + r; v < v1; v += rows) s += act_ld1(g + v * g_ld + c);
         if (r < rows) sh[r * Cb + cl] = s;
         __syncthreads();
         if (r == 0 && c < C) {
@@ -491,6 +513,7 @@ static WgradGenericPlan wgrad_generic_plan(int64_t NV, int Cin, int Cout, int nt
 
 extern "C" int64_t tem_conv3d_wgrad_ws(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                        int use_mfma) {
+    TEM_MODE_SCOPE(use_mfma);
     int64_t NV = (int64_t)N * D * H * W;
     int ntaps = kd * kh * kw;
     WgradGenericPlan p = wgrad_generic_plan(NV, Cin, Cout, ntaps);
@@ -520,8 +543,9 @@ static void launch_wgrad_generic(const float* x, int64_t x_ld, const float* scal
                                  const WgradGenericPlan& p, float* part, hipStream_t s) {
     constexpr int NT = KD * KH * KW;
     size_t lds = (size_t)NT * p.rows * p.npairs_blk * sizeof(float);
-    hipLaunchKernelGGL((k_conv_wgrad_generic<KD, KH, KW>), dim3(p.nchunks, p.npb), dim3(256), lds, s, x, x_ld, scale,
-                       shift, g, g_ld, N, D, H, W, Cin, Cout, p.npairs_blk, p.rows, p.vper, part);
+    TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TG, (void)0,
+                   hipLaunchKernelGGL((k_conv_wgrad_generic<KD, KH, KW, TX, TG>), dim3(p.nchunks, p.npb), dim3(256), lds, s, (const TX*)x,
+                                      x_ld, scale, shift, (const TG*)g, g_ld, N, D, H, W, Cin, Cout, p.npairs_blk, p.rows, p.vper, part));
 }
 
 static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
@@ -535,6 +559,11 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
     TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
                 "tem_conv3d_wgrad: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
     TEM_REQUIRE((scale == nullptr) == (shift == nullptr), "tem_conv3d_wgrad: scale and shift must both be given");
+    const int stx = tem_call_st.x, sty = tem_call_st.y;
+    TEM_REQUIRE(stx >= 0 && stx <= 2 && sty >= 0 && sty <= 2 && (stx == 0 || sty == 0 || stx == sty),
+                "tem_conv3d_wgrad: unsupported storage types (x %d, g %d)", stx, sty);
+    TEM_REQUIRE(!(stx || sty) || !(use_mfma == 1 || use_mfma == 3 || use_mfma == 4 || use_mfma == 6),
+                "tem_conv3d_wgrad: the exact-fp32 MFMA kernels take fp32 tensors only");
     if (ws_bytes < tem_conv3d_wgrad_ws(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma)) {
         tem_set_error("tem_conv3d_wgrad: workspace too small");
         return TEM_EWS;
@@ -558,7 +587,7 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
         return TEM_OK;
     }
     TEM_REQUIRE(!norm_sums, "tem_conv3d_wgrad_sums: only the split-bf16 z-sliding kernel delivers the norm sums");
-    if (use_mfma && tem_conv_wgrad_tr_fp32_ok(N, D, H, W, Cin, Cout, kd, kh, kw) && x_ld % 4 == 0 && g_ld % 4 == 0 &&
+    if (use_mfma && !(stx || sty) && tem_conv_wgrad_tr_fp32_ok(N, D, H, W, Cin, Cout, kd, kh, kw) && x_ld % 4 == 0 && g_ld % 4 == 0 &&
         ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0)) {
         // exact fp32 on the z-sliding staging-team kernel (round 4): fp32 records in LDS, v_mfma_f32_32x32x2_f32
         int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
@@ -590,8 +619,9 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
         int Cb = Cout < 256 ? Cout : 256;
         int rows = 256 / Cb;
         int64_t vper = tem_cdiv(NV, p.db_chunks);
-        hipLaunchKernelGGL(k_colsum_partial, dim3(p.db_chunks), dim3(256), (size_t)rows * Cb * sizeof(float), s, g, g_ld,
-                           NV, Cout, rows, vper, dbpart);
+        TEM_ST_SWITCH(tem_call_st.y, TG,
+                      hipLaunchKernelGGL(k_colsum_partial<TG>, dim3(p.db_chunks), dim3(256), (size_t)rows * Cb * sizeof(float), s,
+                                         (const TG*)g, g_ld, NV, Cout, rows, vper, dbpart));
         tem_reduce_slabs(dbpart, p.db_chunks, (int64_t)Cout, (int64_t)Cout, db, s);
     }
 #define CALL(A, B, C) launch_wgrad_generic<A, B, C>(x, x_ld, scale, shift, g, g_ld, N, D, H, W, Cin, Cout, p, rest, s)
@@ -607,6 +637,7 @@ extern "C" int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale
                                 int64_t g_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int N, int D, int H,
                                 int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma, int sd_layout,
                                 tem_stream_t stream) {
+    TEM_MODE_SCOPE(use_mfma);
     return conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw,
                              use_mfma, sd_layout, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
@@ -633,8 +664,23 @@ extern "C" int tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g,
 }
 extern "C" int64_t tem_conv1x1_out_bwd_ws(int Cin, int Cout) { return tem_conv1x1_proj_wgrad_ws(Cin, Cout); }
 
+// tem_conv1x1_out_bwd for x / gx of storage type st_x and g of storage type st_g (g is the gradient of the network output:
+// normally fp32); out_amax (optional): device word that receives max |gx| (see tem_maxpool3d_bwd_st)
+extern "C" int tem_conv1x1_out_bwd_st(const void* x, int64_t x_ld, const void* g, int64_t g_ld, const float* w, void* gx,
+                                      int64_t gx_ld, float* dw, float* db, void* ws, int64_t ws_bytes, int64_t NV, int Cin,
+                                      int Cout, unsigned* out_amax, int st_x, int st_g, tem_stream_t stream) {
+    TEM_REQUIRE(st_x >= 0 && st_x <= 2 && st_g >= 0 && st_g <= 2, "tem_conv1x1_out_bwd_st: unknown storage type");
+    TemStScope sc(st_x, st_g);
+    if (out_amax) tem_arm_output_amax(out_amax);
+    const int rc = tem_conv1x1_out_bwd((const float*)x, x_ld, (const float*)g, g_ld, w, (float*)gx, gx_ld, dw, db, ws, ws_bytes, NV,
+                                       Cin, Cout, stream);
+    if (out_amax) tem_disarm_output_amax();
+    return rc;
+}
+
 extern "C" int tem_conv3d_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                         int use_mfma) {
+    TEM_MODE_SCOPE(use_mfma);
     return use_mfma == 2 && tem_conv_wgrad_gmax_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
 }
 
@@ -643,6 +689,7 @@ extern "C" int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* 
                                      const float* beta, float* dw, float* db, float* norm_sums, unsigned* g_amax,
                                      void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd,
                                      int kh, int kw, int use_mfma, tem_stream_t stream) {
+    TEM_MODE_SCOPE(use_mfma);
     TEM_REQUIRE(g_amax, "tem_conv3d_wgrad_gmax: null g_amax");
     TEM_REQUIRE(tem_conv3d_wgrad_gmax_ok(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma),
                 "tem_conv3d_wgrad_gmax: tem_conv3d_wgrad_gmax_ok() == 0 for this layer");
@@ -739,6 +786,7 @@ extern "C" int tem_conv3d_fwd_refnorm(const float* x, int64_t x_ld, const float*
                                       const float* ref, int64_t ref_ld, const float* coef, void* ws, int64_t ws_bytes,
                                       int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma,
                                       tem_stream_t stream) {
+    TEM_MODE_SCOPE(use_mfma);
     TEM_REQUIRE(ref && coef, "tem_conv3d_fwd_refnorm: null ref / coef");
     TEM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0 && tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) == 3,
                 "tem_conv3d_fwd_refnorm: only launches that tem_conv3d_fwd_kernel() reports as 3 (z-reuse kernel) apply a "
@@ -757,6 +805,7 @@ extern "C" int tem_conv3d_fwd_refnorm(const float* x, int64_t x_ld, const float*
 
 extern "C" int tem_conv3d_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                         int use_mfma) {
+    TEM_MODE_SCOPE(use_mfma);
     if (use_mfma != 2 && use_mfma != 5 && use_mfma != 7 && use_mfma != 8) return 0;
     return tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
 }
@@ -766,6 +815,7 @@ extern "C" int tem_conv3d_wgrad_sums(const float* x, int64_t x_ld, const float* 
                                      const float* beta, float* dw, float* db, float* norm_sums, void* ws,
                                      int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh,
                                      int kw, int use_mfma, tem_stream_t stream) {
+    TEM_MODE_SCOPE(use_mfma);
     TEM_REQUIRE(w && norm_sums && db, "tem_conv3d_wgrad_sums: null pointer (weights, sums and bias gradient are required)");
     TEM_REQUIRE(tem_conv3d_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma),
                 "tem_conv3d_wgrad_sums: tem_conv3d_wgrad_sums_ok() == 0 for this layer");
@@ -777,6 +827,7 @@ extern "C" int tem_conv3d_wgrad_sums(const float* x, int64_t x_ld, const float* 
 // behind the norm that follows this conv's ReLU: the norm backward (coefficients from tem_norm_bwd_coef) and the ReLU
 // mask are applied while g is loaded -- y (this conv's output, the norm's input) is read instead of a rewritten g.
 extern "C" int tem_conv3d_wgrad_gnorm_ok(int Cin, int Cout, int kd, int kh, int kw, int use_mfma) {
+    TEM_MODE_SCOPE(use_mfma);
     const int cq = Cout / 4, key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
     return use_mfma == 0 && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && cq <= 16 && (cq & (cq - 1)) == 0 && (key == 7 || key == 3);
 }
@@ -789,4 +840,15 @@ extern "C" int tem_conv3d_wgrad_gnorm(const float* x, int64_t x_ld, const float*
     TEM_REQUIRE(tem_conv3d_wgrad_gnorm_ok(Cin, Cout, kd, kh, kw, 0), "tem_conv3d_wgrad_gnorm: tem_conv3d_wgrad_gnorm_ok() == 0");
     return conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw, 0,
                              sd_layout, nullptr, nullptr, nullptr, nullptr, y, y_ld, gcoef, stream);
+}
+
+// tem_conv3d_wgrad_gnorm for x of storage type st_x and g / y of storage type st_g (TEM_ST_*)
+extern "C" int tem_conv3d_wgrad_gnorm_st(const void* x, int64_t x_ld, const float* scale, const float* shift, const void* g,
+                                         int64_t g_ld, const void* y, int64_t y_ld, const float* gcoef, float* dw, float* db,
+                                         void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh,
+                                         int kw, int sd_layout, int st_x, int st_g, tem_stream_t stream) {
+    TEM_REQUIRE(st_x >= 0 && st_x <= 2 && st_g >= 0 && st_g <= 2, "tem_conv3d_wgrad_gnorm_st: unknown storage type");
+    TemStScope sc(st_x, st_g);
+    return tem_conv3d_wgrad_gnorm((const float*)x, x_ld, scale, shift, (const float*)g, g_ld, (const float*)y, y_ld, gcoef, dw, db,
+                                  ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw, sd_layout, stream);
 }

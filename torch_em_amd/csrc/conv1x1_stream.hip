@@ -7,14 +7,17 @@
 // (L1-resident: 12 ... 786 KB per layer).  No LDS, ~100 registers: 8+ waves per SIMD hide the load latency.
 // HBM-bound: algorithmic bytes = 4 (Cin + Cout) per voxel (+ 4 Cout with a ReLU mask).
 #include "tem_common.h"
+#include "tem_act.h"
 #include "conv_split.h"
 #include "conv_internal.h"
 
-template <int NS, bool F16, int CT>
-__global__ __launch_bounds__(256) void k_conv1x1_stream(const float* __restrict__ x, int64_t x_ld,
+// T: element type of x, y and ref.  A 16-bit T is also the operand type of the one-term modes (fp16 storage <-> fp16 operands,
+// bf16 <-> bf16; the launcher checks): a lane's 8 channels of a k-step are ONE 16-byte load and go to the MFMA as loaded.
+template <int NS, bool F16, int CT, typename T>
+__global__ __launch_bounds__(256) void k_conv1x1_stream(const T* __restrict__ x, int64_t x_ld,
                                                         const unsigned short* __restrict__ wp,
-                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                        int64_t y_ld, const float* __restrict__ ref, int64_t ref_ld,
+                                                        const float* __restrict__ bias, T* __restrict__ y,
+                                                        int64_t y_ld, const T* __restrict__ ref, int64_t ref_ld,
                                                         int64_t NV, int Cin, int Cout, int act, int64_t nmt,
                                                         unsigned* __restrict__ amax) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -26,21 +29,25 @@ __global__ __launch_bounds__(256) void k_conv1x1_stream(const float* __restrict_
     for (int64_t mt = (int64_t)blockIdx.x * 4 + wv; mt < nmt; mt += (int64_t)gridDim.x * 4) {
         const int64_t v = mt * 32 + r;
         const bool vok = v < NV;
-        const float* xr = x + (vok ? v : 0) * x_ld + kh * 8;
+        const T* xr = x + (vok ? v : 0) * x_ld + kh * 8;
         floatx16 acc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[ct][k] = 0.f;
         for (int ks = 0; ks < nks; ++ks) {
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-            if (vok) {
-                a0 = *reinterpret_cast<const float4*>(xr + ks * 16);
-                a1 = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
-            }
             // operand terms of the 8 channels: NS bf16 terms (or one fp16 term)
             uint4 t[NS];
-            {
+            if constexpr (sizeof(T) == 2) {
+                static_assert(sizeof(T) == 4 || NS == 1, "16-bit storage: one-term modes only");
+                t[0] = make_uint4(0u, 0u, 0u, 0u);
+                if (vok) t[0] = *reinterpret_cast<const uint4*>(xr + ks * 16);
+            } else {
+                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+                if (vok) {
+                    a0 = act_ld4(xr + ks * 16);
+                    a1 = act_ld4(xr + ks * 16 + 4);
+                }
                 float rem[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
@@ -95,13 +102,13 @@ __global__ __launch_bounds__(256) void k_conv1x1_stream(const float* __restrict_
                         o.z = act_apply_b(o.z, act);
                         o.w = act_apply_b(o.w, act);
                         if (ref) {
-                            const float4 rv = *reinterpret_cast<const float4*>(ref + v * ref_ld + co);
+                            const float4 rv = act_ld4(ref + v * ref_ld + co);
                             o.x = rv.x > 0.f ? o.x : 0.f;
                             o.y = rv.y > 0.f ? o.y : 0.f;
                             o.z = rv.z > 0.f ? o.z : 0.f;
                             o.w = rv.w > 0.f ? o.w : 0.f;
                         }
-                        *reinterpret_cast<float4*>(y + v * y_ld + co) = o;
+                        act_st4(y + v * y_ld + co, o);
                         amx = tem_amax4(amx, o.x, o.y, o.z, o.w);
                     }
                 }
@@ -111,9 +118,9 @@ __global__ __launch_bounds__(256) void k_conv1x1_stream(const float* __restrict_
     if (amax) tem_amax_commit(amax, amx);
 }
 
-template <int NS, bool F16>
-static void stream_launch(const float* x, int64_t x_ld, const float* wp, const float* bias, float* y, int64_t y_ld,
-                          const float* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act, hipStream_t s) {
+template <int NS, bool F16, typename T>
+static void stream_launch(const T* x, int64_t x_ld, const float* wp, const float* bias, T* y, int64_t y_ld,
+                          const T* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act, hipStream_t s) {
     const int64_t nmt = (NV + 31) / 32;
     const int ntile = Cout / 32;
     const int CT = ntile >= 2 ? 2 : 1;
@@ -123,32 +130,41 @@ static void stream_launch(const float* x, int64_t x_ld, const float* wp, const f
     const dim3 grid((unsigned)gx, (unsigned)ngroups);
     unsigned* const amax = tem_take_output_amax();
     if (CT == 2)
-        hipLaunchKernelGGL((k_conv1x1_stream<NS, F16, 2>), grid, dim3(256), 0, s, x, x_ld, (const unsigned short*)wp, bias, y, y_ld,
+        hipLaunchKernelGGL((k_conv1x1_stream<NS, F16, 2, T>), grid, dim3(256), 0, s, x, x_ld, (const unsigned short*)wp, bias, y, y_ld,
                            ref, ref_ld, NV, Cin, Cout, act, nmt, amax);
     else
-        hipLaunchKernelGGL((k_conv1x1_stream<NS, F16, 1>), grid, dim3(256), 0, s, x, x_ld, (const unsigned short*)wp, bias, y, y_ld,
+        hipLaunchKernelGGL((k_conv1x1_stream<NS, F16, 1, T>), grid, dim3(256), 0, s, x, x_ld, (const unsigned short*)wp, bias, y, y_ld,
                            ref, ref_ld, NV, Cin, Cout, act, nmt, amax);
 }
 
 // nsplit as in tem_conv_fwd_bf16x3: 2 = bf16x3, 3 = bf16x6, 5 = one fp16 term, 7 = one bf16 term.  false: not taken (pre-norm, statistics, the
-// scaled fp16x3 layouts, sigmoid -- the patch kernel handles those)
+// scaled fp16x3 layouts, sigmoid -- the patch kernel handles those).  Storage types (tem_call_st): fp32, or the 16-bit type
+// that IS the operand type of the mode (fp16 with nsplit 5, bf16 with nsplit 7).
 bool tem_conv1x1_stream(const float* x, int64_t x_ld, const float* scale, const float* wp, const float* bias, float* y,
                         int64_t y_ld, const float* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act, int nsplit,
                         const float* stat, hipStream_t s) {
+    const int st = tem_call_st.x;
+    if (tem_call_st.y != st) return false;
+    if (st && !((st == 1 && nsplit == 5) || (st == 2 && nsplit == 7))) return false;
+    const uintptr_t a8 = st ? 15 : 15, a4 = tem_st_align4(st) - 1;   // x: 16-byte loads either way; y / ref: vectors of 4 elements
     if (scale || stat || act == TEM_ACT_SIGMOID) return false;
     if (NV < 16384) return false;   // too few 32-voxel tiles to hide the k-loop's load latency: the split-K patch kernel wins
-    if (Cin % 16 || Cout % 32 || (x_ld & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return false;
-    if ((y_ld & 3) || (reinterpret_cast<uintptr_t>(y) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) ||
-        (ref && ((ref_ld & 3) || (reinterpret_cast<uintptr_t>(ref) & 15))))
+    if (Cin % 16 || Cout % 32 || (x_ld & (st ? 7 : 3)) || (reinterpret_cast<uintptr_t>(x) & a8)) return false;
+    if ((y_ld & 3) || (reinterpret_cast<uintptr_t>(y) & a4) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) ||
+        (ref && ((ref_ld & 3) || (reinterpret_cast<uintptr_t>(ref) & a4))))
         return false;
-    if (nsplit == 2)
-        stream_launch<2, false>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
+    if (st == 1)
+        stream_launch<1, true, tem_f16>((const tem_f16*)x, x_ld, wp, bias, (tem_f16*)y, y_ld, (const tem_f16*)ref, ref_ld, NV, Cin, Cout, act, s);
+    else if (st == 2)
+        stream_launch<1, false, tem_bf16>((const tem_bf16*)x, x_ld, wp, bias, (tem_bf16*)y, y_ld, (const tem_bf16*)ref, ref_ld, NV, Cin, Cout, act, s);
+    else if (nsplit == 2)
+        stream_launch<2, false, float>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
     else if (nsplit == 3)
-        stream_launch<3, false>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
+        stream_launch<3, false, float>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
     else if (nsplit == 5)
-        stream_launch<1, true>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
+        stream_launch<1, true, float>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
     else if (nsplit == 7)
-        stream_launch<1, false>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
+        stream_launch<1, false, float>(x, x_ld, wp, bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, s);
     else
         return false;
     return true;

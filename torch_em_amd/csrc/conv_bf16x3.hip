@@ -56,6 +56,7 @@ __device__ __forceinline__ float4 ld4_nt(const float* p) {
 #endif
 
 #include "conv_split.h"
+#include "tem_act.h"
 
 // ---------------------------------------------------------------------------
 // weight packing: [Cout][Cin][kd][kh][kw] fp32 -> [co/32][tap][ci/16][NS planes][64 lanes][8 bf16]
@@ -301,11 +302,11 @@ extern "C" int tem_conv_pack_weights_batch(const void* descs_dev, int n, int64_t
 // (6 MFMAs) -- per-product error ~2^-23, i.e. the fp32 class, at 16/6 of the exact-fp32 MFMA rate;
 // used for the forward pass, whose rounding noise the gradient amplifies (engine.py, PRECISION).
 // ---------------------------------------------------------------------------
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false, bool PS = false>
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false, bool PS = false, typename T = float>
 __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM_SC_WPC : (NR == 2 || NS == 3) ? 2 : 3) void k_conv_fwd_bfsplit(
-    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
-    const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
-    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
+    const T* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint4* __restrict__ wp, const float* __restrict__ bias, T* __restrict__ y, int64_t y_ld,
+    const T* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
     int nY, int nX, int ksplit, float* __restrict__ part, float* __restrict__ stat) {
     constexpr int NT = KD * KH * KW;
     constexpr int PZ = KD / 2, PY = KH / 2, PX = KW / 2;
@@ -403,8 +404,7 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
             const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
             inb[it] = (gz >= 0) & (gz < D) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (((tid + it * 256) >> 2) < HV);
             const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            tmp[it] = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + cz) * H + cy) * W + cx) * x_ld +
-                                                       chunk * BCK + c4 * 4);
+            tmp[it] = act_ld4(x + ((((int64_t)n * D + cz) * H + cy) * W + cx) * x_ld + chunk * BCK + c4 * 4);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -550,13 +550,17 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
                         continue;
                     }
                     float o = act_apply_b(acc[m][nn][reg] + bv, act);
-                    if (ref && !(ref[v * ref_ld + co] > 0.f)) o = 0.f;
-                    ssum[nn] += o;
-                    ssq[nn] = fmaf(o, o, ssq[nn]);
-                    if (TEM_NT_STORE)
+                    if (ref && !(act_ld1(ref + v * ref_ld + co) > 0.f)) o = 0.f;
+                    if constexpr (sizeof(T) == 2) {   // the statistics describe the tensor as stored
+                        const T ot = (T)o;
+                        o = (float)ot;
+                        y[v * y_ld + co] = ot;
+                    } else if (TEM_NT_STORE)
                         __builtin_nontemporal_store(o, y + v * y_ld + co);
                     else
                         y[v * y_ld + co] = o;
+                    ssum[nn] += o;
+                    ssq[nn] = fmaf(o, o, ssq[nn]);
                 }
             }
         }
@@ -596,26 +600,29 @@ __global__ __launch_bounds__(256, NS == 1 ? TEM_NS1_WPC : (F16 && NR == 1) ? TEM
     }
 }
 
-template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false, bool PS = false>
-static void launch_b(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
-                     const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H,
+template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NS, bool F16 = false, bool PS = false, typename T = float>
+static void launch_b(const float* x_, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                     const float* bias, float* y_, int64_t y_ld, const float* ref_, int64_t ref_ld, int N, int D, int H,
                      int W, int Cin, int Cout, int act, int ksplit, float* part, float* stat, hipStream_t s) {
+    const T* x = reinterpret_cast<const T*>(x_);
+    const T* ref = reinterpret_cast<const T*>(ref_);
+    T* y = reinterpret_cast<T*>(y_);
     constexpr int HV = (TZ + KD - 1) * (TY + KH - 1) * (TX + KW - 1);
     const int nZ = (D + TZ - 1) / TZ, nY = (H + TY - 1) / TY, nX = (W + TX - 1) / TX;
     const int64_t nblk = (int64_t)N * nZ * nY * nX * (Cout / (32 * NR)) * ksplit;
     constexpr size_t ldsb = (size_t)HV * (NS * 8 + 4) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done && ldsb > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16, PS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16, PS, T>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16, PS>), dim3((unsigned)nblk), dim3(256), ldsb, s, x,
+    hipLaunchKernelGGL((k_conv_fwd_bfsplit<KD, KH, KW, TZ, TY, TX, NR, NS, F16, PS, T>), dim3((unsigned)nblk), dim3(256), ldsb, s, x,
                        x_ld, scale, shift, reinterpret_cast<const uint4*>(wp), bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin,
                        Cout, act, nZ, nY, nX, ksplit, part, ksplit > 1 ? nullptr : stat);
     if (ksplit > 1) {
         const int64_t NV = (int64_t)N * D * H * W;
-        tem_splitk_epilogue(part, ksplit, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);
+        tem_splitk_epilogue(part, ksplit, NV, Cout, bias, act, ref_, ref_ld, y_, y_ld, s);
     }
 }
 
@@ -625,8 +632,13 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
                         int nsplit, float* stat, hipStream_t s) {
     TEM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0, "tem_conv3d_fwd(split-bf16): needs Cin%%16==0 and Cout%%32==0 (got %d,%d)",
                 Cin, Cout);
-    TEM_REQUIRE(x_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)wp % 16 == 0),
-                "tem_conv3d_fwd(split-bf16): x / packed weights must be 16-byte aligned with ld%%4==0");
+    const int st = tem_call_st.x;
+    TEM_REQUIRE(st == tem_call_st.y, "tem_conv3d_fwd(split-bf16): x and y must have the same storage type");
+    TEM_REQUIRE(st == 0 || (st == 1 && nsplit == 5) || (st == 2 && nsplit == 7),
+                "tem_conv3d_fwd(split-bf16): 16-bit storage goes with the one-term mode of the same type (fp16: use_mfma 5, "
+                "bf16: use_mfma 7), got storage %d with use_mfma %d", st, nsplit);
+    TEM_REQUIRE(x_ld % (st ? 8 : 4) == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)wp % 16 == 0),
+                "tem_conv3d_fwd(split-bf16): x / packed weights must be 16-byte aligned with ld%%4==0 (16-bit storage: ld%%8==0)");
     TEM_REQUIRE(!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)),
                 "tem_conv3d_fwd(split-bf16): scale/shift must be 16-byte aligned");
     const int zr = tem_conv_fwd_zr(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, kd, kh, kw, act,
@@ -684,6 +696,20 @@ int tem_conv_fwd_bf16x3(const float* x, int64_t x_ld, const float* scale, const 
             else                                                                                                      \
                 launch_b<KD, KH, KW, TZ, TY, TX, 1, 2, true, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, \
                                                                    H, W, Cin, Cout, act, ks, part, stat, s);               \
+        } else if (nsplit == 5 && st == 1) {                                                                          \
+            if (nr2)                                                                                                  \
+                launch_b<KD, KH, KW, TZ, TY, TX, 2, 1, true, false, tem_f16>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                             W, Cin, Cout, act, ks, part, stat, s);                         \
+            else                                                                                                      \
+                launch_b<KD, KH, KW, TZ, TY, TX, 1, 1, true, false, tem_f16>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                             W, Cin, Cout, act, ks, part, stat, s);                         \
+        } else if (nsplit == 7 && st == 2) {                                                                          \
+            if (nr2)                                                                                                  \
+                launch_b<KD, KH, KW, TZ, TY, TX, 2, 1, false, false, tem_bf16>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                              W, Cin, Cout, act, ks, part, stat, s);                        \
+            else                                                                                                      \
+                launch_b<KD, KH, KW, TZ, TY, TX, 1, 1, false, false, tem_bf16>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
+                                                              W, Cin, Cout, act, ks, part, stat, s);                        \
         } else if (nsplit == 5) {                                                                                     \
             if (nr2)                                                                                                  \
                 launch_b<KD, KH, KW, TZ, TY, TX, 2, 1, true>(x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, \
@@ -769,11 +795,11 @@ int64_t tem_conv_fwd_bf16x3_stat_blocks(int N, int D, int H, int W, int Cin, int
 
 // PTZ x PTY x 8 patch of 128 voxels: 2 x 8 x 8 for volumes, 1 x 16 x 8 for 2-D data (D == 1: a 2-plane patch would be
 // half padding)
-template <int KD, int KH, int KW, int NCO, int KS2, int PTZ = 2>
-__global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __restrict__ x, int64_t x_ld,
+template <int KD, int KH, int KW, int NCO, int KS2, int PTZ = 2, typename TS = float>
+__global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const TS* __restrict__ x, int64_t x_ld,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
-                                                              const float* __restrict__ g, int64_t g_ld,
+                                                              const TS* __restrict__ g, int64_t g_ld,
                                                               float* __restrict__ part, float* __restrict__ dbpart,
                                                               int N, int D, int H, int W, int Cin, int Cout, int T,
                                                               int S, int P, int nZ, int nY, int nX) {
@@ -869,9 +895,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
                 const int row = rp / XPAIRS, pr = rp % XPAIRS;                                                     \
                 const int gz = z0_ + row / HY - PZ, gy = y0_ + row % HY - PY, gx = x0_ + 2 * pr - PX;              \
                 if (gz >= 0 && gz < D && gy >= 0 && gy < H) {                                \
-                    const float* rowp = x + (((int64_t)n_ * D + gz) * H + gy) * W * x_ld + cit * 32 + xcq * 4;     \
-                    if (gx >= 0 && gx < W) { xa[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * x_ld); inbA |= 1u << it; } \
-                    if (gx + 1 >= 0 && gx + 1 < W) { xb[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * x_ld); inbB |= 1u << it; } \
+                    const TS* rowp = x + (((int64_t)n_ * D + gz) * H + gy) * W * x_ld + cit * 32 + xcq * 4;    \
+                    if (gx >= 0 && gx < W) { xa[it] = act_ld4(rowp + (int64_t)gx * x_ld); inbA |= 1u << it; } \
+                    if (gx + 1 >= 0 && gx + 1 < W) { xb[it] = act_ld4(rowp + (int64_t)(gx + 1) * x_ld); inbB |= 1u << it; } \
                 }                                                                                                  \
             }                                                                                                      \
         }                                                                                                          \
@@ -883,9 +909,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wgrad_bf16x3(const float* __res
             ga[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
             gb[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
             if (gz < D && gy < H && cq < nco_here * 8) {                                     \
-                const float* rowp = g + (((int64_t)n_ * D + gz) * H + gy) * W * g_ld + cog * NCO * 32 + cq * 4;    \
-                if (gx < W) ga[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)gx * g_ld);                  \
-                if (gx + 1 < W) gb[it] = *reinterpret_cast<const float4*>(rowp + (int64_t)(gx + 1) * g_ld);        \
+                const TS* rowp = g + (((int64_t)n_ * D + gz) * H + gy) * W * g_ld + cog * NCO * 32 + cq * 4;   \
+                if (gx < W) ga[it] = act_ld4(rowp + (int64_t)gx * g_ld);                  \
+                if (gx + 1 < W) gb[it] = act_ld4(rowp + (int64_t)(gx + 1) * g_ld);        \
             }                                                                                                      \
         }                                                                                                          \
     } while (0)
@@ -1830,21 +1856,29 @@ int64_t tem_conv_wgrad_bf16x3_ws(int N, int D, int H, int W, int Cin, int Cout, 
     return tem_align_up((int64_t)p.S * p.ks2 * kd * kh * kw * Cin * Cout, 64) * 4 + (int64_t)p.S * Cout * 4 + 256;
 }
 
-template <int KD, int KH, int KW, int NCO, int KS2, int PTZ>
-static void launch_wb_t(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
-                        float* part, float* dbpart, int N, int D, int H, int W, int Cin, int Cout, const WbPlan& p,
-                        hipStream_t s) {
+template <int KD, int KH, int KW, int NCO, int KS2, int PTZ, typename T>
+static void launch_wb_tt(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
+                         float* part, float* dbpart, int N, int D, int H, int W, int Cin, int Cout, const WbPlan& p,
+                         hipStream_t s) {
     constexpr int ROWS = (PTZ + KD - 1) * (16 / PTZ + KH - 1);
     constexpr size_t ldsbytes = 2 * (size_t)32 * (ROWS * 32 + 16) + 2 * (size_t)32 * NCO * WB_GS;
     static_assert(ldsbytes <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2, PTZ>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2, PTZ, T>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2, PTZ>), dim3((unsigned)(p.T * p.S)), dim3(256), ldsbytes, s,
-                       x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p.T, p.S, p.P, p.nZ, p.nY, p.nX);
+    hipLaunchKernelGGL((k_conv_wgrad_bf16x3<KD, KH, KW, NCO, KS2, PTZ, T>), dim3((unsigned)(p.T * p.S)), dim3(256), ldsbytes, s,
+                       reinterpret_cast<const T*>(x), x_ld, scale, shift, reinterpret_cast<const T*>(g), g_ld, part, dbpart, N, D, H, W,
+                       Cin, Cout, p.T, p.S, p.P, p.nZ, p.nY, p.nX);
+}
+template <int KD, int KH, int KW, int NCO, int KS2, int PTZ>
+static void launch_wb_t(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
+                        float* part, float* dbpart, int N, int D, int H, int W, int Cin, int Cout, const WbPlan& p,
+                        hipStream_t s) {
+    TEM_ST_SWITCH(tem_call_st.x, T,
+                  (launch_wb_tt<KD, KH, KW, NCO, KS2, PTZ, T>(x, x_ld, scale, shift, g, g_ld, part, dbpart, N, D, H, W, Cin, Cout, p, s)));
 }
 template <int KD, int KH, int KW, int NCO, int KS2 = 1>
 static void launch_wb(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
@@ -1883,8 +1917,13 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
                           const float* gamma, const float* beta, float* norm_sums, hipStream_t s) {
     TEM_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "tem_conv3d_wgrad(bf16x3): needs Cin%%32==0 and Cout%%32==0 (got %d,%d)",
                 Cin, Cout);
-    TEM_REQUIRE(x_ld % 4 == 0 && g_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0),
-                "tem_conv3d_wgrad(bf16x3): x / g must be 16-byte aligned with ld%%4==0");
+    const int st = tem_call_st.x;
+    TEM_REQUIRE(st == tem_call_st.y, "tem_conv3d_wgrad(split-bf16): x and g must have the same storage type");
+    TEM_REQUIRE(st == 0 || (st == 1 && h16 == 1) || (st == 2 && h16 == 2),
+                "tem_conv3d_wgrad(split-bf16): 16-bit storage goes with the one-term mode of the same type (fp16: use_mfma 5, "
+                "bf16: use_mfma 7), got storage %d", st);
+    TEM_REQUIRE(x_ld % (st ? 8 : 4) == 0 && g_ld % (st ? 8 : 4) == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0),
+                "tem_conv3d_wgrad(bf16x3): x / g must be 16-byte aligned with ld%%4==0 (16-bit storage: ld%%8==0)");
     TEM_REQUIRE(!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)),
                 "tem_conv3d_wgrad(bf16x3): scale/shift must be 16-byte aligned");
     const int ntaps = kd * kh * kw;
@@ -1925,6 +1964,7 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
             else if (h16 == 3) launch(k3, lb);
             else launch(k0, lb);
         };
+        TEM_REQUIRE(!st || z.tr, "tem_conv3d_wgrad: 16-bit storage needs the transposing z-sliding kernel (option wgrad_zs = 3)");
         if (z.tr)
             tem_conv_wgrad_tr_launch(h16, nblk, x, x_ld, scale, shift, g, g_ld, zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX,
                                      z.zsegs, z.Ss, z.ncz, gmax, g_amax, s);

@@ -21,6 +21,7 @@
 //   merged by a deterministic fp64 reduction (no atomics).
 #include "tem_common.h"
 #include "conv_internal.h"
+#include "tem_act.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -435,10 +436,11 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_conv_fwd_mfma_p(
 
 
 // y = act(sum_ks part[ks] + bias) [* (ref > 0)]
+template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict__ part, int ksplit, int64_t NV,
                                                          int Cout, const float* __restrict__ bias, int act,
-                                                         const float* __restrict__ ref, int64_t ref_ld,
-                                                         float* __restrict__ y, int64_t y_ld) {
+                                                         const T* __restrict__ ref, int64_t ref_ld,
+                                                         T* __restrict__ y, int64_t y_ld) {
     const int cq = Cout >> 2;
     const int64_t items = NV * cq;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
         const int c0 = (int)(i % cq) * 4;
         float4 a = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 r = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (ref) r = *reinterpret_cast<const float4*>(ref + v * ref_ld + c0);   // issued with the slices, used at the end
+        if (ref) r = act_ld4(ref + v * ref_ld + c0);   // issued with the slices, used at the end
         // four slices per trip, loads unconditional (slices beyond ksplit re-read the last one and are dropped): the
         // one-load-per-trip loop was ksplit dependent round trips; the sum keeps its order k = 0, 1, 2, ...
         for (int k0 = 0; k0 < ksplit; k0 += 4) {
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
             if (!(r.z > 0.f)) a.z = 0.f;
             if (!(r.w > 0.f)) a.w = 0.f;
         }
-        *reinterpret_cast<float4*>(y + v * y_ld + c0) = a;
+        act_st4(y + v * y_ld + c0, a);
     }
 }
 
@@ -487,17 +489,17 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
 // (sum g, sum g * xn) with xn = (xin - mean) * rstd of that norm's input xin -- the first stage of its backward
 // (k_norm_partial<.,1>), tem_arm_dgrad_norm_sums.
 struct SplitkNormIn {
-    const float* xin;
+    const void* xin;   // element type of the launch (T)
     int64_t xin_ld;
     const float* mean;
     const float* rstd;
     int G;
 };
-template <bool BWD>
+template <bool BWD, typename T>
 __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __restrict__ part, int ksplit, int64_t V,
                                                                int Cout, const float* __restrict__ bias, int act,
-                                                               const float* __restrict__ ref, int64_t ref_ld,
-                                                               float* __restrict__ y, int64_t y_ld, int VB,
+                                                               const T* __restrict__ ref, int64_t ref_ld,
+                                                               T* __restrict__ y, int64_t y_ld, int VB,
                                                                float* __restrict__ stat, SplitkNormIn ni) {
     __shared__ float sh[2048];   // [rows][Cout][2], rows * Cout = 1024
     const int cq = Cout >> 2, rows = 256 / cq;
@@ -526,8 +528,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __re
         const int64_t v = (int64_t)n * V + vl;
         float4 a = bz;
         float4 rr = make_float4(1.f, 1.f, 1.f, 1.f), xi = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ref) rr = *reinterpret_cast<const float4*>(ref + v * ref_ld + c0);
-        if constexpr (BWD) xi = *reinterpret_cast<const float4*>(ni.xin + v * ni.xin_ld + c0);
+        if (ref) rr = act_ld4(ref + v * ref_ld + c0);
+        if constexpr (BWD) xi = act_ld4(static_cast<const T*>(ni.xin) + v * ni.xin_ld + c0);
         for (int k0 = 0; k0 < ksplit; k0 += 4) {
             float4 p[4];
 #pragma unroll
@@ -554,7 +556,11 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __re
             if (!(rr.z > 0.f)) a.z = 0.f;
             if (!(rr.w > 0.f)) a.w = 0.f;
         }
-        if (vin) *reinterpret_cast<float4*>(y + v * y_ld + c0) = a;
+        if constexpr (sizeof(T) == 2) {   // the sums below describe the tensor AS STORED (what the next norm reads)
+            const unsigned p0 = act_pk<T>(a.x, a.y), p1 = act_pk<T>(a.z, a.w);
+            a = make_float4(act_lo<T>(p0), act_hi<T>(p0), act_lo<T>(p1), act_hi<T>(p1));
+        }
+        if (vin) act_st4(y + v * y_ld + c0, a);
         const float av[4] = {a.x, a.y, a.z, a.w}, xv[4] = {xi.x, xi.y, xi.z, xi.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -587,8 +593,10 @@ int64_t tem_splitk_stat_blocks(int64_t V, int Cout) {
 void tem_splitk_epilogue_stats(const float* part, int ksplit, int N, int64_t V, int Cout, const float* bias, int act,
                                const float* ref, int64_t ref_ld, float* y, int64_t y_ld, float* stat, hipStream_t s) {
     const int VB = 4 * (256 / (Cout >> 2));
-    hipLaunchKernelGGL(k_splitk_epilogue_stats<false>, dim3((unsigned)tem_splitk_stat_blocks(V, Cout), (unsigned)N), dim3(256), 0, s,
-                       part, ksplit, V, Cout, bias, act, ref, ref_ld, y, y_ld, VB, stat, SplitkNormIn{nullptr, 0, nullptr, nullptr, 1});
+    TEM_ST_SWITCH(tem_call_st.y, T,
+                  hipLaunchKernelGGL((k_splitk_epilogue_stats<false, T>), dim3((unsigned)tem_splitk_stat_blocks(V, Cout), (unsigned)N),
+                                     dim3(256), 0, s, part, ksplit, V, Cout, bias, act, (const T*)ref, ref_ld, (T*)y, y_ld, VB, stat,
+                                     SplitkNormIn{nullptr, 0, nullptr, nullptr, 1}));
 }
 
 // the epilogue of a DATA GRADIENT that also writes the first stage of the backward of the norm its output lands behind
@@ -596,9 +604,10 @@ void tem_splitk_epilogue_bwd_sums(const float* part, int ksplit, int N, int64_t 
                                   const float* ref, int64_t ref_ld, float* y, int64_t y_ld, const TemDgradSumsReq& rq,
                                   hipStream_t s) {
     const int VB = 4 * (256 / (Cout >> 2));
-    hipLaunchKernelGGL(k_splitk_epilogue_stats<true>, dim3((unsigned)tem_splitk_stat_blocks(V, Cout), (unsigned)N), dim3(256), 0, s,
-                       part, ksplit, V, Cout, bias, act, ref, ref_ld, y, y_ld, VB, rq.part,
-                       SplitkNormIn{rq.x, rq.x_ld, rq.mean, rq.rstd, rq.G});
+    TEM_ST_SWITCH(tem_call_st.y, T,
+                  hipLaunchKernelGGL((k_splitk_epilogue_stats<true, T>), dim3((unsigned)tem_splitk_stat_blocks(V, Cout), (unsigned)N),
+                                     dim3(256), 0, s, part, ksplit, V, Cout, bias, act, (const T*)ref, ref_ld, (T*)y, y_ld, VB, rq.part,
+                                     SplitkNormIn{rq.x, rq.x_ld, rq.mean, rq.rstd, rq.G}));
 }
 
 // Split the input channels over `ks` workgroups when the (patches x Cout tiles) grid cannot fill
@@ -621,8 +630,9 @@ int tem_fwd_ksplit(int64_t nblk, int nchunks) {
 
 void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, const float* bias, int act,
                          const float* ref, int64_t ref_ld, float* y, int64_t y_ld, hipStream_t s) {
-    hipLaunchKernelGGL(k_splitk_epilogue, dim3(tem_grid_1d(NV * (Cout / 4), 256)), dim3(256), 0, s, part, ksplit, NV, Cout,
-                       bias, act, ref, ref_ld, y, y_ld);
+    TEM_ST_SWITCH(tem_call_st.y, T,
+                  hipLaunchKernelGGL(k_splitk_epilogue<T>, dim3(tem_grid_1d(NV * (Cout / 4), 256)), dim3(256), 0, s, part, ksplit, NV,
+                                     Cout, bias, act, (const T*)ref, ref_ld, (T*)y, y_ld));
 }
 
 static void fwd_geometry(int N, int D, int H, int W, int Cout, int kd, bool& flat, int& TZ, int& TY, int& TX, int& NR,
@@ -676,7 +686,7 @@ static void launch_fwd(const float* x, int64_t x_ld, const float* scale, const f
     }
     if (ksplit > 1) {
         const int64_t NV = (int64_t)N * D * H * W;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3(tem_grid_1d(NV * (Cout / 4), 256)), dim3(256), 0, s, part, ksplit, NV,
+        hipLaunchKernelGGL(k_splitk_epilogue<float>, dim3(tem_grid_1d(NV * (Cout / 4), 256)), dim3(256), 0, s, part, ksplit, NV,
                            Cout, bias, act, ref, ref_ld, y, y_ld);
     }
 }

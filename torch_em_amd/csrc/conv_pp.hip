@@ -19,6 +19,7 @@
 #include "tem_common.h"
 #include "conv_internal.h"
 #include "conv_split.h"
+#include "tem_act.h"
 #include <type_traits>
 
 #ifndef TEM_PP_RD
@@ -534,6 +535,7 @@ static PpGeom pp_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     PpGeom g = {};
     const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
     if (opt == 0) return g;   // (2 = z-reuse kernel forced: shapes it does not take still come here)
+    if (tem_call_st.x || tem_call_st.y) return g;   // 16-bit activation storage: the z-reuse / patch kernels carry the element type
     if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7)) return g;   // bf16x3, fp16x3 (scaled lo), one fp16 / bf16 term (mixed modes)
     if (!(kh == 3 && kw == 3 && (kd == 3 || kd == 1))) return g;
     if (D < 4 || Cin % 16 || Cout % 32) return g;

@@ -5,18 +5,27 @@
 // Each reads/writes its big tensor exactly once with 16-byte, fully coalesced accesses.
 #include "tem_common.h"
 #include "conv_internal.h"
+#include "tem_act.h"
 
 #ifndef TEM_SMALL_NT
 #define TEM_SMALL_NT 0
 #endif
-__device__ __forceinline__ void ST4(float* p, float4 v) {
+template <typename T>
+__device__ __forceinline__ void ST4(T* p, float4 v) {
 #if TEM_SMALL_NT
-    typedef float fx4 __attribute__((ext_vector_type(4)));
-    fx4 t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<fx4*>(p));
+    act_st4_nt(p, v);
 #else
-    *reinterpret_cast<float4*>(p) = v;
+    act_st4(p, v);
 #endif
+}
+// v rounded to the storage type T (the statistics by-products describe the tensor AS STORED)
+template <typename T>
+__device__ __forceinline__ float4 act_round4(float4 v) {
+    if constexpr (sizeof(T) == 2) {
+        const unsigned p0 = act_pk<T>(v.x, v.y), p1 = act_pk<T>(v.z, v.w);
+        return make_float4(act_lo<T>(p0), act_hi<T>(p0), act_lo<T>(p1), act_hi<T>(p1));
+    } else
+        return v;
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -35,12 +44,12 @@ __device__ __forceinline__ float act_apply_s(float v, int act) {
 // live in LDS; thread <-> (voxel, 4 output channels): 27 LDS broadcasts + 27 float4 weight
 // reads + 108 FMA, one 16-byte store.
 // ---------------------------------------------------------------------------
-template <int KD, int KH, int KW, int CIN>
-__global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__ x, int64_t x_ld,
+template <int KD, int KH, int KW, int CIN, typename EX, typename EY>
+__global__ __launch_bounds__(256) void k_conv_fwd_cin1(const EX* __restrict__ x, int64_t x_ld,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ w /*[tap][ci][co]*/,
-                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       const float* __restrict__ bias, EY* __restrict__ y,
                                                        int64_t y_ld, int N, int D, int H, int W, int Cout, int act,
                                                        int nZ, int nY, int nX, float* __restrict__ stat) {
     constexpr int NT = KD * KH * KW;
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
         const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
         float v = 0.f;
         if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            v = x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld + ci];
+            v = act_ld1(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld + ci);
             if (scale) v = fmaf(v, scale[n * CIN + ci], shift[n * CIN + ci]);
         }
         lx[ci * HVP + (hz * HY + hy) * HXP + hx] = v;
@@ -100,6 +109,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
         acc.y = act_apply_s(acc.y, act);
         acc.z = act_apply_s(acc.z, act);
         acc.w = act_apply_s(acc.w, act);
+        acc = act_round4<EY>(acc);
         const int64_t v = (((int64_t)n * D + gz) * H + gy) * W + gx;
         ST4(y + v * y_ld + q * 4, acc);
         ssum.x += acc.x; ssum.y += acc.y; ssum.z += acc.z; ssum.w += acc.w;
@@ -142,12 +152,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cin1(const float* __restrict__
 // voxel-pair where the voxel-per-thread kernel had 54 scalar FMAs and 27 reads.
 // ---------------------------------------------------------------------------
 #define C1R_TXW 32
-template <int KD>
-__global__ __launch_bounds__(256) void k_conv_fwd_c1rows(const float* __restrict__ x, int64_t x_ld,
+template <int KD, typename EX, typename EY>
+__global__ __launch_bounds__(256) void k_conv_fwd_c1rows(const EX* __restrict__ x, int64_t x_ld,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ w /*[tap][co]*/,
-                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         const float* __restrict__ bias, EY* __restrict__ y,
                                                          int64_t y_ld, int N, int D, int H, int W, int Cout, int act,
                                                          int nZ, int nY, int nX, float* __restrict__ stat) {
     constexpr int NT = KD * 9, PZ = KD / 2;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_c1rows(const float* __restrict
             const int gz = z0 + hz - PZ, gy = y0 + hy - 1, gx = x0 + hx - 1;
             float v = 0.f;
             if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = fmaf(x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld], sc, sf);
+                v = fmaf(act_ld1(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld), sc, sf);
             lx[hr * HXP + hx] = v;
         }
     }
@@ -224,9 +234,13 @@ __global__ __launch_bounds__(256) void k_conv_fwd_c1rows(const float* __restrict
 #pragma unroll
             for (int px = 0; px < TX; ++px) {
                 if (x0 + xs + px >= W) break;
-                const f2 o = {act_apply_s(acc[px].x, act), act_apply_s(acc[px].y, act)};
+                f2 o = {act_apply_s(acc[px].x, act), act_apply_s(acc[px].y, act)};
+                if constexpr (sizeof(EY) == 2) {   // the statistics describe the tensor as stored
+                    const unsigned pk = act_pk<EY>(o.x, o.y);
+                    o = f2{act_lo<EY>(pk), act_hi<EY>(pk)};
+                }
 #if !(TEM_C1_ABL & 1)
-                *reinterpret_cast<f2*>(y + (v0 + px) * y_ld + q * 2) = o;
+                act_st2(y + (v0 + px) * y_ld + q * 2, o);
 #endif
                 ss += o;
                 sq = __builtin_elementwise_fma(o, o, sq);
@@ -280,7 +294,7 @@ bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const f
                        const float* bias, float* y, int64_t y_ld, const float* ref, int N, int D, int H, int W,
                        int Cin, int Cout, int kd, int kh, int kw, int act, float* stat, hipStream_t s) {
     // Cin 2..4 (RGB / multi-channel raw data) share the kernel; weights stay in LDS, so Cin * Cout is bounded
-    if (Cin > 4 || Cout % 4 || Cin * Cout > 128 || ref || y_ld % 4 || ((uintptr_t)y % 16) ||
+    if (Cin > 4 || Cout % 4 || Cin * Cout > 128 || ref || y_ld % 4 || ((uintptr_t)y % tem_st_align4(tem_call_st.y)) ||
         (bias && ((uintptr_t)bias % 16)))
         return false;
     const int key = (kd == 3) * 4 + (kh == 3) * 2 + (kw == 3);
@@ -290,12 +304,14 @@ bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const f
         const int64_t nblk = (int64_t)N * nZ * nY * nX;
         const int kdv = key == 7 ? 3 : 1;
         const size_t ldsb = (size_t)((kdv + 3) * 10 * (C1R_TXW + 4) + kdv * 9 * Cout) * sizeof(float);
-        if (key == 7)
-            hipLaunchKernelGGL((k_conv_fwd_c1rows<3>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, shift, w,
-                               bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat);
-        else
-            hipLaunchKernelGGL((k_conv_fwd_c1rows<1>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, shift, w,
-                               bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat);
+        TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TY, return false, {
+            if (key == 7)
+                hipLaunchKernelGGL((k_conv_fwd_c1rows<3, TX, TY>), dim3((unsigned)nblk), dim3(256), ldsb, s, (const TX*)x, x_ld, scale,
+                                   shift, w, bias, (TY*)y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat);
+            else
+                hipLaunchKernelGGL((k_conv_fwd_c1rows<1, TX, TY>), dim3((unsigned)nblk), dim3(256), ldsb, s, (const TX*)x, x_ld, scale,
+                                   shift, w, bias, (TY*)y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat);
+        });
         return true;
     }
     const int nZ = (D + 3) / 4, nY = (H + 7) / 8, nX = (W + 7) / 8;
@@ -303,8 +319,9 @@ bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const f
 #define C1(KD_, CI)                                                                                                   \
     case CI: {                                                                                                        \
         size_t ldsb = (size_t)(CI * ((KD_ + 3) * 10 * 12) + KD_ * 9 * CI * Cout) * sizeof(float);                    \
-        hipLaunchKernelGGL((k_conv_fwd_cin1<KD_, 3, 3, CI>), dim3((unsigned)nblk), dim3(256), ldsb, s, x, x_ld, scale, \
-                           shift, w, bias, y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat);                         \
+        TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TY, return false,                                            \
+                       hipLaunchKernelGGL((k_conv_fwd_cin1<KD_, 3, 3, CI, TX, TY>), dim3((unsigned)nblk), dim3(256), ldsb, s, \
+                                          (const TX*)x, x_ld, scale, shift, w, bias, (TY*)y, y_ld, N, D, H, W, Cout, act, nZ, nY, nX, stat)); \
     } break;
     if (key == 7) {
         switch (Cin) { C1(3, 1) C1(3, 2) C1(3, 3) C1(3, 4) }
@@ -322,10 +339,10 @@ bool tem_conv_fwd_cin1(const float* x, int64_t x_ld, const float* scale, const f
 // 16-byte slots: conflict-free float4 reads).  Was the generic VALU kernel: 17.5 ms for 2x128^3x32 -> 1; now HBM/VALU
 // balanced (one read of x).
 // ---------------------------------------------------------------------------
-template <int KD, int KH, int KW>
-__global__ __launch_bounds__(256) void k_conv_fwd_cout1(const float* __restrict__ x, int64_t x_ld,
+template <int KD, int KH, int KW, typename EX, typename EY>
+__global__ __launch_bounds__(256) void k_conv_fwd_cout1(const EX* __restrict__ x, int64_t x_ld,
                                                         const float* __restrict__ w /*[tap][ci]*/,
-                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        const float* __restrict__ bias, EY* __restrict__ y,
                                                         int64_t y_ld, int N, int D, int H, int W, int Cin, int act,
                                                         int nZ, int nY, int nX) {
     constexpr int NT = KD * KH * KW;
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cout1(const float* __restrict_
             const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld + c16 + c4 * 4);
+                v = act_ld4(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld + c16 + c4 * 4);
             *reinterpret_cast<float4*>(lx + hv * LS + c4 * 4) = v;
         }
         __syncthreads();
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_cout1(const float* __restrict_
     const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
     if (gz < D && gy < H && gx < W) {
         if (bias) acc += bias[0];
-        y[((((int64_t)n * D + gz) * H + gy) * W + gx) * y_ld] = act_apply_s(acc, act);
+        act_st1(y + ((((int64_t)n * D + gz) * H + gy) * W + gx) * y_ld, act_apply_s(acc, act));
     }
 }
 
@@ -391,12 +408,14 @@ bool tem_conv_fwd_cout1(const float* x, int64_t x_ld, const float* scale, const 
     if (key != 7 && key != 3) return false;
     const int nZ = (D + 3) / 4, nY = (H + 7) / 8, nX = (W + 7) / 8;
     const int64_t nblk = (int64_t)N * nZ * nY * nX;
-    if (key == 7)
-        hipLaunchKernelGGL((k_conv_fwd_cout1<3, 3, 3>), dim3((unsigned)nblk), dim3(256), 0, s, x, x_ld, w, bias, y, y_ld, N,
-                           D, H, W, Cin, act, nZ, nY, nX);
-    else
-        hipLaunchKernelGGL((k_conv_fwd_cout1<1, 3, 3>), dim3((unsigned)nblk), dim3(256), 0, s, x, x_ld, w, bias, y, y_ld, N,
-                           D, H, W, Cin, act, nZ, nY, nX);
+    TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TY, return false, {
+        if (key == 7)
+            hipLaunchKernelGGL((k_conv_fwd_cout1<3, 3, 3, TX, TY>), dim3((unsigned)nblk), dim3(256), 0, s, (const TX*)x, x_ld, w, bias,
+                               (TY*)y, y_ld, N, D, H, W, Cin, act, nZ, nY, nX);
+        else
+            hipLaunchKernelGGL((k_conv_fwd_cout1<1, 3, 3, TX, TY>), dim3((unsigned)nblk), dim3(256), 0, s, (const TX*)x, x_ld, w, bias,
+                               (TY*)y, y_ld, N, D, H, W, Cin, act, nZ, nY, nX);
+    });
     return true;
 }
 
@@ -406,15 +425,15 @@ bool tem_conv_fwd_cout1(const float* x, int64_t x_ld, const float* scale, const 
 // registers (v_pk_fma_f32), reads its 8 g pairs once with 8-byte loads (16 lanes = one 128-byte line per voxel) and the
 // row's 10 input values per (tz, ty) from LDS in three wide reads; one reduction at the end.
 // ---------------------------------------------------------------------------
-template <int KD, int KH, int KW>
-__global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict__ x, int64_t x_ld,
+template <int KD, int KH, int KW, typename EX, typename EG>
+__global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const EX* __restrict__ x, int64_t x_ld,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
-                                                         const float* __restrict__ g, int64_t g_ld,
+                                                         const EG* __restrict__ g, int64_t g_ld,
                                                          float* __restrict__ part /*[grid][NT+1][Cout]*/, int N,
                                                          int D, int H, int W, int Cout, int P, int nZ, int nY,
                                                          int nX, int sstride /*Cin: scale[n*Cin] of this channel*/,
-                                                         const float* __restrict__ gnx, int64_t gnx_ld,
+                                                         const EG* __restrict__ gnx, int64_t gnx_ld,
                                                          const float* __restrict__ gcoef) {
     static_assert(KH == 3 && KW == 3, "row layout: 3x3 in-plane taps");
     constexpr int NT = KD * KH * KW;
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
             const int gz = z0 + hz - PZ, gy = y0 + hy - PY, gx = x0 + hx - PX;
             float v = 0.f;
             if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = fmaf(x[((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld], sc, sf);
+                v = fmaf(act_ld1(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * x_ld), sc, sf);
             lds[(hz * HY + hy) * HXP + hx] = v;
         }
         __syncthreads();
@@ -469,8 +488,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const float* __restrict
 #pragma unroll
             for (int px = 0; px < TX; ++px) {     // branch-free: a voxel beyond W reads the row's first one and is zeroed
                 const int pc = x0 + px < W ? px : 0;
-                gv[px] = *reinterpret_cast<const f2*>(g + (v0 + pc) * g_ld + q * 2);
-                yv[px] = gcoef ? *reinterpret_cast<const f2*>(gnx + (v0 + pc) * gnx_ld + q * 2) : f2{0.f, 0.f};
+                gv[px] = act_ld2(g + (v0 + pc) * g_ld + q * 2);
+                yv[px] = gcoef ? act_ld2(gnx + (v0 + pc) * gnx_ld + q * 2) : f2{0.f, 0.f};
             }
 #pragma unroll
             for (int px = 0; px < TX; ++px)
@@ -823,15 +842,17 @@ bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const
     for (int ci = 0; ci < Cin; ++ci) {
         const float* sc = scale ? scale + ci : nullptr;
         const float* sf = scale ? shift + ci : nullptr;
-        if (key == 7) {
-            size_t ldsf = 6 * 10 * 12 > 4 * (NT + 1) * Cout ? 6 * 10 * 12 : 4 * (NT + 1) * Cout;
-            hipLaunchKernelGGL((k_conv_wgrad_cin1<3, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x + ci, x_ld, sc,
-                               sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin, gnx, gnx_ld, gcoef);
-        } else {
-            size_t ldsf = 4 * 10 * 12 > 4 * (NT + 1) * Cout ? 4 * 10 * 12 : 4 * (NT + 1) * Cout;
-            hipLaunchKernelGGL((k_conv_wgrad_cin1<1, 3, 3>), dim3(grid), dim3(256), ldsf * sizeof(float), s, x + ci, x_ld, sc,
-                               sf, g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin, gnx, gnx_ld, gcoef);
-        }
+        TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TG, return false, {
+            if (key == 7) {
+                size_t ldsf = 6 * 10 * 12 > 4 * (NT + 1) * Cout ? 6 * 10 * 12 : 4 * (NT + 1) * Cout;
+                hipLaunchKernelGGL((k_conv_wgrad_cin1<3, 3, 3, TX, TG>), dim3(grid), dim3(256), ldsf * sizeof(float), s, (const TX*)x + ci,
+                                   x_ld, sc, sf, (const TG*)g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin, (const TG*)gnx, gnx_ld, gcoef);
+            } else {
+                size_t ldsf = 4 * 10 * 12 > 4 * (NT + 1) * Cout ? 4 * 10 * 12 : 4 * (NT + 1) * Cout;
+                hipLaunchKernelGGL((k_conv_wgrad_cin1<1, 3, 3, TX, TG>), dim3(grid), dim3(256), ldsf * sizeof(float), s, (const TX*)x + ci,
+                                   x_ld, sc, sf, (const TG*)g, g_ld, part, N, D, H, W, Cout, P, nZ, nY, nX, Cin, (const TG*)gnx, gnx_ld, gcoef);
+            }
+        });
         // the first NT*Cout entries of a slab are dw[tap][ci][co]; the last Cout are db
         if (Cin == 1) {   // the usual first layer: weight and bias gradient in one merge launch
             tem_reduce_slabs_w_db(part, grid, NT, 1, Cout, (int64_t)(NT + 1) * Cout, dw, sd_layout, part + (int64_t)NT * Cout, grid, db, s,
@@ -851,10 +872,10 @@ bool tem_conv_wgrad_cin1(const float* x, int64_t x_ld, const float* scale, const
 // 16 bytes of its channel row (one fully coalesced 128-byte line per voxel per pass), partial
 // dot products are combined with 3 xor-shuffles.
 // ---------------------------------------------------------------------------
-template <int COUT>
-__global__ __launch_bounds__(256) void k_conv1x1_proj(const float* __restrict__ x, int64_t x_ld,
+template <int COUT, typename EX, typename EY>
+__global__ __launch_bounds__(256) void k_conv1x1_proj(const EX* __restrict__ x, int64_t x_ld,
                                                       const float* __restrict__ w /*[ci][co]*/,
-                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      const float* __restrict__ bias, EY* __restrict__ y,
                                                       int64_t y_ld, int64_t NV, int Cin, int act) {
     const int l8 = threadIdx.x & 7;
     const int64_t vstride = (int64_t)gridDim.x * 32;
@@ -862,9 +883,9 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj(const float* __restrict__ 
         float acc[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-        const float* xp = x + v * x_ld;
+        const EX* xp = x + v * x_ld;
         for (int c0 = l8 * 4; c0 < Cin; c0 += 32) {
-            const float4 t = *reinterpret_cast<const float4*>(xp + c0);
+            const float4 t = act_ld4(xp + c0);
             const float xv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -879,7 +900,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj(const float* __restrict__ 
         }
 #pragma unroll
         for (int co = 0; co < COUT; ++co)
-            if ((co & 7) == l8) y[v * y_ld + co] = act_apply_s(acc[co] + (bias ? bias[co] : 0.f), act);
+            if ((co & 7) == l8) act_st1(y + v * y_ld + co, act_apply_s(acc[co] + (bias ? bias[co] : 0.f), act));
     }
 }
 
@@ -889,10 +910,10 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj(const float* __restrict__ 
 // 7 (15) shuffles instead of 24 (48), and lane l8 ends up holding output channel l8 (and l8 + 8): exactly what it stores.
 // The generic kernel above re-reads its 4 * COUT weights from the L1 for every voxel: 0.49 ms for 32 -> 8 at 96 x 192 x 192
 // (the SPOCO embedding head, 0.9 TB/s) against 0.14 ms for 32 -> 2 at 2 x 128^3.
-template <int COUT, int NJ>
-__global__ __launch_bounds__(256) void k_conv1x1_proj_r(const float* __restrict__ x, int64_t x_ld,
+template <int COUT, int NJ, typename EX, typename EY>
+__global__ __launch_bounds__(256) void k_conv1x1_proj_r(const EX* __restrict__ x, int64_t x_ld,
                                                         const float* __restrict__ w /*[ci][co]*/,
-                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        const float* __restrict__ bias, EY* __restrict__ y,
                                                         int64_t y_ld, int64_t NV, int act) {
     const int l8 = threadIdx.x & 7;
     float wr[NJ][4][COUT];
@@ -907,10 +928,10 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_r(const float* __restrict_
         float acc[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-        const float* xp = x + v * x_ld + l8 * 4;
+        const EX* xp = x + v * x_ld + l8 * 4;
 #pragma unroll
         for (int a = 0; a < NJ; ++a) {
-            const float4 t = *reinterpret_cast<const float4*>(xp + a * 32);
+            const float4 t = act_ld4(xp + a * 32);
             const float xv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -944,7 +965,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_r(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int co = 8 * r + l8;
-                y[v * y_ld + co] = act_apply_s(h1[r] + (bias ? bias[co] : 0.f), act);
+                act_st1(y + v * y_ld + co, act_apply_s(h1[r] + (bias ? bias[co] : 0.f), act));
             }
         } else {
 #pragma unroll
@@ -955,7 +976,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_r(const float* __restrict_
             }
 #pragma unroll
             for (int co = 0; co < COUT; ++co)
-                if ((co & 7) == l8) y[v * y_ld + co] = act_apply_s(acc[co] + (bias ? bias[co] : 0.f), act);
+                if ((co & 7) == l8) act_st1(y + v * y_ld + co, act_apply_s(acc[co] + (bias ? bias[co] : 0.f), act));
         }
     }
 }
@@ -967,7 +988,9 @@ bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const fl
     // weights in registers where they fit (NJ * COUT <= 32 values per 16-byte piece and lane)
 #define PJR(CO, NJ_)                                                                                                 \
     if (Cout == CO && Cin == 32 * NJ_) {                                                                             \
-        hipLaunchKernelGGL((k_conv1x1_proj_r<CO, NJ_>), grid, dim3(256), 0, s, x, x_ld, w, bias, y, y_ld, NV, act);  \
+        TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TY, return false,                                           \
+                       hipLaunchKernelGGL((k_conv1x1_proj_r<CO, NJ_, TX, TY>), grid, dim3(256), 0, s, (const TX*)x, x_ld, w, bias, \
+                                          (TY*)y, y_ld, NV, act));                                                   \
         return true;                                                                                                 \
     }
     PJR(1, 1) PJR(2, 1) PJR(3, 1) PJR(4, 1) PJR(6, 1) PJR(8, 1) PJR(12, 1) PJR(16, 1)
@@ -976,7 +999,9 @@ bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const fl
 #undef PJR
 #define PJ(CO)                                                                                                     \
     case CO:                                                                                                       \
-        hipLaunchKernelGGL((k_conv1x1_proj<CO>), grid, dim3(256), 0, s, x, x_ld, w, bias, y, y_ld, NV, Cin, act);  \
+        TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TY, return false,                                         \
+                       hipLaunchKernelGGL((k_conv1x1_proj<CO, TX, TY>), grid, dim3(256), 0, s, (const TX*)x, x_ld, w, bias, (TY*)y, \
+                                          y_ld, NV, Cin, act));                                                    \
         return true;
     switch (Cout) {
         PJ(1) PJ(2) PJ(3) PJ(4) PJ(6) PJ(8) PJ(12) PJ(16)
@@ -990,12 +1015,12 @@ bool tem_conv1x1_proj(const float* x, int64_t x_ld, const float* scale, const fl
 //   gx[v][ci] = x[v][ci] > 0 ? sum_co g[v][co] * w[co][ci] : 0   (x is the ReLU output the projection read),
 // which used to be k_conv1x1_expand's own pass over x (a 512 MB tensor at the out_conv of a 128^3 net): the thread that
 // holds 4 channels of x for the weight gradient holds what the mask and the 16-byte store need.
-template <int COUT, int NJ, bool EXP = false>
-__global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restrict__ x, int64_t x_ld,
-                                                            const float* __restrict__ g, int64_t g_ld,
+template <int COUT, int NJ, bool EXP, typename EX, typename EG>
+__global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const EX* __restrict__ x, int64_t x_ld,
+                                                            const EG* __restrict__ g, int64_t g_ld,
                                                             float* __restrict__ part /*[grid][Cin+1][COUT]*/,
                                                             int64_t NV, int Cin, const float* __restrict__ w = nullptr,
-                                                            float* __restrict__ gx = nullptr, int64_t gx_ld = 0,
+                                                            EX* __restrict__ gx = nullptr, int64_t gx_ld = 0,
                                                             unsigned* __restrict__ amax = nullptr) {
     extern __shared__ float lds[];  // [4][Cin+1][COUT]
     const int l8 = threadIdx.x & 7;
@@ -1029,14 +1054,14 @@ __global__ __launch_bounds__(256) void k_conv1x1_proj_wgrad(const float* __restr
         float gv[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
-            gv[co] = g[v * g_ld + co];
+            gv[co] = act_ld1(g + v * g_ld + co);
             gacc[co] += gv[co];
         }
-        const float* xp = x + v * x_ld;
+        const EX* xp = x + v * x_ld;
 #pragma unroll
         for (int a = 0; a < NJ; ++a) {
             if (a < nj) {
-                const float4 t = *reinterpret_cast<const float4*>(xp + a * 32 + l8 * 4);
+                const float4 t = act_ld4(xp + a * 32 + l8 * 4);
                 const float xv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1112,7 +1137,9 @@ bool tem_conv1x1_proj_wgrad(const float* x, int64_t x_ld, const float* scale, co
     float* part = (float*)ws;
     size_t ldsb = (size_t)4 * (Cin + 1) * Cout * sizeof(float);
 #define PWJ(CO, J)                                                                                                \
-    hipLaunchKernelGGL((k_conv1x1_proj_wgrad<CO, J>), dim3(grid), dim3(256), ldsb, s, x, x_ld, g, g_ld, part, NV, Cin)
+    TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TG, return false,                                            \
+                   hipLaunchKernelGGL((k_conv1x1_proj_wgrad<CO, J, false, TX, TG>), dim3(grid), dim3(256), ldsb, s, (const TX*)x, x_ld, \
+                                      (const TG*)g, g_ld, part, NV, Cin))
 #define PW(CO)                                                                                                    \
     case CO:                                                                                                      \
         if (njr == 1) PWJ(CO, 1);                                                                                 \
@@ -1152,8 +1179,9 @@ bool tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g
     size_t ldsb = (size_t)4 * (Cin + 1) * Cout * sizeof(float);
     unsigned* const amax = tem_take_output_amax();
 #define OBJ(CO, J)                                                                                                     \
-    hipLaunchKernelGGL((k_conv1x1_proj_wgrad<CO, J, true>), dim3(grid), dim3(256), ldsb, s, x, x_ld, g, g_ld, part, NV, Cin, w, gx, \
-                       gx_ld, amax)
+    TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TG, return false,                                                 \
+                   hipLaunchKernelGGL((k_conv1x1_proj_wgrad<CO, J, true, TX, TG>), dim3(grid), dim3(256), ldsb, s, (const TX*)x, x_ld, \
+                                      (const TG*)g, g_ld, part, NV, Cin, w, (TX*)gx, gx_ld, amax))
 #define OB(CO)                \
     case CO:                  \
         if (njr == 1) OBJ(CO, 1); \
@@ -1175,10 +1203,11 @@ bool tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g
 // thread <-> (voxel, 4 output channels); the 512 MB result is written once with 16-byte stores,
 // ReLU-backward mask fused.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_conv1x1_expand(const float* __restrict__ x, int64_t x_ld,
+template <typename EX, typename EY>
+__global__ __launch_bounds__(256) void k_conv1x1_expand(const EX* __restrict__ x, int64_t x_ld,
                                                         const float* __restrict__ w /*[ci][co]*/,
-                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                        int64_t y_ld, const float* __restrict__ ref, int64_t ref_ld,
+                                                        const float* __restrict__ bias, EY* __restrict__ y,
+                                                        int64_t y_ld, const EY* __restrict__ ref, int64_t ref_ld,
                                                         int64_t NV, int Cin, int Cout, int act,
                                                         unsigned* __restrict__ amax) {
     const int cq = Cout >> 2;
@@ -1196,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_expand(const float* __restrict_
         }
         float4 a = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int ci = 0; ci < Cin; ++ci) {
-            const float xv = x[v * x_ld + ci];
+            const float xv = act_ld1(x + v * x_ld + ci);
             const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)ci * Cout + q * 4);
             a.x = fmaf(xv, wv.x, a.x);
             a.y = fmaf(xv, wv.y, a.y);
@@ -1208,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_expand(const float* __restrict_
         a.z = act_apply_s(a.z, act);
         a.w = act_apply_s(a.w, act);
         if (ref) {
-            const float4 rr = *reinterpret_cast<const float4*>(ref + v * ref_ld + q * 4);
+            const float4 rr = act_ld4(ref + v * ref_ld + q * 4);
             if (!(rr.x > 0.f)) a.x = 0.f;
             if (!(rr.y > 0.f)) a.y = 0.f;
             if (!(rr.z > 0.f)) a.z = 0.f;
@@ -1226,7 +1255,9 @@ bool tem_conv1x1_expand(const float* x, int64_t x_ld, const float* scale, const 
     if (scale || Cin > 16 || Cout % 4 || y_ld % 4 || ((uintptr_t)y % 16) || ((uintptr_t)w % 16) ||
         (bias && (uintptr_t)bias % 16) || (ref && (ref_ld % 4 || (uintptr_t)ref % 16)))
         return false;
-    hipLaunchKernelGGL(k_conv1x1_expand, dim3(tem_grid_1d(NV * (Cout / 4), 256, 256 * 16)), dim3(256), 0, s, x, x_ld, w,
-                       bias, y, y_ld, ref, ref_ld, NV, Cin, Cout, act, tem_take_output_amax());
+    unsigned* const amax = tem_take_output_amax();
+    TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TY, return false,
+                   hipLaunchKernelGGL((k_conv1x1_expand<TX, TY>), dim3(tem_grid_1d(NV * (Cout / 4), 256, 256 * 16)), dim3(256), 0, s,
+                                      (const TX*)x, x_ld, w, bias, (TY*)y, y_ld, (const TY*)ref, ref_ld, NV, Cin, Cout, act, amax));
     return true;
 }

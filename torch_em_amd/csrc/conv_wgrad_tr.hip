@@ -30,6 +30,7 @@
 #include "tem_common.h"
 #include "conv_internal.h"
 #include "conv_split.h"
+#include "tem_act.h"
 #include <set>
 #include <type_traits>
 
@@ -71,6 +72,24 @@ __device__ __forceinline__ unsigned tr_mix_lo(unsigned h, float e0, float e1) {
     return q;
 }
 
+__device__ __forceinline__ uint4 tr_load4u(tr_rsrc_t r, unsigned voff) {
+    const tr_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// pre-norm of two packed 16-bit activations, rounded once to the operand type (conv_zr.hip: zr_norm2)
+template <bool F16>
+__device__ __forceinline__ unsigned tr_norm2(unsigned h, float s0, float t0, float s1, float t1) {
+    if constexpr (F16) {
+        unsigned q;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(q) : "v"(h), "v"(s0), "v"(t0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(q) : "v"(h), "v"(s1), "v"(t1));
+        return q;
+    } else {
+        const float a = __builtin_bit_cast(float, h << 16), b = __builtin_bit_cast(float, h & 0xffff0000u);
+        return pk_bf16(fmaf(a, s0, t0), fmaf(b, s1, t1));
+    }
+}
+
 // (g0 * s, g1 * s) rounded to two fp16 in one register: the prescaled gradient term (all sources fp32)
 __device__ __forceinline__ unsigned tr_mix_scale(float g0, float g1, float sc) {
     unsigned q;
@@ -102,10 +121,14 @@ void tem_tr_trace_read(unsigned long long* dst) {
 #define TR_STAMP(it, i)
 #endif
 
-template <int ARITH>
-__global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restrict__ x, int64_t x_ld,
+// TS (round 5): element type of x and g in HBM.  A 16-bit TS is the one-term mode of the same type (ARITH 1: fp16, 2: bf16) and
+// changes only the staging team: a voxel record in HBM is what LDS holds (64 bytes), FOUR lanes move it with one 16-byte load
+// each -- x through the packed pre-norm (tr_norm2: 4 instructions per 8 channels), g untouched -- and one ds_write_b128; an x
+// plane is two rounds of loads per thread instead of four, a g plane one instead of two.
+template <int ARITH, typename TS = float>
+__global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__ x, int64_t x_ld,
                                                           const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, const float* __restrict__ g,
+                                                          const float* __restrict__ shift, const TS* __restrict__ g,
                                                           int64_t g_ld, float* __restrict__ part,
                                                           float* __restrict__ dbpart, int N, int D, int H, int W,
                                                           int Cin, int Cout, int T, int nY, int nX, int zsegs,
@@ -116,6 +139,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
     constexpr int NG = (ARITH == 0) ? 2 : 1;                 // terms of g
     constexpr bool F16 = ARITH == 1 || ARITH == 3;
     constexpr bool H21 = ARITH == 3;
+    constexpr bool T16 = sizeof(TS) == 2;
+    static_assert(!T16 || ARITH == 1 || ARITH == 2, "16-bit storage: the one-term mode of the same type");
     constexpr bool FP32 = ARITH == 4;   // exact fp32: v_mfma_f32_32x32x2_f32 on fp32 records (no transpose needed: K = 2 voxels = the two lane halves)
     constexpr int TR_REC = FP32 ? 128 : 64, TR_QB = TR_REC / 8;   // bytes per voxel record / per channel quad
     constexpr int TR_XROW = 10 * TR_REC, TR_XPL = 10 * TR_XROW, TR_XT = TR_XT_OF(TR_REC);
@@ -345,6 +370,122 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
     const bool do_db = (dbpart != nullptr) && (cit == 0);
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
     float gmx = 0.f;
+    if constexpr (T16) {
+        // ---------------- staging team, 16-bit tensors: item = (voxel, channel OCTET), 4 lanes per 64-byte record ----------------
+        const int oct = tl & 3;
+        float db8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!mteam) {
+            uint4 xa[2][2], ga[2];
+            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f), sc5 = sc4, sf5 = sf4;
+            if (scale) {
+                sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + oct * 8);
+                sc5 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + oct * 8 + 4);
+                sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + oct * 8);
+                sf5 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + oct * 8 + 4);
+            }
+            const TS* const xn = x + (int64_t)n * D * H * W * x_ld;
+            const TS* const gn = g + (int64_t)n * D * H * W * g_ld;
+            const int64_t xplane = (int64_t)H * W * x_ld, gplane = (int64_t)H * W * g_ld;
+            constexpr unsigned OOB = 0x80000000u;   // >= num_records of tr_rsrc: the load returns zeros
+            for (int cz = sp % S; cz < ncz; cz += S) {
+                const int zseg = cz % zsegs;
+                const int col = cz / zsegs;
+                const int y0 = (col / nX) * 8, x0 = (col % nX) * 8;
+                const int za = (int)(((int64_t)zseg * D) / zsegs), zb = (int)(((int64_t)(zseg + 1) * D) / zsegs);
+                unsigned offx[2], offg;
+                bool okx[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int hv = (tl + 256 * q) >> 2;                 // halo voxel 0..99 (round 1: threads 0..143 only)
+                    const int gy = y0 + hv / 10 - 1, gx = x0 + hv % 10 - 1;
+                    okx[q] = hv < 100 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    offx[q] = okx[q] ? (unsigned)((gy * W + gx) * (int)x_ld + cit * 32 + oct * 8) * 2u : OOB;
+                }
+                {
+                    const int gv = tl >> 2;                             // patch voxel 0..63
+                    const int hy = y0 + (gv >> 3), hx = x0 + (gv & 7);
+                    const bool ok = hy < H && hx < W && cog * 32 + oct * 8 < Cout;
+                    offg = ok ? (unsigned)((hy * W + hx) * (int)g_ld + cog * 32 + oct * 8) * 2u : OOB;
+                }
+                bool zin[2] = {false, false};
+                // same schedule as the fp32 staging below: iteration t stores x plane t + 3 / g plane t + 2 from the register set
+                // loaded two iterations ago and loads x plane t + 5 / g plane t + 4 into it
+                auto iteration = [&](int t, uint4(&xs_)[2], uint4& gs_, bool& zin_) {
+                    TR_STAMP(t - za, 0);
+                    if (TEM_TR_ABL & 1) {
+                        __syncthreads();
+                        return;
+                    }
+                    if (t >= za - 4) {
+                        unsigned char* const xs = X0 + TR_XSLOT(t + 3) + oct * 16;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int hv = (tl + 256 * q) >> 2;
+                            if (q == 1 && hv >= 100) break;
+                            uint4 r = xs_[q];
+                            if (zin_) {
+                                if (scale) {   // launch-uniform; zero padding applies after the pre-norm
+                                    r.x = tr_norm2<F16>(r.x, sc4.x, sf4.x, sc4.y, sf4.y);
+                                    r.y = tr_norm2<F16>(r.y, sc4.z, sf4.z, sc4.w, sf4.w);
+                                    r.z = tr_norm2<F16>(r.z, sc5.x, sf5.x, sc5.y, sf5.y);
+                                    r.w = tr_norm2<F16>(r.w, sc5.z, sf5.z, sc5.w, sf5.w);
+                                    r.x = okx[q] ? r.x : 0u; r.y = okx[q] ? r.y : 0u; r.z = okx[q] ? r.z : 0u; r.w = okx[q] ? r.w : 0u;
+                                }
+                            } else
+                                r = make_uint4(0u, 0u, 0u, 0u);
+                            *reinterpret_cast<uint4*>(xs + hv * TR_REC) = r;
+                        }
+                    }
+                    if (t + 2 >= za && t + 2 < zb) {
+                        unsigned char* const gs = G0 + TR_GSLOT(t + 2) + oct * 16;
+                        const uint4 v = gs_;   // zeros where out of range (load offset beyond the buffer)
+                        *reinterpret_cast<uint4*>(gs + (tl >> 2) * TR_REC) = v;
+                        if (do_db) {   // workgroup-uniform
+                            db8[0] += act_lo<TS>(v.x); db8[1] += act_hi<TS>(v.x); db8[2] += act_lo<TS>(v.y); db8[3] += act_hi<TS>(v.y);
+                            db8[4] += act_lo<TS>(v.z); db8[5] += act_hi<TS>(v.z); db8[6] += act_lo<TS>(v.w); db8[7] += act_hi<TS>(v.w);
+                        }
+                    }
+                    TR_STAMP(t - za, 1);
+                    {
+                        const int zx = t + 5;
+                        zin_ = zx >= za - 1 && zx <= zb && zx >= 0 && zx < D;   // wave-uniform
+                        if (zin_ && !(TEM_TR_ABL & 8)) {
+                            const tr_rsrc_t rsx = tr_rsrc(xn + zx * xplane);
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) xs_[q] = tr_load4u(rsx, offx[q]);
+                        }
+                        const int zg = t + 4;
+                        if (zg >= za && zg < zb && !(TEM_TR_ABL & 8)) {
+                            const tr_rsrc_t rsg = tr_rsrc(gn + zg * gplane);
+                            gs_ = tr_load4u(rsg, offg);
+                        }
+                    }
+                    TR_STAMP(t - za, 2);
+                    __syncthreads();
+                    TR_STAMP(t - za, 3);
+                };
+#pragma unroll 1
+                for (int t = za - 6; t < zb; t += 2) {
+                    iteration(t, xa[0], ga[0], zin[0]);
+                    if (t + 1 < zb) iteration(t + 1, xa[1], ga[1], zin[1]);
+                }
+            }
+        }
+        if (do_db) {   // bias-gradient partial of this workgroup: 64 threads per channel octet
+            float* red = reinterpret_cast<float*>(ldsb);  // [64][32]
+            if (!mteam) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) red[(tl >> 2) * 32 + oct * 8 + c] = db8[c];
+            }
+            __syncthreads();
+            if (tid < 32 && cog * 32 + tid < Cout) {
+                float a = 0.f;
+                for (int rr = 0; rr < 64; ++rr) a += red[rr * 32 + tid];
+                dbpart[(int64_t)sp * Cout + cog * 32 + tid] = a;
+            }
+        }
+        return;
+    } else
     if (!mteam) {
         // The staging waves share their SIMDs with the multiplying waves and get an issue slot every ~8 cycles (trace of the
         // first version: 250 instructions = 2000 - 2700 cycles per plane, the multiplying team waited for them).  So this
@@ -357,8 +498,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const float* __restric
             sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + quad * 4);
             sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + quad * 4);
         }
-        const float* const xn = x + (int64_t)n * D * H * W * x_ld;   // a load's resource starts at its z-plane: offsets stay
-        const float* const gn = g + (int64_t)n * D * H * W * g_ld;   // inside one plane (< 2 GiB, checked by the host side)
+        const TS* const xn = x + (int64_t)n * D * H * W * x_ld;   // a load's resource starts at its z-plane: offsets stay
+        const TS* const gn = g + (int64_t)n * D * H * W * g_ld;   // inside one plane (< 2 GiB, checked by the host side)
         const int64_t xplane = (int64_t)H * W * x_ld, gplane = (int64_t)H * W * g_ld;
         constexpr unsigned OOB = 0x80000000u;   // >= num_records of tr_rsrc: the load returns zeros
         for (int cz = sp % S; cz < ncz; cz += S) {
@@ -531,7 +672,20 @@ void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_
                            T, nY, nX, zsegs, Ss, ncz, gmax, g_amax);
     };
     constexpr size_t XT = TR_XT_OF(TR_REC16), GT = TR_GT_OF(TR_REC16);
-    if (h16 == 1) launch(&k_conv_wgrad_tr<1>, XT + GT);
+    auto launch16 = [&](auto kern, size_t lb, auto tag) {   // 16-bit x and g (the caller checked that the mode matches the type)
+        using TS = decltype(tag);
+        static std::set<const void*> sized;
+        const void* key = reinterpret_cast<const void*>(kern);
+        if (!sized.count(key)) {
+            (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            sized.insert(key);
+        }
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lb, s, reinterpret_cast<const TS*>(x), x_ld, scale, shift,
+                           reinterpret_cast<const TS*>(g), g_ld, zpart, zdb, N, D, H, W, Cin, Cout, T, nY, nX, zsegs, Ss, ncz, gmax, g_amax);
+    };
+    if (tem_call_st.x == 1) launch16(&k_conv_wgrad_tr<1, tem_f16>, XT + GT, tem_f16{});
+    else if (tem_call_st.x == 2) launch16(&k_conv_wgrad_tr<2, tem_bf16>, XT + GT, tem_bf16{});
+    else if (h16 == 1) launch(&k_conv_wgrad_tr<1>, XT + GT);
     else if (h16 == 2) launch(&k_conv_wgrad_tr<2>, XT + GT);
     else if (h16 == 3) launch(&k_conv_wgrad_tr<3>, 2 * XT + GT);
     else if (h16 == 4) launch(&k_conv_wgrad_tr<4>, (size_t)TR_XT_OF(128) + TR_GT_OF(128));

@@ -29,6 +29,7 @@
 #include "tem_common.h"
 #include "conv_internal.h"
 #include "conv_split.h"
+#include "tem_act.h"
 #include <type_traits>
 
 #ifndef TEM_ZR_PRIO
@@ -78,6 +79,34 @@ __device__ __forceinline__ void zr_store4(__amdgpu_buffer_rsrc_t r, unsigned vof
     // stored the x component of row m + 1 into row m, in 1-99 % of the launches depending on register allocation
     // (scripts/race_zr_store.py; 0 of 1000 with the offset in the VGPR).
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, AUX);
+}
+
+// 8-byte variants for 16-bit activation storage (4 channels per lane in the epilogue)
+__device__ __forceinline__ uint2 zr_load2u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned int u32x2z __attribute__((ext_vector_type(2)));
+    const u32x2z v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_uint2(v.x, v.y);
+}
+template <int AUX>
+__device__ __forceinline__ void zr_store2u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned a, unsigned b) {
+    typedef unsigned int u32x2z __attribute__((ext_vector_type(2)));
+    const u32x2z v = {a, b};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff + soff, 0, AUX);   // offset in the VGPR, as zr_store4
+}
+// pre-norm of two packed 16-bit activations: (h.lo * s0 + t0, h.hi * s1 + t1), computed in fp32, rounded once to the storage /
+// operand type.  fp16: v_fma_mix{lo,hi}_f16 read the fp16 operand by half and round into the selected half of the destination
+// (2 instructions; unpack + fma + pack would be 5).
+template <bool F16>
+__device__ __forceinline__ unsigned zr_norm2(unsigned h, float s0, float t0, float s1, float t1) {
+    if constexpr (F16) {
+        unsigned q;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(q) : "v"(h), "v"(s0), "v"(t0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(q) : "v"(h), "v"(s1), "v"(t1));
+        return q;
+    } else {
+        const float a = __builtin_bit_cast(float, h << 16), b = __builtin_bit_cast(float, h & 0xffff0000u);
+        return pk_bf16(fmaf(a, s0, t0), fmaf(b, s1, t1));
+    }
 }
 
 // value of lane ^ M (M < 32): ds_swizzle in bit mode needs no index register (a __shfl_xor keeps four of them live)
@@ -141,27 +170,39 @@ struct ZrUnit {
 // for a 268 MB input (32 -> 32 at 2 x 128^3), and the one-term kernel ran at the HBM ceiling (5.6 TB/s, 374 us; 274 us
 // with every load an L2 hit, TEM_ZR_ABL 64).  Here eight lanes request the whole line in one load instruction (two
 // requests for the halves, even back to back, still fetched 0.99 GB; half a phase apart 1.38 GB).
-template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false>
+// T (round 5): element type of x, ref and y in HBM.  A 16-bit T is the one-term mixed mode of the same type with WIDE staging
+// (fp16 storage <-> fp16 operands, bf16 <-> bf16): a 32-channel voxel record is 64 bytes, FOUR lanes request it with one
+// 16-byte load each (8 channels per lane, 3 load slots per thread and halo plane instead of 6), the pre-norm runs on the
+// packed pairs (zr_norm2) and ONE ds_write_b128 per slot fills the tile -- without a norm (data gradients) the loaded
+// registers go to LDS as they are.  Outputs are rounded once in the epilogue (8-byte pieces, 64-byte voxel rows); split-K
+// partial sums stay fp32.
+template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float>
 __global__ __launch_bounds__(512, 2) void k_conv_zr(
-    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
-    const uint4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
-    const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
+    const T* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint4* __restrict__ wp, const float* __restrict__ bias, std::conditional_t<KSPLIT, float, T>* __restrict__ y, int64_t y_ld,
+    const T* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
     int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax, int ks, int blk,
     unsigned* __restrict__ out_amax) {
     static_assert(!KSPLIT || MODE == 0, "split-K units write raw partial sums");
     constexpr bool AMAX = MODE == 2 || MODE == 3;   // data gradients: max |y| as a by-product (tem_arm_output_amax)
     float amx = 0.f;
     static_assert(!WIDE || NS == 2, "the wide one-term kernel uses the two LDS planes of the two-term layout");
+    constexpr bool T16 = sizeof(T) == 2;         // 16-bit activations in HBM
+    using TOut = std::conditional_t<KSPLIT, float, T>;
+    constexpr bool Y16 = sizeof(TOut) == 2;
+    constexpr int XB = (int)sizeof(T), YB = (int)sizeof(TOut);   // bytes per element of x / ref and of y
+    static_assert(!T16 || WIDE, "16-bit storage: 32 input channels per phase");
     constexpr int CK = WIDE ? 2 * BCK : BCK;     // input channels per phase
     constexpr int TZ = 4, TY = 16, TX = 8;
     constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     constexpr int HV = HZ * HY * HX;             // 1080 halo voxels
     constexpr int PLB = HV * 32;                 // bytes per plane of a team's tile (16 channels x 2 B per voxel)
     constexpr int NIT = HZ * 3;                  // float4 slots per thread: a ring of RP halo planes
-    constexpr int LPV = WIDE ? 8 : 4;            // lanes per halo voxel: one 16-byte load each (WIDE: a whole 128-byte line)
-    constexpr int SPP = WIDE ? 6 : 3;            // load slots per thread and halo plane (the last one only for part of the team)
+    constexpr int LPV = (WIDE && !T16) ? 8 : 4;  // lanes per halo voxel: one 16-byte load each (WIDE: a whole 128-byte line; 16-bit: the 64-byte record)
+    constexpr int SPP = (WIDE && !T16) ? 6 : 3;  // load slots per thread and halo plane (the last one only for part of the team)
+    constexpr int CPL = T16 ? 8 : 4;             // channels per load slot
     constexpr int RP = NIT / SPP;                // planes the register ring holds
-    constexpr int R0 = WIDE ? ((MODE == 1 || MODE == 3) ? 1 : 2)   // (a ring of three planes: at most two ahead; the statistics / norm-backward epilogues have no room for 12 loads)
+    constexpr int R0 = (WIDE && !T16) ? ((MODE == 1 || MODE == 3) ? 1 : 2)   // (a ring of three planes: at most two ahead; the statistics / norm-backward epilogues have no room for 12 loads)
                             : (TEM_ZR_R0 < HZ ? TEM_ZR_R0 : HZ);   // halo planes loaded before the epilogue
     constexpr int FR = NS * 64;                  // uint4s per (tap, 16-channel chunk) fragment group
     constexpr bool SC = F16 && NS == 2 && !WIDE;
@@ -228,18 +269,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     for (int j = 0; j < SPP; ++j) {
         const int q = min((tl + 256 * j) / LPV, HY * HX - 1);
         const int hy = q / HX, hx = q % HX;
-        poff[j] = ((unsigned)(hy * W + hx) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u;
-        lwj[j] = (unsigned)(q * 32) + (unsigned)(((((c4 >> 1) & 1) ^ (hy & 1)) << 4) | ((c4 & 1) << 3)) + (unsigned)((c4 >> 2) * PLB);
+        poff[j] = ((unsigned)(hy * W + hx) * (unsigned)x_ld + (unsigned)(c4 * CPL)) * (unsigned)XB;
+        if (T16)   // channels 8 c4 .. 8 c4 + 7: plane c4 >> 1, 16-byte half c4 & 1 (swizzled by the row parity)
+            lwj[j] = (unsigned)(q * 32) + (unsigned)((((c4 & 1) ^ (hy & 1)) << 4)) + (unsigned)((c4 >> 1) * PLB);
+        else
+            lwj[j] = (unsigned)(q * 32) + (unsigned)(((((c4 >> 1) & 1) ^ (hy & 1)) << 4) | ((c4 & 1) << 3)) + (unsigned)((c4 >> 2) * PLB);
     }
     const bool slot2 = tl < (HY * HX * LPV - 256 * (SPP - 1));   // the last slot exists for 208 (WIDE: 160) threads
-    const unsigned ctr_off = ((unsigned)(W + 1) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u;  // plane voxel (1, 1): always inside
-    const unsigned plane_b = (unsigned)(H * W) * (unsigned)x_ld * 4u;   // bytes between z-planes of x
+    const unsigned ctr_off = ((unsigned)(W + 1) * (unsigned)x_ld + (unsigned)(c4 * CPL)) * (unsigned)XB;  // plane voxel (1, 1): always inside
+    const unsigned plane_b = (unsigned)(H * W) * (unsigned)x_ld * (unsigned)XB;   // bytes between z-planes of x
     // tap loop: halo voxel of this lane's footprint voxel at (hz, ty, tx) = (0, 0, 0)
     const int hvb = (4 * tw + py) * HX + px;
     // epilogue: this lane owns voxel (py, px) of the wave's footprint and channels 8 j + 4 kh + (0..3), j = 0..3
     // (after the LDS transpose of the epilogue: voxel row 4 tw + m with m per store, x = lane >> 3, 16-byte piece lane & 7)
-    const unsigned yoff_lane = ((unsigned)(4 * tw * W + (lane >> 3)) * (unsigned)y_ld + (unsigned)(4 * (lane & 7))) * 4u;
-    const unsigned roff_lane = ((unsigned)(4 * tw * W + (lane >> 3)) * (unsigned)ref_ld + (unsigned)(4 * (lane & 7))) * 4u;
+    const unsigned yoff_lane = ((unsigned)(4 * tw * W + (lane >> 3)) * (unsigned)y_ld + (unsigned)(4 * (lane & 7))) * (unsigned)YB;
+    const unsigned roff_lane = ((unsigned)(4 * tw * W + (lane >> 3)) * (unsigned)ref_ld + (unsigned)(4 * (lane & 7))) * (unsigned)XB;
     const __amdgpu_buffer_rsrc_t rw = zr_rsrc(wp);
     const unsigned woff_lane = (unsigned)lane * 16u;
     const float act_floor = act == TEM_ACT_RELU ? 0.f : -__builtin_inff();
@@ -300,18 +344,23 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
             float4 tmp[NIT];
             unsigned inb[2] = {0xffffffffu, 0xffffffffu};   // validity of the slots of halo planes 0..2 / 3..5 (border patches)
             float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 sc5 = sc4, sf5 = sf4;   // 16-bit storage: channels 4 .. 7 of this thread's eight
             bool interior = true;
             __amdgpu_buffer_rsrc_t rx = zr_rsrc(x);
             if (do_stage) {
                 if (scale) {
-                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * 4);
-                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * 4);
+                    sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * CPL);
+                    sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * CPL);
+                    if (T16) {
+                        sc5 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * CPL + 4);
+                        sf5 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * CPL + 4);
+                    }
                 } else if (in_amax) {
                     sc4 = make_float4(psc, psc, psc, psc);
                 }
                 // the halo origin may lie outside the tensor for border patches (only in-range voxels are dereferenced)
-                const float* xb = x + ((((int64_t)cu.n * D + (cu.z0 - 1)) * H + (cu.y0 - 1)) * W + (cu.x0 - 1)) * x_ld +
-                                  (cu.ksl * nch + ci) * CK;
+                const T* xb = x + ((((int64_t)cu.n * D + (cu.z0 - 1)) * H + (cu.y0 - 1)) * W + (cu.x0 - 1)) * x_ld +
+                              (cu.ksl * nch + ci) * CK;
                 rx = zr_rsrc((TEM_ZR_ABL & 64) ? x + (cu.ksl * nch + ci) * CK : xb);   // timing experiment: every unit reads the halo at the origin (L2 hits)
                 interior = (cu.z0 >= 1) & (cu.z0 + HZ - 1 <= D) & (cu.y0 >= 1) & (cu.y0 + HY - 1 <= H) & (cu.x0 >= 1) &
                            (cu.x0 + HX - 1 <= W);
@@ -365,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                 const __amdgpu_buffer_rsrc_t ry = zr_rsrc(y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld + eu.cot * 32 +
                                                           (KSPLIT ? (int64_t)eu.ksl * ((int64_t)N * D * H * W * y_ld) : 0));
                 constexpr bool has_ref = MODE == 2 || MODE == 3;
-                const __amdgpu_buffer_rsrc_t rr_ = zr_rsrc(has_ref ? ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld + eu.cot * 32 : y);
+                const __amdgpu_buffer_rsrc_t rr_ = zr_rsrc(has_ref ? (const void*)(ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld + eu.cot * 32) : (const void*)y);
                 const bool full = (TEM_ZR_ABL & 32) ? true : ((eu.z0 + TZ <= D) & (eu.y0 + TY <= H) & (eu.x0 + TX <= W));
                 const bool vok = (eu.y0 + 4 * tw + py < H) & (eu.x0 + px < W);   // this lane's footprint voxel (any z)
                 if (SC) {   // fold the scaled cross products first: their 64 registers are free for the rest of the epilogue
@@ -416,7 +465,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
                             const bool ok = FULL || (tok_yx & (eu.y0 + 4 * tw + m < H) & (eu.z0 + z < D));
-                            q[z & 1][m] = zr_load4(rr_, ok ? roff_l : 0u, ok ? (zo + (unsigned)(m * W)) * (unsigned)ref_ld * 4u : 0u);
+                            if constexpr (T16) {   // 8 bytes: this lane's 4 channels of ref
+                                const uint2 rq = zr_load2u(rr_, ok ? roff_l : 0u, ok ? (zo + (unsigned)(m * W)) * (unsigned)ref_ld * (unsigned)XB : 0u);
+                                q[z & 1][m] = make_float4(act_lo<T>(rq.x), act_hi<T>(rq.x), act_lo<T>(rq.y), act_hi<T>(rq.y));
+                            } else
+                                q[z & 1][m] = zr_load4(rr_, ok ? roff_l : 0u, ok ? (zo + (unsigned)(m * W)) * (unsigned)ref_ld * 4u : 0u);
                         }
                     };
                     if (HASREF) load_ref(0);
@@ -432,6 +485,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                             for (int c = 0; c < 4; ++c) {
                                 const int i = 4 * j + c;
                                 asm("v_max_f32 %0, %1, %2" : "=v"(o[c]) : "v"(acc[z][i]), "v"(act_floor));   // fmaxf() costs a canonicalising v_max first
+                            }
+                            if constexpr (Y16 && STAT) {   // the statistics describe the tensor AS STORED: round here (the store's rounding is then exact)
+                                const unsigned p0 = act_pk<TOut>(o[0], o[1]), p1 = act_pk<TOut>(o[2], o[3]);
+                                o[0] = act_lo<TOut>(p0); o[1] = act_hi<TOut>(p0); o[2] = act_lo<TOut>(p1); o[3] = act_hi<TOut>(p1);
                             }
                             if (STAT) {
 #pragma unroll
@@ -463,7 +520,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                             }
                             const bool sok = FULL || (tok_yx & (eu.y0 + 4 * tw + m < H) & (eu.z0 + z < D));
                             if (AMAX && sok) amx = tem_amax4(amx, t[m].x, t[m].y, t[m].z, t[m].w);
-                            if (sok && (!(TEM_ZR_ABL & 2) || t[m].x == 12345.678f))
+                            if constexpr (Y16) {
+                                if (sok && (!(TEM_ZR_ABL & 2) || t[m].x == 12345.678f))
+                                    zr_store2u<TEM_ZR_ST_AUX>(ry, yoff_l, (zo + (unsigned)(m * W)) * (unsigned)y_ld * (unsigned)YB,
+                                                              act_pk<TOut>(t[m].x, t[m].y), act_pk<TOut>(t[m].z, t[m].w));
+                            } else if (sok && (!(TEM_ZR_ABL & 2) || t[m].x == 12345.678f))
                                 zr_store4<KSPLIT ? TEM_ZR_ST_AUX_KS : TEM_ZR_ST_AUX>(ry, yoff_l, (zo + (unsigned)(m * W)) * (unsigned)y_ld * 4u, t[m].x, t[m].y, t[m].z, t[m].w);
                         }
                     }
@@ -556,6 +617,23 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
 #pragma unroll
                     for (int j = 0; j < SPP; ++j) {
                         const int it = (hz % RP) * SPP + j;
+                        if constexpr (T16) {
+                            if (j < SPP - 1 || slot2) {
+                                u32x4z raw = __builtin_bit_cast(u32x4z, floatx4z{tmp[it].x, tmp[it].y, tmp[it].z, tmp[it].w});
+                                if (scale) {   // launch-uniform; without a norm the operands ARE the stored values
+                                    raw.x = zr_norm2<F16>(raw.x, sc4.x, sf4.x, sc4.y, sf4.y);
+                                    raw.y = zr_norm2<F16>(raw.y, sc4.z, sf4.z, sc4.w, sf4.w);
+                                    raw.z = zr_norm2<F16>(raw.z, sc5.x, sf5.x, sc5.y, sf5.y);
+                                    raw.w = zr_norm2<F16>(raw.w, sc5.z, sf5.z, sc5.w, sf5.w);
+                                }
+                                if (!INTERIOR) {   // zero padding comes after the norm (model/unet.py:429-438)
+                                    const bool ok = ((inb[hz / 3] >> ((hz % 3) * SPP + j)) & 1u) != 0;
+                                    raw.x = ok ? raw.x : 0u; raw.y = ok ? raw.y : 0u; raw.z = ok ? raw.z : 0u; raw.w = ok ? raw.w : 0u;
+                                }
+                                if (!(TEM_ZR_ABL & 8) || raw.x == 0x12345678u)
+                                    *reinterpret_cast<uint4*>(lds + lwj[j] + hz * ZSTEP) = make_uint4(raw.x, raw.y, raw.z, raw.w);
+                            }
+                        } else
                         if (j < SPP - 1 || slot2) {
                             float m = 1.f;
                             if (!INTERIOR) m = ((inb[hz / 3] >> ((hz % 3) * SPP + j)) & 1u) ? 1.f : 0.f;   // zero padding comes after the norm (model/unet.py:429-438)
@@ -743,6 +821,7 @@ static ZrGeom zr_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7)) return g;
     if (!(kd == 3 && kh == 3 && kw == 3)) return g;
     if (D < 4 || Cin % 16 || Cout % 32) return g;
+    if (tem_call_st.x && (Cin % 32 || !(nsplit == 5 || nsplit == 7))) return g;   // 16-bit storage: whole 64-byte records per phase
     if ((int64_t)H * W * 8 * 4 * max_ld >= (1ll << 31)) return g;   // 32-bit byte offsets inside one halo / one patch
     static int ncu = 0;
     if (!ncu) {
@@ -773,13 +852,16 @@ static int zr_tile_blocks(const ZrGeom& g) {
     return lg(g.nX) | (lg(g.nY) << 4) | (lg(g.nZ) << 8);
 }
 
-template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false>
-static void zr_launch(const ZrGeom& g, const float* x, int64_t x_ld, const float* scale, const float* shift, const float* wp,
-                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, int N, int D, int H, int W,
+template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float>
+static void zr_launch(const ZrGeom& g, const float* x_, int64_t x_ld, const float* scale, const float* shift, const float* wp,
+                      const float* bias, float* y_, int64_t y_ld, const float* ref_, int64_t ref_ld, int N, int D, int H, int W,
                       int Cin, int Cout, int act, float* stat, const unsigned* in_amax, hipStream_t s, int ks = 1) {
     constexpr size_t ldsb = (size_t)2 * NS * 1080 * 32 + 4 * 32 * 144;   // two tiles + the epilogue's transpose scratch
     static_assert(ldsb <= 160 * 1024, "LDS budget");
-    auto kern = &k_conv_zr<NS, F16, MODE, KSPLIT, WIDE>;
+    const T* x = reinterpret_cast<const T*>(x_);
+    const T* ref = reinterpret_cast<const T*>(ref_);
+    auto* y = reinterpret_cast<std::conditional_t<KSPLIT, float, T>*>(y_);
+    auto kern = &k_conv_zr<NS, F16, MODE, KSPLIT, WIDE, T>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
@@ -811,6 +893,8 @@ int tem_conv_zr_splitk_ks(int N, int D, int H, int W, int Cin, int Cout, int kd,
     if (opt == 0 || opt == 1 || !tem_option(TEM_OPT_ZR_SPLITK)) return 0;
     if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7)) return 0;
     if (!(kd == 3 && kh == 3 && kw == 3) || D < 4 || Cin % 16 || Cout % 32) return 0;
+    const bool t16 = tem_call_st.x != 0;   // 16-bit storage: slices of whole 32-channel chunks
+    if (t16 && (Cin % 32 || !(nsplit == 5 || nsplit == 7))) return 0;
     if (zr_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, 1).ok) return 0;
     if (tem_conv_pp_tiles(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit)) return 0;
     static int ncu = 0;
@@ -824,7 +908,7 @@ int tem_conv_zr_splitk_ks(int N, int D, int H, int W, int Cin, int Cout, int kd,
     const int64_t units = (int64_t)N * nZ * nY * nX * (Cout / 32);
     const int nch = Cin / 16;
     for (int d = 2; d <= nch / 2; ++d)
-        if (nch % d == 0 && units * d >= 2ll * ncu) return d;
+        if (nch % d == 0 && units * d >= 2ll * ncu && !(t16 && (nch / d) % 2)) return d;
     return 0;
 }
 
@@ -851,8 +935,14 @@ int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, con
 #define ZRKS(NS, F16, WIDE)                                                                                            \
     zr_launch<NS, F16, 0, true, WIDE>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,  \
                                       TEM_ACT_NONE, nullptr, nullptr, s, ks)
-    const bool wide = (nsplit == 5 || nsplit == 7) && (Cin / 16 / ks) % 2 == 0 && tem_option(TEM_OPT_ZR_WIDE);   // slices of whole 32-channel chunks
-    if (nsplit == 5 && wide) ZRKS(2, true, true);
+    const bool wide = (nsplit == 5 || nsplit == 7) && (Cin / 16 / ks) % 2 == 0 && (tem_option(TEM_OPT_ZR_WIDE) || tem_call_st.x);   // slices of whole 32-channel chunks
+    if (tem_call_st.x == 1)
+        zr_launch<2, true, 0, true, true, tem_f16>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,
+                                                   TEM_ACT_NONE, nullptr, nullptr, s, ks);
+    else if (tem_call_st.x == 2)
+        zr_launch<2, false, 0, true, true, tem_bf16>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,
+                                                     TEM_ACT_NONE, nullptr, nullptr, s, ks);
+    else if (nsplit == 5 && wide) ZRKS(2, true, true);
     else if (nsplit == 7 && wide) ZRKS(2, false, true);
     else if (nsplit == 5) ZRKS(1, true, false);
     else if (nsplit == 7) ZRKS(1, false, false);
@@ -932,6 +1022,22 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
     }
     // one-term modes: 32 channels per phase whenever the channel count allows it (whole 128-byte lines per staging phase)
     const bool wide = (nsplit == 5 || nsplit == 7) && Cin % 32 == 0 && tem_option(TEM_OPT_ZR_WIDE);
+#define ZRGO16(F16, T)                                                                                                        \
+    do {                                                                                                                      \
+        if (stat)                                                                                                             \
+            zr_launch<2, F16, 1, false, true, T>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+        else if (ref && rcoef)                                                                                                \
+            zr_launch<2, F16, 3, false, true, T>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act,        \
+                                  const_cast<float*>(rcoef), in_amax, s);                                                     \
+        else if (ref)                                                                                                         \
+            zr_launch<2, F16, 2, false, true, T>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+        else                                                                                                                  \
+            zr_launch<2, F16, 0, false, true, T>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+    } while (0)
+    if (tem_call_st.x == 1) ZRGO16(true, tem_f16);
+    else if (tem_call_st.x == 2) ZRGO16(false, tem_bf16);
+    else
+#undef ZRGO16
     if (nsplit == 5 && wide) ZRGO(2, true, true);
     else if (nsplit == 7 && wide) ZRGO(2, false, true);
     else if (nsplit == 5) ZRGO(1, true, false);

@@ -5,35 +5,39 @@
 // read of x instead of read+write+read).  All reductions are two-stage and
 // deterministic: fp32 per-thread partials -> fp32 per-block partials -> fp64 merge.
 #include "tem_common.h"
+#include "tem_act.h"
 
 #define NORM_MAX_BLOCKS 512
 #ifndef TEM_NORM_NT
 #define TEM_NORM_NT 1   // nontemporal loads / stores in the backward apply pass (streams 3 tensors once): -0.1 ms/step
 #endif
-typedef float floatx4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 nt_load4(const float* p) {
-    floatx4_t v = __builtin_nontemporal_load(reinterpret_cast<const floatx4_t*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void nt_store4(float* p, float4 v) {
-    floatx4_t t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<floatx4_t*>(p));
-}
 #ifndef TEM_NORM_NT2
 #define TEM_NORM_NT2 0
 #endif
+template <typename T> __device__ __forceinline__ float4 nt2_load4(const T* p) {
 #if TEM_NORM_NT2
-#define NT2_LOAD4(p) nt_load4(p)
+    return act_ld4_nt(p);
 #else
-#define NT2_LOAD4(p) (*reinterpret_cast<const float4*>(p))
+    return act_ld4(p);
 #endif
+}
+template <typename T> __device__ __forceinline__ float4 nt_load4(const T* p) {
 #if TEM_NORM_NT
+    return act_ld4_nt(p);
+#else
+    return act_ld4(p);
+#endif
+}
+template <typename T> __device__ __forceinline__ void nt_store4(T* p, float4 v) {
+#if TEM_NORM_NT
+    act_st4_nt(p, v);
+#else
+    act_st4(p, v);
+#endif
+}
+#define NT2_LOAD4(p) nt2_load4(p)
 #define NT_LOAD4(p) nt_load4(p)
 #define NT_STORE4(p, v) nt_store4(p, v)
-#else
-#define NT_LOAD4(p) (*reinterpret_cast<const float4*>(p))
-#define NT_STORE4(p, v) (*reinterpret_cast<float4*>(p) = (v))
-#endif
 #define NORM_MAX_C 1024
 
 struct NormGeom {
@@ -45,9 +49,10 @@ struct NormGeom {
     int64_t vper;  // voxels per block
 };
 
-static NormGeom norm_geom(const void* p0, const void* p1, int64_t ld0, int64_t ld1, int64_t V, int C) {
+static NormGeom norm_geom(const void* p0, const void* p1, int64_t ld0, int64_t ld1, int64_t V, int C, int st = 0) {
     NormGeom g;
-    bool al = ((uintptr_t)p0 % 16 == 0) && (p1 == nullptr || (uintptr_t)p1 % 16 == 0);
+    const uintptr_t a4 = tem_st_align4(st);
+    bool al = ((uintptr_t)p0 % a4 == 0) && (p1 == nullptr || (uintptr_t)p1 % a4 == 0);
     g.vec = (C % 4 == 0 && ld0 % 4 == 0 && (p1 == nullptr || ld1 % 4 == 0) && al) ? 4 : 1;
     g.cq = C / g.vec;
     g.rows = 256 / g.cq;
@@ -70,9 +75,9 @@ extern "C" int64_t tem_norm_ws(int N, int64_t V, int C) {
 // ---------------------------------------------------------------------------
 // stage 1: per-block partial sums.  MODE 0: (sum x, sum x^2); MODE 1: (sum g, sum g*xn)
 // ---------------------------------------------------------------------------
-template <int VEC, int MODE>
-__global__ __launch_bounds__(VEC == 4 ? 256 : 1024) void k_norm_partial(const float* __restrict__ x, int64_t x_ld,
-                                                       const float* __restrict__ g, int64_t g_ld, int64_t V, int C,
+template <int VEC, int MODE, typename T>
+__global__ __launch_bounds__(VEC == 4 ? 256 : 1024) void k_norm_partial(const T* __restrict__ x, int64_t x_ld,
+                                                       const T* __restrict__ g, int64_t g_ld, int64_t V, int C,
                                                        int G, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, int cq, int rows, int64_t vper,
                                                        float* __restrict__ part) {
@@ -100,8 +105,8 @@ __global__ __launch_bounds__(VEC == 4 ? 256 : 1024) void k_norm_partial(const fl
             rs[j] = rstd[n * G + grp];
         }
     }
-    const float* xb = x + (int64_t)n * V * x_ld;
-    const float* gb = (MODE == 1) ? g + (int64_t)n * V * g_ld : nullptr;
+    const T* xb = x + (int64_t)n * V * x_ld;
+    const T* gb = (MODE == 1) ? g + (int64_t)n * V * g_ld : nullptr;
     int64_t vs = v0 + r;
     if constexpr (VEC == 4) {
         // four voxels per trip: 4 (MODE 0) / 8 (MODE 1) independent 16-byte loads in flight per thread
@@ -133,15 +138,15 @@ __global__ __launch_bounds__(VEC == 4 ? 256 : 1024) void k_norm_partial(const fl
     for (int64_t v = vs; v < v1; v += rows) {
         float xv[VEC], gv[VEC];
         if constexpr (VEC == 4) {
-            float4 t = *reinterpret_cast<const float4*>(xb + v * x_ld + c0);
+            float4 t = act_ld4(xb + v * x_ld + c0);
             xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
             if constexpr (MODE == 1) {
-                float4 u = *reinterpret_cast<const float4*>(gb + v * g_ld + c0);
+                float4 u = act_ld4(gb + v * g_ld + c0);
                 gv[0] = u.x; gv[1] = u.y; gv[2] = u.z; gv[3] = u.w;
             }
         } else {
-            xv[0] = xb[v * x_ld + c0];
-            if constexpr (MODE == 1) gv[0] = gb[v * g_ld + c0];
+            xv[0] = act_ld1(xb + v * x_ld + c0);
+            if constexpr (MODE == 1) gv[0] = act_ld1(gb + v * g_ld + c0);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -337,19 +342,19 @@ __global__ __launch_bounds__(256) void k_norm_bwd_affine(const float* __restrict
 // so the per-wave "read the word, atomicMax if larger" of the long kernels degenerates into one atomic per wave on one
 // address (~10 ns each: 8192 waves cost +80 us, measured).  With amax the launcher uses 1024-thread blocks and at most 256
 // of them; a block reduces in LDS and issues ONE atomic.
-template <int VEC>
-__global__ __launch_bounds__(1024) void k_norm_bwd_apply(const float* __restrict__ gy, int64_t gy_ld,
-                                                         const float* __restrict__ x, int64_t x_ld,
-                                                         float* __restrict__ gx, int64_t gx_ld, int64_t V, int C,
+template <int VEC, typename T>
+__global__ __launch_bounds__(1024) void k_norm_bwd_apply(const T* __restrict__ gy, int64_t gy_ld,
+                                                         const T* __restrict__ x, int64_t x_ld,
+                                                         T* __restrict__ gx, int64_t gx_ld, int64_t V, int C,
                                                          const float* __restrict__ coef, int relu_mask,
                                                          unsigned* __restrict__ amax) {
     __shared__ unsigned smax[16];
     const int n = blockIdx.y;
     const int cq = C / VEC;
     const int64_t items = V * cq;
-    const float* gb = gy + (int64_t)n * V * gy_ld;
-    const float* xb = x + (int64_t)n * V * x_ld;
-    float* ob = gx + (int64_t)n * V * gx_ld;
+    const T* gb = gy + (int64_t)n * V * gy_ld;
+    const T* xb = x + (int64_t)n * V * x_ld;
+    T* ob = gx + (int64_t)n * V * gx_ld;
     const float* cf = coef + (int64_t)n * C * 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t dv = stride / cq;
@@ -403,8 +408,8 @@ __global__ __launch_bounds__(1024) void k_norm_bwd_apply(const float* __restrict
             }
             const int c0 = q * VEC;
             if constexpr (VEC == 4) {
-                float4 g4 = *reinterpret_cast<const float4*>(gb + v * gy_ld + c0);
-                float4 x4 = *reinterpret_cast<const float4*>(xb + v * x_ld + c0);
+                float4 g4 = act_ld4(gb + v * gy_ld + c0);
+                float4 x4 = act_ld4(xb + v * x_ld + c0);
                 float gv[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w}, ov[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -413,14 +418,14 @@ __global__ __launch_bounds__(1024) void k_norm_bwd_apply(const float* __restrict
                     ov[j] = (relu_mask && !(xv[j] > 0.f)) ? 0.f : r;
                 }
                 amx = tem_amax4(amx, ov[0], ov[1], ov[2], ov[3]);
-                *reinterpret_cast<float4*>(ob + v * gx_ld + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                act_st4(ob + v * gx_ld + c0, make_float4(ov[0], ov[1], ov[2], ov[3]));
             } else {
-                float gv = gb[v * gy_ld + c0], xv = xb[v * x_ld + c0];
+                float gv = act_ld1(gb + v * gy_ld + c0), xv = act_ld1(xb + v * x_ld + c0);
                 float4 k = *reinterpret_cast<const float4*>(cf + (int64_t)c0 * 4);
                 float r = k.x * gv - k.y - (xv - k.w) * k.z;
                 r = (relu_mask && !(xv > 0.f)) ? 0.f : r;
                 amx = __builtin_fmaxf(amx, __builtin_fabsf(r));
-                ob[v * gx_ld + c0] = r;
+                act_st1(ob + v * gx_ld + c0, r);
             }
         }
     }
@@ -437,30 +442,43 @@ __global__ __launch_bounds__(1024) void k_norm_bwd_apply(const float* __restrict
     }
 }
 
-extern "C" int tem_norm_stats(const float* x, int64_t x_ld, int N, int64_t V, int C, int G, const float* gamma,
-                              const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
-                              void* ws, int64_t ws_bytes, tem_stream_t stream) {
+static int norm_stats_impl(const void* x, int64_t x_ld, int N, int64_t V, int C, int G, const float* gamma,
+                           const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                           void* ws, int64_t ws_bytes, int st, tem_stream_t stream) {
     TEM_REQUIRE(x && mean && rstd && scale && shift && ws, "tem_norm_stats: null pointer");
+    TEM_REQUIRE(st >= 0 && st <= 2, "tem_norm_stats: unknown storage type %d", st);
     TEM_REQUIRE(N > 0 && V > 0 && C > 0 && C <= NORM_MAX_C && x_ld >= C, "tem_norm_stats: bad shape (C=%d)", C);
     TEM_REQUIRE(G > 0 && C % G == 0, "tem_norm_stats: C=%d not divisible by G=%d", C, G);
     if (ws_bytes < tem_norm_ws(N, V, C)) {
         tem_set_error("tem_norm_stats: workspace too small");
         return TEM_EWS;
     }
-    NormGeom g = norm_geom(x, nullptr, x_ld, 0, V, C);
+    NormGeom g = norm_geom(x, nullptr, x_ld, 0, V, C, st);
     float* part = (float*)ws;
     size_t lds = (size_t)g.rows * C * 2 * sizeof(float);
     dim3 grid(g.nblk, N);
-    if (g.vec == 4)
-        hipLaunchKernelGGL((k_norm_partial<4, 0>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, nullptr,
-                           (int64_t)0, V, C, G, nullptr, nullptr, g.cq, g.rows, g.vper, part);
-    else
-        hipLaunchKernelGGL((k_norm_partial<1, 0>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, nullptr,
-                           (int64_t)0, V, C, G, nullptr, nullptr, g.cq, g.rows, g.vper, part);
+    TEM_ST_SWITCH(st, T, {
+        if (g.vec == 4)
+            hipLaunchKernelGGL((k_norm_partial<4, 0, T>), grid, dim3(g.threads), lds, (hipStream_t)stream, (const T*)x, x_ld,
+                               (const T*)nullptr, (int64_t)0, V, C, G, nullptr, nullptr, g.cq, g.rows, g.vper, part);
+        else
+            hipLaunchKernelGGL((k_norm_partial<1, 0, T>), grid, dim3(g.threads), lds, (hipStream_t)stream, (const T*)x, x_ld,
+                               (const T*)nullptr, (int64_t)0, V, C, G, nullptr, nullptr, g.cq, g.rows, g.vper, part);
+    });
     hipLaunchKernelGGL(k_norm_finalize, dim3(N * G), dim3(norm_finalize_threads(g.nblk, C / G)), 0, (hipStream_t)stream, part,
                        g.nblk, V, C, G, gamma, beta, eps, mean, rstd, scale, shift);
     TEM_CHECK_LAUNCH("tem_norm_stats");
     return TEM_OK;
+}
+extern "C" int tem_norm_stats(const float* x, int64_t x_ld, int N, int64_t V, int C, int G, const float* gamma,
+                              const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                              void* ws, int64_t ws_bytes, tem_stream_t stream) {
+    return norm_stats_impl(x, x_ld, N, V, C, G, gamma, beta, eps, mean, rstd, scale, shift, ws, ws_bytes, 0, stream);
+}
+extern "C" int tem_norm_stats_st(const void* x, int64_t x_ld, int N, int64_t V, int C, int G, const float* gamma,
+                                 const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                                 void* ws, int64_t ws_bytes, int st, tem_stream_t stream) {
+    return norm_stats_impl(x, x_ld, N, V, C, G, gamma, beta, eps, mean, rstd, scale, shift, ws, ws_bytes, st, stream);
 }
 
 // Second stage only: the per-(sample, block, channel) partial sums (sum x, sum x^2) were written by the producer of x
@@ -496,11 +514,12 @@ extern "C" int tem_norm_finalize_partials2(const float* partA, int64_t nblkA, in
     return TEM_OK;
 }
 
-static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C,
-                         int G, const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx,
+static int norm_bwd_impl(const void* gy, int64_t gy_ld, const void* x, int64_t x_ld, int N, int64_t V, int C,
+                         int G, const float* gamma, const float* mean, const float* rstd, int relu_mask, void* gx,
                          int64_t gx_ld, float* dgamma, float* dbeta, const float* sums, float* coef_out, void* ws,
-                         int64_t ws_bytes, tem_stream_t stream, int64_t sums_nblk = 1) {
+                         int64_t ws_bytes, tem_stream_t stream, int64_t sums_nblk, unsigned* amax, int st) {
     TEM_REQUIRE(gy && x && mean && rstd && (gx || coef_out) && ws, "tem_norm_bwd: null pointer");
+    TEM_REQUIRE(st >= 0 && st <= 2, "tem_norm_bwd: unknown storage type %d", st);
     TEM_REQUIRE(sums_nblk >= 1 && sums_nblk < (1ll << 24), "tem_norm_bwd: bad number of partial rows");
     if (coef_out) gx_ld = C;
     TEM_REQUIRE(N > 0 && V > 0 && C > 0 && C <= NORM_MAX_C && x_ld >= C && gy_ld >= C && gx_ld >= C,
@@ -510,7 +529,7 @@ static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t
         tem_set_error("tem_norm_bwd: workspace too small");
         return TEM_EWS;
     }
-    NormGeom g = norm_geom(x, gy, x_ld, gy_ld, V, C);
+    NormGeom g = norm_geom(x, gy, x_ld, gy_ld, V, C, st);
     float* part = (float*)ws;
     float* coef = coef_out ? coef_out : part + (int64_t)N * NORM_MAX_BLOCKS * C * 2;
     size_t lds = (size_t)g.rows * C * 2 * sizeof(float);
@@ -519,12 +538,16 @@ static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t
     if (sums) {  // first stage delivered by the weight gradient (tem_conv3d_wgrad_sums): [N][1][C][2]
         part = const_cast<float*>(sums);
         nblk = (int)sums_nblk;   // [N][sums_nblk][C][2]; 1 for the weight gradient's sums
-    } else if (g.vec == 4)
-        hipLaunchKernelGGL((k_norm_partial<4, 1>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, gy, gy_ld,
-                           V, C, G, mean, rstd, g.cq, g.rows, g.vper, part);
-    else
-        hipLaunchKernelGGL((k_norm_partial<1, 1>), grid, dim3(g.threads), lds, (hipStream_t)stream, x, x_ld, gy, gy_ld,
-                           V, C, G, mean, rstd, g.cq, g.rows, g.vper, part);
+    } else {
+        TEM_ST_SWITCH(st, T, {
+            if (g.vec == 4)
+                hipLaunchKernelGGL((k_norm_partial<4, 1, T>), grid, dim3(g.threads), lds, (hipStream_t)stream, (const T*)x, x_ld,
+                                   (const T*)gy, gy_ld, V, C, G, mean, rstd, g.cq, g.rows, g.vper, part);
+            else
+                hipLaunchKernelGGL((k_norm_partial<1, 1, T>), grid, dim3(g.threads), lds, (hipStream_t)stream, (const T*)x, x_ld,
+                                   (const T*)gy, gy_ld, V, C, G, mean, rstd, g.cq, g.rows, g.vper, part);
+        });
+    }
     hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(N * G), dim3(256), 0, (hipStream_t)stream, part, nblk, V, C, G,
                        gamma, mean, rstd, coef);
     if (dgamma || dbeta)
@@ -534,20 +557,22 @@ static int norm_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t
         TEM_CHECK_LAUNCH("tem_norm_bwd_coef");
         return TEM_OK;
     }
-    bool v4 = (C % 4 == 0) && gy_ld % 4 == 0 && x_ld % 4 == 0 && gx_ld % 4 == 0 && (uintptr_t)gy % 16 == 0 &&
-              (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0;
+    const uintptr_t a4 = tem_st_align4(st);
+    bool v4 = (C % 4 == 0) && gy_ld % 4 == 0 && x_ld % 4 == 0 && gx_ld % 4 == 0 && (uintptr_t)gy % a4 == 0 &&
+              (uintptr_t)x % a4 == 0 && (uintptr_t)gx % a4 == 0;
     int64_t items = V * (v4 ? C / 4 : C);
     dim3 agrid(tem_grid_1d(items, 256, 2048), N);
-    // gx is what a weight gradient reads next: max |gx| as a by-product when armed (one atomic per 1024-thread block, see the kernel)
-    unsigned* const amax = tem_take_output_amax();
+    // gx is what a weight gradient reads next: max |gx| as a by-product when asked for (one atomic per 1024-thread block, see the kernel)
     const int threads = amax ? 1024 : 256;
     if (amax) agrid = dim3(tem_grid_1d(items, 1024, N > 0 ? (256 + N - 1) / N : 256), N);
-    if (v4)
-        hipLaunchKernelGGL((k_norm_bwd_apply<4>), agrid, dim3(threads), 0, (hipStream_t)stream, gy, gy_ld, x, x_ld, gx,
-                           gx_ld, V, C, coef, relu_mask, amax);
-    else
-        hipLaunchKernelGGL((k_norm_bwd_apply<1>), agrid, dim3(threads), 0, (hipStream_t)stream, gy, gy_ld, x, x_ld, gx,
-                           gx_ld, V, C, coef, relu_mask, amax);
+    TEM_ST_SWITCH(st, T, {
+        if (v4)
+            hipLaunchKernelGGL((k_norm_bwd_apply<4, T>), agrid, dim3(threads), 0, (hipStream_t)stream, (const T*)gy, gy_ld,
+                               (const T*)x, x_ld, (T*)gx, gx_ld, V, C, coef, relu_mask, amax);
+        else
+            hipLaunchKernelGGL((k_norm_bwd_apply<1, T>), agrid, dim3(threads), 0, (hipStream_t)stream, (const T*)gy, gy_ld,
+                               (const T*)x, x_ld, (T*)gx, gx_ld, V, C, coef, relu_mask, amax);
+    });
     TEM_CHECK_LAUNCH("tem_norm_bwd");
     return TEM_OK;
 }
@@ -557,7 +582,7 @@ extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int6
                             int64_t gx_ld, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
                             tem_stream_t stream) {
     return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, nullptr,
-                         nullptr, ws, ws_bytes, stream);
+                         nullptr, ws, ws_bytes, stream, 1, tem_take_output_amax(), 0);
 }
 
 // tem_norm_bwd whose first stage -- sums[n][c] = (sum_v gy, sum_v gy * xn) -- was delivered by tem_conv3d_wgrad_sums
@@ -567,7 +592,7 @@ extern "C" int tem_norm_bwd_from_sums(const float* gy, int64_t gy_ld, const floa
                                       const float* sums, void* ws, int64_t ws_bytes, tem_stream_t stream) {
     TEM_REQUIRE(sums, "tem_norm_bwd_from_sums: null sums");
     return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, sums,
-                         nullptr, ws, ws_bytes, stream);
+                         nullptr, ws, ws_bytes, stream, 1, tem_take_output_amax(), 0);
 }
 
 // ... was delivered as partial rows part[N][nblk][C][2] by the data gradient that wrote gy (tem_arm_dgrad_norm_sums)
@@ -578,7 +603,7 @@ extern "C" int tem_norm_bwd_from_partials(const float* gy, int64_t gy_ld, const 
                                           tem_stream_t stream) {
     TEM_REQUIRE(part && (gx || coef), "tem_norm_bwd_from_partials: null pointer");
     return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, coef ? nullptr : gx, gx_ld, dgamma, dbeta,
-                         part, coef, ws, ws_bytes, stream, nblk);
+                         part, coef, ws, ws_bytes, stream, nblk, coef ? nullptr : tem_take_output_amax(), 0);
 }
 
 // Reduction stage only: coef[n][c] = {a, m1, m2r, mean} with gx = a*gy - m1 - (x - mean)*m2r (and dgamma / dbeta).  The
@@ -591,5 +616,19 @@ extern "C" int tem_norm_bwd_coef(const float* gy, int64_t gy_ld, const float* x,
                                  tem_stream_t stream) {
     TEM_REQUIRE(coef, "tem_norm_bwd_coef: null coef");
     return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, 0, nullptr, C, dgamma, dbeta, sums, coef, ws,
-                         ws_bytes, stream);
+                         ws_bytes, stream, 1, nullptr, 0);
+}
+
+// All of the above for tensors of storage type st, every variant as explicit arguments:
+//   part / part_nblk : first stage rows [N][part_nblk][C][2] delivered by a producer (tem_conv3d_wgrad_ex: 1 row;
+//                      tem_conv3d_fwd_ex norm sums: its nblk) or NULL = reduce gy and x here;
+//   coef_out         : non-NULL = reduction only, write coef[N][C][4] (gx is not touched, may be NULL);
+//   out_amax         : optional device word that receives max |gx| (see tem_maxpool3d_bwd_st).
+extern "C" int tem_norm_bwd_st(const void* gy, int64_t gy_ld, const void* x, int64_t x_ld, int N, int64_t V, int C, int G,
+                               const float* gamma, const float* mean, const float* rstd, int relu_mask, void* gx,
+                               int64_t gx_ld, float* dgamma, float* dbeta, const float* part, int64_t part_nblk,
+                               float* coef_out, unsigned* out_amax, void* ws, int64_t ws_bytes, int st, tem_stream_t stream) {
+    return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, coef_out ? 0 : relu_mask, coef_out ? nullptr : gx,
+                         coef_out ? C : gx_ld, dgamma, dbeta, part, coef_out, ws, ws_bytes, stream, part ? part_nblk : 1,
+                         coef_out ? nullptr : out_amax, st);
 }

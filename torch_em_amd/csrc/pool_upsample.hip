@@ -3,6 +3,7 @@
 // HBM-bound streaming kernels: one workgroup per output row (n, z, y), threads
 // sweep (x, channel-quad) so every access is a coalesced 16-byte vector.
 #include "tem_common.h"
+#include "tem_act.h"
 
 template <int VEC>
 struct VecT;
@@ -18,34 +19,33 @@ struct VecT<1> {
 #ifndef TEM_POOL_NT
 #define TEM_POOL_NT 0
 #endif
-template <int VEC>
-__device__ __forceinline__ void ld_vec(const float* p, float (&v)[VEC]) {
+template <int VEC, typename T>
+__device__ __forceinline__ void ld_vec(const T* p, float (&v)[VEC]) {
     if constexpr (VEC == 4) {
-        float4 t = *reinterpret_cast<const float4*>(p);
+        const float4 t = act_ld4(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
-        v[0] = *p;
+        v[0] = act_ld1(p);
     }
 }
-template <int VEC>
-__device__ __forceinline__ void st_vec(float* p, const float (&v)[VEC]) {
+template <int VEC, typename T>
+__device__ __forceinline__ void st_vec(T* p, const float (&v)[VEC]) {
     if constexpr (VEC == 4) {
 #if TEM_POOL_NT
-        typedef float fx4 __attribute__((ext_vector_type(4)));
-        fx4 t = {v[0], v[1], v[2], v[3]};
-        __builtin_nontemporal_store(t, reinterpret_cast<fx4*>(p));
+        act_st4_nt(p, make_float4(v[0], v[1], v[2], v[3]));
 #else
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        act_st4(p, make_float4(v[0], v[1], v[2], v[3]));
 #endif
     } else {
-        *p = v[0];
+        act_st1(p, v[0]);
     }
 }
 
-static inline bool vec4_ok(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+// st: storage type of the tensors (a vector of 4 elements is 16 bytes of fp32, 8 bytes of fp16 / bf16)
+static inline bool vec4_ok(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds, int st = 0) {
     if (C % 4) return false;
     for (const void* p : ptrs)
-        if (p && ((uintptr_t)p % 16)) return false;
+        if (p && ((uintptr_t)p % tem_st_align4(st))) return false;
     for (int64_t l : lds)
         if (l % 4) return false;
     return true;
@@ -56,8 +56,8 @@ static inline bool vec4_ok(int C, std::initializer_list<const void*> ptrs, std::
 // ---------------------------------------------------------------------------
 // stat (optional, [N][Do * Ho][C][2], 256 % (C / VEC) == 0): the block's (sum, sum of squares) of every channel of its output
 // row -- the first stage of the statistics of the norm that reads the pooled tensor next (tem_maxpool3d_fwd_stats)
-template <int VEC>
-__global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, int64_t x_ld, float* __restrict__ y,
+template <int VEC, typename T>
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const T* __restrict__ x, int64_t x_ld, T* __restrict__ y,
                                                      int64_t y_ld, int D, int H, int W, int C, int fz, int fy, int fx,
                                                      float* __restrict__ stat) {
     extern __shared__ float pst[];   // stat: [256 / cq rows][C][2]
@@ -139,11 +139,11 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x
     }
 }
 
-template <int VEC>
-__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ gy, int64_t gy_ld,
-                                                     const float* __restrict__ x, int64_t x_ld,
-                                                     const float* __restrict__ gskip, int64_t gskip_ld, int relu_mask,
-                                                     float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
+template <int VEC, typename T>
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const T* __restrict__ gy, int64_t gy_ld,
+                                                     const T* __restrict__ x, int64_t x_ld,
+                                                     const T* __restrict__ gskip, int64_t gskip_ld, int relu_mask,
+                                                     T* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
                                                      int fz, int fy, int fx, const float* __restrict__ gcoef,
                                                      int64_t gcoef_ld, const float* __restrict__ ycoef,
                                                      unsigned* __restrict__ amax) {
@@ -293,30 +293,33 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g
     if (amax) tem_amax_commit(amax, amx);
 }
 
-static int maxpool3d_fwd_impl(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C, int fz,
-                              int fy, int fx, float* stat, tem_stream_t stream) {
+static int maxpool3d_fwd_impl(const void* x, int64_t x_ld, void* y, int64_t y_ld, int N, int D, int H, int W, int C, int fz,
+                              int fy, int fx, float* stat, int st, tem_stream_t stream) {
     TEM_REQUIRE(x && y && N > 0 && C > 0 && x_ld >= C && y_ld >= C, "tem_maxpool3d_fwd: bad arguments");
+    TEM_REQUIRE(st >= 0 && st <= 2, "tem_maxpool3d_fwd: unknown storage type %d", st);
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0 && D % fz == 0 && H % fy == 0 && W % fx == 0,
                 "tem_maxpool3d_fwd: shape (%d,%d,%d) not divisible by factors (%d,%d,%d)", D, H, W, fz, fy, fx);
     int64_t rows = (int64_t)N * (D / fz) * (H / fy);
     TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_fwd: too many rows");
-    const bool v4 = vec4_ok(C, {x, y}, {x_ld, y_ld});
+    const bool v4 = vec4_ok(C, {x, y}, {x_ld, y_ld}, st);
     const int cq = v4 ? C / 4 : C;
     TEM_REQUIRE(!stat || (cq <= 256 && 256 % cq == 0), "tem_maxpool3d_fwd_stats: tem_maxpool3d_fwd_stat_blocks() == 0 for C = %d", C);
     const size_t lds = stat ? (size_t)(256 / cq) * C * 2 * sizeof(float) : 0;
-    if (v4)
-        hipLaunchKernelGGL((k_maxpool_fwd<4>), dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, x, x_ld, y, y_ld,
-                           D, H, W, C, fz, fy, fx, stat);
-    else
-        hipLaunchKernelGGL((k_maxpool_fwd<1>), dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, x, x_ld, y, y_ld,
-                           D, H, W, C, fz, fy, fx, stat);
+    TEM_ST_SWITCH(st, T, {
+        if (v4)
+            hipLaunchKernelGGL((k_maxpool_fwd<4, T>), dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, (const T*)x, x_ld,
+                               (T*)y, y_ld, D, H, W, C, fz, fy, fx, stat);
+        else
+            hipLaunchKernelGGL((k_maxpool_fwd<1, T>), dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, (const T*)x, x_ld,
+                               (T*)y, y_ld, D, H, W, C, fz, fy, fx, stat);
+    });
     TEM_CHECK_LAUNCH("tem_maxpool3d_fwd");
     return TEM_OK;
 }
 
 extern "C" int tem_maxpool3d_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W,
                                  int C, int fz, int fy, int fx, tem_stream_t stream) {
-    return maxpool3d_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, nullptr, stream);
+    return maxpool3d_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, nullptr, 0, stream);
 }
 
 // statistics partial rows per sample of tem_maxpool3d_fwd_stats: one per output row (zo, yo); 0: this channel count cannot
@@ -331,29 +334,43 @@ extern "C" int64_t tem_maxpool3d_fwd_stat_blocks(int D, int H, int C, int fz, in
 // next encoder level: one pass over the pooled tensor and one launch less)
 extern "C" int tem_maxpool3d_fwd_stats(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C,
                                        int fz, int fy, int fx, float* stat_part, int64_t stat_blocks, tem_stream_t stream) {
-    TEM_REQUIRE(stat_part && stat_blocks > 0 && fz > 0 && fy > 0 && stat_blocks == tem_maxpool3d_fwd_stat_blocks(D, H, C, fz, fy),
-                "tem_maxpool3d_fwd_stats: stat_blocks must be tem_maxpool3d_fwd_stat_blocks() (and > 0)");
-    TEM_REQUIRE((C % 4 == 0) == vec4_ok(C, {x, y}, {x_ld, y_ld}), "tem_maxpool3d_fwd_stats: x / y must be 16-byte aligned with ld %% 4 == 0");
-    return maxpool3d_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, stat_part, stream);
+    return tem_maxpool3d_fwd_st(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, stat_part, stat_blocks, TEM_ST_F32, stream);
 }
 
-static int maxpool3d_bwd_impl(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, const float* gskip,
-                              int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H, int W,
+// tem_maxpool3d_fwd / _stats (stat_part != NULL) for tensors of storage type st
+extern "C" int tem_maxpool3d_fwd_st(const void* x, int64_t x_ld, void* y, int64_t y_ld, int N, int D, int H, int W, int C,
+                                    int fz, int fy, int fx, float* stat_part, int64_t stat_blocks, int st, tem_stream_t stream) {
+    if (stat_part) {
+        TEM_REQUIRE(stat_blocks > 0 && fz > 0 && fy > 0 && stat_blocks == tem_maxpool3d_fwd_stat_blocks(D, H, C, fz, fy),
+                    "tem_maxpool3d_fwd_stats: stat_blocks must be tem_maxpool3d_fwd_stat_blocks() (and > 0)");
+        TEM_REQUIRE(st >= 0 && st <= 2 && (C % 4 == 0) == vec4_ok(C, {x, y}, {x_ld, y_ld}, st),
+                    "tem_maxpool3d_fwd_stats: x / y must be aligned to 4 elements with ld %% 4 == 0");
+    }
+    return maxpool3d_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, stat_part, st, stream);
+}
+
+static int maxpool3d_bwd_impl(const void* gy, int64_t gy_ld, const void* x, int64_t x_ld, const void* gskip,
+                              int64_t gskip_ld, int relu_mask, void* gx, int64_t gx_ld, int N, int D, int H, int W,
                               int C, int fz, int fy, int fx, const float* gcoef, int64_t gcoef_ld, const float* ycoef,
-                              tem_stream_t stream) {
+                              unsigned* amax, int st, tem_stream_t stream) {
     TEM_REQUIRE(gy && x && gx && N > 0 && C > 0 && x_ld >= C && gy_ld >= C && gx_ld >= C,
                 "tem_maxpool3d_bwd: bad arguments");
+    TEM_REQUIRE(st >= 0 && st <= 2, "tem_maxpool3d_bwd: unknown storage type %d", st);
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0 && D % fz == 0 && H % fy == 0 && W % fx == 0,
                 "tem_maxpool3d_bwd: shape (%d,%d,%d) not divisible by factors (%d,%d,%d)", D, H, W, fz, fy, fx);
     int64_t rows = (int64_t)N * (D / fz) * (H / fy);
     TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_bwd: too many rows");
-    unsigned* const amax = tem_take_output_amax();
-    if (vec4_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}))
-        hipLaunchKernelGGL((k_maxpool_bwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
-                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef, amax);
-    else
-        hipLaunchKernelGGL((k_maxpool_bwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, x,
-                           x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef, amax);
+    const bool v4 = vec4_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}, st);
+    TEM_ST_SWITCH(st, T, {
+        if (v4)
+            hipLaunchKernelGGL((k_maxpool_bwd<4, T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)gy, gy_ld,
+                               (const T*)x, x_ld, (const T*)gskip, gskip_ld, relu_mask, (T*)gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef,
+                               gcoef_ld, ycoef, amax);
+        else
+            hipLaunchKernelGGL((k_maxpool_bwd<1, T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)gy, gy_ld,
+                               (const T*)x, x_ld, (const T*)gskip, gskip_ld, relu_mask, (T*)gx, gx_ld, D, H, W, C, fz, fy, fx, gcoef,
+                               gcoef_ld, ycoef, amax);
+    });
     TEM_CHECK_LAUNCH("tem_maxpool3d_bwd");
     return TEM_OK;
 }
@@ -362,7 +379,7 @@ extern "C" int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x,
                                  int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H, int W,
                                  int C, int fz, int fy, int fx, tem_stream_t stream) {
     return maxpool3d_bwd_impl(gy, gy_ld, x, x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, N, D, H, W, C, fz, fy, fx, nullptr,
-                              0, nullptr, stream);
+                              0, nullptr, tem_take_output_amax(), 0, stream);
 }
 
 // tem_maxpool3d_bwd whose skip gradient is still the RAW data gradient of the decoder conv behind the concat norm: that
@@ -375,11 +392,21 @@ extern "C" int tem_maxpool3d_bwd_norm(const float* gy, int64_t gy_ld, const floa
                                       int W, int C, int fz, int fy, int fx, const float* gcoef, int64_t gcoef_ld,
                                       const float* ycoef, tem_stream_t stream) {
     TEM_REQUIRE(gcoef || ycoef, "tem_maxpool3d_bwd_norm: no coefficients given");
+    return tem_maxpool3d_bwd_st(gy, gy_ld, x, x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, N, D, H, W, C, fz, fy, fx, gcoef,
+                                gcoef_ld, ycoef, tem_take_output_amax(), TEM_ST_F32, stream);
+}
+
+// tem_maxpool3d_bwd / _bwd_norm (gcoef / ycoef != NULL) for tensors of storage type st; out_amax (optional): the device word
+// that receives max |gx| (bit pattern, integer atomicMax) for the weight gradient that reads gx next
+extern "C" int tem_maxpool3d_bwd_st(const void* gy, int64_t gy_ld, const void* x, int64_t x_ld, const void* gskip,
+                                    int64_t gskip_ld, int relu_mask, void* gx, int64_t gx_ld, int N, int D, int H, int W, int C,
+                                    int fz, int fy, int fx, const float* gcoef, int64_t gcoef_ld, const float* ycoef,
+                                    unsigned* out_amax, int st, tem_stream_t stream) {
     TEM_REQUIRE(!gcoef || (gskip && gcoef_ld >= 4 * C && ((uintptr_t)gcoef % 16 == 0) && gcoef_ld % 4 == 0),
                 "tem_maxpool3d_bwd_norm: bad skip coefficient arguments");
     TEM_REQUIRE(!ycoef || ((uintptr_t)ycoef % 16 == 0), "tem_maxpool3d_bwd_norm: ycoef must be 16-byte aligned");
     return maxpool3d_bwd_impl(gy, gy_ld, x, x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, N, D, H, W, C, fz, fy, fx, gcoef,
-                              gcoef_ld, ycoef, stream);
+                              gcoef_ld, ycoef, out_amax, st, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -398,8 +425,8 @@ __device__ __forceinline__ void lin_src(int o, int f, int in, int& i0, int& i1, 
     l0 = 1.f - l1;
 }
 
-template <int VEC>
-__global__ __launch_bounds__(256) void k_upsample_fwd(const float* __restrict__ x, int64_t x_ld, float* __restrict__ y,
+template <int VEC, typename T>
+__global__ __launch_bounds__(256) void k_upsample_fwd(const T* __restrict__ x, int64_t x_ld, T* __restrict__ y,
                                                       int64_t y_ld, int D, int H, int W, int C, int fz, int fy, int fx) {
     const int Do = D * fz, Ho = H * fy, Wo = W * fx;
     const int cq = C / VEC;
@@ -487,10 +514,10 @@ __device__ __forceinline__ void utu_axis(int i, int f, int in, float (&a)[3], fl
     }
 }
 
-template <int VEC>
-__global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ gy, int64_t gy_ld,
-                                                      float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
-                                                      int fz, int fy, int fx, const float* __restrict__ u, int64_t u_ld,
+template <int VEC, typename T>
+__global__ __launch_bounds__(256) void k_upsample_bwd(const T* __restrict__ gy, int64_t gy_ld,
+                                                      T* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
+                                                      int fz, int fy, int fx, const T* __restrict__ u, int64_t u_ld,
                                                       const float* __restrict__ ncoef, int64_t ncoef_ld) {
     const int Do = D * fz, Ho = H * fy, Wo = W * fx;
     const int cq = C / VEC;
@@ -618,11 +645,13 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
 struct F4 {
     float v[4];
 };
-__device__ __forceinline__ F4 ld4(const float* p) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
+template <typename T>
+__device__ __forceinline__ F4 ld4(const T* p) {
+    const float4 t = act_ld4(p);
     return F4{{t.x, t.y, t.z, t.w}};
 }
-__device__ __forceinline__ void st4(float* p, const F4& a) { *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
+template <typename T>
+__device__ __forceinline__ void st4(T* p, const F4& a) { act_st4(p, make_float4(a.v[0], a.v[1], a.v[2], a.v[3])); }
 __device__ __forceinline__ F4 lerp2(float l0, const F4& a, float l1, const F4& b) {
     F4 r;
 #pragma unroll
@@ -632,8 +661,8 @@ __device__ __forceinline__ F4 lerp2(float l0, const F4& a, float l1, const F4& b
 
 // forward; optionally the (sum y, sum y^2) partials of the block's coarse row [N][D*H][C][2] (what tem_upsample_stats
 // derives from u with a 27-point stencil: here the outputs are in registers anyway)
-template <int FZ>
-__global__ __launch_bounds__(256) void k_upsample2_fwd(const float* __restrict__ x, int64_t x_ld, float* __restrict__ y,
+template <int FZ, typename T>
+__global__ __launch_bounds__(256) void k_upsample2_fwd(const T* __restrict__ x, int64_t x_ld, T* __restrict__ y,
                                                        int64_t y_ld, int D, int H, int W, int C,
                                                        float* __restrict__ part) {
     extern __shared__ float lsu[];  // [4 waves][C][2] when part
@@ -661,7 +690,7 @@ __global__ __launch_bounds__(256) void k_upsample2_fwd(const float* __restrict__
             F4 X[3][2];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const float* r = x + ((((int64_t)n * D + zc) * H + yrow[ky]) * W) * x_ld + c0;
+                const T* r = x + ((((int64_t)n * D + zc) * H + yrow[ky]) * W) * x_ld + c0;
                 const F4 a = ld4(r + (int64_t)xm * x_ld), b = ld4(r + (int64_t)xi * x_ld), c = ld4(r + (int64_t)xp * x_ld);
                 X[ky][0] = lerp2(xa0, a, xa1, b);
                 X[ky][1] = lerp2(0.75f, b, 0.25f, c);
@@ -685,6 +714,10 @@ __global__ __launch_bounds__(256) void k_upsample2_fwd(const float* __restrict__
                     else
                         o = Y[0][sy][sx];
                     const int64_t vo = (((int64_t)n * (D * FZ) + zi * FZ + sz) * Ho + 2 * yi + sy) * Wo + 2 * xi + sx;
+                    if constexpr (sizeof(T) == 2) {   // the row sums describe the tensor AS STORED
+                        const unsigned p0 = act_pk<T>(o.v[0], o.v[1]), p1 = act_pk<T>(o.v[2], o.v[3]);
+                        o = F4{{act_lo<T>(p0), act_hi<T>(p0), act_lo<T>(p1), act_hi<T>(p1)}};
+                    }
                     st4(y + vo * y_ld + c0, o);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -762,10 +795,10 @@ __device__ __forceinline__ UtuAxis utu_axis2(int i0, int f, int in) {
     return r;
 }
 
-template <int FZ>
-__global__ __launch_bounds__(256) void k_upsample2_bwd(const float* __restrict__ gy, int64_t gy_ld,
-                                                       float* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
-                                                       const float* __restrict__ u, int64_t u_ld,
+template <int FZ, typename T>
+__global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy, int64_t gy_ld,
+                                                       T* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
+                                                       const T* __restrict__ u, int64_t u_ld,
                                                        const float* __restrict__ ncoef, int64_t ncoef_ld) {
     constexpr int CZ = FZ == 2 ? 2 : 1;      // coarse z per thread
     constexpr int NZF = FZ == 2 ? 6 : 1;     // fine z planes it reads
@@ -805,7 +838,7 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const float* __restrict__
             for (int ky = 0; ky < 6; ++ky) {
                 const int oy = 2 * y0 - 1 + ky;
                 const float wy[2] = {upb_w(oy, H, y0), upb_w(oy, H, y0 + 1)};
-                const float* r = gy + ((((int64_t)n * Do + zf) * Ho + min(max(oy, 0), Ho - 1)) * Wo) * gy_ld + c0;
+                const T* r = gy + ((((int64_t)n * Do + zf) * Ho + min(max(oy, 0), Ho - 1)) * Wo) * gy_ld + c0;
                 F4 t[6];
 #pragma unroll
                 for (int kx = 0; kx < 6; ++kx) t[kx] = ld4(r + (int64_t)ax.idx[kx] * gy_ld);
@@ -854,7 +887,7 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const float* __restrict__
 #pragma unroll 2
                 for (int ky = 0; ky < 4; ++ky) {
                     const float wy[2] = {pick3(by.a[0], ky), pick3(by.a[1], ky - 1)};
-                    const float* r = u + ((((int64_t)n * D + zc) * H + min(max(y0 - 1 + ky, 0), H - 1)) * W) * u_ld + c0;
+                    const T* r = u + ((((int64_t)n * D + zc) * H + min(max(y0 - 1 + ky, 0), H - 1)) * W) * u_ld + c0;
                     F4 t[4];
 #pragma unroll
                     for (int kx = 0; kx < 4; ++kx) t[kx] = ld4(r + (int64_t)bx.idx[kx] * u_ld);
@@ -907,8 +940,8 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const float* __restrict__
 // Statistics of y = upsample(u) WITHOUT reading y: sum_o y[o] = sum_i (U^T 1)[i] u[i] and sum_o y[o]^2 = sum_i u[i] (U^T U u)[i]
 // -- the same low-resolution 27-point stencil as tem_upsample_bwd_norm.  One block per low-resolution row (n, z, y);
 // part: [N][D*H][C][2] partial sums (sum y, sum y^2) in the layout tem_norm_finalize_partials2 merges.
-template <int VEC>
-__global__ __launch_bounds__(256) void k_upsample_stats(const float* __restrict__ u, int64_t u_ld, int D, int H, int W,
+template <int VEC, typename T>
+__global__ __launch_bounds__(256) void k_upsample_stats(const T* __restrict__ u, int64_t u_ld, int D, int H, int W,
                                                         int C, int fz, int fy, int fx, float* __restrict__ part) {
     extern __shared__ float lsu[];  // [4 waves][C][2]
     const int cq = C / VEC;         // VEC == 4: power of two <= 64 (launcher); a thread keeps its channel quad
@@ -980,22 +1013,31 @@ __global__ __launch_bounds__(256) void k_upsample_stats(const float* __restrict_
     }
 }
 
-extern "C" int tem_upsample_stats(const float* u, int64_t u_ld, int N, int D, int H, int W, int C, int fz, int fy, int fx,
-                                  float* part, tem_stream_t stream) {
+static int upsample_stats_impl(const void* u, int64_t u_ld, int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                               float* part, int st, tem_stream_t stream) {
     TEM_REQUIRE(u && part && N > 0 && C > 0 && u_ld >= C && D > 0 && H > 0 && W > 0 && fz > 0 && fy > 0 && fx > 0,
                 "tem_upsample_stats: bad arguments");
+    TEM_REQUIRE(st >= 0 && st <= 2, "tem_upsample_stats: unknown storage type %d", st);
     const int cq = C / 4;
-    TEM_REQUIRE(C % 4 == 0 && cq <= 64 && (cq & (cq - 1)) == 0 && u_ld % 4 == 0 && ((uintptr_t)u % 16 == 0),
-                "tem_upsample_stats: needs C = 4 * 2^k <= 256 channels, 16-byte aligned rows (got C=%d)", C);
+    TEM_REQUIRE(C % 4 == 0 && cq <= 64 && (cq & (cq - 1)) == 0 && u_ld % 4 == 0 && ((uintptr_t)u % tem_st_align4(st) == 0),
+                "tem_upsample_stats: needs C = 4 * 2^k <= 256 channels, rows aligned to 4 elements (got C=%d)", C);
     int64_t rows = (int64_t)N * D * H;
     TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_stats: too many rows");
-    hipLaunchKernelGGL((k_upsample_stats<4>), dim3((unsigned)rows), dim3(256), (size_t)4 * C * 2 * sizeof(float),
-                       (hipStream_t)stream, u, u_ld, D, H, W, C, fz, fy, fx, part);
+    TEM_ST_SWITCH(st, T, hipLaunchKernelGGL((k_upsample_stats<4, T>), dim3((unsigned)rows), dim3(256), (size_t)4 * C * 2 * sizeof(float),
+                                            (hipStream_t)stream, (const T*)u, u_ld, D, H, W, C, fz, fy, fx, part));
     TEM_CHECK_LAUNCH("tem_upsample_stats");
     return TEM_OK;
 }
+extern "C" int tem_upsample_stats(const float* u, int64_t u_ld, int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                                  float* part, tem_stream_t stream) {
+    return upsample_stats_impl(u, u_ld, N, D, H, W, C, fz, fy, fx, part, 0, stream);
+}
+extern "C" int tem_upsample_stats_st(const void* u, int64_t u_ld, int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                                     float* part, int st, tem_stream_t stream) {
+    return upsample_stats_impl(u, u_ld, N, D, H, W, C, fz, fy, fx, part, st, stream);
+}
 
-// the factor-2 kernels: 16-byte channel quads, and (for the row partials) a quad per lane: C = 4 * 2^k <= 256
+// the factor-2 kernels: channel quads per thread, and (for the row partials) a quad per lane: C = 4 * 2^k <= 256
 static inline bool upsample2_ok(int C, int fz, int fy, int fx) {
     return fy == 2 && fx == 2 && (fz == 1 || fz == 2) && C % 4 == 0 && !tem_option(TEM_OPT_UPSAMPLE_GENERIC);
 }
@@ -1008,83 +1050,96 @@ extern "C" int tem_upsample_fwd_stats_ok(int C, int fz, int fy, int fx) {
     return upsample2_ok(C, fz, fy, fx) && cq <= 64 && (cq & (cq - 1)) == 0;
 }
 
-extern "C" int tem_upsample_fwd_stats(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W,
-                                      int C, int fz, int fy, int fx, float* part, tem_stream_t stream) {
-    TEM_REQUIRE(x && y && part && N > 0 && C > 0 && x_ld >= C && y_ld >= C && D > 0 && H > 0 && W > 0,
-                "tem_upsample_fwd_stats: bad arguments");
-    TEM_REQUIRE(tem_upsample_fwd_stats_ok(C, fz, fy, fx) && vec4_ok(C, {x, y}, {x_ld, y_ld}),
-                "tem_upsample_fwd_stats: needs factors (1|2, 2, 2), C = 4 * 2^k <= 256 and 16-byte aligned rows");
-    const int64_t crow = (int64_t)N * D * H;
-    TEM_REQUIRE(crow < (1ll << 31), "tem_upsample_fwd_stats: too many rows");
-    const size_t ldsb = (size_t)4 * C * 2 * sizeof(float);
-    if (fz == 2)
-        hipLaunchKernelGGL((k_upsample2_fwd<2>), dim3((unsigned)crow), dim3(256), ldsb, (hipStream_t)stream, x, x_ld, y, y_ld,
-                           D, H, W, C, part);
-    else
-        hipLaunchKernelGGL((k_upsample2_fwd<1>), dim3((unsigned)crow), dim3(256), ldsb, (hipStream_t)stream, x, x_ld, y, y_ld,
-                           D, H, W, C, part);
-    TEM_CHECK_LAUNCH("tem_upsample_fwd_stats");
-    return TEM_OK;
-}
-
-extern "C" int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C,
-                                int fz, int fy, int fx, tem_stream_t stream) {
+static int upsample_fwd_impl(const void* x, int64_t x_ld, void* y, int64_t y_ld, int N, int D, int H, int W, int C, int fz,
+                             int fy, int fx, float* part, int st, tem_stream_t stream) {
     TEM_REQUIRE(x && y && N > 0 && C > 0 && x_ld >= C && y_ld >= C && D > 0 && H > 0 && W > 0,
                 "tem_upsample_fwd: bad arguments");
+    TEM_REQUIRE(st >= 0 && st <= 2, "tem_upsample_fwd: unknown storage type %d", st);
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0, "tem_upsample_fwd: bad factors");
+    const bool v4 = vec4_ok(C, {x, y}, {x_ld, y_ld}, st);
+    TEM_REQUIRE(!part || (tem_upsample_fwd_stats_ok(C, fz, fy, fx) && v4),
+                "tem_upsample_fwd_stats: needs factors (1|2, 2, 2), C = 4 * 2^k <= 256 and rows aligned to 4 elements");
     int64_t rows = (int64_t)N * D * fz * H * fy;
     TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_fwd: too many rows");
-    if (upsample2_ok(C, fz, fy, fx) && vec4_ok(C, {x, y}, {x_ld, y_ld})) {
-        const int64_t crow = (int64_t)N * D * H;
-        if (fz == 2)
-            hipLaunchKernelGGL((k_upsample2_fwd<2>), dim3((unsigned)crow), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
-                               y_ld, D, H, W, C, (float*)nullptr);
+    const size_t ldsb = part ? (size_t)4 * C * 2 * sizeof(float) : 0;
+    TEM_ST_SWITCH(st, T, {
+        const T* xs = (const T*)x;
+        T* ys = (T*)y;
+        if (upsample2_ok(C, fz, fy, fx) && v4) {
+            const int64_t crow = (int64_t)N * D * H;
+            if (fz == 2)
+                hipLaunchKernelGGL((k_upsample2_fwd<2, T>), dim3((unsigned)crow), dim3(256), ldsb, (hipStream_t)stream, xs, x_ld, ys,
+                                   y_ld, D, H, W, C, part);
+            else
+                hipLaunchKernelGGL((k_upsample2_fwd<1, T>), dim3((unsigned)crow), dim3(256), ldsb, (hipStream_t)stream, xs, x_ld, ys,
+                                   y_ld, D, H, W, C, part);
+        } else if (v4)
+            hipLaunchKernelGGL((k_upsample_fwd<4, T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, xs, x_ld, ys,
+                               y_ld, D, H, W, C, fz, fy, fx);
         else
-            hipLaunchKernelGGL((k_upsample2_fwd<1>), dim3((unsigned)crow), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
-                               y_ld, D, H, W, C, (float*)nullptr);
-    } else if (vec4_ok(C, {x, y}, {x_ld, y_ld}))
-        hipLaunchKernelGGL((k_upsample_fwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
-                           y_ld, D, H, W, C, fz, fy, fx);
-    else
-        hipLaunchKernelGGL((k_upsample_fwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
-                           y_ld, D, H, W, C, fz, fy, fx);
+            hipLaunchKernelGGL((k_upsample_fwd<1, T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, xs, x_ld, ys,
+                               y_ld, D, H, W, C, fz, fy, fx);
+    });
     TEM_CHECK_LAUNCH("tem_upsample_fwd");
     return TEM_OK;
 }
 
-static int upsample_bwd_impl(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld, int N, int D, int H, int W,
-                             int C, int fz, int fy, int fx, const float* u, int64_t u_ld, const float* ncoef,
-                             int64_t ncoef_ld, tem_stream_t stream) {
+extern "C" int tem_upsample_fwd_stats(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W,
+                                      int C, int fz, int fy, int fx, float* part, tem_stream_t stream) {
+    TEM_REQUIRE(part, "tem_upsample_fwd_stats: bad arguments");
+    return upsample_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, part, 0, stream);
+}
+
+extern "C" int tem_upsample_fwd(const float* x, int64_t x_ld, float* y, int64_t y_ld, int N, int D, int H, int W, int C,
+                                int fz, int fy, int fx, tem_stream_t stream) {
+    return upsample_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, nullptr, 0, stream);
+}
+
+// tem_upsample_fwd / _fwd_stats (part != NULL) for tensors of storage type st
+extern "C" int tem_upsample_fwd_st(const void* x, int64_t x_ld, void* y, int64_t y_ld, int N, int D, int H, int W, int C,
+                                   int fz, int fy, int fx, float* part, int st, tem_stream_t stream) {
+    return upsample_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, part, st, stream);
+}
+
+static int upsample_bwd_impl(const void* gy, int64_t gy_ld, void* gx, int64_t gx_ld, int N, int D, int H, int W,
+                             int C, int fz, int fy, int fx, const void* u, int64_t u_ld, const float* ncoef,
+                             int64_t ncoef_ld, int st, tem_stream_t stream) {
     TEM_REQUIRE(gy && gx && N > 0 && C > 0 && gy_ld >= C && gx_ld >= C && D > 0 && H > 0 && W > 0,
                 "tem_upsample_bwd: bad arguments");
+    TEM_REQUIRE(st >= 0 && st <= 2, "tem_upsample_bwd: unknown storage type %d", st);
     TEM_REQUIRE(fz > 0 && fy > 0 && fx > 0, "tem_upsample_bwd: bad factors");
     int64_t rows = (int64_t)N * D * H;
     TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_bwd: too many rows");
     // the 2x2x2-per-thread kernel has 1/8 of the gather kernel's threads: it needs a volume that still fills the chip
     const int64_t pairs = (int64_t)N * ((D + fz - 1) / fz) * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    if (upsample2_ok(C, fz, fy, fx) && pairs >= 65536 && vec4_ok(C, {gy, gx, u}, {gy_ld, gx_ld, u_ld})) {
-        if (fz == 2) {
-            const int64_t prow = (int64_t)N * ((D + 1) / 2) * ((H + 1) / 2);
-            hipLaunchKernelGGL((k_upsample2_bwd<2>), dim3((unsigned)prow), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
-                               gx_ld, D, H, W, C, u, u_ld, ncoef, ncoef_ld);
-        } else {
-            const int64_t prow = (int64_t)N * D * ((H + 1) / 2);
-            hipLaunchKernelGGL((k_upsample2_bwd<1>), dim3((unsigned)prow), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
-                               gx_ld, D, H, W, C, u, u_ld, ncoef, ncoef_ld);
-        }
-    } else if (vec4_ok(C, {gy, gx}, {gy_ld, gx_ld}))
-        hipLaunchKernelGGL((k_upsample_bwd<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
-                           gx_ld, D, H, W, C, fz, fy, fx, u, u_ld, ncoef, ncoef_ld);
-    else
-        hipLaunchKernelGGL((k_upsample_bwd<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gy, gy_ld, gx,
-                           gx_ld, D, H, W, C, fz, fy, fx, u, u_ld, ncoef, ncoef_ld);
+    TEM_ST_SWITCH(st, T, {
+        const T* gys = (const T*)gy;
+        const T* us = (const T*)u;
+        T* gxs = (T*)gx;
+        if (upsample2_ok(C, fz, fy, fx) && pairs >= 65536 && vec4_ok(C, {gy, gx, u}, {gy_ld, gx_ld, u_ld}, st)) {
+            if (fz == 2) {
+                const int64_t prow = (int64_t)N * ((D + 1) / 2) * ((H + 1) / 2);
+                hipLaunchKernelGGL((k_upsample2_bwd<2, T>), dim3((unsigned)prow), dim3(256), 0, (hipStream_t)stream, gys, gy_ld, gxs,
+                                   gx_ld, D, H, W, C, us, u_ld, ncoef, ncoef_ld);
+            } else {
+                const int64_t prow = (int64_t)N * D * ((H + 1) / 2);
+                hipLaunchKernelGGL((k_upsample2_bwd<1, T>), dim3((unsigned)prow), dim3(256), 0, (hipStream_t)stream, gys, gy_ld, gxs,
+                                   gx_ld, D, H, W, C, us, u_ld, ncoef, ncoef_ld);
+            }
+        } else if (vec4_ok(C, {gy, gx, u}, {gy_ld, gx_ld, u ? u_ld : 0}, st))
+            hipLaunchKernelGGL((k_upsample_bwd<4, T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gys, gy_ld, gxs,
+                               gx_ld, D, H, W, C, fz, fy, fx, us, u_ld, ncoef, ncoef_ld);
+        else
+            hipLaunchKernelGGL((k_upsample_bwd<1, T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, gys, gy_ld, gxs,
+                               gx_ld, D, H, W, C, fz, fy, fx, us, u_ld, ncoef, ncoef_ld);
+    });
     TEM_CHECK_LAUNCH("tem_upsample_bwd");
     return TEM_OK;
 }
 
 extern "C" int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld, int N, int D, int H, int W,
                                 int C, int fz, int fy, int fx, tem_stream_t stream) {
-    return upsample_bwd_impl(gy, gy_ld, gx, gx_ld, N, D, H, W, C, fz, fy, fx, nullptr, 0, nullptr, 0, stream);
+    return upsample_bwd_impl(gy, gy_ld, gx, gx_ld, N, D, H, W, C, fz, fy, fx, nullptr, 0, nullptr, 0, 0, stream);
 }
 
 // tem_upsample_bwd of the RAW data gradient behind a norm whose input was upsample(u): U^T(norm backward(g)) =
@@ -1092,8 +1147,20 @@ extern "C" int tem_upsample_bwd(const float* gy, int64_t gy_ld, float* gx, int64
 extern "C" int tem_upsample_bwd_norm(const float* gy, int64_t gy_ld, float* gx, int64_t gx_ld, int N, int D, int H,
                                      int W, int C, int fz, int fy, int fx, const float* u, int64_t u_ld,
                                      const float* ncoef, int64_t ncoef_ld, tem_stream_t stream) {
-    TEM_REQUIRE(u && ncoef && u_ld >= C && ncoef_ld >= 4 * C && ((uintptr_t)ncoef % 16 == 0) && ncoef_ld % 4 == 0,
-                "tem_upsample_bwd_norm: bad arguments");
-    TEM_REQUIRE(C % 4 || (u_ld % 4 == 0 && (uintptr_t)u % 16 == 0), "tem_upsample_bwd_norm: u must be 16-byte aligned");
-    return upsample_bwd_impl(gy, gy_ld, gx, gx_ld, N, D, H, W, C, fz, fy, fx, u, u_ld, ncoef, ncoef_ld, stream);
+    TEM_REQUIRE(u && ncoef, "tem_upsample_bwd_norm: bad arguments");
+    return tem_upsample_bwd_st(gy, gy_ld, gx, gx_ld, N, D, H, W, C, fz, fy, fx, u, u_ld, ncoef, ncoef_ld, TEM_ST_F32, stream);
+}
+
+// tem_upsample_bwd / _bwd_norm (u, ncoef != NULL) for tensors of storage type st
+extern "C" int tem_upsample_bwd_st(const void* gy, int64_t gy_ld, void* gx, int64_t gx_ld, int N, int D, int H, int W, int C,
+                                   int fz, int fy, int fx, const void* u, int64_t u_ld, const float* ncoef, int64_t ncoef_ld,
+                                   int st, tem_stream_t stream) {
+    TEM_REQUIRE((u == nullptr) == (ncoef == nullptr), "tem_upsample_bwd_norm: u and ncoef come together");
+    if (ncoef) {
+        TEM_REQUIRE(u_ld >= C && ncoef_ld >= 4 * C && ((uintptr_t)ncoef % 16 == 0) && ncoef_ld % 4 == 0,
+                    "tem_upsample_bwd_norm: bad arguments");
+        TEM_REQUIRE(st >= 0 && st <= 2 && (C % 4 || (u_ld % 4 == 0 && (uintptr_t)u % tem_st_align4(st) == 0)),
+                    "tem_upsample_bwd_norm: u must be aligned to 4 elements");
+    }
+    return upsample_bwd_impl(gy, gy_ld, gx, gx_ld, N, D, H, W, C, fz, fy, fx, u, u_ld, ncoef, ncoef_ld, st, stream);
 }

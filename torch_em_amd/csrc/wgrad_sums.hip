@@ -14,6 +14,7 @@
 // one block per sample of arithmetic on [27][Cout] numbers.
 #include "tem_common.h"
 #include "conv_internal.h"
+#include "tem_act.h"
 
 // ---------------------------------------------------------------------------
 // boundary shell of g: sums over the 9 (y class, x class) position classes (class 0 = first index, 1 = middle, 2 = last)
@@ -23,7 +24,8 @@
 // ---------------------------------------------------------------------------
 // body for one HALF (256 threads, `tid` = thread index inside it) of a 512-thread block: slot `slot` of sample n, or nothing
 // (act == false: the half only meets the barrier); lsh: this half's [4 waves][9][C] floats
-__device__ __forceinline__ void shell_plane_sums_body(const float* __restrict__ g, int64_t g_ld, int D, int H, int W, int C,
+template <typename T>
+__device__ __forceinline__ void shell_plane_sums_body(const T* __restrict__ g, int64_t g_ld, int D, int H, int W, int C,
                                                       float* __restrict__ planepart, int slot, int n, float* lsh, int tid,
                                                       bool act) {
     const int nslot = D - 2 + 2 * H;
@@ -36,7 +38,7 @@ __device__ __forceinline__ void shell_plane_sums_body(const float* __restrict__ 
     float4 acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* gp = g + ((int64_t)n * D + z) * H * W * g_ld + q * 4;
+    const T* gp = g + ((int64_t)n * D + z) * H * W * g_ld + q * 4;
     // four voxels per trip, loads unconditional (a clamped index, the value masked out below): the one-load-per-trip loop
     // was 16 dependent round trips for a ring slot
     constexpr int SU = 4;
@@ -62,7 +64,7 @@ __device__ __forceinline__ void shell_plane_sums_body(const float* __restrict__ 
                 x = (j & 1) ? W - 1 : 0;
             }
             cls[u] = idx0 + u * nlv < count ? ((y == 0) ? 0 : (y == H - 1) ? 2 : 1) * 3 + ((x == 0) ? 0 : (x == W - 1) ? 2 : 1) : -1;
-            v[u] = *reinterpret_cast<const float4*>(gp + ((int64_t)y * W + x) * g_ld);
+            v[u] = act_ld4(gp + ((int64_t)y * W + x) * g_ld);
         }
 #pragma unroll
         for (int u = 0; u < SU; ++u)
@@ -94,7 +96,8 @@ __device__ __forceinline__ void shell_plane_sums_body(const float* __restrict__ 
 }
 
 struct ShellArgs {
-    const float* g;
+    const void* g;   // element type: st (TEM_ST_*)
+    int st;
     int64_t g_ld;
     int D, H, W;
     float* planepart;
@@ -126,8 +129,15 @@ __global__ __launch_bounds__(512) void k_reduce_slabs_wsum(const float* __restri
         const int sb = (int)blockIdx.x * 2 + half;
         const bool act = sb < nslot * N;
         extern __shared__ float lsh[];   // [2 halves][4 waves][9][Cout]
-        shell_plane_sums_body(sa.g, sa.g_ld, sa.D, sa.H, sa.W, Cout, sa.planepart, act ? sb % nslot : 0, act ? sb / nslot : 0,
-                              lsh + half * 4 * 9 * Cout, threadIdx.x & 255, act);
+        if (sa.st == 0)   // launch-uniform
+            shell_plane_sums_body((const float*)sa.g, sa.g_ld, sa.D, sa.H, sa.W, Cout, sa.planepart, act ? sb % nslot : 0,
+                                  act ? sb / nslot : 0, lsh + half * 4 * 9 * Cout, threadIdx.x & 255, act);
+        else if (sa.st == 1)
+            shell_plane_sums_body((const tem_f16*)sa.g, sa.g_ld, sa.D, sa.H, sa.W, Cout, sa.planepart, act ? sb % nslot : 0,
+                                  act ? sb / nslot : 0, lsh + half * 4 * 9 * Cout, threadIdx.x & 255, act);
+        else
+            shell_plane_sums_body((const tem_bf16*)sa.g, sa.g_ld, sa.D, sa.H, sa.W, Cout, sa.planepart, act ? sb % nslot : 0,
+                                  act ? sb / nslot : 0, lsh + half * 4 * 9 * Cout, threadIdx.x & 255, act);
         return;
     }
     if (bid >= nb_w) {  // the bias gradient rides along (arithmetic of k_reduce_slabs): one launch less per layer
@@ -410,7 +420,7 @@ void tem_wgrad_sums_launch(const float* zpart, int Ss, int ks2, const float* zdb
     int64_t nb = tem_cdiv(n_out, 64);
     if (nb > 4096) nb = 4096;
     const int nb_db = db ? (Cout + 63) / 64 : 0;   // zdb: [db_chunks][Cout] rows -> db
-    const ShellArgs sa = {g, g_ld, D, H, W, planepart};
+    const ShellArgs sa = {g, tem_call_st.y, g_ld, D, H, W, planepart};
     hipLaunchKernelGGL(k_reduce_slabs_wsum, dim3((unsigned)(nb + nb_db + ((int64_t)(D - 2 + 2 * H) * N + 1) / 2)), dim3(512),
                        (size_t)2 * 4 * 9 * Cout * sizeof(float), s, zpart,
                        Ss * ks2, N, 27, Cin, Cout, n_out, dw, w, P, (int)nb, zdb, db_chunks, db, nb_db, sa);

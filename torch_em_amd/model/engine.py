@@ -64,6 +64,22 @@ _FORCE_GENERIC = os.environ.get("TEM_DISABLE_MFMA", "0") == "1"
 # pass, so their 1e-5 error is not amplified.
 PRECISION = os.environ.get("TEM_PRECISION", "split16")
 _F16X3_MODE = int(os.environ.get("TEM_F16X3_LAYOUT", "4"))
+# Activation STORAGE of the two mixed modes (round 5): every tensor between two kernels of the step -- activations, saved
+# tensors, data gradients -- is fp16 ("amp") / bf16 ("amp_bf16") in HBM, as under torch.autocast in the reference trainer
+# (trainer/default_trainer.py:134-142, 781-794); the network input, the prediction, statistics, coefficients, parameters and
+# the gradient arena stay fp32, all arithmetic stays fp32 with one rounding per stored value.  TEM_AMP_STORAGE=32 keeps fp32
+# tensors (the mixed modes of rounds 1-4: 16-bit operands only).  The fp32-class modes always store fp32.
+_AMP_STORAGE16 = os.environ.get("TEM_AMP_STORAGE", "16") != "32"
+
+
+def act_dtype():
+    """element type of the activation tensors the engine allocates in the current precision mode"""
+    if _AMP_STORAGE16 and not _FORCE_GENERIC:
+        if PRECISION == "amp":
+            return torch.float16
+        if PRECISION == "amp_bf16":
+            return torch.bfloat16
+    return torch.float32
 
 
 def set_precision(mode: str):
@@ -641,7 +657,7 @@ def _block_fwd(blk, xin, out, in_partials2=None, out_stats=False, in_partials=No
     c1, c2 = blk.conv_specs()
     N, D, H, W, _ = xin.shape
     s1 = _stats(c1, xin, partials=in_partials, partials2=in_partials2)
-    a1 = ops.new_act(N, D, H, W, c1.cout, xin.device)
+    a1 = ops.new_act(N, D, H, W, c1.cout, xin.device, out.dtype)
     live = _norm_is_live(c2.norm)
     part = _conv(c1, xin, a1, s1, act="relu", want_stats=_FUSE_STATS and live)
     s2 = _stats(c2, a1, partials=part if (_FUSE_STATS and live) else None)
@@ -736,7 +752,7 @@ def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
         return
     if gin is None:
         N, D, H, W, _ = xin.shape
-        gin = ops.new_act(N, D, H, W, c1.cin, xin.device)
+        gin = ops.new_act(N, D, H, W, c1.cin, xin.device, xin.dtype)
     if _dgrad16_ok(c1, ga1):
         gm = grads.amax_slot()
         sums = _wgrad(c1, xin, ga1, grads, bs["s1"], want_sums=bs["s1"] is not None, gmax=gm)
@@ -781,6 +797,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
     xin = ops.nchw_to_nhwc(x.float())
     N = xin.shape[0]
     dev = xin.device
+    adt = act_dtype()   # fp32, or the 16-bit storage type of the mixed modes (the network input and the prediction stay fp32)
     st = {"levels": [], "dim": dim, "x_shape": tuple(x.shape)}
     cur = xin
     cur_part = None   # first-stage statistics of `cur` from the kernel that produced it (the max-pool), if any
@@ -792,13 +809,13 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         floor = bool(D % f[0] or H % f[1] or W % f[2])
         if floor and getattr(model, "check_shape", True):
             raise ValueError(f"Invalid shape for U-Net: {(D, H, W)[3 - dim:]} is not divisible by {f[3 - dim:]}")
-        cat = ops.new_act(N, D, H, W, c_up + blk.out_channels, dev)
+        cat = ops.new_act(N, D, H, W, c_up + blk.out_channels, dev, adt)
         skip = cat[..., c_up:]
         # the skip tensor feeds the norm in front of the decoder block of this level: its statistics come out of the
         # epilogue of this block's second conv (with the upsampled half's from the low-resolution tensor, see below)
         dnorm = dec.blocks[depth - 1 - l].conv_specs()[0].norm
         bs = _block_fwd(blk, cur, skip, out_stats=_FUSE_STATS and _FUSE_CONCAT_STATS and _norm_is_live(dnorm), in_partials=cur_part)
-        pooled = ops.new_act(N, D // f[0], H // f[1], W // f[2], blk.out_channels, dev)
+        pooled = ops.new_act(N, D // f[0], H // f[1], W // f[2], blk.out_channels, dev, adt)
         lvl = {"cat": cat, "skip": skip, "bs": bs, "f": f, "c_up": c_up}
         if floor:
             # model.check_shape = False and a size the factor does not divide: nn.MaxPool3d drops the remainder.  The pooling
@@ -818,7 +835,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         st["levels"].append(lvl)
         cur = pooled
     _, D, H, W, _ = cur.shape
-    base_out = ops.new_act(N, D, H, W, model.base.out_channels, dev)
+    base_out = ops.new_act(N, D, H, W, model.base.out_channels, dev, adt)
     st["base"] = _block_fwd(model.base, cur, base_out, in_partials=cur_part)
     cur = base_out
     st["dec"] = []
@@ -830,7 +847,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
             raise ValueError("decoder scale factors must mirror the encoder's")
         sspec = ConvSpec(sampler.conv, None)
         _, d, h, w, _ = cur.shape
-        t = ops.new_act(N, d, h, w, sspec.cout, dev)
+        t = ops.new_act(N, d, h, w, sspec.cout, dev, adt)
         _conv(sspec, cur, t)                       # 1x1 conv at low resolution ...
         cat = lv["cat"]
         up_sp, sk_sp = (d * f[0], h * f[1], w * f[2]), tuple(cat.shape[1:4])
@@ -846,7 +863,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
                                    f"skip connection {sk_sp} (Decoder._crop removes (difference // 2) per side, which only "
                                    "fits even differences; the reference fails in torch.cat the same way)")
             off = [v // 2 for v in diff]
-            cat = ops.new_act(N, up_sp[0], up_sp[1], up_sp[2], lv["cat"].shape[4], dev)
+            cat = ops.new_act(N, up_sp[0], up_sp[1], up_sp[2], lv["cat"].shape[4], dev, adt)
             cat[..., lv["c_up"]:] = lv["skip"][:, off[0]:off[0] + up_sp[0], off[1]:off[1] + up_sp[1], off[2]:off[2] + up_sp[2]]
             lv["cat_c"], lv["crop"] = cat, off
         # statistics of the concat for the block's first norm without reading it: the skip half's partial sums were
@@ -861,7 +878,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
             cpg = cat.shape[4] // na[0]
             want_stats = lv["c_up"] % cpg == 0 and ops.upsample_stats_ok(t)
         up_part = ops.upsample_fwd(t, cat[..., :lv["c_up"]], f, stats=want_stats)  # ... interpolated straight into the concat buffer
-        out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev)
+        out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev, adt)
         if want_stats:
             p2 = (up_part if up_part is not None else ops.upsample_stats(t, f), skip_part[0])
         bs = _block_fwd(blk, cat, out, in_partials2=p2)
@@ -891,7 +908,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         _conv(ospec, cur, y, act=act)
         st["ospec"] = ospec
     else:
-        y = cur
+        y = cur if cur.dtype == torch.float32 else cur.float()   # the prediction is fp32 in every mode
         if act == "sigmoid":
             raise NotImplementedError("final Sigmoid without out_conv is not supported")
     st["y"] = y
@@ -969,14 +986,14 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
             _wgrad(osp, last, g, grads)
     else:
         g_cur = torch.empty_like(last)
-        ops.maxpool_bwd(g, last, g_cur, (1, 1, 1), relu_mask=True)
+        ops.maxpool_bwd(g.to(last.dtype), last, g_cur, (1, 1, 1), relu_mask=True)
     for i in reversed(range(depth)):
         d = st["dec"][i]
         lv = st["levels"][depth - 1 - i]
         g_cat = torch.empty_like(lv.get("cat_c", lv["cat"]))
         coef = _block_bwd(d["bs"], g_cur, g_cat, grads, defer_input_norm="crop" not in lv)
         low, sspec = d["low"], d["sspec"]
-        g_t = ops.new_act(low.shape[0], low.shape[1], low.shape[2], low.shape[3], sspec.cout, low.device)
+        g_t = ops.new_act(low.shape[0], low.shape[1], low.shape[2], low.shape[3], sspec.cout, low.device, low.dtype)
         ops.upsample_bwd(g_cat[..., :lv["c_up"]], g_t, d["f"],
                          norm=None if coef is None else (d["t"], coef[:, :lv["c_up"]]))
         lv["g_skip_coef"] = None if coef is None else coef[:, lv["c_up"]:]
@@ -1007,7 +1024,7 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         lv = st["levels"][l]
         skip = lv["skip"]
         g_skip_full = ops.new_act(skip.shape[0], skip.shape[1], skip.shape[2], skip.shape[3], skip.shape[4],
-                                  skip.device)
+                                  skip.device, skip.dtype)
         if "floor_sub" in lv:
             # remainder voxels outside every pooling window only receive the (zero-padded, cropped) decoder gradient
             sub = lv["floor_sub"]

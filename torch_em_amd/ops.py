@@ -73,6 +73,26 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+# activation storage types of the C-ABI (TEM_ST_F32 / _F16 / _BF16, include/tem_hip.h): the element type of a tensor handed to
+# the `_st` entry points, and -- shifted into the high bits of `use_mfma` -- to the convolution entry points
+_ST = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _st(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else _ST[t.dtype]
+
+
+def _mode(mfma, x, y) -> int:
+    """use_mfma | TEM_MFMA_STX(storage of x) | TEM_MFMA_STY(storage of y)"""
+    return int(mfma) | (_st(x) << 8) | (_st(y) << 12)
+
+
+def _same_st(*ts):
+    sts = {t.dtype for t in ts if t is not None}
+    if len(sts) > 1:
+        raise ValueError(f"tensors of one call must share their storage type, got {sorted(str(d) for d in sts)}")
+
+
 def _req_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -86,8 +106,8 @@ def _act5(t: torch.Tensor) -> Tuple[int, int, int, int, int, int]:
     element (n,z,y,x,c) at (((n*D+z)*H+y)*W+x)*ld + c."""
     if t.dim() != 5:
         raise ValueError(f"expected a 5-D NDHWC tensor, got shape {tuple(t.shape)}")
-    if t.dtype != torch.float32:
-        raise ValueError(f"expected float32, got {t.dtype}")
+    if t.dtype not in _ST:
+        raise ValueError(f"expected float32 (or float16 / bfloat16 activation storage), got {t.dtype}")
     N, D, H, W, C = t.shape
     s = t.stride()
     sizes = (N, D, H, W)
@@ -112,8 +132,8 @@ def _act5(t: torch.Tensor) -> Tuple[int, int, int, int, int, int]:
     return N, D, H, W, C, ld
 
 
-def new_act(N, D, H, W, C, device) -> torch.Tensor:
-    return torch.empty((N, D, H, W, C), dtype=torch.float32, device=device)
+def new_act(N, D, H, W, C, device, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty((N, D, H, W, C), dtype=dtype, device=device)
 
 
 # ---------------------------------------------------------------- layout ----
@@ -216,24 +236,26 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     ref_ld = 0
     if ref is not None:
         ref_ld = _act5(ref)[5]
+        _same_st(y, ref)
     lib = _lib.load()
-    nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if mfma else 0
+    mode = _mode(mfma, x, y)
+    nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], mode) if mfma else 0
     ws = _workspace(nws, x.device) if nws else None
     kind = None
     if PROFILER is not None:
-        pp = lib.tem_conv3d_fwd_kernel(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if mfma else 0
+        pp = lib.tem_conv3d_fwd_kernel(N, D, H, W, cin, cout, k[0], k[1], k[2], mode) if mfma else 0
         kind = _fwd_tag(mfma, k, cout, pp)
-    nblk = lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)) if want_stats else 0
+    nblk = lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, cin, cout, k[0], k[1], k[2], mode) if want_stats else 0
     ev0 = _prof_begin(x, kind)
     part = None
     if nblk > 0:
         part = torch.empty((N, nblk, cout, 2), dtype=torch.float32, device=x.device)
         _lib.check(lib.tem_conv3d_fwd_stats(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld,
                                             _p(ref), ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2],
-                                            ACT[act], int(mfma), _p(part), nblk, _stream(x)), "tem_conv3d_fwd_stats")
+                                            ACT[act], mode, _p(part), nblk, _stream(x)), "tem_conv3d_fwd_stats")
     else:
         _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
-                                      ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], int(mfma),
+                                      ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], mode,
                                       _stream(x)), "tem_conv3d_fwd")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
@@ -268,21 +290,27 @@ def conv_wgrad_gnorm(x, g, y, coef, k, cin, cout, dw_out, db_out=None, scale=Non
     _req_cuda(x, g, y, coef, dw_out)
     N, D, H, W, C, x_ld = _act5(x)
     g_ld, y_ld = _act5(g)[5], _act5(y)[5]
+    _same_st(g, y)
     lib = _lib.load()
     nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 0)
     ws = _workspace(nws, x.device)
     kind = _wgrad_tag(0, k, cout) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
-    _lib.check(lib.tem_conv3d_wgrad_gnorm(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(y), y_ld, _p(coef), _p(dw_out),
-                                          _p(db_out), _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], 1, _stream(x)),
-               "tem_conv3d_wgrad_gnorm")
+    if _st(x) or _st(g):
+        _lib.check(lib.tem_conv3d_wgrad_gnorm_st(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(y), y_ld, _p(coef), _p(dw_out),
+                                                 _p(db_out), _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], 1, _st(x), _st(g),
+                                                 _stream(x)), "tem_conv3d_wgrad_gnorm_st")
+    else:
+        _lib.check(lib.tem_conv3d_wgrad_gnorm(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(y), y_ld, _p(coef), _p(dw_out),
+                                              _p(db_out), _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], 1, _stream(x)),
+                   "tem_conv3d_wgrad_gnorm")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
 
 
 def conv_wgrad_sums_ok(x, k, cin, cout, mfma) -> bool:
     N, D, H, W, _, _ = _act5(x)
-    return bool(_lib.load().tem_conv3d_wgrad_sums_ok(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
+    return bool(_lib.load().tem_conv3d_wgrad_sums_ok(N, D, H, W, cin, cout, k[0], k[1], k[2], _mode(mfma, x, x)))
 
 
 def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, mfma=False, sums_from=None):
@@ -299,14 +327,15 @@ def _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sum
     N, D, H, W, C, x_ld = _act5(x)
     g_ld = _act5(g)[5]
     lib = _lib.load()
-    nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma))
+    mode = _mode(mfma, x, g)
+    nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], mode)
     ws = _workspace(nws, x.device)
     sums = torch.empty((N, cin, 2), dtype=torch.float32, device=x.device)
     kind = _wgrad_tag(mfma, k, cout) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
     _lib.check(lib.tem_conv3d_wgrad_sums(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w.detach()), _p(gamma), _p(beta),
                                          _p(dw_out), _p(db_out), _p(sums), _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1],
-                                         k[2], int(mfma), _stream(x)), "tem_conv3d_wgrad_sums")
+                                         k[2], mode, _stream(x)), "tem_conv3d_wgrad_sums")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return sums
@@ -355,6 +384,12 @@ def conv1x1_out_bwd(x, g, w, gx, dw_out, db_out=None):
     lib = _lib.load()
     nws = lib.tem_conv1x1_out_bwd_ws(cin, cout)
     ws = _workspace(nws, x.device)
+    _same_st(x, gx)
+    if _st(x) or _st(g):
+        _lib.check(lib.tem_conv1x1_out_bwd_st(_p(x), x_ld, _p(g), g_ld, _p(w.detach()), _p(gx), gx_ld, _p(dw_out), _p(db_out),
+                                              _p(ws), nws, N * D * H * W, cin, cout, None, _st(x), _st(g), _stream(x)),
+                   "tem_conv1x1_out_bwd_st")
+        return gx
     _lib.check(lib.tem_conv1x1_out_bwd(_p(x), x_ld, _p(g), g_ld, _p(w.detach()), _p(gx), gx_ld, _p(dw_out), _p(db_out), _p(ws), nws,
                                        N * D * H * W, cin, cout, _stream(x)), "tem_conv1x1_out_bwd")
     return gx
@@ -466,13 +501,14 @@ def conv_fwd_refnorm(x, w_packed, y, k, cin, cout, ref, coef, mfma):
             not coef.is_contiguous():
         raise ValueError(f"conv_fwd_refnorm: shape mismatch x{tuple(x.shape)} y{tuple(y.shape)} coef{tuple(coef.shape)}")
     ref_ld = _act5(ref)[5]
+    _same_st(x, y, ref)
     lib = _lib.load()
     nws = lib.tem_conv3d_fwd_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], 1)
     ws = _workspace(nws, x.device) if nws else None
     kind = _fwd_tag(mfma, k, cout, 3) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
     _lib.check(lib.tem_conv3d_fwd_refnorm(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(coef), _p(ws), nws,
-                                          N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma), _stream(x)),
+                                          N, D, H, W, cin, cout, k[0], k[1], k[2], _mode(mfma, x, y), _stream(x)),
                "tem_conv3d_fwd_refnorm")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
@@ -482,13 +518,13 @@ def conv_fwd_refnorm(x, w_packed, y, k, cin, cout, ref, coef, mfma):
 def conv_fwd_stat_blocks(x, k, cin, cout, mfma) -> int:
     """tem_conv3d_fwd_stat_blocks: statistics partial rows per sample this launch writes (0: it cannot)"""
     N, D, H, W, _, _ = _act5(x)
-    return int(_lib.load().tem_conv3d_fwd_stat_blocks(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
+    return int(_lib.load().tem_conv3d_fwd_stat_blocks(N, D, H, W, cin, cout, k[0], k[1], k[2], _mode(mfma, x, x)))
 
 
 def conv_fwd_family(x, k, cin, cout, mfma) -> int:
     """tem_conv3d_fwd_kernel: 0 patch / other kernels, 1 / 2 ping-pong teams, 3 z-reuse teams, 4 z-reuse teams with split-K"""
     N, D, H, W, _, _ = _act5(x)
-    return int(_lib.load().tem_conv3d_fwd_kernel(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
+    return int(_lib.load().tem_conv3d_fwd_kernel(N, D, H, W, cin, cout, k[0], k[1], k[2], _mode(mfma, x, x)))
 
 
 def _conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, mfma=False):
@@ -499,13 +535,14 @@ def _conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None,
     if C != cin or Cg != cout:
         raise ValueError("conv_wgrad: channel mismatch")
     lib = _lib.load()
-    nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma))
+    mode = _mode(mfma, x, g)
+    nws = lib.tem_conv3d_wgrad_ws(N, D, H, W, cin, cout, k[0], k[1], k[2], mode)
     ntaps = k[0] * k[1] * k[2]
     ws = _workspace(nws, x.device)
     kind = _wgrad_tag(mfma, k, cout) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
     _lib.check(lib.tem_conv3d_wgrad(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(dw_out), _p(db_out), _p(ws), nws,
-                                    N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma), 1, _stream(x)),
+                                    N, D, H, W, cin, cout, k[0], k[1], k[2], mode, 1, _stream(x)),
                "tem_conv3d_wgrad")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
@@ -526,6 +563,10 @@ def norm_stats(x, groups: int, gamma=None, beta=None, eps: float = 1e-5):
     V = D * H * W
     nws = lib.tem_norm_ws(N, V, C)
     ws = _workspace(nws, dev)
+    if _st(x):
+        _lib.check(lib.tem_norm_stats_st(_p(x), ld, N, V, C, groups, _p(gamma), _p(beta), eps, _p(mean), _p(rstd), _p(scale),
+                                         _p(shift), _p(ws), nws, _st(x), _stream(x)), "tem_norm_stats_st")
+        return mean, rstd, scale, shift
     _lib.check(lib.tem_norm_stats(_p(x), ld, N, V, C, groups, _p(gamma), _p(beta), eps, _p(mean), _p(rstd), _p(scale),
                                   _p(shift), _p(ws), nws, _stream(x)), "tem_norm_stats")
     return mean, rstd, scale, shift
@@ -563,6 +604,13 @@ def norm_bwd_coef(gy, x, groups, gamma, mean, rstd, dgamma=None, dbeta=None, sum
     nws = lib.tem_norm_ws(N, V, C)
     ws = _workspace(nws, x.device)
     coef = torch.empty((N, C, 4), dtype=torch.float32, device=x.device)
+    if _st(x) or _st(gy):
+        _same_st(gy, x)
+        nrow = 0 if sums is None else (sums.shape[1] if sums.dim() == 4 else 1)
+        _lib.check(lib.tem_norm_bwd_st(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd), 0, None, C,
+                                       _p(dgamma), _p(dbeta), _p(sums), nrow, _p(coef), None, _p(ws), nws, _st(x), _stream(x)),
+                   "tem_norm_bwd_st")
+        return coef
     if sums is not None and sums.dim() == 4:   # partial rows [N, nblk, C, 2] from a data gradient (arm_dgrad_norm_sums)
         _lib.check(lib.tem_norm_bwd_from_partials(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd), 0,
                                                   None, C, _p(dgamma), _p(dbeta), _p(sums), sums.shape[1], _p(coef), _p(ws), nws,
@@ -584,6 +632,13 @@ def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None,
     V = D * H * W
     nws = lib.tem_norm_ws(N, V, C)
     ws = _workspace(nws, x.device)
+    if _st(x) or _st(gy) or _st(gx):
+        _same_st(gy, x, gx)
+        nrow = 0 if sums is None else (sums.shape[1] if sums.dim() == 4 else 1)
+        _lib.check(lib.tem_norm_bwd_st(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd), int(relu_mask),
+                                       _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(sums), nrow, None, None, _p(ws), nws, _st(x),
+                                       _stream(x)), "tem_norm_bwd_st")
+        return gx
     if sums is not None and sums.dim() == 4:   # partial rows [N, nblk, C, 2] from a data gradient (arm_dgrad_norm_sums)
         _lib.check(lib.tem_norm_bwd_from_partials(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd),
                                                   int(relu_mask), _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(sums), sums.shape[1],
@@ -609,6 +664,16 @@ def maxpool_fwd(x, y, f, want_stats=False):
     y_ld = _act5(y)[5]
     lib = _lib.load()
     nblk = int(lib.tem_maxpool3d_fwd_stat_blocks(D, H, C, f[0], f[1])) if want_stats else 0
+    if _st(x) or _st(y):
+        _same_st(x, y)
+        part = None
+        if nblk > 0 and x_ld % 4 == 0 and y_ld % 4 == 0 and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
+            part = torch.empty((N, nblk, C, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.tem_maxpool3d_fwd_st(_p(x), x_ld, _p(y), y_ld, N, D, H, W, C, f[0], f[1], f[2], _p(part),
+                                            nblk if part is not None else 0, _st(x), _stream(x)), "tem_maxpool3d_fwd_st")
+        if want_stats:
+            return None if part is None else (part, nblk)
+        return y
     if nblk > 0 and x_ld % 4 == 0 and y_ld % 4 == 0 and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
         part = torch.empty((N, nblk, C, 2), dtype=torch.float32, device=x.device)
         _lib.check(lib.tem_maxpool3d_fwd_stats(_p(x), x_ld, _p(y), y_ld, N, D, H, W, C, f[0], f[1], f[2], _p(part), nblk,
@@ -628,6 +693,15 @@ def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None, gy_c
     gx_ld = _act5(gx)[5]
     gs_ld = _act5(gskip)[5] if gskip is not None else 0
     lib = _lib.load()
+    if gy_coef is not None and not gy_coef.is_contiguous():
+        raise ValueError("maxpool_bwd: gy_coef must be contiguous")
+    if _st(x) or _st(gy) or _st(gx):
+        _same_st(gy, x, gx, gskip)
+        _lib.check(lib.tem_maxpool3d_bwd_st(_p(gy), gy_ld, _p(x), x_ld, _p(gskip), gs_ld, int(relu_mask), _p(gx), gx_ld,
+                                            N, D, H, W, C, f[0], f[1], f[2], _p(gskip_coef),
+                                            gskip_coef.stride(0) if gskip_coef is not None else 0, _p(gy_coef), None, _st(x),
+                                            _stream(x)), "tem_maxpool3d_bwd_st")
+        return gx
     if gskip_coef is not None or gy_coef is not None:
         # gy_coef: dense [N, C, 4] coefficients of the norm whose input is the pooled tensor (gy raw as well)
         if gy_coef is not None and not gy_coef.is_contiguous():
@@ -650,6 +724,15 @@ def upsample_fwd(x, y, f, stats: bool = False):
     N, D, H, W, C, x_ld = _act5(x)
     y_ld = _act5(y)[5]
     lib = _lib.load()
+    if _st(x) or _st(y):
+        _same_st(x, y)
+        part = None
+        if stats and lib.tem_upsample_fwd_stats_ok(C, f[0], f[1], f[2]) and x_ld % 4 == 0 and y_ld % 4 == 0 and \
+                x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
+            part = torch.empty((N, D * H, C, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.tem_upsample_fwd_st(_p(x), x_ld, _p(y), y_ld, N, D, H, W, C, f[0], f[1], f[2], _p(part), _st(x),
+                                           _stream(x)), "tem_upsample_fwd_st")
+        return part if stats else y
     if stats:
         if not (lib.tem_upsample_fwd_stats_ok(C, f[0], f[1], f[2]) and x_ld % 4 == 0 and y_ld % 4 == 0 and
                 x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
@@ -676,6 +759,10 @@ def upsample_stats(u, f):
     N, D, H, W, C, u_ld = _act5(u)
     part = torch.empty((N, D * H, C, 2), dtype=torch.float32, device=u.device)
     lib = _lib.load()
+    if _st(u):
+        _lib.check(lib.tem_upsample_stats_st(_p(u), u_ld, N, D, H, W, C, f[0], f[1], f[2], _p(part), _st(u), _stream(u)),
+                   "tem_upsample_stats_st")
+        return part
     _lib.check(lib.tem_upsample_stats(_p(u), u_ld, N, D, H, W, C, f[0], f[1], f[2], _p(part), _stream(u)),
                "tem_upsample_stats")
     return part
@@ -712,6 +799,13 @@ def upsample_bwd(gy, gx, f, norm=None):
     N, D, H, W, C, gx_ld = _act5(gx)
     gy_ld = _act5(gy)[5]
     lib = _lib.load()
+    if _st(gy) or _st(gx):
+        u, coef = norm if norm is not None else (None, None)
+        _same_st(gy, gx, u)
+        _lib.check(lib.tem_upsample_bwd_st(_p(gy), gy_ld, _p(gx), gx_ld, N, D, H, W, C, f[0], f[1], f[2], _p(u),
+                                           _act5(u)[5] if u is not None else 0, _p(coef), coef.stride(0) if coef is not None else 0,
+                                           _st(gy), _stream(gx)), "tem_upsample_bwd_st")
+        return gx
     if norm is not None:
         u, coef = norm
         _lib.check(lib.tem_upsample_bwd_norm(_p(gy), gy_ld, _p(gx), gx_ld, N, D, H, W, C, f[0], f[1], f[2], _p(u),
