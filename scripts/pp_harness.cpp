@@ -16,6 +16,8 @@ void tem_pp_trace_read(unsigned long long* dst);
 #ifdef TEM_ZR_TRACE
 void tem_zr_trace_read(unsigned long long* dst);
 #endif
+#include "../torch_em_amd/csrc/tem_act.h"
+#include <string.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 static float frand(uint64_t& s) {  // uniform [-1, 1)
@@ -54,22 +56,39 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&ref, hr.size() * 4));
         CK(hipMemcpy(ref, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
     }
+    // ZR_ST=1|2: x, ref, y as fp16 / bf16 tensors (round 5: 16-bit activation storage; mode must be 5 / 7)
+    const int st = getenv("ZR_ST") ? atoi(getenv("ZR_ST")) : 0;
+    if (st) {
+        auto cv = [&](float v) -> unsigned short {
+            if (st == 1) { _Float16 h = (_Float16)v; unsigned short u; memcpy(&u, &h, 2); return u; }
+            unsigned u; memcpy(&u, &v, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        };
+        std::vector<unsigned short> x16(hx.size());
+        for (size_t i = 0; i < hx.size(); ++i) x16[i] = cv(hx[i]);
+        CK(hipMemcpy(x, x16.data(), x16.size() * 2, hipMemcpyHostToDevice));
+        if (ref) {
+            std::vector<unsigned short> r16(V * Cout);
+            for (auto& v : r16) v = cv(frand(seed));
+            CK(hipMemcpy(ref, r16.data(), r16.size() * 2, hipMemcpyHostToDevice));
+        }
+    }
     hipStream_t s = 0;
     tem_pack_weights_bf16x3(w, wp, Cout, Cin, 3, 3, 3, 0, mode, s);
     void* ws = nullptr;
     const int64_t wsb = tem_conv_fwd_mfma_ws(N, D, H, W, Cin, Cout, 3, 3, 3);
     if (wsb) CK(hipMalloc(&ws, wsb));
     auto run = [&]() {
-        float* st = use_norm && !use_ref ? stat : nullptr;
+        TemStScope sc_(st, st);
+        float* stp = use_norm && !use_ref ? stat : nullptr;
         // variants >= 1: straight into THIS executable's copy of conv_pp.hip (calls inside libtem_hip.so bind locally)
         if (variant == 2 && tem_conv_fwd_zr(x, Cin, use_norm ? sc : nullptr, use_norm ? sf : nullptr, wp, b, y, Cout, ref, Cout, N, D,
-                                            H, W, Cin, Cout, 3, 3, 3, TEM_ACT_RELU, mode, st, s) > 0)
+                                            H, W, Cin, Cout, 3, 3, 3, TEM_ACT_RELU, mode, stp, s) > 0)
             return;
         if (variant == 1 && tem_conv_fwd_pp(x, Cin, use_norm ? sc : nullptr, use_norm ? sf : nullptr, wp, b, y, Cout, ref, Cout, N, D,
-                                            H, W, Cin, Cout, 3, 3, 3, TEM_ACT_RELU, mode, st, s))
+                                            H, W, Cin, Cout, 3, 3, 3, TEM_ACT_RELU, mode, stp, s))
             return;
         int rc = tem_conv_fwd_bf16x3(x, Cin, use_norm ? sc : nullptr, use_norm ? sf : nullptr, wp, b, y, Cout, ref, Cout, ws, wsb, N,
-                                     D, H, W, Cin, Cout, 3, 3, 3, TEM_ACT_RELU, mode, st, s);
+                                     D, H, W, Cin, Cout, 3, 3, 3, TEM_ACT_RELU, mode, stp, s);
         if (rc) { printf("launch failed: %s\n", tem_last_error()); exit(1); }
     };
     for (int i = 0; i < 3; ++i) run();

@@ -3,10 +3,12 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include <math.h>
 #include "../torch_em_amd/csrc/tem_common.h"
 #include "../torch_em_amd/csrc/conv_internal.h"
+#include "../torch_em_amd/csrc/tem_act.h"
 #ifdef TEM_ZS_TRACE
 void tem_zs_trace_read(unsigned long long* dst);
 #endif
@@ -49,7 +51,20 @@ int main(int argc, char** argv) {
     int h16 = getenv("WG_ONE") ? atoi(getenv("WG_ONE")) : 0;   // 0 bf16x3, 1 fp16, 2 bf16, 3 fp16 2x1 (prescaled g)
     unsigned* amax; CK(hipMalloc(&amax, 4)); CK(hipMemset(amax, 0, 4));
     if (tem_absmax(g, Cout, Cout, (int64_t)V, amax, s)) { printf("absmax failed: %s\n", tem_last_error()); return 1; }
+    // WG_ST=1|2: x and g as fp16 / bf16 tensors (round 5: 16-bit activation storage; WG_ONE must be the one-term mode of the type)
+    const int st = getenv("WG_ST") ? atoi(getenv("WG_ST")) : 0;
+    if (st) {
+        std::vector<unsigned short> x16(hx.size()), g16(hg.size());
+        auto cv = [&](float v) -> unsigned short {
+            if (st == 1) { _Float16 h = (_Float16)v; unsigned short u; memcpy(&u, &h, 2); return u; }
+            unsigned u; memcpy(&u, &v, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        };
+        for (size_t i = 0; i < hx.size(); ++i) x16[i] = cv(hx[i]);
+        for (size_t i = 0; i < hg.size(); ++i) g16[i] = cv(hg[i]);
+        CK(hipMemcpy(x, x16.data(), x16.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(g, g16.data(), g16.size() * 2, hipMemcpyHostToDevice));
+    }
     auto run = [&]() {
+        TemStScope sc_(st, st);
         tem_wgrad_gscale_source = h16 == 3 ? amax : nullptr;
         int rc = tem_conv_wgrad_bf16x3(x, Cin, sc, sf, g, Cout, dw, db, ws, wsb, N, D, H, W, Cin, Cout, 3, 3, 3, 1, h16, nullptr, nullptr,
                                        nullptr, nullptr, s);

@@ -37,6 +37,9 @@
 #define TR_REC16 64                // bytes per voxel record: 32 channels x 16 bit (ARITH 4, exact fp32: 128)
 #define TR_NXS 5                   // ring slots of x^ halo planes: 3 being multiplied + 1 prefetched by the multiplying team + 1 being written
 #define TR_NGS 3                   // g planes: multiplied, prefetched, being written
+#ifndef TR_UNROLL
+#define TR_UNROLL 8                // iterations per trip of the 16-bit staging loop (even: two register sets alternate)
+#endif
 #define TR_XT_OF(rec) (TR_NXS * 100 * (rec))   // one term of x^: ring of 10 x 10 halo planes
 #define TR_GT_OF(rec) (TR_NGS * 64 * (rec))    // one term of g: 8 x 8 planes
 
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const X0 = ldsb;                  // [term NX][slot 4][row 10][x 10][32 ch]
     unsigned char* const G0 = ldsb + NX * TR_XT;     // [term NG][buffer 2][row 8][x 8][32 ch]
+    unsigned char* const TRASH = G0 + NG * TR_GT;    // 16-bit tensors: 256 x 16 bytes that threads without a halo voxel write to
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -331,17 +335,30 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                     const uint4 ghc = gh;
                     load_g(sl < 3 ? gb : gbn, (sl + 1) & 3);
                     if (NX == 2) load_x(xl, sl < 3 ? xb : xbn, 1, (sl + 1) & 3);
+                    if constexpr (NX == 1) {
+                        // one-term x (the mixed modes): the lo register set is free, so it is the SECOND fragment buffer -- the
+                        // reads of slab sl + 1 fly during the 7 MFMAs of slab sl (even slabs multiply xh and fill xl, odd ones the
+                        // reverse; four slabs per plane keep the parity).  Round 4 read the next fragments into the SAME registers
+                        // behind the MFMAs that used them: every slab then waited a full LDS round trip (trace of round 5, amp mode:
+                        // 2200 cycles per plane for 28 MFMAs = 0.4 of the matrix pipe, unchanged by 16-bit staging).
+                        uint4* const cur = (sl & 1) ? xl : xh;
+                        uint4* const nxt = (sl & 1) ? xh : xl;
+                        load_x(nxt, sl < 3 ? xb : xbn, 0, (sl + 1) & 3);
+#pragma unroll
+                        for (int j = 0; j < NA; ++j) acc[j] = mfma16<F16>(cur[j], ghc, acc[j]);
+                        interleave();
+                        continue;
+                    }
 #pragma unroll
                     for (int j = 0; j < NA; ++j) acc[j] = mfma16<F16>(xh[j], ghc, acc[j]);
-                    if (NX == 1) {   // one-term x: its next fragments can only follow the MFMAs that read the current ones
-                        __builtin_amdgcn_sched_barrier(0);
-                        load_x(xh, sl < 3 ? xb : xbn, 0, (sl + 1) & 3);
-                    }
                     interleave();
                 }
                 TR_STAMP(t - za, 2);
                 __syncthreads();
                 TR_STAMP(t - za, 3);
+            }
+            if constexpr (T16) {   // the staging team of the 16-bit kernel walks a segment in trips of TR_UNROLL iterations
+                for (int e = zb - za + 6; e % TR_UNROLL; ++e) __syncthreads();
             }
         }
         // ---- partial slabs: D[row = ci][col = co] ----
@@ -375,7 +392,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
         const int oct = tl & 3;
         float db8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (!mteam) {
-            uint4 xa[2][2], ga[2];
+            uint4 xa[2][2] = {{make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)}, {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)}};
+            uint4 ga[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
             float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f), sc5 = sc4, sf5 = sf4;
             if (scale) {
                 sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + oct * 8);
@@ -410,64 +428,73 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                 bool zin[2] = {false, false};
                 // same schedule as the fp32 staging below: iteration t stores x plane t + 3 / g plane t + 2 from the register set
                 // loaded two iterations ago and loads x plane t + 5 / g plane t + 4 into it
+                // Every iteration issues its three loads UNCONDITIONALLY (a plane outside the volume / the segment reads with an
+                // offset beyond the buffer: zeros) and in straight-line code.  With the loads inside `if (plane in range)` blocks
+                // -- round 4, and the first 16-bit version -- the compiler cannot count what is outstanding at the loop head and
+                // waits with vmcnt(0) before the first conversion: the loads of the OTHER register set, issued one iteration
+                // earlier, were waited for at once -- the full memory latency sat in every iteration (trace: 900 - 1900 cycles
+                // from the top of an iteration to its last LDS store, the multiplying team waiting at the barrier).
                 auto iteration = [&](int t, uint4(&xs_)[2], uint4& gs_, bool& zin_) {
                     TR_STAMP(t - za, 0);
                     if (TEM_TR_ABL & 1) {
                         __syncthreads();
                         return;
                     }
-                    if (t >= za - 4) {
+                    {   // (no branch in here: the pre-norm always runs -- scale 1, shift 0 without a norm reproduces the value bit for
+                        // bit --, threads without a second halo voxel write a scratch record, the priming iterations write planes
+                        // that are rewritten before anything reads them)
                         unsigned char* const xs = X0 + TR_XSLOT(t + 3) + oct * 16;
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int hv = (tl + 256 * q) >> 2;
-                            if (q == 1 && hv >= 100) break;
-                            uint4 r = xs_[q];
-                            if (zin_) {
-                                if (scale) {   // launch-uniform; zero padding applies after the pre-norm
-                                    r.x = tr_norm2<F16>(r.x, sc4.x, sf4.x, sc4.y, sf4.y);
-                                    r.y = tr_norm2<F16>(r.y, sc4.z, sf4.z, sc4.w, sf4.w);
-                                    r.z = tr_norm2<F16>(r.z, sc5.x, sf5.x, sc5.y, sf5.y);
-                                    r.w = tr_norm2<F16>(r.w, sc5.z, sf5.z, sc5.w, sf5.w);
-                                    r.x = okx[q] ? r.x : 0u; r.y = okx[q] ? r.y : 0u; r.z = okx[q] ? r.z : 0u; r.w = okx[q] ? r.w : 0u;
-                                }
-                            } else
-                                r = make_uint4(0u, 0u, 0u, 0u);
-                            *reinterpret_cast<uint4*>(xs + hv * TR_REC) = r;
+                            uint4 r = xs_[q];   // zeros for a plane or a voxel outside the volume
+                            const bool ok = okx[q] && zin_;
+                            r.x = tr_norm2<F16>(r.x, sc4.x, sf4.x, sc4.y, sf4.y);
+                            r.y = tr_norm2<F16>(r.y, sc4.z, sf4.z, sc4.w, sf4.w);
+                            r.z = tr_norm2<F16>(r.z, sc5.x, sf5.x, sc5.y, sf5.y);
+                            r.w = tr_norm2<F16>(r.w, sc5.z, sf5.z, sc5.w, sf5.w);
+                            r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
+                            unsigned char* const dst = (q == 0 || hv < 100) ? xs + hv * TR_REC : TRASH + tl * 16;
+                            *reinterpret_cast<uint4*>(dst) = r;
                         }
                     }
-                    if (t + 2 >= za && t + 2 < zb) {
+                    {
                         unsigned char* const gs = G0 + TR_GSLOT(t + 2) + oct * 16;
                         const uint4 v = gs_;   // zeros where out of range (load offset beyond the buffer)
                         *reinterpret_cast<uint4*>(gs + (tl >> 2) * TR_REC) = v;
-                        if (do_db) {   // workgroup-uniform
-                            db8[0] += act_lo<TS>(v.x); db8[1] += act_hi<TS>(v.x); db8[2] += act_lo<TS>(v.y); db8[3] += act_hi<TS>(v.y);
-                            db8[4] += act_lo<TS>(v.z); db8[5] += act_hi<TS>(v.z); db8[6] += act_lo<TS>(v.w); db8[7] += act_hi<TS>(v.w);
-                        }
+                        db8[0] += act_lo<TS>(v.x); db8[1] += act_hi<TS>(v.x); db8[2] += act_lo<TS>(v.y); db8[3] += act_hi<TS>(v.y);
+                        db8[4] += act_lo<TS>(v.z); db8[5] += act_hi<TS>(v.z); db8[6] += act_lo<TS>(v.w); db8[7] += act_hi<TS>(v.w);
                     }
                     TR_STAMP(t - za, 1);
                     {
+                        // (plain scalar arithmetic, no short-circuit operators: a branch around a load would be back)
                         const int zx = t + 5;
-                        zin_ = zx >= za - 1 && zx <= zb && zx >= 0 && zx < D;   // wave-uniform
-                        if (zin_ && !(TEM_TR_ABL & 8)) {
-                            const tr_rsrc_t rsx = tr_rsrc(xn + zx * xplane);
+                        const int ldx = (int)(zx >= za - 1) & (int)(zx <= zb) & (int)(zx >= 0) & (int)(zx < D) & (int)!(TEM_TR_ABL & 8);   // wave-uniform
+                        zin_ = ldx != 0;
+                        const tr_rsrc_t rsx = tr_rsrc(xn + (int64_t)(zx * ldx) * xplane);
+                        const unsigned mx = ldx ? 0u : OOB;   // OR-ed into the offsets (< 2^31): beyond the buffer -> zeros
 #pragma unroll
-                            for (int q = 0; q < 2; ++q) xs_[q] = tr_load4u(rsx, offx[q]);
-                        }
+                        for (int q = 0; q < 2; ++q) xs_[q] = tr_load4u(rsx, offx[q] | mx);
                         const int zg = t + 4;
-                        if (zg >= za && zg < zb && !(TEM_TR_ABL & 8)) {
-                            const tr_rsrc_t rsg = tr_rsrc(gn + zg * gplane);
-                            gs_ = tr_load4u(rsg, offg);
-                        }
+                        const int ldg = (int)(zg >= za) & (int)(zg < zb) & (int)!(TEM_TR_ABL & 8);
+                        const tr_rsrc_t rsg = tr_rsrc(gn + (int64_t)(zg * ldg) * gplane);
+                        gs_ = tr_load4u(rsg, offg | (ldg ? 0u : OOB));
                     }
                     TR_STAMP(t - za, 2);
                     __syncthreads();
                     TR_STAMP(t - za, 3);
                 };
+                // Trips of TR_UNROLL iterations, straight-line: inside a trip the compiler counts the outstanding loads exactly
+                // (vmcnt(3) before a conversion: the other set's three loads stay in flight); at the loop head it does not -- it
+                // waits for everything (vmcnt(0)), i.e. for the loads issued one barrier earlier: one exposed memory latency per
+                // TRIP (with trips of two iterations, round 4's loop, per two planes: 900 of 2300 cycles per plane in the trace).
+                // A segment is padded to whole trips with idle iterations (zero planes into free ring slots; the multiplying team
+                // meets their barriers).
+                const int t_end = za - 6 + (zb - za + 6 + TR_UNROLL - 1) / TR_UNROLL * TR_UNROLL;
 #pragma unroll 1
-                for (int t = za - 6; t < zb; t += 2) {
-                    iteration(t, xa[0], ga[0], zin[0]);
-                    if (t + 1 < zb) iteration(t + 1, xa[1], ga[1], zin[1]);
+                for (int t = za - 6; t < t_end; t += TR_UNROLL) {
+#pragma unroll
+                    for (int k = 0; k < TR_UNROLL; ++k) iteration(t + k, xa[k & 1], ga[k & 1], zin[k & 1]);
                 }
             }
         }
@@ -683,8 +710,8 @@ void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lb, s, reinterpret_cast<const TS*>(x), x_ld, scale, shift,
                            reinterpret_cast<const TS*>(g), g_ld, zpart, zdb, N, D, H, W, Cin, Cout, T, nY, nX, zsegs, Ss, ncz, gmax, g_amax);
     };
-    if (tem_call_st.x == 1) launch16(&k_conv_wgrad_tr<1, tem_f16>, XT + GT, tem_f16{});
-    else if (tem_call_st.x == 2) launch16(&k_conv_wgrad_tr<2, tem_bf16>, XT + GT, tem_bf16{});
+    if (tem_call_st.x == 1) launch16(&k_conv_wgrad_tr<1, tem_f16>, XT + GT + 4096, tem_f16{});
+    else if (tem_call_st.x == 2) launch16(&k_conv_wgrad_tr<2, tem_bf16>, XT + GT + 4096, tem_bf16{});
     else if (h16 == 1) launch(&k_conv_wgrad_tr<1>, XT + GT);
     else if (h16 == 2) launch(&k_conv_wgrad_tr<2>, XT + GT);
     else if (h16 == 3) launch(&k_conv_wgrad_tr<3>, 2 * XT + GT);

@@ -35,8 +35,17 @@
 #ifndef TEM_ZR_PRIO
 #define TEM_ZR_PRIO 1    // s_setprio of the team in its MFMA phase
 #endif
+#ifndef TEM_ZR_STAGE_PRIO
+#define TEM_ZR_STAGE_PRIO 0   // s_setprio of the team in its staging phase (experiment)
+#endif
 #ifndef TEM_ZR_R0
 #define TEM_ZR_R0 2      // halo planes (of 6; three 16-byte loads each) requested BEFORE the epilogue of the previous unit
+#endif
+#ifndef TEM_ZR_R0_16
+#define TEM_ZR_R0_16 2   // ... with 16-bit tensors (three 16-byte loads per plane: all six planes fit the register ring), plain / ReLU-mask epilogues
+#endif
+#ifndef TEM_ZR_R0_16S
+#define TEM_ZR_R0_16S 2  // ... statistics / norm-backward epilogues
 #endif
 #ifndef TEM_ZR_AD
 #define TEM_ZR_AD 2      // activation-fragment prefetch depth (LDS reads in flight ahead of the MFMAs that use them)
@@ -113,6 +122,22 @@ __device__ __forceinline__ unsigned zr_norm2(unsigned h, float s0, float t0, flo
 template <int M>
 __device__ __forceinline__ float zr_swz(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (M << 10) | 0x1f));
+}
+
+// r + (value of lane ^ 16) / r + (value of lane ^ 32) on the vector ALU: gfx950's v_permlane{16,32}_swap_b32 exchange the odd
+// 16-lane rows (the upper 32-lane half) of one register with the even rows (lower half) of another; with both registers
+// holding r the two results are [r0 r0 r2 r2] / [r1 r1 r3 r3] (rows), whose sum is the pairwise total in every lane.  (An LDS
+// crossbar op -- ds_swizzle / ds_bpermute -- issues every ~32 cycles beside the partner team's MFMAs, a VALU op every ~6; the
+// clang builtin for the swap returned the same register for both results, ROCm 7.2: hence the asm, s_nop for the VALU hazard.)
+__device__ __forceinline__ float zr_xor16_sum(float r) {
+    float a = r, b = r;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float zr_xor32_sum(float r) {
+    float a = r, b = r;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
 }
 
 // value of the lane a DPP control selects (row_ror / row_half_mirror / quad_perm: inside a row of 16 lanes)
@@ -203,7 +228,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     constexpr int CPL = T16 ? 8 : 4;             // channels per load slot
     constexpr int RP = NIT / SPP;                // planes the register ring holds
     constexpr int R0 = (WIDE && !T16) ? ((MODE == 1 || MODE == 3) ? 1 : 2)   // (a ring of three planes: at most two ahead; the statistics / norm-backward epilogues have no room for 12 loads)
-                            : (TEM_ZR_R0 < HZ ? TEM_ZR_R0 : HZ);   // halo planes loaded before the epilogue
+                       : T16 ? ((MODE == 1 || MODE == 3) ? TEM_ZR_R0_16S : TEM_ZR_R0_16)
+                             : (TEM_ZR_R0 < HZ ? TEM_ZR_R0 : HZ);   // halo planes loaded before the epilogue
     constexpr int FR = NS * 64;                  // uint4s per (tap, 16-channel chunk) fragment group
     constexpr bool SC = F16 && NS == 2 && !WIDE;
     constexpr int ZSTEP = HY * HX * 32;          // bytes between halo z-planes: 5760 = 45 * 128 (bank-neutral)
@@ -336,6 +362,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
         {
             // ================= staging phase (the partner team runs its tap loop) =================
             ZR_STAMP(0);
+            if (TEM_ZR_STAGE_PRIO) __builtin_amdgcn_s_setprio(TEM_ZR_STAGE_PRIO);
             // keep hipcc from hoisting the 18 LDS / 18 global addresses of a phase out of the unit loop (it spills them)
 #pragma unroll
             for (int j = 0; j < SPP; ++j) asm volatile("" : "+v"(lwj[j]), "+v"(poff[j]));
@@ -417,6 +444,142 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                 const __amdgpu_buffer_rsrc_t rr_ = zr_rsrc(has_ref ? (const void*)(ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld + eu.cot * 32) : (const void*)y);
                 const bool full = (TEM_ZR_ABL & 32) ? true : ((eu.z0 + TZ <= D) & (eu.y0 + TY <= H) & (eu.x0 + TX <= W));
                 const bool vok = (eu.y0 + 4 * tw + py < H) & (eu.x0 + px < W);   // this lane's footprint voxel (any z)
+                if constexpr (Y16) {
+                    // ---- 16-bit outputs (round 5).  What bounds the staging team beside the partner's MFMAs is instruction
+                    // ISSUE, and nothing issues slower than a global store (~370 cycles each, scripts/proto/issue_bench.hip; in the
+                    // trace of the first 16-bit version the 16 eight-byte stores of a unit WERE its epilogue: 6300 of the 12.2 k
+                    // cycles of a staging phase against 7.5 k of MFMAs).  So a lane stores 8 channels = 16 bytes: 4 lanes cover the
+                    // 64-byte record of a voxel, a store instruction 16 voxels = two footprint rows, 8 stores per unit instead of 16
+                    // (the reference loads of the mask modes halve the same way).  Bias, activation, masks, rounding and the
+                    // statistics all run AFTER the LDS transpose on those 8 channels: the bias is two float4 per lane (the fp32
+                    // epilogue below folds it into the accumulator layout with 32 v_readlane), the statistics 16 values per lane
+                    // summed over the 16 lanes that share a channel octet with DPP / v_permlane swaps (no 16 -> 1 transposing
+                    // reduction).
+                    constexpr bool has_ref16 = MODE == 2 || MODE == 3;
+                    float s8[8], q8[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) s8[c] = q8[c] = 0.f;
+                    unsigned char* scr = zr_lds + 2 * NS * PLB + tw * (32 * 144);
+                    unsigned char* scr_w = scr + v * 144 + kh * 16;
+                    // lane = (row mm of a row pair, x = X, channel octet oct); pass P handles footprint rows m = 2 P + mm.
+                    // scratch row of footprint voxel (m, X): m = 0: X (+ 8 for X >= 4), 1: 20 + X, 2: 4 + X, 3: row of m = 0 + 16
+                    const int oct = lane & 3, X = (lane >> 2) & 7, mm = lane >> 5;
+                    const int r00 = X < 4 ? X : X + 8;
+                    const unsigned char* scr_p0 = scr + (mm ? 20 + X : r00) * 144 + oct * 32;
+                    const unsigned char* scr_p1 = scr + (mm ? 16 + r00 : 4 + X) * 144 + oct * 32;
+                    const bool tok_x = (eu.x0 + X < W);
+                    unsigned yo16 = ((unsigned)((4 * tw + mm) * W + X) * (unsigned)y_ld + (unsigned)(8 * oct)) * 2u;
+                    unsigned ro16 = ((unsigned)((4 * tw + mm) * W + X) * (unsigned)ref_ld + (unsigned)(8 * oct)) * 2u;
+                    asm volatile("" : "+v"(yo16), "+v"(ro16));
+                    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+                    if (bias) {   // launch-uniform
+                        b0 = *reinterpret_cast<const float4*>(bias + eu.cot * 32 + 8 * oct);
+                        b1 = *reinterpret_cast<const float4*>(bias + eu.cot * 32 + 8 * oct + 4);
+                    }
+                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    float4 kc[MODE == 3 ? 8 : 1];
+                    if (MODE == 3) {
+                        const float4* cf = reinterpret_cast<const float4*>(stat) + ((int64_t)eu.n * Cout + eu.cot * 32 + oct * 8);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) kc[MODE == 3 ? c : 0] = cf[c];
+                    }
+                    ZR_STAMP(8);
+                    auto body16 = [&](auto full_tag) {
+                        constexpr bool FULL = decltype(full_tag)::value;
+                        uint4 rq[2][2];
+                        auto load_ref = [&](int z) {
+                            const unsigned zo = (unsigned)z * (unsigned)(H * W);
+#pragma unroll
+                            for (int P = 0; P < 2; ++P) {
+                                const bool ok = FULL || (tok_x & (eu.y0 + 4 * tw + 2 * P + mm < H) & (eu.z0 + z < D));
+                                rq[z & 1][P] = zr_load4u(rr_, ok ? ro16 : 0u, ok ? (zo + (unsigned)(2 * P * W)) * (unsigned)ref_ld * 2u : 0u);
+                            }
+                        };
+                        if (has_ref16) load_ref(0);
+#pragma unroll
+                        for (int z = 0; z < TZ; ++z) {
+                            const unsigned zo = (unsigned)z * (unsigned)(H * W);
+                            if (has_ref16 && z + 1 < TZ) load_ref(z + 1);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                *reinterpret_cast<float4*>(scr_w + 32 * j) = make_float4(acc[z][4 * j], acc[z][4 * j + 1], acc[z][4 * j + 2], acc[z][4 * j + 3]);
+                            float4 t[2][2];
+#pragma unroll
+                            for (int P = 0; P < 2; ++P) {
+                                t[P][0] = *reinterpret_cast<const float4*>((P ? scr_p1 : scr_p0));
+                                t[P][1] = *reinterpret_cast<const float4*>((P ? scr_p1 : scr_p0) + 16);
+                            }
+#pragma unroll
+                            for (int P = 0; P < 2; ++P) {
+                                float o[8] = {t[P][0].x + bb[0], t[P][0].y + bb[1], t[P][0].z + bb[2], t[P][0].w + bb[3],
+                                              t[P][1].x + bb[4], t[P][1].y + bb[5], t[P][1].z + bb[6], t[P][1].w + bb[7]};
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) asm("v_max_f32 %0, %1, %2" : "=v"(o[c]) : "v"(o[c]), "v"(act_floor));
+                                if (has_ref16) {
+                                    const uint4 rr4 = rq[z & 1][P];
+                                    const float r[8] = {act_lo<T>(rr4.x), act_hi<T>(rr4.x), act_lo<T>(rr4.y), act_hi<T>(rr4.y),
+                                                        act_lo<T>(rr4.z), act_hi<T>(rr4.z), act_lo<T>(rr4.w), act_hi<T>(rr4.w)};
+#pragma unroll
+                                    for (int c = 0; c < 8; ++c) {
+                                        if (MODE == 3) {
+                                            const float4 k4 = kc[MODE == 3 ? c : 0];
+                                            o[c] = r[c] > 0.f ? k4.x * o[c] - k4.y - (r[c] - k4.w) * k4.z : 0.f;
+                                        } else
+                                            o[c] = r[c] > 0.f ? o[c] : 0.f;
+                                    }
+                                }
+                                const bool sok = FULL || (tok_x & (eu.y0 + 4 * tw + 2 * P + mm < H) & (eu.z0 + z < D));
+                                const unsigned p0 = act_pk<TOut>(o[0], o[1]), p1 = act_pk<TOut>(o[2], o[3]);
+                                const unsigned p2 = act_pk<TOut>(o[4], o[5]), p3 = act_pk<TOut>(o[6], o[7]);
+                                if (MODE == 1) {   // the statistics describe the tensor AS STORED
+                                    float a[8] = {act_lo<TOut>(p0), act_hi<TOut>(p0), act_lo<TOut>(p1), act_hi<TOut>(p1),
+                                                  act_lo<TOut>(p2), act_hi<TOut>(p2), act_lo<TOut>(p3), act_hi<TOut>(p3)};
+#pragma unroll
+                                    for (int c = 0; c < 8; ++c) {
+                                        if (!FULL) a[c] = sok ? a[c] : 0.f;
+                                        s8[c] += a[c];
+                                        q8[c] = fmaf(a[c], a[c], q8[c]);
+                                    }
+                                }
+                                if (AMAX && sok) amx = tem_amax4(tem_amax4(amx, o[0], o[1], o[2], o[3]), o[4], o[5], o[6], o[7]);
+                                if (sok && (!(TEM_ZR_ABL & 2) || o[0] == 12345.678f)) {
+                                    const u32x4z pv = {p0, p1, p2, p3};
+                                    // (offset in the VGPR, soffset an immediate: the store-data hazard of zr_store4)
+                                    __builtin_amdgcn_raw_buffer_store_b128(pv, ry, yo16 + (zo + (unsigned)(2 * P * W)) * (unsigned)y_ld * 2u, 0, TEM_ZR_ST_AUX);
+                                }
+                            }
+                        }
+                    };
+                    if (full) body16(std::true_type{});
+                    else body16(std::false_type{});
+                    ZR_STAMP(9);
+                    if (MODE == 1) {
+                        // sums over the 16 lanes that hold the same channel octet (lane & 3): partners 4 and 8 lanes on in the
+                        // row of 16 (DPP row_ror), then lane ^ 16 and lane ^ 32 (v_permlane{16,32}_swap); lanes 0 .. 3 write
+                        // [8 channels][2] = four float4
+                        float r16[16];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            r16[2 * c] = s8[c];
+                            r16[2 * c + 1] = q8[c];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) r16[i] += zr_dpp<0x124>(r16[i]);   // row_ror:4
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) r16[i] += zr_dpp<0x128>(r16[i]);   // row_ror:8
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) r16[i] = zr_xor16_sum(r16[i]);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) r16[i] = zr_xor32_sum(r16[i]);
+                        if (lane < 4) {
+                            const int64_t patch = ((int64_t)(eu.z0 / TZ) * nY + eu.y0 / TY) * nX + eu.x0 / TX;
+                            const int64_t nblk = (int64_t)nZ * nY * nX * 4;
+                            float4* dst = reinterpret_cast<float4*>(stat + (((int64_t)eu.n * nblk + patch * 4 + tw) * Cout + eu.cot * 32 + 8 * lane) * 2);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) dst[k] = make_float4(r16[4 * k], r16[4 * k + 1], r16[4 * k + 2], r16[4 * k + 3]);
+                        }
+                    }
+                } else {
                 if (SC) {   // fold the scaled cross products first: their 64 registers are free for the rest of the epilogue
 #pragma unroll
                     for (int z = 0; z < TZ; ++z)
@@ -590,6 +753,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                     float* dst = stat + (((int64_t)eu.n * nblk + patch * 4 + tw) * Cout + ch) * 2;
                     dst[lane & 1] = (lane & 1) ? b1 : a1;
                 }
+                }   // fp32 outputs
                 ZR_STAMP(10);
                 // the next unit of this team starts from zero (the accumulator registers were dead from their stores up to here)
 #pragma unroll
@@ -699,6 +863,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                         wq[0][tz][p] = zr_load4u(rw, woff_lane, wsoff + (unsigned)((tz * 9) * tapstride + p * 64) * 16u);
             }
             ZR_STAMP(2);
+            if (TEM_ZR_STAGE_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         {

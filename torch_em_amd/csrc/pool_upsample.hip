@@ -21,7 +21,9 @@ struct VecT<1> {
 #endif
 template <int VEC, typename T>
 __device__ __forceinline__ void ld_vec(const T* p, float (&v)[VEC]) {
-    if constexpr (VEC == 4) {
+    if constexpr (VEC == 8) {   // 16-bit tensors: 8 channels = one 16-byte access, as 4 fp32 channels are
+        act_ld8(p, v);
+    } else if constexpr (VEC == 4) {
         const float4 t = act_ld4(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
@@ -30,7 +32,9 @@ __device__ __forceinline__ void ld_vec(const T* p, float (&v)[VEC]) {
 }
 template <int VEC, typename T>
 __device__ __forceinline__ void st_vec(T* p, const float (&v)[VEC]) {
-    if constexpr (VEC == 4) {
+    if constexpr (VEC == 8) {
+        act_st8(p, v);
+    } else if constexpr (VEC == 4) {
 #if TEM_POOL_NT
         act_st4_nt(p, make_float4(v[0], v[1], v[2], v[3]));
 #else
@@ -48,6 +52,17 @@ static inline bool vec4_ok(int C, std::initializer_list<const void*> ptrs, std::
         if (p && ((uintptr_t)p % tem_st_align4(st))) return false;
     for (int64_t l : lds)
         if (l % 4) return false;
+    return true;
+}
+
+// 16-bit tensors whose rows allow 16-byte accesses of 8 channels (what a load / store instruction moves per lane decides the
+// rate of these kernels: with 8-byte accesses the 16-bit max-pool backward of round 5's first cut ran SLOWER than fp32)
+static inline bool vec8_ok(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds, int st) {
+    if (!st || C % 8) return false;
+    for (const void* p : ptrs)
+        if (p && ((uintptr_t)p % 16)) return false;
+    for (int64_t l : lds)
+        if (l % 8) return false;
     return true;
 }
 
@@ -302,9 +317,16 @@ static int maxpool3d_fwd_impl(const void* x, int64_t x_ld, void* y, int64_t y_ld
     int64_t rows = (int64_t)N * (D / fz) * (H / fy);
     TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_fwd: too many rows");
     const bool v4 = vec4_ok(C, {x, y}, {x_ld, y_ld}, st);
-    const int cq = v4 ? C / 4 : C;
+    const bool v8 = vec8_ok(C, {x, y}, {x_ld, y_ld}, st) && 256 % (C / 8) == 0 && tem_option(TEM_OPT_POOL_VEC8);
+    const int cq = v8 ? C / 8 : v4 ? C / 4 : C;
     TEM_REQUIRE(!stat || (cq <= 256 && 256 % cq == 0), "tem_maxpool3d_fwd_stats: tem_maxpool3d_fwd_stat_blocks() == 0 for C = %d", C);
     const size_t lds = stat ? (size_t)(256 / cq) * C * 2 * sizeof(float) : 0;
+    if (v8) {
+        TEM_ST16_SWITCH(st, T, hipLaunchKernelGGL((k_maxpool_fwd<8, T>), dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream,
+                                                  (const T*)x, x_ld, (T*)y, y_ld, D, H, W, C, fz, fy, fx, stat));
+        TEM_CHECK_LAUNCH("tem_maxpool3d_fwd");
+        return TEM_OK;
+    }
     TEM_ST_SWITCH(st, T, {
         if (v4)
             hipLaunchKernelGGL((k_maxpool_fwd<4, T>), dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, (const T*)x, x_ld,
@@ -361,6 +383,13 @@ static int maxpool3d_bwd_impl(const void* gy, int64_t gy_ld, const void* x, int6
     int64_t rows = (int64_t)N * (D / fz) * (H / fy);
     TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_bwd: too many rows");
     const bool v4 = vec4_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}, st);
+    if (vec8_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}, st) && tem_option(TEM_OPT_POOL_VEC8)) {
+        TEM_ST16_SWITCH(st, T, hipLaunchKernelGGL((k_maxpool_bwd<8, T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                                                  (const T*)gy, gy_ld, (const T*)x, x_ld, (const T*)gskip, gskip_ld, relu_mask, (T*)gx,
+                                                  gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef, amax));
+        TEM_CHECK_LAUNCH("tem_maxpool3d_bwd");
+        return TEM_OK;
+    }
     TEM_ST_SWITCH(st, T, {
         if (v4)
             hipLaunchKernelGGL((k_maxpool_bwd<4, T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)gy, gy_ld,
@@ -642,32 +671,51 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const T* __restrict__ gy, 
 //   fine o = 2i reads coarse (i-1, i) with (0.25, 0.75) -- (x[0], x[0]) with (1, 0) at i = 0; o = 2i+1 reads (i, i+1) with
 //   (0.75, 0.25), i+1 clamped: area_pixel_compute_source_index for scale 1/2, as lin_src().
 // ---------------------------------------------------------------------------
-struct F4 {
-    float v[4];
+// CH channels of one voxel: 4 (one 16-byte access of fp32, 8 bytes of a 16-bit type) or 8 (16 bytes of a 16-bit type)
+template <int CH>
+struct FV {
+    float v[CH];
 };
-template <typename T>
-__device__ __forceinline__ F4 ld4(const T* p) {
-    const float4 t = act_ld4(p);
-    return F4{{t.x, t.y, t.z, t.w}};
+template <int CH, typename T>
+__device__ __forceinline__ FV<CH> ldv(const T* p) {
+    FV<CH> r;
+    if constexpr (CH == 8) {
+        act_ld8(p, r.v);
+    } else {
+        const float4 t = act_ld4(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    }
+    return r;
 }
-template <typename T>
-__device__ __forceinline__ void st4(T* p, const F4& a) { act_st4(p, make_float4(a.v[0], a.v[1], a.v[2], a.v[3])); }
-__device__ __forceinline__ F4 lerp2(float l0, const F4& a, float l1, const F4& b) {
-    F4 r;
+template <int CH, typename T>
+__device__ __forceinline__ void stv(T* p, const FV<CH>& a) {
+    if constexpr (CH == 8) act_st8(p, a.v);
+    else act_st4(p, make_float4(a.v[0], a.v[1], a.v[2], a.v[3]));
+}
+template <int CH>
+__device__ __forceinline__ FV<CH> fv_zero() {
+    FV<CH> r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.v[j] = l0 * a.v[j] + l1 * b.v[j];
+    for (int j = 0; j < CH; ++j) r.v[j] = 0.f;
+    return r;
+}
+template <int CH>
+__device__ __forceinline__ FV<CH> lerp2(float l0, const FV<CH>& a, float l1, const FV<CH>& b) {
+    FV<CH> r;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) r.v[j] = l0 * a.v[j] + l1 * b.v[j];
     return r;
 }
 
 // forward; optionally the (sum y, sum y^2) partials of the block's coarse row [N][D*H][C][2] (what tem_upsample_stats
 // derives from u with a 27-point stencil: here the outputs are in registers anyway)
-template <int FZ, typename T>
+template <int FZ, typename T, int CH = 4>
 __global__ __launch_bounds__(256) void k_upsample2_fwd(const T* __restrict__ x, int64_t x_ld, T* __restrict__ y,
                                                        int64_t y_ld, int D, int H, int W, int C,
                                                        float* __restrict__ part) {
     extern __shared__ float lsu[];  // [4 waves][C][2] when part
     const int Ho = 2 * H, Wo = 2 * W;
-    const int cq = C >> 2;
+    const int cq = C / CH;
     int row = blockIdx.x;  // (n, zi, yi) of the coarse grid
     const int yi = row % H;
     row /= H;
@@ -678,20 +726,22 @@ __global__ __launch_bounds__(256) void k_upsample2_fwd(const T* __restrict__ x, 
     const float ya0 = yi == 0 ? 1.f : 0.25f, ya1 = yi == 0 ? 0.f : 0.75f;   // fine 2yi: (ym, yi)
     const float za0 = zi == 0 ? 1.f : 0.25f, za1 = zi == 0 ? 0.f : 0.75f;
     const int zrow[3] = {zm, zi, zp}, yrow[3] = {ym, yi, yp};
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
     for (int i = threadIdx.x; i < W * cq; i += 256) {
-        const int xi = i / cq, c0 = (i % cq) * 4;
+        const int xi = i / cq, c0 = (i % cq) * CH;
         const int xm = max(xi - 1, 0), xp = min(xi + 1, W - 1);
         const float xa0 = xi == 0 ? 1.f : 0.25f, xa1 = xi == 0 ? 0.f : 0.75f;
-        F4 Y[FZ == 2 ? 3 : 1][2][2];  // [coarse z][fine y parity][fine x parity]
+        FV<CH> Y[FZ == 2 ? 3 : 1][2][2];  // [coarse z][fine y parity][fine x parity]
 #pragma unroll
         for (int kz = 0; kz < (FZ == 2 ? 3 : 1); ++kz) {
             const int zc = FZ == 2 ? zrow[kz] : zi;
-            F4 X[3][2];
+            FV<CH> X[3][2];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const T* r = x + ((((int64_t)n * D + zc) * H + yrow[ky]) * W) * x_ld + c0;
-                const F4 a = ld4(r + (int64_t)xm * x_ld), b = ld4(r + (int64_t)xi * x_ld), c = ld4(r + (int64_t)xp * x_ld);
+                const FV<CH> a = ldv<CH>(r + (int64_t)xm * x_ld), b = ldv<CH>(r + (int64_t)xi * x_ld), c = ldv<CH>(r + (int64_t)xp * x_ld);
                 X[ky][0] = lerp2(xa0, a, xa1, b);
                 X[ky][1] = lerp2(0.75f, b, 0.25f, c);
             }
@@ -708,19 +758,23 @@ __global__ __launch_bounds__(256) void k_upsample2_fwd(const T* __restrict__ x, 
             for (int sy = 0; sy < 2; ++sy)
 #pragma unroll
                 for (int sx = 0; sx < 2; ++sx) {
-                    F4 o;
+                    FV<CH> o;
                     if constexpr (FZ == 2)
                         o = sz == 0 ? lerp2(za0, Y[0][sy][sx], za1, Y[1][sy][sx]) : lerp2(0.75f, Y[1][sy][sx], 0.25f, Y[2][sy][sx]);
                     else
                         o = Y[0][sy][sx];
                     const int64_t vo = (((int64_t)n * (D * FZ) + zi * FZ + sz) * Ho + 2 * yi + sy) * Wo + 2 * xi + sx;
                     if constexpr (sizeof(T) == 2) {   // the row sums describe the tensor AS STORED
-                        const unsigned p0 = act_pk<T>(o.v[0], o.v[1]), p1 = act_pk<T>(o.v[2], o.v[3]);
-                        o = F4{{act_lo<T>(p0), act_hi<T>(p0), act_lo<T>(p1), act_hi<T>(p1)}};
-                    }
-                    st4(y + vo * y_ld + c0, o);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < CH; j += 2) {
+                            const unsigned pk = act_pk<T>(o.v[j], o.v[j + 1]);
+                            o.v[j] = act_lo<T>(pk);
+                            o.v[j + 1] = act_hi<T>(pk);
+                        }
+                    }
+                    stv<CH>(y + vo * y_ld + c0, o);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
                         s1[j] += o.v[j];
                         s2[j] = fmaf(o.v[j], o.v[j], s2[j]);
                     }
@@ -729,14 +783,14 @@ __global__ __launch_bounds__(256) void k_upsample2_fwd(const T* __restrict__ x, 
     if (part) {
         const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            for (int o = cq; o < 64; o <<= 1) {  // lanes sharing a quad sit cq apart (256 % cq == 0)
+        for (int j = 0; j < CH; ++j) {
+            for (int o = cq; o < 64; o <<= 1) {  // lanes sharing a channel group sit cq apart (256 % cq == 0)
                 s1[j] += __shfl_xor(s1[j], o, 64);
                 s2[j] += __shfl_xor(s2[j], o, 64);
             }
             if (lane < cq) {
-                lsu[(wv * C + lane * 4 + j) * 2 + 0] = s1[j];
-                lsu[(wv * C + lane * 4 + j) * 2 + 1] = s2[j];
+                lsu[(wv * C + lane * CH + j) * 2 + 0] = s1[j];
+                lsu[(wv * C + lane * CH + j) * 2 + 1] = s2[j];
             }
         }
         __syncthreads();
@@ -795,7 +849,7 @@ __device__ __forceinline__ UtuAxis utu_axis2(int i0, int f, int in) {
     return r;
 }
 
-template <int FZ, typename T>
+template <int FZ, typename T, int CH = 4>
 __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy, int64_t gy_ld,
                                                        T* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
                                                        const T* __restrict__ u, int64_t u_ld,
@@ -803,7 +857,7 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy,
     constexpr int CZ = FZ == 2 ? 2 : 1;      // coarse z per thread
     constexpr int NZF = FZ == 2 ? 6 : 1;     // fine z planes it reads
     const int Do = D * FZ, Ho = 2 * H, Wo = 2 * W;
-    const int cq = C >> 2;
+    const int cq = C / CH;
     const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1, Dp = (D + CZ - 1) / CZ;
     int row = blockIdx.x;  // (n, z pair, y pair) of the coarse grid
     const int y0 = (row % Hp) * 2;
@@ -811,15 +865,15 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy,
     const int z0 = (row % Dp) * CZ;
     const int n = row / Dp;
     for (int i = threadIdx.x; i < Wp * cq; i += 256) {
-        const int x0 = (i / cq) * 2, c0 = (i % cq) * 4;
+        const int x0 = (i / cq) * 2, c0 = (i % cq) * CH;
         const UpbAxis ax = upb_axis2(x0, W);
-        F4 acc[CZ][2][2];
+        FV<CH> acc[CZ][2][2];
 #pragma unroll
         for (int a = 0; a < CZ; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) acc[a][b][c] = F4{{0.f, 0.f, 0.f, 0.f}};
+                for (int c = 0; c < 2; ++c) acc[a][b][c] = fv_zero<CH>();
         // the z and y loops stay rolled (plane / row index and weights recomputed from the loop counter: wave-uniform
         // scalar work): unrolled, the 216 loads and their addresses were all hoisted (500 VGPRs, occupancy 1)
 #pragma unroll 1
@@ -829,23 +883,23 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy,
             float wz[CZ];
 #pragma unroll
             for (int a = 0; a < CZ; ++a) wz[a] = FZ == 2 ? upb_w(oz, D, z0 + a) : 1.f;
-            F4 pp[2][2];
+            FV<CH> pp[2][2];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) pp[b][c] = F4{{0.f, 0.f, 0.f, 0.f}};
+                for (int c = 0; c < 2; ++c) pp[b][c] = fv_zero<CH>();
 #pragma unroll 2
             for (int ky = 0; ky < 6; ++ky) {
                 const int oy = 2 * y0 - 1 + ky;
                 const float wy[2] = {upb_w(oy, H, y0), upb_w(oy, H, y0 + 1)};
                 const T* r = gy + ((((int64_t)n * Do + zf) * Ho + min(max(oy, 0), Ho - 1)) * Wo) * gy_ld + c0;
-                F4 t[6];
+                FV<CH> t[6];
 #pragma unroll
-                for (int kx = 0; kx < 6; ++kx) t[kx] = ld4(r + (int64_t)ax.idx[kx] * gy_ld);
+                for (int kx = 0; kx < 6; ++kx) t[kx] = ldv<CH>(r + (int64_t)ax.idx[kx] * gy_ld);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < CH; ++j) {
                         const float xr = ax.w[c][0] * t[2 * c].v[j] + ax.w[c][1] * t[2 * c + 1].v[j] +
                                          ax.w[c][2] * t[2 * c + 2].v[j] + ax.w[c][3] * t[2 * c + 3].v[j];
                         pp[0][c].v[j] = fmaf(wy[0], xr, pp[0][c].v[j]);
@@ -859,19 +913,19 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy,
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[a][b][c].v[j] = fmaf(wz[a], pp[b][c].v[j], acc[a][b][c].v[j]);
+                        for (int j = 0; j < CH; ++j) acc[a][b][c].v[j] = fmaf(wz[a], pp[b][c].v[j], acc[a][b][c].v[j]);
         }
         if (ncoef) {
             // U^T(norm backward(g)) = a*U^T g - m1*U^T 1 - m2r*(U^T U u - mean*U^T 1) (see k_upsample_bwd): the 27-point
             // stencil on u, separably over the pair's 4x4x4 neighbourhood
             const UtuAxis bx = utu_axis2(x0, 2, W), by = utu_axis2(y0, 2, H), bz = utu_axis2(z0, FZ, D);
-            F4 q[CZ][2][2];
+            FV<CH> q[CZ][2][2];
 #pragma unroll
             for (int a = 0; a < CZ; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) q[a][b][c] = F4{{0.f, 0.f, 0.f, 0.f}};
+                    for (int c = 0; c < 2; ++c) q[a][b][c] = fv_zero<CH>();
             constexpr int NZU = FZ == 2 ? 4 : 1;
 #pragma unroll 1
             for (int kz = 0; kz < NZU; ++kz) {
@@ -879,22 +933,22 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy,
                 float wz[CZ];
 #pragma unroll
                 for (int a = 0; a < CZ; ++a) wz[a] = FZ == 2 ? pick3(bz.a[a], kz - a) : 1.f;
-                F4 qp[2][2];
+                FV<CH> qp[2][2];
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) qp[b][c] = F4{{0.f, 0.f, 0.f, 0.f}};
+                    for (int c = 0; c < 2; ++c) qp[b][c] = fv_zero<CH>();
 #pragma unroll 2
                 for (int ky = 0; ky < 4; ++ky) {
                     const float wy[2] = {pick3(by.a[0], ky), pick3(by.a[1], ky - 1)};
                     const T* r = u + ((((int64_t)n * D + zc) * H + min(max(y0 - 1 + ky, 0), H - 1)) * W) * u_ld + c0;
-                    F4 t[4];
+                    FV<CH> t[4];
 #pragma unroll
-                    for (int kx = 0; kx < 4; ++kx) t[kx] = ld4(r + (int64_t)bx.idx[kx] * u_ld);
+                    for (int kx = 0; kx < 4; ++kx) t[kx] = ldv<CH>(r + (int64_t)bx.idx[kx] * u_ld);
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < CH; ++j) {
                             const float xr = bx.a[c][0] * t[c].v[j] + bx.a[c][1] * t[c + 1].v[j] + bx.a[c][2] * t[c + 2].v[j];
                             qp[0][c].v[j] = fmaf(wy[0], xr, qp[0][c].v[j]);
                             qp[1][c].v[j] = fmaf(wy[1], xr, qp[1][c].v[j]);
@@ -907,11 +961,11 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy,
 #pragma unroll
                         for (int c = 0; c < 2; ++c)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) q[a][b][c].v[j] = fmaf(wz[a], qp[b][c].v[j], q[a][b][c].v[j]);
+                            for (int j = 0; j < CH; ++j) q[a][b][c].v[j] = fmaf(wz[a], qp[b][c].v[j], q[a][b][c].v[j]);
             }
-            float4 kc[4];
+            float4 kc[CH];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) kc[j] = *reinterpret_cast<const float4*>(ncoef + (int64_t)n * ncoef_ld + (c0 + j) * 4);
+            for (int j = 0; j < CH; ++j) kc[j] = *reinterpret_cast<const float4*>(ncoef + (int64_t)n * ncoef_ld + (c0 + j) * 4);
 #pragma unroll
             for (int a = 0; a < CZ; ++a)
 #pragma unroll
@@ -920,7 +974,7 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy,
                     for (int c = 0; c < 2; ++c) {
                         const float S = (FZ == 2 ? bz.s[a] : 1.f) * by.s[b] * bx.s[c];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < CH; ++j)
                             acc[a][b][c].v[j] = kc[j].x * acc[a][b][c].v[j] - kc[j].y * S - kc[j].z * (q[a][b][c].v[j] - kc[j].w * S);
                     }
         }
@@ -932,7 +986,7 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gy,
                 for (int c = 0; c < 2; ++c) {
                     if (z0 + a >= D || y0 + b >= H || x0 + c >= W) continue;
                     const int64_t v = (((int64_t)n * D + z0 + a) * H + y0 + b) * W + x0 + c;
-                    st4(gx + v * gx_ld + c0, acc[a][b][c]);
+                    stv<CH>(gx + v * gx_ld + c0, acc[a][b][c]);
                 }
     }
 }
@@ -1062,6 +1116,17 @@ static int upsample_fwd_impl(const void* x, int64_t x_ld, void* y, int64_t y_ld,
     int64_t rows = (int64_t)N * D * fz * H * fy;
     TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_fwd: too many rows");
     const size_t ldsb = part ? (size_t)4 * C * 2 * sizeof(float) : 0;
+    // 16-bit tensors: 8 channels per thread (16-byte accesses) where the row partials keep their layout (C / 8 a power of two)
+    // (factor (1, 2, 2) only: with three coarse z-planes in registers the 8-channel variant needs 300 VGPRs)
+    if (fz == 1 && upsample2_ok(C, fz, fy, fx) && vec8_ok(C, {x, y}, {x_ld, y_ld}, st) && ((C / 8) & (C / 8 - 1)) == 0 && C / 8 <= 64) {
+        const int64_t crow = (int64_t)N * D * H;
+        TEM_ST16_SWITCH(st, T, {
+            hipLaunchKernelGGL((k_upsample2_fwd<1, T, 8>), dim3((unsigned)crow), dim3(256), ldsb, (hipStream_t)stream, (const T*)x,
+                               x_ld, (T*)y, y_ld, D, H, W, C, part);
+        });
+        TEM_CHECK_LAUNCH("tem_upsample_fwd");
+        return TEM_OK;
+    }
     TEM_ST_SWITCH(st, T, {
         const T* xs = (const T*)x;
         T* ys = (T*)y;
@@ -1112,6 +1177,21 @@ static int upsample_bwd_impl(const void* gy, int64_t gy_ld, void* gx, int64_t gx
     TEM_REQUIRE(rows < (1ll << 31), "tem_upsample_bwd: too many rows");
     // the 2x2x2-per-thread kernel has 1/8 of the gather kernel's threads: it needs a volume that still fills the chip
     const int64_t pairs = (int64_t)N * ((D + fz - 1) / fz) * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    if (upsample2_ok(C, fz, fy, fx) && pairs >= 2 * 65536 && vec8_ok(C, {gy, gx, u}, {gy_ld, gx_ld, u ? u_ld : 0}, st) && tem_option(TEM_OPT_UPSAMPLE2_CH8)) {
+        TEM_ST16_SWITCH(st, T, {
+            if (fz == 2) {
+                const int64_t prow = (int64_t)N * ((D + 1) / 2) * ((H + 1) / 2);
+                hipLaunchKernelGGL((k_upsample2_bwd<2, T, 8>), dim3((unsigned)prow), dim3(256), 0, (hipStream_t)stream, (const T*)gy,
+                                   gy_ld, (T*)gx, gx_ld, D, H, W, C, (const T*)u, u_ld, ncoef, ncoef_ld);
+            } else {
+                const int64_t prow = (int64_t)N * D * ((H + 1) / 2);
+                hipLaunchKernelGGL((k_upsample2_bwd<1, T, 8>), dim3((unsigned)prow), dim3(256), 0, (hipStream_t)stream, (const T*)gy,
+                                   gy_ld, (T*)gx, gx_ld, D, H, W, C, (const T*)u, u_ld, ncoef, ncoef_ld);
+            }
+        });
+        TEM_CHECK_LAUNCH("tem_upsample_bwd");
+        return TEM_OK;
+    }
     TEM_ST_SWITCH(st, T, {
         const T* gys = (const T*)gy;
         const T* us = (const T*)u;

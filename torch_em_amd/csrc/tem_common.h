@@ -24,6 +24,8 @@ enum {
     TEM_OPT_ZR_WIDE,
     TEM_OPT_ZR_TILE_BLOCKS,
     TEM_OPT_DICE_VOX,
+    TEM_OPT_UPSAMPLE2_CH8,
+    TEM_OPT_POOL_VEC8,
     TEM_OPT_COUNT
 };
 long long tem_option(int id);
