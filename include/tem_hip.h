@@ -181,8 +181,9 @@ int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float
  * patch, channel) partial sums (sum y, sum y^2) of the stored output, taken from the accumulators in the epilogue --
  * the 2 x 128^3 x 32 output of a level-0 conv is not read back for `nn.InstanceNorm3d` / `GroupNorm` / `BatchNorm3d`
  * (reference ConvBlock, model/unet.py:429-438: norm(conv(x))).  stat_part: [N][stat_blocks][Cout][2] floats with
- * stat_blocks = tem_conv3d_fwd_stat_blocks(...), which returns 0 for launches that cannot provide them (VALU / exact
- * fp32 kernels, split-K shapes): use tem_norm_stats there.  tem_norm_finalize_partials (below) merges them. */
+ * stat_blocks = tem_conv3d_fwd_stat_blocks(...), which returns 0 for launches that cannot provide them (the generic VALU
+ * kernels, the exact-fp32 kernels, the patch kernel's split-K launches; the split-K launches of the z-reuse kernel DO:
+ * their epilogue writes the rows): use tem_norm_stats there.  tem_norm_finalize_partials (below) merges them. */
 int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 /* Which kernel family a tem_conv3d_fwd launch of this shape selects under the current options: 3 = the z-reuse team
  * kernel (csrc/conv_zr.hip: 3x3x3, 4x16x8 patches), 4 = the same kernel with the input channels split over several units

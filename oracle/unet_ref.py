@@ -106,3 +106,39 @@ def unet_loss_and_grads(sd, x, y, scale_factors, norm="InstanceNorm", final_acti
     loss = (loss_fn or dice_loss)(pred, y)
     loss.backward()
     return pred.detach(), loss.detach(), {k: v.grad for k, v in sd.items()}
+
+
+class DecisionTap:
+    """Context manager around unet_forward: records the input of every ReLU (`pre`, forward order) and of every max-pool
+    (`pool_in`), and -- given `force = {"relu": [bool masks], "pool": [flat arg-max indices as max_pool*_with_indices
+    returns them]}` -- replaces the network's own decisions by those: ReLU becomes `x * mask`, the pooling a gather.
+    With the decisions of another arithmetic forced, what is left of the distance between the two gradients is rounding,
+    not near-ties resolved differently (scripts/flip_census.py, tests/test_gpu_unet.py)."""
+
+    def __init__(self, force=None):
+        self.pre, self.pool_in, self.force, self._i, self._j = [], [], force, 0, 0
+
+    def _relu(self, t):
+        self.pre.append(t.detach())
+        if self.force is None:
+            return torch.relu(t)
+        m = self.force["relu"][self._i]
+        self._i += 1
+        return t * m.to(t.dtype)
+
+    def _pool(self, t, f):
+        self.pool_in.append(t.detach())
+        if self.force is None:
+            return torch.max_pool3d(t, f) if t.dim() == 5 else torch.max_pool2d(t, f)
+        idx = self.force["pool"][self._j]
+        self._j += 1
+        return torch.gather(t.flatten(2), 2, idx.flatten(2)).view(idx.shape)
+
+    def __enter__(self):
+        self._orig = (F.relu, F.max_pool2d, F.max_pool3d)
+        F.relu, F.max_pool2d, F.max_pool3d = self._relu, self._pool, self._pool
+        return self
+
+    def __exit__(self, *exc):
+        F.relu, F.max_pool2d, F.max_pool3d = self._orig
+        return False

@@ -77,10 +77,11 @@ def test_predict_with_halo_3d(case):
 
 @pytest.mark.parametrize("case", ["plain", "mask"])
 def test_predict_with_halo_over_several_gpu_ids(case):
-    """`gpu_ids` with more than one entry: one worker thread per entry, blocks dealt round-robin, per-device output volumes
-    merged box by box (reference util/prediction.py:188-193, 313).  On a one-GPU box the entries name the same device
-    twice -- the threads, the block split and the merge are what is under test; the result must be bit-identical to the
-    single-worker run (and to more workers than blocks)."""
+    """`gpu_ids` with more than one entry: one worker thread per DEVICE (each with its own model copy, made before the
+    workers start, and its own HIP stream), blocks dealt round-robin, per-device output volumes merged box by box (reference
+    util/prediction.py:188-193, 313).  Repeated entries of one device share its worker (round 5, advisor: two workers on
+    one device shared the model and the library's per-stream scratch buffers), so on a one-GPU box this checks the argument
+    handling and that the result is bit-identical to the single-entry run; the threads and the merge need two devices."""
     from torch_em_amd.util import predict_with_halo
     model, _ = _model(True, 1, 2)
     rng = np.random.default_rng(5)
@@ -118,3 +119,72 @@ def test_predict_with_halo_2d_and_padding():
     gotp = predict_with_padding(model, xs, (4, 4))
     assert gotp.shape == wantp.shape == (1, 3, 37, 50)
     assert float(np.abs(gotp - wantp).max()) < 1e-4
+
+
+def test_block_kernels_against_the_reference_helpers():
+    """G9 (tests/golden/gen_golden_predict.py): what the reference's own `_load_block` and `_write_prediction` return
+    (util/prediction.py:98-142, 420-447) for halos crossing no / one / both borders, 2-D, channel axes, mask blocks -- the
+    gather kernel (tem_block_load_reflect) and the masked inner-box scatter (tem_block_store_inner) reproduce them bit for bit."""
+    import os
+    from conftest import GOLDEN
+    from torch_em_amd import _lib
+    from torch_em_amd.util.prediction import _load_block_device, _store_inner
+    g = dict(np.load(os.path.join(GOLDEN, "g9_predict_helpers.npz")))
+    for case in g["load_block_cases"]:
+        name, key, wc = str(case).split("|")
+        wc = bool(int(wc))
+        off, bs, ha = (list(map(int, r)) for r in g[name + ".args"])
+        nd = 2 if key == "vol2" else 3
+        off, bs, ha = off[:nd], bs[:nd], ha[:nd]
+        x = g[key]
+        vol = torch.from_numpy(x if wc else x[None]).to(DEV)
+        while vol.dim() < 4:
+            vol = vol[:, None]
+        got = _load_block_device(vol.contiguous(), off, bs, ha, nd).cpu().numpy()
+        assert np.array_equal(got if wc else got[0], g[name + ".data"]), name
+    begin, end, halo = (list(map(int, r)) for r in g["wp.args"])
+    size = [e - b for b, e in zip(begin, end)]
+    pred = torch.from_numpy(g["wp.pred"]).to(DEV)
+    lib = _lib.load()
+    out = torch.full((3, 7, 9, 11), -7.0, device=DEV)
+    _store_inner(lib, pred, out, None, halo, begin, size)
+    assert np.array_equal(out.cpu().numpy(), g["wp.out_channels"])
+    mask = torch.zeros((7, 9, 11), dtype=torch.uint8, device=DEV)
+    mask[tuple(slice(b, e) for b, e in zip(begin, end))] = torch.from_numpy(g["wp.mask_block"].astype("uint8")).to(DEV)
+    out = torch.full((3, 7, 9, 11), -7.0, device=DEV)
+    _store_inner(lib, pred, out, mask, halo, begin, size)
+    assert np.array_equal(out.cpu().numpy(), g["wp.out_masked"])
+
+
+@pytest.mark.parametrize("case", ["plain", "mask", "roi", "channels", "list_output"])
+@pytest.mark.parametrize("batch_size", [1, 3])
+def test_predict_with_halo_pipelined(case, batch_size):
+    """reference util/prediction.py:487-759: same arguments, same result as predict_with_halo -- here bit for bit (the same
+    kernels, staged over a prefetch / compute / write-back stream; `batch_size` blocks per forward pass)."""
+    from torch_em_amd.util import predict_with_halo, predict_with_halo_pipelined
+    cin = 2 if case == "channels" else 1
+    model, _ = _model(True, cin, 3)
+    rng = np.random.default_rng(7)
+    shape = (20, 36, 28)
+    x = rng.standard_normal(((cin,) if case == "channels" else ()) + shape).astype("float32")
+    bs, halo = (8, 16, 16), (4, 8, 8)
+    kw = dict(with_channels=case == "channels", disable_tqdm=True)
+    if case == "mask":
+        m = np.zeros(shape, dtype="uint8")
+        m[2:14, 5:30, :20] = 1
+        kw["mask"] = m
+    if case == "roi":
+        kw["roi"] = (slice(4, 20), slice(None, 30), slice(6, None))
+    if case == "list_output":
+        oa, ob = np.zeros(shape, "float32"), np.zeros((2,) + shape, "float32")
+        pa, pb = np.zeros(shape, "float32"), np.zeros((2,) + shape, "float32")
+        predict_with_halo(x, model, [DEV], bs, halo, output=[(oa, 0), (ob, slice(1, 3))], **kw)
+        predict_with_halo_pipelined(x, model, [DEV], bs, halo, output=[(pa, 0), (pb, slice(1, 3))], batch_size=batch_size, **kw)
+        assert np.array_equal(oa, pa) and np.array_equal(ob, pb) and float(np.abs(pb).max()) > 0
+        return
+    want = predict_with_halo(x, model, [DEV], bs, halo, **kw)
+    got = predict_with_halo_pipelined(x, model, [DEV], bs, halo, batch_size=batch_size, num_prefetch_workers=2,
+                                      num_write_workers=2, **kw)
+    assert got.shape == want.shape and np.array_equal(got, want) and float(np.abs(got).max()) > 0
+    with pytest.raises(NotImplementedError):
+        predict_with_halo_pipelined(x, model, [DEV], bs, halo, grid_shift=(0.5, 0.5, 0.5), **kw)

@@ -191,6 +191,72 @@ def test_unet3d_benchmark_widths_depth4_match_fp64_oracle(dispatch_mix):
     _median_over_seeds(make, (0, 1, 2, 3))
 
 
+def _library_decisions(model, x):
+    """ReLU masks (forward order of oracle.unet_ref.unet_forward) and pooling arg-maxes of this library's forward pass"""
+    import torch.nn.functional as F
+    from torch_em_amd.model import engine
+    _, st = engine._forward_impl(model, x.to(DEV), keep=True)
+    nchw = lambda t: t.permute(0, 4, 1, 2, 3).float().cpu()  # noqa: E731
+    blocks = [lv["bs"] for lv in st["levels"]] + [st["base"]] + [d["bs"] for d in st["dec"]]
+    masks = [nchw(bs[k]) > 0 for bs in blocks for k in ("a1", "out")]
+    pools = [F.max_pool3d_with_indices(nchw(lv["skip"]), tuple(lv["f"]))[1] for lv in st["levels"]]
+    return {"relu": masks, "pool": pools}
+
+
+@pytest.mark.parametrize("seed", [0, 5])
+def test_depth4_gradient_max_norm_with_the_library_decisions_forced(seed):
+    """The plain north-star bound -- 1e-3, MAX norm, every parameter tensor -- for the 32 ... 512-feature benchmark network,
+    on a comparison without near-ties: the float64 oracle runs with every ReLU mask and every pooling arg-max forced to the
+    decisions this library took (oracle.unet_ref.DecisionTap), so what is compared is the arithmetic of the kernels and not
+    which way a pre-activation of 1e-9 x rms was rounded.  profiles/r05_flip_census.txt (scripts/flip_census.py) has the
+    census behind this: seed 0 is the 1.5e-2 outlier of the free comparison, seed 5 an ordinary one; both must pass here."""
+    from oracle import loss_ref, unet_ref
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d
+    torch.manual_seed(seed)
+    model = UNet3d(1, 2, depth=4, initial_features=32)
+    g = torch.Generator().manual_seed(100 + seed)
+    x = torch.randn(1, 1, 64, 64, 64, generator=g)
+    y = (torch.rand(1, 2, 64, 64, 64, generator=g) > 0.5).float()
+    sd = {k: v.detach().double().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model.to(DEV)
+    force = _library_decisions(model, x)
+    with unet_ref.DecisionTap(force):
+        pred64 = unet_ref.unet_forward(sd, x.double(), [2, 2, 2, 2], norm="InstanceNorm")
+    loss64 = loss_ref.dice_loss(pred64, y.double())
+    loss64.backward()
+    pred = model(x.to(DEV))
+    loss = DiceLoss()(pred, y.to(DEV))
+    loss.backward()
+    assert rel_err(pred.detach().cpu(), pred64.detach()) < TOL and abs(float(loss) - float(loss64.detach())) < TOL
+    gscale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref = sd[k].grad
+        if float(ref.abs().max()) < 1e-4 * gscale:
+            continue                       # conv biases in front of an InstanceNorm: analytically zero
+        err = float((p.grad.double().cpu() - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        assert err < TOL, (k, err)
+    print(f"seed {seed}: worst per-tensor max-norm gradient error with forced decisions {worst:.2e}")
+
+
+def test_default_arithmetic_is_bit_identical_to_round4():
+    """The 16-bit activation storage of round 5 templates every kernel of the step on its element type; the fp32-class
+    default must not have moved by a bit.  tests/golden/default_step_digest.json holds SHA-256 digests of prediction / loss
+    / flat gradient of three networks written by scripts/digest_default.py under TEM_LIB=<the round-4 library>; every
+    kernel is deterministic, so the digests are a property of the source tree and the chip.  (A deliberate change of a
+    summation order in a default-path kernel moves them: regenerate the fixture in the same commit and say so there.)"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+    import digest_default
+    with open(os.path.join(GOLDEN, "default_step_digest.json")) as f:
+        want = json.load(f)
+    for name, (kw, shape) in digest_default.CASES.items():
+        assert digest_default.run_case(kw, shape) == want[name], name
+
+
 def _median_over_seeds(make, seeds):
     """The bounds of _check_against_fp64 (whole gradient within 2x, every tensor within 4x the fp32 reference path's own
     error against float64, never above 1e-2) on the MEDIAN over `seeds`; make(seed) -> (oracle case, loss on the device)."""
@@ -218,7 +284,7 @@ def _median_over_seeds(make, seeds):
             per_tensor.setdefault(k, []).append((float(np.linalg.norm(hip[k] - r) / np.linalg.norm(r)),
                                                  float(np.linalg.norm(g32[k].numpy() - r) / np.linalg.norm(r))))
         print(f"seed {seed}: global gradient L2 rel err vs float64: hip {e_h:.2e}, fp32 reference path {e_c:.2e}")
-        assert e_h < 3e-2, (seed, e_h)              # a single seed may lose the near-tie lottery, but not by more than this
+        assert e_h < 2e-2, (seed, e_h)              # a single seed may lose the near-tie lottery (profiles/r05_flip_census.txt), but not by more than this
         del model
     med_h, med_c = float(np.median([a for a, _ in per_seed])), float(np.median([b for _, b in per_seed]))
     print(f"median over seeds: hip {med_h:.2e}, fp32 reference path {med_c:.2e}")

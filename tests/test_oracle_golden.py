@@ -269,3 +269,55 @@ def test_oracle_affinities_match_the_reference_definitions(tag):
     assert np.array_equal(out[:n], g[f"{tag}_affs_ignore0"]) and np.array_equal(out[n:], g[f"{tag}_mask_ignore0"])
     out = label_ref.affinities(seg, offs, ignore_label=0, add_mask=True, include_ignore_transitions=True)
     assert np.array_equal(out[:n], g[f"{tag}_affs_trans"]) and np.array_equal(out[n:], g[f"{tag}_mask_trans"])
+
+
+def test_predict_oracle_matches_the_reference_helpers():
+    """G9 = outputs of the reference's own `_load_block`, `_pad_for_shift_left` / `_crop_after_shift_left`,
+    `_prepare_block_input` and `_write_prediction` (util/prediction.py:79-142, 388-447; tests/golden/gen_golden_predict.py):
+    the halo / reflect / inner-crop / mask / channel-split semantics of the tiled prediction are pinned; only the block grid
+    (`bioimage_cpp.utils.Blocking`, not installed) stays restated."""
+    from oracle import predict_ref
+    g = dict(np.load(os.path.join(GOLDEN, "g9_predict_helpers.npz")))
+    for case in g["load_block_cases"]:
+        name, key, wc = str(case).split("|")
+        off, bs, ha = (list(map(int, r)) for r in g[name + ".args"])
+        if key == "vol2":
+            off, bs, ha = off[:2], bs[:2], ha[:2]
+        data, bb = predict_ref.load_block_bb(g[key], off, bs, ha, with_channels=bool(int(wc)))
+        assert np.array_equal(data, g[name + ".data"]), name
+        assert [list(b) for b in bb] == g[name + ".bb"].tolist(), name
+    padded, pad_left = predict_ref.pad_for_shift_left(g["vol3"], g["shift.pad_left"], False)
+    assert np.array_equal(padded, g["shift.pad"])
+    assert np.array_equal(predict_ref.crop_after_shift_left(padded, pad_left, False, g["vol3"].shape), g["shift.crop"])
+    padded_c, pad_left_c = predict_ref.pad_for_shift_left(g["vol3c"], (2, 1, 0), True)
+    assert np.array_equal(padded_c, g["shift.pad_c"])
+    assert np.array_equal(predict_ref.crop_after_shift_left(padded_c, pad_left_c, True, g["vol3c"].shape[1:]), g["shift.crop_c"])
+    for case in g["prepare_cases"]:
+        name, use_mask = str(case).split("|")
+        begin, end, bs, ha = (list(map(int, r)) for r in g[name + ".args"])
+        res = predict_ref.prepare_block_input(g["vol3"], g["mask3"] if int(use_mask) else None, begin, end, bs, ha, False, None,
+                                              predict_ref.standardize)
+        assert (res is None) == bool(g[name + ".skipped"]), name
+        if res is not None:
+            assert np.allclose(res[0], g[name + ".tensor"], rtol=1e-6, atol=1e-6), name
+            assert [list(b) for b in res[2]] == g[name + ".inner_bb"].tolist()
+            if int(use_mask):
+                assert np.array_equal(res[1], g[name + ".mask_block"])
+    res = predict_ref.prepare_block_input(g["vol3c"], None, [0, 3, 0], [3, 6, 6], (3, 3, 6), (1, 1, 2), True, lambda a: False, None)
+    assert np.array_equal(res[0], g["pb_channels.tensor"])
+    assert predict_ref.prepare_block_input(g["vol3c"], None, [0, 3, 0], [3, 6, 6], (3, 3, 6), (1, 1, 2), True, lambda a: True, None) is None
+    begin, end, halo = (list(map(int, r)) for r in g["wp.args"])
+    inner = tuple(slice(h, h + e - b) for h, b, e in zip(halo, begin, end))
+    mb = g["wp.mask_block"]
+    o = np.full((3, 7, 9, 11), -7.0, dtype="float32")
+    predict_ref.write_prediction(g["wp.pred"].copy(), begin, end, o, 3, None, inner, None)
+    assert np.array_equal(o, g["wp.out_channels"])
+    o = np.full((3, 7, 9, 11), -7.0, dtype="float32")
+    predict_ref.write_prediction(g["wp.pred"].copy(), begin, end, o, 3, mb, inner, None)
+    assert np.array_equal(o, g["wp.out_masked"])
+    oa, ob = np.full((7, 9, 11), -7.0, dtype="float32"), np.full((2, 7, 9, 11), -7.0, dtype="float32")
+    predict_ref.write_prediction(g["wp.pred"].copy(), begin, end, [(oa, 0), (ob, slice(1, 3))], 3, mb, inner, None)
+    assert np.array_equal(oa, g["wp.out_list_a"]) and np.array_equal(ob, g["wp.out_list_b"])
+    o = np.full((7, 9, 11), -7.0, dtype="float32")
+    predict_ref.write_prediction(g["wp.pred"].copy(), begin, end, o, 3, mb, inner, lambda p: p[1] * 2.0)
+    assert np.array_equal(o, g["wp.out_post"])

@@ -533,17 +533,17 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const float* __re
         for (int k0 = 0; k0 < ksplit; k0 += 4) {
             float4 p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u < ksplit ? k0 + u : ksplit - 1;
-                p[u] = *reinterpret_cast<const float4*>(part + ((int64_t)k * NV + v) * Cout + c0);
+            for (int s = 0; s < 4; ++s) {
+                const int k = k0 + s < ksplit ? k0 + s : ksplit - 1;
+                p[s] = *reinterpret_cast<const float4*>(part + ((int64_t)k * NV + v) * Cout + c0);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = k0 + u < ksplit;
-                a.x += in ? p[u].x : 0.f;
-                a.y += in ? p[u].y : 0.f;
-                a.z += in ? p[u].z : 0.f;
-                a.w += in ? p[u].w : 0.f;
+            for (int s = 0; s < 4; ++s) {
+                const bool in = k0 + s < ksplit;
+                a.x += in ? p[s].x : 0.f;
+                a.y += in ? p[s].y : 0.f;
+                a.z += in ? p[s].z : 0.f;
+                a.w += in ? p[s].w : 0.f;
             }
         }
         a.x = act_apply(a.x, act);

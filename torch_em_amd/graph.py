@@ -126,11 +126,16 @@ class GraphedTrainStep:
             engine._repack_stale(prepare_only=True)   # the weight-packing job table: its upload cannot be captured
         self.graph = torch.cuda.CUDAGraph()
         sync = getattr(getattr(model, "module", model), "_tem_grad_sync", None)
+        measure = None
         if sync is not None:
-            sync.measure = False   # its HIP events would become graph nodes: exposed time is an eager-step measurement
+            measure, sync.measure = sync.measure, False   # its HIP events would become graph nodes: exposed time is an eager-step measurement
         optimizer.zero_grad(set_to_none=True)   # autograd must ASSIGN the captured gradients, not add to old ones
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.pred, self.loss = self._forward_backward_step()
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.pred, self.loss = self._forward_backward_step()
+        finally:
+            if sync is not None:
+                sync.measure = measure   # later eager steps (validation, bench) keep their exposed-time measurement
         # Everything the captured launches point to that was allocated OUTSIDE the capture (and is therefore not owned by
         # the graph's memory pool) must outlive the graph even if the engine later replaces its own reference -- a new
         # pack-job table after an eager validation pass, new packed-weight buffers under another precision mode, a

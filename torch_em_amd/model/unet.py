@@ -219,20 +219,16 @@ class UNetBase(nn.Module):
         super().__init__()
         if len(encoder) != len(decoder):
             raise ValueError(f"Incompatible depth of encoder (depth={len(encoder)}) and decoder (depth={len(decoder)})")
-        self.encoder, self.base, self.decoder = encoder, base, decoder
-        if out_conv is None:
-            self.return_decoder_outputs = False
-            self._out_channels = self.decoder.out_channels
-        elif isinstance(out_conv, nn.ModuleList):
-            if len(out_conv) != len(self.decoder):
-                raise ValueError(f"Invalid length of out_conv, expected {len(decoder)}, got {len(out_conv)}")
-            self.return_decoder_outputs = True
-            self._out_channels = [None if conv is None else conv.out_channels for conv in out_conv]
+        # one output conv, one per decoder level (side outputs), or none: `out_channels` reports what forward() returns
+        per_level = isinstance(out_conv, nn.ModuleList)
+        if per_level and len(out_conv) != len(decoder):
+            raise ValueError(f"Invalid length of out_conv, expected {len(decoder)}, got {len(out_conv)}")
+        self.encoder, self.base, self.decoder, self.out_conv = encoder, base, decoder, out_conv
+        self.return_decoder_outputs, self.check_shape = per_level, check_shape
+        if per_level:
+            self._out_channels = [getattr(conv, "out_channels", None) for conv in out_conv]   # a level without a conv: None
         else:
-            self.return_decoder_outputs = False
-            self._out_channels = out_conv.out_channels
-        self.out_conv = out_conv
-        self.check_shape = check_shape
+            self._out_channels = (decoder if out_conv is None else out_conv).out_channels
         self.final_activation = self._get_activation(final_activation)
         self.postprocessing = self._get_postprocessing(postprocessing)
 
@@ -291,6 +287,21 @@ class UNetBase(nn.Module):
         return y
 
 
+def _widths_and_head(conv_cls, in_channels, out_channels, depth, initial_features, gain, return_side_outputs):
+    """Channel widths down / up the U and the output conv(s) of the three U-Net constructors -> (down, up, out_conv,
+    out_channels as stored in init_kwargs).  The output convs are CREATED HERE, i.e. before encoder / decoder / base: the
+    reference draws its random initial weights in that order (tests/golden/g1b_init_unet3d.npz)."""
+    level = [initial_features * gain ** i for i in range(depth + 1)]
+    down, up = [in_channels] + level[:depth], level[::-1]
+    if not return_side_outputs:
+        return down, up, (None if out_channels is None else conv_cls(up[-1], out_channels, 1)), out_channels
+    if out_channels is None or isinstance(out_channels, int):
+        out_channels = [out_channels] * depth
+    if len(out_channels) != depth:
+        raise ValueError()
+    return down, up, nn.ModuleList([conv_cls(f, o, 1) for f, o in zip(up[1:], out_channels)]), out_channels
+
+
 class UNet2d(UNetBase):
     """2-D U-Net (reference model/unet.py:481-563); runs on the 3-D kernels with D == 1."""
 
@@ -299,31 +310,20 @@ class UNet2d(UNetBase):
                  pooler_impl: nn.Module = nn.MaxPool2d, sampler_impl: nn.Module = Upsampler2d,
                  postprocessing: Optional[Union[nn.Module, str]] = None, check_shape: bool = True,
                  **conv_block_kwargs):
-        features_encoder = [in_channels] + [initial_features * gain ** i for i in range(depth)]
-        features_decoder = [initial_features * gain ** i for i in range(depth + 1)][::-1]
-        scale_factors = depth * [2]
-        if return_side_outputs:
-            if isinstance(out_channels, int) or out_channels is None:
-                out_channels = [out_channels] * depth
-            if len(out_channels) != depth:
-                raise ValueError()
-            out_conv = nn.ModuleList([nn.Conv2d(f, o, 1) for f, o in zip(features_decoder[1:], out_channels)])
-        else:
-            out_conv = None if out_channels is None else nn.Conv2d(features_decoder[-1], out_channels, 1)
         if pooler_impl is not nn.MaxPool2d:
             raise NotImplementedError("the MI355X path implements nn.MaxPool2d pooling")
-        super().__init__(
-            encoder=Encoder(features_encoder, scale_factors, conv_block_impl, pooler_impl, **conv_block_kwargs),
-            decoder=Decoder(features_decoder, scale_factors[::-1], conv_block_impl, sampler_impl, **conv_block_kwargs),
-            base=conv_block_impl(features_encoder[-1], features_encoder[-1] * gain, **conv_block_kwargs),
-            out_conv=out_conv, final_activation=final_activation, postprocessing=postprocessing,
-            check_shape=check_shape,
-        )
-        self.init_kwargs = {"in_channels": in_channels, "out_channels": out_channels, "depth": depth,
-                            "initial_features": initial_features, "gain": gain,
-                            "final_activation": final_activation, "return_side_outputs": return_side_outputs,
-                            "conv_block_impl": conv_block_impl, "pooler_impl": pooler_impl,
-                            "sampler_impl": sampler_impl, "postprocessing": postprocessing, **conv_block_kwargs}
+        down, up, out_conv, out_channels = _widths_and_head(nn.Conv2d, in_channels, out_channels, depth, initial_features, gain,
+                                                            return_side_outputs)
+        factors = [2] * depth
+        encoder = Encoder(down, factors, conv_block_impl, pooler_impl, **conv_block_kwargs)
+        decoder = Decoder(up, factors, conv_block_impl, sampler_impl, **conv_block_kwargs)
+        base = conv_block_impl(down[-1], down[-1] * gain, **conv_block_kwargs)
+        super().__init__(encoder, base, decoder, out_conv, final_activation, postprocessing, check_shape)
+        # what `DefaultTrainer.save_checkpoint` / `get_constructor_arguments` read back (reference util/util.py)
+        self.init_kwargs = dict(in_channels=in_channels, out_channels=out_channels, depth=depth, initial_features=initial_features,
+                                gain=gain, final_activation=final_activation, return_side_outputs=return_side_outputs,
+                                conv_block_impl=conv_block_impl, pooler_impl=pooler_impl, sampler_impl=sampler_impl,
+                                postprocessing=postprocessing, **conv_block_kwargs)
 
 
 class AnisotropicUNet(UNetBase):
@@ -334,31 +334,18 @@ class AnisotropicUNet(UNetBase):
                  return_side_outputs: bool = False, conv_block_impl: nn.Module = ConvBlock3d,
                  anisotropic_kernel: bool = False, postprocessing: Optional[Union[str, nn.Module]] = None,
                  check_shape: bool = True, **conv_block_kwargs):
-        depth = len(scale_factors)
-        features_encoder = [in_channels] + [initial_features * gain ** i for i in range(depth)]
-        features_decoder = [initial_features * gain ** i for i in range(depth + 1)][::-1]
-        if return_side_outputs:
-            if isinstance(out_channels, int) or out_channels is None:
-                out_channels = [out_channels] * depth
-            if len(out_channels) != depth:
-                raise ValueError()
-            out_conv = nn.ModuleList([nn.Conv3d(f, o, 1) for f, o in zip(features_decoder[1:], out_channels)])
-        else:
-            out_conv = None if out_channels is None else nn.Conv3d(features_decoder[-1], out_channels, 1)
-        super().__init__(
-            encoder=Encoder(features_encoder, scale_factors, conv_block_impl, nn.MaxPool3d,
-                            anisotropic_kernel=anisotropic_kernel, **conv_block_kwargs),
-            decoder=Decoder(features_decoder, scale_factors[::-1], conv_block_impl, Upsampler3d,
-                            anisotropic_kernel=anisotropic_kernel, **conv_block_kwargs),
-            base=conv_block_impl(features_encoder[-1], features_encoder[-1] * gain, **conv_block_kwargs),
-            out_conv=out_conv, final_activation=final_activation, postprocessing=postprocessing,
-            check_shape=check_shape,
-        )
-        self.init_kwargs = {"in_channels": in_channels, "out_channels": out_channels, "scale_factors": scale_factors,
-                            "initial_features": initial_features, "gain": gain,
-                            "final_activation": final_activation, "return_side_outputs": return_side_outputs,
-                            "conv_block_impl": conv_block_impl, "anisotropic_kernel": anisotropic_kernel,
-                            "postprocessing": postprocessing, **conv_block_kwargs}
+        down, up, out_conv, out_channels = _widths_and_head(nn.Conv3d, in_channels, out_channels, len(scale_factors),
+                                                            initial_features, gain, return_side_outputs)
+        encoder = Encoder(down, scale_factors, conv_block_impl, nn.MaxPool3d, anisotropic_kernel=anisotropic_kernel,
+                          **conv_block_kwargs)
+        decoder = Decoder(up, scale_factors[::-1], conv_block_impl, Upsampler3d, anisotropic_kernel=anisotropic_kernel,
+                          **conv_block_kwargs)
+        base = conv_block_impl(down[-1], down[-1] * gain, **conv_block_kwargs)
+        super().__init__(encoder, base, decoder, out_conv, final_activation, postprocessing, check_shape)
+        self.init_kwargs = dict(in_channels=in_channels, out_channels=out_channels, scale_factors=scale_factors,
+                                initial_features=initial_features, gain=gain, final_activation=final_activation,
+                                return_side_outputs=return_side_outputs, conv_block_impl=conv_block_impl,
+                                anisotropic_kernel=anisotropic_kernel, postprocessing=postprocessing, **conv_block_kwargs)
 
     def _check_shape(self, x):
         spatial_shape = tuple(x.shape)[2:]
@@ -381,7 +368,6 @@ class UNet3d(AnisotropicUNet):
                          final_activation=final_activation, return_side_outputs=return_side_outputs,
                          anisotropic_kernel=False, postprocessing=postprocessing, conv_block_impl=conv_block_impl,
                          check_shape=check_shape, **conv_block_kwargs)
-        self.init_kwargs = {"in_channels": in_channels, "out_channels": out_channels, "depth": depth,
-                            "initial_features": initial_features, "gain": gain,
-                            "final_activation": final_activation, "return_side_outputs": return_side_outputs,
-                            "conv_block_impl": conv_block_impl, "postprocessing": postprocessing, **conv_block_kwargs}
+        self.init_kwargs = dict(in_channels=in_channels, out_channels=out_channels, depth=depth, initial_features=initial_features,
+                                gain=gain, final_activation=final_activation, return_side_outputs=return_side_outputs,
+                                conv_block_impl=conv_block_impl, postprocessing=postprocessing, **conv_block_kwargs)

@@ -227,6 +227,7 @@ class GradScaler:
         """Move the scaler's state to the device, as torch.amp.GradScaler keeps it: scale(), unscale_(), step() and
         update() then run without the host reading the overflow flag, so the whole step can be captured in a HIP graph
         (torch_em_amd/graph.py).  `applied_steps` seeds the optimizer step count that travels with it."""
+        self._from_device()   # a re-capture: the live scale / growth tracker are on the device, not in the host fields
         self._sstate = torch.tensor([self._scale, float(self._growth_tracker), 0.0, float(applied_steps)],
                                     dtype=torch.float32, device=device)
         return self._sstate
@@ -303,6 +304,11 @@ class GradScaler:
         if id(optimizer) not in self._unscaled:
             self.unscale_(optimizer)
         if self._sstate is not None:
+            if getattr(optimizer, "_table", None) is None:
+                # the optimizer left its capture mode (FusedAdamW.load_state_dict drops the step table) while this scaler is
+                # still on the device: its plain step would apply an overflowed gradient -- read the flag here
+                if float(self._sstate[2].item()) != 0.0:
+                    return None
             return optimizer.step(*args, **kwargs)      # tem_adamw_step_tab reads the overflow flag itself
         found = any(float(f.item()) != 0.0 for f in self._found_inf.values())   # host sync, like torch's _maybe_opt_step
         if found:

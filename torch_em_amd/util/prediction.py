@@ -11,8 +11,16 @@ U-Net forward kernels, and scattered into a device output volume by one HIP kern
 comes back over PCIe once.  The reference pads, normalises and crops every block with numpy on the host and copies it
 H2D and D2H.  Callables: `preprocess` may be this package's `standardize` (runs on device), None, or a function of
 a CUDA tensor; `postprocess`, `skip_block` and `prediction_function` receive CUDA tensors.  Several `gpu_ids`: one worker
-thread per entry (as the reference, :188-193, 313), each with its own copy of the model and of the input volume on its
-device and the blocks dealt round-robin; the per-device output volumes are merged box by box on the host.
+thread per DEVICE (as the reference, :188-193, 313; repeated entries of one device share its worker), each with its own copy
+of the model -- made on the calling thread before the workers start -- and of the input volume, its own HIP stream (the
+library's workspaces are per stream) and the blocks dealt round-robin; the per-device output volumes are merged box by box
+on the host.
+
+`predict_with_halo_pipelined` (reference :487-759: producer threads -> GPU consumers -> writer threads over queues) is the
+same three stages as HIP streams of one worker per device: the gather + preprocessing of the NEXT batch of blocks runs on a
+prefetch stream, the forward pass on the worker's compute stream, the masked scatter of the PREVIOUS batch on a write-back
+stream, joined by events -- the role of the reference's queues, without the PCIe copies between the stages; `batch_size`
+blocks are stacked into one forward pass.
 """
 import ctypes
 from typing import Any, Callable, List, Optional, Tuple, Union
@@ -101,6 +109,166 @@ def predict_with_padding(model: torch.nn.Module, input_: np.ndarray, min_divisib
     return output[crop]
 
 
+class _Setup:
+    """argument handling shared by predict_with_halo and predict_with_halo_pipelined (reference :145-260 / :487-560)"""
+
+    def __init__(self, input_, model, gpu_ids, block_shape, halo, output, with_channels, mask, roi, iter_list, grid_shift,
+                 disable_tqdm, tqdm_desc):
+        if len(gpu_ids) < 1:
+            raise ValueError("predict_with_halo: gpu_ids is empty")
+        devices = [torch.device(g if not isinstance(g, int) else f"cuda:{g}") for g in gpu_ids]
+        if any(d.type != "cuda" for d in devices):
+            raise RuntimeError("torch_em_amd.predict_with_halo runs on MI355X only; there is no CPU fallback")
+        # one worker per DEVICE: two workers on one device would share the model object (whose packed weights are built on
+        # first use) and gain nothing -- a device runs one block at a time
+        self.devices = []
+        for d in devices:
+            d = torch.device("cuda", torch.cuda.current_device()) if d.index is None else d
+            if d not in self.devices:
+                self.devices.append(d)
+        self.shape_spatial0 = tuple(input_.shape[1:] if with_channels else input_.shape)
+        self.ndim = ndim = len(self.shape_spatial0)
+        assert len(block_shape) == len(halo) == ndim
+        self.input_eff, self.mask_eff, self.pad_left = input_, mask, (0,) * ndim
+        if grid_shift is not None:
+            assert len(grid_shift) == ndim, "grid_shift must match number of spatial dims"
+            self.pad_left = tuple(int(np.rint(abs(gs) * bs)) for gs, bs in zip(grid_shift, block_shape))
+            if not isinstance(input_, np.ndarray):
+                raise TypeError("grid_shift padding currently requires input_ to be a numpy array")
+            pw = tuple((pl, 0) for pl in self.pad_left)
+            self.input_eff = np.pad(input_, (((0, 0),) + pw) if with_channels else pw, mode="constant", constant_values=0)
+            if mask is not None:
+                if not isinstance(mask, np.ndarray):
+                    raise TypeError("grid_shift padding currently requires mask to be a numpy array")
+                self.mask_eff = np.pad(mask, pw, mode="constant", constant_values=0)
+        self.shape_spatial = tuple(self.input_eff.shape[1:] if with_channels else self.input_eff.shape)
+        if roi is None:
+            self.blocking = _Blocking([0] * ndim, list(self.shape_spatial), block_shape)
+        else:
+            assert len(roi) == ndim
+            self.blocking = _Blocking([0 if ro.start is None else ro.start for ro in roi],
+                                      [sh if ro.stop is None else ro.stop for ro, sh in zip(roi, self.shape_spatial)],
+                                      block_shape)
+        if output is not None and grid_shift:
+            raise ValueError(
+                "grid_shift is not supported together with a user-provided `output`, because "
+                "grid_shift requires internal zero-padding and a final cropping step. "
+                "Pass `output=None` (let this function allocate the output) or disable `grid_shift`. "
+                "Or pad the input manually beforehand."
+            )
+        self.block_ids = list(range(self.blocking.number_of_blocks)) if iter_list is None else [int(b) for b in iter_list]
+        try:
+            from tqdm import tqdm
+        except ImportError:  # pragma: no cover
+            def tqdm(it=None, **kw):
+                return it
+        self.progress = tqdm(total=len(self.block_ids), disable=disable_tqdm, desc=tqdm_desc)
+        # the per-device model copies are made HERE, on the calling thread, before any worker runs a forward pass (which
+        # attaches packed weights to the conv modules of ITS model: a deepcopy racing with that sees half-built entries);
+        # the reference builds its (model, device) pairs up front as well (:188-192)
+        self.models = []
+        for d in self.devices:
+            if next(model.parameters()).device == d:
+                self.models.append(model)
+            else:
+                from copy import deepcopy
+                copy = deepcopy(model)
+                for mod in copy.modules():   # the packed weights are device buffers of the source model: the copy builds its own
+                    mod.__dict__.pop("_tem_pack", None)
+                self.models.append(copy.to(d))
+        self.model, self.with_channels, self.user_output, self.grid_shift = model, with_channels, output, grid_shift
+
+    def upload(self, device):
+        vol = _to_volume(self.input_eff, self.with_channels, self.ndim, device)
+        mask_dev = None
+        if self.mask_eff is not None:
+            mask_dev = torch.as_tensor(np.asarray(self.mask_eff) != 0).to(device=device, dtype=torch.uint8).contiguous()
+        return vol, mask_dev
+
+    def run(self, run_on):
+        """run_on(device, block ids, model) -> (device output volume or None, boxes written), one worker per device"""
+        devs = self.devices
+        if len(devs) == 1:
+            parts = [run_on(devs[0], self.block_ids, self.models[0])]
+        else:
+            # block list dealt round-robin (the reference: one consumer per device pulling blocks, util/prediction.py:188-193,
+            # 313); the inner boxes of the blocks are disjoint, so the per-device output volumes merge by copying boxes
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(len(devs)) as pool:
+                futs = [pool.submit(run_on, d, self.block_ids[i::len(devs)], self.models[i]) for i, d in enumerate(devs)]
+                parts = [f.result() for f in futs]
+        self.progress.close()
+        return self.finish(parts)
+
+    def finish(self, parts):
+        ndim, shape_spatial = self.ndim, self.shape_spatial
+        written = [bb for _, w in parts for bb in w]
+        out_dev, result = None, None
+        for od, w in parts:
+            if od is None:
+                continue
+            host = od.reshape([od.shape[0]] + list(shape_spatial)).cpu().numpy()
+            if result is None:
+                result, out_dev = host, od
+            else:
+                for bb in w:
+                    result[(slice(None),) + bb] = host[(slice(None),) + bb]
+        if out_dev is None:  # nothing was predicted (everything masked / skipped)
+            result = np.zeros((getattr(self.model, "out_channels", 1),) + shape_spatial, dtype="float32")
+        if self.user_output is None:
+            output = result
+        else:  # copy only the boxes that were predicted into the caller's array(s), like the reference's in-place writes
+            output = self.user_output
+            for bb in written:
+                if isinstance(output, list):
+                    for out, channel_slice in output:
+                        this_bb = bb if out.ndim == ndim else (slice(None),) + bb
+                        out[this_bb] = result[(channel_slice,) + bb]
+                elif output.ndim == ndim + 1:
+                    output[(slice(None),) + bb] = result[(slice(None),) + bb]
+                else:
+                    output[bb] = result[(0,) + bb]
+        if self.grid_shift is not None:
+            crop = tuple(slice(pl, pl + sh) for pl, sh in zip(self.pad_left, self.shape_spatial0))
+            output = output[(slice(None),) + crop] if output.ndim == ndim + 1 else output[crop]
+        return output
+
+
+def _store_inner(lib, pred, out_dev, mask_dev, halo, begin, size):
+    _lib.check(lib.tem_block_store_inner(
+        ops._p(pred), _i3(_pad3(pred.shape[1:], 1)), ops._p(out_dev), pred.shape[0], out_dev.shape[1], out_dev.shape[2],
+        out_dev.shape[3], ops._p(mask_dev), _i3(_pad3(halo, 0)), _i3(_pad3(begin, 0)), _i3(_pad3(size, 1)),
+        ops._stream(pred)), "tem_block_store_inner")
+
+
+def _gather_block(su, vol, mask_dev, block_id, block_shape, halo, preprocess, skip_block):
+    """One block up to the network input: None (masked out / skipped) or (input [C, *block + 2 halo] or [*...], begin, size)."""
+    begin, end = su.blocking.get_block(block_id)
+    size = [e - b for b, e in zip(begin, end)]
+    if mask_dev is not None:
+        sl = tuple(slice(b, e) for b, e in zip(begin, end))
+        if not bool(mask_dev[sl].any()):
+            return None
+    inp = _load_block_device(vol, begin, block_shape, halo, su.ndim)
+    if not su.with_channels:
+        inp = inp[0]
+    if skip_block is not None and skip_block(inp):
+        return None
+    if preprocess is standardize:
+        inp = ops.standardize(inp.reshape(1, -1), 1e-7).reshape(inp.shape)  # whole-block statistics
+    elif preprocess is not None:
+        inp = preprocess(inp)
+    return inp, begin, size
+
+
+def _postprocessed(pred, postprocess, ndim):
+    if postprocess is not None:
+        pred = postprocess(pred)
+    if pred.dim() == ndim:
+        pred = pred[None]
+    return pred.float().contiguous()
+
+
 def predict_with_halo(input_, model: torch.nn.Module, gpu_ids: List[Union[str, int]], block_shape: Tuple[int, ...],
                       halo: Tuple[int, ...], output=None, preprocess: Optional[Callable] = standardize,
                       postprocess: Optional[Callable] = None, with_channels: bool = False,
@@ -109,145 +277,122 @@ def predict_with_halo(input_, model: torch.nn.Module, gpu_ids: List[Union[str, i
                       roi: Optional[Tuple[slice]] = None, iter_list: Optional[List[int]] = None,
                       grid_shift: Optional[Tuple[float, ...]] = None):
     """Block-wise network prediction with a halo; see the module docstring (reference :145-330)."""
-    if len(gpu_ids) < 1:
-        raise ValueError("predict_with_halo: gpu_ids is empty")
-    devices = [torch.device(g if not isinstance(g, int) else f"cuda:{g}") for g in gpu_ids]
-    if any(d.type != "cuda" for d in devices):
-        raise RuntimeError("torch_em_amd.predict_with_halo runs on MI355X only; there is no CPU fallback")
-    shape_spatial0 = tuple(input_.shape[1:] if with_channels else input_.shape)
-    ndim = len(shape_spatial0)
-    assert len(block_shape) == len(halo) == ndim
-
-    input_eff, mask_eff = input_, mask
-    pad_left = (0,) * ndim
-    if grid_shift is not None:
-        assert len(grid_shift) == ndim, "grid_shift must match number of spatial dims"
-        pad_left = tuple(int(np.rint(abs(gs) * bs)) for gs, bs in zip(grid_shift, block_shape))
-        if not isinstance(input_eff, np.ndarray):
-            raise TypeError("grid_shift padding currently requires input_ to be a numpy array")
-        pw = tuple((pl, 0) for pl in pad_left)
-        input_eff = np.pad(input_eff, (((0, 0),) + pw) if with_channels else pw, mode="constant", constant_values=0)
-        if mask_eff is not None:
-            if not isinstance(mask_eff, np.ndarray):
-                raise TypeError("grid_shift padding currently requires mask to be a numpy array")
-            mask_eff = np.pad(mask_eff, pw, mode="constant", constant_values=0)
-    shape_spatial = tuple(input_eff.shape[1:] if with_channels else input_eff.shape)
-
-    if roi is None:
-        blocking = _Blocking([0] * ndim, list(shape_spatial), block_shape)
-    else:
-        assert len(roi) == ndim
-        blocking = _Blocking([0 if ro.start is None else ro.start for ro in roi],
-                             [sh if ro.stop is None else ro.stop for ro, sh in zip(roi, shape_spatial)], block_shape)
-
-    user_output = output
-    if output is not None and grid_shift:
-        raise ValueError(
-            "grid_shift is not supported together with a user-provided `output`, because "
-            "grid_shift requires internal zero-padding and a final cropping step. "
-            "Pass `output=None` (let this function allocate the output) or disable `grid_shift`. "
-            "Or pad the input manually beforehand."
-        )
-
-    block_ids = list(range(blocking.number_of_blocks)) if iter_list is None else [int(b) for b in iter_list]
-    try:
-        from tqdm import tqdm
-    except ImportError:  # pragma: no cover
-        def tqdm(it, **kw):
-            return it
-    progress = tqdm(total=len(block_ids), disable=disable_tqdm, desc=tqdm_desc)
+    su = _Setup(input_, model, gpu_ids, block_shape, halo, output, with_channels, mask, roi, iter_list, grid_shift,
+                disable_tqdm, tqdm_desc)
     lib = _lib.load()
+    ndim = su.ndim
 
     def run_on(device, my_blocks, my_model):
         """The blocks `my_blocks` on ONE device: the whole input is uploaded once, every block is a gather kernel, the
         forward pass and a masked scatter into the device's output volume -> (output volume or None, boxes written)."""
-        if next(my_model.parameters()).device != device:
-            from copy import deepcopy
-            my_model = deepcopy(my_model).to(device)
-        vol = _to_volume(input_eff, with_channels, ndim, device)
-        mask_dev = None
-        if mask_eff is not None:
-            mask_dev = torch.as_tensor(np.asarray(mask_eff) != 0).to(device=device, dtype=torch.uint8).contiguous()
         out_dev, written = None, []
-        with torch.no_grad(), torch.cuda.device(device):
+        # the worker's own stream: the library's scratch buffers are keyed by (device, stream), so two workers never share one
+        with torch.no_grad(), torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device)):
+            vol, mask_dev = su.upload(device)
             for block_id in my_blocks:
-                progress.update(1)
-                begin, end = blocking.get_block(block_id)
-                size = [e - b for b, e in zip(begin, end)]
-                if mask_dev is not None:
-                    sl = tuple(slice(b, e) for b, e in zip(begin, end))
-                    if not bool(mask_dev[sl].any()):
-                        continue
-                inp = _load_block_device(vol, begin, block_shape, halo, ndim)
-                if not with_channels:
-                    inp = inp[0]
-                if skip_block is not None and skip_block(inp):
+                su.progress.update(1)
+                got = _gather_block(su, vol, mask_dev, block_id, block_shape, halo, preprocess, skip_block)
+                if got is None:
                     continue
-                if preprocess is standardize:
-                    inp = ops.standardize(inp.reshape(1, -1), 1e-7).reshape(inp.shape)  # whole-block statistics
-                elif preprocess is not None:
-                    inp = preprocess(inp)
+                inp, begin, size = got
                 model_in = inp[None] if with_channels else inp[None, None]
                 pred = my_model(model_in) if prediction_function is None else prediction_function(my_model, model_in)
                 if not torch.is_tensor(pred):
                     pred = pred[0]
-                pred = pred.squeeze(0)
-                if postprocess is not None:
-                    pred = postprocess(pred)
-                if pred.dim() == ndim:
-                    pred = pred[None]
-                pred = pred.float().contiguous()
-                n_out = pred.shape[0]
+                pred = _postprocessed(pred.squeeze(0), postprocess, ndim)
                 if out_dev is None:
-                    out_dev = torch.zeros([n_out] + _pad3(shape_spatial, 1), dtype=torch.float32, device=device)
-                _lib.check(lib.tem_block_store_inner(
-                    ops._p(pred), _i3(_pad3(pred.shape[1:], 1)), ops._p(out_dev), n_out, out_dev.shape[1], out_dev.shape[2],
-                    out_dev.shape[3], ops._p(mask_dev), _i3(_pad3(halo, 0)), _i3(_pad3(begin, 0)), _i3(_pad3(size, 1)),
-                    ops._stream(pred)), "tem_block_store_inner")
-                written.append(tuple(slice(b, e) for b, e in zip(begin, end)))
+                    out_dev = torch.zeros([pred.shape[0]] + _pad3(su.shape_spatial, 1), dtype=torch.float32, device=device)
+                _store_inner(lib, pred, out_dev, mask_dev, halo, begin, size)
+                written.append(tuple(slice(b, b + s) for b, s in zip(begin, size)))
+            torch.cuda.current_stream(device).synchronize()
         return out_dev, written
 
-    if len(devices) == 1:
-        parts = [run_on(devices[0], block_ids, model)]
-    else:
-        # one worker thread per entry of gpu_ids, block list dealt round-robin (the reference: a thread pool with one
-        # worker per device pulling blocks, util/prediction.py:188-193, 313); the inner boxes of the blocks are disjoint,
-        # so the per-device output volumes merge by copying each device's boxes
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(len(devices)) as pool:
-            futs = [pool.submit(run_on, d, block_ids[i::len(devices)], model) for i, d in enumerate(devices)]
-            parts = [f.result() for f in futs]
-    progress.close()
-    written = [bb for _, w in parts for bb in w]
-    out_dev = None
-    result = None
-    for od, w in parts:
-        if od is None:
-            continue
-        host = od.reshape([od.shape[0]] + list(shape_spatial)).cpu().numpy()
-        if result is None:
-            result, out_dev = host, od
-        else:
-            for bb in w:
-                result[(slice(None),) + bb] = host[(slice(None),) + bb]
+    return su.run(run_on)
 
-    if out_dev is None:  # nothing was predicted (everything masked / skipped)
-        n_out = getattr(model, "out_channels", 1)
-        result = np.zeros((n_out,) + shape_spatial, dtype="float32")
-    if user_output is None:
-        output = result
-    else:  # copy only the boxes that were predicted into the caller's array(s), like the reference's in-place writes
-        output = user_output
-        for bb in written:
-            if isinstance(output, list):
-                for out, channel_slice in output:
-                    this_bb = bb if out.ndim == ndim else (slice(None),) + bb
-                    out[this_bb] = result[(channel_slice,) + bb]
-            elif output.ndim == ndim + 1:
-                output[(slice(None),) + bb] = result[(slice(None),) + bb]
-            else:
-                output[bb] = result[(0,) + bb]
+
+def predict_with_halo_pipelined(input_, model: torch.nn.Module, gpu_ids: List[Union[str, int]], block_shape: Tuple[int, ...],
+                                halo: Tuple[int, ...], output=None, preprocess: Optional[Callable] = standardize,
+                                postprocess: Optional[Callable] = None, with_channels: bool = False,
+                                skip_block: Optional[Callable] = None, mask=None, disable_tqdm: bool = False,
+                                tqdm_desc: str = "predict with halo (pipelined)",
+                                prediction_function: Optional[Callable] = None, roi: Optional[Tuple[slice]] = None,
+                                iter_list: Optional[List[int]] = None, batch_size: int = 1, num_prefetch_workers: int = 4,
+                                queue_size: Optional[int] = None, num_write_workers: int = 1,
+                                write_queue_size: Optional[int] = None, grid_shift: Optional[Tuple[float, ...]] = None):
+    """`predict_with_halo` as a three-stage pipeline (reference util/prediction.py:487-759), same arguments and results.
+
+    The reference decouples loading + preprocessing (producer threads), prediction (one consumer per GPU, `batch_size`
+    blocks per forward pass) and postprocessing + writing (writer threads) with queues, because each stage works on host
+    arrays and crosses PCIe.  Here the volume, every block and the output live in HBM, so the stages are HIP STREAMS of the
+    device's worker thread: the gather / reflect padding / `standardize` of batch i + 1 run on a prefetch stream, the forward
+    pass of batch i on the compute stream, the masked scatter of batch i - 1 on a write-back stream; events order them.
+    `num_prefetch_workers`, `queue_size`, `num_write_workers`, `write_queue_size` are accepted for signature compatibility:
+    they size host threads and queues this design does not have (the prefetch depth is one batch).  Blocks of a batch are
+    stacked along the batch axis, so `prediction_function` and `postprocess` see what the reference's see; a batch whose
+    blocks cannot be stacked is never formed (every block has the shape block_shape + 2 halo)."""
     if grid_shift is not None:
-        crop = tuple(slice(pl, pl + sh) for pl, sh in zip(pad_left, shape_spatial0))
-        output = output[(slice(None),) + crop] if output.ndim == ndim + 1 else output[crop]
-    return output
+        raise NotImplementedError(
+            "grid_shift is not supported by predict_with_halo_pipelined. "
+            "Use predict_with_halo for grid_shift, or pre-pad the input and use roi."
+        )
+    batch_size = max(1, int(batch_size))
+    su = _Setup(input_, model, gpu_ids, block_shape, halo, output, with_channels, mask, roi, iter_list, None, disable_tqdm,
+                tqdm_desc)
+    lib = _lib.load()
+    ndim = su.ndim
+
+    def run_on(device, my_blocks, my_model):
+        out_dev, written = None, []
+        with torch.no_grad(), torch.cuda.device(device):
+            s_main, s_pre, s_post = (torch.cuda.Stream(device) for _ in range(3))
+            with torch.cuda.stream(s_main):
+                vol, mask_dev = su.upload(device)
+            s_pre.wait_stream(s_main)
+            pending = list(my_blocks)
+
+            def prefetch():
+                """the next batch, gathered and preprocessed on the prefetch stream -> (stacked input, [(begin, size)], event)"""
+                jobs = []
+                with torch.cuda.stream(s_pre):
+                    while pending and len(jobs) < batch_size:
+                        su.progress.update(1)
+                        got = _gather_block(su, vol, mask_dev, pending.pop(0), block_shape, halo, preprocess, skip_block)
+                        if got is not None:
+                            jobs.append(got)
+                    if not jobs:
+                        return None
+                    batch = torch.stack([j[0] for j in jobs]) if with_channels else torch.stack([j[0] for j in jobs])[:, None]
+                    ev = torch.cuda.Event()
+                    ev.record(s_pre)
+                return batch, [(j[1], j[2]) for j in jobs], ev
+
+            nxt = prefetch()
+            while nxt is None and pending:
+                nxt = prefetch()
+            while nxt is not None:
+                batch, boxes, ev = nxt
+                with torch.cuda.stream(s_main):
+                    s_main.wait_event(ev)
+                    pred = my_model(batch) if prediction_function is None else prediction_function(my_model, batch)
+                    if not torch.is_tensor(pred):
+                        pred = pred[0]
+                    done = torch.cuda.Event()
+                    done.record(s_main)
+                    batch.record_stream(s_main)
+                nxt = None
+                while nxt is None and pending:   # the gather of the next batch is enqueued while this forward pass runs
+                    nxt = prefetch()
+                with torch.cuda.stream(s_post):
+                    s_post.wait_event(done)
+                    for k, (begin, size) in enumerate(boxes):
+                        pk = _postprocessed(pred[k], postprocess, ndim)
+                        if out_dev is None:
+                            out_dev = torch.zeros([pk.shape[0]] + _pad3(su.shape_spatial, 1), dtype=torch.float32, device=device)
+                        _store_inner(lib, pk, out_dev, mask_dev, halo, begin, size)
+                        written.append(tuple(slice(b, b + s) for b, s in zip(begin, size)))
+                    pred.record_stream(s_post)
+            for st in (s_pre, s_main, s_post):
+                st.synchronize()
+        return out_dev, written
+
+    return su.run(run_on)
