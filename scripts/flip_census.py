@@ -64,7 +64,7 @@ def hip_run(model, x, y, mode):
         pred = model(x.cuda())
         loss = DiceLoss()(pred, y.cuda())
         loss.backward()
-    return relus, pools, float(loss), {k: p.grad.double().cpu().numpy() for k, p in model.named_parameters()}
+    return relus, pools, float(loss.detach()), {k: p.grad.double().cpu().numpy() for k, p in model.named_parameters()}
 
 
 def l2(a, b, keys):

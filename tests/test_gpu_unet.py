@@ -228,7 +228,7 @@ def test_depth4_gradient_max_norm_with_the_library_decisions_forced(seed):
     pred = model(x.to(DEV))
     loss = DiceLoss()(pred, y.to(DEV))
     loss.backward()
-    assert rel_err(pred.detach().cpu(), pred64.detach()) < TOL and abs(float(loss) - float(loss64.detach())) < TOL
+    assert rel_err(pred.detach().cpu(), pred64.detach()) < TOL and abs(float(loss.detach()) - float(loss64.detach())) < TOL
     gscale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
     worst = 0.0
     for k, p in model.named_parameters():
@@ -253,8 +253,14 @@ def test_default_arithmetic_is_bit_identical_to_round4():
     import digest_default
     with open(os.path.join(GOLDEN, "default_step_digest.json")) as f:
         want = json.load(f)
-    for name, (kw, shape) in digest_default.CASES.items():
-        assert digest_default.run_case(kw, shape) == want[name], name
+    from torch_em_amd import _lib
+    old = _lib.get_option("wgrad_sums_min_mb")
+    _lib.set_option("wgrad_sums_min_mb", 128)     # the fixture is of the PRODUCT kernel mix (tests/conftest.py lowers this to 0)
+    try:
+        for name, (kw, shape) in digest_default.CASES.items():
+            assert digest_default.run_case(kw, shape) == want[name], name
+    finally:
+        _lib.set_option("wgrad_sums_min_mb", old)
 
 
 def _median_over_seeds(make, seeds):
