@@ -216,7 +216,7 @@ int tem_conv3d_wgrad(const float* x, int64_t x_ld, const float* scale, const flo
  * the wgrad + dgrad halves of its convolution_backward, and the threshold_backward of the ReLU in front of it) in ONE pass over
  * x [NV][Cin] (the ReLU output the projection read): dw [Cout][Cin] (state_dict order), db [Cout] (optional) from
  * g [NV][Cout], and gx[v][ci] = x[v][ci] > 0 ? sum_co g[v][co] w[co][ci] : 0.  w in state_dict layout.  Shapes:
- * tem_conv1x1_out_bwd_ok (Cin 32 or 64, Cout <= 4); workspace tem_conv1x1_out_bwd_ws() bytes.  Honours tem_arm_output_amax. */
+ * tem_conv1x1_out_bwd_ok (Cin 32 or 64, Cout <= 4); workspace tem_conv1x1_out_bwd_ws() bytes.  */
 int tem_conv1x1_out_bwd_ok(int Cin, int Cout);
 int64_t tem_conv1x1_out_bwd_ws(int Cin, int Cout);
 int tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g_ld, const float* w, float* gx, int64_t gx_ld,
@@ -251,32 +251,59 @@ int tem_conv3d_wgrad_gscaled(const float* x, int64_t x_ld, const float* scale, c
                              const float* g, int64_t g_ld, const float* w, const float* gamma, const float* beta,
                              float* dw, float* db, float* norm_sums, const unsigned* g_amax, void* ws, int64_t ws_bytes,
                              int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, tem_stream_t stream);
-/* max |y| of a tensor as a BY-PRODUCT of the launch that writes it (saves tem_absmax's pass over the tensor):
- * tem_arm_output_amax(p) attaches the device word p (cleared by the caller) to the calling thread's NEXT launch.  If that
- * entry point is one of the producers of data gradients that support it -- tem_maxpool3d_bwd / _bwd_norm, tem_conv3d_fwd on
- * the 1x1x1 streaming / expanding kernels and on the z-reuse kernel with a ReLU mask, tem_conv3d_fwd_refnorm -- the
- * launch also leaves the bit pattern of max |y| in *p (integer atomicMax) and consumes the
- * request.  tem_disarm_output_amax() clears it and returns 1 when it was NOT consumed (the caller then runs tem_absmax).
- * Never affects the values written. */
-int tem_arm_output_amax(unsigned* amax);
-int tem_disarm_output_amax(void);
-/* The second stage of the norm backward as a BY-PRODUCT of the weight gradient that delivers its first stage
- * (tem_conv3d_wgrad_sums / _gscaled / _gmax with norm_sums): tem_arm_wgrad_norm_coef attaches the request to the calling
- * thread's NEXT such call; when C / G is a power of two <= 32 that call also writes coef [N][C][4] -- bit for bit what
- * tem_norm_bwd_coef(sums = norm_sums, dgamma = dbeta = NULL) would -- and consumes the request (one launch less per layer).
- * tem_disarm_wgrad_norm_coef() clears it and returns 1 when it was NOT consumed (the caller then runs tem_norm_bwd_coef).
- * The affine gradients (dgamma, dbeta) are not part of it: a norm with affine parameters still needs tem_norm_bwd_coef. */
-int tem_arm_wgrad_norm_coef(int G, const float* mean, const float* rstd, float* coef);
-int tem_disarm_wgrad_norm_coef(void);
-/* The FIRST stage of a norm backward (tem_norm_bwd: per-block rows of (sum gy, sum gy * xn)) as a BY-PRODUCT of the data
- * gradient that writes gy: tem_arm_dgrad_norm_sums attaches the request -- x = the norm's input [N*V][x_ld], its mean / rstd
- * [N][G], part [N][nblk][C][2] with nblk = tem_conv3d_fwd_stat_blocks() of that launch -- to the calling thread's NEXT
- * tem_conv3d_fwd.  Launches on the z-reuse kernel with split input channels (tem_conv3d_fwd_kernel() == 4: the 16^3 / 8^3
- * levels) honour it in their split-K epilogue and consume the request; tem_disarm_dgrad_norm_sums() clears it and returns
- * 1 when it was NOT consumed.  Feed the rows to tem_norm_bwd_from_partials (coef != NULL: coefficients only, as
- * tem_norm_bwd_coef; else the elementwise pass as tem_norm_bwd_from_sums). */
-int tem_arm_dgrad_norm_sums(const float* x, int64_t x_ld, const float* mean, const float* rstd, int G, float* part, int64_t nblk);
-int tem_disarm_dgrad_norm_sums(void);
+/* ---- BY-PRODUCTS of a call, as explicit arguments (round 5; rounds 3-4 attached them to "the calling thread's next
+ * launch" through tem_arm_* / tem_disarm_* -- those entry points are gone) ------------------------------------------------
+ * A caller that wants one fills the matching fields of a TemByproducts (the others zero), passes it to the *_ex entry point
+ * and reads `delivered` afterwards: the call sets the bit of every by-product it wrote and leaves the others untouched (the
+ * caller then runs the separate stage).  Never affects the values of the call's main outputs.
+ *
+ *  TEM_BP_OUT_AMAX   out_amax (device word, cleared by the caller) receives the bit pattern of max |y| of the tensor the call
+ *                    writes (integer atomicMax; saves tem_absmax's pass) -- tem_conv3d_fwd_ex on the 1x1x1 streaming /
+ *                    expanding kernels and on the z-reuse kernel with a ReLU mask or ref_coef.  tem_maxpool3d_bwd_st,
+ *                    tem_norm_bwd_st and tem_conv1x1_out_bwd_st take the word as a plain argument and always deliver.
+ *  TEM_BP_NORM_COEF  tem_conv3d_wgrad_ex with norm_sums: when C / coef_G is a power of two <= 32 the call also writes
+ *                    coef [N][C][4] -- bit for bit what tem_norm_bwd_coef(sums = norm_sums, dgamma = dbeta = NULL) would
+ *                    (one launch less per layer).  dgamma / dbeta are not part of it.
+ *  TEM_BP_NORM_SUMS  tem_conv3d_fwd_ex as a data gradient on the z-reuse kernel with split input channels
+ *                    (tem_conv3d_fwd_kernel() == 4: the 16^3 / 8^3 levels): its split-K epilogue also writes the FIRST stage
+ *                    of the backward of the norm the gradient lands behind -- sums_part [N][sums_nblk][C][2] rows of
+ *                    (sum gy, sum gy * xn), sums_nblk = tem_conv3d_fwd_stat_blocks() of the launch, sums_x = that norm's
+ *                    input [N*V][sums_x_ld] (element type of y), its mean / rstd [N][sums_G].  Feed the rows to
+ *                    tem_norm_bwd_from_partials / tem_norm_bwd_st. */
+#define TEM_BP_OUT_AMAX 1u
+#define TEM_BP_NORM_COEF 2u
+#define TEM_BP_NORM_SUMS 4u
+typedef struct TemByproducts {
+    unsigned* out_amax;
+    int coef_G;
+    const float* coef_mean;
+    const float* coef_rstd;
+    float* coef;
+    const void* sums_x;
+    int64_t sums_x_ld;
+    const float* sums_mean;
+    const float* sums_rstd;
+    int sums_G;
+    float* sums_part;
+    int64_t sums_nblk;
+    unsigned delivered; /* out: TEM_BP_* bits */
+} TemByproducts;
+/* tem_conv3d_fwd / _fwd_gscaled / _fwd_refnorm in one entry point with every variant as an argument:
+ *   in_amax  != NULL: tem_conv3d_fwd_gscaled (use_mfma must be 4; scale / shift / bias NULL, act none);
+ *   ref_coef != NULL: tem_conv3d_fwd_refnorm (ref required; scale / shift / bias NULL, act none);
+ *   bp       != NULL: by-products, see above (NULL: none). */
+int tem_conv3d_fwd_ex(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w_packed,
+                      const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws, int64_t ws_bytes,
+                      int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act, int use_mfma,
+                      const unsigned* in_amax, const float* ref_coef, TemByproducts* bp, tem_stream_t stream);
+/* tem_conv3d_wgrad (sd_layout = 1) / _wgrad_sums / _wgrad_gmax / _wgrad_gscaled in one entry point:
+ *   norm_sums  != NULL: tem_conv3d_wgrad_sums (w and db required; gamma / beta of the norm or NULL);
+ *   g_amax_out != NULL: tem_conv3d_wgrad_gmax;   g_amax_in != NULL: tem_conv3d_wgrad_gscaled (use_mfma must be 8);
+ *   bp         != NULL: TEM_BP_NORM_COEF (needs norm_sums). */
+int tem_conv3d_wgrad_ex(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
+                        const float* w, const float* gamma, const float* beta, float* dw, float* db, float* norm_sums,
+                        const unsigned* g_amax_in, unsigned* g_amax_out, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
+                        int Cin, int Cout, int kd, int kh, int kw, int use_mfma, TemByproducts* bp, tem_stream_t stream);
 int tem_norm_bwd_from_partials(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C, int G,
                                const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx, int64_t gx_ld,
                                float* dgamma, float* dbeta, const float* part, int64_t nblk, float* coef, void* ws,

@@ -652,11 +652,11 @@ def test_wgrad_delivers_norm_backward_sums(case):
     (2, 16, 16, 16, 64, 64, 16),    # GroupNorm without affine, 4 channels per group, two blocks of 32 channels
     (1, 20, 24, 17, 32, 32, 1),     # one group of 32 channels
     (3, 17, 9, 10, 64, 32, 1),      # one group of 64 channels: wider than a block -> the request stays armed
-    (2, 16, 16, 16, 96, 32, 32),    # 3 channels per group: not a power of two -> stays armed
+    (2, 16, 16, 16, 96, 32, 32),    # 3 channels per group: not a power of two -> not delivered
 ])
 def test_wgrad_sums_also_deliver_the_norm_backward_coefficients(case):
-    """tem_arm_wgrad_norm_coef: the kernel that finishes the norm sums also writes coef [N, C, 4] -- bit for bit what
-    tem_norm_bwd_coef(sums=...) derives from them -- and leaves the request armed when the group layout does not fit."""
+    """TEM_BP_NORM_COEF of tem_conv3d_wgrad_ex: the kernel that finishes the norm sums also writes coef [N, C, 4] -- bit for
+    bit what tem_norm_bwd_coef(sums=...) derives from them -- and reports it as not delivered when the group layout does not fit."""
     ops = _ops()
     N, D, H, W, Cin, Cout, G = case
     k = (3, 3, 3)
@@ -669,21 +669,26 @@ def test_wgrad_sums_also_deliver_the_norm_backward_coefficients(case):
     mean, rstd, scale, shift = ops.norm_stats(x5, G, None, None, 1e-5)[:4]
     dw, db = torch.empty(w.numel(), device=DEV), torch.empty(Cout, device=DEV)
     coef = torch.full((N, Cin, 4), float("nan"), device=DEV)
-    ops.arm_wgrad_norm_coef(G, mean, rstd, coef)
-    sums = ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=2, sums_from=(w, None, None))
-    left = ops.disarm_wgrad_norm_coef()
+    bp = ops.Byproducts(norm_coef=(G, mean, rstd, coef))
+    sums = ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=2, sums_from=(w, None, None), bp=bp)
+    left = not bp.coef
     cg = Cin // G
     assert left == (not (cg <= 32 and cg & (cg - 1) == 0))
-    assert not ops.disarm_wgrad_norm_coef()          # one-shot: nothing stays behind
+    assert not (bp.amax or bp.sums)
     want = ops.norm_bwd_coef(x5, x5, G, None, mean, rstd, sums=sums)   # with sums the tensors are not read
     if left:
         assert bool(torch.isnan(coef).all())          # untouched
     else:
         assert torch.equal(coef, want)
-    # a plain weight gradient in between does not consume the request; the next sums launch does
-    ops.arm_wgrad_norm_coef(G, mean, rstd, coef)
-    ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=2)
-    assert ops.disarm_wgrad_norm_coef()
+    # nothing survives the call: the same launch without the argument leaves coef alone
+    coef2 = coef.clone()
+    sums2 = ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=2, sums_from=(w, None, None))
+    assert torch.equal(sums2, sums)
+    assert bool(torch.isnan(coef).all()) if left else torch.equal(coef2, coef)
+    # a request that makes no sense for the entry point is an error, not a silent no-op
+    with pytest.raises(Exception, match="by-product"):
+        ops.conv_wgrad(x5, g5, k, Cin, Cout, dw, db, scale=scale, shift=shift, mfma=2, sums_from=(w, None, None),
+                       bp=ops.Byproducts(out_amax=torch.zeros(1, dtype=torch.int32, device=DEV)))
 
 
 @pytest.mark.parametrize("case", [
@@ -692,7 +697,7 @@ def test_wgrad_sums_also_deliver_the_norm_backward_coefficients(case):
     (4, 6, 12, 12, 128, 128, 128, True),    # ragged split-K tiles
 ])
 def test_split_k_data_gradient_delivers_the_norm_backward_rows(case):
-    """tem_arm_dgrad_norm_sums: the split-K epilogue of a data gradient writes per-block (sum g, sum g * xn) of the norm in
+    """TEM_BP_NORM_SUMS of tem_conv3d_fwd_ex: the split-K epilogue of a data gradient writes per-block (sum g, sum g * xn) of the norm in
     front of the conv; tem_norm_bwd_from_partials on those rows == tem_norm_bwd on the tensors (its own reduction pass)."""
     ops = _ops()
     N, D, H, W, Cout, Cin, G, apply = case          # the conv is Cin -> Cout; its data gradient Cout -> Cin
@@ -710,9 +715,9 @@ def test_split_k_data_gradient_delivers_the_norm_backward_rows(case):
     assert nblk > 0
     part = torch.full((N, nblk, Cin, 2), float("nan"), device=DEV)
     gx, gx_ref = ops.new_act(N, D, H, W, Cin, DEV), ops.new_act(N, D, H, W, Cin, DEV)
-    ops.arm_dgrad_norm_sums(x5, G, mean, rstd, part)
-    ops.conv_fwd(g5, wp, None, gx, k, Cout, Cin, mfma=mode)
-    assert not ops.disarm_dgrad_norm_sums()                       # consumed
+    bp = ops.Byproducts(norm_sums=(x5, G, mean, rstd, part))
+    ops.conv_fwd(g5, wp, None, gx, k, Cout, Cin, mfma=mode, bp=bp)
+    assert bp.sums and not bp.amax                                # delivered
     ops.conv_fwd(g5, wp, None, gx_ref, k, Cout, Cin, mfma=mode)
     assert torch.equal(gx, gx_ref)                                # the gradient itself is unchanged
     sums = part.sum(1).cpu().double()
@@ -730,10 +735,11 @@ def test_split_k_data_gradient_delivers_the_norm_backward_rows(case):
     else:
         assert rel_err(ops.norm_bwd_coef(gx, x5, G, None, mean, rstd, sums=part).cpu(),
                        ops.norm_bwd_coef(gx, x5, G, None, mean, rstd).cpu()) < 2e-5
-    # a launch that cannot deliver the rows leaves the request armed
-    ops.arm_dgrad_norm_sums(x5, G, mean, rstd, part)
-    ops.conv_fwd(g5, ops.pack_weights(w, transpose=True, mfma=0), None, gx_ref, k, Cout, Cin, mfma=0)
-    assert ops.disarm_dgrad_norm_sums()
+    # a launch that cannot deliver the rows says so and leaves them alone
+    part2 = torch.full_like(part, float("nan"))
+    bp = ops.Byproducts(norm_sums=(x5, G, mean, rstd, part2))
+    ops.conv_fwd(g5, ops.pack_weights(w, transpose=True, mfma=0), None, gx_ref, k, Cout, Cin, mfma=0, bp=bp)
+    assert not bp.sums and bool(torch.isnan(part2).all())
 
 
 @pytest.fixture
@@ -852,9 +858,11 @@ def test_out_conv_backward_in_one_pass(case):
     dw = torch.empty(w.numel(), device=DEV)
     db = torch.empty(Cout, device=DEV)
     am = torch.zeros(1, dtype=torch.int32, device=DEV)
-    ops.arm_output_amax(am)
-    ops.conv1x1_out_bwd(x5, g5, wd, gx, dw, db)
-    assert not ops.disarm_output_amax() and int(am.item()) == int(gx.abs().max().view(torch.int32).item())
+    ops.conv1x1_out_bwd(x5, g5, wd, gx, dw, db, out_amax=am)
+    assert int(am.item()) == int(gx.abs().max().view(torch.int32).item())
+    gx_plain, dw_plain = torch.empty_like(x5), torch.empty_like(dw)
+    ops.conv1x1_out_bwd(x5, g5, wd, gx_plain, dw_plain, torch.empty_like(db))       # without the by-product: same values
+    assert torch.equal(gx_plain, gx) and torch.equal(dw_plain, dw)
     # the two separate kernels
     gx2 = torch.empty_like(x5)
     ops.conv_fwd(g5, ops.pack_weights(wd, transpose=True, mfma=0), None, gx2, (1, 1, 1), Cout, Cin, ref=x5, mfma=0)
@@ -871,18 +879,17 @@ def test_out_conv_backward_in_one_pass(case):
 
 
 def test_output_amax_is_a_by_product_of_the_gradient_producers():
-    """tem_arm_output_amax: the kernels that write the data gradients of the big levels (max-pool backward, the 1x1x1
+    """TEM_BP_OUT_AMAX (tem_conv3d_fwd_ex) / out_amax (tem_maxpool3d_bwd_st): the kernels that write the data gradients of the big levels (max-pool backward, the 1x1x1
     expanding / streaming data gradients, the z-reuse data gradient with a ReLU mask or a fused norm backward) deliver the
-    exact bit pattern of max |output|; a launch that does not support it leaves the request armed."""
+    exact bit pattern of max |output|; a launch that does not support it reports it as not delivered."""
     ops = _ops()
     gen = torch.Generator().manual_seed(21)
 
     def armed(fn):
         am = torch.zeros(1, dtype=torch.int32, device=DEV)
-        ops.arm_output_amax(am)
-        out = fn()
-        left = ops.disarm_output_amax()
-        return out, am, left
+        bp = ops.Byproducts(out_amax=am)
+        out = fn(bp)
+        return out, am, not bp.amax
 
     def bits(t):
         return int(t.abs().max().view(torch.int32).item())
@@ -893,14 +900,15 @@ def test_output_amax_is_a_by_product_of_the_gradient_producers():
     gy = to5(torch.randn(N, C, D // 2, H // 2, W // 2, generator=gen) * 3e-6)
     gs = to5(torch.randn(N, C, D, H, W, generator=gen) * 1e-6)
     gx = torch.empty_like(x)
-    out, am, left = armed(lambda: ops.maxpool_bwd(gy, x, gx, (2, 2, 2), gskip=gs, relu_mask=True))
-    assert not left and int(am.item()) == bits(out)
+    am = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = ops.maxpool_bwd(gy, x, gx, (2, 2, 2), gskip=gs, relu_mask=True, out_amax=am)
+    assert int(am.item()) == bits(out)
     # out_conv data gradient (2 -> 32 channels, masked): expanding kernel
     ref = to5(torch.randn(N, 32, D, H, W, generator=gen))
     w = torch.randn(2, 32, 1, 1, 1, generator=gen).to(DEV)
     g2 = to5(torch.randn(N, 2, D, H, W, generator=gen) * 1e-5)
     y = torch.empty_like(ref)
-    out, am, left = armed(lambda: ops.conv_fwd(g2, ops.pack_weights(w, transpose=True, mfma=0), None, y, (1, 1, 1), 2, 32, ref=ref, mfma=0))
+    out, am, left = armed(lambda bp: ops.conv_fwd(g2, ops.pack_weights(w, transpose=True, mfma=0), None, y, (1, 1, 1), 2, 32, ref=ref, mfma=0, bp=bp))
     assert not left and int(am.item()) == bits(out)
     # sampler data gradient (1x1x1, >= 16384 voxels): streaming kernel
     N, D, H, W = 1, 16, 32, 32
@@ -908,9 +916,9 @@ def test_output_amax_is_a_by_product_of_the_gradient_producers():
     g3 = to5(torch.randn(N, 32, D, H, W, generator=gen) * 1e-4)
     ref = to5(torch.randn(N, 64, D, H, W, generator=gen))
     y = torch.empty_like(ref)
-    out, am, left = armed(lambda: ops.conv_fwd(g3, ops.pack_weights(w, transpose=True, mfma=2), None, y, (1, 1, 1), 32, 64, ref=ref, mfma=2))
+    out, am, left = armed(lambda bp: ops.conv_fwd(g3, ops.pack_weights(w, transpose=True, mfma=2), None, y, (1, 1, 1), 32, 64, ref=ref, mfma=2, bp=bp))
     assert not left and int(am.item()) == bits(out)
-    # 3x3x3 data gradient on the z-reuse kernel: with a ReLU mask it delivers, without one it leaves the request armed
+    # 3x3x3 data gradient on the z-reuse kernel: with a ReLU mask it delivers, without one it does not
     N, D, H, W = 2, 32, 64, 64
     w = (torch.randn(32, 32, 3, 3, 3, generator=gen) * 0.1).to(DEV)
     g4 = to5(torch.randn(N, 32, D, H, W, generator=gen) * 1e-3)
@@ -918,12 +926,12 @@ def test_output_amax_is_a_by_product_of_the_gradient_producers():
     y = torch.empty_like(ref)
     wp = ops.pack_weights(w, transpose=True, mfma=2)
     assert ops.conv_fwd_family(g4, (3, 3, 3), 32, 32, 2) == 3
-    out, am, left = armed(lambda: ops.conv_fwd(g4, wp, None, y, (3, 3, 3), 32, 32, ref=ref, mfma=2))
+    out, am, left = armed(lambda bp: ops.conv_fwd(g4, wp, None, y, (3, 3, 3), 32, 32, ref=ref, mfma=2, bp=bp))
     assert not left and int(am.item()) == bits(out)
     coef = torch.rand(N, 32, 4, generator=gen).to(DEV)
-    out, am, left = armed(lambda: ops.conv_fwd_refnorm(g4, wp, y, (3, 3, 3), 32, 32, ref, coef, 2))
+    out, am, left = armed(lambda bp: ops.conv_fwd_refnorm(g4, wp, y, (3, 3, 3), 32, 32, ref, coef, 2, bp=bp))
     assert not left and int(am.item()) == bits(out)
-    out, am, left = armed(lambda: ops.conv_fwd(g4, wp, None, y, (3, 3, 3), 32, 32, mfma=2))
+    out, am, left = armed(lambda bp: ops.conv_fwd(g4, wp, None, y, (3, 3, 3), 32, 32, mfma=2, bp=bp))
     assert left and int(am.item()) == 0
 
 

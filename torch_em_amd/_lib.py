@@ -52,14 +52,13 @@ SIGNATURES = {
     "tem_conv3d_wgrad_gscaled": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]
                                  + [c_int] * 9 + [c_vp]),
     "tem_absmax": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_vp]),
-    "tem_arm_output_amax": (c_int, [c_vp]),
-    "tem_disarm_output_amax": (c_int, []),
-    "tem_arm_dgrad_norm_sums": (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_i64]),
-    "tem_disarm_dgrad_norm_sums": (c_int, []),
     "tem_norm_bwd_from_partials": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64,
                                            c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
-    "tem_arm_wgrad_norm_coef": (c_int, [c_int, c_vp, c_vp, c_vp]),
-    "tem_disarm_wgrad_norm_coef": (c_int, []),
+    # (..., in_amax, ref_coef, TemByproducts*, stream) / (..., g_amax_in, g_amax_out, ws, ws_bytes, dims, use_mfma, TemByproducts*, stream)
+    "tem_conv3d_fwd_ex": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64] + [c_int] * 11
+                          + [c_vp, c_vp, c_vp, c_vp]),
+    "tem_conv3d_wgrad_ex": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]
+                            + [c_int] * 10 + [c_vp, c_vp]),
     "tem_conv3d_fwd_gscaled": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp]),
     "tem_conv3d_fwd_refnorm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp]),
     "tem_norm_ws": (c_i64, [c_int, c_i64, c_int]),
@@ -164,6 +163,16 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+BP_OUT_AMAX, BP_NORM_COEF, BP_NORM_SUMS = 1, 2, 4
+
+
+class Byproducts(ctypes.Structure):
+    """include/tem_hip.h: TemByproducts -- the optional by-products of ONE call, passed to a *_ex entry point"""
+    _fields_ = [("out_amax", c_vp), ("coef_G", c_int), ("coef_mean", c_vp), ("coef_rstd", c_vp), ("coef", c_vp),
+                ("sums_x", c_vp), ("sums_x_ld", c_i64), ("sums_mean", c_vp), ("sums_rstd", c_vp), ("sums_G", c_int),
+                ("sums_part", c_vp), ("sums_nblk", c_i64), ("delivered", ctypes.c_uint)]
 
 
 class TemError(RuntimeError):

@@ -75,48 +75,25 @@ extern "C" int tem_get_option(const char* name, int64_t* value) {
 }
 extern "C" int tem_version(void) { return 100; }
 
-// ---- output amax: one-shot request attached to the calling thread's NEXT launch -------------------------------------
-static thread_local unsigned* g_output_amax = nullptr;
+// ---- by-products of the call in flight (include/tem_hip.h: TemByproducts) ----------------------------------------------------
+// The *_ex entry points install the struct their caller passed for the duration of the call (TemBpScope restores the previous
+// pointer on exit: nothing survives a call, and a call without by-products sees NULL); a launch site that can deliver one
+// takes it here, which records it in `delivered`.  Same standing as tem_call_st: plumbing between an entry point and the
+// launchers it reaches, not state of the C-ABI.
+thread_local TemByproducts* tem_call_bp = nullptr;
 unsigned* tem_take_output_amax() {
-    unsigned* p = g_output_amax;
-    g_output_amax = nullptr;
-    return p;
+    TemByproducts* bp = tem_call_bp;
+    if (!bp || !bp->out_amax || (bp->delivered & TEM_BP_OUT_AMAX)) return nullptr;
+    bp->delivered |= TEM_BP_OUT_AMAX;
+    return bp->out_amax;
 }
-extern "C" int tem_arm_output_amax(unsigned* amax) {
-    g_output_amax = amax;
-    return TEM_OK;
+bool tem_bp_wants(unsigned bit) {
+    const TemByproducts* bp = tem_call_bp;
+    if (!bp || (bp->delivered & bit)) return false;
+    return bit == TEM_BP_NORM_COEF ? bp->coef != nullptr : bit == TEM_BP_NORM_SUMS ? bp->sums_part != nullptr : bp->out_amax != nullptr;
 }
-extern "C" int tem_disarm_output_amax(void) {
-    const int pending = g_output_amax != nullptr;
-    g_output_amax = nullptr;
-    return pending;
-}
-
-// ---- norm-backward coefficients as a by-product of the weight gradient that delivers the norm sums (same one-shot shape) --
-thread_local TemWgradCoefReq tem_wgrad_coef_req = {0, nullptr, nullptr, nullptr};
-extern "C" int tem_arm_wgrad_norm_coef(int G, const float* mean, const float* rstd, float* coef) {
-    TEM_REQUIRE(G > 0 && mean && rstd && coef, "tem_arm_wgrad_norm_coef: bad arguments");
-    tem_wgrad_coef_req = {G, mean, rstd, coef};
-    return TEM_OK;
-}
-extern "C" int tem_disarm_wgrad_norm_coef(void) {
-    const int pending = tem_wgrad_coef_req.coef != nullptr;
-    tem_wgrad_coef_req = {0, nullptr, nullptr, nullptr};
-    return pending;
-}
-
-// ---- first stage of a norm backward as a by-product of the data gradient that produces its input gradient -------------
-thread_local TemDgradSumsReq tem_dgrad_sums_req = {nullptr, 0, nullptr, nullptr, 0, nullptr, 0};
-extern "C" int tem_arm_dgrad_norm_sums(const float* x, int64_t x_ld, const float* mean, const float* rstd, int G, float* part,
-                                       int64_t nblk) {
-    TEM_REQUIRE(x && mean && rstd && part && G > 0 && nblk > 0, "tem_arm_dgrad_norm_sums: bad arguments");
-    tem_dgrad_sums_req = {x, x_ld, mean, rstd, G, part, nblk};
-    return TEM_OK;
-}
-extern "C" int tem_disarm_dgrad_norm_sums(void) {
-    const int pending = tem_dgrad_sums_req.part != nullptr;
-    tem_dgrad_sums_req = {nullptr, 0, nullptr, nullptr, 0, nullptr, 0};
-    return pending;
+void tem_bp_delivered(unsigned bit) {
+    if (tem_call_bp) tem_call_bp->delivered |= bit;
 }
 
 extern "C" int tem_device_cus(void) {

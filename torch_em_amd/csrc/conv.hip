@@ -671,11 +671,11 @@ extern "C" int tem_conv1x1_out_bwd_st(const void* x, int64_t x_ld, const void* g
                                       int Cout, unsigned* out_amax, int st_x, int st_g, tem_stream_t stream) {
     TEM_REQUIRE(st_x >= 0 && st_x <= 2 && st_g >= 0 && st_g <= 2, "tem_conv1x1_out_bwd_st: unknown storage type");
     TemStScope sc(st_x, st_g);
-    if (out_amax) tem_arm_output_amax(out_amax);
-    const int rc = tem_conv1x1_out_bwd((const float*)x, x_ld, (const float*)g, g_ld, w, (float*)gx, gx_ld, dw, db, ws, ws_bytes, NV,
-                                       Cin, Cout, stream);
-    if (out_amax) tem_disarm_output_amax();
-    return rc;
+    TemByproducts bp = {};
+    bp.out_amax = out_amax;
+    TemBpScope bsc(&bp);
+    return tem_conv1x1_out_bwd((const float*)x, x_ld, (const float*)g, g_ld, w, (float*)gx, gx_ld, dw, db, ws, ws_bytes, NV, Cin,
+                               Cout, stream);
 }
 
 extern "C" int tem_conv3d_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
@@ -821,6 +821,56 @@ extern "C" int tem_conv3d_wgrad_sums(const float* x, int64_t x_ld, const float* 
                 "tem_conv3d_wgrad_sums: tem_conv3d_wgrad_sums_ok() == 0 for this layer");
     return conv3d_wgrad_impl(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw,
                              use_mfma, 1, w, gamma, beta, norm_sums, nullptr, 0, nullptr, stream);
+}
+
+// ---- every variant and by-product of the forward / data-gradient convolution as explicit arguments (tem_hip.h) -----------------
+extern "C" int tem_conv3d_fwd_ex(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w_packed,
+                                 const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
+                                 int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
+                                 int use_mfma, const unsigned* in_amax, const float* ref_coef, TemByproducts* bp,
+                                 tem_stream_t stream) {
+    TEM_REQUIRE(!(in_amax && ref_coef), "tem_conv3d_fwd_ex: in_amax and ref_coef exclude each other");
+    TEM_REQUIRE(!bp || (!bp->coef && (!bp->sums_part || (bp->sums_x && bp->sums_mean && bp->sums_rstd && bp->sums_G > 0 && bp->sums_nblk > 0))),
+                "tem_conv3d_fwd_ex: bad by-product request (TEM_BP_NORM_COEF belongs to tem_conv3d_wgrad_ex; TEM_BP_NORM_SUMS needs "
+                "sums_x / sums_mean / sums_rstd / sums_G / sums_nblk)");
+    TemBpScope bsc(bp);
+    if (in_amax) {
+        TEM_REQUIRE(!scale && !shift && !bias && act == TEM_ACT_NONE && (use_mfma & 0xff) == 4,
+                    "tem_conv3d_fwd_ex: in_amax (the fp16 two-term data gradient) takes use_mfma 4 and no scale / shift / bias / act");
+        return tem_conv3d_fwd_gscaled(x, x_ld, w_packed, y, y_ld, ref, ref_ld, in_amax, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh,
+                                      kw, stream);
+    }
+    if (ref_coef) {
+        TEM_REQUIRE(!scale && !shift && !bias && act == TEM_ACT_NONE, "tem_conv3d_fwd_ex: ref_coef takes no scale / shift / bias / act");
+        return tem_conv3d_fwd_refnorm(x, x_ld, w_packed, y, y_ld, ref, ref_ld, ref_coef, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh,
+                                      kw, use_mfma, stream);
+    }
+    return tem_conv3d_fwd(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh,
+                          kw, act, use_mfma, stream);
+}
+
+extern "C" int tem_conv3d_wgrad_ex(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g,
+                                   int64_t g_ld, const float* w, const float* gamma, const float* beta, float* dw, float* db,
+                                   float* norm_sums, const unsigned* g_amax_in, unsigned* g_amax_out, void* ws, int64_t ws_bytes,
+                                   int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma,
+                                   TemByproducts* bp, tem_stream_t stream) {
+    TEM_REQUIRE(!(g_amax_in && g_amax_out), "tem_conv3d_wgrad_ex: g_amax_in and g_amax_out exclude each other");
+    TEM_REQUIRE(!bp || (!bp->out_amax && !bp->sums_part && (!bp->coef || (norm_sums && bp->coef_mean && bp->coef_rstd && bp->coef_G > 0))),
+                "tem_conv3d_wgrad_ex: bad by-product request (only TEM_BP_NORM_COEF, which needs norm_sums, coef_mean, coef_rstd, coef_G)");
+    TemBpScope bsc(bp);
+    if (g_amax_in) {
+        TEM_REQUIRE((use_mfma & 0xff) == 8, "tem_conv3d_wgrad_ex: g_amax_in (the fp16 2x1 arithmetic) takes use_mfma 8");
+        return tem_conv3d_wgrad_gscaled(x, x_ld, scale, shift, g, g_ld, w, gamma, beta, dw, db, norm_sums, g_amax_in, ws, ws_bytes, N, D,
+                                        H, W, Cin, Cout, kd, kh, kw, stream);
+    }
+    if (g_amax_out)
+        return tem_conv3d_wgrad_gmax(x, x_ld, scale, shift, g, g_ld, w, gamma, beta, dw, db, norm_sums, g_amax_out, ws, ws_bytes, N, D,
+                                     H, W, Cin, Cout, kd, kh, kw, use_mfma, stream);
+    if (norm_sums)
+        return tem_conv3d_wgrad_sums(x, x_ld, scale, shift, g, g_ld, w, gamma, beta, dw, db, norm_sums, ws, ws_bytes, N, D, H, W, Cin,
+                                     Cout, kd, kh, kw, use_mfma, stream);
+    return tem_conv3d_wgrad(x, x_ld, scale, shift, g, g_ld, dw, db, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma, 1,
+                            stream);
 }
 
 // tem_conv3d_wgrad of a FIRST layer (small Cin, VALU kernel) whose output gradient g is still the raw data gradient

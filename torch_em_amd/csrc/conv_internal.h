@@ -76,9 +76,9 @@ bool tem_conv1x1_stream(const float* x, int64_t x_ld, const float* scale, const 
 int tem_fwd_ksplit(int64_t nblk, int nchunks);
 void tem_splitk_epilogue(const float* part, int ksplit, int64_t NV, int Cout, const float* bias, int act,
                          const float* ref, int64_t ref_ld, float* y, int64_t y_ld, hipStream_t s);
-// capi.hip: tem_arm_dgrad_norm_sums -- taken (cleared) by the split-K data gradient whose epilogue can deliver the rows
+// TEM_BP_NORM_SUMS of the call in flight, as the split-K data gradient whose epilogue can deliver the rows reads it
 struct TemDgradSumsReq {
-    const float* x;      // input of the norm the gradient lands behind: [N*V][x_ld]
+    const void* x;       // input of the norm the gradient lands behind: [N*V][x_ld], element type of the gradient
     int64_t x_ld;
     const float* mean;
     const float* rstd;
@@ -86,7 +86,6 @@ struct TemDgradSumsReq {
     float* part;         // [N][nblk][C][2]
     int64_t nblk;
 };
-extern thread_local TemDgradSumsReq tem_dgrad_sums_req;
 void tem_splitk_epilogue_bwd_sums(const float* part, int ksplit, int N, int64_t V, int Cout, const float* bias, int act,
                                   const float* ref, int64_t ref_ld, float* y, int64_t y_ld, const TemDgradSumsReq& rq,
                                   hipStream_t s);
@@ -114,14 +113,13 @@ void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_
                               const float* g, int64_t g_ld, float* zpart, float* zdb, int N, int D, int H, int W, int Cin,
                               int Cout, int T, int nY, int nX, int zsegs, int Ss, int ncz, unsigned* gmax,
                               const unsigned* g_amax, hipStream_t s);
-// capi.hip: tem_arm_wgrad_norm_coef -- taken (cleared) by tem_wgrad_sums_launch when the layer's group layout allows it
+// TEM_BP_NORM_COEF of the call in flight, as tem_wgrad_sums_launch reads it (delivered when the layer's group layout allows it)
 struct TemWgradCoefReq {
     int G;
     const float* mean;
     const float* rstd;
     float* coef;
 };
-extern thread_local TemWgradCoefReq tem_wgrad_coef_req;
 // wgrad_sums.hip: norm-backward sums from the weight gradient
 int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
 int64_t tem_wgrad_sums_ws_floats(int N, int D, int H, int Cin, int Cout);

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
 // quad q, row r of 256 / cq rows); stat: [N][gridDim.x][Cout][2].
 // BWD: the launch is a data gradient whose output lands behind a norm (the one in front of the conv): the rows are
 // (sum g, sum g * xn) with xn = (xin - mean) * rstd of that norm's input xin -- the first stage of its backward
-// (k_norm_partial<.,1>), tem_arm_dgrad_norm_sums.
+// (k_norm_partial<.,1>), TEM_BP_NORM_SUMS of tem_conv3d_fwd_ex.
 struct SplitkNormIn {
     const void* xin;   // element type of the launch (T)
     int64_t xin_ld;

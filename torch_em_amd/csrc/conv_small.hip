@@ -1177,6 +1177,7 @@ bool tem_conv1x1_out_bwd(const float* x, int64_t x_ld, const float* g, int64_t g
     const int grid = (int)(nb < PROJ_GRID ? nb : PROJ_GRID);
     float* part = (float*)ws;
     size_t ldsb = (size_t)4 * (Cin + 1) * Cout * sizeof(float);
+    if (!tem_st2_ok(tem_call_st.x, tem_call_st.y)) return false;
     unsigned* const amax = tem_take_output_amax();
 #define OBJ(CO, J)                                                                                                     \
     TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TG, return false,                                                 \
@@ -1253,7 +1254,7 @@ bool tem_conv1x1_expand(const float* x, int64_t x_ld, const float* scale, const 
                         int64_t y_ld, const float* ref, int64_t ref_ld, int64_t NV, int Cin, int Cout, int act,
                         hipStream_t s) {
     if (scale || Cin > 16 || Cout % 4 || y_ld % 4 || ((uintptr_t)y % 16) || ((uintptr_t)w % 16) ||
-        (bias && (uintptr_t)bias % 16) || (ref && (ref_ld % 4 || (uintptr_t)ref % 16)))
+        (bias && (uintptr_t)bias % 16) || (ref && (ref_ld % 4 || (uintptr_t)ref % 16)) || !tem_st2_ok(tem_call_st.x, tem_call_st.y))
         return false;
     unsigned* const amax = tem_take_output_amax();
     TEM_ST2_SWITCH(tem_call_st.x, tem_call_st.y, TX, TY, return false,

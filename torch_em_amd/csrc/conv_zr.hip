@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax, int ks, int blk,
     unsigned* __restrict__ out_amax) {
     static_assert(!KSPLIT || MODE == 0, "split-K units write raw partial sums");
-    constexpr bool AMAX = MODE == 2 || MODE == 3;   // data gradients: max |y| as a by-product (tem_arm_output_amax)
+    constexpr bool AMAX = MODE == 2 || MODE == 3;   // data gradients: max |y| as a by-product (TEM_BP_OUT_AMAX)
     float amx = 0.f;
     static_assert(!WIDE || NS == 2, "the wide one-term kernel uses the two LDS planes of the two-term layout");
     constexpr bool T16 = sizeof(T) == 2;         // 16-bit activations in HBM
@@ -1114,12 +1114,16 @@ int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, con
     else if (nsplit == 4) ZRKS(2, true, false);
     else ZRKS(2, false, false);
 #undef ZRKS
-    const TemDgradSumsReq rq = tem_dgrad_sums_req;
+    TemDgradSumsReq rq = {nullptr, 0, nullptr, nullptr, 0, nullptr, 0};
+    if (!stat && tem_bp_wants(TEM_BP_NORM_SUMS)) {
+        const TemByproducts* bp = tem_call_bp;
+        rq = TemDgradSumsReq{bp->sums_x, bp->sums_x_ld, bp->sums_mean, bp->sums_rstd, bp->sums_G, bp->sums_part, bp->sums_nblk};
+    }
     if (stat)
         tem_splitk_epilogue_stats(part, ks, N, (int64_t)D * H * W, Cout, bias, act, ref, ref_ld, y, y_ld, stat, s);
-    else if (rq.part && rq.nblk == tem_splitk_stat_blocks((int64_t)D * H * W, Cout) && rq.G > 0 && Cout % rq.G == 0 &&
-             rq.x_ld % 4 == 0 && ((uintptr_t)rq.x % 16 == 0)) {
-        tem_dgrad_sums_req = TemDgradSumsReq{nullptr, 0, nullptr, nullptr, 0, nullptr, 0};   // consumed
+    else if (rq.part && rq.x && rq.mean && rq.rstd && rq.nblk == tem_splitk_stat_blocks((int64_t)D * H * W, Cout) && rq.G > 0 &&
+             Cout % rq.G == 0 && rq.x_ld % 4 == 0 && ((uintptr_t)rq.x % 16 == 0)) {
+        tem_bp_delivered(TEM_BP_NORM_SUMS);
         tem_splitk_epilogue_bwd_sums(part, ks, N, (int64_t)D * H * W, Cout, bias, act, ref, ref_ld, y, y_ld, rq, s);
     } else
         tem_splitk_epilogue(part, ks, NV, Cout, bias, act, ref, ref_ld, y, y_ld, s);

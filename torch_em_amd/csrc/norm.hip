@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_affine(const float* __restrict
     }
 }
 
-// amax (optional, tem_arm_output_amax): max |gx| as a by-product.  This kernel is SHORT: all its waves end at the same moment,
+// amax (optional, out_amax of tem_norm_bwd_st): max |gx| as a by-product.  This kernel is SHORT: all its waves end at the same moment,
 // so the per-wave "read the word, atomicMax if larger" of the long kernels degenerates into one atomic per wave on one
 // address (~10 ns each: 8192 waves cost +80 us, measured).  With amax the launcher uses 1024-thread blocks and at most 256
 // of them; a block reduces in LDS and issues ONE atomic.
@@ -582,7 +582,7 @@ extern "C" int tem_norm_bwd(const float* gy, int64_t gy_ld, const float* x, int6
                             int64_t gx_ld, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
                             tem_stream_t stream) {
     return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, nullptr,
-                         nullptr, ws, ws_bytes, stream, 1, tem_take_output_amax(), 0);
+                         nullptr, ws, ws_bytes, stream, 1, nullptr, 0);
 }
 
 // tem_norm_bwd whose first stage -- sums[n][c] = (sum_v gy, sum_v gy * xn) -- was delivered by tem_conv3d_wgrad_sums
@@ -592,10 +592,10 @@ extern "C" int tem_norm_bwd_from_sums(const float* gy, int64_t gy_ld, const floa
                                       const float* sums, void* ws, int64_t ws_bytes, tem_stream_t stream) {
     TEM_REQUIRE(sums, "tem_norm_bwd_from_sums: null sums");
     return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, gx, gx_ld, dgamma, dbeta, sums,
-                         nullptr, ws, ws_bytes, stream, 1, tem_take_output_amax(), 0);
+                         nullptr, ws, ws_bytes, stream, 1, nullptr, 0);
 }
 
-// ... was delivered as partial rows part[N][nblk][C][2] by the data gradient that wrote gy (tem_arm_dgrad_norm_sums)
+// ... was delivered as partial rows part[N][nblk][C][2] by the data gradient that wrote gy (TEM_BP_NORM_SUMS of tem_conv3d_fwd_ex)
 extern "C" int tem_norm_bwd_from_partials(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V,
                                           int C, int G, const float* gamma, const float* mean, const float* rstd,
                                           int relu_mask, float* gx, int64_t gx_ld, float* dgamma, float* dbeta,
@@ -603,7 +603,7 @@ extern "C" int tem_norm_bwd_from_partials(const float* gy, int64_t gy_ld, const 
                                           tem_stream_t stream) {
     TEM_REQUIRE(part && (gx || coef), "tem_norm_bwd_from_partials: null pointer");
     return norm_bwd_impl(gy, gy_ld, x, x_ld, N, V, C, G, gamma, mean, rstd, relu_mask, coef ? nullptr : gx, gx_ld, dgamma, dbeta,
-                         part, coef, ws, ws_bytes, stream, nblk, coef ? nullptr : tem_take_output_amax(), 0);
+                         part, coef, ws, ws_bytes, stream, nblk, nullptr, 0);
 }
 
 // Reduction stage only: coef[n][c] = {a, m1, m2r, mean} with gx = a*gy - m1 - (x - mean)*m2r (and dgamma / dbeta).  The
@@ -620,7 +620,7 @@ extern "C" int tem_norm_bwd_coef(const float* gy, int64_t gy_ld, const float* x,
 }
 
 // All of the above for tensors of storage type st, every variant as explicit arguments:
-//   part / part_nblk : first stage rows [N][part_nblk][C][2] delivered by a producer (tem_conv3d_wgrad_ex: 1 row;
+//   part / part_nblk : first stage rows [N][part_nblk][C][2] delivered by a producer (tem_conv3d_wgrad_ex norm_sums: 1 row;
 //                      tem_conv3d_fwd_ex norm sums: its nblk) or NULL = reduce gy and x here;
 //   coef_out         : non-NULL = reduction only, write coef[N][C][4] (gx is not touched, may be NULL);
 //   out_amax         : optional device word that receives max |gx| (see tem_maxpool3d_bwd_st).

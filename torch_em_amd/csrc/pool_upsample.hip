@@ -408,7 +408,7 @@ extern "C" int tem_maxpool3d_bwd(const float* gy, int64_t gy_ld, const float* x,
                                  int64_t gskip_ld, int relu_mask, float* gx, int64_t gx_ld, int N, int D, int H, int W,
                                  int C, int fz, int fy, int fx, tem_stream_t stream) {
     return maxpool3d_bwd_impl(gy, gy_ld, x, x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, N, D, H, W, C, fz, fy, fx, nullptr,
-                              0, nullptr, tem_take_output_amax(), 0, stream);
+                              0, nullptr, nullptr, 0, stream);
 }
 
 // tem_maxpool3d_bwd whose skip gradient is still the RAW data gradient of the decoder conv behind the concat norm: that
@@ -422,7 +422,7 @@ extern "C" int tem_maxpool3d_bwd_norm(const float* gy, int64_t gy_ld, const floa
                                       const float* ycoef, tem_stream_t stream) {
     TEM_REQUIRE(gcoef || ycoef, "tem_maxpool3d_bwd_norm: no coefficients given");
     return tem_maxpool3d_bwd_st(gy, gy_ld, x, x_ld, gskip, gskip_ld, relu_mask, gx, gx_ld, N, D, H, W, C, fz, fy, fx, gcoef,
-                                gcoef_ld, ycoef, tem_take_output_amax(), TEM_ST_F32, stream);
+                                gcoef_ld, ycoef, nullptr, TEM_ST_F32, stream);
 }
 
 // tem_maxpool3d_bwd / _bwd_norm (gcoef / ycoef != NULL) for tensors of storage type st; out_amax (optional): the device word

@@ -132,6 +132,7 @@ static inline uintptr_t tem_st_align4(int st) { return st == 0 ? 16 : 8; }
 
 // run `...` with TX / TY bound to the element types of an (input, output) storage pair: both fp32, one side fp32 and the
 // other 16-bit, or both the SAME 16-bit type (the pairs a training step produces); `bad` runs for any other pair
+static inline bool tem_st2_ok(int stx, int sty) { return !(stx && sty && stx != sty); }   // the pairs TEM_ST2_SWITCH instantiates
 #define TEM_ST2_SWITCH(stx, sty, TX, TY, bad, ...)                                                  \
     do {                                                                                            \
         const int k__ = (stx) * 3 + (sty);                                                          \

@@ -60,8 +60,20 @@ static inline int tem_grid_1d(int64_t work_items, int block, int max_blocks = 25
 
 #define TEM_WAVE 64
 
-// "output amax": max |y| of the tensor a launch writes, as a by-product (tem_arm_output_amax, capi.hip).  A launch site
-// that supports it takes the armed device word with tem_take_output_amax(); its kernel keeps a per-thread maximum
+// By-products of the call in flight (tem_hip.h: TemByproducts, an explicit argument of the *_ex entry points; capi.hip).
+extern thread_local TemByproducts* tem_call_bp;
+struct TemBpScope {
+    TemByproducts* prev;
+    explicit TemBpScope(TemByproducts* bp) : prev(tem_call_bp) {
+        tem_call_bp = bp;
+        if (bp) bp->delivered = 0;
+    }
+    ~TemBpScope() { tem_call_bp = prev; }
+};
+bool tem_bp_wants(unsigned bit);        // the call in flight asks for by-product `bit` and nothing has delivered it yet
+void tem_bp_delivered(unsigned bit);
+// "output amax": max |y| of the tensor a launch writes, as a by-product (TEM_BP_OUT_AMAX).  A launch site that supports it
+// takes the caller's device word with tem_take_output_amax() (NULL: not asked for); its kernel keeps a per-thread maximum
 // (tem_amax4) and ends with tem_amax_commit() -- wave reduction, then an integer atomicMax of the bit pattern (exact,
 // order-independent) that most waves skip after one plain read of the word.
 unsigned* tem_take_output_amax();

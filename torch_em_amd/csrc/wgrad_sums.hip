@@ -425,10 +425,11 @@ void tem_wgrad_sums_launch(const float* zpart, int Ss, int ks2, const float* zdb
                        (size_t)2 * 4 * 9 * Cout * sizeof(float), s, zpart,
                        Ss * ks2, N, 27, Cin, Cout, n_out, dw, w, P, (int)nb, zdb, db_chunks, db, nb_db, sa);
     NormCoef nc = {0, 0, 0.0, nullptr, nullptr, nullptr};
-    const TemWgradCoefReq rq = tem_wgrad_coef_req;
-    const int cgn = (rq.coef && Cin % rq.G == 0) ? Cin / rq.G : 0;
-    if (cgn >= 1 && cgn <= 32 && (cgn & (cgn - 1)) == 0 && Cin % cgn == 0) {   // else: stays armed, the caller runs tem_norm_bwd_coef
-        tem_wgrad_coef_req = {0, nullptr, nullptr, nullptr};
+    TemWgradCoefReq rq = {0, nullptr, nullptr, nullptr};
+    if (tem_bp_wants(TEM_BP_NORM_COEF)) rq = TemWgradCoefReq{tem_call_bp->coef_G, tem_call_bp->coef_mean, tem_call_bp->coef_rstd, tem_call_bp->coef};
+    const int cgn = (rq.coef && rq.mean && rq.rstd && rq.G > 0 && Cin % rq.G == 0) ? Cin / rq.G : 0;
+    if (cgn >= 1 && cgn <= 32 && (cgn & (cgn - 1)) == 0 && Cin % cgn == 0) {   // else: not delivered, the caller runs tem_norm_bwd_coef
+        tem_bp_delivered(TEM_BP_NORM_COEF);
         nc.cgn = cgn;
         nc.G = rq.G;
         nc.cnt = (double)((int64_t)D * H * W) * (double)nc.cgn;

@@ -215,54 +215,43 @@ _FUSE_POOL_STATS = os.environ.get("TEM_FUSE_POOL_STATS", "1") != "0"   # max-poo
 
 
 class _sums_coef:
-    """`with _sums_coef(spec, stats, x) as rq: sums = <weight gradient with sums_from>; rq.attach(sums)` -- the launch inside
-    also writes the coefficients of the norm backward (tem_arm_wgrad_norm_coef) when the layer allows it; they travel on the
-    sums tensor (`_tem_coef`) to _norm_bwd_inplace(coef_only=True).  Norms with affine parameters keep the separate stage:
-    their dgamma / dbeta come from it."""
+    """`rq = _sums_coef(spec, stats, x); sums = <weight gradient with sums_from>(..., bp=rq.bp); rq.attach(sums)` -- the
+    launch also writes the coefficients of the norm backward (ops.Byproducts.norm_coef: an explicit argument of the call)
+    when the layer allows it; they travel on the sums tensor (`_tem_coef`) to _norm_bwd_inplace(coef_only=True).  Norms with
+    affine parameters keep the separate stage: their dgamma / dbeta come from it."""
 
     def __init__(self, spec, stats, x, on=True):
         groups, gamma, beta, _ = spec.norm_args()
-        self.coef = None
+        self.coef = self.bp = None
         if on and _FUSE_COEF and gamma is None and beta is None and stats is not None and stats[4] == "sample":
             self.coef = torch.empty((x.shape[0], spec.cin, 4), dtype=torch.float32, device=x.device)
-            self.args = (groups, stats[0], stats[1])
-
-    def __enter__(self):
-        if self.coef is not None:
-            ops.arm_wgrad_norm_coef(*self.args, self.coef)
-        return self
+            self.bp = ops.Byproducts(norm_coef=(groups, stats[0], stats[1], self.coef))
 
     def attach(self, sums):
-        if self.coef is not None and not ops.disarm_wgrad_norm_coef() and sums is not None:
+        if self.bp is not None and self.bp.coef and sums is not None:
             sums._tem_coef = self.coef
-        self.coef = None
         return sums
-
-    def __exit__(self, *exc):
-        if self.coef is not None:   # the launch raised before attach()
-            ops.disarm_wgrad_norm_coef()
-        return False
 
 
 class _output_amax:
-    """`with _output_amax(grads, out):` -- the launch inside that writes the data gradient `out` also delivers max |out|
-    (tem_arm_output_amax) for the fp16 2x1 weight gradient that reads `out` next; when no kernel of the launch supports it
-    the consumer falls back to one absmax pass.  `out` must not be modified afterwards (callers that do drop the entry)."""
+    """`rq = _output_amax(grads, out); <launch that writes the data gradient out>(..., out_amax=rq.slot | bp=rq.bp);
+    rq.done(delivered)` -- the launch also delivers max |out| for the fp16 2x1 weight gradient that reads `out` next; when
+    no kernel of the launch supports it the consumer falls back to one absmax pass.  `out` must not be modified afterwards
+    (callers that do drop the entry)."""
 
-    def __init__(self, grads, out):
-        self.on = grads is not None and _FUSE_AMAX and _WGRAD_F16X2 and PRECISION == "split16" and not _FORCE_GENERIC
-        self.grads, self.out = grads, out
+    def __init__(self, grads, out, bp=None):
+        on = grads is not None and _FUSE_AMAX and _WGRAD_F16X2 and PRECISION == "split16" and not _FORCE_GENERIC
+        self.out = out
+        self.slot = grads.amax_slot() if on else None
+        self.bp = bp
+        if on and bp is None:
+            self.bp = ops.Byproducts(out_amax=self.slot)
+        elif on:
+            bp.c.out_amax = self.slot.data_ptr()
 
-    def __enter__(self):
-        if self.on:
-            self.slot = self.grads.amax_slot()
-            ops.arm_output_amax(self.slot)
-        return self
-
-    def __exit__(self, *exc):
-        if self.on and not ops.disarm_output_amax() and exc[0] is None:
+    def done(self, delivered=None):
+        if self.slot is not None and (self.bp.amax if delivered is None else delivered):
             self.out._tem_amax = self.slot   # on the tensor OBJECT: dies with it (an address could be reused by another tensor)
-        return False
 
 
 def _wgrad_f16x2_ok(spec, x, stats) -> bool:
@@ -475,7 +464,7 @@ def _join_side(device):
 
 
 # the split-K epilogue of a data gradient also writes the first stage of the backward of the norm in front of the conv
-# (tem_arm_dgrad_norm_sums: k_norm_partial<.,1> disappears for the 16^3 / 8^3 levels); 0: the pass over gx and x
+# (TEM_BP_NORM_SUMS of tem_conv3d_fwd_ex: k_norm_partial<.,1> disappears for the 16^3 / 8^3 levels); 0: the pass over gx and x
 _FUSE_DGRAD_SUMS = os.environ.get("TEM_FUSE_DGRAD_SUMS", "1") != "0"
 
 
@@ -485,7 +474,7 @@ def _dgrad(spec: ConvSpec, g, gx, ref=None, gmax=None, refnorm=None, grads=None,
     grads: gx is FINAL after this call (nothing rewrites it): ask the kernel for max |gx| as a by-product.
     sums_for = (x, stats): gx lands behind the norm whose input is x -> partial rows [N, nblk, C, 2] of its backward's first
     stage when this launch can deliver them (plain launch on the split-K z-reuse kernel), else None."""
-    part = None
+    part = bp = None
     if sums_for is not None and _FUSE_DGRAD_SUMS and ref is None and gmax is None and refnorm is None and not _FORCE_GENERIC:
         x, stats = sums_for
         mode = spec.packed()["dgrad_mfma"]
@@ -493,17 +482,14 @@ def _dgrad(spec: ConvSpec, g, gx, ref=None, gmax=None, refnorm=None, grads=None,
             nblk = ops.conv_fwd_stat_blocks(g, spec.k, spec.cout, spec.cin, mode)
             if nblk > 0:
                 part = torch.empty((x.shape[0], nblk, spec.cin, 2), dtype=torch.float32, device=x.device)
-                ops.arm_dgrad_norm_sums(x, spec.norm_args()[0], stats[0], stats[1], part)
-    try:
-        with _output_amax(grads, gx):
-            _dgrad_launch(spec, g, gx, ref, gmax, refnorm)
-    finally:
-        if part is not None and ops.disarm_dgrad_norm_sums():
-            part = None   # not delivered
-    return part
+                bp = ops.Byproducts(norm_sums=(x, spec.norm_args()[0], stats[0], stats[1], part))
+    rq = _output_amax(grads, gx, bp)
+    _dgrad_launch(spec, g, gx, ref, gmax, refnorm, rq.bp)
+    rq.done()
+    return part if bp is not None and bp.sums else None
 
 
-def _dgrad_launch(spec: ConvSpec, g, gx, ref, gmax, refnorm):
+def _dgrad_launch(spec: ConvSpec, g, gx, ref, gmax, refnorm, bp=None):
     if _OVERLAP_WGRAD == 2:
         _join_side(g.device)  # MFMA kernels never overlap each other: wait for the weight gradient in flight
     ent = spec.packed()
@@ -511,18 +497,18 @@ def _dgrad_launch(spec: ConvSpec, g, gx, ref, gmax, refnorm):
         if "dgrad" not in ent:
             ent["dgrad"] = ops.pack_weights(spec.conv.weight, transpose=True, mfma=ent["dgrad_mfma"])
         ent["dgrad_used"] = True
-        ops.conv_fwd_refnorm(g, ent["dgrad"], gx, spec.k, spec.cout, spec.cin, ref, refnorm, ent["dgrad_mfma"])
+        ops.conv_fwd_refnorm(g, ent["dgrad"], gx, spec.k, spec.cout, spec.cin, ref, refnorm, ent["dgrad_mfma"], bp=bp)
         return
     if gmax is not None:
         if "dgrad16" not in ent:
             ent["dgrad16"], ent["dgrad16_mfma"] = ops.pack_weights(spec.conv.weight, transpose=True, mfma=4), 4
         ent["dgrad16_used"] = True
-        ops.conv_fwd_gscaled(g, ent["dgrad16"], gx, spec.k, spec.cout, spec.cin, gmax, ref=ref)
+        ops.conv_fwd_gscaled(g, ent["dgrad16"], gx, spec.k, spec.cout, spec.cin, gmax, ref=ref, bp=bp)
         return
     if "dgrad" not in ent:
         ent["dgrad"] = ops.pack_weights(spec.conv.weight, transpose=True, mfma=ent["dgrad_mfma"])
     ent["dgrad_used"] = True
-    ops.conv_fwd(g, ent["dgrad"], None, gx, spec.k, spec.cout, spec.cin, ref=ref, mfma=ent["dgrad_mfma"])
+    ops.conv_fwd(g, ent["dgrad"], None, gx, spec.k, spec.cout, spec.cin, ref=ref, mfma=ent["dgrad_mfma"], bp=bp)
 
 
 # Norm-backward sums from the weight gradient (csrc/wgrad_sums.hip, tem_conv3d_wgrad_sums): the reduction pass over the
@@ -542,9 +528,9 @@ def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None, want_sums=False, gma
                 ops.conv_wgrad_sums_ok(x, spec.k, spec.cin, spec.cout, ent["wgrad_mfma"]):
             _, gamma, beta, _ = spec.norm_args()
             sums_from = (spec.conv.weight, gamma, beta)
-        with _sums_coef(spec, stats, x, on=sums_from is not None) as rq:
-            return rq.attach(ops.conv_wgrad_gmax(x, g, spec.k, spec.cin, spec.cout, dw, db, gmax, scale=scale, shift=shift,
-                                                 mfma=ent["wgrad_mfma"], sums_from=sums_from))
+        rq = _sums_coef(spec, stats, x, on=sums_from is not None)
+        return rq.attach(ops.conv_wgrad_gmax(x, g, spec.k, spec.cin, spec.cout, dw, db, gmax, scale=scale, shift=shift,
+                                             mfma=ent["wgrad_mfma"], sums_from=sums_from, bp=rq.bp))
     if ent["wgrad_mfma"] == 2 and _wgrad_f16x2_ok(spec, x, stats):
         sums_from = None
         if want_sums and stats[4] == "sample" and db is not None and \
@@ -555,15 +541,15 @@ def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None, want_sums=False, gma
             amax = getattr(g, "_tem_amax", None)
         if amax is None:   # no producer of g delivered max |g|: one pass over g
             amax = ops.absmax(g, grads.amax_slot())
-        with _sums_coef(spec, stats, x, on=sums_from is not None) as rq:
-            return rq.attach(ops.conv_wgrad_gscaled(x, g, spec.k, spec.cin, spec.cout, dw, db, amax, scale=scale, shift=shift,
-                                                    sums_from=sums_from))
+        rq = _sums_coef(spec, stats, x, on=sums_from is not None)
+        return rq.attach(ops.conv_wgrad_gscaled(x, g, spec.k, spec.cin, spec.cout, dw, db, amax, scale=scale, shift=shift,
+                                                sums_from=sums_from, bp=rq.bp))
     if want_sums and stats is not None and stats[4] == "sample" and db is not None and not _OVERLAP_WGRAD and \
             ops.conv_wgrad_sums_ok(x, spec.k, spec.cin, spec.cout, ent["wgrad_mfma"]):
         _, gamma, beta, _ = spec.norm_args()
-        with _sums_coef(spec, stats, x) as rq:
-            return rq.attach(ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift,
-                                            mfma=ent["wgrad_mfma"], sums_from=(spec.conv.weight, gamma, beta)))
+        rq = _sums_coef(spec, stats, x)
+        return rq.attach(ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift,
+                                        mfma=ent["wgrad_mfma"], sums_from=(spec.conv.weight, gamma, beta), bp=rq.bp))
     if not _OVERLAP_WGRAD or (_OVERLAP_WGRAD == 1 and vox > _OVERLAP_MAX_VOXELS):
         ops.conv_wgrad(x, g, spec.k, spec.cin, spec.cout, dw, db, scale=scale, shift=shift, mfma=ent["wgrad_mfma"])
         return
@@ -696,8 +682,9 @@ def _norm_bwd_inplace(spec: ConvSpec, g, x, stats, relu_mask, grads: _Grads, sum
         gb = _flat_batch(g)
         ops.norm_bwd(gb, _flat_batch(x), groups, gamma, stats[0], stats[1], relu_mask, gb, dgamma, dbeta)
         return
-    with _output_amax(grads if amax else None, g):
-        ops.norm_bwd(g, x, groups, gamma, stats[0], stats[1], relu_mask, g, dgamma, dbeta, sums=sums)
+    rq = _output_amax(grads if amax else None, g)
+    ops.norm_bwd(g, x, groups, gamma, stats[0], stats[1], relu_mask, g, dgamma, dbeta, sums=sums, out_amax=rq.slot)
+    rq.done(True)
 
 
 def _block_bwd(bs, gout, gin, grads: _Grads, defer_input_norm=False):
@@ -978,9 +965,10 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
         if _FUSE_OUT_BWD and not _FORCE_GENERIC and not _OVERLAP_WGRAD and osp.k == (1, 1, 1) and osp.conv.weight.is_contiguous() and \
                 ops.conv1x1_out_bwd_ok(osp.cin, osp.cout):
             # weight / bias gradient of out_conv and its masked data gradient in one pass over `last`
-            with _output_amax(grads, g_cur):
-                ops.conv1x1_out_bwd(last, g, osp.conv.weight, g_cur, grads.view(osp.conv.weight),
-                                    grads.view(osp.conv.bias) if osp.conv.bias is not None else None)
+            rq = _output_amax(grads, g_cur)
+            ops.conv1x1_out_bwd(last, g, osp.conv.weight, g_cur, grads.view(osp.conv.weight),
+                                grads.view(osp.conv.bias) if osp.conv.bias is not None else None, out_amax=rq.slot)
+            rq.done(True)
         else:
             _dgrad(osp, g, g_cur, ref=last, grads=grads)
             _wgrad(osp, last, g, grads)
@@ -1034,9 +1022,10 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
             g_skip_full[:, :sub.shape[1], :sub.shape[2], :sub.shape[3]] += g_sub
             g_skip_full.mul_(skip > 0)
         else:
-            with _output_amax(grads, g_skip_full):
-                ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True,
-                                gskip_coef=lv.get("g_skip_coef"), gy_coef=pool_coef)
+            rq = _output_amax(grads, g_skip_full)
+            ops.maxpool_bwd(g_cur, skip, g_skip_full, lv["f"], gskip=lv["g_skip"], relu_mask=True,
+                            gskip_coef=lv.get("g_skip_coef"), gy_coef=pool_coef, out_amax=rq.slot)
+            rq.done(True)
         need_in = (l > 0) or need_input_grad
         xin = lv["bs"]["xin"]
         g_in = torch.empty_like(xin) if need_in else None

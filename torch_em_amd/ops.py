@@ -225,9 +225,12 @@ def pack_weights_batch(tab):
 
 
 def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=None, ref=None, mfma=False,
-             want_stats=False):
+             want_stats=False, bp=None):
     """want_stats: also emit the first stage of the statistics of y (tem_conv3d_fwd_stats) when this launch can; returns
-    (partials [N, nblk, cout, 2], nblk) then, else y (and `None` for launches that cannot: use norm_stats)."""
+    (partials [N, nblk, cout, 2], nblk) then, else y (and `None` for launches that cannot: use norm_stats).
+    bp: Byproducts of this call (tem_conv3d_fwd_ex), not together with want_stats."""
+    if bp is not None and want_stats:
+        raise ValueError("conv_fwd: by-products and want_stats exclude each other")
     _req_cuda(x, w_packed, y)
     N, D, H, W, C, x_ld = _act5(x)
     Ny, Dy, Hy, Wy, Cy, y_ld = _act5(y)
@@ -253,6 +256,10 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
         _lib.check(lib.tem_conv3d_fwd_stats(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld,
                                             _p(ref), ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2],
                                             ACT[act], mode, _p(part), nblk, _stream(x)), "tem_conv3d_fwd_stats")
+    elif bp is not None:
+        _lib.check(lib.tem_conv3d_fwd_ex(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
+                                         ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], mode,
+                                         None, None, bp.ref(), _stream(x)), "tem_conv3d_fwd_ex")
     else:
         _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
                                       ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], mode,
@@ -313,15 +320,15 @@ def conv_wgrad_sums_ok(x, k, cin, cout, mfma) -> bool:
     return bool(_lib.load().tem_conv3d_wgrad_sums_ok(N, D, H, W, cin, cout, k[0], k[1], k[2], _mode(mfma, x, x)))
 
 
-def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, mfma=False, sums_from=None):
+def conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None, mfma=False, sums_from=None, bp=None):
     """sums_from = (weight [state_dict layout], gamma, beta): also return sums[N, cin, 2] = (sum gz, sum gz*xn) of the
     norm in front of this conv (tem_conv3d_wgrad_sums; check conv_wgrad_sums_ok first)."""
     if sums_from is not None:
-        return _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sums_from)
+        return _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sums_from, bp)
     return _conv_wgrad(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma)
 
 
-def _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sums_from):
+def _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sums_from, bp=None):
     _req_cuda(x, g, dw_out, db_out)
     w, gamma, beta = sums_from
     N, D, H, W, C, x_ld = _act5(x)
@@ -333,9 +340,9 @@ def _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sum
     sums = torch.empty((N, cin, 2), dtype=torch.float32, device=x.device)
     kind = _wgrad_tag(mfma, k, cout) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
-    _lib.check(lib.tem_conv3d_wgrad_sums(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w.detach()), _p(gamma), _p(beta),
-                                         _p(dw_out), _p(db_out), _p(sums), _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1],
-                                         k[2], mode, _stream(x)), "tem_conv3d_wgrad_sums")
+    _lib.check(lib.tem_conv3d_wgrad_ex(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w.detach()), _p(gamma), _p(beta),
+                                       _p(dw_out), _p(db_out), _p(sums), None, None, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1],
+                                       k[2], mode, bp.ref() if bp is not None else None, _stream(x)), "tem_conv3d_wgrad_ex")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return sums
@@ -346,7 +353,7 @@ def conv_wgrad_gmax_ok(x, k, cin, cout, mfma) -> bool:
     return bool(_lib.load().tem_conv3d_wgrad_gmax_ok(N, D, H, W, cin, cout, k[0], k[1], k[2], int(mfma)))
 
 
-def conv_wgrad_gmax(x, g, k, cin, cout, dw_out, db_out, gmax, scale=None, shift=None, mfma=2, sums_from=None):
+def conv_wgrad_gmax(x, g, k, cin, cout, dw_out, db_out, gmax, scale=None, shift=None, mfma=2, sums_from=None, bp=None):
     """conv_wgrad that also leaves the bit pattern of max |g| in `gmax` (int32[1], cleared by the caller) -- the prescale
     of the fp16 two-term data gradient (conv_fwd_gscaled).  sums_from as in conv_wgrad -> sums[N, cin, 2] or None."""
     _req_cuda(x, g, dw_out, gmax)
@@ -362,9 +369,10 @@ def conv_wgrad_gmax(x, g, k, cin, cout, dw_out, db_out, gmax, scale=None, shift=
         sums = torch.empty((N, cin, 2), dtype=torch.float32, device=x.device)
     kind = _wgrad_tag(mfma, k, cout) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
-    _lib.check(lib.tem_conv3d_wgrad_gmax(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w), _p(gamma), _p(beta),
-                                         _p(dw_out), _p(db_out), _p(sums), _p(gmax), _p(ws), nws, N, D, H, W, cin, cout,
-                                         k[0], k[1], k[2], int(mfma), _stream(x)), "tem_conv3d_wgrad_gmax")
+    _lib.check(lib.tem_conv3d_wgrad_ex(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w), _p(gamma), _p(beta),
+                                       _p(dw_out), _p(db_out), _p(sums), None, _p(gmax), _p(ws), nws, N, D, H, W, cin, cout,
+                                       k[0], k[1], k[2], int(mfma), bp.ref() if bp is not None else None, _stream(x)),
+               "tem_conv3d_wgrad_ex")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return sums
@@ -374,7 +382,7 @@ def conv1x1_out_bwd_ok(cin, cout) -> bool:
     return bool(_lib.load().tem_conv1x1_out_bwd_ok(int(cin), int(cout)))
 
 
-def conv1x1_out_bwd(x, g, w, gx, dw_out, db_out=None):
+def conv1x1_out_bwd(x, g, w, gx, dw_out, db_out=None, out_amax=None):
     """Backward of the output projection in one pass over its input x (tem_conv1x1_out_bwd): dw [cout, cin, 1, 1, 1]-ordered, db,
     and gx = (x > 0) * (g . w).  x, gx: [N, D, H, W, cin(ld)]; g: [N, D, H, W, cout(ld)]; w: the conv's weight (state_dict)."""
     _req_cuda(x, g, w, gx, dw_out)
@@ -385,9 +393,9 @@ def conv1x1_out_bwd(x, g, w, gx, dw_out, db_out=None):
     nws = lib.tem_conv1x1_out_bwd_ws(cin, cout)
     ws = _workspace(nws, x.device)
     _same_st(x, gx)
-    if _st(x) or _st(g):
+    if _st(x) or _st(g) or out_amax is not None:
         _lib.check(lib.tem_conv1x1_out_bwd_st(_p(x), x_ld, _p(g), g_ld, _p(w.detach()), _p(gx), gx_ld, _p(dw_out), _p(db_out),
-                                              _p(ws), nws, N * D * H * W, cin, cout, None, _st(x), _st(g), _stream(x)),
+                                              _p(ws), nws, N * D * H * W, cin, cout, _p(out_amax), _st(x), _st(g), _stream(x)),
                    "tem_conv1x1_out_bwd_st")
         return gx
     _lib.check(lib.tem_conv1x1_out_bwd(_p(x), x_ld, _p(g), g_ld, _p(w.detach()), _p(gx), gx_ld, _p(dw_out), _p(db_out), _p(ws), nws,
@@ -411,42 +419,38 @@ def absmax(x, amax=None):
     return amax
 
 
-def arm_output_amax(amax):
-    """The NEXT library launch of this thread, if it is a producer of data gradients that supports it, also leaves the bit
-    pattern of max |output| in `amax` (int32[1], cleared by the caller): tem_arm_output_amax."""
-    _lib.check(_lib.load().tem_arm_output_amax(_p(amax)), "tem_arm_output_amax")
+class Byproducts:
+    """Optional by-products of ONE library call, passed explicitly (include/tem_hip.h: TemByproducts):
+      out_amax  = int32[1] (cleared by the caller): bit pattern of max |output| of the tensor the call writes;
+      norm_coef = (groups, mean, rstd, coef [N, C, 4]): a weight gradient that delivers the norm sums (sums_from=...) also
+                  finishes them into what norm_bwd_coef(sums=...) returns for a norm without affine parameters;
+      norm_sums = (x, groups, mean, rstd, part [N, nblk, C, 2]): a data gradient on the split-K z-reuse kernel also writes
+                  the first stage of the backward of the norm whose input is x.
+    After the call `amax` / `coef` / `sums` tell which of them it delivered (the caller runs the separate stage otherwise)."""
+
+    def __init__(self, out_amax=None, norm_coef=None, norm_sums=None):
+        c = _lib.Byproducts()
+        self._keep = (out_amax, norm_coef, norm_sums)
+        c.out_amax = _p(out_amax)
+        if norm_coef is not None:
+            groups, mean, rstd, coef = norm_coef
+            c.coef_G, c.coef_mean, c.coef_rstd, c.coef = int(groups), _p(mean), _p(rstd), _p(coef)
+        if norm_sums is not None:
+            x, groups, mean, rstd, part = norm_sums
+            c.sums_x, c.sums_x_ld, c.sums_mean, c.sums_rstd = _p(x), _act5(x)[5], _p(mean), _p(rstd)
+            c.sums_G, c.sums_part, c.sums_nblk = int(groups), _p(part), part.shape[1]
+        self.c = c
+
+    def ref(self):
+        import ctypes
+        return ctypes.cast(ctypes.pointer(self.c), ctypes.c_void_p)
+
+    amax = property(lambda self: bool(self.c.delivered & _lib.BP_OUT_AMAX))
+    coef = property(lambda self: bool(self.c.delivered & _lib.BP_NORM_COEF))
+    sums = property(lambda self: bool(self.c.delivered & _lib.BP_NORM_SUMS))
 
 
-def disarm_output_amax() -> bool:
-    """-> True when the armed request was NOT consumed (the caller then needs absmax())"""
-    return bool(_lib.load().tem_disarm_output_amax())
-
-
-def arm_dgrad_norm_sums(x, groups, mean, rstd, part):
-    """The NEXT conv_fwd of this thread, if it is a data gradient on the split-K z-reuse kernel, also writes part[N, nblk, C, 2]
-    = per-block (sum g, sum g * xn) of the norm whose input is x (tem_arm_dgrad_norm_sums): the first stage of norm_bwd."""
-    _lib.check(_lib.load().tem_arm_dgrad_norm_sums(_p(x), _act5(x)[5], _p(mean), _p(rstd), int(groups), _p(part),
-                                                   part.shape[1]), "tem_arm_dgrad_norm_sums")
-
-
-def disarm_dgrad_norm_sums() -> bool:
-    """-> True when the armed request was NOT consumed"""
-    return bool(_lib.load().tem_disarm_dgrad_norm_sums())
-
-
-def arm_wgrad_norm_coef(groups, mean, rstd, coef):
-    """The NEXT weight gradient of this thread that delivers the norm sums (sums_from=...) also writes coef [N, C, 4] -- what
-    norm_bwd_coef(sums=...) would return for a norm without affine parameters -- when the group layout allows it:
-    tem_arm_wgrad_norm_coef."""
-    _lib.check(_lib.load().tem_arm_wgrad_norm_coef(int(groups), _p(mean), _p(rstd), _p(coef)), "tem_arm_wgrad_norm_coef")
-
-
-def disarm_wgrad_norm_coef() -> bool:
-    """-> True when the armed request was NOT consumed (the caller then needs norm_bwd_coef())"""
-    return bool(_lib.load().tem_disarm_wgrad_norm_coef())
-
-
-def conv_wgrad_gscaled(x, g, k, cin, cout, dw_out, db_out, amax, scale=None, shift=None, sums_from=None):
+def conv_wgrad_gscaled(x, g, k, cin, cout, dw_out, db_out, amax, scale=None, shift=None, sums_from=None, bp=None):
     """Weight gradient in the fp16 2x1 arithmetic (tem_conv3d_wgrad_gscaled): x^ two fp16 terms, g one fp16 term prescaled
     from amax = int32[1] with the bit pattern of max |g| (absmax or a producer of g).  sums_from as in conv_wgrad."""
     _req_cuda(x, g, dw_out, amax)
@@ -462,15 +466,15 @@ def conv_wgrad_gscaled(x, g, k, cin, cout, dw_out, db_out, amax, scale=None, shi
         sums = torch.empty((N, cin, 2), dtype=torch.float32, device=x.device)
     kind = _wgrad_tag(8, k, cout) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
-    _lib.check(lib.tem_conv3d_wgrad_gscaled(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w), _p(gamma), _p(beta),
-                                            _p(dw_out), _p(db_out), _p(sums), _p(amax), _p(ws), nws, N, D, H, W, cin, cout,
-                                            k[0], k[1], k[2], _stream(x)), "tem_conv3d_wgrad_gscaled")
+    _lib.check(lib.tem_conv3d_wgrad_ex(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w), _p(gamma), _p(beta),
+                                       _p(dw_out), _p(db_out), _p(sums), _p(amax), None, _p(ws), nws, N, D, H, W, cin, cout,
+                                       k[0], k[1], k[2], 8, bp.ref() if bp is not None else None, _stream(x)), "tem_conv3d_wgrad_ex")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return sums
 
 
-def conv_fwd_gscaled(x, w_packed, y, k, cin, cout, amax, ref=None):
+def conv_fwd_gscaled(x, w_packed, y, k, cin, cout, amax, ref=None, bp=None):
     """Data gradient with fp32-class products (tem_conv3d_fwd_gscaled): x an unnormalised gradient, w_packed =
     pack_weights(w, transpose=True, mfma=4), amax = int32[1] holding the bit pattern of max |x| (conv_wgrad_gmax)."""
     _req_cuda(x, w_packed, y, amax)
@@ -484,14 +488,19 @@ def conv_fwd_gscaled(x, w_packed, y, k, cin, cout, amax, ref=None):
     ws = _workspace(nws, x.device) if nws else None
     kind = _fwd_tag(4, k, cout, 3) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
-    _lib.check(lib.tem_conv3d_fwd_gscaled(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(amax), _p(ws), nws,
-                                          N, D, H, W, cin, cout, k[0], k[1], k[2], _stream(x)), "tem_conv3d_fwd_gscaled")
+    if bp is not None:
+        _lib.check(lib.tem_conv3d_fwd_ex(_p(x), x_ld, None, None, _p(w_packed), None, _p(y), y_ld, _p(ref), ref_ld, _p(ws), nws,
+                                         N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[None], 4, _p(amax), None, bp.ref(),
+                                         _stream(x)), "tem_conv3d_fwd_ex")
+    else:
+        _lib.check(lib.tem_conv3d_fwd_gscaled(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(amax), _p(ws), nws,
+                                              N, D, H, W, cin, cout, k[0], k[1], k[2], _stream(x)), "tem_conv3d_fwd_gscaled")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return y
 
 
-def conv_fwd_refnorm(x, w_packed, y, k, cin, cout, ref, coef, mfma):
+def conv_fwd_refnorm(x, w_packed, y, k, cin, cout, ref, coef, mfma, bp=None):
     """Data gradient that lands behind a ReLU + norm (tem_conv3d_fwd_refnorm): y = ref > 0 ? a*conv(x) - m1 - (ref - mean)*m2r
     : 0, coef [N, cout, 4] from norm_bwd_coef.  Only where conv_fwd_family(...) == 3."""
     _req_cuda(x, w_packed, y, ref, coef)
@@ -507,9 +516,14 @@ def conv_fwd_refnorm(x, w_packed, y, k, cin, cout, ref, coef, mfma):
     ws = _workspace(nws, x.device) if nws else None
     kind = _fwd_tag(mfma, k, cout, 3) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
-    _lib.check(lib.tem_conv3d_fwd_refnorm(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(coef), _p(ws), nws,
-                                          N, D, H, W, cin, cout, k[0], k[1], k[2], _mode(mfma, x, y), _stream(x)),
-               "tem_conv3d_fwd_refnorm")
+    if bp is not None:
+        _lib.check(lib.tem_conv3d_fwd_ex(_p(x), x_ld, None, None, _p(w_packed), None, _p(y), y_ld, _p(ref), ref_ld, _p(ws), nws,
+                                         N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[None], _mode(mfma, x, y), None, _p(coef),
+                                         bp.ref(), _stream(x)), "tem_conv3d_fwd_ex")
+    else:
+        _lib.check(lib.tem_conv3d_fwd_refnorm(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(coef), _p(ws), nws,
+                                              N, D, H, W, cin, cout, k[0], k[1], k[2], _mode(mfma, x, y), _stream(x)),
+                   "tem_conv3d_fwd_refnorm")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return y
@@ -611,7 +625,7 @@ def norm_bwd_coef(gy, x, groups, gamma, mean, rstd, dgamma=None, dbeta=None, sum
                                        _p(dgamma), _p(dbeta), _p(sums), nrow, _p(coef), None, _p(ws), nws, _st(x), _stream(x)),
                    "tem_norm_bwd_st")
         return coef
-    if sums is not None and sums.dim() == 4:   # partial rows [N, nblk, C, 2] from a data gradient (arm_dgrad_norm_sums)
+    if sums is not None and sums.dim() == 4:   # partial rows [N, nblk, C, 2] from a data gradient (Byproducts.norm_sums of the data gradient)
         _lib.check(lib.tem_norm_bwd_from_partials(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd), 0,
                                                   None, C, _p(dgamma), _p(dbeta), _p(sums), sums.shape[1], _p(coef), _p(ws), nws,
                                                   _stream(x)), "tem_norm_bwd_from_partials")
@@ -622,8 +636,9 @@ def norm_bwd_coef(gy, x, groups, gamma, mean, rstd, dgamma=None, dbeta=None, sum
     return coef
 
 
-def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None, dbeta=None, sums=None):
-    """sums: [N, C, 2] from conv_wgrad(sums_from=...) -- skips the reduction pass over gy and x"""
+def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None, dbeta=None, sums=None, out_amax=None):
+    """sums: [N, C, 2] from conv_wgrad(sums_from=...) -- skips the reduction pass over gy and x;
+    out_amax: int32[1] (cleared by the caller) that receives the bit pattern of max |gx|"""
     _req_cuda(gy, x, gx)
     N, D, H, W, C, x_ld = _act5(x)
     gy_ld = _act5(gy)[5]
@@ -632,14 +647,14 @@ def norm_bwd(gy, x, groups, gamma, mean, rstd, relu_mask: bool, gx, dgamma=None,
     V = D * H * W
     nws = lib.tem_norm_ws(N, V, C)
     ws = _workspace(nws, x.device)
-    if _st(x) or _st(gy) or _st(gx):
+    if _st(x) or _st(gy) or _st(gx) or out_amax is not None:
         _same_st(gy, x, gx)
         nrow = 0 if sums is None else (sums.shape[1] if sums.dim() == 4 else 1)
         _lib.check(lib.tem_norm_bwd_st(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd), int(relu_mask),
-                                       _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(sums), nrow, None, None, _p(ws), nws, _st(x),
+                                       _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(sums), nrow, None, _p(out_amax), _p(ws), nws, _st(x),
                                        _stream(x)), "tem_norm_bwd_st")
         return gx
-    if sums is not None and sums.dim() == 4:   # partial rows [N, nblk, C, 2] from a data gradient (arm_dgrad_norm_sums)
+    if sums is not None and sums.dim() == 4:   # partial rows [N, nblk, C, 2] from a data gradient (Byproducts.norm_sums of the data gradient)
         _lib.check(lib.tem_norm_bwd_from_partials(_p(gy), gy_ld, _p(x), x_ld, N, V, C, groups, _p(gamma), _p(mean), _p(rstd),
                                                   int(relu_mask), _p(gx), gx_ld, _p(dgamma), _p(dbeta), _p(sums), sums.shape[1],
                                                   None, _p(ws), nws, _stream(x)), "tem_norm_bwd_from_partials")
@@ -684,7 +699,7 @@ def maxpool_fwd(x, y, f, want_stats=False):
     return None if want_stats else y
 
 
-def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None, gy_coef=None):
+def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None, gy_coef=None, out_amax=None):
     """gskip_coef: [N, C, 4] view (row stride = multiple of 4 floats) of norm_bwd_coef() -- gskip is then the raw data
     gradient behind that norm and the norm backward is applied on the fly (tem_maxpool3d_bwd_norm)."""
     _req_cuda(gy, x, gx)
@@ -695,11 +710,11 @@ def maxpool_bwd(gy, x, gx, f, gskip=None, relu_mask=False, gskip_coef=None, gy_c
     lib = _lib.load()
     if gy_coef is not None and not gy_coef.is_contiguous():
         raise ValueError("maxpool_bwd: gy_coef must be contiguous")
-    if _st(x) or _st(gy) or _st(gx):
+    if _st(x) or _st(gy) or _st(gx) or out_amax is not None:
         _same_st(gy, x, gx, gskip)
         _lib.check(lib.tem_maxpool3d_bwd_st(_p(gy), gy_ld, _p(x), x_ld, _p(gskip), gs_ld, int(relu_mask), _p(gx), gx_ld,
                                             N, D, H, W, C, f[0], f[1], f[2], _p(gskip_coef),
-                                            gskip_coef.stride(0) if gskip_coef is not None else 0, _p(gy_coef), None, _st(x),
+                                            gskip_coef.stride(0) if gskip_coef is not None else 0, _p(gy_coef), _p(out_amax), _st(x),
                                             _stream(x)), "tem_maxpool3d_bwd_st")
         return gx
     if gskip_coef is not None or gy_coef is not None:
