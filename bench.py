@@ -73,11 +73,13 @@ PRECISION_DTYPE = {
                "r04_backward_arith_sim.txt; TEM_WGRAD_ARITH=bf16x3 restores 3 MFMAs: key wgrad_bf16x3_ms_per_step); fp32 "
                "accumulate and storage; gradient error vs float64 = that of the fp32 reference path, tests/test_gpu_unet.py)",
     "bf16x3": "bf16x3 (all MFMA convs split-bf16, fp32 accumulate)",
-    "amp": "f16 operands (REDUCED PRECISION, not the headline configuration: conv operands rounded to fp16, one fp16 MFMA "
-           "per product, fp32 accumulate and storage -- the counterpart of the reference's torch.autocast(float16); no "
-           "loss scaling in this synthetic step)",
-    "amp_bf16": "bf16 operands (REDUCED PRECISION, not the headline configuration: conv operands rounded to bf16, one bf16 "
-                "MFMA per product, fp32 accumulate and storage -- the counterpart of torch.autocast(bfloat16))",
+    "amp": "f16 (REDUCED PRECISION, not the headline configuration: activations and their gradients STORED as fp16 between "
+           "the kernels of the step, conv operands fp16, one fp16 MFMA per product; fp32 accumulate, statistics, parameters, "
+           "gradient arena and network output -- the counterpart of the reference's torch.autocast(float16); no loss scaling "
+           "in this synthetic step; TEM_AMP_STORAGE=32 keeps fp32 tensors as in rounds 1-4)",
+    "amp_bf16": "bf16 (REDUCED PRECISION, not the headline configuration: activations and their gradients STORED as bf16, "
+                "conv operands bf16, one bf16 MFMA per product; fp32 accumulate, statistics, parameters, gradient arena and "
+                "network output -- the counterpart of torch.autocast(bfloat16))",
 }
 
 
@@ -139,10 +141,28 @@ def extra_measurements(step, args, engine):
         return (time.perf_counter() - t0) / n * 1e3
     try:
         if args.batch == 2 and args.size == 128:
+            vox = args.batch * args.size ** 3
+            out["modes"] = {}
             for prec, key in (("fp32", "exact_fp32_ms_per_step"), ("amp", "amp_ms_per_step"),
                               ("amp_bf16", "amp_bf16_ms_per_step")):
                 engine.set_precision(prec)
-                out[key] = timed()
+                out[key] = t = timed(n=5 if prec != "fp32" else 3)
+                # the same line the headline carries, for the other arithmetics of the same step (none of them is `value`)
+                m = {"ms_per_step": t, "value": vox / (t / 1e3), "unit": "voxels/s", "dtype": PRECISION_DTYPE[prec]}
+                if prec == "fp32":
+                    m["step_roofline"] = {"flops_frac_fp32_mfma": STEP_GFLOP / t / PEAK_FP32_MFMA_TFLOPS,
+                                          "hbm_frac_8TBs": (STEP_GB / (t / 1e3)) / (PEAK_HBM_TBS * 1e3)}
+                else:
+                    st16 = engine.act_dtype() != torch.float32
+                    gb = STEP_GB / 2 if st16 else STEP_GB
+                    m["step_roofline"] = {
+                        "flops_frac_16bit_mfma": STEP_GFLOP / t / PEAK_BF16_MFMA_TFLOPS,
+                        "hbm_frac_8TBs": (gb / (t / 1e3)) / (PEAK_HBM_TBS * 1e3),
+                        "note": f"{gb:.2f} GB algorithmic per step: the 25.58 GB of SURVEY.md 8(d) "
+                                + ("halved, every activation / gradient tensor is 2 bytes per element" if st16 else
+                                   "(fp32 tensors: TEM_AMP_STORAGE=32)")
+                                + "; one 16-bit MFMA per product => the step is HBM-bound in this mode"}
+                out["modes"]["exact_fp32" if prec == "fp32" else prec] = m
             # the default arithmetic with the three-product (bf16x3) weight gradients of rounds 1-3
             engine.set_precision(prev)
             f16x2, engine._WGRAD_F16X2 = engine._WGRAD_F16X2, False
@@ -409,7 +429,7 @@ def main():
         achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s (algorithmic: 2*MACs of the convolution)
         split = 6 if "bf16x6" in dom_tag else (3 if ("bf16x3" in dom_tag or "f16x3" in dom_tag) else
                                                2 if "f16x2" in dom_tag else 1 if "_f16<" in dom_tag else 0)
-        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_bytes_per_launch.json") for r in (4, 3, 2, 1))
+        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_bytes_per_launch.json") for r in (5, 4, 3, 2, 1))
                              if os.path.exists(f)), "")
         # split-bf16 kernels execute 3 (or 6) bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3 (6)
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS

@@ -203,6 +203,12 @@ def test_pool_upsample_norm_kernels_on_16bit_tensors(dt):
         gx32 = torch.empty_like(x32)
         ops.maxpool_bwd(gy32, x32, gx32, f, **kw32)
         _assert_rounded_equal(gx16, gx32, f"maxpool_bwd {sorted(kw)}")
+        # anisotropic window (1, 2, 2): the other instantiation of the packed-word kernel
+        gya = _rt(to5(torch.randn(N, C, D, H // 2, W // 2, generator=g)), dt)
+        ga16, ga32 = torch.empty_like(x16), torch.empty_like(x32)
+        ops.maxpool_bwd(gya.to(dt), x16, ga16, (1, 2, 2), **kw16)
+        ops.maxpool_bwd(gya, x32, ga32, (1, 2, 2), **kw32)
+        _assert_rounded_equal(ga16, ga32, f"maxpool_bwd (1, 2, 2) {sorted(kw)}")
     # upsampling: factor-2 and generic kernels, forward (+ statistics), backward (+ norm backward)
     for ff in ((2, 2, 2), (1, 2, 2), (1, 3, 3)):
         u16 = torch.empty((N, D * ff[0], H * ff[1], W * ff[2], C), device=DEV, dtype=dt)

@@ -89,7 +89,7 @@ def _oracle_case(model, scale_factors, x, y, norm, final_activation=None, loss_f
                                         final_activation=final_activation, loss_fn=loss_fn)
 
 
-def _check_against_fp64(model, pred, loss, case, l2_factor=4.0, global_factor=2.0):
+def _check_against_fp64(model, pred, loss, case, l2_factor=4.0, global_factor=2.0, known=None):
     """At MFMA-eligible widths fp32 gradients through InstanceNorm / ReLU / max-pool are ill-conditioned:
     a 1e-7 forward difference flips a ReLU mask or a pooling arg-max of a near-tie, which moves single
     gradient entries by up to ~1e-2 -- the reference's OWN fp32 arithmetic deviates from the exact
@@ -102,7 +102,8 @@ def _check_against_fp64(model, pred, loss, case, l2_factor=4.0, global_factor=2.
         implementation falls on is random, so single tensors scatter by a small factor),
       * and in the max norm within 5e-2 (isolated flips only).
     Kernel-level arithmetic is pinned separately to 2e-5 (tests/test_gpu_ops.py) and the whole model to
-    TOL in the max norm on the reference's golden vectors (narrow nets, no near-ties)."""
+    TOL in the max norm on the reference's golden vectors (narrow nets, no near-ties).
+    known: {tensor name: explicit L2 bound} for DOCUMENTED deviations (the caller says why); replaces the relative bound."""
     pred64, loss64, g64 = _oracle_case(*case, dtype=torch.float64)
     _, loss32, g32 = _oracle_case(*case, dtype=torch.float32)
     assert rel_err(pred.detach().cpu(), pred64) < TOL
@@ -120,7 +121,10 @@ def _check_against_fp64(model, pred, loss, case, l2_factor=4.0, global_factor=2.
         m_hip = float(np.abs(a - r).max() / np.abs(r).max())
         m_ref = float(np.abs(b - r).max() / np.abs(r).max())
         report[k] = (e_hip, e_ref, m_hip)
-        assert e_hip <= min(1e-2, max(TOL, l2_factor * e_ref)), (k, "L2", e_hip, e_ref)
+        if known and k in known:
+            assert e_hip <= known[k], (k, "L2 (documented deviation)", e_hip, known[k])
+        else:
+            assert e_hip <= min(1e-2, max(TOL, l2_factor * e_ref)), (k, "L2", e_hip, e_ref)
         # isolated flips only -- or, where the fp32 reference path itself is that far from float64 in single entries
         # (instance statistics over the 64 voxels of a 4^3 level), the same class as the reference
         # isolated flips only.  At a level with few voxels (4^3 = 64 per channel under the depth-4 net) ONE flipped ReLU
@@ -163,6 +167,32 @@ def test_unet3d_mfma_sizes_match_oracle(norm, dispatch_mix):
     loss = DiceLoss()(pred, y.to(DEV))
     loss.backward()
     _check_against_fp64(model, pred, loss, case)
+
+
+def test_exact_fp32_mode_groupnorm_first_norm_bias_gradient():
+    """The exact-fp32 build (TEM_PRECISION=fp32, not the default) on the GroupNorm case above.  Every gradient tensor meets the
+    standard bounds but ONE, pinned here with an explicit number instead of living in DESIGN.md only: the bias of the FIRST
+    norm, GroupNorm(1, 1) on the 1-channel input.  Its gradient is sum_v gz over ALL voxels of the first conv's data gradient,
+    and behind the second norm's backward (whose output sums to zero per group) that sum cancels to boundary terms: 2 x 12288
+    values of magnitude 1 adding up to ~1e-3.  The reference's fp32 CPU path sums pairwise (5e-5 from float64); this mode's
+    reduction (`k_norm_partial<.,1>`: per-thread running sums, then rows) reaches 5.3e-3 relative -- 5e-6 of the summands.
+    The default arithmetic passes the standard bound on the same case (test_unet3d_mfma_sizes_match_oracle)."""
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d, engine
+    torch.manual_seed(0)
+    model = UNet3d(1, 2, depth=2, initial_features=32, norm="GroupNorm")
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, 16, 24, 32, generator=g)
+    y = (torch.rand(2, 2, 16, 24, 32, generator=g) > 0.5).float()
+    case = (model, [2, 2], x, y, "GroupNorm")
+    _oracle_case(*case)
+    model.to(DEV)
+    with engine.precision_scope("fp32"):
+        pred = model(x.to(DEV))
+        loss = DiceLoss()(pred, y.to(DEV))
+        loss.backward()
+    report = _check_against_fp64(model, pred, loss, case, known={"encoder.blocks.0.block.0.bias": 1e-2})
+    print("first-norm bias gradient, exact-fp32 mode: L2 vs float64 %.2e (fp32 reference path %.2e)" % report["encoder.blocks.0.block.0.bias"][:2])
 
 
 def test_unet3d_benchmark_widths_depth4_match_fp64_oracle(dispatch_mix):

@@ -44,7 +44,7 @@ static const TemOption g_opt_table[TEM_OPT_COUNT] = {
     {"zr_tile_blocks", 1},      // TEM_OPT_ZR_TILE_BLOCKS: z-reuse kernel walks its tiles in 4 x 4 x 4 blocks (one block per XCD at a time; 0: x, y, z order, A/B)
     {"dice_vox", 1},            // TEM_OPT_DICE_VOX: Dice sums / gradient with one voxel per thread for C <= 16 (0: one (channel, voxel) per thread, A/B)
     {"upsample2_ch8", 1},       // TEM_OPT_UPSAMPLE2_CH8: factor-2 upsampling BACKWARD of 16-bit tensors with 8 channels per thread (0: 4, A/B)
-    {"pool_vec8", 1},           // TEM_OPT_POOL_VEC8: max-pool kernels on 16-bit tensors with 8 channels (16 bytes) per thread (0: 4 channels / 8 bytes, A/B)
+    {"pool_vec8", 2},           // TEM_OPT_POOL_VEC8: max-pool kernels on 16-bit tensors with 8 channels (16 bytes) per thread; 2: backward on the packed-word kernel k_maxpool_bwd16 (1: generic kernel, 0: 4 channels / 8 bytes -- A/B)
 };
 static long long g_opt_val[TEM_OPT_COUNT];
 static bool g_opt_set[TEM_OPT_COUNT];

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_c1rows(const EX* __restrict__ 
                     o = f2{act_lo<EY>(pk), act_hi<EY>(pk)};
                 }
 #if !(TEM_C1_ABL & 1)
-                act_st2(y + (v0 + px) * y_ld + q * 2, o);
+                act_st2_nt(y + (v0 + px) * y_ld + q * 2, o);
 #endif
                 ss += o;
                 sq = __builtin_elementwise_fma(o, o, sq);

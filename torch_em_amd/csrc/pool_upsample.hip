@@ -371,6 +371,100 @@ extern "C" int tem_maxpool3d_fwd_st(const void* x, int64_t x_ld, void* y, int64_
     return maxpool3d_fwd_impl(x, x_ld, y, y_ld, N, D, H, W, C, fz, fy, fx, stat_part, st, stream);
 }
 
+// k_maxpool_bwd<8, T> for 16-bit tensors and windows of FZ x 2 x 2 voxels, written for REGISTERS: the generic kernel
+// unpacks the whole window (2 x 8 voxels x 8 channels of floats + 16 coefficient rows = 256 VGPRs, two waves per SIMD: a
+// streaming kernel that waits for its one batch of loads with a quarter of the chip's wave slots -- 305 us for the
+// 128^3 level of cfg 2, 2.7 TB/s).  Here the 16-byte words stay packed; a thread walks its 8 channels in four PAIRS
+// (unpack 2 x NW values, arg-max, norm backward, mask, re-pack into the word it came from), the coefficient rows of the
+// block's sample sit in LDS.  Same arithmetic, same order of operations per element: bit-identical to the generic kernel.
+template <int FZ, typename T>
+__global__ __launch_bounds__(256, 3) void k_maxpool_bwd16(const T* __restrict__ gy, int64_t gy_ld, const T* __restrict__ x, int64_t x_ld,
+                                                       const T* __restrict__ gskip, int64_t gskip_ld, int relu_mask,
+                                                       T* __restrict__ gx, int64_t gx_ld, int D, int H, int W, int C,
+                                                       const float* __restrict__ gcoef, int64_t gcoef_ld,
+                                                       const float* __restrict__ ycoef, unsigned* __restrict__ amax) {
+    static_assert(sizeof(T) == 2, "16-bit storage only");
+    constexpr int NW = FZ * 4;
+    extern __shared__ __attribute__((aligned(16))) float4 mp_coef[];   // [C] skip-norm rows, then [C] pooled-norm rows
+    const int Do = D / FZ, Ho = H / 2, Wo = W / 2;
+    const int cq = C / 8;
+    int row = blockIdx.x;
+    const int yo = row % Ho;
+    row /= Ho;
+    const int zo = row % Do;
+    const int n = row / Do;
+    if (gcoef)
+        for (int c = threadIdx.x; c < C; c += 256) mp_coef[c] = *reinterpret_cast<const float4*>(gcoef + (int64_t)n * gcoef_ld + c * 4);
+    if (ycoef)
+        for (int c = threadIdx.x; c < C; c += 256) mp_coef[C + c] = *reinterpret_cast<const float4*>(ycoef + ((int64_t)n * C + c) * 4);
+    if (gcoef || ycoef) __syncthreads();
+    float amx = 0.f;
+    for (int i = threadIdx.x; i < Wo * cq; i += 256) {
+        const int xo = i / cq, c0 = (i % cq) * 8;
+        unsigned tw[NW][4], ow[NW][4];
+        // the window's first voxel per thread, its other voxels at wave-uniform distances
+        const int64_t v0 = (((int64_t)n * D + zo * FZ) * H + yo * 2) * W + xo * 2;
+        const T* const xb = x + v0 * x_ld + c0;
+        const T* const sb = gskip ? gskip + v0 * gskip_ld + c0 : nullptr;
+        T* const ob = gx + v0 * gx_ld + c0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int64_t dv = ((int64_t)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1);
+            const act_u4 a = *reinterpret_cast<const act_u4*>(xb + dv * x_ld);
+            tw[k][0] = a.x, tw[k][1] = a.y, tw[k][2] = a.z, tw[k][3] = a.w;
+            act_u4 b = {0u, 0u, 0u, 0u};
+            if (gskip) b = *reinterpret_cast<const act_u4*>(sb + dv * gskip_ld);
+            ow[k][0] = b.x, ow[k][1] = b.y, ow[k][2] = b.z, ow[k][3] = b.w;
+        }
+        const int64_t vo = (((int64_t)n * Do + zo) * Ho + yo) * Wo + xo;
+        const act_u4 gq = *reinterpret_cast<const act_u4*>(gy + vo * gy_ld + c0);
+        const unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            float r[2][NW];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float t[NW];
+#pragma unroll
+                for (int k = 0; k < NW; ++k) t[k] = h ? act_hi<T>(tw[k][jp]) : act_lo<T>(tw[k][jp]);
+                float m = -INFINITY;
+                int am = 0;
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+                    if (t[k] > m || t[k] != t[k]) {
+                        m = t[k];
+                        am = k;
+                    }
+                float g = h ? act_hi<T>(gw[jp]) : act_lo<T>(gw[jp]);
+                const int c = c0 + jp * 2 + h;
+                if (ycoef) {
+                    const float4 ky = mp_coef[C + c];
+                    g = ky.x * g - ky.y - (m - ky.w) * ky.z;
+                }
+                float4 kg = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gcoef) kg = mp_coef[c];
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    float v = h ? act_hi<T>(ow[k][jp]) : act_lo<T>(ow[k][jp]);
+                    if (gcoef) v = kg.x * v - kg.y - (t[k] - kg.w) * kg.z;
+                    if (am == k) v += g;
+                    if (relu_mask && !(t[k] > 0.f)) v = 0.f;
+                    amx = __builtin_fmaxf(amx, __builtin_fabsf(v));
+                    r[h][k] = v;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NW; ++k) ow[k][jp] = act_pk<T>(r[0][k], r[1][k]);   // one rounding per stored value
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int64_t dv = ((int64_t)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1);
+            *reinterpret_cast<act_u4*>(ob + dv * gx_ld) = act_u4{ow[k][0], ow[k][1], ow[k][2], ow[k][3]};
+        }
+    }
+    if (amax) tem_amax_commit(amax, amx);
+}
+
 static int maxpool3d_bwd_impl(const void* gy, int64_t gy_ld, const void* x, int64_t x_ld, const void* gskip,
                               int64_t gskip_ld, int relu_mask, void* gx, int64_t gx_ld, int N, int D, int H, int W,
                               int C, int fz, int fy, int fx, const float* gcoef, int64_t gcoef_ld, const float* ycoef,
@@ -384,6 +478,21 @@ static int maxpool3d_bwd_impl(const void* gy, int64_t gy_ld, const void* x, int6
     TEM_REQUIRE(rows < (1ll << 31), "tem_maxpool3d_bwd: too many rows");
     const bool v4 = vec4_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}, st);
     if (vec8_ok(C, {gy, x, gskip, gx}, {gy_ld, x_ld, gskip ? gskip_ld : 0, gx_ld}, st) && tem_option(TEM_OPT_POOL_VEC8)) {
+        if (fy == 2 && fx == 2 && (fz == 1 || fz == 2) && C <= 2048 && tem_option(TEM_OPT_POOL_VEC8) >= 2) {
+            const size_t ldsb = (gcoef || ycoef) ? (size_t)2 * C * sizeof(float4) : 0;
+            TEM_ST16_SWITCH(st, T, {
+                if (fz == 2)
+                    hipLaunchKernelGGL((k_maxpool_bwd16<2, T>), dim3((unsigned)rows), dim3(256), ldsb, (hipStream_t)stream, (const T*)gy,
+                                       gy_ld, (const T*)x, x_ld, (const T*)gskip, gskip_ld, relu_mask, (T*)gx, gx_ld, D, H, W, C, gcoef,
+                                       gcoef_ld, ycoef, amax);
+                else
+                    hipLaunchKernelGGL((k_maxpool_bwd16<1, T>), dim3((unsigned)rows), dim3(256), ldsb, (hipStream_t)stream, (const T*)gy,
+                                       gy_ld, (const T*)x, x_ld, (const T*)gskip, gskip_ld, relu_mask, (T*)gx, gx_ld, D, H, W, C, gcoef,
+                                       gcoef_ld, ycoef, amax);
+            });
+            TEM_CHECK_LAUNCH("tem_maxpool3d_bwd");
+            return TEM_OK;
+        }
         TEM_ST16_SWITCH(st, T, hipLaunchKernelGGL((k_maxpool_bwd<8, T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
                                                   (const T*)gy, gy_ld, (const T*)x, x_ld, (const T*)gskip, gskip_ld, relu_mask, (T*)gx,
                                                   gx_ld, D, H, W, C, fz, fy, fx, gcoef, gcoef_ld, ycoef, amax));

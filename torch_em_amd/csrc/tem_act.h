@@ -88,6 +88,9 @@ template <typename T> __device__ __forceinline__ act_f2 act_ld2(const T* p) {
 }
 __device__ __forceinline__ void act_st2(float* p, act_f2 v) { *reinterpret_cast<act_f2*>(p) = v; }
 template <typename T> __device__ __forceinline__ void act_st2(T* p, act_f2 v) { *reinterpret_cast<unsigned*>(p) = act_pk<T>(v.x, v.y); }
+// ... streaming stores (tensors far beyond the caches that the next kernel reads from HBM anyway)
+__device__ __forceinline__ void act_st2_nt(float* p, act_f2 v) { __builtin_nontemporal_store(v, reinterpret_cast<act_f2*>(p)); }
+template <typename T> __device__ __forceinline__ void act_st2_nt(T* p, act_f2 v) { __builtin_nontemporal_store(act_pk<T>(v.x, v.y), reinterpret_cast<unsigned*>(p)); }
 
 // ---- four consecutive elements (16 / 8 bytes) ----
 __device__ __forceinline__ float4 act_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
