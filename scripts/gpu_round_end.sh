@@ -13,6 +13,14 @@ for d in rocprof pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq; do       # rocprofv3 nest
   done
 done
 python scripts/summarize_profiles.py $O $O/$tag 13 > $O/summarize.log 2>&1
+# every launch of the last step in order + the launches under 30 us (default arithmetic, then the fp16-storage mode)
+python scripts/step_trace.py $O/rocprof/bench_kernel_trace.csv > $O/${tag}_step_trace.txt 2>&1
+for m in amp amp_bf16; do
+  rm -rf /tmp/tr_$m
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_$m -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --precision $m --no-cpu-baseline --no-extras > $O/trace_$m.log 2>&1)
+  f=$(find /tmp/tr_$m -name "*_kernel_trace.csv" | head -1)
+  [ -n "$f" ] && python scripts/step_trace.py $f > $O/${tag}_step_trace_$m.txt 2>&1
+done
 find $O -name "*.csv" -size +2M -delete; find $O -name "*.db" -delete
 bash scripts/collect_stalls.sh $tag >> $O/collect.log 2>&1
 find $O -name "*.csv" -size +2M -delete

@@ -46,6 +46,12 @@ def durations(dirname):
 
 fetch, write, sq = pmc("pmc_FETCH_SIZE"), pmc("pmc_WRITE_SIZE"), pmc("pmc_sq")
 dur = durations("pmc_sq")
+# per-launch pairing of counters and durations of the SQ pass (same run: Dispatch_Id is the key)
+sq_ids = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(os.path.join(src, "pmc_sq", "bench_counter_collection.csv"))):
+    sq_ids[short(r["Kernel_Name"])][r["Counter_Name"]].append(r.get("Dispatch_Id"))
+dur_by_id = {r.get("Dispatch_Id"): float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+             for r in csv.DictReader(open(os.path.join(src, "pmc_sq", "bench_kernel_trace.csv")))}
 traffic = {}
 with open(dst + "_pmc_summary.txt", "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc <counters> (one pass per TCC counter group, as MI355X_MICROARCH.md prescribes)\n")
@@ -65,7 +71,13 @@ with open(dst + "_pmc_summary.txt", "w") as f:
         traffic[k] = byts
         # GRBM_GUI_ACTIVE also counts the dispatch ramp around a launch: the derived clock is meaningless (> 2.4 GHz) for
         # launches shorter than ~40 us, so it is only printed for longer ones
-        ghz = f"{cyc / d:5.2f}" if (d >= 200e3 and cyc / d <= 2.45) else "    -"   # launches < 200 us still showed > 2.4 GHz
+        # ... so: the clock of a kernel = GRBM_GUI_ACTIVE / 8 / duration over its launches of >= 200 us only, paired by
+        # Dispatch_Id (shorter launches still showed > 2.4 GHz; r4: a family whose AVERAGE is below 200 us --
+        # k_conv_wgrad_tr, 197 us -- got no cell although its big layers run 400 us)
+        long_c = [(c, dur_by_id[i]) for c, i in zip(sq[k].get("GRBM_GUI_ACTIVE", []), sq_ids[k].get("GRBM_GUI_ACTIVE", []))
+                  if dur_by_id.get(i, 0) >= 200e3]
+        g = (sum(c for c, _ in long_c) / 8) / sum(t for _, t in long_c) if long_c else 0.0
+        ghz = f"{g:5.2f}" if (long_c and g <= 2.45) else "    -"
         f.write(f"{k:80s} {len(dur[k]):8d} {d / 1e3:9.1f} {2 * fe / 1024:11.1f} {wr / 1024:9.1f} "
                 f"{byts / d:8.0f} {busy:9.3f} {ghz}\n")
 json.dump(traffic, open(dst + "_traffic_bytes_per_launch.json", "w"), indent=1)
