@@ -4,7 +4,7 @@
 tag=${1:-r04}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/$tag; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $O
 bash scripts/collect_profiles.sh $tag > $O/collect.log 2>&1
 for d in rocprof pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq; do       # rocprofv3 nests its outputs: bring them to the expected names
   for kind in kernel_stats kernel_trace counter_collection; do

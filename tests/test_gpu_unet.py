@@ -169,15 +169,15 @@ def test_unet3d_mfma_sizes_match_oracle(norm, dispatch_mix):
     _check_against_fp64(model, pred, loss, case)
 
 
-def test_exact_fp32_mode_groupnorm_first_norm_bias_gradient():
-    """The exact-fp32 build (TEM_PRECISION=fp32, not the default) on the GroupNorm case above.  Every gradient tensor meets the
-    standard bounds but ONE, pinned here with an explicit number instead of living in DESIGN.md only: the bias of the FIRST
-    norm, GroupNorm(1, 1) on the 1-channel input.  Its gradient is the sum of the first conv's data gradient gz over ALL
-    voxels, and behind the second norm's backward (whose output sums to zero per group) that sum cancels to boundary terms:
-    in float64 sum gz = -7.45e-3 against sum |gz| = 3.20 (24576 values, cancellation factor 430).  This mode lands 5.3e-3
-    from that (4e-5 absolute = 1.2e-5 of sum |gz|); the reference's fp32 CPU path 5.5e-5; the default arithmetic passes the
-    standard bound on the same case (test_unet3d_mfma_sizes_match_oracle).  Origin not isolated (round 5): a relative 1e-5
-    somewhere in the exact-fp32 chain norm backward -> fp32 patch data gradient that the cancellation amplifies."""
+def test_exact_fp32_mode_groupnorm_gradients_with_forced_decisions():
+    """The exact-fp32 build (TEM_PRECISION=fp32, not the default) on the GroupNorm case of test_unet3d_mfma_sizes_match_oracle.
+    Rounds 3-4 carried a "known deviation" of this mode: the bias gradient of the first norm 5e-3 from float64 (the fp32
+    reference path: 5e-5), explained as a cancelling sum.  The per-tensor table (round 5) says otherwise: EVERY encoder tensor
+    is 2-3e-3 off while base and decoder agree to 1e-6 -- the signature of one decision between them that the two arithmetics
+    take differently (a ReLU mask / pooling arg-max of a near-tie in the encoder), not of a summation.  So this test runs the
+    float64 oracle with the library's decisions forced (oracle.unet_ref.DecisionTap) and asks for the plain 1e-3 max-norm bound
+    on every tensor, the first norm's bias included."""
+    from oracle import loss_ref, unet_ref
     from torch_em_amd.loss import DiceLoss
     from torch_em_amd.model import UNet3d, engine
     torch.manual_seed(0)
@@ -185,15 +185,33 @@ def test_exact_fp32_mode_groupnorm_first_norm_bias_gradient():
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 1, 16, 24, 32, generator=g)
     y = (torch.rand(2, 2, 16, 24, 32, generator=g) > 0.5).float()
-    case = (model, [2, 2], x, y, "GroupNorm")
-    _oracle_case(*case)
+    sd = {k: v.detach().double().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
     model.to(DEV)
     with engine.precision_scope("fp32"):
+        force = _library_decisions(model, x)
         pred = model(x.to(DEV))
         loss = DiceLoss()(pred, y.to(DEV))
         loss.backward()
-    report = _check_against_fp64(model, pred, loss, case, known={"encoder.blocks.0.block.0.bias": 1e-2})
-    print("first-norm bias gradient, exact-fp32 mode: L2 vs float64 %.2e (fp32 reference path %.2e)" % report["encoder.blocks.0.block.0.bias"][:2])
+    worst = {}
+    for forced in (False, True):
+        for v in sd.values():
+            v.grad = None
+        with unet_ref.DecisionTap(force if forced else None):
+            pred64 = unet_ref.unet_forward(sd, x.double(), [2, 2], norm="GroupNorm")
+        loss64 = loss_ref.dice_loss(pred64, y.double())
+        loss64.backward()
+        gscale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+        for k, p in model.named_parameters():
+            ref = sd[k].grad
+            if float(ref.abs().max()) < 1e-4 * gscale:
+                continue
+            err = float((p.grad.double().cpu() - ref).abs().max() / ref.abs().max())
+            if err >= worst.get(forced, (0.0, ""))[0]:
+                worst[forced] = (err, k)
+            if forced:
+                assert err < TOL, (k, err)
+    print(f"exact-fp32 mode, GroupNorm: worst max-norm gradient error free {worst[False][0]:.2e} ({worst[False][1]}), "
+          f"with the library's decisions forced {worst[True][0]:.2e} ({worst[True][1]})")
 
 
 def test_unet3d_benchmark_widths_depth4_match_fp64_oracle(dispatch_mix):
