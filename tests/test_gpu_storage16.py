@@ -345,6 +345,59 @@ def test_model_step_with_16bit_storage_against_fp32_storage(mode, norm, monkeypa
     assert bool(torch.isfinite(g16).all())
 
 
+def _family_cases():
+    from torch_em_amd.model import AnisotropicUNet, UNet2d, UNet3d
+    return {
+        "anisotropic_1x3x3": (lambda: AnisotropicUNet(1, 3, [[1, 2, 2], [2, 2, 2]], initial_features=32, final_activation="Sigmoid",
+                                                      anisotropic_kernel=True), (2, 1, 8, 32, 32)),
+        "unet2d": (lambda: UNet2d(1, 2, depth=3, initial_features=32), (4, 1, 64, 64)),
+        "side_outputs": (lambda: UNet3d(1, 2, depth=2, initial_features=32, return_side_outputs=True), (1, 1, 16, 32, 32)),
+        "batchnorm": (lambda: UNet3d(1, 2, depth=2, initial_features=32, norm="BatchNorm"), (2, 1, 16, 16, 32)),
+        "no_norm_rgb": (lambda: UNet3d(3, 2, depth=2, initial_features=32, norm=None), (1, 3, 16, 32, 32)),
+        "narrow_4_features": (lambda: UNet3d(1, 2, depth=2, initial_features=4), (2, 1, 16, 16, 16)),   # no MFMA kernel at all
+        # factor 3 on 20 voxels: 6 after the pooling (floor), 18 after the upsampling -> the skip tensor is centre-cropped by 1 per side
+        "odd_size_cropped_skip": (lambda: AnisotropicUNet(1, 2, [[3, 3, 3]], initial_features=32), (1, 1, 20, 20, 20)),
+    }
+
+
+@pytest.mark.parametrize("mode", ["amp", "amp_bf16"])
+@pytest.mark.parametrize("case", ["anisotropic_1x3x3", "unet2d", "side_outputs", "batchnorm", "no_norm_rgb", "narrow_4_features",
+                                  "odd_size_cropped_skip"])
+def test_model_families_with_16bit_storage(case, mode, monkeypatch):
+    """Every model family / option of the drop-in runs a training step with 16-bit tensors and stays close to the same mode
+    with fp32 tensors: the kernels that have no 16-bit instantiation must be reached through a conversion, never crash or
+    silently read 16-bit data as fp32 (a wrong element type shows up as garbage far outside these bounds)."""
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import engine
+    make, shape = _family_cases()[case]
+    torch.manual_seed(5)
+    model = make().to(DEV)
+    if case == "odd_size_cropped_skip":
+        model.check_shape = False
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(*shape, generator=g).to(DEV)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        with engine.precision_scope(mode):
+            pred = model(x)
+            preds = pred if isinstance(pred, (list, tuple)) else [pred]
+            loss = sum(DiceLoss()(p, (torch.rand(p.shape, generator=torch.Generator().manual_seed(7)) > 0.5).float().to(DEV))
+                       for p in preds) * 1024.0
+            loss.backward()
+        grads = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]) / 1024.0
+        return preds[0].detach().clone(), grads
+    monkeypatch.setattr(engine, "_AMP_STORAGE16", True)
+    p16, g16 = step()
+    monkeypatch.setattr(engine, "_AMP_STORAGE16", False)
+    p32, g32 = step()
+    ep, eg = float((p16 - p32).norm() / p32.norm()), float((g16 - g32).norm() / g32.norm())
+    print(f"{case} {mode}: 16-bit vs fp32 tensors: pred {ep:.2e}, grads {eg:.2e}")
+    assert bool(torch.isfinite(p16).all()) and bool(torch.isfinite(g16).all())
+    ptol, gtol = (2e-2, 0.3) if mode == "amp" else (1e-1, 0.7)
+    assert ep < ptol and eg < gtol, (ep, eg)
+
+
 def test_default_mode_never_allocates_16bit_tensors():
     from torch_em_amd.model import engine
     for mode in ("fp32", "mixed", "split", "split16", "bf16x3"):
