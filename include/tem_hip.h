@@ -291,19 +291,27 @@ typedef struct TemByproducts {
 /* tem_conv3d_fwd / _fwd_gscaled / _fwd_refnorm in one entry point with every variant as an argument:
  *   in_amax  != NULL: tem_conv3d_fwd_gscaled (use_mfma must be 4; scale / shift / bias NULL, act none);
  *   ref_coef != NULL: tem_conv3d_fwd_refnorm (ref required; scale / shift / bias NULL, act none);
- *   bp       != NULL: by-products, see above (NULL: none). */
+ *   stat_part != NULL: tem_conv3d_fwd_stats (stat_blocks = tem_conv3d_fwd_stat_blocks() of the launch);
+ *   bp       != NULL: by-products, see above (NULL: none);
+ *   x_cs / y_cs != 0: CHUNK strides in elements (16-bit tensors, use_mfma 5 / 7, launches tem_conv3d_fwd_kernel() reports as
+ *                     3): the 32-channel chunk k of a voxel lives at x + k * x_cs + voxel * x_ld (y likewise) instead of
+ *                     x + k * 32 -- the two halves of a 2 x 32-channel concat as two DENSE planes, so that the kernels which
+ *                     read one half move whole 128-byte lines (DESIGN.md 6.R5 "half lines").  A launch that cannot honour
+ *                     them returns TEM_EINVAL before anything is enqueued. */
 int tem_conv3d_fwd_ex(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w_packed,
                       const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws, int64_t ws_bytes,
                       int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act, int use_mfma,
-                      const unsigned* in_amax, const float* ref_coef, TemByproducts* bp, tem_stream_t stream);
+                      const unsigned* in_amax, const float* ref_coef, float* stat_part, int64_t stat_blocks, int64_t x_cs,
+                      int64_t y_cs, TemByproducts* bp, tem_stream_t stream);
 /* tem_conv3d_wgrad (sd_layout = 1) / _wgrad_sums / _wgrad_gmax / _wgrad_gscaled in one entry point:
  *   norm_sums  != NULL: tem_conv3d_wgrad_sums (w and db required; gamma / beta of the norm or NULL);
  *   g_amax_out != NULL: tem_conv3d_wgrad_gmax;   g_amax_in != NULL: tem_conv3d_wgrad_gscaled (use_mfma must be 8);
- *   bp         != NULL: TEM_BP_NORM_COEF (needs norm_sums). */
+ *   bp         != NULL: TEM_BP_NORM_COEF (needs norm_sums);
+ *   x_cs       != 0:    chunk stride of x as in tem_conv3d_fwd_ex (16-bit tensors on the z-sliding 3x3x3 kernel only). */
 int tem_conv3d_wgrad_ex(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* g, int64_t g_ld,
                         const float* w, const float* gamma, const float* beta, float* dw, float* db, float* norm_sums,
                         const unsigned* g_amax_in, unsigned* g_amax_out, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
-                        int Cin, int Cout, int kd, int kh, int kw, int use_mfma, TemByproducts* bp, tem_stream_t stream);
+                        int Cin, int Cout, int kd, int kh, int kw, int use_mfma, int64_t x_cs, TemByproducts* bp, tem_stream_t stream);
 int tem_norm_bwd_from_partials(const float* gy, int64_t gy_ld, const float* x, int64_t x_ld, int N, int64_t V, int C, int G,
                                const float* gamma, const float* mean, const float* rstd, int relu_mask, float* gx, int64_t gx_ld,
                                float* dgamma, float* dbeta, const float* part, int64_t nblk, float* coef, void* ws,

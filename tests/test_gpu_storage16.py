@@ -316,7 +316,7 @@ def _step(model, x, y, mode):
         pred = model(x)
         loss = DiceLoss()(pred, y) * 16384.0
         loss.backward()
-    return pred.detach().clone(), float(loss) / 16384.0, torch.cat([p.grad.flatten() / 16384.0 for p in model.parameters()])
+    return pred.detach().clone(), float(loss.detach()) / 16384.0, torch.cat([p.grad.flatten() / 16384.0 for p in model.parameters()])
 
 
 @pytest.mark.parametrize("mode", ["amp", "amp_bf16"])
@@ -396,6 +396,91 @@ def test_model_families_with_16bit_storage(case, mode, monkeypatch):
     assert bool(torch.isfinite(p16).all()) and bool(torch.isfinite(g16).all())
     ptol, gtol = (2e-2, 0.3) if mode == "amp" else (1e-1, 0.7)
     assert ep < ptol and eg < gtol, (ep, eg)
+
+
+def _planar_of(t):
+    """interleaved [N, D, H, W, 64] 16-bit tensor -> ops.Planar holding the same values"""
+    from torch_em_amd import ops
+    pl = ops.Planar.empty(*t.shape[:4], t.device, t.dtype)
+    pl.halves[0].copy_(t[..., :32])
+    pl.halves[1].copy_(t[..., 32:])
+    return pl
+
+
+@pytest.mark.parametrize("dt,mode", TYPES)
+def test_planar_concat_halves_through_the_chunk_stride(dt, mode):
+    """ops.Planar (x_cs / y_cs of tem_conv3d_fwd_ex / _wgrad_ex): the 2 x 32 channels of a concat buffer as two dense planes.
+    Same values at other addresses: forward (+ norm + statistics), data gradient into a planar tensor, weight gradient (+ norm
+    sums) must equal the launches on the interleaved tensor BIT FOR BIT; a launch that cannot honour the stride raises."""
+    from torch_em_amd import ops
+    g = torch.Generator().manual_seed(21)
+    N, D, H, W = 2, 32, 64, 64
+    k = (3, 3, 3)
+    x = to5(torch.randn(N, 64, D, H, W, generator=g)).to(dt)
+    xp = _planar_of(x)
+    assert xp.cs == N * D * H * W * 32 and tuple(xp.shape) == (N, D, H, W, 64)
+    w = (torch.randn(32, 64, *k, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(32, generator=g).to(DEV)
+    mean, rstd, scale, shift = ops.norm_stats(x, 64)
+    # forward, norm fused, statistics rows
+    assert ops.conv_fwd_family(xp, k, 64, 32, mode) == 3
+    wp = ops.pack_weights(w, transpose=False, mfma=mode)
+    y_a, y_b = (torch.empty((N, D, H, W, 32), device=DEV, dtype=dt) for _ in range(2))
+    pa = ops.conv_fwd(x, wp, bias, y_a, k, 64, 32, scale=scale, shift=shift, act="relu", mfma=mode, want_stats=True)
+    pb = ops.conv_fwd(xp, wp, bias, y_b, k, 64, 32, scale=scale, shift=shift, act="relu", mfma=mode, want_stats=True)
+    assert torch.equal(y_a, y_b) and pa is not None and pb is not None and torch.equal(pa[0], pb[0])
+    # data gradient: 32 -> 64 channels written into a planar tensor
+    gy = to5(torch.randn(N, 32, D, H, W, generator=g) * 1e-2).to(dt)
+    wt = ops.pack_weights(w, transpose=True, mfma=mode)
+    gx_a = torch.empty_like(x)
+    gx_p = xp.empty_like()
+    ops.conv_fwd(gy, wt, None, gx_a, k, 32, 64, mfma=mode)
+    ops.conv_fwd(gy, wt, None, gx_p, k, 32, 64, mfma=mode)
+    assert torch.equal(gx_a[..., :32], gx_p.halves[0]) and torch.equal(gx_a[..., 32:], gx_p.halves[1])
+    # weight gradient with the norm sums, and the plain one
+    assert ops.conv_wgrad_gscaled_ok(xp, k, 64, 32)
+    for sums_from in ((w, None, None), None):
+        if sums_from is not None and not ops.conv_wgrad_sums_ok(x, k, 64, 32, mode):
+            continue
+        dwa, dba = torch.zeros(w.numel(), device=DEV), torch.zeros(32, device=DEV)
+        dwb, dbb = torch.zeros(w.numel(), device=DEV), torch.zeros(32, device=DEV)
+        sa = ops.conv_wgrad(x, gy, k, 64, 32, dwa, dba, scale=scale, shift=shift, mfma=mode, sums_from=sums_from)
+        sb = ops.conv_wgrad(xp, gy, k, 64, 32, dwb, dbb, scale=scale, shift=shift, mfma=mode, sums_from=sums_from)
+        assert torch.equal(dwa, dwb) and torch.equal(dba, dbb)
+        if sums_from is not None:
+            assert torch.equal(sa, sb)
+            assert torch.equal(ops.norm_bwd_coef(gx_a, x, 64, None, mean, rstd, sums=sa), ops.norm_bwd_coef(gx_p, xp, 64, None, mean, rstd, sums=sb))
+    # without sums the reduction runs per half
+    ca, cb = ops.norm_bwd_coef(gx_a, x, 32, None, *ops.norm_stats(x, 32)[:2]), ops.norm_bwd_coef(gx_p, xp, 32, None, *ops.norm_stats(x, 32)[:2])
+    assert torch.allclose(ca, cb, rtol=1e-4, atol=1e-6)
+    # a launch that cannot take the stride refuses it (too few units for the z-reuse kernel here), nothing is written
+    small = ops.Planar.empty(1, 8, 8, 8, DEV, dt)
+    with pytest.raises(Exception):
+        ops.conv_fwd(small, wp, bias, torch.empty((1, 8, 8, 8, 32), device=DEV, dtype=dt), k, 64, 32, mfma=mode)
+    with pytest.raises(Exception):   # and fp32-class modes never see one
+        ops.conv_fwd(xp, ops.pack_weights(w, transpose=False, mfma=2), bias, y_b, k, 64, 32, mfma=2)
+
+
+@pytest.mark.parametrize("mode", ["amp", "amp_bf16"])
+@pytest.mark.parametrize("norm", ["InstanceNorm", "GroupNorm"])
+def test_model_step_is_bit_identical_with_planar_concat(mode, norm, monkeypatch):
+    """engine: the 2 x 32-channel concat of the top level as two dense planes (16-bit storage) changes addresses only"""
+    from torch_em_amd import ops
+    from torch_em_amd.model import UNet3d, engine
+    torch.manual_seed(3)
+    model = UNet3d(1, 2, depth=2, initial_features=32, norm=norm).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, 32, 64, 64, generator=g).to(DEV)
+    y = (torch.rand(2, 2, 32, 64, 64, generator=g) > 0.5).float().to(DEV)
+    monkeypatch.setattr(engine, "_PLANAR_CONCAT", True)
+    with engine.precision_scope(mode):
+        _, st = engine._forward_impl(model, x, keep=True)
+    assert isinstance(st["levels"][0]["cat"], ops.Planar) and not isinstance(st["levels"][1]["cat"], ops.Planar)
+    del st
+    pa, la, ga = _step(model, x, y, mode)
+    monkeypatch.setattr(engine, "_PLANAR_CONCAT", False)
+    pb, lb, gb = _step(model, x, y, mode)
+    assert torch.equal(pa, pb) and la == lb and torch.equal(ga, gb)
 
 
 def test_default_mode_never_allocates_16bit_tensors():

@@ -56,9 +56,9 @@ SIGNATURES = {
                                            c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     # (..., in_amax, ref_coef, TemByproducts*, stream) / (..., g_amax_in, g_amax_out, ws, ws_bytes, dims, use_mfma, TemByproducts*, stream)
     "tem_conv3d_fwd_ex": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64] + [c_int] * 11
-                          + [c_vp, c_vp, c_vp, c_vp]),
+                          + [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "tem_conv3d_wgrad_ex": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]
-                            + [c_int] * 10 + [c_vp, c_vp]),
+                            + [c_int] * 10 + [c_i64, c_vp, c_vp]),
     "tem_conv3d_fwd_gscaled": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp]),
     "tem_conv3d_fwd_refnorm": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp]),
     "tem_norm_ws": (c_i64, [c_int, c_i64, c_int]),

@@ -9,6 +9,7 @@ static thread_local char g_err[512] = "";
 
 // storage types of the call in flight on this thread (tem_act.h): set and restored by the entry point itself
 thread_local TemCallSt tem_call_st = {0, 0};
+thread_local TemCallCs tem_call_cs = {0, 0};
 
 void tem_set_error(const char* fmt, ...) {
     va_list ap;

@@ -264,7 +264,8 @@ static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, con
                            int64_t ref_ld, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout,
                            int kd, int kh, int kw, int act, int use_mfma, float* stat, tem_stream_t stream) {
     TEM_REQUIRE(x && w_packed && y, "tem_conv3d_fwd: null pointer");
-    TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= Cin && y_ld >= Cout,
+    TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= (tem_call_cs.x ? 32 : Cin) &&
+                    y_ld >= (tem_call_cs.y ? 32 : Cout),
                 "tem_conv3d_fwd: bad shape");
     TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
                 "tem_conv3d_fwd: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
@@ -276,6 +277,7 @@ static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, con
                 "tem_conv3d_fwd: unsupported storage types (x %d, y %d)", stx, sty);
     TEM_REQUIRE(!(stx || sty) || use_mfma != 1, "tem_conv3d_fwd: the exact-fp32 MFMA kernels take fp32 tensors only");
     hipStream_t s = (hipStream_t)stream;
+    TEM_REQUIRE(!(tem_call_cs.x || tem_call_cs.y) || use_mfma == 5 || use_mfma == 7, "tem_conv3d_fwd_ex: chunk strides need use_mfma 5 / 7");
     if (use_mfma >= 2 && use_mfma <= 7) {
         int rc = tem_conv_fwd_bf16x3(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
                                      W, Cin, Cout, kd, kh, kw, act, use_mfma, stat, s);
@@ -554,7 +556,7 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
                              const float* w_sd, const float* gamma, const float* beta, float* norm_sums,
                              const float* gnx, int64_t gnx_ld, const float* gcoef, tem_stream_t stream) {
     TEM_REQUIRE(x && g && dw && ws, "tem_conv3d_wgrad: null pointer");
-    TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= Cin && g_ld >= Cout,
+    TEM_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && x_ld >= (tem_call_cs.x ? 32 : Cin) && g_ld >= Cout,
                 "tem_conv3d_wgrad: bad shape");
     TEM_REQUIRE((kd == 1 || kd == 3) && (kh == 1 || kh == 3) && (kw == 1 || kw == 3),
                 "tem_conv3d_wgrad: kernel size (%d,%d,%d) not supported (1 or 3 per axis)", kd, kh, kw);
@@ -575,6 +577,7 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
     float* dbpart = (float*)ws;
     float* rest = dbpart + tem_align_up(p.db_floats, 64);
     TEM_REQUIRE(!gcoef || !use_mfma, "tem_conv3d_wgrad_gnorm: use_mfma must be 0");
+    TEM_REQUIRE(!tem_call_cs.x || use_mfma == 5 || use_mfma == 7, "tem_conv3d_wgrad_ex: a chunk stride needs use_mfma 5 / 7");
     if (use_mfma == 2 || use_mfma == 5 || use_mfma == 7 || use_mfma == 8) {
         // 5: single fp16 product in the z-sliding kernel (autocast-equivalent); the other shapes keep bf16x3
         // 8: fp16 2x1 (tem_conv3d_wgrad_gscaled; z-sliding kernel only)
@@ -827,9 +830,13 @@ extern "C" int tem_conv3d_wgrad_sums(const float* x, int64_t x_ld, const float* 
 extern "C" int tem_conv3d_fwd_ex(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* w_packed,
                                  const float* bias, float* y, int64_t y_ld, const float* ref, int64_t ref_ld, void* ws,
                                  int64_t ws_bytes, int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int act,
-                                 int use_mfma, const unsigned* in_amax, const float* ref_coef, TemByproducts* bp,
-                                 tem_stream_t stream) {
+                                 int use_mfma, const unsigned* in_amax, const float* ref_coef, float* stat_part,
+                                 int64_t stat_blocks, int64_t x_cs, int64_t y_cs, TemByproducts* bp, tem_stream_t stream) {
+    TEM_REQUIRE(!stat_part || (!in_amax && !ref_coef && !bp), "tem_conv3d_fwd_ex: stat_part excludes in_amax / ref_coef / by-products");
     TEM_REQUIRE(!(in_amax && ref_coef), "tem_conv3d_fwd_ex: in_amax and ref_coef exclude each other");
+    TEM_REQUIRE(x_cs >= 0 && y_cs >= 0 && (!(x_cs || y_cs) || (!in_amax && !ref_coef && ((use_mfma & 0xff) == 5 || (use_mfma & 0xff) == 7))),
+                "tem_conv3d_fwd_ex: chunk strides go with the one-term modes on 16-bit tensors (use_mfma 5 / 7), no in_amax / ref_coef");
+    TemCsScope csc(x_cs, y_cs);
     TEM_REQUIRE(!bp || (!bp->coef && (!bp->sums_part || (bp->sums_x && bp->sums_mean && bp->sums_rstd && bp->sums_G > 0 && bp->sums_nblk > 0))),
                 "tem_conv3d_fwd_ex: bad by-product request (TEM_BP_NORM_COEF belongs to tem_conv3d_wgrad_ex; TEM_BP_NORM_SUMS needs "
                 "sums_x / sums_mean / sums_rstd / sums_G / sums_nblk)");
@@ -845,6 +852,9 @@ extern "C" int tem_conv3d_fwd_ex(const float* x, int64_t x_ld, const float* scal
         return tem_conv3d_fwd_refnorm(x, x_ld, w_packed, y, y_ld, ref, ref_ld, ref_coef, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh,
                                       kw, use_mfma, stream);
     }
+    if (stat_part)
+        return tem_conv3d_fwd_stats(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin, Cout,
+                                    kd, kh, kw, act, use_mfma, stat_part, stat_blocks, stream);
     return tem_conv3d_fwd(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin, Cout, kd, kh,
                           kw, act, use_mfma, stream);
 }
@@ -853,8 +863,11 @@ extern "C" int tem_conv3d_wgrad_ex(const float* x, int64_t x_ld, const float* sc
                                    int64_t g_ld, const float* w, const float* gamma, const float* beta, float* dw, float* db,
                                    float* norm_sums, const unsigned* g_amax_in, unsigned* g_amax_out, void* ws, int64_t ws_bytes,
                                    int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma,
-                                   TemByproducts* bp, tem_stream_t stream) {
+                                   int64_t x_cs, TemByproducts* bp, tem_stream_t stream) {
     TEM_REQUIRE(!(g_amax_in && g_amax_out), "tem_conv3d_wgrad_ex: g_amax_in and g_amax_out exclude each other");
+    TEM_REQUIRE(x_cs >= 0 && (!x_cs || (!g_amax_in && !g_amax_out && ((use_mfma & 0xff) == 5 || (use_mfma & 0xff) == 7))),
+                "tem_conv3d_wgrad_ex: a chunk stride goes with the one-term modes on 16-bit tensors (use_mfma 5 / 7)");
+    TemCsScope csc(x_cs, 0);
     TEM_REQUIRE(!bp || (!bp->out_amax && !bp->sums_part && (!bp->coef || (norm_sums && bp->coef_mean && bp->coef_rstd && bp->coef_G > 0))),
                 "tem_conv3d_wgrad_ex: bad by-product request (only TEM_BP_NORM_COEF, which needs norm_sums, coef_mean, coef_rstd, coef_G)");
     TemBpScope bsc(bp);

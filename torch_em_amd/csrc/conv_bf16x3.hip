@@ -1838,6 +1838,7 @@ int tem_conv_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd
     const int enable = (int)tem_option(TEM_OPT_WGRAD_SUMS);
     if (!enable || Cin % 32 || Cout % 32) return 0;
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
+    TEM_REQUIRE(!tem_call_cs.x || z.use, "tem_conv3d_wgrad_ex: a chunk stride (x_cs) needs the z-sliding kernel (3x3x3, D >= 8)");
     const int cq = Cout / 4;
     // four small launches replace one pass over gz and x: only worth it where that pass is long (>= 128 MB tensors by default)
     const int64_t min_bytes = (int64_t)tem_option(TEM_OPT_WGRAD_SUMS_MIN_MB) << 20;
@@ -1965,6 +1966,8 @@ int tem_conv_wgrad_bf16x3(const float* x, int64_t x_ld, const float* scale, cons
             else launch(k0, lb);
         };
         TEM_REQUIRE(!st || z.tr, "tem_conv3d_wgrad: 16-bit storage needs the transposing z-sliding kernel (option wgrad_zs = 3)");
+        TEM_REQUIRE(!tem_call_cs.x || (st && z.tr && tem_call_cs.x % 8 == 0),
+                    "tem_conv3d_wgrad_ex: a chunk stride (x_cs) needs 16-bit tensors on the transposing z-sliding kernel, x_cs %% 8 == 0");
         if (z.tr)
             tem_conv_wgrad_tr_launch(h16, nblk, x, x_ld, scale, shift, g, g_ld, zpart, zdb, N, D, H, W, Cin, Cout, z.T, z.nY, z.nX,
                                      z.zsegs, z.Ss, z.ncz, gmax, g_amax, s);

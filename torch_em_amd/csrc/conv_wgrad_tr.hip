@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                                                           float* __restrict__ dbpart, int N, int D, int H, int W,
                                                           int Cin, int Cout, int T, int nY, int nX, int zsegs,
                                                           int S, int ncz, unsigned* __restrict__ gmax,
-                                                          const unsigned* __restrict__ g_amax) {
+                                                          const unsigned* __restrict__ g_amax, int64_t x_cs) {
     constexpr int NT = 27, NA = 7;
     constexpr int NX = (ARITH == 0 || ARITH == 3) ? 2 : 1;   // terms of x^
     constexpr int NG = (ARITH == 0) ? 2 : 1;                 // terms of g
@@ -401,7 +401,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                 sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + oct * 8);
                 sf5 = *reinterpret_cast<const float4*>(shift + (int64_t)n * Cin + cit * 32 + oct * 8 + 4);
             }
-            const TS* const xn = x + (int64_t)n * D * H * W * x_ld;
+            // (a chunk stride x_cs != 0 puts the 32-channel tile cit at x + cit * x_cs: planar concat halves, tem_act.h;
+            //  the in-plane offsets below keep their cit * 32)
+            const TS* const xn = x + (int64_t)n * D * H * W * x_ld + (x_cs ? (int64_t)cit * (x_cs - 32) : 0);
             const TS* const gn = g + (int64_t)n * D * H * W * g_ld;
             const int64_t xplane = (int64_t)H * W * x_ld, gplane = (int64_t)H * W * g_ld;
             constexpr unsigned OOB = 0x80000000u;   // >= num_records of tr_rsrc: the load returns zeros
@@ -696,7 +698,7 @@ void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_
             sized.insert(key);
         }
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lb, s, x, x_ld, scale, shift, g, g_ld, zpart, zdb, N, D, H, W, Cin, Cout,
-                           T, nY, nX, zsegs, Ss, ncz, gmax, g_amax);
+                           T, nY, nX, zsegs, Ss, ncz, gmax, g_amax, (int64_t)0);
     };
     constexpr size_t XT = TR_XT_OF(TR_REC16), GT = TR_GT_OF(TR_REC16);
     auto launch16 = [&](auto kern, size_t lb, auto tag) {   // 16-bit x and g (the caller checked that the mode matches the type)
@@ -708,7 +710,8 @@ void tem_conv_wgrad_tr_launch(int h16, unsigned nblk, const float* x, int64_t x_
             sized.insert(key);
         }
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lb, s, reinterpret_cast<const TS*>(x), x_ld, scale, shift,
-                           reinterpret_cast<const TS*>(g), g_ld, zpart, zdb, N, D, H, W, Cin, Cout, T, nY, nX, zsegs, Ss, ncz, gmax, g_amax);
+                           reinterpret_cast<const TS*>(g), g_ld, zpart, zdb, N, D, H, W, Cin, Cout, T, nY, nX, zsegs, Ss, ncz, gmax, g_amax,
+                           tem_call_cs.x);
     };
     if (tem_call_st.x == 1) launch16(&k_conv_wgrad_tr<1, tem_f16>, XT + GT + 4096, tem_f16{});
     else if (tem_call_st.x == 2) launch16(&k_conv_wgrad_tr<2, tem_bf16>, XT + GT + 4096, tem_bf16{});

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const uint4* __restrict__ wp, const float* __restrict__ bias, std::conditional_t<KSPLIT, float, T>* __restrict__ y, int64_t y_ld,
     const T* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
     int nY, int nX, float* __restrict__ stat, int nunits, const unsigned* __restrict__ in_amax, int ks, int blk,
-    unsigned* __restrict__ out_amax) {
+    unsigned* __restrict__ out_amax, int64_t x_cs, int64_t y_cs) {
     static_assert(!KSPLIT || MODE == 0, "split-K units write raw partial sums");
     constexpr bool AMAX = MODE == 2 || MODE == 3;   // data gradients: max |y| as a by-product (TEM_BP_OUT_AMAX)
     float amx = 0.f;
@@ -386,9 +386,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                     sc4 = make_float4(psc, psc, psc, psc);
                 }
                 // the halo origin may lie outside the tensor for border patches (only in-range voxels are dereferenced)
-                const T* xb = x + ((((int64_t)cu.n * D + (cu.z0 - 1)) * H + (cu.y0 - 1)) * W + (cu.x0 - 1)) * x_ld +
-                              (cu.ksl * nch + ci) * CK;
-                rx = zr_rsrc((TEM_ZR_ABL & 64) ? x + (cu.ksl * nch + ci) * CK : xb);   // timing experiment: every unit reads the halo at the origin (L2 hits)
+                // (16-bit storage: a chunk stride x_cs != 0 puts chunk k at x + k * x_cs -- planar concat halves, tem_act.h)
+                const int64_t xch = (T16 && x_cs) ? (int64_t)(cu.ksl * nch + ci) * x_cs : (int64_t)((cu.ksl * nch + ci) * CK);
+                const T* xb = x + ((((int64_t)cu.n * D + (cu.z0 - 1)) * H + (cu.y0 - 1)) * W + (cu.x0 - 1)) * x_ld + xch;
+                rx = zr_rsrc((TEM_ZR_ABL & 64) ? x + xch : xb);   // timing experiment: every unit reads the halo at the origin (L2 hits)
                 interior = (cu.z0 >= 1) & (cu.z0 + HZ - 1 <= D) & (cu.y0 >= 1) & (cu.y0 + HY - 1 <= H) & (cu.x0 >= 1) &
                            (cu.x0 + HX - 1 <= W);
                 if (TEM_ZR_ABL & 32) interior = true;   // timing experiment: border code paths compiled out (wrong at the faces)
@@ -438,7 +439,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
             ZR_STAMP(1);
             // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
             if (epi_pending) {
-                const __amdgpu_buffer_rsrc_t ry = zr_rsrc(y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld + eu.cot * 32 +
+                const __amdgpu_buffer_rsrc_t ry = zr_rsrc(y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld +
+                                                          ((Y16 && y_cs) ? (int64_t)eu.cot * y_cs : (int64_t)(eu.cot * 32)) +
                                                           (KSPLIT ? (int64_t)eu.ksl * ((int64_t)N * D * H * W * y_ld) : 0));
                 constexpr bool has_ref = MODE == 2 || MODE == 3;
                 const __amdgpu_buffer_rsrc_t rr_ = zr_rsrc(has_ref ? (const void*)(ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld + eu.cot * 32) : (const void*)y);
@@ -1042,7 +1044,7 @@ static void zr_launch(const ZrGeom& g, const float* x_, int64_t x_ld, const floa
     unsigned* const out_amax = (MODE == 2 || MODE == 3) ? tem_take_output_amax() : nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp),
                        bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits, in_amax, ks,
-                       zr_tile_blocks(g), out_amax);
+                       zr_tile_blocks(g), out_amax, (int64_t)(sizeof(T) == 2 ? tem_call_cs.x : 0), (int64_t)(sizeof(T) == 2 && !KSPLIT ? tem_call_cs.y : 0));
 }
 
 // Split-K launch for shapes zr_geometry() declines only because they have too few (tile, column tile) units: the input
@@ -1151,12 +1153,18 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
     int64_t max_ld = x_ld > y_ld ? x_ld : y_ld;
     if (ref && ref_ld > max_ld) max_ld = ref_ld;
     const ZrGeom g = zr_geometry(N, D, H, W, Cin, Cout, kd, kh, kw, nsplit, max_ld);
+    const bool strided = tem_call_cs.x != 0 || tem_call_cs.y != 0;
+    if (strided && (!g.ok || !tem_call_st.x || ref || (tem_call_cs.x && Cin % 32) || (tem_call_cs.x % 8) || (tem_call_cs.y % 8))) {
+        tem_set_error("tem_conv3d_fwd_ex: chunk strides (x_cs / y_cs) need 16-bit tensors on the z-reuse kernel (tem_conv3d_fwd_kernel() "
+                      "== 3), no ref, strides %% 8 == 0");
+        return -1;
+    }
     if (!g.ok) return 0;
     if ((y_ld % 4) || ((uintptr_t)y % 16) || (ref && ((ref_ld % 4) || ((uintptr_t)ref % 16))) || (stat && ref) ||
         (bias && ((uintptr_t)bias % 16)) || act == TEM_ACT_SIGMOID) {
-        if (stat) {
-            tem_set_error("tem_conv3d_fwd_stats: statistics were sized for the z-reuse kernel but this launch cannot take it "
-                          "(y / ref / bias need 16-byte alignment and ld %% 4 == 0, no ref, no sigmoid)");
+        if (stat || strided) {
+            tem_set_error("tem_conv3d_fwd_stats / _ex: statistics (or chunk strides) were sized for the z-reuse kernel but this launch "
+                          "cannot take it (y / ref / bias need 16-byte alignment and ld %% 4 == 0, no ref, no sigmoid)");
             return -1;
         }
         return 0;

@@ -32,6 +32,21 @@ struct TemStScope {
     ~TemStScope() { tem_call_st = prev; }
 };
 
+// Channel-CHUNK strides of the call in flight (tem_conv3d_fwd_ex / tem_conv3d_wgrad_ex: x_cs / y_cs, in elements; 0 = the
+// channels of a voxel are contiguous).  With a stride the 32-channel chunk k of a voxel lives at base + k * stride + voxel * ld:
+// the two halves of a 2 x 32-channel concat as two DENSE planes, so that a 16-bit half is a whole 128-byte line per two
+// voxels instead of half of every line (DESIGN.md 6.R5 "half lines").  Only the z-reuse forward / data-gradient kernel and the
+// transposing z-sliding weight gradient on 16-bit tensors take them; every other launch site refuses a call that carries one.
+struct TemCallCs {
+    int64_t x, y;
+};
+extern thread_local TemCallCs tem_call_cs;
+struct TemCsScope {
+    TemCallCs prev;
+    TemCsScope(int64_t x_cs, int64_t y_cs) : prev(tem_call_cs) { tem_call_cs = TemCallCs{x_cs, y_cs}; }
+    ~TemCsScope() { tem_call_cs = prev; }
+};
+
 // run `...` with T bound to the element type of storage id `st`
 #define TEM_ST_SWITCH(st, T, ...)                                   \
     do {                                                            \

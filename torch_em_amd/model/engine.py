@@ -586,6 +586,48 @@ def _update_running(n, mean, var_biased, count):
         n.running_var.mul_(1.0 - m).add_(unbiased.mean(0), alpha=m)
 
 
+# 16-bit storage: the concat buffer of a level with 2 x 32 channels as two dense planes (ops.Planar) -- a 32-channel slice of
+# an interleaved 16-bit buffer is 64 bytes of every 128-byte line, and the kernels that read one half (max-pool forward /
+# backward, upsample backward) pay for the whole line (profiles/r05_halfline.txt).  TEM_PLANAR_CONCAT=0: interleaved as in fp32.
+_PLANAR_CONCAT = os.environ.get("TEM_PLANAR_CONCAT", "1") != "0"
+
+
+def _planar_concat_ok(adt, c_up, enc_blk, dec_blk, shape, dev, floor) -> bool:
+    if not _PLANAR_CONCAT or adt == torch.float32 or c_up != 32 or enc_blk.out_channels != 32 or floor or _FORCE_GENERIC or \
+            _OVERLAP_WGRAD or not _DEFER_CONCAT_NORM:
+        return False
+    c1 = dec_blk.conv_specs()[0]
+    n = c1.norm
+    if c1.k != (3, 3, 3) or c1.cin != 64 or c1.cout % 32 or (n is not None and (_is_batchnorm(n) or not _norm_is_live(n))):
+        return False
+    N, D, H, W = shape
+    ent = c1.packed()
+    x64, g = ops.Probe(N, D, H, W, 64, adt), ops.Probe(N, D, H, W, c1.cout, adt)
+    return ops.conv_fwd_family(x64, c1.k, 64, c1.cout, ent["fwd_mfma"]) == 3 and \
+        ops.conv_fwd_family(g, c1.k, c1.cout, 64, ent["dgrad_mfma"]) == 3 and ops.conv_wgrad_gscaled_ok(x64, c1.k, 64, c1.cout)
+
+
+def _half(t, c_up, i):
+    """channels [:c_up] (i = 0: the upsampled half) or [c_up:] (i = 1: the skip half) of a concat buffer"""
+    if isinstance(t, ops.Planar):
+        return t.halves[i]
+    return t[..., :c_up] if i == 0 else t[..., c_up:]
+
+
+def _like(t):
+    return t.empty_like() if isinstance(t, ops.Planar) else torch.empty_like(t)
+
+
+def _planar_stats(x, groups, gamma, beta, eps):
+    """ops.norm_stats of a planar concat without first-stage rows from its producers: each dense half on its own"""
+    cg = 64 // groups
+    if 32 % cg:
+        raise ValueError("a norm group straddles the halves of a planar concat buffer")
+    sl = lambda t, i: None if t is None else t[i * 32:(i + 1) * 32]  # noqa: E731
+    parts = [ops.norm_stats(x.halves[i], 32 // cg, sl(gamma, i), sl(beta, i), eps) for i in (0, 1)]
+    return tuple(torch.cat([parts[0][j], parts[1][j]], dim=1) for j in range(4))
+
+
 def _stats(spec: ConvSpec, x, partials=None, partials2=None):
     """Statistics of the norm in front of a conv -> (mean, rstd, scale[N,C], shift[N,C], mode).
     partials: (part, nblk) from the producing conv's epilogue (ops.conv_fwd(want_stats=True)) or None.
@@ -622,6 +664,8 @@ def _stats(spec: ConvSpec, x, partials=None, partials2=None):
         mean, rstd, scale, shift = ops.norm_stats_from_partials2(partials2[0], partials2[1], N, vox, groups, gamma, beta, eps)
     elif partials is not None:
         mean, rstd, scale, shift = ops.norm_stats_from_partials(partials[0], N, vox, x.shape[4], groups, gamma, beta, eps)
+    elif isinstance(x, ops.Planar):
+        mean, rstd, scale, shift = _planar_stats(x, groups, gamma, beta, eps)
     else:
         mean, rstd, scale, shift = ops.norm_stats(x, groups, gamma, beta, eps)
     if tracked:  # InstanceNormTrackStats: per-instance statistics, running averages of their batch means
@@ -796,8 +840,12 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
         floor = bool(D % f[0] or H % f[1] or W % f[2])
         if floor and getattr(model, "check_shape", True):
             raise ValueError(f"Invalid shape for U-Net: {(D, H, W)[3 - dim:]} is not divisible by {f[3 - dim:]}")
-        cat = ops.new_act(N, D, H, W, c_up + blk.out_channels, dev, adt)
-        skip = cat[..., c_up:]
+        if _planar_concat_ok(adt, c_up, blk, dec.blocks[depth - 1 - l], (N, D, H, W), dev, floor):
+            cat = ops.Planar.empty(N, D, H, W, dev, adt)   # two dense 32-channel planes (16-bit storage: whole lines per half)
+            skip = cat.halves[1]
+        else:
+            cat = ops.new_act(N, D, H, W, c_up + blk.out_channels, dev, adt)
+            skip = cat[..., c_up:]
         # the skip tensor feeds the norm in front of the decoder block of this level: its statistics come out of the
         # epilogue of this block's second conv (with the upsampled half's from the low-resolution tensor, see below)
         dnorm = dec.blocks[depth - 1 - l].conv_specs()[0].norm
@@ -864,7 +912,7 @@ def _forward_impl_body(model, x: torch.Tensor, keep: bool):
             na = blk.conv_specs()[0].norm_args()
             cpg = cat.shape[4] // na[0]
             want_stats = lv["c_up"] % cpg == 0 and ops.upsample_stats_ok(t)
-        up_part = ops.upsample_fwd(t, cat[..., :lv["c_up"]], f, stats=want_stats)  # ... interpolated straight into the concat buffer
+        up_part = ops.upsample_fwd(t, _half(cat, lv["c_up"], 0), f, stats=want_stats)  # ... interpolated straight into the concat buffer
         out = ops.new_act(N, cat.shape[1], cat.shape[2], cat.shape[3], blk.out_channels, dev, adt)
         if want_stats:
             p2 = (up_part if up_part is not None else ops.upsample_stats(t, f), skip_part[0])
@@ -978,11 +1026,11 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
     for i in reversed(range(depth)):
         d = st["dec"][i]
         lv = st["levels"][depth - 1 - i]
-        g_cat = torch.empty_like(lv.get("cat_c", lv["cat"]))
+        g_cat = _like(lv.get("cat_c", lv["cat"]))
         coef = _block_bwd(d["bs"], g_cur, g_cat, grads, defer_input_norm="crop" not in lv)
         low, sspec = d["low"], d["sspec"]
         g_t = ops.new_act(low.shape[0], low.shape[1], low.shape[2], low.shape[3], sspec.cout, low.device, low.dtype)
-        ops.upsample_bwd(g_cat[..., :lv["c_up"]], g_t, d["f"],
+        ops.upsample_bwd(_half(g_cat, lv["c_up"], 0), g_t, d["f"],
                          norm=None if coef is None else (d["t"], coef[:, :lv["c_up"]]))
         lv["g_skip_coef"] = None if coef is None else coef[:, lv["c_up"]:]
         g_low = torch.empty_like(low)
@@ -993,7 +1041,7 @@ def _backward_impl(model, st, gy: torch.Tensor, params: List[torch.Tensor], need
             if extra is not None:
                 g_low.add_(extra)
                 g_low._tem_amax = None   # rewritten: the producer's max |g_low| no longer holds
-        lv["g_skip"] = g_cat[..., lv["c_up"]:]
+        lv["g_skip"] = _half(g_cat, lv["c_up"], 1)
         if "crop" in lv:   # the adjoint of the centre crop: zeros around the gradient of the cropped window
             o, sk = lv["crop"], lv["skip"]
             gs = torch.zeros(sk.shape, dtype=sk.dtype, device=sk.device)

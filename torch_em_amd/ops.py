@@ -104,6 +104,10 @@ def _req_cuda(*ts):
 def _act5(t: torch.Tensor) -> Tuple[int, int, int, int, int, int]:
     """(N, D, H, W, C, ld) of a channels-last 5-D view; validates the stride contract:
     element (n,z,y,x,c) at (((n*D+z)*H+y)*W+x)*ld + c."""
+    if isinstance(t, Planar):
+        return (*t.shape, 32)
+    if isinstance(t, Probe):
+        return (*t.shape, t.shape[4])
     if t.dim() != 5:
         raise ValueError(f"expected a 5-D NDHWC tensor, got shape {tuple(t.shape)}")
     if t.dtype not in _ST:
@@ -134,6 +138,48 @@ def _act5(t: torch.Tensor) -> Tuple[int, int, int, int, int, int]:
 
 def new_act(N, D, H, W, C, device, dtype=torch.float32) -> torch.Tensor:
     return torch.empty((N, D, H, W, C), dtype=dtype, device=device)
+
+
+class Planar:
+    """A [N, D, H, W, 2 * 32] activation whose two 32-channel halves are two DENSE tensors of one allocation
+    (buf [2, N, D, H, W, 32]): the concat buffer of a level whose halves would otherwise be 64 bytes of every 128-byte line
+    in 16-bit storage (DESIGN.md 6.R5 "half lines").  The kernels that read / write all 64 channels take it through a chunk
+    stride (x_cs / y_cs of tem_conv3d_fwd_ex / _wgrad_ex); everything else gets `halves[i]`, an ordinary dense tensor."""
+
+    def __init__(self, buf: torch.Tensor):
+        if buf.dim() != 6 or buf.shape[0] != 2 or buf.shape[5] != 32 or not buf.is_contiguous() or buf.dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("Planar: expects a contiguous 16-bit [2, N, D, H, W, 32] buffer")
+        self.buf, self.halves = buf, (buf[0], buf[1])
+        self.shape = (*buf.shape[1:5], 64)
+        self.dtype, self.device, self.is_cuda = buf.dtype, buf.device, buf.is_cuda
+        self.cs = buf[0].numel()      # elements between the two 32-channel chunks of a voxel
+
+    @staticmethod
+    def empty(N, D, H, W, device, dtype):
+        return Planar(torch.empty((2, N, D, H, W, 32), dtype=dtype, device=device))
+
+    def empty_like(self):
+        return Planar(torch.empty_like(self.buf))
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
+
+    def dim(self):
+        return 5
+
+    def record_stream(self, s):
+        self.buf.record_stream(s)
+
+
+def _cs(t) -> int:
+    return t.cs if isinstance(t, Planar) else 0
+
+
+class Probe:
+    """shape + storage type of a dense activation, for the query functions (conv_fwd_family, ..._ok) only"""
+
+    def __init__(self, N, D, H, W, C, dtype):
+        self.shape, self.dtype = (N, D, H, W, C), dtype
 
 
 # ---------------------------------------------------------------- layout ----
@@ -251,7 +297,16 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     nblk = lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, cin, cout, k[0], k[1], k[2], mode) if want_stats else 0
     ev0 = _prof_begin(x, kind)
     part = None
-    if nblk > 0:
+    if _cs(x) or _cs(y):
+        if want_stats and nblk <= 0:
+            raise RuntimeError("conv_fwd: a planar tensor needs the z-reuse kernel (statistics rows expected)")
+        if nblk > 0:
+            part = torch.empty((N, nblk, cout, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.tem_conv3d_fwd_ex(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
+                                         ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], mode,
+                                         None, None, _p(part), nblk if part is not None else 0, _cs(x), _cs(y),
+                                         bp.ref() if bp is not None else None, _stream(x)), "tem_conv3d_fwd_ex")
+    elif nblk > 0:
         part = torch.empty((N, nblk, cout, 2), dtype=torch.float32, device=x.device)
         _lib.check(lib.tem_conv3d_fwd_stats(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld,
                                             _p(ref), ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2],
@@ -259,7 +314,7 @@ def conv_fwd(x, w_packed, bias, y, k, cin, cout, scale=None, shift=None, act=Non
     elif bp is not None:
         _lib.check(lib.tem_conv3d_fwd_ex(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
                                          ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], mode,
-                                         None, None, bp.ref(), _stream(x)), "tem_conv3d_fwd_ex")
+                                         None, None, None, 0, 0, 0, bp.ref(), _stream(x)), "tem_conv3d_fwd_ex")
     else:
         _lib.check(lib.tem_conv3d_fwd(_p(x), x_ld, _p(scale), _p(shift), _p(w_packed), _p(bias), _p(y), y_ld, _p(ref),
                                       ref_ld, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[act], mode,
@@ -342,7 +397,7 @@ def _conv_wgrad_sums(x, g, k, cin, cout, dw_out, db_out, scale, shift, mfma, sum
     ev0 = _prof_begin(x, kind)
     _lib.check(lib.tem_conv3d_wgrad_ex(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w.detach()), _p(gamma), _p(beta),
                                        _p(dw_out), _p(db_out), _p(sums), None, None, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1],
-                                       k[2], mode, bp.ref() if bp is not None else None, _stream(x)), "tem_conv3d_wgrad_ex")
+                                       k[2], mode, _cs(x), bp.ref() if bp is not None else None, _stream(x)), "tem_conv3d_wgrad_ex")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return sums
@@ -371,7 +426,7 @@ def conv_wgrad_gmax(x, g, k, cin, cout, dw_out, db_out, gmax, scale=None, shift=
     ev0 = _prof_begin(x, kind)
     _lib.check(lib.tem_conv3d_wgrad_ex(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w), _p(gamma), _p(beta),
                                        _p(dw_out), _p(db_out), _p(sums), None, _p(gmax), _p(ws), nws, N, D, H, W, cin, cout,
-                                       k[0], k[1], k[2], int(mfma), bp.ref() if bp is not None else None, _stream(x)),
+                                       k[0], k[1], k[2], int(mfma), 0, bp.ref() if bp is not None else None, _stream(x)),
                "tem_conv3d_wgrad_ex")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
@@ -468,7 +523,7 @@ def conv_wgrad_gscaled(x, g, k, cin, cout, dw_out, db_out, amax, scale=None, shi
     ev0 = _prof_begin(x, kind)
     _lib.check(lib.tem_conv3d_wgrad_ex(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(w), _p(gamma), _p(beta),
                                        _p(dw_out), _p(db_out), _p(sums), _p(amax), None, _p(ws), nws, N, D, H, W, cin, cout,
-                                       k[0], k[1], k[2], 8, bp.ref() if bp is not None else None, _stream(x)), "tem_conv3d_wgrad_ex")
+                                       k[0], k[1], k[2], 8, 0, bp.ref() if bp is not None else None, _stream(x)), "tem_conv3d_wgrad_ex")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return sums
@@ -490,8 +545,8 @@ def conv_fwd_gscaled(x, w_packed, y, k, cin, cout, amax, ref=None, bp=None):
     ev0 = _prof_begin(x, kind)
     if bp is not None:
         _lib.check(lib.tem_conv3d_fwd_ex(_p(x), x_ld, None, None, _p(w_packed), None, _p(y), y_ld, _p(ref), ref_ld, _p(ws), nws,
-                                         N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[None], 4, _p(amax), None, bp.ref(),
-                                         _stream(x)), "tem_conv3d_fwd_ex")
+                                         N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[None], 4, _p(amax), None, None, 0, 0, 0,
+                                         bp.ref(), _stream(x)), "tem_conv3d_fwd_ex")
     else:
         _lib.check(lib.tem_conv3d_fwd_gscaled(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(amax), _p(ws), nws,
                                               N, D, H, W, cin, cout, k[0], k[1], k[2], _stream(x)), "tem_conv3d_fwd_gscaled")
@@ -519,7 +574,7 @@ def conv_fwd_refnorm(x, w_packed, y, k, cin, cout, ref, coef, mfma, bp=None):
     if bp is not None:
         _lib.check(lib.tem_conv3d_fwd_ex(_p(x), x_ld, None, None, _p(w_packed), None, _p(y), y_ld, _p(ref), ref_ld, _p(ws), nws,
                                          N, D, H, W, cin, cout, k[0], k[1], k[2], ACT[None], _mode(mfma, x, y), None, _p(coef),
-                                         bp.ref(), _stream(x)), "tem_conv3d_fwd_ex")
+                                         None, 0, 0, 0, bp.ref(), _stream(x)), "tem_conv3d_fwd_ex")
     else:
         _lib.check(lib.tem_conv3d_fwd_refnorm(_p(x), x_ld, _p(w_packed), _p(y), y_ld, _p(ref), ref_ld, _p(coef), _p(ws), nws,
                                               N, D, H, W, cin, cout, k[0], k[1], k[2], _mode(mfma, x, y), _stream(x)),
@@ -555,9 +610,14 @@ def _conv_wgrad(x, g, k, cin, cout, dw_out, db_out=None, scale=None, shift=None,
     ws = _workspace(nws, x.device)
     kind = _wgrad_tag(mfma, k, cout) if PROFILER is not None else None
     ev0 = _prof_begin(x, kind)
-    _lib.check(lib.tem_conv3d_wgrad(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(dw_out), _p(db_out), _p(ws), nws,
-                                    N, D, H, W, cin, cout, k[0], k[1], k[2], mode, 1, _stream(x)),
-               "tem_conv3d_wgrad")
+    if _cs(x):
+        _lib.check(lib.tem_conv3d_wgrad_ex(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, None, None, None, _p(dw_out), _p(db_out),
+                                           None, None, None, _p(ws), nws, N, D, H, W, cin, cout, k[0], k[1], k[2], mode, _cs(x), None,
+                                           _stream(x)), "tem_conv3d_wgrad_ex")
+    else:
+        _lib.check(lib.tem_conv3d_wgrad(_p(x), x_ld, _p(scale), _p(shift), _p(g), g_ld, _p(dw_out), _p(db_out), _p(ws), nws,
+                                        N, D, H, W, cin, cout, k[0], k[1], k[2], mode, 1, _stream(x)),
+                   "tem_conv3d_wgrad")
     if ev0 is not None:
         _prof_end(x, ev0, (kind, f"{N}x{D}x{H}x{W} {cin}->{cout}"), 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2])
     return dw_out
@@ -611,8 +671,19 @@ def norm_stats_from_partials(part, rows: int, voxels: int, C: int, groups: int, 
 def norm_bwd_coef(gy, x, groups, gamma, mean, rstd, dgamma=None, dbeta=None, sums=None):
     """Reduction stage of norm_bwd only -> coef[N, C, 4] = (a, m1, m2r, mean) per (sample, channel)."""
     _req_cuda(gy, x)
+    if isinstance(x, Planar) and sums is None:
+        # no producer delivered the sums: reduce each dense half on its own (groups never straddle the halves: 32 % (C / G) == 0)
+        cg = 64 // groups
+        if 32 % cg:
+            raise ValueError("norm_bwd_coef: a group straddles the halves of a planar tensor")
+        gh = 32 // cg
+        sl = lambda t, i, n: None if t is None else t[..., i * n:(i + 1) * n]  # noqa: E731
+        return torch.cat([norm_bwd_coef(gy.halves[i], x.halves[i], gh, sl(gamma, i, 32), sl(mean, i, gh).contiguous(),
+                                        sl(rstd, i, gh).contiguous(), sl(dgamma, i, 32), sl(dbeta, i, 32)) for i in (0, 1)], dim=1)
     N, D, H, W, C, x_ld = _act5(x)
     gy_ld = _act5(gy)[5]
+    if isinstance(x, Planar):   # with the sums given the tensors are not read: any valid leading dimension
+        x_ld = gy_ld = C
     lib = _lib.load()
     V = D * H * W
     nws = lib.tem_norm_ws(N, V, C)
