@@ -440,8 +440,10 @@ def main():
         try:
             tj = json.load(open(traffic_file))
             key = RP_NAMES.get(dom_tag.split("(")[0])
-            if key in tj:
-                traffic = tj[key]
+            for cand in (key, key[:-1] + ", float>" if key else None):   # round 5: the kernels carry their element type
+                if cand in tj:
+                    traffic = tj[cand]
+                    break
         except (OSError, ValueError):
             pass
         out = {
