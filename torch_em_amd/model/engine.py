@@ -252,6 +252,7 @@ class _output_amax:
     def done(self, delivered=None):
         if self.slot is not None and (self.bp.amax if delivered is None else delivered):
             self.out._tem_amax = self.slot   # on the tensor OBJECT: dies with it (an address could be reused by another tensor)
+            self.out._tem_amax_ver = self.out._version   # ... and with any torch in-place op on it (no manual clearing needed)
 
 
 def _wgrad_f16x2_ok(spec, x, stats) -> bool:
@@ -539,6 +540,8 @@ def _wgrad(spec: ConvSpec, x, g, grads: _Grads, stats=None, want_sums=False, gma
             sums_from = (spec.conv.weight, gamma, beta)
         if amax is None:
             amax = getattr(g, "_tem_amax", None)
+            if amax is not None and getattr(g, "_tem_amax_ver", None) != g._version:
+                amax = None   # g was rewritten in place by a torch op after its producer delivered max |g|
         if amax is None:   # no producer of g delivered max |g|: one pass over g
             amax = ops.absmax(g, grads.amax_slot())
         rq = _sums_coef(spec, stats, x, on=sums_from is not None)
