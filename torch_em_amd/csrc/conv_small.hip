@@ -479,17 +479,48 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const EX* __restrict__ 
             lds[(hz * HY + hy) * HXP + hx] = v;
         }
         __syncthreads();
-        for (int row = rl; row < TZ * TY; row += nrl) {
+        // 16-bit g: the loads of TWO row passes are issued before the first one is consumed (same registers as one pass of
+        // fp32 pairs: the raw words are widened on use) -- the kernel waits for memory once per patch instead of twice
+        constexpr int NPASS = sizeof(EG) == 2 ? 2 : 1;
+        for (int row0 = rl; row0 < TZ * TY; row0 += NPASS * nrl) {
+            // (16-bit: the raw 4-byte words wait in registers, widened when their pass is computed)
+            using Raw = std::conditional_t<sizeof(EG) == 2, unsigned, f2>;
+            Raw gvp[NPASS][TX], yvp[NPASS][TX];
+            bool live[NPASS];
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int row = row0 + ps * nrl;
+                const int pz = row / TY, py = row % TY;
+                const int gz = z0 + pz, gy = y0 + py;
+                live[ps] = row < TZ * TY && gz < D && gy < H;
+                const int64_t v0 = live[ps] ? (((int64_t)n * D + gz) * H + gy) * W + x0 : (((int64_t)n * D + z0) * H + y0) * W + x0;
+#pragma unroll
+                for (int px = 0; px < TX; ++px) {     // branch-free: a voxel beyond W reads the row's first one and is zeroed
+                    const int pc = x0 + px < W ? px : 0;
+                    if constexpr (sizeof(EG) == 2) {
+                        gvp[ps][px] = *reinterpret_cast<const unsigned*>(g + (v0 + pc) * g_ld + q * 2);
+                        yvp[ps][px] = gcoef ? *reinterpret_cast<const unsigned*>(gnx + (v0 + pc) * gnx_ld + q * 2) : 0u;
+                    } else {
+                        gvp[ps][px] = act_ld2(g + (v0 + pc) * g_ld + q * 2);
+                        yvp[ps][px] = gcoef ? act_ld2(gnx + (v0 + pc) * gnx_ld + q * 2) : f2{0.f, 0.f};
+                    }
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+            if (!live[ps]) continue;
+            const int row = row0 + ps * nrl;
             const int pz = row / TY, py = row % TY;
-            const int gz = z0 + pz, gy = y0 + py;
-            if (gz >= D || gy >= H) continue;
-            const int64_t v0 = (((int64_t)n * D + gz) * H + gy) * W + x0;
             f2 gv[TX], yv[TX];
 #pragma unroll
-            for (int px = 0; px < TX; ++px) {     // branch-free: a voxel beyond W reads the row's first one and is zeroed
-                const int pc = x0 + px < W ? px : 0;
-                gv[px] = act_ld2(g + (v0 + pc) * g_ld + q * 2);
-                yv[px] = gcoef ? act_ld2(gnx + (v0 + pc) * gnx_ld + q * 2) : f2{0.f, 0.f};
+            for (int px = 0; px < TX; ++px) {
+                if constexpr (sizeof(EG) == 2) {
+                    gv[px] = f2{act_lo<EG>(gvp[ps][px]), act_hi<EG>(gvp[ps][px])};
+                    yv[px] = f2{act_lo<EG>(yvp[ps][px]), act_hi<EG>(yvp[ps][px])};
+                } else {
+                    gv[px] = gvp[ps][px];
+                    yv[px] = yvp[ps][px];
+                }
             }
 #pragma unroll
             for (int px = 0; px < TX; ++px)
@@ -520,6 +551,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_cin1(const EX* __restrict__ 
                 }
 #pragma unroll
             for (int px = 0; px < TX; ++px) acc[NT] += gv[px];
+            }
         }
     }
     // reduce over the row lanes: lanes sharing q inside a wave sit cp apart
