@@ -483,6 +483,45 @@ def test_model_step_is_bit_identical_with_planar_concat(mode, norm, monkeypatch)
     assert torch.equal(pa, pb) and la == lb and torch.equal(ga, gb)
 
 
+def test_graphed_step_with_16bit_storage_and_planar_concat_equals_eager():
+    """the fp16-storage step (planar concat halves at the top level) replayed as ONE HIP graph: bit-identical to eager"""
+    from torch_em_amd import ops
+    from torch_em_amd.graph import GraphedTrainStep
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d, engine
+    from torch_em_amd.optim import FusedAdamW, GradScaler
+    torch.manual_seed(2)
+    sd0 = {k: v.detach().clone() for k, v in UNet3d(1, 2, depth=2, initial_features=32).to(DEV).state_dict().items()}
+    g = torch.Generator().manual_seed(8)
+    xs = [torch.randn(2, 1, 32, 64, 64, generator=g).to(DEV) for _ in range(4)]
+    ys = [(torch.rand(2, 2, 32, 64, 64, generator=g) > 0.5).float().to(DEV) for _ in range(4)]
+    loss_fn = DiceLoss()
+    m0 = UNet3d(1, 2, depth=2, initial_features=32).to(DEV)
+    m0.load_state_dict(sd0)
+    with engine.precision_scope("amp"):
+        _, st = engine._forward_impl(m0, xs[0], keep=True)
+    assert isinstance(st["levels"][0]["cat"], ops.Planar)
+    del st
+    opt0, sc0, l0 = FusedAdamW(m0.parameters(), lr=1e-3), GradScaler(init_scale=2.0 ** 10), []
+    for x, y in zip(xs, ys):
+        opt0.zero_grad()
+        with engine.precision_scope("amp"):
+            loss = loss_fn(m0(x), y)
+            sc0.scale(loss).backward()
+            sc0.step(opt0)
+            sc0.update()
+        l0.append(loss.detach().clone())
+    m1 = UNet3d(1, 2, depth=2, initial_features=32).to(DEV)
+    m1.load_state_dict(sd0)
+    opt1, sc1 = FusedAdamW(m1.parameters(), lr=1e-3), GradScaler(init_scale=2.0 ** 10)
+    step = GraphedTrainStep(m1, loss_fn, opt1, xs[0], ys[0], scaler=sc1, precision="amp")
+    l1 = [step(x, y)[1].detach().clone() for x, y in zip(xs, ys)]
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b), (float(a), float(b))
+    for (k, a), b in zip(m0.state_dict().items(), m1.state_dict().values()):
+        assert torch.equal(a, b), k
+
+
 def test_default_mode_never_allocates_16bit_tensors():
     from torch_em_amd.model import engine
     for mode in ("fp32", "mixed", "split", "split16", "bf16x3"):
