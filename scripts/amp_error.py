@@ -19,9 +19,9 @@ def run(mode, scale):
         (l * scale).backward()
     return out.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone() / scale, float(l)
 o32, g32, l32 = run("split16", 1.0)
-for s in (1.0, 1024.0, 65536.0):
-    o16, g16, l16 = run("amp", s)
-    print(f"scale {s:8.0f}: out rel L2 {float((o16 - o32).norm() / o32.norm()):.2e}  loss {l16:.6f} vs {l32:.6f}  "
+for mode, s in (("amp", 1.0), ("amp", 1024.0), ("amp", 65536.0), ("amp_bf16", 1.0)):
+    o16, g16, l16 = run(mode, s)
+    print(f"{mode:8s} storage {engine.act_dtype() if False else ('16-bit' if engine._AMP_STORAGE16 else 'fp32')} scale {s:8.0f}: out rel L2 {float((o16 - o32).norm() / o32.norm()):.2e}  loss {l16:.6f} vs {l32:.6f}  "
           f"grad rel L2 {float((g16 - g32).norm() / g32.norm()):.2e}  finite {bool(torch.isfinite(g16).all())}")
 for mode in ("split16", "amp"):
     for _ in range(3):
