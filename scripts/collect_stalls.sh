@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/$1/stalls
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export TEM_BENCH_PREWARM_S=0
-CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras"
+CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras ${TEM_STALLS_ARGS:-}"   # TEM_STALLS_ARGS="--precision amp": the 16-bit-storage step
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"; do
