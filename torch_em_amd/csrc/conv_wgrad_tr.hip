@@ -104,6 +104,9 @@ __device__ __forceinline__ unsigned tr_mix_scale(float g0, float g1, float sc) {
 #ifndef TEM_TR_TX1_DIRECT
 #define TEM_TR_TX1_DIRECT 1   // the tx = 1 fragment of a row group by two more transposing reads (0: four v_alignbyte on the window; measured +2 % kernel time: the SIMD is issue-bound at ~5 non-MFMA instructions per MFMA over both waves)
 #endif
+#ifndef TEM_TR_PF2
+#define TEM_TR_PF2 1   // one-term modes: fragments of slab s + 2 are read during the MFMAs of slab s (four register sets; 0: s + 1, two sets)
+#endif
 #ifndef TEM_TR_ABL
 #define TEM_TR_ABL 0   // harness-only ablations (wrong results): 1 staging team idle, 2 multiplying team idle, 4 fragments read once
 #endif                 // per plane (no LDS reads in the MFMA stream), 8 staging without global loads
@@ -265,7 +268,22 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                 for (int a = 0; a < 3; ++a) xb[a] = X0 + lane_x + TR_XSLOT(t + rgtz[a] - 1) + rgoff[a];
                 return G0 + lane_g + TR_GSLOT(t);
             };
-            if constexpr (!FP32) {   // first fragments of the segment's first plane
+            // One-term x with the prefetch TWO slabs deep: a slab is only 7 MFMAs (224 cycles) and a transposing LDS read under
+            // the load of eight waves takes longer than that to return -- with one slab of lead every slab still waited
+            // (counters of the amp step: matrix pipe 0.44 busy at 2.2 GHz, not power-limited).  Four register sets named by the
+            // slab index (four slabs per plane: static names), 170 -> ~235 VGPRs of the 256 this kernel may use.
+            constexpr bool PF2 = NX == 1 && !FP32 && TEM_TR_PF2;
+            uint4 xq[PF2 ? 4 : 1][NA], gq[PF2 ? 4 : 1];
+            if constexpr (PF2) {
+                const unsigned char* xb0[3];
+                const unsigned char* gb0 = bases(za, xb0);
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    gq[PF2 ? sl : 0] = tr_frag(gb0 + sl * 16 * TR_REC);
+                    load_x(xq[PF2 ? sl : 0], xb0, 0, sl);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (!FP32) {   // first fragments of the segment's first plane
                 const unsigned char* xb0[3];
                 const unsigned char* gb0 = bases(za, xb0);
                 load_g(gb0, 0);
@@ -316,6 +334,21 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                     continue;
                 }
                 TR_STAMP(t - za, 1);
+                if constexpr (PF2) {
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const int nsl = (sl + 2) & 3;
+                        gq[PF2 ? nsl : 0] = tr_frag((sl < 2 ? gb : gbn) + nsl * 16 * TR_REC);
+                        load_x(xq[PF2 ? nsl : 0], sl < 2 ? xb : xbn, 0, nsl);
+#pragma unroll
+                        for (int j = 0; j < NA; ++j) acc[j] = mfma16<F16>(xq[PF2 ? sl : 0][j], gq[PF2 ? sl : 0], acc[j]);
+                        interleave();
+                    }
+                    TR_STAMP(t - za, 2);
+                    __syncthreads();
+                    TR_STAMP(t - za, 3);
+                    continue;
+                }
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) {
                     if (NX == 2) {
