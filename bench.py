@@ -215,6 +215,53 @@ def self_launch(args_gpus):
     return subprocess.call(cmd, env=env)
 
 
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_rank_to_gpu_numa_node(local_rank, world):
+    """One rank per GPU under torch.distributed.run: the launcher exports OMP_NUM_THREADS=1 and leaves every rank free to
+    run on any core.  Each rank is pinned to the CPUs of the NUMA node its GPU hangs off (PCI address from the device
+    properties -> /sys/bus/pci/devices/<bdf>/numa_node), ranks that share a node split its CPUs evenly, and the OpenMP /
+    torch intra-op thread count is set explicitly.  Returns what was done (the `ddp.cpu_affinity` object of the line)."""
+    info = {"numa_node": None, "cpus": None, "omp_threads": None}
+    try:
+        allowed = os.sched_getaffinity(0)
+        nodes = []
+        for d in range(world):
+            pr = torch.cuda.get_device_properties(d)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            try:
+                nodes.append(int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read()))
+            except (OSError, ValueError):
+                nodes.append(-1)
+        node = nodes[local_rank]
+        cpus = set(allowed)
+        if node >= 0:
+            try:
+                cpus = _cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) & allowed or set(allowed)
+            except OSError:
+                pass
+        peers = [r for r in range(world) if nodes[r] == node]
+        mine = sorted(cpus)
+        share = max(len(mine) // len(peers), 1)
+        k = peers.index(local_rank)
+        mine = mine[k * share:(k + 1) * share] or mine
+        os.sched_setaffinity(0, mine)
+        threads = max(1, min(len(mine), 8))
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        torch.set_num_threads(threads)
+        info = {"numa_node": node, "cpus": len(mine), "omp_threads": threads}
+    except Exception as e:  # an unusual /sys layout must not cost the run
+        info["error"] = f"{type(e).__name__}: {e}"
+    return info
+
+
 def main():
     if "WORLD_SIZE" not in os.environ:
         pre = argparse.ArgumentParser(add_help=False)
@@ -264,6 +311,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    affinity = pin_rank_to_gpu_numa_node(local_rank, world) if (world > 1 or os.environ.get("TEM_BENCH_PIN", "0") == "1") else None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -336,7 +384,10 @@ def main():
     # the exposed all-reduce time come from `ev_eager` eager steps right before the timed region.
     graphed = None
     ddp_exposed_eager = None
-    if os.environ.get("TEM_HIP_GRAPH", "0") == "1":
+    # N > 1: the graph replay is the DEFAULT (eight ranks share one host: ~5 ms of Python enqueue per step and rank against
+    # one hipGraphLaunch); TEM_HIP_GRAPH=0 / 1 overrides in both directions.
+    use_graph = os.environ.get("TEM_HIP_GRAPH", "1" if world > 1 else "0") == "1"
+    if use_graph:
         from torch_em_amd.graph import GraphedTrainStep
         for i in range(n_ev):   # on EVERY rank: the eager steps carry collectives
             ops.PROFILER_FILTER = {dom_tag} if ev_steps else set()
@@ -383,7 +434,7 @@ def main():
         ddp_info = {"bytes": model.sync.stats["bytes"], "n_collectives": model.sync.stats["n_collectives"],
                     "allreduce_exposed_ms": ddp_exposed_eager if graphed is not None else model.sync.exposed_ms(),
                     "ranks": dist.get_world_size(),
-                    "backend": dist.get_backend(), "per_rank_ms_per_step": per_rank_ms,
+                    "backend": dist.get_backend(), "per_rank_ms_per_step": per_rank_ms, "cpu_affinity": affinity,
                     "note": "bytes / collectives of one step's gradient exchange (in-place all-reduce of arena ranges on "
                             "RCCL's stream, overlapped with backward); allreduce_exposed_ms = mean time the compute stream "
                             "waited at the join before the optimizer (HIP events), over the timed steps"}
@@ -451,8 +502,9 @@ def main():
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "host_loop_ms_per_step": host_loop_ms,
-            "step_mode": ("one HIP graph replay per step (TEM_HIP_GRAPH=1; roofline events from eager steps before the timed "
-                          "region)" if graphed is not None else "eager launches"),
+            "step_mode": ("one HIP graph replay per step (" + ("default for --gpus > 1" if "TEM_HIP_GRAPH" not in os.environ
+                                                                else "TEM_HIP_GRAPH=1")
+                          + "; roofline events from eager steps before the timed region)" if graphed is not None else "eager launches"),
             "dtype": PRECISION_DTYPE[engine.PRECISION], "data": "synthetic",
             "config": {"workload": f"UNet3d(1->2, initial_features=32, depth=4, norm={args.norm}) + DiceLoss, "
                                    f"zero_grad+fwd+loss+bwd+AdamW, per-GPU batch {args.batch}x1x{S}^3"

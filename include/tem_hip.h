@@ -19,10 +19,16 @@
  *     tem_set_option() (the library never reads the environment);
  *   - return 0 on success, negative TEM_E* on failure (never throws);
  *     tem_last_error() gives the message for the calling thread;
- *   - activations are fp32, channels-last "NDHWC": element (n,z,y,x,c) of a
- *     tensor with leading dimension `ld` (floats between consecutive voxels,
+ *   - activations are channels-last "NDHWC": element (n,z,y,x,c) of a
+ *     tensor with leading dimension `ld` (ELEMENTS between consecutive voxels,
  *     ld >= C, so a tensor can be a channel slice of a wider concat buffer)
- *     lives at ((((n*D+z)*H+y)*W+x)*ld + c);  2-D data uses D == 1;
+ *     lives at ((((n*D+z)*H+y)*W+x)*ld + c);  2-D data uses D == 1.
+ *     Element type: fp32 by default (the `const float*` signatures); the two
+ *     mixed modes store fp16 / bf16 tensors between the kernels of a step
+ *     (round 5) -- such a call names the storage of its tensors explicitly
+ *     (TEM_ST_F32 / TEM_ST_F16 / TEM_ST_BF16: the TEM_MFMA_STX / STY bits of
+ *     `use_mfma`, or the `int st` of the *_st entry points) and passes the
+ *     16-bit buffers through the same pointer arguments;
  *   - V = D*H*W voxels per sample.
  */
 #ifndef TEM_HIP_H
@@ -247,6 +253,12 @@ int tem_conv3d_wgrad_gmax(const float* x, int64_t x_ld, const float* scale, cons
  * order; w / gamma / beta / norm_sums as in tem_conv3d_wgrad_sums (NULL: plain weight gradient).  Only the z-sliding
  * 3x3x3 kernel (tem_conv3d_wgrad_gscaled_ok: 3x3x3, D >= 8, Cin, Cout % 32 == 0); workspace tem_conv3d_wgrad_ws(.., 8). */
 int tem_conv3d_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
+/* Does tem_conv3d_wgrad_ex honour a CHUNK STRIDE x_cs (the planar halves of a 16-bit concat buffer: 32-channel chunk k of a
+ * voxel at base + k * x_cs + voxel * x_ld) for this layer, storage type `st` (TEM_ST_*) and stride?  Exactly the conditions
+ * the launch checks: the transposing z-sliding kernel (3x3x3, D >= 8, Cin, Cout % 32 == 0, option wgrad_zs = 3), 16-bit
+ * storage, x_cs % 8 == 0.  A caller lays a tensor out in planes only when this (and the forward / data-gradient queries)
+ * say yes -- a launch that cannot honour a stride returns TEM_EINVAL before anything is enqueued. */
+int tem_conv3d_wgrad_cs_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int st, int64_t x_cs);
 int tem_conv3d_wgrad_gscaled(const float* x, int64_t x_ld, const float* scale, const float* shift,
                              const float* g, int64_t g_ld, const float* w, const float* gamma, const float* beta,
                              float* dw, float* db, float* norm_sums, const unsigned* g_amax, void* ws, int64_t ws_bytes,

@@ -188,3 +188,30 @@ def test_predict_with_halo_pipelined(case, batch_size):
     assert got.shape == want.shape and np.array_equal(got, want) and float(np.abs(got).max()) > 0
     with pytest.raises(NotImplementedError):
         predict_with_halo_pipelined(x, model, [DEV], bs, halo, grid_shift=(0.5, 0.5, 0.5), **kw)
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_prediction_is_ordered_behind_the_callers_stream(pipelined):
+    """The workers run on streams of their own; a weight update the caller has ENQUEUED but not finished (an optimizer step,
+    `load_state_dict`) must still be seen by the first forward pass.  The caller's stream is kept busy for tens of
+    milliseconds in front of the update, so an unordered worker stream would read the old weights."""
+    from torch_em_amd.util import predict_with_halo, predict_with_halo_pipelined
+    fn = predict_with_halo_pipelined if pipelined else predict_with_halo
+    model, _ = _model(True, 1, 2)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((16, 32, 32)).astype("float32")
+    bs, halo = (8, 16, 16), (4, 8, 8)
+    new = {k: torch.randn_like(v) * 0.3 for k, v in model.state_dict().items()}
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        busy = torch.randn(4096, 4096, device=DEV)
+        for _ in range(60):                      # ~tens of ms of queued work in front of the weight update
+            busy = busy @ busy * 1e-2
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(new[k])
+        got = fn(x, model, [DEV], bs, halo, disable_tqdm=True)
+    torch.cuda.synchronize()
+    want = fn(x, model, [DEV], bs, halo, disable_tqdm=True)
+    assert np.array_equal(got, want)
+    assert float(np.abs(want).max()) > 0

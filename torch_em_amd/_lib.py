@@ -49,6 +49,7 @@ SIGNATURES = {
     "tem_conv3d_wgrad_gmax": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]
                               + [c_int] * 10 + [c_vp]),
     "tem_conv3d_wgrad_gscaled_ok": (c_int, [c_int] * 9),
+    "tem_conv3d_wgrad_cs_ok": (c_int, [c_int] * 10 + [c_i64]),
     "tem_conv3d_wgrad_gscaled": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]
                                  + [c_int] * 9 + [c_vp]),
     "tem_absmax": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_vp]),

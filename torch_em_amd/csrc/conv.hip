@@ -744,6 +744,10 @@ extern "C" int tem_conv3d_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, 
     return tem_conv_wgrad_gscaled_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
 }
 
+extern "C" int tem_conv3d_wgrad_cs_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int st, int64_t x_cs) {
+    return tem_conv_wgrad_cs_ok(N, D, H, W, Cin, Cout, kd, kh, kw, st, x_cs);
+}
+
 extern "C" int tem_conv3d_wgrad_gscaled(const float* x, int64_t x_ld, const float* scale, const float* shift,
                                         const float* g, int64_t g_ld, const float* w, const float* gamma,
                                         const float* beta, float* dw, float* db, float* norm_sums,

@@ -1908,6 +1908,12 @@ int tem_conv_wgrad_tr_fp32_ok(int N, int D, int H, int W, int Cin, int Cout, int
     const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
     return Cin % 32 == 0 && Cout % 32 == 0 && z.use && z.tr;
 }
+// the chunk-stride conditions of the launch below (x_cs != 0), as a query
+int tem_conv_wgrad_cs_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int st, int64_t x_cs) {
+    if (Cin % 32 || Cout % 32) return 0;
+    const ZsPlan z = zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw);
+    return z.use && z.tr && st != 0 && x_cs % 8 == 0;
+}
 int tem_conv_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw) {
     return Cin % 32 == 0 && Cout % 32 == 0 && zs_plan(N, D, H, W, Cin, Cout, kd, kh, kw).use;
 }

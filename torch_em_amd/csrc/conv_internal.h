@@ -104,6 +104,7 @@ int tem_conv_wgrad_gmax_ok(int N, int D, int H, int W, int Cin, int Cout, int kd
 // h16 == 3 of tem_conv_wgrad_bf16x3 ("fp16 2x1": x^ two fp16 terms, g one fp16 term prescaled from this device word)
 extern thread_local const unsigned* tem_wgrad_gscale_source;
 int tem_conv_wgrad_gscaled_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);
+int tem_conv_wgrad_cs_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int st, int64_t x_cs);
 int tem_conv_wgrad_tr_fp32_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw);   // h16 == 4
 // prescale of the z-reuse kernel's input by a power of two derived from a device-side |max| (tem_conv3d_fwd_gscaled)
 extern thread_local const unsigned* tem_zr_in_amax;

@@ -607,7 +607,8 @@ def _planar_concat_ok(adt, c_up, enc_blk, dec_blk, shape, dev, floor) -> bool:
     ent = c1.packed()
     x64, g = ops.Probe(N, D, H, W, 64, adt), ops.Probe(N, D, H, W, c1.cout, adt)
     return ops.conv_fwd_family(x64, c1.k, 64, c1.cout, ent["fwd_mfma"]) == 3 and \
-        ops.conv_fwd_family(g, c1.k, c1.cout, 64, ent["dgrad_mfma"]) == 3 and ops.conv_wgrad_gscaled_ok(x64, c1.k, 64, c1.cout)
+        ops.conv_fwd_family(g, c1.k, c1.cout, 64, ent["dgrad_mfma"]) == 3 and \
+        ops.conv_wgrad_cs_ok(x64, c1.k, 64, c1.cout, N * D * H * W * 32)   # the stride ops.Planar gives its two planes
 
 
 def _half(t, c_up, i):

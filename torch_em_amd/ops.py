@@ -463,6 +463,12 @@ def conv_wgrad_gscaled_ok(x, k, cin, cout) -> bool:
     return bool(_lib.load().tem_conv3d_wgrad_gscaled_ok(N, D, H, W, cin, cout, k[0], k[1], k[2]))
 
 
+def conv_wgrad_cs_ok(x, k, cin, cout, x_cs) -> bool:
+    """does the weight gradient honour the chunk stride `x_cs` (elements) of a Planar input of x's size and element type?"""
+    N, D, H, W, _, _ = _act5(x)
+    return bool(_lib.load().tem_conv3d_wgrad_cs_ok(N, D, H, W, cin, cout, k[0], k[1], k[2], _ST[x.dtype], int(x_cs)))
+
+
 def absmax(x, amax=None):
     """bit pattern of max |x| of an activation tensor [N, D, H, W, C(ld)] -> int32[1] on the device (tem_absmax);
     `amax` (cleared by the caller) accumulates when given."""

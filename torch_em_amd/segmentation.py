@@ -66,8 +66,10 @@ def default_segmentation_trainer(name: str, model: torch.nn.Module, train_loader
                                  compile_model: Optional[Union[bool, str]] = None, rank: Optional[int] = None,
                                  mixed_precision_dtype: Optional[str] = None, optimizer=None, lr_scheduler=None,
                                  target_transform: Optional[Callable] = None, augmentation: Optional[Callable] = None,
-                                 raw_transform: Optional[Callable] = None, prefetch: bool = True):
-    """Trainer with the reference's defaults (reference :466-577)."""
+                                 raw_transform: Optional[Callable] = None, prefetch: bool = True,
+                                 hip_graph: Optional[bool] = None):
+    """Trainer with the reference's defaults (reference :466-577).  Not in the reference: the on-device `target_transform` /
+    `augmentation` / `raw_transform`, `prefetch` and `hip_graph` arguments of this path's DefaultTrainer, handed through."""
     if optimizer is None:
         optimizer = FusedAdamW(model.parameters(), lr=learning_rate, **optimizer_kwargs)
     if lr_scheduler is None:
@@ -84,4 +86,4 @@ def default_segmentation_trainer(name: str, model: torch.nn.Module, train_loader
                          log_image_interval=log_image_interval, logger=logger, logger_kwargs=logger_kwargs, id_=id_,
                          save_root=save_root, compile_model=compile_model, rank=rank,
                          mixed_precision_dtype=mixed_precision_dtype, target_transform=target_transform,
-                         augmentation=augmentation, raw_transform=raw_transform, prefetch=prefetch)
+                         augmentation=augmentation, raw_transform=raw_transform, prefetch=prefetch, hip_graph=hip_graph)

@@ -160,8 +160,7 @@ class _Setup:
         try:
             from tqdm import tqdm
         except ImportError:  # pragma: no cover
-            def tqdm(it=None, **kw):
-                return it
+            tqdm = _NoProgress
         self.progress = tqdm(total=len(self.block_ids), disable=disable_tqdm, desc=tqdm_desc)
         # the per-device model copies are made HERE, on the calling thread, before any worker runs a forward pass (which
         # attaches packed weights to the conv modules of ITS model: a deepcopy racing with that sees half-built entries);
@@ -176,7 +175,21 @@ class _Setup:
                 for mod in copy.modules():   # the packed weights are device buffers of the source model: the copy builds its own
                     mod.__dict__.pop("_tem_pack", None)
                 self.models.append(copy.to(d))
+        # Every worker runs on a stream of its own, and a fresh torch.cuda.Stream does not wait for anything: whatever the
+        # CALLER still has in flight on its current stream of a device (the peer copies just above, an optimizer step or a
+        # load_state_dict before a train-then-predict call) must be ordered in front of the workers' first upload / forward.
+        self.ready = {}
+        for d in self.devices:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(d))
+            self.ready[d] = ev
         self.model, self.with_channels, self.user_output, self.grid_shift = model, with_channels, output, grid_shift
+
+    def worker_stream(self, device):
+        """A new stream of `device` that starts behind everything the calling thread had enqueued when the setup ended."""
+        s = torch.cuda.Stream(device)
+        s.wait_event(self.ready[device])
+        return s
 
     def upload(self, device):
         vol = _to_volume(self.input_eff, self.with_channels, self.ndim, device)
@@ -234,6 +247,19 @@ class _Setup:
         return output
 
 
+class _NoProgress:
+    """Stand-in for tqdm(total=...) when tqdm is not installed: the two methods the workers call."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def update(self, n=1):
+        pass
+
+    def close(self):
+        pass
+
+
 def _store_inner(lib, pred, out_dev, mask_dev, halo, begin, size):
     _lib.check(lib.tem_block_store_inner(
         ops._p(pred), _i3(_pad3(pred.shape[1:], 1)), ops._p(out_dev), pred.shape[0], out_dev.shape[1], out_dev.shape[2],
@@ -287,7 +313,7 @@ def predict_with_halo(input_, model: torch.nn.Module, gpu_ids: List[Union[str, i
         forward pass and a masked scatter into the device's output volume -> (output volume or None, boxes written)."""
         out_dev, written = None, []
         # the worker's own stream: the library's scratch buffers are keyed by (device, stream), so two workers never share one
-        with torch.no_grad(), torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device)):
+        with torch.no_grad(), torch.cuda.device(device), torch.cuda.stream(su.worker_stream(device)):
             vol, mask_dev = su.upload(device)
             for block_id in my_blocks:
                 su.progress.update(1)
@@ -344,7 +370,7 @@ def predict_with_halo_pipelined(input_, model: torch.nn.Module, gpu_ids: List[Un
     def run_on(device, my_blocks, my_model):
         out_dev, written = None, []
         with torch.no_grad(), torch.cuda.device(device):
-            s_main, s_pre, s_post = (torch.cuda.Stream(device) for _ in range(3))
+            s_main, s_pre, s_post = (su.worker_stream(device) for _ in range(3))
             with torch.cuda.stream(s_main):
                 vol, mask_dev = su.upload(device)
             s_pre.wait_stream(s_main)
