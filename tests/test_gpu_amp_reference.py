@@ -117,7 +117,7 @@ def test_default_mode_step_against_the_reference_fp32_step():
     for k, le, re, n in zip(names, lib_err, ref_err, norm64):
         assert le <= 2.0 * max(re, 2e-4 * n, 1e-6 * glob64), (k, le / max(n, 1e-300), re / max(n, 1e-300))
     assert abs(float(loss) - float(g["f64.loss"])) < 1e-5
-    assert float(np.abs(pred.double().cpu().numpy() - g["f64.pred"]).max()) < 1e-4 * float(np.abs(g["f64.pred"]).max())
+    assert float(np.abs(pred.detach().double().cpu().numpy() - g["f64.pred"]).max()) < 1e-4 * float(np.abs(g["f64.pred"]).max())
 
 
 @pytest.mark.parametrize("hip_graph", [False, True])
@@ -139,11 +139,13 @@ def test_fp16_storage_trainer_survives_an_overflow_backoff_cycle(hip_graph, tmp_
     trainer = torch_em_amd.default_segmentation_trainer(
         "overflow", model, train, val, learning_rate=1e-4, device=DEV, mixed_precision=True, mixed_precision_dtype="float16",
         save_root=str(tmp_path), hip_graph=hip_graph)
-    start = 2.0 ** 22                       # the reference's autocast overflows this net at 2^16 already (G10: settles at 2^15)
+    # (the reference's CPU autocast overflows this net at 2^16 already, G10: its fp16 tensors start at the loss; here the Dice
+    #  gradient and the out_conv backward are fp32 and the first STORED fp16 gradient is 1e-5-sized: 2^22 still fits, measured)
+    start = 2.0 ** 36
     trainer.scaler = GradScaler(init_scale=start)
     before = torch.cat([p.detach().flatten().clone() for p in model.parameters()])
     scales, moved = [], []
-    for it in range(1, 13):
+    for it in range(1, 31):
         trainer.fit(iterations=1)
         torch.cuda.synchronize()
         now = torch.cat([p.detach().flatten() for p in trainer.model.parameters()])
@@ -153,7 +155,7 @@ def test_fp16_storage_trainer_survives_an_overflow_backoff_cycle(hip_graph, tmp_
         before = now.clone()
     print(f"\nhip_graph={hip_graph}: scales {[int(np.log2(s)) for s in scales]}, parameter moved {moved}")
     n_skipped = moved.index(True)
-    assert 1 <= n_skipped <= 10, (scales, moved)                 # at least the first step overflowed, and it recovered
+    assert 1 <= n_skipped <= 26, (scales, moved)                 # at least the first step overflowed, and it recovered
     assert all(moved[n_skipped:])                                   # once the scale fits every step is applied
     assert scales[:n_skipped] == [start / 2 ** (i + 1) for i in range(n_skipped)]   # halved once per skipped step
     assert scales[-1] == start / 2 ** n_skipped                     # and untouched afterwards (growth interval 2000)

@@ -100,7 +100,8 @@ def test_train_multi_gpu_end_to_end(tmp_path, hip_graph):
         assert r["world"] == world and r["backend"] == "nccl" and r["device"] == f"cuda:{r['rank']}"
         assert r["iteration"] == ITERATIONS and r["saves"] >= 1               # every rank CALLS save_checkpoint; one writes
         assert r["graphed"] == hip_graph, r["graph_why"]
-        assert r["collectives"]["bytes"] == recs[0]["params"].numel() * 4    # the whole gradient arena was exchanged
+        nbytes = recs[0]["params"].numel() * 4                                 # the whole gradient arena was exchanged
+        assert nbytes <= r["collectives"]["bytes"] <= nbytes + 4096          # (+ the arena's alignment padding)
         assert torch.equal(r["params"], recs[0]["params"])                     # bit-identical parameters on every rank
     # DistributedSampler: per epoch the ranks see disjoint samples that together cover the dataset (the loader of every
     # rank has N / world / batch_size batches, so 4 iterations span ITERATIONS * 2 * world / N epochs)

@@ -40,6 +40,9 @@
 #ifndef TR_UNROLL
 #define TR_UNROLL 8                // iterations per trip of the 16-bit staging loop (even: two register sets alternate)
 #endif
+#ifndef TR_UNROLL32
+#define TR_UNROLL32 4              // the same for the fp32-tensor staging loop (round 6; 8 and 16 measured: more idle padding at D = 32)
+#endif
 #define TR_XT_OF(rec) (TR_NXS * 100 * (rec))   // one term of x^: ring of 10 x 10 halo planes
 #define TR_GT_OF(rec) (TR_NGS * 64 * (rec))    // one term of g: 8 x 8 planes
 
@@ -106,6 +109,15 @@ __device__ __forceinline__ unsigned tr_mix_scale(float g0, float g1, float sc) {
 #endif
 #ifndef TEM_TR_PF2
 #define TEM_TR_PF2 1   // one-term modes: fragments of slab s + 2 are read during the MFMAs of slab s (four register sets; 0: s + 1, two sets)
+#endif
+#ifndef TEM_TR_RTZ
+#define TEM_TR_RTZ 0    // experiment: hi term of x^ by v_cvt_pkrtz_f16_f32 (one instruction per pair; the split stays exact, lo grows to 1 ulp)
+#endif
+#ifndef TEM_TR_DBCOND
+#define TEM_TR_DBCOND 0   // experiment: bias-gradient adds only in the workgroups that store them (cit == 0)
+#endif
+#ifndef TEM_TR_PRIO
+#define TEM_TR_PRIO 0   // s_setprio of the multiplying team (its MFMAs and fragment reads against the staging wave of the same SIMD)
 #endif
 #ifndef TEM_TR_ABL
 #define TEM_TR_ABL 0   // harness-only ablations (wrong results): 1 staging team idle, 2 multiplying team idle, 4 fragments read once
@@ -182,6 +194,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
 
     if (mteam) {
         // ---------------- multiplying team ----------------
+        if (TEM_TR_PRIO) __builtin_amdgcn_s_setprio(TEM_TR_PRIO);
         floatx16 acc[NA];
 #pragma unroll
         for (int j = 0; j < NA; ++j)
@@ -321,6 +334,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                     }
                     __syncthreads();
                 }
+                for (int e = zb - za + 6; e % TR_UNROLL32; ++e) __syncthreads();
                 continue;
             }
 #pragma unroll 1
@@ -390,10 +404,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                 __syncthreads();
                 TR_STAMP(t - za, 3);
             }
-            if constexpr (T16) {   // the staging team of the 16-bit kernel walks a segment in trips of TR_UNROLL iterations
-                for (int e = zb - za + 6; e % TR_UNROLL; ++e) __syncthreads();
-            }
+            // the staging team walks a segment in trips of TR_UNROLL (16-bit tensors) / TR_UNROLL32 iterations
+            for (int e = zb - za + 6; e % (T16 ? TR_UNROLL : TR_UNROLL32); ++e) __syncthreads();
         }
+        if (TEM_TR_PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- partial slabs: D[row = ci][col = co] ----
         if (cog * 32 < Cout) {
             const int kh = lane >> 5, r = lane & 31;
@@ -555,6 +569,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
         // per column and a load offset beyond the buffer, which returns zeros), no branches around loads, and
         // TWO sets of pending registers: the loads of an iteration are converted two iterations later.
         float4 xa[2][4], ga[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {   // (a set is stored before it is first loaded: the priming iterations write zero planes)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xa[i][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ga[i][0] = ga[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (scale) {
             sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)n * Cin + cit * 32 + quad * 4);
@@ -564,6 +584,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
         const TS* const gn = g + (int64_t)n * D * H * W * g_ld;   // inside one plane (< 2 GiB, checked by the host side)
         const int64_t xplane = (int64_t)H * W * x_ld, gplane = (int64_t)H * W * g_ld;
         constexpr unsigned OOB = 0x80000000u;   // >= num_records of tr_rsrc: the load returns zeros
+        const bool q3 = tl < 32;                // the fourth round of an x plane: halo voxels 96..99
         for (int cz = sp % S; cz < ncz; cz += S) {
             const int zseg = cz % zsegs;
             const int col = cz / zsegs;
@@ -592,19 +613,26 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
             // this team converts and stores the register set loaded two iterations ago (x plane t + 3 into its ring slot,
             // g plane t + 2 into its buffer), loads x plane t + 5 and g plane t + 4 into the same set, and joins the barrier.
             // Planes -1 and D are stored as zeros.
+            // Round 6: the SIX LOADS of an iteration are issued unconditionally, in straight-line code, in trips of TR_UNROLL32
+            // iterations (a plane outside the volume / the segment reads with an offset beyond the buffer: zeros) -- what the
+            // 16-bit path above does since round 5.  With the loads inside `if (plane in range)` blocks the compiler cannot count
+            // what is outstanding and waited `vmcnt(3) .. vmcnt(0)` in front of the conversions: all of this set's loads AND the
+            // other set's, issued ONE plane earlier -- a full memory latency exposed in every iteration, with the multiplying
+            // team waiting at the barrier (ablations of round 6, profiles/r06_wgrad_tr_ablations.txt: staging team idle
+            // 0.446 -> 0.306 ms, fragment reads removed 0.446 -> 0.407 ms: the staging team WAS the critical path).
             auto iteration = [&](int t, float4(&xs_)[4], float4(&gs_)[2], bool& zin_) {
                 TR_STAMP(t - za, 0);
                 if (TEM_TR_ABL & 1) {
                     __syncthreads();
                     return;
                 }
-                if (t >= za - 4) {
+                {
                     unsigned char* const xs = X0 + TR_XSLOT(t + 3) + quad * TR_QB;
                     if (zin_) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int hv = (tl + 256 * q) >> 3;
-                            if (q == 3 && hv >= 100) break;
+                            if (q == 3 && !q3) break;
                             const float e0 = fmaf(xs_[q].x, scm[q].x, sfm[q].x), e1 = fmaf(xs_[q].y, scm[q].y, sfm[q].y);
                             const float e2 = fmaf(xs_[q].z, scm[q].z, sfm[q].z), e3 = fmaf(xs_[q].w, scm[q].w, sfm[q].w);
                             if constexpr (FP32) {
@@ -613,7 +641,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                             }
                             uint2 hi, lo;
                             if (H21) {
-                                hi = make_uint2(pk16<true>(e0, e1), pk16<true>(e2, e3));
+                                if (TEM_TR_RTZ)
+                                    hi = make_uint2(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0, e1)),
+                                                    __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e2, e3)));
+                                else
+                                    hi = make_uint2(pk16<true>(e0, e1), pk16<true>(e2, e3));
                                 lo = make_uint2(tr_mix_lo(hi.x, e0, e1), tr_mix_lo(hi.y, e2, e3));
                             } else if (ARITH == 0) {
                                 split2(e0, e1, hi.x, lo.x);
@@ -628,7 +660,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int hv = (tl + 256 * q) >> 3;
-                            if (q == 3 && hv >= 100) break;
+                            if (q == 3 && !q3) break;
                             if constexpr (FP32) {
                                 *reinterpret_cast<float4*>(xs + hv * TR_REC) = make_float4(0.f, 0.f, 0.f, 0.f);
                                 continue;
@@ -638,7 +670,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                         }
                     }
                 }
-                if (t + 2 >= za && t + 2 < zb) {
+                {   // g plane t + 2 (zeros outside the segment: the load was sent beyond the buffer; such a plane lands in a slot
+                    // that is rewritten before anything multiplies with it)
                     unsigned char* const gs = G0 + TR_GSLOT(t + 2) + quad * TR_QB;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -658,10 +691,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                         }
                         if (!FP32) *reinterpret_cast<uint2*>(gs + gv * TR_REC) = hi;
                         if (NG == 2) *reinterpret_cast<uint2*>(gs + TR_GT + gv * TR_REC) = lo;
-                        dbacc[0] += v.x;
-                        dbacc[1] += v.y;
-                        dbacc[2] += v.z;
-                        dbacc[3] += v.w;
+                        if (!TEM_TR_DBCOND || do_db) {
+                            dbacc[0] += v.x;
+                            dbacc[1] += v.y;
+                            dbacc[2] += v.z;
+                            dbacc[3] += v.w;
+                        }
                         if (gmax)   // grid-uniform
                             gmx = __builtin_fmaxf(gmx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)),
                                                                        __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
@@ -669,28 +704,33 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                 }
                 TR_STAMP(t - za, 1);
                 {
+                    // (plain scalar arithmetic, no short-circuit operators: a branch around a load would be back)
                     const int zx = t + 5;
-                    zin_ = zx >= za - 1 && zx <= zb && zx >= 0 && zx < D;   // wave-uniform
-                    if (zin_ && !(TEM_TR_ABL & 8)) {
-                        const tr_rsrc_t rsx = tr_rsrc(xn + zx * xplane);
+                    const int ldx = (int)(zx >= za - 1) & (int)(zx <= zb) & (int)(zx >= 0) & (int)(zx < D) & (int)!(TEM_TR_ABL & 8);   // wave-uniform
+                    zin_ = ldx != 0;
+                    const tr_rsrc_t rsx = tr_rsrc(xn + (int64_t)(zx * ldx) * xplane);
+                    const unsigned mx = ldx ? 0u : OOB;   // OR-ed into the offsets (< 2^31): beyond the buffer -> zeros
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) xs_[q] = tr_load4(rsx, offx[q]);
-                    }
+                    for (int q = 0; q < 4; ++q) xs_[q] = tr_load4(rsx, offx[q] | mx);
                     const int zg = t + 4;
-                    if (zg >= za && zg < zb && !(TEM_TR_ABL & 8)) {
-                        const tr_rsrc_t rsg = tr_rsrc(gn + zg * gplane);
+                    const int ldg = (int)(zg >= za) & (int)(zg < zb) & (int)!(TEM_TR_ABL & 8);
+                    const tr_rsrc_t rsg = tr_rsrc(gn + (int64_t)(zg * ldg) * gplane);
+                    const unsigned mg = ldg ? 0u : OOB;
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) gs_[q] = tr_load4(rsg, offg[q]);
-                    }
+                    for (int q = 0; q < 2; ++q) gs_[q] = tr_load4(rsg, offg[q] | mg);
                 }
                 TR_STAMP(t - za, 2);
                 __syncthreads();
                 TR_STAMP(t - za, 3);
             };
+            // trips of TR_UNROLL32 straight-line iterations (the compiler counts the outstanding loads exactly inside a trip and
+            // waits for all of them once per trip); a segment is padded to whole trips with idle iterations whose barriers the
+            // multiplying team meets
+            const int t_end = za - 6 + (zb - za + 6 + TR_UNROLL32 - 1) / TR_UNROLL32 * TR_UNROLL32;
 #pragma unroll 1
-            for (int t = za - 6; t < zb; t += 2) {
-                iteration(t, xa[0], ga[0], zin[0]);
-                if (t + 1 < zb) iteration(t + 1, xa[1], ga[1], zin[1]);
+            for (int t = za - 6; t < t_end; t += TR_UNROLL32) {
+#pragma unroll
+                for (int k = 0; k < TR_UNROLL32; ++k) iteration(t + k, xa[k & 1], ga[k & 1], zin[k & 1]);
             }
         }
     }
