@@ -37,7 +37,7 @@ def measure(steps=12, workers=2, size=128, batch=2, dev="cuda"):
         loader = torch.utils.data.DataLoader(Repeat(), batch_size=batch, shuffle=False, num_workers=workers,
                                              pin_memory=True, persistent_workers=workers > 0)
         trainer = torch_em_amd.default_segmentation_trainer(
-            "bl", model, loader, loader, device=dev, logger=None, save_root="/tmp/bench_loader",
+            "bl", model, loader, loader, device=dev, logger=None, save_root="/tmp/bench_loader", mixed_precision=False,
             raw_transform=functools.partial(standardize, per_sample=True), augmentation=get_augmentations(3),
             target_transform=BatchTargets(BoundaryTransform(add_binary_target=True, ndim=3)), prefetch=(mode != "loader_serial"))
         trainer._initialize(steps, None)

@@ -57,7 +57,7 @@ else:
     dl = torch.utils.data.DataLoader(ds, batch_size=1)
     tr = SPOCOTrainer(model=model, momentum=0.999, name="b", train_loader=dl, val_loader=dl, loss=loss,
                       optimizer=FusedAdamW(model.parameters(), lr=1e-4), metric=loss, device=dev, save_root="/tmp/spoco_b",
-                      logger=None)
+                      logger=None, mixed_precision=False)   # the fp32-class step (the bare flag means fp16 autocast since round 6)
     tr._initialize(1, None)
 
     def run():

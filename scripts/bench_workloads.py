@@ -102,7 +102,7 @@ def cfg5(steps=3, warmup=2, dev="cuda"):
     dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x.cpu(), lbl[0].cpu()[None]), batch_size=1)
     tr = SPOCOTrainer(model=model, momentum=0.999, name="b", train_loader=dl, val_loader=dl, loss=loss,
                       optimizer=FusedAdamW(model.parameters(), lr=1e-4), metric=loss, device=dev, save_root="/tmp/spoco_b",
-                      logger=None)
+                      logger=None, mixed_precision=False)   # the fp32-class step (the bare flag means fp16 autocast since round 6)
     tr._initialize(1, None)
     ms, v = _time(lambda: tr._step(x, tr.loss, lbl)[1], steps, warmup)
     return {"ms_per_step": ms, "voxels_per_s": D * H * W / ms * 1e3, "loss": float(v)}

@@ -3,6 +3,11 @@ import os
 # exercise the weight-gradient-derived norm sums (csrc/wgrad_sums.hip) on every layer that qualifies, not only on the
 # >= 256 MB tensors where the product path switches them on
 os.environ.setdefault("TEM_OPT_WGRAD_SUMS_MIN_MB", "0")  # applied through tem_set_option() when the library loads
+# DefaultTrainer(mixed_precision=True) -- the reference's default flag -- selects the fp16 mixed mode since round 6 (as in
+# the reference).  The suite checks the trainers against fp32 / float64 oracles at 1e-3 unless a test names a dtype, so it
+# pins the bare flag to the parity-grade fp32-class path; tests/test_gpu_trainer.py::test_mixed_precision_default_flag
+# removes the pin and checks the product default.
+os.environ.setdefault("TEM_MIXED_PRECISION", "0")
 import sys
 
 import pytest

@@ -371,10 +371,46 @@ def test_mixed_precision_training(tmp_path):
     assert torch.equal(before, after)
     assert trainer.scaler.get_scale() == 2.0 ** 99
     assert {int(v["step"]) for v in trainer.optimizer.state_dict()["state"].values()} == steps
-    # default flags (the reference's mixed_precision=True alone) keep the fp32-class path: no scaler
+    # the suite pins the bare flag to the fp32-class path (tests/conftest.py: TEM_MIXED_PRECISION=0): no scaler
     t2 = torch_em_amd.default_segmentation_trainer("fp32", model, loader, loader, device=DEV, logger=None,
                                                    save_root=str(tmp_path))
     assert t2.scaler is None and not t2._amp
+
+
+def test_mixed_precision_default_flag(tmp_path, monkeypatch):
+    """What `mixed_precision` means without a dtype (reference trainer/default_trainer.py:132-140: True is the default and
+    selects autocast(float16) + GradScaler on a GPU): the product default follows the reference since round 6; False -- or
+    TEM_MIXED_PRECISION=0 for scripts that cannot be edited -- is the parity-grade fp32-class path."""
+    import torch_em_amd
+    from torch_em_amd.model import UNet3d
+    from torch_em_amd.optim import GradScaler
+    torch.manual_seed(0)
+    model = UNet3d(1, 2, depth=1, initial_features=32)
+    g = torch.Generator().manual_seed(0)
+    ds = torch.utils.data.TensorDataset(torch.randn(2, 1, 8, 16, 16, generator=g),
+                                        (torch.rand(2, 2, 8, 16, 16, generator=g) > 0.5).float())
+    loader = torch.utils.data.DataLoader(ds, batch_size=1)
+
+    def make(**kw):
+        return torch_em_amd.default_segmentation_trainer("d", model, loader, loader, device=DEV, logger=None,
+                                                         save_root=str(tmp_path), **kw)
+    monkeypatch.delenv("TEM_MIXED_PRECISION", raising=False)
+    t = make()                                            # the reference's defaults
+    assert t.mixed_precision and t._amp and not t._amp_bf16 and isinstance(t.scaler, GradScaler) and t.scaler.is_enabled()
+    assert t.mixed_precision_dtype == "float16"
+    t.fit(iterations=2)
+    ck = torch.load(os.path.join(t.checkpoint_folder, "latest.pt"), weights_only=False)
+    assert ck["scaler_state"]["scale"] == t.scaler.get_scale() and ck["init"]["mixed_precision"] is True
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    t = make(mixed_precision=False)
+    assert t.scaler is None and not t._amp and not t._amp_bf16
+    t = make(mixed_precision_dtype="bfloat16")
+    assert t._amp_bf16 and not t._amp and not t.scaler.is_enabled()
+    monkeypatch.setenv("TEM_MIXED_PRECISION", "0")
+    t = make()
+    assert t.scaler is None and not t._amp                # the bare flag pinned to the fp32-class path
+    t = make(mixed_precision_dtype="float16")
+    assert t._amp                                         # an explicit dtype always wins
 
 
 def test_default_trainer_matches_the_reference_trainer_run(tmp_path):
