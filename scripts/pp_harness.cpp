@@ -37,7 +37,9 @@ int main(int argc, char** argv) {
     uint64_t seed = 1234;
     std::vector<float> hx(V * Cin), hw((size_t)Cout * Cin * 27), hb(Cout), hs((size_t)N * Cin), hf((size_t)N * Cin);
     for (auto& v : hx) v = 2.f * frand(seed);
+    if (getenv("ZERO_X")) for (auto& v : hx) v = 0.f;   // power experiment: all-zero activations (run with norm 0: the staged operands are zeros)
     for (auto& v : hw) v = 0.05f * frand(seed);
+    if (getenv("ZERO_W")) for (auto& v : hw) v = 0.f;
     for (auto& v : hb) v = frand(seed);
     for (auto& v : hs) v = 1.f + 0.5f * frand(seed);
     for (auto& v : hf) v = frand(seed);

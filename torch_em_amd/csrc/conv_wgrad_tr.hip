@@ -52,6 +52,25 @@ typedef __amdgpu_buffer_rsrc_t tr_rsrc_t;
 typedef float tr_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int tr_u4 __attribute__((ext_vector_type(4)));
 
+// The per-plane barrier of the MULTIPLYING team.  __syncthreads() is fence(release) + s_barrier + fence(acquire), and the release
+// costs `s_waitcnt lgkmcnt(0)`: every transposing read in flight -- the fragments of the NEXT plane, requested during the last
+// MFMAs of this one precisely so that they travel across the barrier -- had to land first: one exposed LDS round trip per
+// plane (round 6, found in the ISA: lgkmcnt(0) in front of every s_barrier of the plane loop).  This team writes nothing to
+// LDS inside the plane loop, so it has nothing to release; what it reads after the barrier was written (and waited for) by the
+// staging team before it, and the LDS serves requests in arrival order.  The empty asm keeps the compiler from moving a
+// read across the barrier.  TEM_TR_SYNC=1 restores __syncthreads().
+#ifndef TEM_TR_SYNC
+#define TEM_TR_SYNC 0
+#endif
+__device__ __forceinline__ void tr_barrier_mult() {
+    if (TEM_TR_SYNC) {
+        __syncthreads();
+        return;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
     const tr_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_p)(p));
     return __builtin_bit_cast(uint2, v);
@@ -109,6 +128,9 @@ __device__ __forceinline__ unsigned tr_mix_scale(float g0, float g1, float sc) {
 #endif
 #ifndef TEM_TR_PF2
 #define TEM_TR_PF2 1   // one-term modes: fragments of slab s + 2 are read during the MFMAs of slab s (four register sets; 0: s + 1, two sets)
+#endif
+#ifndef TEM_TR_SHARE
+#define TEM_TR_SHARE 1   // one-term modes (round 6): row groups (tz, ty = 0) and (tz, ty = 2) of one wave share their x windows (0: the PF2 loop)
 #endif
 #ifndef TEM_TR_RTZ
 #define TEM_TR_RTZ 0    // experiment: hi term of x^ by v_cvt_pkrtz_f16_f32 (one instruction per pair; the split stays exact, lo grows to 1 ulp)
@@ -285,7 +307,173 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
             // the load of eight waves takes longer than that to return -- with one slab of lead every slab still waited
             // (counters of the amp step: matrix pipe 0.44 busy at 2.2 GHz, not power-limited).  Four register sets named by the
             // slab index (four slabs per plane: static names), 170 -> ~235 VGPRs of the 256 this kernel may use.
-            constexpr bool PF2 = NX == 1 && !FP32 && TEM_TR_PF2;
+            // ---- one-term modes, round 6: SHARED WINDOWS ------------------------------------------------------------------
+            // The one-term kernel is bound by LDS bandwidth: 14 transposing reads per slab and wave x 4 waves x 512 B = 28 KB per
+            // 224 cycles of MFMAs = the 128 B / clock the LDS delivers.  The fragment of tap (tz, ty = 2) at slab s -- halo rows
+            // 2 s + 2, 2 s + 3 -- IS the fragment of tap (tz, ty = 0) at slab s + 1, so a wave that owns both row groups of one tz
+            // reads FIVE 12-voxel windows per plane instead of eight.  Ownership: waves 0..2 = (tz = wave, ty = 0), (tz = wave,
+            // ty = 2) and one tap of (tz = 2, ty = 1); wave 3 = (0, 1) and (1, 1), no shared rows.  Reads per plane and CU
+            // 224 -> 171.  Window k of a plane lives in register set k & 3; a set is refilled as soon as the last MFMA group that
+            // reads it has been issued, two slabs before its next use; the B group (ty = 2) of a slab is issued before the A
+            // group, so that window 0 of the NEXT plane can follow window 4 into set 0 inside slab 3.
+            constexpr bool SH = NX == 1 && !FP32 && TEM_TR_SHARE;
+            if constexpr (SH) {
+                auto wbase = [&](int t, int tz, int ro) -> const unsigned char* {
+                    return X0 + lane_x + TR_XSLOT(t + tz - 1) + ro * TR_XROW;
+                };
+                auto rd_win = [&](uint4* f, const unsigned char* p) {   // taps tx = 0, 1, 2 of one row pair: 3 + 2 transposing reads
+                    const uint2 w0 = tr_read(p), w1 = tr_read(p + 4 * TR_REC), w2 = tr_read(p + 8 * TR_REC);
+                    f[0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
+                    f[1] = tr_frag(p + TR_REC16);
+                    f[2] = make_uint4(w0.y, w1.x, w1.y, w2.x);
+                };
+                uint4 Bw[4][3], gq[4], eq[4];
+                if (wv < 3) {
+                    {
+                        const unsigned char* wb = wbase(za, wv, 0);
+                        rd_win(Bw[0], wb);
+                        rd_win(Bw[1], wb + 2 * TR_XROW);
+                        rd_win(Bw[2], wb + 4 * TR_XROW);
+                        const unsigned char* eb = wbase(za, 2, 1) + wv * TR_REC;
+                        eq[0] = tr_frag(eb);
+                        eq[1] = tr_frag(eb + 2 * TR_XROW);
+                        const unsigned char* gb = G0 + lane_g + TR_GSLOT(za);
+                        gq[0] = tr_frag(gb);
+                        gq[1] = tr_frag(gb + 16 * TR_REC);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll 1
+                    for (int t = za; t < zb; ++t) {
+                        const unsigned char *wb = wbase(t, wv, 0), *wbn = wbase(t + 1, wv, 0);
+                        const unsigned char *eb = wbase(t, 2, 1) + wv * TR_REC, *ebn = wbase(t + 1, 2, 1) + wv * TR_REC;
+                        const unsigned char *gb = G0 + lane_g + TR_GSLOT(t), *gbn = G0 + lane_g + TR_GSLOT(t + 1);
+                        TR_STAMP(t - za, 0);
+                        if (TEM_TR_ABL & 2) {
+                            __syncthreads();
+                            continue;
+                        }
+                        TR_STAMP(t - za, 1);
+                        auto group = [&](int a0, const uint4* f, const uint4& gg) {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc[a0 + j] = mfma16<F16>(f[j], gg, acc[a0 + j]);
+                        };
+                        auto pat9 = [&]() {   // 7 MFMAs, 9 reads
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        };
+                        // slab 0: windows 0 (set 0), 1 (set 1); window 3 -> set 3
+                        rd_win(Bw[3], wb + 6 * TR_XROW);
+                        gq[2] = tr_frag(gb + 2 * 16 * TR_REC);
+                        eq[2] = tr_frag(eb + 4 * TR_XROW);
+                        group(3, Bw[1], gq[0]);
+                        group(0, Bw[0], gq[0]);
+                        acc[6] = mfma16<F16>(eq[0], gq[0], acc[6]);
+                        pat9();
+                        // slab 1: windows 1, 2; window 4 -> set 0
+                        rd_win(Bw[0], wb + 8 * TR_XROW);
+                        gq[3] = tr_frag(gb + 3 * 16 * TR_REC);
+                        eq[3] = tr_frag(eb + 6 * TR_XROW);
+                        group(3, Bw[2], gq[1]);
+                        group(0, Bw[1], gq[1]);
+                        acc[6] = mfma16<F16>(eq[1], gq[1], acc[6]);
+                        pat9();
+                        // slab 2: windows 2, 3; window 1 of the NEXT plane -> set 1
+                        rd_win(Bw[1], wbn + 2 * TR_XROW);
+                        gq[0] = tr_frag(gbn);
+                        eq[0] = tr_frag(ebn);
+                        group(3, Bw[3], gq[2]);
+                        group(0, Bw[2], gq[2]);
+                        acc[6] = mfma16<F16>(eq[2], gq[2], acc[6]);
+                        pat9();
+                        // slab 3: windows 3 (set 3), 4 (set 0); windows 2 and -- behind the MFMAs that read set 0 -- 0 of the next plane
+                        rd_win(Bw[2], wbn + 4 * TR_XROW);
+                        gq[1] = tr_frag(gbn + 16 * TR_REC);
+                        eq[1] = tr_frag(ebn + 2 * TR_XROW);
+                        group(3, Bw[0], gq[3]);
+                        rd_win(Bw[0], wbn);
+                        group(0, Bw[3], gq[3]);
+                        acc[6] = mfma16<F16>(eq[3], gq[3], acc[6]);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        TR_STAMP(t - za, 2);
+                        tr_barrier_mult();
+                        TR_STAMP(t - za, 3);
+                    }
+                } else {
+                    // wave 3: row groups (tz = 0, ty = 1) [A, accumulators 0..2] and (tz = 1, ty = 1) [B, 3..5]: different halo planes,
+                    // nothing to share.  Slab s uses sets 2 (s & 1) and 2 (s & 1) + 1; each is refilled for slab s + 2 right behind
+                    // the three MFMAs that read it (two slabs of lead, as the shared windows have).
+                    {
+                        const unsigned char *ab = wbase(za, 0, 1), *bb = wbase(za, 1, 1);
+                        rd_win(Bw[0], ab);
+                        rd_win(Bw[1], bb);
+                        rd_win(Bw[2], ab + 2 * TR_XROW);
+                        rd_win(Bw[3], bb + 2 * TR_XROW);
+                        const unsigned char* gb = G0 + lane_g + TR_GSLOT(za);
+                        gq[0] = tr_frag(gb);
+                        gq[1] = tr_frag(gb + 16 * TR_REC);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll 1
+                    for (int t = za; t < zb; ++t) {
+                        const unsigned char *ab = wbase(t, 0, 1), *bb = wbase(t, 1, 1);
+                        const unsigned char *abn = wbase(t + 1, 0, 1), *bbn = wbase(t + 1, 1, 1);
+                        const unsigned char *gb = G0 + lane_g + TR_GSLOT(t), *gbn = G0 + lane_g + TR_GSLOT(t + 1);
+                        TR_STAMP(t - za, 0);
+                        if (TEM_TR_ABL & 2) {
+                            __syncthreads();
+                            continue;
+                        }
+                        TR_STAMP(t - za, 1);
+#pragma unroll
+                        for (int sl = 0; sl < 4; ++sl) {
+                            const int nsl = (sl + 2) & 3;
+                            uint4* const pa = Bw[2 * (sl & 1)];
+                            uint4* const pb = Bw[2 * (sl & 1) + 1];
+                            gq[nsl] = tr_frag((sl < 2 ? gb : gbn) + nsl * 16 * TR_REC);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc[3 + j] = mfma16<F16>(pb[j], gq[sl], acc[3 + j]);
+                            rd_win(pb, (sl < 2 ? bb : bbn) + nsl * 2 * TR_XROW);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc[j] = mfma16<F16>(pa[j], gq[sl], acc[j]);
+                            rd_win(pa, (sl < 2 ? ab : abn) + nsl * 2 * TR_XROW);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        TR_STAMP(t - za, 2);
+                        tr_barrier_mult();
+                        TR_STAMP(t - za, 3);
+                    }
+                }
+                for (int e = zb - za + 6; e % (T16 ? TR_UNROLL : TR_UNROLL32); ++e) __syncthreads();
+                continue;
+            }
+            constexpr bool PF2 = NX == 1 && !FP32 && TEM_TR_PF2 && !SH;
             uint4 xq[PF2 ? 4 : 1][NA], gq[PF2 ? 4 : 1];
             if constexpr (PF2) {
                 const unsigned char* xb0[3];
@@ -332,7 +520,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                         for (int j = 0; j < NA; ++j) xc[j] = xn[j];
                         gc = gn;
                     }
-                    __syncthreads();
+                    tr_barrier_mult();
                 }
                 for (int e = zb - za + 6; e % TR_UNROLL32; ++e) __syncthreads();
                 continue;
@@ -359,7 +547,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                         interleave();
                     }
                     TR_STAMP(t - za, 2);
-                    __syncthreads();
+                    tr_barrier_mult();
                     TR_STAMP(t - za, 3);
                     continue;
                 }
@@ -401,7 +589,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                     interleave();
                 }
                 TR_STAMP(t - za, 2);
-                __syncthreads();
+                tr_barrier_mult();
                 TR_STAMP(t - za, 3);
             }
             // the staging team walks a segment in trips of TR_UNROLL (16-bit tensors) / TR_UNROLL32 iterations
@@ -414,7 +602,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 if (j == 6 && wv >= 3) break;
-                const int tap = (j < 6) ? (wv + 4 * (j / 3)) * 3 + (j % 3) : 8 * 3 + wv;
+                // shared windows (one-term modes): waves 0..2 hold row groups (wave, 0), (wave, 2) and tap tx = wave of row group (2, 1),
+                // wave 3 row groups (0, 1) and (1, 1); else row groups wave, wave + 4 and tap tx = wave of row group 8
+                constexpr bool SHT = NX == 1 && !FP32 && TEM_TR_SHARE;
+                const int tap = SHT ? (wv < 3 ? (j < 3 ? (wv * 3) * 3 + j : j < 6 ? (wv * 3 + 2) * 3 + (j - 3) : 7 * 3 + wv)
+                                              : (j < 3 ? 1 * 3 + j : 4 * 3 + (j - 3)))
+                                    : (j < 6) ? (wv + 4 * (j / 3)) * 3 + (j % 3) : 8 * 3 + wv;
                 float* dst = part + (((int64_t)sp * NT + tap) * Cin + cit * 32) * Cout + cog * 32 + r;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
@@ -708,13 +901,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_tr(const TS* __restrict__
                     const int zx = t + 5;
                     const int ldx = (int)(zx >= za - 1) & (int)(zx <= zb) & (int)(zx >= 0) & (int)(zx < D) & (int)!(TEM_TR_ABL & 8);   // wave-uniform
                     zin_ = ldx != 0;
-                    const tr_rsrc_t rsx = tr_rsrc(xn + (int64_t)(zx * ldx) * xplane);
+                    // (TEM_TR_ABL & 16, timing only: every plane is read from z = 0 -- the loads stay, the HBM traffic goes)
+                    const tr_rsrc_t rsx = tr_rsrc(xn + (int64_t)((TEM_TR_ABL & 16) ? 0 : zx * ldx) * xplane);
                     const unsigned mx = ldx ? 0u : OOB;   // OR-ed into the offsets (< 2^31): beyond the buffer -> zeros
 #pragma unroll
                     for (int q = 0; q < 4; ++q) xs_[q] = tr_load4(rsx, offx[q] | mx);
                     const int zg = t + 4;
                     const int ldg = (int)(zg >= za) & (int)(zg < zb) & (int)!(TEM_TR_ABL & 8);
-                    const tr_rsrc_t rsg = tr_rsrc(gn + (int64_t)(zg * ldg) * gplane);
+                    const tr_rsrc_t rsg = tr_rsrc(gn + (int64_t)((TEM_TR_ABL & 16) ? 0 : zg * ldg) * gplane);
                     const unsigned mg = ldg ? 0u : OOB;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) gs_[q] = tr_load4(rsg, offg[q] | mg);
