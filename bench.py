@@ -159,7 +159,9 @@ def extra_measurements(step, args, engine):
                         "flops_frac_16bit_mfma": STEP_GFLOP / t / PEAK_BF16_MFMA_TFLOPS,
                         "hbm_frac_8TBs": (gb / (t / 1e3)) / (PEAK_HBM_TBS * 1e3),
                         "note": f"{gb:.2f} GB algorithmic per step: the 25.58 GB of SURVEY.md 8(d) "
-                                + ("halved, every activation / gradient tensor is 2 bytes per element" if st16 else
+                                + ("halved: every activation / gradient tensor is 2 bytes per element (a LOWER bound on the bytes: "
+                                   "network input, prediction, statistics, packed weights and the gradient arena stay fp32, so "
+                                   "hbm_frac is slightly understated)" if st16 else
                                    "(fp32 tensors: TEM_AMP_STORAGE=32)")
                                 + "; one 16-bit MFMA per product => the step is HBM-bound in this mode"}
                 out["modes"]["exact_fp32" if prec == "fp32" else prec] = m
@@ -480,7 +482,7 @@ def main():
         achieved = dom["flops"] / dom["ms"] / 1e9  # TFLOP/s (algorithmic: 2*MACs of the convolution)
         split = 6 if "bf16x6" in dom_tag else (3 if ("bf16x3" in dom_tag or "f16x3" in dom_tag) else
                                                2 if "f16x2" in dom_tag else 1 if "_f16<" in dom_tag else 0)
-        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_bytes_per_launch.json") for r in (5, 4, 3, 2, 1))
+        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_bytes_per_launch.json") for r in (6, 5, 4, 3, 2, 1))
                              if os.path.exists(f)), "")
         # split-bf16 kernels execute 3 (or 6) bf16 MFMAs per algorithmic product: effective peak = dense bf16 peak / 3 (6)
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS

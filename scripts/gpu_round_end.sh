@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- 'bash scripts/gpu_round_end.sh r04'): everything behind profiles/<tag>_*: rocprofv3 kernel
 # stats + PMC passes of the bench command, their summaries, the SQ stall counters, the full bench line and the GPU suite.
-tag=${1:-r04}
+tag=${1:-r06}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $O
@@ -22,6 +22,13 @@ for m in amp amp_bf16; do
   [ -n "$f" ] && python scripts/step_trace.py $f > $O/${tag}_step_trace_$m.txt 2>&1
 done
 find $O -name "*.csv" -size +2M -delete; find $O -name "*.db" -delete
+# matrix-pipe utilisation and clock of the other arithmetics of the same step (round 6: is a mode at the socket power limit?)
+for m in amp fp32; do
+  rm -rf /tmp/sq_$m
+  C="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 3 --precision $m --no-cpu-baseline --no-extras"
+  (cd /tmp && TEM_BENCH_PREWARM_S=0 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d /tmp/sq_$m -o bench -- $C > $O/sq_$m.log 2>&1)
+  python scripts/mfma_busy.py /tmp/sq_$m "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- $C" > $O/${tag}_mfma_busy_$m.txt 2>&1
+done
 bash scripts/collect_stalls.sh $tag >> $O/collect.log 2>&1
 find $O -name "*.csv" -size +2M -delete
 timeout 1500 python bench.py --kernel-table $O/${tag}_bench_kernel_table.txt > $O/${tag}_bench.json 2> $O/bench.err
