@@ -34,7 +34,7 @@ for f in glob.glob(sys.argv[1] + "/*/b_counter_collection.csv"):
         k = r["Kernel_Name"].replace("void ", "").split("(")[0]
         if k.startswith("_Z"):   # rocprofv3 (and c++filt) leave kernels with _Float16 / __bf16 template arguments mangled
             k = demangle(k)
-        if k.startswith("k_conv_zr<2") or k.startswith("k_conv_wgrad_zs") or k.startswith("k_conv_wgrad_tr"):
+        if k.startswith("k_conv_zr<2") or k.startswith("k_conv_wgrad_zs") or k.startswith("k_conv_wgrad_tr") or k.startswith("k_conv_fwd_mfma"):
             agg[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])   # sum over XCCs / instances of a dispatch
 names = sorted({c for v in agg.values() for c in v})
 for k, v in sorted(agg.items()):

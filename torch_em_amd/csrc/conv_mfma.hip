@@ -25,6 +25,12 @@
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifndef TEM_MF_RD
+#define TEM_MF_RD 0      // weight ring depth of the forward kernels (0: 3 for 32-column tiles, 2 for 64-column tiles)
+#endif
+#ifndef TEM_MF_OCC2
+#define TEM_MF_OCC2 2    // workgroups per CU of the 64-column instantiations
+#endif
 #define CK 16      // input channels per staged chunk (fwd)
 #define LSF 20     // LDS floats per halo voxel (16 + 4 pad -> 80 B, keeps b128 alignment)
 
@@ -38,7 +44,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // forward / dgrad
 // ---------------------------------------------------------------------------
 template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? 2 : 3)) void k_conv_fwd_mfma(
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? TEM_MF_OCC2 : 3)) void k_conv_fwd_mfma(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? 2 : 3)) void k_co
     const int chunk_begin = ks * cpk, chunk_end = (ks + 1) * cpk;
     constexpr int NG = 2 * NT;                       // k-groups (8 input channels each) per chunk
     // ring depth (NG % RD == 0 keeps the phase across chunks); one k-group is 8*NR MFMAs = 512*NR cycles
-    constexpr int RD = (NR == 1 && NG % 3 == 0) ? 3 : 2;
+    constexpr int RD = (TEM_MF_RD && NG % TEM_MF_RD == 0) ? TEM_MF_RD : (NR == 1 && NG % 3 == 0) ? 3 : 2;
     const int tapstride = cin8 * 64;
     const float4* wq[NR];  // this lane's slot in the first fragment of each column tile
 #pragma unroll
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? 2 : 3)) void k_co
 // last weight-ring load of the step so that no in-order vmcnt wait of the ring sits behind them.
 // ---------------------------------------------------------------------------
 template <int KD, int KH, int KW, int TZ, int TY, int TX, int NR>
-__global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_conv_fwd_mfma_p(
+__global__ __launch_bounds__(256, NR == 1 ? 3 : TEM_MF_OCC2) void k_conv_fwd_mfma_p(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld,
     const float* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_conv_fwd_mfma_p(
     constexpr int HV = HZ * HY * HX;
     constexpr int NIT = (HV * 4 + 255) / 256;
     constexpr int NG = 2 * NT;
-    constexpr int RD = (NR == 1 && NG % 3 == 0) ? 3 : 2;
+    constexpr int RD = (TEM_MF_RD && NG % TEM_MF_RD == 0) ? TEM_MF_RD : (NR == 1 && NG % 3 == 0) ? 3 : 2;
     constexpr int GH = NG - RD + 1 > 0 ? NG - RD + 1 : 0;  // k-group after whose ring issue the halo prefetch goes out
     static_assert(TZ * TY * TX == 256, "patch must hold 256 voxels");
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [HV][LSF]
@@ -673,7 +679,7 @@ static void launch_fwd(const float* x, int64_t x_ld, const float* scale, const f
             ncu = tem_device_cus();
             if (ncu <= 0) ncu = 256;
         }
-        const int bpc = NR == 1 ? 3 : 2;
+        const int bpc = NR == 1 ? 3 : TEM_MF_OCC2;
         const int64_t grid = nblk < (int64_t)ncu * bpc ? nblk : (int64_t)ncu * bpc;
         hipLaunchKernelGGL((k_conv_fwd_mfma_p<KD, KH, KW, TZ, TY, TX, NR>), dim3((unsigned)grid), dim3(256), ldsb, s, x,
                            x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, nZ, nY, nX,

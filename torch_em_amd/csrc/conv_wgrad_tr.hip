@@ -130,7 +130,9 @@ __device__ __forceinline__ unsigned tr_mix_scale(float g0, float g1, float sc) {
 #define TEM_TR_PF2 1   // one-term modes: fragments of slab s + 2 are read during the MFMAs of slab s (four register sets; 0: s + 1, two sets)
 #endif
 #ifndef TEM_TR_SHARE
-#define TEM_TR_SHARE 1   // one-term modes (round 6): row groups (tz, ty = 0) and (tz, ty = 2) of one wave share their x windows (0: the PF2 loop)
+#define TEM_TR_SHARE 0   // one-term modes (round 6 experiment): row groups (tz, ty = 0) and (tz, ty = 2) of one wave share their x windows -- 24 % fewer
+                         // LDS reads, bit-identical results, -1.5 .. 3 % in the harness on dense operands and +-0.5 % in the amp step
+                         // (profiles/r06_wgrad_tr_ablations.txt): off, the PF2 loop stays the product path
 #endif
 #ifndef TEM_TR_RTZ
 #define TEM_TR_RTZ 0    // experiment: hi term of x^ by v_cvt_pkrtz_f16_f32 (one instruction per pair; the split stays exact, lo grows to 1 ulp)
