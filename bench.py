@@ -385,6 +385,7 @@ def main():
     # all-reduces are nodes of it).  Per-launch events cannot be taken inside a replay, so the dominant kernel's events and
     # the exposed all-reduce time come from `ev_eager` eager steps right before the timed region.
     graphed = None
+    graph_error = None
     ddp_exposed_eager = None
     # N > 1: the graph replay is the DEFAULT (eight ranks share one host: ~5 ms of Python enqueue per step and rank against
     # one hipGraphLaunch); TEM_HIP_GRAPH=0 / 1 overrides in both directions.
@@ -398,13 +399,26 @@ def main():
         if isinstance(model, DDP):
             ddp_exposed_eager = model.sync.exposed_ms()
         eager_dom_prof, ops.PROFILER, ops.PROFILER_FILTER = ops.PROFILER or [], None, None
-        graphed = GraphedTrainStep(model, loss_fn, opt, x, y)
-        for _ in range(2):
-            graphed(x, y)
-        torch.cuda.synchronize()
+        # the capture (incl. the RCCL all-reduces at N > 1) and two replays; a rank whose capture raises falls back to eager
+        # launches -- TOGETHER with every other rank (the flag is MIN-reduced), so that a first contact with a multi-GPU RCCL
+        # capture that does not work costs the graph, not the run
+        try:
+            graphed = GraphedTrainStep(model, loss_fn, opt, x, y)
+            for _ in range(2):
+                graphed(x, y)
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            graph_error, graphed = f"{type(e).__name__}: {e}", None
         if world > 1:
+            ok = torch.tensor([0.0 if graph_error else 1.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0 and graphed is not None:
+                graph_error, graphed = "another rank could not capture the step", None
             dist.barrier()
-        ev_steps = set()
+        if graphed is not None:
+            ev_steps = set()
+        elif rank == 0:
+            print(f"bench.py: HIP-graph capture failed ({graph_error}); timing eager launches", file=sys.stderr)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if ev_steps:
@@ -420,6 +434,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dom_prof, ops.PROFILER, ops.PROFILER_FILTER = ops.PROFILER or [], None, None
+    if use_graph and graphed is None and not dom_prof:
+        dom_prof = eager_dom_prof   # capture failed: the eager steps in front of the timed region carried the events
     if graphed is not None:
         dom_prof, ev_steps = eager_dom_prof, (set(range(n_ev)) if (rank == 0 and dom_tag is not None) else set())
     per_rank_ms = [elapsed / args.steps * 1e3]
@@ -530,6 +546,8 @@ def main():
                          "avg_launch_ms": dom["ms"] / dom["launches"],
                          "flops_per_launch_avg": dom["flops"] / dom["launches"]},
         }
+        if graph_error is not None:
+            out["step_mode"] += f" (the HIP-graph replay that is the default for --gpus > 1 could not be captured: {graph_error})"
         if ddp_info is not None:
             out["ddp"] = ddp_info
         if standard:
