@@ -29,6 +29,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef TEM_MF_RD
 #define TEM_MF_RD 0      // weight ring depth of the forward kernels (0: 3 for 32-column tiles, 2 for 64-column tiles)
 #endif
+#ifndef TEM_MF_KOUTER
+#define TEM_MF_KOUTER 1  // MFMA order inside a k-group: k-step outermost (1) or the four k-steps of one accumulator back to back (0, rounds 1-5)
+#endif
 #ifndef TEM_MF_OCC2
 #define TEM_MF_OCC2 2    // workgroups per CU of the 64-column instantiations
 #endif
@@ -275,15 +278,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? TEM_MF_OCC2 : 3))
 #pragma unroll
             for (int m = 0; m < 2; ++m)
                 a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff + kg * 8);
+            // k-step outermost (TEM_MF_KOUTER): consecutive MFMAs go to DIFFERENT accumulators -- a dependent v_mfma_f32_32x32x2_f32
+            // cannot start before its predecessor's 16 passes have written back
+#pragma unroll
+            for (int kq = 0; kq < (TEM_MF_KOUTER ? 4 : 1); ++kq)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int nn = 0; nn < NR; ++nn) {
                     const float4 bb = bq[g % RD][nn];
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bb.x, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bb.y, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bb.z, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bb.w, acc[m][nn], 0, 0, 0);
+                    if (!TEM_MF_KOUTER || kq == 0) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bb.x, acc[m][nn], 0, 0, 0);
+                    if (!TEM_MF_KOUTER || kq == 1) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bb.y, acc[m][nn], 0, 0, 0);
+                    if (!TEM_MF_KOUTER || kq == 2) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bb.z, acc[m][nn], 0, 0, 0);
+                    if (!TEM_MF_KOUTER || kq == 3) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bb.w, acc[m][nn], 0, 0, 0);
                 }
         }
     }
@@ -468,15 +475,19 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : TEM_MF_OCC2) void k_conv_fwd_mfm
             float4 a[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff + kg * 8);
+            // k-step outermost (TEM_MF_KOUTER): consecutive MFMAs go to DIFFERENT accumulators -- a dependent v_mfma_f32_32x32x2_f32
+            // cannot start before its predecessor's 16 passes have written back
+#pragma unroll
+            for (int kq = 0; kq < (TEM_MF_KOUTER ? 4 : 1); ++kq)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int nn = 0; nn < NR; ++nn) {
                     const float4 bb = bq[g % RD][nn];
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bb.x, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bb.y, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bb.z, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bb.w, acc[m][nn], 0, 0, 0);
+                    if (!TEM_MF_KOUTER || kq == 0) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bb.x, acc[m][nn], 0, 0, 0);
+                    if (!TEM_MF_KOUTER || kq == 1) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bb.y, acc[m][nn], 0, 0, 0);
+                    if (!TEM_MF_KOUTER || kq == 2) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bb.z, acc[m][nn], 0, 0, 0);
+                    if (!TEM_MF_KOUTER || kq == 3) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bb.w, acc[m][nn], 0, 0, 0);
                 }
         }
         first = false;
