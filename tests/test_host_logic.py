@@ -276,3 +276,18 @@ def test_bench_self_launches_one_rank_per_gpu():
     assert p.returncode != 0
     assert "No HIP GPUs are available" in err or "set_device" in err, err[-2000:]
     assert "WORLD_SIZE" not in err.split("Traceback")[0] or "assert" not in err
+
+
+def test_bench_cpu_list_parser_and_numa_pinning_is_harmless_without_a_gpu():
+    """bench.py pins each rank of an N > 1 run to the NUMA node of its GPU; the /sys parsing must never cost a run."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert bench._cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    info = bench.pin_rank_to_gpu_numa_node(0, 2)     # no GPU here: the device query raises, the function reports it and pins nothing
+    assert "error" in info and os.sched_getaffinity(0) == before

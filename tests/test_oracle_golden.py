@@ -321,3 +321,35 @@ def test_predict_oracle_matches_the_reference_helpers():
     o = np.full((7, 9, 11), -7.0, dtype="float32")
     predict_ref.write_prediction(g["wp.pred"].copy(), begin, end, o, 3, mb, inner, lambda p: p[1] * 2.0)
     assert np.array_equal(o, g["wp.out_post"])
+
+
+def test_oracle_at_mfma_widths_matches_the_reference_float64_and_fp32_steps():
+    """G10 (tests/golden/gen_golden_amp_step.py): ONE step of the reference's UNet3d(1, 2, depth=2, initial_features=32) on
+    1x1x16x24x32 in float64 and in float32.  Pins the oracle at the widths the MFMA kernels run at: its float64 gradients equal the
+    reference's (stored as float32: 1e-6), its float32 step sits at the reference's own fp32 distance from float64."""
+    import hashlib
+    from torch_em_amd.model import UNet3d
+    g = _load("g10_amp_step.npz")
+    torch.manual_seed(0)
+    model = UNet3d(1, 2, depth=2, initial_features=32)
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        h.update(k.encode())
+        h.update(v.detach().contiguous().numpy().tobytes())
+    assert h.hexdigest() == str(g["sd_sha256"])     # this repo's seed-0 initialisation IS the reference's
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    names = [str(n) for n in g["param_names"]]
+    pred, loss, grads = unet_ref.unet_loss_and_grads({k: v.double() for k, v in sd.items()}, x.double(), y.double(), [2, 2])
+    assert rel_err(pred, g["f64.pred"]) < 1e-12 and abs(float(loss) - float(g["f64.loss"])) < 1e-12
+    gscale = float(np.sqrt((g["f64.grad_norm"] ** 2).sum()))
+    for k, n64 in zip(names, g["f64.grad_norm"]):
+        ref = g[f"f64.grad.{k}"].astype("float64")
+        err = float(np.linalg.norm(grads[k].numpy() - ref))
+        assert err <= 2e-7 * max(float(n64), 1e-6 * gscale), (k, err, n64)      # float32 storage of the fixture
+    # the oracle's fp32 step: the distance the reference's fp32 step has from float64, tensor by tensor (same ATen kernels)
+    pred32, loss32, g32 = unet_ref.unet_loss_and_grads(sd, x, y, [2, 2])
+    assert abs(float(loss32) - float(g["f32.loss"])) < 1e-6
+    for k, n64, e_ref in zip(names, g["f64.grad_norm"], g["f32.grad_err"]):
+        err = float(np.linalg.norm(g32[k].double().numpy() - g[f"f64.grad.{k}"].astype("float64")))
+        assert err <= 3.0 * max(float(e_ref), 1e-6 * gscale), (k, err, e_ref)
