@@ -32,6 +32,21 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef TEM_MF_KOUTER
 #define TEM_MF_KOUTER 1  // MFMA order inside a k-group: k-step outermost (1) or the four k-steps of one accumulator back to back (0, rounds 1-5)
 #endif
+#ifndef TEM_MF_APF
+#define TEM_MF_APF 1     // A fragments of k-group g + 1 are requested before the MFMAs of k-group g
+#endif
+#ifndef TEM_MF_EARLY_HALO
+#define TEM_MF_EARLY_HALO 0   // persistent forward kernel: the next step's halo is requested in front of the first k-group (1) or behind the last
+                              // ring load of the step (0).  Measured (profiles/r06_fp32_variants.txt): early is SLOWER (0.646 against 0.631 ms per
+                              // launch) -- vmcnt counts in order, so every wait for a ring load issued after the prefetch waits for the ten
+                              // HBM loads in front of it; deeper rings (6 / 9 k-groups of cover) do not buy it back
+#endif
+#ifndef TEM_MF_RD1
+#define TEM_MF_RD1 0     // persistent kernel, 32-column tiles: weight ring depth (0: as TEM_MF_RD)
+#endif
+#ifndef TEM_MF_RD2
+#define TEM_MF_RD2 0     // persistent kernel, 64-column tiles
+#endif
 #ifndef TEM_MF_OCC2
 #define TEM_MF_OCC2 2    // workgroups per CU of the 64-column instantiations
 #endif
@@ -256,6 +271,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? TEM_MF_OCC2 : 3))
         // its use: PMC showed the matrix pipe 28% idle.)
         int ts = tapstride;
         asm volatile("" : "+s"(ts));  // opaque per chunk: keeps LICM from hoisting 2*NT address pairs out of the loop
+        float4 apf[2];
+        if (TEM_MF_APF) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) apf[m] = *reinterpret_cast<const float4*>(lds + abase[m]);   // tap 0, k-group 0
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int tap = g >> 1, kg = g & 1;
@@ -274,10 +294,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NR == 2 ? TEM_MF_OCC2 : 3))
                 }
                 __builtin_amdgcn_sched_barrier(0x38F);  // everything but VMEM may cross: keep the loads early
             }
+            // A fragments one k-group AHEAD (TEM_MF_APF, round 6): left to itself hipcc issues the two ds_read_b128 of a k-group one MFMA
+            // before the MFMAs that consume them -- an LDS round trip in front of every 8 NR MFMAs of the wave
             float4 a[2];
+            if (TEM_MF_APF) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-                a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff + kg * 8);
+                for (int m = 0; m < 2; ++m) a[m] = apf[m];
+                if (g + 1 < NG) {
+                    const int tap1 = (g + 1) >> 1, kg1 = (g + 1) & 1;
+                    const int toff1 = (((tap1 / (KH * KW)) * HY + (tap1 / KW) % KH) * HX + tap1 % KW) * LSF;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) apf[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff1 + kg1 * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff + kg * 8);
+            }
             // k-step outermost (TEM_MF_KOUTER): consecutive MFMAs go to DIFFERENT accumulators -- a dependent v_mfma_f32_32x32x2_f32
             // cannot start before its predecessor's 16 passes have written back
 #pragma unroll
@@ -322,8 +355,11 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : TEM_MF_OCC2) void k_conv_fwd_mfm
     constexpr int HV = HZ * HY * HX;
     constexpr int NIT = (HV * 4 + 255) / 256;
     constexpr int NG = 2 * NT;
-    constexpr int RD = (TEM_MF_RD && NG % TEM_MF_RD == 0) ? TEM_MF_RD : (NR == 1 && NG % 3 == 0) ? 3 : 2;
-    constexpr int GH = NG - RD + 1 > 0 ? NG - RD + 1 : 0;  // k-group after whose ring issue the halo prefetch goes out
+    // ring depth of the persistent kernel: the waits for ring loads issued BEFORE the halo prefetch are the ones that do not wait
+    // for it (vmcnt counts in order), i.e. RD k-groups of cover for the prefetch
+    constexpr int RDP = NR == 1 ? TEM_MF_RD1 : TEM_MF_RD2;
+    constexpr int RD = (RDP && NG % RDP == 0) ? RDP : (TEM_MF_RD && NG % TEM_MF_RD == 0) ? TEM_MF_RD : (NR == 1 && NG % 3 == 0) ? 3 : 2;
+    constexpr int GH = TEM_MF_EARLY_HALO ? 0 : (NG - RD + 1 > 0 ? NG - RD + 1 : 0);  // k-group after whose ring issue the halo prefetch goes out
     static_assert(TZ * TY * TX == 256, "patch must hold 256 voxels");
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [HV][LSF]
 
@@ -362,26 +398,47 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : TEM_MF_OCC2) void k_conv_fwd_mfm
     float4 tmp[NIT];
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sf4 = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned inb = 0;  // bit `it`: staging item is inside the volume
-    // issue the halo loads of one step (raw values; the fused norm is applied at LDS-write time)
+    // Halo loads of one step (raw values; the fused norm is applied at LDS-write time).  Round 6: UNCONDITIONAL buffer loads with
+    // per-thread constant 32-bit offsets from the halo origin (an item outside the volume, or beyond the tile, reads with an offset
+    // beyond the buffer: zeros) -- rounds 1-5 kept every load inside `if (voxel in range)`, so the compiler could not count what was
+    // in flight at the join points.  The prefetch is still issued behind the LAST weight-ring load of a step (TEM_MF_EARLY_HALO
+    // above says why not earlier); the straight-line loads alone are worth 1.7 % of the launch.  Needs the halo of a patch inside
+    // 2 GiB (launcher).
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned hoff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int hv = (tid + it * 256) >> 2;
+        const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;
+        hoff[it] = hv < HV ? ((unsigned)((hz * H + hy) * W + hx) * (unsigned)x_ld + (unsigned)(c4 * 4)) * 4u : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rsc = mf_rsrc(scale ? (const void*)scale : (const void*)x);
+    const __amdgpu_buffer_rsrc_t rsf = mf_rsrc(scale ? (const void*)shift : (const void*)x);
+    const bool has_scale = scale != nullptr;
+    typedef unsigned int mf_u4 __attribute__((ext_vector_type(4)));
+    auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float4 {
+        const mf_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        typedef float mf_f4 __attribute__((ext_vector_type(4)));
+        const mf_f4 f = __builtin_bit_cast(mf_f4, v);
+        return make_float4(f.x, f.y, f.z, f.w);
+    };
 #define LOAD_HALO(NN, Z0, Y0, X0, CHUNK)                                                                         \
     do {                                                                                                         \
         inb = 0;                                                                                                 \
-        if (scale) {                                                                                             \
-            sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)(NN) * Cin + (CHUNK) * CK + c4 * 4);         \
-            sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)(NN) * Cin + (CHUNK) * CK + c4 * 4);         \
+        {                                                                                                        \
+            const unsigned so = has_scale ? (unsigned)(((int64_t)(NN) * Cin + (CHUNK) * CK + c4 * 4) * 4) : OOB;  \
+            sc4 = ld4(rsc, so);                                                                                  \
+            sf4 = ld4(rsf, so);                                                                                  \
         }                                                                                                        \
+        const __amdgpu_buffer_rsrc_t rx_ = mf_rsrc(x + ((((int64_t)(NN) * D + ((Z0) - PZ)) * H + ((Y0) - PY)) * W + ((X0) - PX)) * x_ld + \
+                                                   (CHUNK) * CK);                                                \
         _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                     \
             const int hv = (tid + it * 256) >> 2;                                                                \
-            tmp[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
-            if (hv < HV) {                                                                                       \
-                const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;               \
-                const int gz = (Z0) + hz - PZ, gy = (Y0) + hy - PY, gx = (X0) + hx - PX;                         \
-                if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {                               \
-                    tmp[it] = *reinterpret_cast<const float4*>(                                                  \
-                        x + ((((int64_t)(NN) * D + gz) * H + gy) * W + gx) * x_ld + (CHUNK) * CK + c4 * 4);      \
-                    inb |= 1u << it;                                                                             \
-                }                                                                                                \
-            }                                                                                                    \
+            const int hz = hv / (HY * HX), rem = hv % (HY * HX), hy = rem / HX, hx = rem % HX;                   \
+            const unsigned gz = (unsigned)((Z0) + hz - PZ), gy = (unsigned)((Y0) + hy - PY), gx = (unsigned)((X0) + hx - PX); \
+            const bool ok = (hv < HV) & (gz < (unsigned)D) & (gy < (unsigned)H) & (gx < (unsigned)W);            \
+            inb |= ok ? (1u << it) : 0u;                                                                         \
+            tmp[it] = ld4(rx_, ok ? hoff[it] : OOB);                                                             \
         }                                                                                                        \
     } while (0)
 
@@ -417,6 +474,8 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : TEM_MF_OCC2) void k_conv_fwd_mfm
                 n_n = b % N;
                 n_ks = b / N;
                 n_chunk = n_ks * cpk;
+            } else {
+                n_chunk = c_chunk;   // nothing follows: the (unconditional) prefetch below re-reads this step's own tile
             }
         }
         // ---- halo tile of the current step: registers -> LDS (fused pre-norm, zero padding after it) ----
@@ -426,7 +485,7 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : TEM_MF_OCC2) void k_conv_fwd_mfm
             const int hv = (tid + it * 256) >> 2;
             if (hv < HV) {
                 float4 v = tmp[it];
-                if (inb & (1u << it)) {
+                if (has_scale && (inb & (1u << it))) {
                     v.x = fmaf(v.x, sc4.x, sf4.x);
                     v.y = fmaf(v.y, sc4.y, sf4.y);
                     v.z = fmaf(v.z, sc4.z, sf4.z);
@@ -450,6 +509,11 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : TEM_MF_OCC2) void k_conv_fwd_mfm
         const int64_t wo_c = (int64_t)(c_cot * NR) * NT * cin8 * 64 + (int64_t)c_chunk * 128;
         const int64_t wo_n = (int64_t)(n_cot * NR) * NT * cin8 * 64 + (int64_t)n_chunk * 128;
         const int64_t wnn = (int64_t)NT * cin8 * 64;
+        float4 apf[2];
+        if (TEM_MF_APF) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) apf[m] = *reinterpret_cast<const float4*>(lds + abase[m]);   // tap 0, k-group 0
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int tap = g >> 1, kg = g & 1;
@@ -468,13 +532,28 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : TEM_MF_OCC2) void k_conv_fwd_mfm
                 }
                 __builtin_amdgcn_sched_barrier(0x38F);
             }
-            if (g == GH && has_next) {
+            if (g == GH) {   // (no `if (has_next)`: a branch around loads would hide them from the wait counting; the last step of a
+                             //  workgroup reloads its own tile)
                 LOAD_HALO(n_n, n_z0, n_y0, n_x0, n_chunk);
                 __builtin_amdgcn_sched_barrier(0x38F);
             }
+            // A fragments one k-group AHEAD (TEM_MF_APF, round 6): left to itself hipcc issues the two ds_read_b128 of a k-group one MFMA
+            // before the MFMAs that consume them -- an LDS round trip in front of every 8 NR MFMAs of the wave
             float4 a[2];
+            if (TEM_MF_APF) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff + kg * 8);
+                for (int m = 0; m < 2; ++m) a[m] = apf[m];
+                if (g + 1 < NG) {
+                    const int tap1 = (g + 1) >> 1, kg1 = (g + 1) & 1;
+                    const int toff1 = (((tap1 / (KH * KW)) * HY + (tap1 / KW) % KH) * HX + tap1 % KW) * LSF;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) apf[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff1 + kg1 * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + toff + kg * 8);
+            }
             // k-step outermost (TEM_MF_KOUTER): consecutive MFMAs go to DIFFERENT accumulators -- a dependent v_mfma_f32_32x32x2_f32
             // cannot start before its predecessor's 16 passes have written back
 #pragma unroll
@@ -736,7 +815,9 @@ static void launch_fwd(const float* x, int64_t x_ld, const float* scale, const f
     size_t ldsb = (size_t)HV * LSF * sizeof(float);
     // persistent pipelining pays for the 64-column tiles (measured +5%), not for the 32-column ones
     const int pmode = (int)tem_option(TEM_OPT_FWD_PERSISTENT);
-    const bool persistent = NW == 4 && (pmode < 0 ? NR == 2 : pmode != 0);
+    // (the persistent kernel addresses a patch's halo with 32-bit offsets from its origin)
+    const bool halo32 = (int64_t)(TZ + KD - 1) * H * W * x_ld * 4 < (1ll << 31);
+    const bool persistent = NW == 4 && halo32 && (pmode < 0 ? NR == 2 : pmode != 0);
     if constexpr (NW == 4) if (persistent) {
         static int ncu = 0;
         if (!ncu) {
