@@ -137,10 +137,17 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, float c, fl
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
         for (int it = 0; it < 256; ++it) {   // 1024 MFMAs = 32768 cycles of matrix-pipe time
+#ifdef PARTNER_F32   // round 6: the partner streams v_mfma_f32_32x32x2_f32 (16 passes = 64 cycles each: 1024 MFMAs = 65536 cycles)
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c, c + 1.f, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c, c + 1.f, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(c, c + 1.f, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(c, c + 1.f, a3, 0, 0, 0);
+#else
             a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a1, 0, 0, 0);
             a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a2, 0, 0, 0);
             a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a3, 0, 0, 0);
+#endif
         }
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
         r[0] = a0[0] + a1[1] + a2[2] + a3[3];

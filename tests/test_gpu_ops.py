@@ -1416,3 +1416,177 @@ def test_batched_weight_repack_is_bit_identical():
         assert n == int((~used).sum()) or torch.equal(ref.view(torch.int32)[used.view(-1)], dst.view(torch.int32)[used.view(-1)]), what
         assert torch.equal(ref.view(torch.int32)[used.view(-1)], dst.view(torch.int32)[used.view(-1)]), what
         assert int(used.sum()) > 0, what
+
+
+def _fma32(a, b, c):
+    """fmaf(a, b, c) on float32 arrays, bit for bit: the product of two fp32 is exact in float64; TwoSum gives the error of
+    the float64 addition, and nudging an inexact sum to its neighbour with an odd last bit (round to odd, 53 >= 24 + 2 bits)
+    makes the final rounding to fp32 the correctly rounded one."""
+    p = a.astype(np.float64) * b.astype(np.float64)
+    c = c.astype(np.float64)
+    s = p + c
+    bb = s - p
+    e = (p - (s - bb)) + (c - bb)
+    odd = (s.view(np.int64) & 1) == 1
+    nudged = np.nextafter(s, np.where(e > 0, np.inf, -np.inf))
+    s = np.where((e != 0) & ~odd, nudged, s)
+    return s.astype(np.float32)
+
+
+ZR32_CASES = [
+    (2, 32, 64, 64, 32, 32),    # level-0 shape class, 512 units both ways: one per team
+    (2, 36, 61, 67, 64, 32),    # ragged borders in z, y, x; four chunks (648 units; data gradient 1296)
+    (2, 32, 64, 64, 64, 64),    # two column tiles both ways
+    (2, 24, 70, 72, 96, 32),    # six chunks, ragged (540 units; data gradient three column tiles)
+]
+
+
+@pytest.mark.parametrize("case", ZR32_CASES)
+def test_conv_exact_fp32_on_the_zreuse_kernel(case):
+    """use_mfma 1 (engine precision "fp32": the arithmetic of the reference's CPU path, nn.Conv3d in fp32,
+    model/unet.py:417-438) on k_conv_zr<..., X32> (round 6): forward with the fused pre-norm, bias, ReLU and the fused
+    statistics; data gradient plain, with the ReLU mask and with the norm-backward epilogue -- against F.conv3d in float64
+    (an fp32 FMA chain over 27 x Cin terms: 5e-6), and bit for bit against the patch kernel's launch wherever only the
+    epilogue differs.  tem_conv3d_fwd_kernel() must report the z-reuse family; option fp32_zr = 0 restores k_conv_fwd_mfma."""
+    ops = _ops()
+    from torch_em_amd import _lib
+    lib = _lib.load()
+    N, D, H, W, Cin, Cout = case
+    k, pad = (3, 3, 3), (1, 1, 1)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    scale, shift = torch.rand(N, Cin, generator=g) + 0.5, torch.randn(N, Cin, generator=g)
+    xn = torch.addcmul(shift[:, :, None, None, None], x, scale[:, :, None, None, None])      # one fp32 fma per element, as the staging does
+    exp = F.relu(F.conv3d(xn.double(), w.double(), b.double(), padding=pad))
+    x5, wd = to5(x), w.to(DEV)
+    assert lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, 3, 3, 3, 1) == 3
+    nblk = lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, Cin, Cout, 3, 3, 3, 1)
+    assert nblk == ((D + 3) // 4) * ((H + 15) // 16) * ((W + 7) // 8) * 4
+    wp = ops.pack_weights(wd, transpose=False, mfma=1)
+    y5 = torch.full((N, D, H, W, Cout + 4), 3.0, device=DEV)
+    stat, nb = ops.conv_fwd(x5, wp, b.to(DEV), y5[..., :Cout], k, Cin, Cout, scale=scale.to(DEV), shift=shift.to(DEV), act="relu",
+                            mfma=1, want_stats=True)
+    assert nb == nblk
+    err = rel_err(from5(y5[..., :Cout]), exp)
+    assert err < 5e-6, f"fwd: {err}"
+    assert float(y5[..., Cout:].min()) == 3.0 and float(y5[..., Cout:].max()) == 3.0
+    got = from5(y5[..., :Cout]).double()
+    assert rel_err(stat[..., 0].sum(1).cpu(), got.sum((2, 3, 4))) < 1e-5
+    assert rel_err(stat[..., 1].sum(1).cpu(), (got * got).sum((2, 3, 4))) < 1e-5
+    y6 = ops.new_act(N, D, H, W, Cout, DEV)
+    ops.conv_fwd(x5, wp, b.to(DEV), y6, k, Cin, Cout, scale=scale.to(DEV), shift=shift.to(DEV), act="relu", mfma=1)
+    assert torch.equal(y6, y5[..., :Cout])                                      # the statistics epilogue stores the same values
+    # the patch kernel (rounds 1-5) on the same operands: fp32 both, another summation order
+    _lib.set_option("fp32_zr", 0)
+    try:
+        assert lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, 3, 3, 3, 1) == 0
+        assert lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, Cin, Cout, 3, 3, 3, 1) == 0
+        y7 = ops.new_act(N, D, H, W, Cout, DEV)
+        ops.conv_fwd(x5, wp, b.to(DEV), y7, k, Cin, Cout, scale=scale.to(DEV), shift=shift.to(DEV), act="relu", mfma=1)
+    finally:
+        _lib.set_option("fp32_zr", 1)
+    assert rel_err(y7.cpu(), y6.cpu()) < 5e-6 and rel_err(from5(y7), exp) < 5e-6
+    # data gradient: transposed pack, no norm / bias / activation; masked; with the norm backward of the layer in front
+    gy = torch.randn(N, Cout, D, H, W, generator=g)
+    gxe = torch.nn.grad.conv3d_input(x.shape, w.double(), gy.double(), padding=pad)
+    g5 = to5(gy)
+    assert lib.tem_conv3d_fwd_kernel(N, D, H, W, Cout, Cin, 3, 3, 3, 1) == 3
+    wpt = ops.pack_weights(wd, transpose=True, mfma=1)
+    gx5 = ops.new_act(N, D, H, W, Cin, DEV)
+    ops.conv_fwd(g5, wpt, None, gx5, k, Cout, Cin, mfma=1)
+    err = rel_err(from5(gx5), gxe)
+    assert err < 5e-6, f"dgrad: {err}"
+    a1 = torch.relu(torch.randn(N, Cin, D, H, W, generator=g) + 0.2)
+    a15 = to5(a1)
+    gm5 = ops.new_act(N, D, H, W, Cin, DEV)
+    ops.conv_fwd(g5, wpt, None, gm5, k, Cout, Cin, mfma=1, ref=a15)
+    assert torch.equal(gm5, torch.where(a15 > 0, gx5, torch.zeros_like(gx5)))
+    coef = torch.randn(N, Cin, 4, generator=g).to(DEV)
+    kc = coef.view(N, 1, 1, 1, Cin, 4)
+    want = torch.where(a15 > 0, kc[..., 0] * gx5 - kc[..., 1] - (a15 - kc[..., 3]) * kc[..., 2], torch.zeros_like(gx5))
+    gn5 = ops.new_act(N, D, H, W, Cin, DEV)
+    ops.conv_fwd_refnorm(g5, wpt, gn5, k, Cout, Cin, a15, coef, 1)
+    assert float((gn5 - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 16, 128, 256), (2, 15, 16, 15, 128, 256), (2, 8, 8, 8, 512, 512)])
+def test_conv_exact_fp32_zreuse_split_k(case):
+    """The 16^3 / 8^3 levels in exact fp32: k_conv_zr<..., KSPLIT, X32> + the summing epilogue (bias, ReLU, ReLU mask, fused
+    statistics), against F.conv3d in float64; reference model/unet.py:417-438."""
+    ops = _ops()
+    from torch_em_amd import _lib
+    lib = _lib.load()
+    N, D, H, W, Cin, Cout = case
+    k, pad = (3, 3, 3), (1, 1, 1)
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    scale, shift = torch.rand(N, Cin, generator=g) + 0.5, torch.randn(N, Cin, generator=g)
+    xn = torch.addcmul(shift[:, :, None, None, None], x, scale[:, :, None, None, None])
+    exp = F.relu(F.conv3d(xn.double(), w.double(), b.double(), padding=pad))
+    x5, wd = to5(x), w.to(DEV)
+    assert lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, 3, 3, 3, 1) == 4
+    wp = ops.pack_weights(wd, transpose=False, mfma=1)
+    y5 = ops.new_act(N, D, H, W, Cout, DEV)
+    stat, nb = ops.conv_fwd(x5, wp, b.to(DEV), y5, k, Cin, Cout, scale=scale.to(DEV), shift=shift.to(DEV), act="relu", mfma=1,
+                            want_stats=True)
+    err = rel_err(from5(y5), exp)
+    assert err < 5e-6, f"fwd: {err}"
+    assert rel_err(stat[..., 0].sum(1).cpu(), from5(y5).double().sum((2, 3, 4))) < 1e-5
+    gy = torch.randn(N, Cout, D, H, W, generator=g)
+    refm = torch.randn(N, Cin, D, H, W, generator=g)
+    gxe = torch.nn.grad.conv3d_input(x.shape, w.double(), gy.double(), padding=pad) * (refm > 0)
+    assert lib.tem_conv3d_fwd_kernel(N, D, H, W, Cout, Cin, 3, 3, 3, 1) in (3, 4)
+    gx5 = ops.new_act(N, D, H, W, Cin, DEV)
+    ops.conv_fwd(to5(gy), ops.pack_weights(wd, transpose=True, mfma=1), None, gx5, k, Cout, Cin, mfma=1, ref=to5(refm))
+    err = rel_err(from5(gx5), gxe)
+    assert err < 5e-6, f"masked dgrad: {err}"
+
+
+def test_conv_exact_fp32_zreuse_is_an_fmaf_chain():
+    """The exact mode's claim, checked bit for bit: v_mfma_f32_32x32x2_f32 adds its two products to the accumulator as two
+    fused multiply-adds in k order, so one output value of k_conv_zr<..., X32> is ONE fp32 fmaf chain in the kernel's
+    summation order -- 16-channel chunks in order; inside a chunk the nine (ty, tx) columns; inside a column the channel
+    octets p = 0..1 and their four k-steps c = 0..3; per k-step the three z taps, each the channel pair (8 p + c, 8 p + 4 + c)
+    -- then the bias, then the ReLU.  The host
+    loop below (numpy, _fma32) reproduces a 2 x 8 x 32 x 16 x 32 -> 32 layer with the fused pre-norm exactly."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout = 2, 32, 64, 64, 32, 32
+    k = (3, 3, 3)
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    scale, shift = torch.rand(N, Cin, generator=g) + 0.5, torch.randn(N, Cin, generator=g)
+    y5 = ops.new_act(N, D, H, W, Cout, DEV)
+    ops.conv_fwd(to5(x), ops.pack_weights(w.to(DEV), transpose=False, mfma=1), b.to(DEV), y5, k, Cin, Cout, scale=scale.to(DEV),
+                 shift=shift.to(DEV), act="relu", mfma=1)
+    # a sub-block that touches the volume's corner (zero padding) and crosses tile borders in z (4), y (16) and x (8)
+    n, Z, Y, X = 1, 8, 20, 12
+    xs = x[n, :, :Z + 1, :Y + 1, :X + 1].numpy()
+    sc, sf = scale[n].numpy()[:, None, None, None], shift[n].numpy()[:, None, None, None]
+    xh = _fma32(xs, np.broadcast_to(sc, xs.shape).copy(), np.broadcast_to(sf, xs.shape).copy())
+    xp = np.zeros((Cin, Z + 2, Y + 2, X + 2), np.float32)          # zero padding comes after the norm
+    xp[:, 1:, 1:, 1:] = xh
+    wn = w.numpy()
+    acc = np.zeros((Cout, Z, Y, X), np.float32)
+    for z in range(Z):
+        a = np.zeros((Cout, Y, X), np.float32)
+        for ch in range(Cin // 16):
+            for ty in range(3):
+                for tx in range(3):
+                    for p in range(2):
+                        for c in range(4):
+                            for tz in range(3):
+                                win = xp[:, z + tz, ty:ty + Y, tx:tx + X]
+                                for ci in (16 * ch + 8 * p + c, 16 * ch + 8 * p + 4 + c):
+                                    a = _fma32(np.broadcast_to(wn[:, ci, tz, ty, tx][:, None, None], a.shape).copy(),
+                                               np.broadcast_to(win[ci][None], a.shape).copy(), a)
+        acc[:, z] = a
+    want = np.maximum(acc + b.numpy()[:, None, None, None], 0.0).astype(np.float32)
+    got = y5[n, :Z, :Y, :X, :].permute(3, 0, 1, 2).cpu().numpy()
+    nbad = int((got.view(np.int32) != want.view(np.int32)).sum())
+    assert nbad == 0, f"{nbad} of {got.size} values differ from the fmaf chain (max |d| {np.abs(got - want).max():.3e})"

@@ -252,7 +252,7 @@ extern "C" int64_t tem_conv3d_fwd_ws(int N, int D, int H, int W, int Cin, int Co
     TEM_MODE_SCOPE(use_mfma);
     if (!use_mfma || Cin % 16 || Cout % 32) return 0;
     int64_t ws = tem_conv_fwd_mfma_ws(N, D, H, W, Cin, Cout, kd, kh, kw);
-    if (use_mfma >= 2 && use_mfma <= 7) {   // the z-reuse kernel's split-K launch may want more slices than the patch kernel's
+    if (use_mfma >= 1 && use_mfma <= 7) {   // the z-reuse kernel's split-K launch may want more slices than the patch kernel's
         const int64_t zk = (int64_t)tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) * N * D * H * W * Cout * 4;
         if (zk > ws) ws = zk;
     }
@@ -285,7 +285,24 @@ static int conv3d_fwd_impl(const float* x, int64_t x_ld, const float* scale, con
         TEM_CHECK_LAUNCH("tem_conv3d_fwd(bf16x3)");
         return TEM_OK;
     }
-    TEM_REQUIRE(!stat || !use_mfma, "tem_conv3d_fwd_stats: the exact-fp32 MFMA kernel writes no statistics");
+    if (use_mfma == 1 && Cin % 16 == 0 && Cout % 32 == 0 && x_ld % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w_packed % 16 == 0) &&
+        (!scale || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)))) {
+        // exact fp32 on the z-reuse team kernel (k_conv_zr<..., X32>, round 6): the levels with enough units directly, the
+        // 16^3 / 8^3 levels with split input channels; other shapes stay with k_conv_fwd_mfma[_p] below
+        const int zr = tem_conv_fwd_zr(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, kd, kh, kw,
+                                       act, 1, stat, s);
+        if (zr < 0) return TEM_EINVAL;
+        if (!zr && tem_conv_fwd_zr_splitk(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H, W, Cin,
+                                          Cout, kd, kh, kw, act, 1, stat, s)) {
+            TEM_CHECK_LAUNCH("tem_conv3d_fwd(fp32, z-reuse split-K)");
+            return TEM_OK;
+        }
+        if (zr) {
+            TEM_CHECK_LAUNCH("tem_conv3d_fwd(fp32, z-reuse)");
+            return TEM_OK;
+        }
+    }
+    TEM_REQUIRE(!stat || !use_mfma, "tem_conv3d_fwd_stats: the exact-fp32 patch kernel writes no statistics (tem_conv3d_fwd_stat_blocks() == 0)");
     if (use_mfma) {
         int rc = tem_conv_fwd_mfma(x, x_ld, scale, shift, w_packed, bias, y, y_ld, ref, ref_ld, ws, ws_bytes, N, D, H,
                                    W, Cin, Cout, kd, kh, kw, act, s);
@@ -355,6 +372,13 @@ extern "C" int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Ci
     TEM_MODE_SCOPE(use_mfma);
     if (use_mfma == 0)  // VALU kernels: only the small-Cin first-layer kernel (conv_small.hip) provides them
         return (ref_free_cin1_ok(Cout)) ? tem_conv_fwd_cin1_stat_blocks(D, H, W, Cin, Cout, kd, kh, kw) : 0;
+    if (use_mfma == 1) {   // exact fp32: only the z-reuse kernel (direct or split-K) writes statistics
+        if (Cin % 16 || Cout % 32) return 0;
+        const int64_t zrb = tem_conv_zr_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, 1);
+        if (zrb >= 0) return zrb;
+        const int64_t skb = tem_conv_zr_splitk_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, 1);
+        return skb > 0 ? skb : 0;
+    }
     if (use_mfma < 2 || use_mfma > 7) return 0;
     return tem_conv_fwd_bf16x3_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma);
 }
@@ -365,6 +389,10 @@ extern "C" int tem_conv3d_fwd_kernel(int N, int D, int H, int W, int Cin, int Co
         if (tem_conv_zr_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma) >= 0) return 3;
         if (tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma)) return 4;   // z-reuse kernel, split input channels
         return tem_conv_pp_tiles(N, D, H, W, Cin, Cout, kd, kh, kw, use_mfma);
+    }
+    if (use_mfma == 1 && Cin % 16 == 0 && Cout % 32 == 0) {
+        if (tem_conv_zr_stat_blocks(N, D, H, W, Cin, Cout, kd, kh, kw, 1) >= 0) return 3;
+        if (tem_conv_zr_splitk_ks(N, D, H, W, Cin, Cout, kd, kh, kw, 1)) return 4;
     }
     return 0;
 }

@@ -57,6 +57,18 @@
 #ifndef TEM_ZR_ST_AUX_KS
 #define TEM_ZR_ST_AUX_KS 2  // ... of split-K partial sums (read back at once by tem_splitk_epilogue)
 #endif
+#ifndef TEM_ZR_X32_SCHED
+#define TEM_ZR_X32_SCHED 1   // exact-fp32 tap loop: 1 = (column, channel octet) steps, MFMAs round-robin over the four accumulators; 0 = plane by plane
+#endif
+#ifndef TEM_ZR_X32_R0_M0
+#define TEM_ZR_X32_R0_M0 6   // exact fp32: halo planes requested at the start of a staging phase, per epilogue mode (plain / statistics / ReLU mask /
+#define TEM_ZR_X32_R0_M1 2   // mask + norm backward): 18 registers per plane live across the epilogue -- the largest count without spills
+#define TEM_ZR_X32_R0_M2 5
+#define TEM_ZR_X32_R0_M3 3
+#endif
+#ifndef TEM_ZR_X32_GAP
+#define TEM_ZR_X32_GAP 0     // exact-fp32 tap loop: units of 4 cycles of s_nop behind every MFMA (experiment, see zr_x32_gap: does not help)
+#endif
 #ifndef TEM_ZR_ABL
 #define TEM_ZR_ABL 0     // harness-only ablations: 1 no halo loads, 2 no stores, 4 no weight loads, 8 no LDS writes, 16 no MFMAs
 #endif
@@ -175,6 +187,32 @@ void tem_zr_trace_read(unsigned long long* dst) {
 #define ZR_STAMP(i) asm volatile("; ZRMARK " #i)
 #endif
 
+// Measured (scripts/proto/issue_bench.hip -DPARTNER_F32, profiles/r06_issue_bench_f32.txt): beside a wave that streams
+// v_mfma_f32_32x32x2_f32 back to back, the other wave of the SIMD issues NO vector-ALU instruction at all -- 512 v_fma_f32 took
+// 68 288 ticks next to a 65 896-tick MFMA loop (LDS and memory instructions are not affected; beside the 8-pass fp16 MFMAs
+// a VALU instruction goes through every ~6 cycles).  The next MFMA of a dense stream waits at the vector-ALU port for the
+// 64 cycles its predecessor occupies the matrix pipe, and the port is the staging team's, too: the first trace of the exact-fp32
+// kernel showed the partner's staging phase starting only AFTER the tap phase (step = 55.6 k cycles of MFMAs + 10 k of staging,
+// 0.84 of the pipe).  So the multiplying wave stays away from the port while its MFMA runs: s_nop for most of the 64 cycles,
+// the next MFMA arrives shortly before the pipe is free, and the staging wave has the port in between.
+__device__ __forceinline__ void zr_x32_gap() {
+    if constexpr (TEM_ZR_X32_GAP > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int FULL16 = TEM_ZR_X32_GAP / 16, REST = TEM_ZR_X32_GAP % 16;
+#pragma unroll
+        for (int i = 0; i < FULL16; ++i) asm volatile("s_nop 15");
+        if constexpr (REST > 0) asm volatile("s_nop %0" ::"n"(REST - 1));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// a < b ? t : f on the scalar ALU, spelled out (see the exact-fp32 staging phase)
+__device__ __forceinline__ unsigned zr_ssel_ltu(unsigned a, unsigned b, unsigned t, unsigned f) {
+    unsigned r;
+    asm volatile("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(a), "s"(b), "s"(t), "s"(f) : "scc");
+    return r;
+}
+
 struct ZrUnit {
     int cot, n, z0, y0, x0, ksl;
 };
@@ -201,7 +239,15 @@ struct ZrUnit {
 // packed pairs (zr_norm2) and ONE ds_write_b128 per slot fills the tile -- without a norm (data gradients) the loaded
 // registers go to LDS as they are.  Outputs are rounded once in the epilogue (8-byte pieces, 64-byte voxel rows); split-K
 // partial sums stay fp32.
-template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float>
+// X32 (round 6): EXACT fp32 on v_mfma_f32_32x32x2_f32 (use_mfma 1, TEM_WL_MFMA pack) in the same structure.  The two LDS planes of
+// a team's tile hold channels 0..7 / 8..15 of the chunk as fp32 (32-byte records, the 16-byte half chosen by row parity as above):
+// a staging slot writes its four normalised channels with one ds_write_b128 (no split: the staging phase gets SHORTER), a lane
+// (k = lane >> 5) reads channels 8 p + 4 k + (0..3) with one ds_read_b128 per plane and feeds four MFMAs from it; the weight
+// fragments are the [co/32][tap][ci/8][2][32][4] records of the exact-fp32 pack as they are (two 16-byte loads per tap and
+// chunk, like the two terms of the split layouts).  Eight 16-pass MFMAs per (tap, chunk, z-plane) instead of three 8-pass ones:
+// the tap phase is 5.3x as long as the fp16x3 one while staging and epilogue shrink, so the matrix pipe only idles in the
+// barrier hand-overs -- this is the mode that is NOT power-limited (profiles/r06_mfma_busy_fp32.txt), where that converts.
+template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float, bool X32 = false>
 __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const T* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, std::conditional_t<KSPLIT, float, T>* __restrict__ y, int64_t y_ld,
@@ -212,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     constexpr bool AMAX = MODE == 2 || MODE == 3;   // data gradients: max |y| as a by-product (TEM_BP_OUT_AMAX)
     float amx = 0.f;
     static_assert(!WIDE || NS == 2, "the wide one-term kernel uses the two LDS planes of the two-term layout");
+    static_assert(!X32 || (NS == 2 && !F16 && !WIDE && sizeof(T) == 4), "exact fp32: two LDS planes of eight fp32 channels, fp32 tensors");
     constexpr bool T16 = sizeof(T) == 2;         // 16-bit activations in HBM
     using TOut = std::conditional_t<KSPLIT, float, T>;
     constexpr bool Y16 = sizeof(TOut) == 2;
@@ -227,7 +274,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     constexpr int SPP = (WIDE && !T16) ? 6 : 3;  // load slots per thread and halo plane (the last one only for part of the team)
     constexpr int CPL = T16 ? 8 : 4;             // channels per load slot
     constexpr int RP = NIT / SPP;                // planes the register ring holds
-    constexpr int R0 = (WIDE && !T16) ? ((MODE == 1 || MODE == 3) ? 1 : 2)   // (a ring of three planes: at most two ahead; the statistics / norm-backward epilogues have no room for 12 loads)
+    constexpr int R0 = X32 ? (MODE == 0 ? TEM_ZR_X32_R0_M0 : MODE == 1 ? TEM_ZR_X32_R0_M1 : MODE == 2 ? TEM_ZR_X32_R0_M2 : TEM_ZR_X32_R0_M3)   // exact fp32: as much of the halo as the epilogue's registers allow, by instructions that need no vector ALU (see pvo below)
+                       : (WIDE && !T16) ? ((MODE == 1 || MODE == 3) ? 1 : 2)   // (a ring of three planes: at most two ahead; the statistics / norm-backward epilogues have no room for 12 loads)
                        : T16 ? ((MODE == 1 || MODE == 3) ? TEM_ZR_R0_16S : TEM_ZR_R0_16)
                              : (TEM_ZR_R0 < HZ ? TEM_ZR_R0 : HZ);   // halo planes loaded before the epilogue
     constexpr int FR = NS * 64;                  // uint4s per (tap, 16-channel chunk) fragment group
@@ -296,11 +344,33 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
         const int q = min((tl + 256 * j) / LPV, HY * HX - 1);
         const int hy = q / HX, hx = q % HX;
         poff[j] = ((unsigned)(hy * W + hx) * (unsigned)x_ld + (unsigned)(c4 * CPL)) * (unsigned)XB;
-        if (T16)   // channels 8 c4 .. 8 c4 + 7: plane c4 >> 1, 16-byte half c4 & 1 (swizzled by the row parity)
+        if (T16 || X32)   // 16-bit: channels 8 c4 .. 8 c4 + 7, exact fp32: 4 c4 .. 4 c4 + 3 -- plane c4 >> 1, 16-byte half c4 & 1 (swizzled by the row parity)
             lwj[j] = (unsigned)(q * 32) + (unsigned)((((c4 & 1) ^ (hy & 1)) << 4)) + (unsigned)((c4 >> 1) * PLB);
         else
             lwj[j] = (unsigned)(q * 32) + (unsigned)(((((c4 >> 1) & 1) ^ (hy & 1)) << 4) | ((c4 & 1) << 3)) + (unsigned)((c4 >> 2) * PLB);
     }
+    // Exact fp32: the vector ALU of a SIMD is the matrix pipe of v_mfma_f32_32x32x2_f32 (zr_x32_gap above: beside the partner's
+    // MFMA stream this wave issues no VALU instruction), so a staging phase must get its halo loads out WITHOUT one: the per-slot
+    // offsets with the in-plane validity of the unit folded in (out-of-range slots read the always-valid plane voxel (1, 1) and
+    // are zeroed later) are prepared where the unit is chosen -- behind this team's own tap phase, when the ALU is free -- and the
+    // z validity is a scalar select of the plane offset.  The loads are then buffer_load + SALU only and fly during the
+    // partner's MFMAs; the VALU work of the phase (epilogue, norm, LDS writes) runs as one dense burst behind them.
+    const unsigned ctr_off_ = ((unsigned)(W + 1) * (unsigned)x_ld + (unsigned)(c4 * CPL)) * (unsigned)XB;
+    unsigned pvo[X32 ? SPP : 1];
+    unsigned yxu = (1u << SPP) - 1u;   // in-plane validity bits of the unit in `cu`
+    auto unit_offsets = [&](const ZrUnit& t) {
+        if constexpr (X32) {
+            yxu = 0;
+#pragma unroll
+            for (int j = 0; j < SPP; ++j) {
+                const int q = min((tl + 256 * j) / LPV, HY * HX - 1);
+                const unsigned gy = (unsigned)(t.y0 - 1 + q / HX), gx = (unsigned)(t.x0 - 1 + q % HX);
+                const bool ok = (gy < (unsigned)H) & (gx < (unsigned)W);
+                yxu |= ok ? (1u << j) : 0u;
+                pvo[X32 ? j : 0] = ok ? poff[j] : ctr_off_;
+            }
+        }
+    };
     const bool slot2 = tl < (HY * HX * LPV - 256 * (SPP - 1));   // the last slot exists for 208 (WIDE: 160) threads
     const unsigned ctr_off = ((unsigned)(W + 1) * (unsigned)x_ld + (unsigned)(c4 * CPL)) * (unsigned)XB;  // plane voxel (1, 1): always inside
     const unsigned plane_b = (unsigned)(H * W) * (unsigned)x_ld * (unsigned)XB;   // bytes between z-planes of x
@@ -330,6 +400,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
 
     int ui = 0, ci = 0;
     ZrUnit cu = decode(0), eu = cu;
+    unit_offsets(cu);
     bool epi_pending = false;
     // bias: lane l keeps channel (l & 31) of the unit being computed.  It is added in the epilogue: accumulators that START
     // from it measure worse -- the matrix core truncates each step's products against the larger accumulator, a one-sided
@@ -374,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
             float4 sc5 = sc4, sf5 = sf4;   // 16-bit storage: channels 4 .. 7 of this thread's eight
             bool interior = true;
             __amdgpu_buffer_rsrc_t rx = zr_rsrc(x);
-            if (do_stage) {
+            auto load_norm = [&]() {
                 if (scale) {
                     sc4 = *reinterpret_cast<const float4*>(scale + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * CPL);
                     sf4 = *reinterpret_cast<const float4*>(shift + (int64_t)cu.n * Cin + (cu.ksl * nch + ci) * CK + c4 * CPL);
@@ -385,6 +456,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                 } else if (in_amax) {
                     sc4 = make_float4(psc, psc, psc, psc);
                 }
+            };
+            if (do_stage) {
+                if constexpr (!X32) load_norm();   // (exact fp32: behind the halo loads -- its address arithmetic is vector-ALU work)
                 // the halo origin may lie outside the tensor for border patches (only in-range voxels are dereferenced)
                 // (16-bit storage: a chunk stride x_cs != 0 puts chunk k at x + k * x_cs -- planar concat halves, tem_act.h)
                 const int64_t xch = (T16 && x_cs) ? (int64_t)(cu.ksl * nch + ci) * x_cs : (int64_t)((cu.ksl * nch + ci) * CK);
@@ -393,8 +467,39 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                 interior = (cu.z0 >= 1) & (cu.z0 + HZ - 1 <= D) & (cu.y0 >= 1) & (cu.y0 + HY - 1 <= H) & (cu.x0 >= 1) &
                            (cu.x0 + HX - 1 <= W);
                 if (TEM_ZR_ABL & 32) interior = true;   // timing experiment: border code paths compiled out (wrong at the faces)
+                if constexpr (X32) {
+                    // the whole halo: 18 buffer loads whose offsets exist already (pvo; the plane offset with the z validity is a
+                    // scalar select written as SALU instructions: hipcc legalises a uniform bool that crosses a block through a
+                    // VGPR -- v_cndmask / v_cmp -- and one such instruction in front of the loads holds them back for the whole
+                    // tap phase of the partner) -- no vector ALU
+#pragma unroll
+                    for (int hz = 0; hz < R0; ++hz) {
+                        const unsigned so = zr_ssel_ltu((unsigned)(cu.z0 - 1 + hz), (unsigned)D, (unsigned)hz * plane_b, plane_b);
+#pragma unroll
+                        for (int j = 0; j < SPP; ++j) {
+                            if (TEM_ZR_ABL & 1) tmp[hz * SPP + j] = make_float4(0.5f + hz, 0.25f, -1.f, 2.f);
+                            else tmp[hz * SPP + j] = zr_load4(rx, pvo[X32 ? j : 0], so);
+                        }
+                    }
+                    load_norm();   // (scalar base + a loop-invariant lane offset: no vector ALU either)
+                }
             }
             unsigned yx = (1u << SPP) - 1u;   // in-plane validity of the slots: border patches only, once per phase, from a laundered
+            if constexpr (X32) {
+                if (do_stage) {
+                    yx = yxu;
+                    if (!interior) {
+                        inb[0] = inb[1] = 0;
+#pragma unroll
+                        for (int hz = 0; hz < HZ; ++hz) {
+                            const bool zok = (unsigned)(cu.z0 - 1 + hz) < (unsigned)D;
+#pragma unroll
+                            for (int j = 0; j < SPP; ++j)
+                                inb[hz / 3] |= (zok & ((yx >> j) & 1u)) ? (1u << ((hz % 3) * SPP + j)) : 0u;
+                        }
+                    }
+                }
+            } else
             if (do_stage && !interior) {   // copy of tl (loop-invariant code motion would keep six more registers live)
                 int tl_ = tl;
                 asm volatile("" : "+v"(tl_));
@@ -432,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                     }
                 }
             };
-            if (do_stage) {
+            if (do_stage && !X32) {
                 if (interior) issue_loads(std::true_type{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R0>{});
                 else issue_loads(std::false_type{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R0>{});
             }
@@ -810,6 +915,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                                 for (int c = 0; c < 4; ++c) e[c] *= m;
                             }
                             unsigned char* dstp = lds + lwj[j] + hz * ZSTEP;   // HY is even: the row parity does not depend on the plane
+                            if constexpr (X32) {
+                                if (!(TEM_ZR_ABL & 8) || e[0] == 12345.678f) *reinterpret_cast<float4*>(dstp) = make_float4(e[0], e[1], e[2], e[3]);
+                            } else
                             if (SC) {
                                 const half2_t hh0 = {(_Float16)e[0], (_Float16)e[1]}, hh1 = {(_Float16)e[2], (_Float16)e[3]};
                                 unsigned u0 = __builtin_bit_cast(unsigned, hh0), u1 = __builtin_bit_cast(unsigned, hh1);
@@ -895,6 +1003,114 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                     for (int p = 0; p < NS; ++p)
                         af[st % (AD + 1)][p] = *reinterpret_cast<const uint4*>(lds + a0 + hz * ZSTEP + p * PLB);
                 };
+                if constexpr (X32 && TEM_ZR_X32_SCHED == 1) {
+                    // Exact fp32.  A step = (column g, channel octet p): the six halo planes of the column are read once (one
+                    // ds_read_b128 each: channels 8 p + 4 k + (0..3) of this lane's voxel) and each of the four k-steps multiplies
+                    // its twelve (plane, z tap) pairs ROUND-ROBIN over the four accumulators -- a v_mfma_f32_32x32x2_f32 cannot start
+                    // before its predecessor on the same accumulator has written back, and this SIMD has no second multiplying wave
+                    // to fill such a gap: here three other MFMAs (192 cycles) lie between two that share an accumulator.
+                    // Two register sets of six fragments: the reads of step u + 1 fly during the 48 MFMAs of step u.
+                    uint4 xr[2][HZ];
+                    auto r_read = [&](int u) {   // compile-time after unrolling
+                        if ((u & 1) == 0) col_addr(u >> 1);
+#pragma unroll
+                        for (int hz = 0; hz < HZ; ++hz)
+                            xr[u & 1][hz] = *reinterpret_cast<const uint4*>(lds + a0 + hz * ZSTEP + (u & 1) * PLB);
+                    };
+                    auto comp = [](const uint4& q, int c) {
+                        return __builtin_bit_cast(float, c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w)));
+                    };
+                    r_read(0);
+#pragma unroll
+                    for (int u = 0; u < 18; ++u) {
+                        const int g = u >> 1, p = u & 1;
+                        if (u + 1 < 18) r_read(u + 1);
+                        if (g + 1 < 9 && !(TEM_ZR_ABL & 4)) {   // weight fragments of the next column: tz = 0, 1 in the first step, 2 in the second
+                            const int gn = g + 1;
+#pragma unroll
+                            for (int tz = (p ? 2 : 0); tz < (p ? 3 : 2); ++tz)
+#pragma unroll
+                                for (int pp = 0; pp < 2; ++pp)
+                                    wq[gn & 1][tz][pp] = zr_load4u(rw, woff_lane, wsoff + (unsigned)((tz * 9 + gn) * ts + pp * 64) * 16u);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+                                for (int z = 0; z < TZ; ++z) {
+                                    if (TEM_ZR_ABL & 16) {
+                                        asm volatile("" ::"v"(xr[u & 1][z + tz].x), "v"(wq[g & 1][tz][p].x));
+                                        continue;
+                                    }
+                                    acc[z] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(wq[g & 1][tz][p], c), comp(xr[u & 1][z + tz], c), acc[z], 0, 0, 0);
+                                    zr_x32_gap();
+                                }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if constexpr (X32) {
+                    // (first schedule, TEM_ZR_X32_SCHED 0: kept for the A/B.)  Fragment order inside a column: halo planes 0, 5, 1, 2, 3, 4.  Planes 0 and 5 feed ONE accumulator
+                    // each (output planes 0 / 3): their MFMAs alternate, so that no v_mfma_f32_32x32x2_f32 directly follows the one
+                    // that writes its accumulator (a dependent one cannot start before its predecessor has written back, and this
+                    // SIMD has no second multiplying wave to fill the gap); planes 1..4 feed two or three accumulators in turn.
+                    // A ring of four fragments (2 x 16 bytes each), two ahead of the MFMAs; 96 MFMAs of 16 passes per column.
+                    constexpr int NF = 9 * HZ, RING = 4, PF = 2;
+                    uint4 xf[RING][2];
+                    auto x_read = [&](int f) {   // fragment f = g * 6 + i, i-th plane of the order above (compile-time after unrolling)
+                        const int i = f % HZ;
+                        const int hz = i == 0 ? 0 : (i == 1 ? HZ - 1 : i - 1);
+                        if (i == 0) col_addr(f / HZ);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) xf[f % RING][p] = *reinterpret_cast<const uint4*>(lds + a0 + hz * ZSTEP + p * PLB);
+                    };
+                    auto comp = [](const uint4& q, int c) {
+                        return __builtin_bit_cast(float, c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w)));
+                    };
+#pragma unroll
+                    for (int f = 0; f < 2 + PF; ++f) x_read(f);
+#pragma unroll
+                    for (int g = 0; g < 9; ++g) {
+#pragma unroll
+                        for (int sub = 0; sub < 5; ++sub) {
+                            const int flast = g * HZ + (sub == 0 ? 1 : sub + 1);   // last fragment this substep multiplies
+                            if (sub == 0 && g != 0 && flast + PF - 1 < NF) x_read(flast + PF - 1);   // two fragments are consumed here
+                            if (!(g == 0 && sub == 0) && flast + PF < NF) x_read(flast + PF);
+                            // weight fragments of the next column, one tz per substep
+                            if (sub < 3 && g + 1 < 9 && !(TEM_ZR_ABL & 4)) {
+                                const int gn = g + 1, tz = sub;
+                                const int tap = tz * 9 + gn;
+#pragma unroll
+                                for (int p = 0; p < 2; ++p)
+                                    wq[gn & 1][tz][p] = zr_load4u(rw, woff_lane, wsoff + (unsigned)(tap * ts + p * 64) * 16u);
+                            }
+                            if (sub == 0) {
+                                const uint4* a_lo = xf[(g * HZ) % RING];
+                                const uint4* a_hi = xf[(g * HZ + 1) % RING];
+#pragma unroll
+                                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) {
+                                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(wq[g & 1][0][p], c), comp(a_lo[p], c), acc[0], 0, 0, 0);
+                                        acc[TZ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(wq[g & 1][2][p], c), comp(a_hi[p], c), acc[TZ - 1], 0, 0, 0);
+                                    }
+                            } else {
+                                const int hz = sub;   // halo planes 1 .. 4
+                                const uint4* a = xf[(g * HZ + sub + 1) % RING];
+#pragma unroll
+                                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                                        for (int tz = 0; tz < 3; ++tz) {
+                                            const int z = hz - tz;
+                                            if (z < 0 || z >= TZ) continue;
+                                            acc[z] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(wq[g & 1][tz][p], c), comp(a[p], c), acc[z], 0, 0, 0);
+                                        }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
                 col_addr(0);
 #pragma unroll
                 for (int st = 0; st < AD; ++st) a_read(st);
@@ -946,6 +1162,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                             }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                }   // !X32
                 if (TEM_ZR_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             ZR_STAMP(4);
@@ -960,6 +1177,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
                 if (++ui < my_units) {
                     cu = decode(ui);
                     if (bias) bv = bias[cu.cot * 32 + v];
+                    unit_offsets(cu);
                 }
             }
         }
@@ -985,7 +1203,7 @@ static ZrGeom zr_geometry(int N, int D, int H, int W, int Cin, int Cout, int kd,
     ZrGeom g = {};
     const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
     if (opt == 0 || opt == 1) return g;
-    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7)) return g;
+    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7 || (nsplit == 1 && tem_option(TEM_OPT_FP32_ZR) && !tem_call_st.x))) return g;
     if (!(kd == 3 && kh == 3 && kw == 3)) return g;
     if (D < 4 || Cin % 16 || Cout % 32) return g;
     if (tem_call_st.x && (Cin % 32 || !(nsplit == 5 || nsplit == 7))) return g;   // 16-bit storage: whole 64-byte records per phase
@@ -1019,7 +1237,7 @@ static int zr_tile_blocks(const ZrGeom& g) {
     return lg(g.nX) | (lg(g.nY) << 4) | (lg(g.nZ) << 8);
 }
 
-template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float>
+template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float, bool X32 = false>
 static void zr_launch(const ZrGeom& g, const float* x_, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                       const float* bias, float* y_, int64_t y_ld, const float* ref_, int64_t ref_ld, int N, int D, int H, int W,
                       int Cin, int Cout, int act, float* stat, const unsigned* in_amax, hipStream_t s, int ks = 1) {
@@ -1028,7 +1246,7 @@ static void zr_launch(const ZrGeom& g, const float* x_, int64_t x_ld, const floa
     const T* x = reinterpret_cast<const T*>(x_);
     const T* ref = reinterpret_cast<const T*>(ref_);
     auto* y = reinterpret_cast<std::conditional_t<KSPLIT, float, T>*>(y_);
-    auto kern = &k_conv_zr<NS, F16, MODE, KSPLIT, WIDE, T>;
+    auto kern = &k_conv_zr<NS, F16, MODE, KSPLIT, WIDE, T, X32>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
@@ -1058,7 +1276,7 @@ static void zr_launch(const ZrGeom& g, const float* x_, int64_t x_ld, const floa
 int tem_conv_zr_splitk_ks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int nsplit) {
     const long long opt = tem_option(TEM_OPT_CONV_FWD_VARIANT);
     if (opt == 0 || opt == 1 || !tem_option(TEM_OPT_ZR_SPLITK)) return 0;
-    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7)) return 0;
+    if (!(nsplit == 2 || nsplit == 4 || nsplit == 5 || nsplit == 7 || (nsplit == 1 && tem_option(TEM_OPT_FP32_ZR) && !tem_call_st.x))) return 0;
     if (!(kd == 3 && kh == 3 && kw == 3) || D < 4 || Cin % 16 || Cout % 32) return 0;
     const bool t16 = tem_call_st.x != 0;   // 16-bit storage: slices of whole 32-channel chunks
     if (t16 && (Cin % 32 || !(nsplit == 5 || nsplit == 7))) return 0;
@@ -1109,6 +1327,9 @@ int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, con
     else if (tem_call_st.x == 2)
         zr_launch<2, false, 0, true, true, tem_bf16>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,
                                                      TEM_ACT_NONE, nullptr, nullptr, s, ks);
+    else if (nsplit == 1)
+        zr_launch<2, false, 0, true, false, float, true>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,
+                                                         TEM_ACT_NONE, nullptr, nullptr, s, ks);
     else if (nsplit == 5 && wide) ZRKS(2, true, true);
     else if (nsplit == 7 && wide) ZRKS(2, false, true);
     else if (nsplit == 5) ZRKS(1, true, false);
@@ -1211,16 +1432,30 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
         else                                                                                                                  \
             zr_launch<2, F16, 0, false, true, T>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
     } while (0)
+#define ZRGO32()                                                                                                                \
+    do {                                                                                                                      \
+        if (stat)                                                                                                             \
+            zr_launch<2, false, 1, false, false, float, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+        else if (ref && rcoef)                                                                                                \
+            zr_launch<2, false, 3, false, false, float, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act,        \
+                                  const_cast<float*>(rcoef), in_amax, s);                                                     \
+        else if (ref)                                                                                                         \
+            zr_launch<2, false, 2, false, false, float, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+        else                                                                                                                  \
+            zr_launch<2, false, 0, false, false, float, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+    } while (0)
     if (tem_call_st.x == 1) ZRGO16(true, tem_f16);
     else if (tem_call_st.x == 2) ZRGO16(false, tem_bf16);
     else
 #undef ZRGO16
-    if (nsplit == 5 && wide) ZRGO(2, true, true);
+    if (nsplit == 1) ZRGO32();
+    else if (nsplit == 5 && wide) ZRGO(2, true, true);
     else if (nsplit == 7 && wide) ZRGO(2, false, true);
     else if (nsplit == 5) ZRGO(1, true, false);
     else if (nsplit == 7) ZRGO(1, false, false);
     else if (nsplit == 4) ZRGO(2, true, false);
     else ZRGO(2, false, false);
 #undef ZRGO
+#undef ZRGO32
     return 1;
 }

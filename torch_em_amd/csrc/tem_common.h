@@ -26,6 +26,7 @@ enum {
     TEM_OPT_DICE_VOX,
     TEM_OPT_UPSAMPLE2_CH8,
     TEM_OPT_POOL_VEC8,
+    TEM_OPT_FP32_ZR,
     TEM_OPT_COUNT
 };
 long long tem_option(int id);
