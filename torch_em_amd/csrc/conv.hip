@@ -617,17 +617,18 @@ static int conv3d_wgrad_impl(const float* x, int64_t x_ld, const float* scale, c
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(bf16x3)");
         return TEM_OK;
     }
-    TEM_REQUIRE(!norm_sums, "tem_conv3d_wgrad_sums: only the split-bf16 z-sliding kernel delivers the norm sums");
     if (use_mfma && !(stx || sty) && tem_conv_wgrad_tr_fp32_ok(N, D, H, W, Cin, Cout, kd, kh, kw) && x_ld % 4 == 0 && g_ld % 4 == 0 &&
         ((uintptr_t)x % 16 == 0) && ((uintptr_t)g % 16 == 0)) {
-        // exact fp32 on the z-sliding staging-team kernel (round 4): fp32 records in LDS, v_mfma_f32_32x32x2_f32
+        // exact fp32 on the z-sliding staging-team kernel (round 4): fp32 records in LDS, v_mfma_f32_32x32x2_f32; the slab
+        // merge delivers the norm sums as in the split modes (round 6: the merge does not care which arithmetic filled the slabs)
         int rc = tem_conv_wgrad_bf16x3(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                        ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
-                                       sd_layout, 4, nullptr, nullptr, nullptr, nullptr, s);
+                                       sd_layout, 4, w_sd, gamma, beta, norm_sums, s);
         if (rc != TEM_OK) return rc;
         TEM_CHECK_LAUNCH("tem_conv3d_wgrad(fp32, z-sliding)");
         return TEM_OK;
     }
+    TEM_REQUIRE(!norm_sums, "tem_conv3d_wgrad_sums: only the z-sliding kernels deliver the norm sums (tem_conv3d_wgrad_sums_ok() == 0)");
     if (use_mfma) {
         int rc = tem_conv_wgrad_mfma(x, x_ld, scale, shift, g, g_ld, dw, db, rest,
                                      ws_bytes - (int64_t)((char*)rest - (char*)ws), N, D, H, W, Cin, Cout, kd, kh, kw,
@@ -841,6 +842,9 @@ extern "C" int tem_conv3d_fwd_refnorm(const float* x, int64_t x_ld, const float*
 extern "C" int tem_conv3d_wgrad_sums_ok(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                         int use_mfma) {
     TEM_MODE_SCOPE(use_mfma);
+    if (use_mfma == 1)   // exact fp32: the layers k_conv_wgrad_tr<4> takes (option fp32_zr: the data gradient that consumes the sums)
+        return tem_option(TEM_OPT_FP32_ZR) && !tem_call_st.x && !tem_call_st.y && tem_conv_wgrad_tr_fp32_ok(N, D, H, W, Cin, Cout, kd, kh, kw) &&
+               tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
     if (use_mfma != 2 && use_mfma != 5 && use_mfma != 7 && use_mfma != 8) return 0;
     return tem_conv_wgrad_sums_ok(N, D, H, W, Cin, Cout, kd, kh, kw);
 }

@@ -62,9 +62,9 @@
 #endif
 #ifndef TEM_ZR_X32_R0_M0
 #define TEM_ZR_X32_R0_M0 6   // exact fp32: halo planes requested at the start of a staging phase, per epilogue mode (plain / statistics / ReLU mask /
-#define TEM_ZR_X32_R0_M1 2   // mask + norm backward): 18 registers per plane live across the epilogue -- the largest count without spills
-#define TEM_ZR_X32_R0_M2 5
-#define TEM_ZR_X32_R0_M3 3
+#define TEM_ZR_X32_R0_M1 4   // mask + norm backward).  With the epilogue inside the staging phase (TEM_ZR_X32_EPI_NOW 0) the largest counts without
+#define TEM_ZR_X32_R0_M2 6   // spills were 6 / 2 / 5 / 3
+#define TEM_ZR_X32_R0_M3 5
 #endif
 #ifndef TEM_ZR_X32_GAP
 #define TEM_ZR_X32_GAP 0     // exact-fp32 tap loop: units of 4 cycles of s_nop behind every MFMA (experiment, see zr_x32_gap: does not help)
@@ -425,6 +425,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
         }
     unsigned wsoff = 0;
 
+    // Exact fp32: the epilogue runs straight behind the last tap phase of a unit (see there); the same text as in the staging phase.
+    auto epilogue_now = [&](unsigned yoff_l, unsigned roff_l, int s) {
+        (void)s;
+        if constexpr (X32) {
+            // lane-derived values from a laundered lane id: left to itself hipcc computes the two dozen per-lane addresses of the
+            // epilogue once in front of the unit loop, keeps them live through it and spills 60 registers to do so
+            int lane_ = (int)(threadIdx.x & 63);
+            asm volatile("" : "+v"(lane_));
+            const int lane = lane_, kh = lane >> 5, v = lane & 31;
+            const int vu = (int)((0x73261540u >> (4 * (v >> 2))) & 7u) * 4 + (v & 3);
+            const int py = vu >> 3, px = vu & 7;
+            (void)py; (void)px; (void)kh;
+#include "conv_zr_epilogue.inc"
+        }
+    };
     if (team) __syncthreads();
     for (int s = 0; s <= P; ++s) {
         const bool do_stage = ui < my_units;
@@ -543,333 +558,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
             }
             ZR_STAMP(1);
             // ---- epilogue of the unit whose last chunk this team computed in its previous phase ----
-            if (epi_pending) {
-                const __amdgpu_buffer_rsrc_t ry = zr_rsrc(y + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * y_ld +
-                                                          ((Y16 && y_cs) ? (int64_t)eu.cot * y_cs : (int64_t)(eu.cot * 32)) +
-                                                          (KSPLIT ? (int64_t)eu.ksl * ((int64_t)N * D * H * W * y_ld) : 0));
-                constexpr bool has_ref = MODE == 2 || MODE == 3;
-                const __amdgpu_buffer_rsrc_t rr_ = zr_rsrc(has_ref ? (const void*)(ref + ((((int64_t)eu.n * D + eu.z0) * H + eu.y0) * W + eu.x0) * ref_ld + eu.cot * 32) : (const void*)y);
-                const bool full = (TEM_ZR_ABL & 32) ? true : ((eu.z0 + TZ <= D) & (eu.y0 + TY <= H) & (eu.x0 + TX <= W));
-                const bool vok = (eu.y0 + 4 * tw + py < H) & (eu.x0 + px < W);   // this lane's footprint voxel (any z)
-                if constexpr (Y16) {
-                    // ---- 16-bit outputs (round 5).  What bounds the staging team beside the partner's MFMAs is instruction
-                    // ISSUE, and nothing issues slower than a global store (~370 cycles each, scripts/proto/issue_bench.hip; in the
-                    // trace of the first 16-bit version the 16 eight-byte stores of a unit WERE its epilogue: 6300 of the 12.2 k
-                    // cycles of a staging phase against 7.5 k of MFMAs).  So a lane stores 8 channels = 16 bytes: 4 lanes cover the
-                    // 64-byte record of a voxel, a store instruction 16 voxels = two footprint rows, 8 stores per unit instead of 16
-                    // (the reference loads of the mask modes halve the same way).  Bias, activation, masks, rounding and the
-                    // statistics all run AFTER the LDS transpose on those 8 channels: the bias is two float4 per lane (the fp32
-                    // epilogue below folds it into the accumulator layout with 32 v_readlane), the statistics 16 values per lane
-                    // summed over the 16 lanes that share a channel octet with DPP / v_permlane swaps (no 16 -> 1 transposing
-                    // reduction).
-                    constexpr bool has_ref16 = MODE == 2 || MODE == 3;
-                    float s8[8], q8[8];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) s8[c] = q8[c] = 0.f;
-                    unsigned char* scr = zr_lds + 2 * NS * PLB + tw * (32 * 144);
-                    unsigned char* scr_w = scr + v * 144 + kh * 16;
-                    // lane = (row mm of a row pair, x = X, channel octet oct); pass P handles footprint rows m = 2 P + mm.
-                    // scratch row of footprint voxel (m, X): m = 0: X (+ 8 for X >= 4), 1: 20 + X, 2: 4 + X, 3: row of m = 0 + 16
-                    const int oct = lane & 3, X = (lane >> 2) & 7, mm = lane >> 5;
-                    const int r00 = X < 4 ? X : X + 8;
-                    const unsigned char* scr_p0 = scr + (mm ? 20 + X : r00) * 144 + oct * 32;
-                    const unsigned char* scr_p1 = scr + (mm ? 16 + r00 : 4 + X) * 144 + oct * 32;
-                    const bool tok_x = (eu.x0 + X < W);
-                    unsigned yo16 = ((unsigned)((4 * tw + mm) * W + X) * (unsigned)y_ld + (unsigned)(8 * oct)) * 2u;
-                    unsigned ro16 = ((unsigned)((4 * tw + mm) * W + X) * (unsigned)ref_ld + (unsigned)(8 * oct)) * 2u;
-                    asm volatile("" : "+v"(yo16), "+v"(ro16));
-                    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-                    if (bias) {   // launch-uniform
-                        b0 = *reinterpret_cast<const float4*>(bias + eu.cot * 32 + 8 * oct);
-                        b1 = *reinterpret_cast<const float4*>(bias + eu.cot * 32 + 8 * oct + 4);
-                    }
-                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                    float4 kc[MODE == 3 ? 8 : 1];
-                    if (MODE == 3) {
-                        const float4* cf = reinterpret_cast<const float4*>(stat) + ((int64_t)eu.n * Cout + eu.cot * 32 + oct * 8);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) kc[MODE == 3 ? c : 0] = cf[c];
-                    }
-                    ZR_STAMP(8);
-                    auto body16 = [&](auto full_tag) {
-                        constexpr bool FULL = decltype(full_tag)::value;
-                        uint4 rq[2][2];
-                        auto load_ref = [&](int z) {
-                            const unsigned zo = (unsigned)z * (unsigned)(H * W);
-#pragma unroll
-                            for (int P = 0; P < 2; ++P) {
-                                const bool ok = FULL || (tok_x & (eu.y0 + 4 * tw + 2 * P + mm < H) & (eu.z0 + z < D));
-                                rq[z & 1][P] = zr_load4u(rr_, ok ? ro16 : 0u, ok ? (zo + (unsigned)(2 * P * W)) * (unsigned)ref_ld * 2u : 0u);
-                            }
-                        };
-                        if (has_ref16) load_ref(0);
-#pragma unroll
-                        for (int z = 0; z < TZ; ++z) {
-                            const unsigned zo = (unsigned)z * (unsigned)(H * W);
-                            if (has_ref16 && z + 1 < TZ) load_ref(z + 1);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                *reinterpret_cast<float4*>(scr_w + 32 * j) = make_float4(acc[z][4 * j], acc[z][4 * j + 1], acc[z][4 * j + 2], acc[z][4 * j + 3]);
-                            float4 t[2][2];
-#pragma unroll
-                            for (int P = 0; P < 2; ++P) {
-                                t[P][0] = *reinterpret_cast<const float4*>((P ? scr_p1 : scr_p0));
-                                t[P][1] = *reinterpret_cast<const float4*>((P ? scr_p1 : scr_p0) + 16);
-                            }
-#pragma unroll
-                            for (int P = 0; P < 2; ++P) {
-                                float o[8] = {t[P][0].x + bb[0], t[P][0].y + bb[1], t[P][0].z + bb[2], t[P][0].w + bb[3],
-                                              t[P][1].x + bb[4], t[P][1].y + bb[5], t[P][1].z + bb[6], t[P][1].w + bb[7]};
-#pragma unroll
-                                for (int c = 0; c < 8; ++c) asm("v_max_f32 %0, %1, %2" : "=v"(o[c]) : "v"(o[c]), "v"(act_floor));
-                                if (has_ref16) {
-                                    const uint4 rr4 = rq[z & 1][P];
-                                    const float r[8] = {act_lo<T>(rr4.x), act_hi<T>(rr4.x), act_lo<T>(rr4.y), act_hi<T>(rr4.y),
-                                                        act_lo<T>(rr4.z), act_hi<T>(rr4.z), act_lo<T>(rr4.w), act_hi<T>(rr4.w)};
-#pragma unroll
-                                    for (int c = 0; c < 8; ++c) {
-                                        if (MODE == 3) {
-                                            const float4 k4 = kc[MODE == 3 ? c : 0];
-                                            o[c] = r[c] > 0.f ? k4.x * o[c] - k4.y - (r[c] - k4.w) * k4.z : 0.f;
-                                        } else
-                                            o[c] = r[c] > 0.f ? o[c] : 0.f;
-                                    }
-                                }
-                                const bool sok = FULL || (tok_x & (eu.y0 + 4 * tw + 2 * P + mm < H) & (eu.z0 + z < D));
-                                const unsigned p0 = act_pk<TOut>(o[0], o[1]), p1 = act_pk<TOut>(o[2], o[3]);
-                                const unsigned p2 = act_pk<TOut>(o[4], o[5]), p3 = act_pk<TOut>(o[6], o[7]);
-                                if (MODE == 1) {   // the statistics describe the tensor AS STORED
-                                    float a[8] = {act_lo<TOut>(p0), act_hi<TOut>(p0), act_lo<TOut>(p1), act_hi<TOut>(p1),
-                                                  act_lo<TOut>(p2), act_hi<TOut>(p2), act_lo<TOut>(p3), act_hi<TOut>(p3)};
-#pragma unroll
-                                    for (int c = 0; c < 8; ++c) {
-                                        if (!FULL) a[c] = sok ? a[c] : 0.f;
-                                        s8[c] += a[c];
-                                        q8[c] = fmaf(a[c], a[c], q8[c]);
-                                    }
-                                }
-                                if (AMAX && sok) amx = tem_amax4(tem_amax4(amx, o[0], o[1], o[2], o[3]), o[4], o[5], o[6], o[7]);
-                                if (sok && (!(TEM_ZR_ABL & 2) || o[0] == 12345.678f)) {
-                                    const u32x4z pv = {p0, p1, p2, p3};
-                                    // (offset in the VGPR, soffset an immediate: the store-data hazard of zr_store4)
-                                    __builtin_amdgcn_raw_buffer_store_b128(pv, ry, yo16 + (zo + (unsigned)(2 * P * W)) * (unsigned)y_ld * 2u, 0, TEM_ZR_ST_AUX);
-                                }
-                            }
-                        }
-                    };
-                    if (full) body16(std::true_type{});
-                    else body16(std::false_type{});
-                    ZR_STAMP(9);
-                    if (MODE == 1) {
-                        // sums over the 16 lanes that hold the same channel octet (lane & 3): partners 4 and 8 lanes on in the
-                        // row of 16 (DPP row_ror), then lane ^ 16 and lane ^ 32 (v_permlane{16,32}_swap); lanes 0 .. 3 write
-                        // [8 channels][2] = four float4
-                        float r16[16];
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            r16[2 * c] = s8[c];
-                            r16[2 * c + 1] = q8[c];
-                        }
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) r16[i] += zr_dpp<0x124>(r16[i]);   // row_ror:4
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) r16[i] += zr_dpp<0x128>(r16[i]);   // row_ror:8
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) r16[i] = zr_xor16_sum(r16[i]);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) r16[i] = zr_xor32_sum(r16[i]);
-                        if (lane < 4) {
-                            const int64_t patch = ((int64_t)(eu.z0 / TZ) * nY + eu.y0 / TY) * nX + eu.x0 / TX;
-                            const int64_t nblk = (int64_t)nZ * nY * nX * 4;
-                            float4* dst = reinterpret_cast<float4*>(stat + (((int64_t)eu.n * nblk + patch * 4 + tw) * Cout + eu.cot * 32 + 8 * lane) * 2);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) dst[k] = make_float4(r16[4 * k], r16[4 * k + 1], r16[4 * k + 2], r16[4 * k + 3]);
-                        }
-                    }
-                } else {
-                if (SC) {   // fold the scaled cross products first: their 64 registers are free for the rest of the epilogue
-#pragma unroll
-                    for (int z = 0; z < TZ; ++z)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            if (in_amax) acc[z][i] = fmaf(accl[SC ? z : 0][i], pinv * (1.f / F16_LO_SCALE), acc[z][i] * pinv);
-                            else acc[z][i] = fmaf(accl[SC ? z : 0][i], 1.f / F16_LO_SCALE, acc[z][i]);
-                        }
-                }
-                if (bias) {   // launch-uniform
-                    float b16[16];
-                    bias16(b16, bve);
-#pragma unroll
-                    for (int z = 0; z < TZ; ++z)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[z][i] += b16[i];
-                }
-                ZR_STAMP(8);
-                float ssum[16], ssq[16];   // per-lane statistics partials (scalar fp32: packed fp32 waits for the matrix pipe)
-                if (MODE == 1) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
-                }
-                // Stores: a lane holds 16 B pieces of ONE voxel, so a direct store touches 32 lines with 32 B each -- measured at
-                // ~370 cycles per instruction beside the partner's MFMAs (scripts/proto/issue_bench.hip), 5900 per unit.  Each
-                // plane therefore goes through a wave-private LDS scratch ([32 voxels][128 B + 16 B pad]): written as it sits
-                // in the accumulators, read back with 8 consecutive lanes on one voxel row, stored (and masked) as full lines.
-                unsigned char* scr = zr_lds + 2 * NS * PLB + tw * (32 * 144);
-                unsigned char* scr_w = scr + v * 144 + kh * 16;                 // row = lane: + 32 j: piece (2 j + kh) of this lane's voxel
-                // voxel (py = m, px = X = lane >> 3) sits in the row of the lane with vu = 8 m + X:
-                // m = 0: X (+ 8 for X >= 4), m = 1: 20 + X, m = 2: 4 + X, m = 3: row of m = 0 + 16
-                const unsigned char* scr_r1 = scr + (lane >> 3) * 144 + (lane & 7) * 16;
-                const unsigned char* scr_r0 = scr_r1 + ((lane & 32) ? 8 * 144 : 0);
-                const bool tok_yx = (eu.x0 + (lane >> 3) < W);                  // transposed voxel: x in range (y, z per store)
-                float4 kc[4];   // MODE 3: (a, m1, m2r, mean) of the 4 channels this lane stores
-                if (MODE == 3) {
-                    const float4* cf = reinterpret_cast<const float4*>(stat) + ((int64_t)eu.n * Cout + eu.cot * 32 + (lane & 7) * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) kc[c] = cf[c];
-                }
-                auto body = [&](auto full_tag, auto ref_tag, auto stat_tag) {
-                    constexpr bool FULL = decltype(full_tag)::value, HASREF = decltype(ref_tag)::value, STAT = decltype(stat_tag)::value;
-                    float4 q[2][4];
-                    auto load_ref = [&](int z) {
-                        const unsigned zo = (unsigned)z * (unsigned)(H * W);
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const bool ok = FULL || (tok_yx & (eu.y0 + 4 * tw + m < H) & (eu.z0 + z < D));
-                            if constexpr (T16) {   // 8 bytes: this lane's 4 channels of ref
-                                const uint2 rq = zr_load2u(rr_, ok ? roff_l : 0u, ok ? (zo + (unsigned)(m * W)) * (unsigned)ref_ld * (unsigned)XB : 0u);
-                                q[z & 1][m] = make_float4(act_lo<T>(rq.x), act_hi<T>(rq.x), act_lo<T>(rq.y), act_hi<T>(rq.y));
-                            } else
-                                q[z & 1][m] = zr_load4(rr_, ok ? roff_l : 0u, ok ? (zo + (unsigned)(m * W)) * (unsigned)ref_ld * 4u : 0u);
-                        }
-                    };
-                    if (HASREF) load_ref(0);
-#pragma unroll
-                    for (int z = 0; z < TZ; ++z) {
-                        const bool ok = FULL || (vok & (eu.z0 + z < D));
-                        const unsigned zo = (unsigned)z * (unsigned)(H * W);
-                        if (HASREF && z + 1 < TZ) load_ref(z + 1);   // the masks of the next plane fly during this one
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float o[4];
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                const int i = 4 * j + c;
-                                asm("v_max_f32 %0, %1, %2" : "=v"(o[c]) : "v"(acc[z][i]), "v"(act_floor));   // fmaxf() costs a canonicalising v_max first
-                            }
-                            if constexpr (Y16 && STAT) {   // the statistics describe the tensor AS STORED: round here (the store's rounding is then exact)
-                                const unsigned p0 = act_pk<TOut>(o[0], o[1]), p1 = act_pk<TOut>(o[2], o[3]);
-                                o[0] = act_lo<TOut>(p0); o[1] = act_hi<TOut>(p0); o[2] = act_lo<TOut>(p1); o[3] = act_hi<TOut>(p1);
-                            }
-                            if (STAT) {
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    const float ov = (FULL || ok) ? o[c] : 0.f;
-                                    ssum[4 * j + c] += ov;
-                                    ssq[4 * j + c] = fmaf(ov, ov, ssq[4 * j + c]);
-                                }
-                            }
-                            *reinterpret_cast<float4*>(scr_w + 32 * j) = make_float4(o[0], o[1], o[2], o[3]);
-                        }
-                        float4 t[4];
-#pragma unroll
-                        for (int m = 0; m < 4; ++m)
-                            t[m] = *reinterpret_cast<const float4*>((m == 0 || m == 3 ? scr_r0 : scr_r1) + (m == 1 ? 20 : m == 2 ? 4 : m == 3 ? 16 : 0) * 144);
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            if (MODE == 3) {
-                                const float4 r = q[z & 1][m];
-                                t[m].x = r.x > 0.f ? kc[0].x * t[m].x - kc[0].y - (r.x - kc[0].w) * kc[0].z : 0.f;
-                                t[m].y = r.y > 0.f ? kc[1].x * t[m].y - kc[1].y - (r.y - kc[1].w) * kc[1].z : 0.f;
-                                t[m].z = r.z > 0.f ? kc[2].x * t[m].z - kc[2].y - (r.z - kc[2].w) * kc[2].z : 0.f;
-                                t[m].w = r.w > 0.f ? kc[3].x * t[m].w - kc[3].y - (r.w - kc[3].w) * kc[3].z : 0.f;
-                            } else if (HASREF) {
-                                t[m].x = q[z & 1][m].x > 0.f ? t[m].x : 0.f;
-                                t[m].y = q[z & 1][m].y > 0.f ? t[m].y : 0.f;
-                                t[m].z = q[z & 1][m].z > 0.f ? t[m].z : 0.f;
-                                t[m].w = q[z & 1][m].w > 0.f ? t[m].w : 0.f;
-                            }
-                            const bool sok = FULL || (tok_yx & (eu.y0 + 4 * tw + m < H) & (eu.z0 + z < D));
-                            if (AMAX && sok) amx = tem_amax4(amx, t[m].x, t[m].y, t[m].z, t[m].w);
-                            if constexpr (Y16) {
-                                if (sok && (!(TEM_ZR_ABL & 2) || t[m].x == 12345.678f))
-                                    zr_store2u<TEM_ZR_ST_AUX>(ry, yoff_l, (zo + (unsigned)(m * W)) * (unsigned)y_ld * (unsigned)YB,
-                                                              act_pk<TOut>(t[m].x, t[m].y), act_pk<TOut>(t[m].z, t[m].w));
-                            } else if (sok && (!(TEM_ZR_ABL & 2) || t[m].x == 12345.678f))
-                                zr_store4<KSPLIT ? TEM_ZR_ST_AUX_KS : TEM_ZR_ST_AUX>(ry, yoff_l, (zo + (unsigned)(m * W)) * (unsigned)y_ld * 4u, t[m].x, t[m].y, t[m].z, t[m].w);
-                        }
-                    }
-                };
-                if (full) body(std::true_type{}, std::integral_constant<bool, has_ref>{}, std::integral_constant<bool, MODE == 1>{});
-                else body(std::false_type{}, std::integral_constant<bool, has_ref>{}, std::integral_constant<bool, MODE == 1>{});
-                ZR_STAMP(9);
-                if (MODE == 1) {
-                    // transposing reduction over the 32 voxel lanes of each half-wave: after the step with partner lane ^ m
-                    // a lane keeps the half of its values selected by its own bit m -- 16 -> 8 -> 4 -> 2 -> 1 values per lane
-                    // and quantity; the last step (partner lane ^ 1) leaves the total in both lanes.
-                    float a8[8], b8[8];
-                    {
-                        const bool up = (lane & 16) != 0;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const float keepa = up ? ssum[i + 8] : ssum[i], senda = up ? ssum[i] : ssum[i + 8];
-                            const float keepb = up ? ssq[i + 8] : ssq[i], sendb = up ? ssq[i] : ssq[i + 8];
-                            a8[i] = keepa + zr_swz<16>(senda);
-                            b8[i] = keepb + zr_swz<16>(sendb);
-                        }
-                    }
-                    // the remaining steps stay inside a row of 16 lanes: DPP operands (no LDS round trip).  Partners: lane ^ 8
-                    // (row_ror:8), lane ^ 7 (row_half_mirror), lane ^ 3 (quad_perm [3,2,1,0]), lane ^ 1 (quad_perm [1,0,3,2]) --
-                    // any pairing works as long as the two lanes differ in the bit that selects what they keep.
-                    float a4[4], b4[4];
-                    {
-                        const bool up = (lane & 8) != 0;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float keepa = up ? a8[i + 4] : a8[i], senda = up ? a8[i] : a8[i + 4];
-                            const float keepb = up ? b8[i + 4] : b8[i], sendb = up ? b8[i] : b8[i + 4];
-                            a4[i] = keepa + zr_dpp<0x128>(senda);
-                            b4[i] = keepb + zr_dpp<0x128>(sendb);
-                        }
-                    }
-                    float a2[2], b2[2];
-                    {
-                        const bool up = (lane & 4) != 0;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const float keepa = up ? a4[i + 2] : a4[i], senda = up ? a4[i] : a4[i + 2];
-                            const float keepb = up ? b4[i + 2] : b4[i], sendb = up ? b4[i] : b4[i + 2];
-                            a2[i] = keepa + zr_dpp<0x141>(senda);
-                            b2[i] = keepb + zr_dpp<0x141>(sendb);
-                        }
-                    }
-                    float a1, b1;
-                    {
-                        const bool up = (lane & 2) != 0;
-                        const float keepa = up ? a2[1] : a2[0], senda = up ? a2[0] : a2[1];
-                        const float keepb = up ? b2[1] : b2[0], sendb = up ? b2[0] : b2[1];
-                        a1 = keepa + zr_dpp<0x1B>(senda);
-                        b1 = keepb + zr_dpp<0x1B>(sendb);
-                    }
-                    a1 += zr_dpp<0xB1>(a1);
-                    b1 += zr_dpp<0xB1>(b1);
-                    // this lane now holds register index i = bits (4,3,2,1) of its lane id: channel 8 (i >> 2) + 4 kh + (i & 3)
-                    const int i = (lane >> 1) & 15;
-                    const int ch = eu.cot * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
-                    const int64_t patch = ((int64_t)(eu.z0 / TZ) * nY + eu.y0 / TY) * nX + eu.x0 / TX;
-                    const int64_t nblk = (int64_t)nZ * nY * nX * 4;
-                    float* dst = stat + (((int64_t)eu.n * nblk + patch * 4 + tw) * Cout + ch) * 2;
-                    dst[lane & 1] = (lane & 1) ? b1 : a1;
-                }
-                }   // fp32 outputs
-                ZR_STAMP(10);
-                // the next unit of this team starts from zero (the accumulator registers were dead from their stores up to here)
-#pragma unroll
-                for (int z = 0; z < TZ; ++z)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        acc[z][i] = 0.f;
-                        if (SC) accl[SC ? z : 0][i] = 0.f;
-                    }
+            if (!X32 && epi_pending) {
+#include "conv_zr_epilogue.inc"
                 epi_pending = false;
                 ZR_STAMP(11);
             }
@@ -1171,8 +861,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
             if (++ci == nch) {
                 ci = 0;
                 eu = cu;
-                epi_pending = true;
+                epi_pending = !X32;
                 bve = bv;
+                // Exact fp32: the unit's epilogue runs HERE, by the team that has just finished its taps, while the partner (blocked
+                // during those taps: the vector ALU was the matrix pipe) works through the VALU part of its staging phase -- two
+                // latency-bound instruction streams side by side instead of one after the other in front of the next tap phase; and
+                // a staging phase without an epilogue has the registers to request its whole halo at once.
+                if constexpr (X32) {
+                    unsigned yo = yoff_lane, ro = roff_lane;
+                    asm volatile("" : "+v"(yo), "+v"(ro));
+                    epilogue_now(yo, ro, s);
+                }
                 bv = 0.f;
                 if (++ui < my_units) {
                     cu = decode(ui);
