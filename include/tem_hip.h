@@ -93,6 +93,9 @@ int tem_device_cus(void);
  *   "zr_splitk"           1 | 0   z-reuse kernel with split input channels for launches with too few tiles (16^3 / 32^3 levels)
  *   "zr_wide"             1 | 0   one-term modes (5, 7) of the z-reuse kernel stage 32 channels = whole 128-byte lines per phase
  *   "zr_tile_blocks"      1 | 0   z-reuse kernel walks its tiles in 4 x 4 x 4 blocks (one compact block per XCD at a time)
+ *   "fp32_zr"             1 | 0   use_mfma 1 (exact fp32): 3x3x3 forward / data gradient on the z-reuse team kernel
+ *                        (k_conv_zr<..., X32>: fused statistics, ReLU mask, norm backward, split-K as in the split modes;
+ *                        0: the one-patch-per-workgroup kernels of rounds 1-5, which deliver none of those)
  * Unknown names return TEM_EINVAL. */
 int tem_set_option(const char* name, int64_t value);
 int tem_get_option(const char* name, int64_t* value);
@@ -152,8 +155,9 @@ int tem_conv_unpack_wgrad(const float* dw_tap_ci_co, float* dw, int Cout, int Ci
  *   bias:        optional [Cout].
  *   ref:         optional tensor (ld ref_ld) of y's shape; when given the result
  *                is zeroed where ref <= 0 (ReLU backward, threshold_backward).
- *   use_mfma:    1 = v_mfma_f32_32x32x2_f32 implicit-GEMM kernel, exact fp32 (needs the
- *                TEM_WL_MFMA pack); 2 = split-bf16 kernel: every operand x = hi + lo in bf16,
+ *   use_mfma:    1 = v_mfma_f32_32x32x2_f32 implicit-GEMM kernels, exact fp32: every output value is ONE fp32 fmaf
+ *                chain (tests/test_gpu_ops.py::test_conv_exact_fp32_zreuse_is_an_fmaf_chain), the arithmetic of the
+ *                reference's CPU path (needs the TEM_WL_MFMA pack); 2 = split-bf16 kernel: every operand x = hi + lo in bf16,
  *                products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
  *                accumulation, ~1e-5 relative per product (needs the TEM_WL_BF16X3 pack);
  *                3 = the same with three bf16 terms per operand and the six products of order
@@ -188,7 +192,8 @@ int tem_conv3d_fwd(const float* x, int64_t x_ld, const float* scale, const float
  * the 2 x 128^3 x 32 output of a level-0 conv is not read back for `nn.InstanceNorm3d` / `GroupNorm` / `BatchNorm3d`
  * (reference ConvBlock, model/unet.py:429-438: norm(conv(x))).  stat_part: [N][stat_blocks][Cout][2] floats with
  * stat_blocks = tem_conv3d_fwd_stat_blocks(...), which returns 0 for launches that cannot provide them (the generic VALU
- * kernels, the exact-fp32 kernels, the patch kernel's split-K launches; the split-K launches of the z-reuse kernel DO:
+ * kernels, the exact-fp32 PATCH kernels (use_mfma 1 on shapes the z-reuse kernel does not take, or option fp32_zr = 0),
+ * the patch kernel's split-K launches; the split-K launches of the z-reuse kernel DO:
  * their epilogue writes the rows): use tem_norm_stats there.  tem_norm_finalize_partials (below) merges them. */
 int64_t tem_conv3d_fwd_stat_blocks(int N, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int use_mfma);
 /* Which kernel family a tem_conv3d_fwd launch of this shape selects under the current options: 3 = the z-reuse team

@@ -26,7 +26,7 @@ PROFILER_FILTER = None
 
 def _fwd_tag(mfma, k, cout, pp=False):
     if pp in (3, 4):  # the z-reuse team kernel (csrc/conv_zr.hip); 4 = its split-K launch (16^3 / 32^3 levels)
-        return f"k_conv_zr_{'f16x3' if int(mfma) == 4 else 'f16' if int(mfma) == 5 else 'bf16' if int(mfma) == 7 else 'bf16x3'}<3,3,3>"
+        return f"k_conv_zr_{'f16x3' if int(mfma) == 4 else 'f16' if int(mfma) == 5 else 'bf16' if int(mfma) == 7 else 'fp32' if int(mfma) == 1 else 'bf16x3'}<3,3,3>"
     if pp:  # the ping-pong team kernel (csrc/conv_pp.hip)
         return f"k_conv_pp_{'f16x3' if int(mfma) == 4 else 'bf16x3'}<{k[0]},{k[1]},{k[2]},CT={2 if cout % 64 == 0 else 1}>"
     kind = ({2: "k_conv_fwd_bf16x3", 3: "k_conv_fwd_bf16x6", 4: "k_conv_fwd_f16x3", 5: "k_conv_fwd_f16",
