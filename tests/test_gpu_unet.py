@@ -550,6 +550,51 @@ def test_benchmark_config_full_size_properties(dispatch_mix):
     assert glob < 1e-2, glob
 
 
+def test_benchmark_config_full_size_exact_fp32_on_the_team_kernels():
+    """cfg 2 at full size in the exact-fp32 mode (engine precision "fp32": every convolution output one fp32 fmaf chain, the
+    arithmetic of the reference's CPU path, model/unet.py:417-438).  Since round 6 its 3x3x3 layers run on the z-reuse team
+    kernel with the fused statistics / norm-backward epilogues (k_conv_zr<..., X32>, option fp32_zr).  Size-independent
+    checks: the step is bitwise reproducible, and it agrees with the same step on the one-patch-per-workgroup kernels of
+    rounds 1-5 (fp32_zr = 0: another summation order, two-pass norms) -- prediction 1e-4 (measured 3.4e-5 through the 18
+    layers), loss 1e-5, whole gradient 1e-2 in
+    relative L2 (two fp32 implementations of an ill-conditioned gradient: a handful of near-tie decisions differ)."""
+    from torch_em_amd import _lib
+    from torch_em_amd.loss import DiceLoss
+    from torch_em_amd.model import UNet3d, engine
+    torch.manual_seed(0)
+    model = UNet3d(1, 2, initial_features=32, depth=4).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 1, 128, 128, 128, generator=g).to(DEV)
+    y = (torch.rand(2, 2, 128, 128, 128, generator=g) > 0.5).float().to(DEV)
+
+    def step():
+        model.zero_grad()
+        pred = model(x)
+        loss = DiceLoss()(pred, y)
+        loss.backward()
+        return pred.detach().clone(), float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    assert _lib.get_option("fp32_zr") == 1
+    with engine.precision_scope("fp32"):
+        p1, l1, g1 = step()
+        p1b, l1b, g1b = step()
+        _lib.set_option("fp32_zr", 0)
+        try:
+            p0, l0, g0 = step()
+        finally:
+            _lib.set_option("fp32_zr", 1)
+    assert np.isfinite(l1) and l1 == l1b and torch.equal(p1, p1b)
+    for k in g1:
+        assert torch.equal(g1[k], g1b[k]), k
+    assert rel_err(p1.cpu(), p0.cpu()) < 1e-4 and abs(l1 - l0) < 1e-5
+    num = sum(float(((g1[k].double() - g0[k].double()) ** 2).sum()) for k in g1)
+    den = sum(float((g0[k].double() ** 2).sum()) for k in g1)
+    glob = (num / den) ** 0.5
+    print(f"cfg 2 full size, exact fp32: team kernels vs patch kernels: prediction {rel_err(p1.cpu(), p0.cpu()):.2e}, "
+          f"loss {l1:.7f} / {l0:.7f}, global gradient L2 {glob:.2e}")
+    assert glob < 1e-2, glob
+
+
 def test_affinity_config_full_size_properties():
     """BASELINE cfg 3 at its full size (AnisotropicUNet 1->12 + Sigmoid, 2x1x64x256x256, masked Dice on 12 affinity
     channels): the CPU oracle needs minutes there, so the size-independent properties of the path are checked instead
