@@ -87,7 +87,8 @@ class ConvSim(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         pad = tuple(k // 2 for k in w.shape[2:])
-        sim = w.shape[2:] == (3, 3, 3) and w.shape[1] >= VARIANT["min_cin"]
+        sim = (w.shape[2:] == (3, 3, 3) or (VARIANT.get("sim_1x1") and w.shape[2:] == (1, 1, 1) and w.shape[0] % 32 == 0)) and \
+            w.shape[1] >= VARIANT["min_cin"]   # sim_1x1: the 1x1x1 convs of the Upsampler ride on the same bf16x3 data gradient
         gf, wf, kd = VARIANT["dgrad"] if sim else ("exact", "exact", 1)
         xf, gf2, kw = VARIANT["wgrad"] if sim else ("exact", "exact", 1)
         if sim and x.shape[2] * x.shape[3] * x.shape[4] * x.shape[0] < VARIANT["wgrad_min_voxels"]:
