@@ -510,7 +510,8 @@ def main():
         try:
             tj = json.load(open(traffic_file))
             key = RP_NAMES.get(dom_tag.split("(")[0])
-            for cand in (key, key[:-1] + ", float>" if key else None):   # round 5: the kernels carry their element type
+            for cand in (key, key[:-1] + ", float>" if key else None,
+                         key[:-1] + ", float, false>" if key else None):   # round 5: the kernels carry their element type; round 6: k_conv_zr its X32 flag
                 if cand in tj:
                     traffic = tj[cand]
                     break
