@@ -93,7 +93,8 @@ int tem_device_cus(void);
  *   "zr_splitk"           1 | 0   z-reuse kernel with split input channels for launches with too few tiles (16^3 / 32^3 levels)
  *   "zr_wide"             1 | 0   one-term modes (5, 7) of the z-reuse kernel stage 32 channels = whole 128-byte lines per phase
  *   "zr_tile_blocks"      1 | 0   z-reuse kernel walks its tiles in 4 x 4 x 4 blocks (one compact block per XCD at a time)
- *   "fp32_zr"             1 | 0   use_mfma 1 (exact fp32): 3x3x3 forward / data gradient on the z-reuse team kernel
+ *   "fp32_zr"             1 | 2 | 0   use_mfma 1 (exact fp32): 3x3x3 forward / data gradient on the z-reuse team kernel (2: its
+ *                        one-team-per-workgroup variant, staging from inside the tap loop: measured 1-4 % slower, same results)
  *                        (k_conv_zr<..., X32>: fused statistics, ReLU mask, norm backward, split-K as in the split modes;
  *                        0: the one-patch-per-workgroup kernels of rounds 1-5, which deliver none of those)
  * Unknown names return TEM_EINVAL. */

@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
     tem_set_option("conv_fwd_variant", variant);
     if (getenv("ZR_TILE_BLOCKS")) tem_set_option("zr_tile_blocks", atoi(getenv("ZR_TILE_BLOCKS")));   // A/B of the tile order
     if (getenv("ZR_WIDE")) tem_set_option("zr_wide", atoi(getenv("ZR_WIDE")));
+    if (getenv("FP32_ZR")) tem_set_option("fp32_zr", atoi(getenv("FP32_ZR")));   // 2: exact fp32 with one team per workgroup (mode 1)
     const size_t V = (size_t)N * D * H * W;
     uint64_t seed = 1234;
     std::vector<float> hx(V * Cin), hw((size_t)Cout * Cin * 27), hb(Cout), hs((size_t)N * Cin), hf((size_t)N * Cin);

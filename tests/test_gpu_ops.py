@@ -1441,9 +1441,20 @@ ZR32_CASES = [
 ]
 
 
+@pytest.fixture
+def fp32_zr_option():
+    from torch_em_amd import _lib
+    old = _lib.get_option("fp32_zr")
+    yield lambda v: _lib.set_option("fp32_zr", v)
+    _lib.set_option("fp32_zr", old)
+
+
 @pytest.mark.parametrize("case", ZR32_CASES)
-def test_conv_exact_fp32_on_the_zreuse_kernel(case):
-    """use_mfma 1 (engine precision "fp32": the arithmetic of the reference's CPU path, nn.Conv3d in fp32,
+@pytest.mark.parametrize("teams", [2, 1])
+def test_conv_exact_fp32_on_the_zreuse_kernel(case, teams, fp32_zr_option):
+    """(teams = 1: option fp32_zr = 2, the one-team-per-workgroup variant that stages the next chunk from inside its own tap
+    loop -- measured 1-4 % slower than the two-team kernel, kept as the documented alternative; same arithmetic, same order.)
+    use_mfma 1 (engine precision "fp32": the arithmetic of the reference's CPU path, nn.Conv3d in fp32,
     model/unet.py:417-438) on k_conv_zr<..., X32> (round 6): forward with the fused pre-norm, bias, ReLU and the fused
     statistics; data gradient plain, with the ReLU mask and with the norm-backward epilogue -- against F.conv3d in float64
     (an fp32 FMA chain over 27 x Cin terms: 5e-6), and bit for bit against the patch kernel's launch wherever only the
@@ -1461,6 +1472,7 @@ def test_conv_exact_fp32_on_the_zreuse_kernel(case):
     xn = torch.addcmul(shift[:, :, None, None, None], x, scale[:, :, None, None, None])      # one fp32 fma per element, as the staging does
     exp = F.relu(F.conv3d(xn.double(), w.double(), b.double(), padding=pad))
     x5, wd = to5(x), w.to(DEV)
+    fp32_zr_option(1 if teams == 2 else 2)
     assert lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, 3, 3, 3, 1) == 3
     nblk = lib.tem_conv3d_fwd_stat_blocks(N, D, H, W, Cin, Cout, 3, 3, 3, 1)
     assert nblk == ((D + 3) // 4) * ((H + 15) // 16) * ((W + 7) // 8) * 4
@@ -1486,7 +1498,7 @@ def test_conv_exact_fp32_on_the_zreuse_kernel(case):
         y7 = ops.new_act(N, D, H, W, Cout, DEV)
         ops.conv_fwd(x5, wp, b.to(DEV), y7, k, Cin, Cout, scale=scale.to(DEV), shift=shift.to(DEV), act="relu", mfma=1)
     finally:
-        _lib.set_option("fp32_zr", 1)
+        _lib.set_option("fp32_zr", 1 if teams == 2 else 2)
     assert rel_err(y7.cpu(), y6.cpu()) < 5e-6 and rel_err(from5(y7), exp) < 5e-6
     # data gradient: transposed pack, no norm / bias / activation; masked; with the norm backward of the layer in front
     gy = torch.randn(N, Cout, D, H, W, generator=g)
@@ -1512,7 +1524,8 @@ def test_conv_exact_fp32_on_the_zreuse_kernel(case):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 16, 128, 256), (2, 15, 16, 15, 128, 256), (2, 8, 8, 8, 512, 512)])
-def test_conv_exact_fp32_zreuse_split_k(case):
+@pytest.mark.parametrize("teams", [2, 1])
+def test_conv_exact_fp32_zreuse_split_k(case, teams, fp32_zr_option):
     """The 16^3 / 8^3 levels in exact fp32: k_conv_zr<..., KSPLIT, X32> + the summing epilogue (bias, ReLU, ReLU mask, fused
     statistics), against F.conv3d in float64; reference model/unet.py:417-438."""
     ops = _ops()
@@ -1528,6 +1541,7 @@ def test_conv_exact_fp32_zreuse_split_k(case):
     xn = torch.addcmul(shift[:, :, None, None, None], x, scale[:, :, None, None, None])
     exp = F.relu(F.conv3d(xn.double(), w.double(), b.double(), padding=pad))
     x5, wd = to5(x), w.to(DEV)
+    fp32_zr_option(1 if teams == 2 else 2)
     assert lib.tem_conv3d_fwd_kernel(N, D, H, W, Cin, Cout, 3, 3, 3, 1) == 4
     wp = ops.pack_weights(wd, transpose=False, mfma=1)
     y5 = ops.new_act(N, D, H, W, Cout, DEV)
@@ -1546,7 +1560,8 @@ def test_conv_exact_fp32_zreuse_split_k(case):
     assert err < 5e-6, f"masked dgrad: {err}"
 
 
-def test_conv_exact_fp32_zreuse_is_an_fmaf_chain():
+@pytest.mark.parametrize("teams", [2, 1])
+def test_conv_exact_fp32_zreuse_is_an_fmaf_chain(teams, fp32_zr_option):
     """The exact mode's claim, checked bit for bit: v_mfma_f32_32x32x2_f32 adds its two products to the accumulator as two
     fused multiply-adds in k order, so one output value of k_conv_zr<..., X32> is ONE fp32 fmaf chain in the kernel's
     summation order -- 16-channel chunks in order; inside a chunk the nine (ty, tx) columns; inside a column the channel
@@ -1554,6 +1569,7 @@ def test_conv_exact_fp32_zreuse_is_an_fmaf_chain():
     -- then the bias, then the ReLU.  The host
     loop below (numpy, _fma32) reproduces a 2 x 8 x 32 x 16 x 32 -> 32 layer with the fused pre-norm exactly."""
     ops = _ops()
+    fp32_zr_option(1 if teams == 2 else 2)
     N, D, H, W, Cin, Cout = 2, 32, 64, 64, 32, 32
     k = (3, 3, 3)
     g = torch.Generator().manual_seed(33)

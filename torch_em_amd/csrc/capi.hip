@@ -46,7 +46,7 @@ static const TemOption g_opt_table[TEM_OPT_COUNT] = {
     {"dice_vox", 1},            // TEM_OPT_DICE_VOX: Dice sums / gradient with one voxel per thread for C <= 16 (0: one (channel, voxel) per thread, A/B)
     {"upsample2_ch8", 1},       // TEM_OPT_UPSAMPLE2_CH8: factor-2 upsampling BACKWARD of 16-bit tensors with 8 channels per thread (0: 4, A/B)
     {"pool_vec8", 2},           // TEM_OPT_POOL_VEC8: max-pool kernels on 16-bit tensors with 8 channels (16 bytes) per thread; 2: backward on the packed-word kernel k_maxpool_bwd16 (1: generic kernel, 0: 4 channels / 8 bytes -- A/B)
-    {"fp32_zr", 1},             // TEM_OPT_FP32_ZR: exact-fp32 3x3x3 forward / data gradient on the z-reuse team kernel (k_conv_zr<..., X32>; 0: k_conv_fwd_mfma[_p], A/B)
+    {"fp32_zr", 1},             // TEM_OPT_FP32_ZR: exact-fp32 3x3x3 forward / data gradient on the z-reuse team kernel (k_conv_zr<..., X32>; 2: one team per workgroup <..., X32, XS>; 0: k_conv_fwd_mfma[_p], A/B)
 };
 static long long g_opt_val[TEM_OPT_COUNT];
 static bool g_opt_set[TEM_OPT_COUNT];

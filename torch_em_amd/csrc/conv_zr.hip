@@ -247,8 +247,8 @@ struct ZrUnit {
 // chunk, like the two terms of the split layouts).  Eight 16-pass MFMAs per (tap, chunk, z-plane) instead of three 8-pass ones:
 // the tap phase is 5.3x as long as the fp16x3 one while staging and epilogue shrink, so the matrix pipe only idles in the
 // barrier hand-overs -- this is the mode that is NOT power-limited (profiles/r06_mfma_busy_fp32.txt), where that converts.
-template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float, bool X32 = false>
-__global__ __launch_bounds__(512, 2) void k_conv_zr(
+template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float, bool X32 = false, bool XS = false>
+__global__ __launch_bounds__(XS ? 256 : 512, XS ? 1 : 2) void k_conv_zr(
     const T* __restrict__ x, int64_t x_ld, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ wp, const float* __restrict__ bias, std::conditional_t<KSPLIT, float, T>* __restrict__ y, int64_t y_ld,
     const T* __restrict__ ref, int64_t ref_ld, int N, int D, int H, int W, int Cin, int Cout, int act, int nZ,
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     float amx = 0.f;
     static_assert(!WIDE || NS == 2, "the wide one-term kernel uses the two LDS planes of the two-term layout");
     static_assert(!X32 || (NS == 2 && !F16 && !WIDE && sizeof(T) == 4), "exact fp32: two LDS planes of eight fp32 channels, fp32 tensors");
+    static_assert(!XS || X32, "the one-team workgroup exists for the exact-fp32 arithmetic only");
     constexpr bool T16 = sizeof(T) == 2;         // 16-bit activations in HBM
     using TOut = std::conditional_t<KSPLIT, float, T>;
     constexpr bool Y16 = sizeof(TOut) == 2;
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
     const int py = vu >> 3, px = vu & 7;
     unsigned char* lds = zr_lds + team * (NS * PLB);
 
-    const int G = 2 * gridDim.x;
-    const int slot = tem_xcd_remap(blockIdx.x, gridDim.x) * 2 + team;
+    const int G = (XS ? 1 : 2) * gridDim.x;   // (XS: 256 threads = one team per workgroup, team == 0)
+    const int slot = XS ? tem_xcd_remap(blockIdx.x, gridDim.x) : tem_xcd_remap(blockIdx.x, gridDim.x) * 2 + team;
     const int ncot = Cout >> 5;
     const int nch_all = Cin / CK;                          // chunks of the input (16 channels; WIDE: 32)
     const int nch = KSPLIT ? nch_all / ks : nch_all;       // ... of one unit
@@ -440,6 +441,170 @@ __global__ __launch_bounds__(512, 2) void k_conv_zr(
 #include "conv_zr_epilogue.inc"
         }
     };
+    // =====================================================================================================================
+    // XS (round 6): exact fp32 with ONE team per workgroup.  Beside a stream of v_mfma_f32_32x32x2_f32 the partner wave of a SIMD
+    // issues no vector-ALU instruction (zr_x32_gap above), so a second team cannot stage "behind" the MFMAs: whatever it does on
+    // the vector ALU waits until they are over and then runs exposed, once per phase, with two workgroup barriers around it.  Here
+    // the four waves that multiply also stage: the tile of the NEXT chunk (the other half of the same LDS) is filled from inside
+    // the tap loop -- one halo slot per step of 48 MFMAs: a buffer_load four steps ahead, four fused multiply-adds, one
+    // ds_write_b128 -- so the staging costs its own issue slots and nothing else, and there is one barrier per phase.  The
+    // epilogue runs behind the unit's last tap phase (same text, conv_zr_epilogue.inc).
+    // =====================================================================================================================
+    if constexpr (XS) {
+        constexpr int PFD = 4;                       // halo slots in flight ahead of their conversion
+        constexpr int NSL = HZ * SPP;                // 18 slots per thread and chunk = the steps of the tap loop
+        static_assert(NSL == 18, "one halo slot per step of the tap loop");
+        const int nph = my_units * nch;
+        uint4 wq[2][3][2], wqn[3][2];
+        float4 tn[PFD + 1];
+        float4 scn = make_float4(1.f, 1.f, 1.f, 1.f), sfn = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned zso[HZ];                            // scalar plane offsets of the chunk being staged (z validity folded in)
+        unsigned inbn[2] = {0xffffffffu, 0xffffffffu};
+        bool interior_n = true;
+        __amdgpu_buffer_rsrc_t rxn = zr_rsrc(x);
+        auto stage_setup = [&](const ZrUnit& t, int c) {
+            const T* xb = x + ((((int64_t)t.n * D + (t.z0 - 1)) * H + (t.y0 - 1)) * W + (t.x0 - 1)) * x_ld + (int64_t)((t.ksl * nch + c) * CK);
+            rxn = zr_rsrc(xb);
+            interior_n = (t.z0 >= 1) & (t.z0 + HZ - 1 <= D) & (t.y0 >= 1) & (t.y0 + HY - 1 <= H) & (t.x0 >= 1) & (t.x0 + HX - 1 <= W);
+#pragma unroll
+            for (int hz = 0; hz < HZ; ++hz) zso[hz] = zr_ssel_ltu((unsigned)(t.z0 - 1 + hz), (unsigned)D, (unsigned)hz * plane_b, plane_b);
+            if (scale) {
+                scn = *reinterpret_cast<const float4*>(scale + (int64_t)t.n * Cin + (t.ksl * nch + c) * CK + c4 * CPL);
+                sfn = *reinterpret_cast<const float4*>(shift + (int64_t)t.n * Cin + (t.ksl * nch + c) * CK + c4 * CPL);
+            }
+            inbn[0] = inbn[1] = 0xffffffffu;
+            if (!interior_n) {
+                inbn[0] = inbn[1] = 0;
+#pragma unroll
+                for (int hz = 0; hz < HZ; ++hz) {
+                    const bool zok = (unsigned)(t.z0 - 1 + hz) < (unsigned)D;
+#pragma unroll
+                    for (int j = 0; j < SPP; ++j) inbn[hz / 3] |= (zok & ((yxu >> j) & 1u)) ? (1u << ((hz % 3) * SPP + j)) : 0u;
+                }
+            }
+        };
+        auto stage_load = [&](int s) {               // s compile-time after unrolling
+            if (TEM_ZR_ABL & 1) tn[s % (PFD + 1)] = make_float4(0.5f, 0.25f, -1.f, 2.f);
+            else tn[s % (PFD + 1)] = zr_load4(rxn, pvo[X32 ? s % SPP : 0], zso[s / SPP]);
+        };
+        auto stage_conv = [&](int s, unsigned char* tile) {
+            const int hz = s / SPP, j = s % SPP;
+            const float4 t4 = tn[s % (PFD + 1)];
+            float e[4] = {fmaf(t4.x, scn.x, sfn.x), fmaf(t4.y, scn.y, sfn.y), fmaf(t4.z, scn.z, sfn.z), fmaf(t4.w, scn.w, sfn.w)};
+            if (!interior_n) {   // zero padding comes after the norm (model/unet.py:429-438)
+                const float m = ((inbn[hz / 3] >> ((hz % 3) * SPP + j)) & 1u) ? 1.f : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) e[c] *= m;
+            }
+            if (j < SPP - 1 || slot2) *reinterpret_cast<float4*>(tile + lwj[j] + hz * ZSTEP) = make_float4(e[0], e[1], e[2], e[3]);
+        };
+        auto wbase = [&](const ZrUnit& t, int c) { return (unsigned)((t.cot * 27 * nch_all + t.ksl * nch + c) * FR) * 16u; };
+        auto comp = [](const uint4& q, int c) {
+            return __builtin_bit_cast(float, c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w)));
+        };
+        // ---- first chunk of the first unit: staged without anything to hide behind ----
+        if (nph > 0) {
+            stage_setup(cu, 0);
+#pragma unroll
+            for (int s = 0; s < PFD; ++s) stage_load(s);
+#pragma unroll
+            for (int s = 0; s < NSL; ++s) {
+                if (s + PFD < NSL) stage_load(s + PFD);
+                stage_conv(s, zr_lds);
+            }
+            const unsigned wb = wbase(cu, 0);
+#pragma unroll
+            for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) wq[0][tz][p] = zr_load4u(rw, woff_lane, wb + (unsigned)((tz * 9) * tapstride + p * 64) * 16u);
+        }
+        __syncthreads();
+        for (int ph = 0; ph < nph; ++ph) {
+            unsigned char* const tcur = zr_lds + (ph & 1) * (NS * PLB);
+            unsigned char* const tnxt = zr_lds + ((ph + 1) & 1) * (NS * PLB);
+            const bool last_chunk = ci + 1 == nch;
+            // the chunk staged during this phase: the next one -- or, in the very last phase, this one again (into the free tile:
+            // the loop has one shape, and the few wasted instructions of one phase per workgroup buy half the code size)
+            ZrUnit tu = cu;
+            int tc = ci;
+            if (ph + 1 < nph) {
+                if (last_chunk) {
+                    tu = decode(ui + 1);
+                    tc = 0;
+                    unit_offsets(tu);
+                } else
+                    tc = ci + 1;
+            }
+            stage_setup(tu, tc);
+#pragma unroll
+            for (int s = 0; s < PFD; ++s) stage_load(s);
+            wsoff = wbase(cu, ci);
+            const unsigned wsoff_n = wbase(tu, tc);
+            int ts = tapstride;
+            asm volatile("" : "+s"(ts));
+            const unsigned hsel = (unsigned)((py & 1) ^ kh) << 4;
+            int hvb_ = hvb;
+            asm volatile("" : "+v"(hvb_));
+            unsigned a0 = 0u;
+            auto col_addr = [&](int g) {
+                const int hvv = hvb_ + (g / 3) * HX + (g % 3);
+                a0 = (unsigned)hvv * 32u + (((g / 3) & 1) ? hsel ^ 16u : hsel);
+            };
+            uint4 xr[2][HZ];
+            auto r_read = [&](int u) {
+                if ((u & 1) == 0) col_addr(u >> 1);
+#pragma unroll
+                for (int hz = 0; hz < HZ; ++hz) xr[u & 1][hz] = *reinterpret_cast<const uint4*>(tcur + a0 + hz * ZSTEP + (u & 1) * PLB);
+            };
+            r_read(0);
+#pragma unroll
+            for (int u = 0; u < 18; ++u) {
+                const int g = u >> 1, p = u & 1;
+                if (u + PFD < NSL) stage_load(u + PFD);
+                if (u + 1 < 18) r_read(u + 1);
+                if (g + 1 < 9 && !(TEM_ZR_ABL & 4)) {   // weight fragments of the next column: tz = 0, 1 in the first step, 2 in the second
+                    const int gn = g + 1;
+#pragma unroll
+                    for (int tz = (p ? 2 : 0); tz < (p ? 3 : 2); ++tz)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+                            wq[gn & 1][tz][pp] = zr_load4u(rw, woff_lane, wsoff + (unsigned)((tz * 9 + gn) * ts + pp * 64) * 16u);
+                }
+                if (u >= 15) {   // first column of the next phase, into its own registers (wq[0] is in use until the last step)
+                    const int tz = u - 15;
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) wqn[tz][pp] = zr_load4u(rw, woff_lane, wsoff_n + (unsigned)((tz * 9) * ts + pp * 64) * 16u);
+                }
+                stage_conv(u, tnxt);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+                        for (int z = 0; z < TZ; ++z)
+                            acc[z] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(wq[g & 1][tz][p], c), comp(xr[u & 1][z + tz], c), acc[z], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (last_chunk) {
+                eu = cu;
+                bve = bv;
+                unsigned yo = yoff_lane, ro = roff_lane;
+                asm volatile("" : "+v"(yo), "+v"(ro));
+                epilogue_now(yo, ro, ph);
+                bv = bias ? bias[tu.cot * 32 + v] : 0.f;
+                ++ui;
+            }
+            cu = tu;
+            ci = tc;
+#pragma unroll
+            for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) wq[0][tz][p] = wqn[tz][p];
+            __syncthreads();
+        }
+        if (AMAX && out_amax) tem_amax_commit(out_amax, amx);
+        return;
+    }
     if (team) __syncthreads();
     for (int s = 0; s <= P; ++s) {
         const bool do_stage = ui < my_units;
@@ -936,7 +1101,7 @@ static int zr_tile_blocks(const ZrGeom& g) {
     return lg(g.nX) | (lg(g.nY) << 4) | (lg(g.nZ) << 8);
 }
 
-template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float, bool X32 = false>
+template <int NS, bool F16, int MODE, bool KSPLIT = false, bool WIDE = false, typename T = float, bool X32 = false, bool XS = false>
 static void zr_launch(const ZrGeom& g, const float* x_, int64_t x_ld, const float* scale, const float* shift, const float* wp,
                       const float* bias, float* y_, int64_t y_ld, const float* ref_, int64_t ref_ld, int N, int D, int H, int W,
                       int Cin, int Cout, int act, float* stat, const unsigned* in_amax, hipStream_t s, int ks = 1) {
@@ -945,7 +1110,7 @@ static void zr_launch(const ZrGeom& g, const float* x_, int64_t x_ld, const floa
     const T* x = reinterpret_cast<const T*>(x_);
     const T* ref = reinterpret_cast<const T*>(ref_);
     auto* y = reinterpret_cast<std::conditional_t<KSPLIT, float, T>*>(y_);
-    auto kern = &k_conv_zr<NS, F16, MODE, KSPLIT, WIDE, T, X32>;
+    auto kern = &k_conv_zr<NS, F16, MODE, KSPLIT, WIDE, T, X32, XS>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
@@ -956,10 +1121,10 @@ static void zr_launch(const ZrGeom& g, const float* x_, int64_t x_ld, const floa
         ncu = tem_device_cus();
         if (ncu <= 0) ncu = 256;
     }
-    int64_t grid = (g.nunits + 1) / 2;
+    int64_t grid = XS ? g.nunits : (g.nunits + 1) / 2;   // (XS: one team per workgroup)
     if (grid > ncu) grid = ncu;
     unsigned* const out_amax = (MODE == 2 || MODE == 3) ? tem_take_output_amax() : nullptr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp),
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(XS ? 256 : 512), ldsb, s, x, x_ld, scale, shift, reinterpret_cast<const uint4*>(wp),
                        bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, g.nZ, g.nY, g.nX, stat, (int)g.nunits, in_amax, ks,
                        zr_tile_blocks(g), out_amax, (int64_t)(sizeof(T) == 2 ? tem_call_cs.x : 0), (int64_t)(sizeof(T) == 2 && !KSPLIT ? tem_call_cs.y : 0));
 }
@@ -1026,6 +1191,9 @@ int tem_conv_fwd_zr_splitk(const float* x, int64_t x_ld, const float* scale, con
     else if (tem_call_st.x == 2)
         zr_launch<2, false, 0, true, true, tem_bf16>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,
                                                      TEM_ACT_NONE, nullptr, nullptr, s, ks);
+    else if (nsplit == 1 && tem_option(TEM_OPT_FP32_ZR) == 2)
+        zr_launch<2, false, 0, true, false, float, true, true>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,
+                                                               TEM_ACT_NONE, nullptr, nullptr, s, ks);
     else if (nsplit == 1)
         zr_launch<2, false, 0, true, false, float, true>(g, x, x_ld, scale, shift, wp, nullptr, part, Cout, nullptr, 0, N, D, H, W, Cin, Cout,
                                                          TEM_ACT_NONE, nullptr, nullptr, s, ks);
@@ -1131,6 +1299,18 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
         else                                                                                                                  \
             zr_launch<2, F16, 0, false, true, T>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
     } while (0)
+#define ZRGO32S()                                                                                                               \
+    do {                                                                                                                      \
+        if (stat)                                                                                                             \
+            zr_launch<2, false, 1, false, false, float, true, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+        else if (ref && rcoef)                                                                                                \
+            zr_launch<2, false, 3, false, false, float, true, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act,        \
+                                  const_cast<float*>(rcoef), in_amax, s);                                                     \
+        else if (ref)                                                                                                         \
+            zr_launch<2, false, 2, false, false, float, true, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+        else                                                                                                                  \
+            zr_launch<2, false, 0, false, false, float, true, true>(g, x, x_ld, scale, shift, wp, bias, y, y_ld, ref, ref_ld, N, D, H, W, Cin, Cout, act, stat, in_amax, s); \
+    } while (0)
 #define ZRGO32()                                                                                                                \
     do {                                                                                                                      \
         if (stat)                                                                                                             \
@@ -1147,7 +1327,8 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
     else if (tem_call_st.x == 2) ZRGO16(false, tem_bf16);
     else
 #undef ZRGO16
-    if (nsplit == 1) ZRGO32();
+    if (nsplit == 1 && tem_option(TEM_OPT_FP32_ZR) == 2) ZRGO32S();
+    else if (nsplit == 1) ZRGO32();
     else if (nsplit == 5 && wide) ZRGO(2, true, true);
     else if (nsplit == 7 && wide) ZRGO(2, false, true);
     else if (nsplit == 5) ZRGO(1, true, false);
@@ -1156,5 +1337,6 @@ int tem_conv_fwd_zr(const float* x, int64_t x_ld, const float* scale, const floa
     else ZRGO(2, false, false);
 #undef ZRGO
 #undef ZRGO32
+#undef ZRGO32S
     return 1;
 }
