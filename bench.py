@@ -37,7 +37,7 @@ RP_NAMES = {
     "k_conv_zr_bf16x3<3,3,3>": "k_conv_zr<2, false, 0, false, false>",
     "k_conv_zr_f16<3,3,3>": "k_conv_zr<2, true, 1, false, true>",         # one-term modes: 32 channels per phase
     "k_conv_zr_bf16<3,3,3>": "k_conv_zr<2, false, 1, false, true>",
-    "k_conv_zr_fp32<3,3,3>": "k_conv_zr<2, false, 1, false, false, float, true>",   # exact fp32 on the z-reuse structure (round 6, --precision fp32)
+    "k_conv_zr_fp32<3,3,3>": "k_conv_zr<2, false, 1, false, false, float, true, false>",   # exact fp32 on the z-reuse structure (round 6, --precision fp32)
     "k_conv_pp_bf16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, false>",
     "k_conv_pp_bf16x3<3,3,3,CT=1>": "k_conv_pp<3, 3, 3, 4, 8, 8, 1, 1, 2, false>",
     "k_conv_pp_f16x3<3,3,3,CT=2>": "k_conv_pp<3, 3, 3, 4, 8, 8, 2, 2, 2, true>",
@@ -510,8 +510,8 @@ def main():
         try:
             tj = json.load(open(traffic_file))
             key = RP_NAMES.get(dom_tag.split("(")[0])
-            for cand in (key, key[:-1] + ", float>" if key else None,
-                         key[:-1] + ", float, false>" if key else None):   # round 5: the kernels carry their element type; round 6: k_conv_zr its X32 flag
+            for cand in (key, key[:-1] + ", float>" if key else None, key[:-1] + ", float, false>" if key else None,
+                         key[:-1] + ", float, false, false>" if key else None):   # round 5: the kernels carry their element type; round 6: k_conv_zr its X32 / XS flags
                 if cand in tj:
                     traffic = tj[cand]
                     break

@@ -256,6 +256,22 @@ __global__ __launch_bounds__(1024) void k_pack_weights_tiles(const PackTileDesc*
         }
         const int c16 = (d.transpose ? cob * 2 : cib * 2) + fr;
         uint4* out = reinterpret_cast<uint4*>(d.dst) + ((((long long)ntL * ntaps + tap) * c16n + c16) * d.NS) * 64 + lane;
+        if (d.fp16 == 4) {
+            // exact fp32 (TEM_WL_MFMA, round 6: the exact mode re-packed 43 tensors with one launch each): the two 64-lane groups
+            // of a 16-channel chunk hold channels 8 p + 4 kh + (0..3) as they are -- rem[] has 8 kh + j: gather the other four
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float f[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = fr * 16 + 8 * p + 4 * kh + c;
+                    f[c] = d.transpose ? tile[k * pitch + col * ntaps + ftap] : tile[col * pitch + k * ntaps + tap];
+                }
+                out[(long long)p * 64] = make_uint4(__builtin_bit_cast(unsigned, f[0]), __builtin_bit_cast(unsigned, f[1]),
+                                                    __builtin_bit_cast(unsigned, f[2]), __builtin_bit_cast(unsigned, f[3]));
+            }
+            continue;
+        }
         for (int p = 0; p < d.NS; ++p) {
             unsigned pk[4];
 #pragma unroll

@@ -293,6 +293,9 @@ def _repack_stale(prepare_only: bool = False):
                     mode = ent[key + "_mfma"]
                     jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
                                  3 if mode == 3 else 1 if mode in (5, 7) else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
+                elif ent.get(key + "_mfma") == 1 and _PACK_BATCH and k[0] * k[1] * k[2] <= 27 and conv.out_channels % 16 == 0 and \
+                        conv.in_channels % 16 == 0:
+                    jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose, 2, 4))
                 elif ent.get(key + "_mfma") == 0 and _generic_batchable(conv, k):
                     jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose, 0, 0))
                 continue
@@ -308,6 +311,9 @@ def _repack_stale(prepare_only: bool = False):
             if mode in (2, 3, 4, 5, 6, 7):
                 jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose,
                              3 if mode == 3 else 1 if mode in (5, 7) else 2, {4: 2, 5: 1, 6: 3}.get(mode, 0)))
+            elif mode == 1 and _PACK_BATCH and k[0] * k[1] * k[2] <= 27 and conv.out_channels % 16 == 0 and conv.in_channels % 16 == 0:
+                # exact fp32 (TEM_WL_MFMA): two 64-lane groups per 16-channel chunk, written by the tile kernel (code 4)
+                jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose, 2, 4))
             elif mode == 0 and _generic_batchable(conv, k):
                 # the generic fp32 layout (first conv, out_conv) rides along in the batched launch: nsplit 0
                 jobs.append((w, ent[key], conv.out_channels, conv.in_channels, k, transpose, 0, 0))
