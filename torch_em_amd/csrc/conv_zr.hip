@@ -62,8 +62,8 @@
 #endif
 #ifndef TEM_ZR_X32_R0_M0
 #define TEM_ZR_X32_R0_M0 6   // exact fp32: halo planes requested at the start of a staging phase, per epilogue mode (plain / statistics / ReLU mask /
-#define TEM_ZR_X32_R0_M1 4   // mask + norm backward).  With the epilogue inside the staging phase (TEM_ZR_X32_EPI_NOW 0) the largest counts without
-#define TEM_ZR_X32_R0_M2 6   // spills were 6 / 2 / 5 / 3
+#define TEM_ZR_X32_R0_M1 4   // mask + norm backward): the largest counts without register spills.  (With the epilogue inside the staging phase,
+#define TEM_ZR_X32_R0_M2 6   // as in the split modes, they were 6 / 2 / 5 / 3: the 18 registers of a plane overlapped the epilogue's temporaries.)
 #define TEM_ZR_X32_R0_M3 5
 #endif
 #ifndef TEM_ZR_X32_GAP
